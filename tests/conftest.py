@@ -1,0 +1,30 @@
+"""pytest configuration: registers the ``gpu`` marker and common helpers."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pkg(sub: str = ""):
+    """Import ``3d_sln_amd[.sub]`` (the package name is not a Python identifier)."""
+    return importlib.import_module("3d_sln_amd" + ("." + sub if sub else ""))
+
+
+def load_golden(name: str):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+@pytest.fixture(scope="session")
+def sln():
+    return pkg()

@@ -1,0 +1,54 @@
+"""Tolerance policy shared by the parity tests.
+
+BASELINE.json north_star: fp32 box/angle/SPADE outputs within 1e-4 relative;
+triangle / pixel indices bit-exact.  "Relative" is taken per tensor against the
+tensor's max magnitude (what a per-element relative test degenerates to for
+values that cancel to ~0), plus a small absolute floor.
+
+Train-mode BatchNorm over very few rows (BASELINE config c1: 8 objects) is
+ill-conditioned in the REFERENCE itself: running the reference on 1 vs 8 CPU
+threads moves boxes_pred by 1e-2 (measured).  For such cases
+``assert_close_conditioned`` bounds the error against an fp64 evaluation of the
+oracle by the reference-fp32 path's own distance from that fp64 result.
+"""
+import numpy as np
+
+RTOL = 1e-4
+ATOL = 2e-6
+
+
+def max_err(a, b):
+    a = np.asarray(a, dtype=np.float64); b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.size == 0:
+        return 0.0, 1.0
+    return float(np.abs(a - b).max()), float(max(np.abs(b).max(), 1e-30))
+
+
+def assert_close(got, ref, name, rtol=RTOL, atol=ATOL):
+    err, scale = max_err(got, ref)
+    assert np.isfinite(err), name + ": non-finite"
+    assert err <= atol + rtol * scale, "%s: max err %.3e vs scale %.3e (rtol %.1e atol %.1e)" % (
+        name, err, scale, rtol, atol)
+
+
+def assert_close_conditioned(got, ref64, ref32, name, rtol=RTOL, atol=ATOL, k=8.0):
+    """|got - ref64| <= rtol*scale + atol + k * |ref32 - ref64| (max norms)."""
+    err, scale = max_err(got, ref64)
+    noise, _ = max_err(ref32, ref64)
+    assert np.isfinite(err), name + ": non-finite"
+    assert err <= atol + rtol * scale + k * noise, "%s: err %.3e, scale %.3e, fp32-reference noise %.3e" % (
+        name, err, scale, noise)
+
+
+def assert_adam_close(p_new, p_ref, grad_ref, name, lr=1e-4, rtol=1e-5):
+    """Adam's first step is +-lr*g/(|g|+eps): chaotic where the true gradient is 0
+    (every Linear bias in front of a BatchNorm).  Compare tightly where |g| is
+    meaningful and bound the move by lr elsewhere."""
+    p_new = np.asarray(p_new, np.float64); p_ref = np.asarray(p_ref, np.float64)
+    g = np.abs(np.asarray(grad_ref, np.float64))
+    solid = g > 1e-5 * max(g.max(), 1e-30) + 1e-7
+    d = np.abs(p_new - p_ref)
+    if solid.any():
+        assert d[solid].max() <= 2e-7 + rtol * np.abs(p_ref).max(), name + ": adam mismatch %.3e" % d[solid].max()
+    assert d.max() <= 2.02 * lr, name + ": adam moved more than 2*lr"
