@@ -1,0 +1,123 @@
+"""ctypes binding of libsln_hip.so (the C ABI declared in include/sln_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call
+fails, an exception is raised.  PyTorch is only used by the callers for device
+memory and streams; nothing here touches torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsln_hip.so")
+
+SLN_E = {-1: "SLN_E_BADARG", -2: "SLN_E_UNSUPPORTED", -3: "SLN_E_STATE", -4: "SLN_E_NOGPU"}
+
+c_f32p = C.c_void_p
+c_i64p = C.c_void_p
+
+
+class SlnError(RuntimeError):
+    pass
+
+
+class SlnVaeConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "embedding_dim", "gconv_num_layers", "recurrent", "batch_norm", "decoder_cat", "use_ae",
+        "box_dim", "n_angle", "num_objs", "num_preds", "num_attrs", "reserved")]
+
+
+class SlnVaeUnit(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "weight", "bias", "bn_weight", "bn_bias", "bn_running_mean", "bn_running_var",
+        "bn_num_batches_tracked", "d_weight", "d_bias", "d_bn_weight", "d_bn_bias")]
+
+
+EMB_NAMES = ("obj_emb_ec", "pred_emb_ec", "obj_emb_dc", "pred_emb_dc", "attr_emb_ec", "attr_emb_dc",
+             "box_emb_w", "box_emb_b", "angle_emb")
+
+
+class SlnVaeTensors(C.Structure):
+    _fields_ = ([(p + n, C.c_void_p) for n in EMB_NAMES for p in ("", "d_")] +
+                [("units_host", C.POINTER(SlnVaeUnit)),
+                 ("flat_params", C.c_void_p), ("flat_grads", C.c_void_p),
+                 ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("n_flat", C.c_int64)])
+
+
+class SlnVaeBatch(C.Structure):
+    _fields_ = [("objs", C.c_void_p), ("triples", C.c_void_p), ("boxes", C.c_void_p),
+                ("angles", C.c_void_p), ("attributes", C.c_void_p), ("O", C.c_int), ("T", C.c_int)]
+
+
+HOST_HOOK = C.CFUNCTYPE(None, C.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
+# (tests/test_abi.py checks the header against this table and against the built library).
+SIGNATURES = {
+    "sln_version": (C.c_int, []),
+    "sln_build_arch": (C.c_char_p, []),
+    "sln_device_ok": (C.c_int, []),
+    "sln_vae_num_units": (C.c_int, [C.POINTER(SlnVaeConfig)]),
+    "sln_vae_create": (C.c_int, [C.POINTER(SlnVaeConfig), C.POINTER(C.c_void_p)]),
+    "sln_vae_destroy": (None, [C.c_void_p]),
+    "sln_vae_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
+    "sln_vae_bind": (C.c_int, [C.c_void_p, C.POINTER(SlnVaeTensors), C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "sln_vae_set_batch": (C.c_int, [C.c_void_p, C.POINTER(SlnVaeBatch), C.c_void_p]),
+    "sln_vae_encoder": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+    "sln_vae_decoder": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+    "sln_vae_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
+    "sln_vae_loss": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, C.c_int, C.c_void_p]),
+    "sln_vae_decoder_backward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_vae_encoder_backward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_vae_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sln_vae_params_changed": (C.c_int, [C.c_void_p]),
+    "sln_vae_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sln_vae_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
+    "sln_vae_adam_reset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "sln_vae_tap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "sln_linear_forward": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_void_p]),
+    "sln_linear_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the shared library (once).  Raises SlnError when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SlnError("libsln_hip.so is not built (%s); run `python __graft_entry__.py` or "
+                           "`python 3d_sln_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError -> missing export: fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    """Turn a C-ABI return code into an exception."""
+    if rc == 0:
+        return
+    if rc < 0:
+        raise SlnError("%s failed: %s" % (what, SLN_E.get(int(rc), "error %d" % rc)))
+    raise SlnError("%s failed: hipError_t %d" % (what, rc))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,504 @@
+// Fused fp32 MFMA GEMM family for the scene-graph VAE (gfx950).
+//
+// All matmuls of the hot path are tiny-K (<= 640) fp32 products whose operands are *views* of
+// stored pre-activations: BatchNorm+ReLU (forward) or the BatchNorm backward formula is applied
+// while the tile is staged, the GraphTripleConv gather/concat is a row-indexed segment, and the
+// epilogue produces the column statistics the next BatchNorm needs.  v_mfma_f32_32x32x2_f32 is
+// exact fp32 (an fmaf chain) so results stay within 1e-4 of the reference without tricks.
+//
+//   gemm_nt : Y[M,N]  = op(A)[M,K] * W[N,K]^T (+bias)        forward Linear and dgrad (with W^T)
+//   gemm_tn : dW[N,K] += op(G)[R,N]^T * op(X)[R,K]            wgrad, split over row chunks
+//
+// LDS tiles are k-major ([BK][rows+pad]); each lane feeds the MFMA with one ds_read_b32 per
+// operand (conflict-free: consecutive lanes -> consecutive rows).  Global->LDS staging goes
+// through registers (transform on the way), double-buffered so one barrier per K tile.
+#include "sln_common.h"
+#include "sln_gemm.h"
+
+namespace {
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+__device__ __forceinline__ float4 xform(float4 x1, float4 x2, const float4* cf) {
+  float4 r;
+  float4 c;
+  c = cf[0]; r.x = fmaxf(fmaf(c.x, x1.x, fmaf(c.y, x2.x, c.z)), c.w);
+  c = cf[1]; r.y = fmaxf(fmaf(c.x, x1.y, fmaf(c.y, x2.y, c.z)), c.w);
+  c = cf[2]; r.z = fmaxf(fmaf(c.x, x1.z, fmaf(c.y, x2.z, c.z)), c.w);
+  c = cf[3]; r.w = fmaxf(fmaf(c.x, x1.w, fmaf(c.y, x2.w, c.z)), c.w);
+  return r;
+}
+
+// XCD-aware bijective remap of a linear block id: consecutive logical ids share an XCD (and its L2).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+struct SegSel {   // block-uniform view of the segment that holds logical column k0
+  const float* x1; const float* x2; int ld1, ld2, c1, c2, which, base, end;
+};
+__device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
+  const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
+  const int s = (op.nseg > 1 && k0 >= e0) ? ((op.nseg > 2 && k0 >= e1) ? 2 : 1) : 0;
+  SegSel r;
+  r.x1 = s == 0 ? op.seg[0].x1 : (s == 1 ? op.seg[1].x1 : op.seg[2].x1);
+  r.x2 = s == 0 ? op.seg[0].x2 : (s == 1 ? op.seg[1].x2 : op.seg[2].x2);
+  r.ld1 = s == 0 ? op.seg[0].ld1 : (s == 1 ? op.seg[1].ld1 : op.seg[2].ld1);
+  r.ld2 = s == 0 ? op.seg[0].ld2 : (s == 1 ? op.seg[1].ld2 : op.seg[2].ld2);
+  r.c1 = s == 0 ? op.seg[0].c1 : (s == 1 ? op.seg[1].c1 : op.seg[2].c1);
+  r.c2 = s == 0 ? op.seg[0].c2 : (s == 1 ? op.seg[1].c2 : op.seg[2].c2);
+  r.which = s == 0 ? op.seg[0].which : (s == 1 ? op.seg[1].which : op.seg[2].which);
+  r.base = s == 0 ? 0 : (s == 1 ? e0 : e1);
+  r.end = r.base + (s == 0 ? op.seg[0].len : (s == 1 ? op.seg[1].len : op.seg[2].len));
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int SA = BM + 1, SB = BN + 1;
+  constexpr int PA = BM / 32, PB = BN / 32;
+  static_assert(WM * WN == 4, "4 waves per block");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int kpad = (a.K + 31) & ~31;
+  float4* coef = reinterpret_cast<float4*>(smem);
+  float* As = reinterpret_cast<float*>(coef + kpad);
+  float* Bs = As + 2 * BK * SA;
+  float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BK * SB);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int lb = xcd_remap(blockIdx.x, nwg);
+  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+  sln_fill_coefs(a.A, coef, tid, 256);
+  for (int c = a.K + tid; c < kpad; c += 256) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (EPI == EPI_MASK) {
+    for (int c = tid; c < BN; c += 256) {
+      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+      if (n0 + c < a.N) {
+        bn_fwd_coef(a.obn, n0 + c, e.x, e.y);
+        bn_mean_istd(a.obn, n0 + c, e.z, e.w);
+      }
+      ecoef[c] = e;
+    }
+  }
+
+  const int kq = tid & 7, r0 = tid >> 3;
+  int ra_idx[PA], rb_idx[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = m0 + r0 + 32 * p;
+    const bool v = row < a.M;
+    ra_idx[p] = (v && a.A.idx_a) ? a.A.idx_a[row] : row;
+    rb_idx[p] = (v && a.A.idx_b) ? a.A.idx_b[row] : row;
+  }
+
+  float4 ga1[PA], ga2[PA], gb[PB];
+  const int ntiles = kpad / BK;
+
+  auto gload = [&](int kt) {
+    const int k0 = kt * BK, col = k0 + 4 * kq;
+    const SegSel sg = pick_seg(a.A, k0);
+    const bool cv = col < sg.end;   // segments start at multiples of BK, so col >= sg.base
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int row = m0 + r0 + 32 * p;
+      const bool v = cv && row < a.M;
+      const int r = sg.which == 0 ? row : (sg.which == 1 ? ra_idx[p] : rb_idx[p]);
+      ga1[p] = v ? ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + (col - sg.base)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (HAS_X2)
+        ga2[p] = (v && sg.x2) ? ld4(sg.x2 + (size_t)r * sg.ld2 + sg.c2 + (col - sg.base)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int n = n0 + r0 + 32 * p;
+      gb[p] = (n < a.N && col < a.K) ? ld4(a.W + (size_t)n * a.ldw + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int kt, int buf) {
+    const int k0 = kt * BK, col = k0 + 4 * kq;
+    const SegSel sg = pick_seg(a.A, k0);
+    const bool cv = col < sg.end;
+    float* as = As + buf * BK * SA + (4 * kq) * SA;
+    float* bs = Bs + buf * BK * SB + (4 * kq) * SB;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int rl = r0 + 32 * p;
+      const bool v = cv && (m0 + rl) < a.M;
+      float4 t = z;
+      if (v) t = xform(ga1[p], HAS_X2 ? ga2[p] : z, coef + col);
+      as[0 * SA + rl] = t.x; as[1 * SA + rl] = t.y; as[2 * SA + rl] = t.z; as[3 * SA + rl] = t.w;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int rl = r0 + 32 * p;
+      bs[0 * SB + rl] = gb[p].x; bs[1 * SB + rl] = gb[p].y; bs[2 * SB + rl] = gb[p].z; bs[3 * SB + rl] = gb[p].w;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  __syncthreads();            // coef tables visible
+  gload(0);
+  lstore(0, 0);
+  __syncthreads();
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < ntiles) gload(kt + 1);
+    const float* as = As + buf * BK * SA + wm0 + lrow;
+    const float* bs = Bs + buf * BK * SB + wn0 + lrow;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lk) * SA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lk) * SB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < ntiles) lstore(kt + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+  // ------------------------------- epilogue -------------------------------
+  float* red = As;   // [WM][BN][2] (tiles no longer needed: last loop iteration ended on a barrier)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
+    const int col = n0 + cl;
+    const bool cvalid = col < a.N;
+    const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+    float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (EPI == EPI_MASK) ec = ecoef[cl];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (cvalid && row < a.M) {
+          float y = acc[i][j][r] + bias;
+          if (a.addend) y += a.addend[(size_t)row * a.ldadd + a.addcol0 + col];
+          if (EPI == EPI_STATS) { s1 += y; s2 = fmaf(y, y, s2); }
+          if (EPI == EPI_MASK) {
+            const float xp = a.xprev[(size_t)row * a.ldx + a.xcol0 + col];
+            y = fmaf(ec.x, xp, ec.y) > 0.f ? y : 0.f;
+            s1 += y; s2 = fmaf(y, (xp - ec.z) * ec.w, s2);
+          }
+          a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
+        }
+      }
+    }
+    if (EPI != EPI_PLAIN) {
+      s1 = wave_sum_halves(s1); s2 = wave_sum_halves(s2);
+      if (lk == 0) { red[((wave / WN) * BN + cl) * 2 + 0] = s1; red[((wave / WN) * BN + cl) * 2 + 1] = s2; }
+    }
+  }
+  if (EPI != EPI_PLAIN) {
+    __syncthreads();
+    double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
+    if (out != nullptr) {
+      for (int c = tid; c < BN; c += 256) {
+        if (n0 + c < a.N) {
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + c) * 2]; s2 += red[(w * BN + c) * 2 + 1]; }
+          atomicAdd(out + n0 + c, (double)s1);
+          atomicAdd(out + a.ocstride + n0 + c, (double)s2);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+int sln_gemm_init();
+namespace {
+
+template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
+int launch_nt(const GemmNTArgs& a, hipStream_t st) {
+  const int kpad = (a.K + 31) & ~31;
+  const size_t smem = (size_t)kpad * 16 + (size_t)2 * BK * (BM + 1 + BN + 1) * 4 + (size_t)BN * 16;
+  const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
+  if (grid <= 0) return 0;
+  if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, HAS_X2, EPI>), dim3(grid), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <bool HAS_X2, int EPI>
+int dispatch_nt_tile(const GemmNTArgs& a, hipStream_t st, int tile) {
+  switch (tile) {
+    case 1: return launch_nt<128, 64, 2, 2, HAS_X2, EPI>(a, st);
+    case 2: return launch_nt<128, 128, 2, 2, HAS_X2, EPI>(a, st);
+    case 3: return launch_nt<64, 128, 2, 2, HAS_X2, EPI>(a, st);
+    case 4: return launch_nt<32, 128, 1, 4, HAS_X2, EPI>(a, st);
+    default: return launch_nt<64, 64, 2, 2, HAS_X2, EPI>(a, st);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TN kernel (wgrad)
+// ---------------------------------------------------------------------------------------------
+struct ColSel { const float* x1; const float* x2; int ld1, ld2, which; bool valid; };
+
+__device__ __forceinline__ ColSel pick_col(const Operand& op, int col) {
+  // per-thread (non-uniform) choice of the segment holding logical column `col`
+  ColSel r;
+  const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
+  const int s = (op.nseg > 1 && col >= e0) ? ((op.nseg > 2 && col >= e1) ? 2 : 1) : 0;
+  const int base = s == 0 ? 0 : (s == 1 ? e0 : e1);
+  const int c = col - base;
+  r.valid = col < op.cols;
+  const Seg& g0 = op.seg[0]; const Seg& g1 = op.seg[1]; const Seg& g2 = op.seg[2];
+  r.x1 = (s == 0 ? g0.x1 + g0.c1 : (s == 1 ? g1.x1 + g1.c1 : g2.x1 + g2.c1)) + c;
+  const float* b2 = s == 0 ? g0.x2 : (s == 1 ? g1.x2 : g2.x2);
+  r.x2 = b2 ? b2 + (s == 0 ? g0.c2 : (s == 1 ? g1.c2 : g2.c2)) + c : nullptr;
+  r.ld1 = s == 0 ? g0.ld1 : (s == 1 ? g1.ld1 : g2.ld1);
+  r.ld2 = s == 0 ? g0.ld2 : (s == 1 ? g1.ld2 : g2.ld2);
+  r.which = s == 0 ? g0.which : (s == 1 ? g1.which : g2.which);
+  return r;
+}
+
+__device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (col < op.cols) {
+    const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
+    if (op.nseg > 2 && col >= e1) v = sln_coef_for(op.seg[2], col - e1);
+    else if (op.nseg > 1 && col >= e0) v = sln_coef_for(op.seg[1], col - e0);
+    else v = sln_coef_for(op.seg[0], col);
+  }
+  return v;
+}
+
+template <int BM, int BN, int WM, int WN, bool G_X2>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int SA = BM + 4, SB = BN + 4;
+  constexpr int TPRA = BM / 4, TPRB = BN / 4;         // threads per row
+  constexpr int RPA = 256 / TPRA, RPB = 256 / TPRB;   // rows per pass
+  constexpr int PA = BK / RPA, PB = BK / RPB;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* coefG = reinterpret_cast<float4*>(smem);          // [BM]
+  float4* coefX = coefG + BM;                               // [BN]
+  float* As = reinterpret_cast<float*>(coefX + BN);         // [2][BK][SA]
+  float* Bs = As + 2 * BK * SA;                             // [2][BK][SB]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_k = (a.Kin + BN - 1) / BN;
+  const int n0 = (blockIdx.x / tiles_k) * BM, k0 = (blockIdx.x % tiles_k) * BN;
+  const int rbeg = blockIdx.y * a.rows_per_block;
+  const int rend = min(a.R, rbeg + a.rows_per_block);
+  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
+
+  // per-column coefficient tables for this block's column ranges
+  for (int c = tid; c < BM; c += 256) coefG[c] = coef_for_col(a.G, n0 + c);
+  for (int c = tid; c < BN; c += 256) coefX[c] = coef_for_col(a.X, k0 + c);
+
+  const int ca = 4 * (tid % TPRA), ra0 = tid / TPRA;
+  const int cb = 4 * (tid % TPRB), rb0 = tid / TPRB;
+  const ColSel gs = pick_col(a.G, n0 + ca);
+  const ColSel xs = pick_col(a.X, k0 + cb);
+
+  float4 g1[PA], g2[PA], x1[PB];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto gload = [&](int rt) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int row = rbeg + rt * BK + ra0 + RPA * p;
+      const bool v = gs.valid && row < rend;
+      int r = row;
+      if (v && gs.which) r = (gs.which == 1 ? a.G.idx_a : a.G.idx_b)[row];
+      g1[p] = v ? ld4(gs.x1 + (size_t)r * gs.ld1) : z4;
+      if (G_X2) g2[p] = (v && gs.x2) ? ld4(gs.x2 + (size_t)r * gs.ld2) : z4;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int row = rbeg + rt * BK + rb0 + RPB * p;
+      const bool v = xs.valid && row < rend;
+      int r = row;
+      if (v && xs.which) r = (xs.which == 1 ? a.X.idx_a : a.X.idx_b)[row];
+      x1[p] = v ? ld4(xs.x1 + (size_t)r * xs.ld1) : z4;
+    }
+  };
+  float4 dbacc = z4;
+  auto lstore = [&](int rt, int buf) {
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int rl = ra0 + RPA * p;
+      const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
+      float4 t = z4;
+      if (v) t = xform(g1[p], G_X2 ? g2[p] : z4, coefG + ca);
+      dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
+      *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int rl = rb0 + RPB * p;
+      const bool v = xs.valid && (rbeg + rt * BK + rl) < rend;
+      float4 t = z4;
+      if (v) t = xform(x1[p], z4, coefX + cb);
+      *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = t;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int ntiles = (rend - rbeg + BK - 1) / BK;
+  __syncthreads();
+  if (ntiles > 0) { gload(0); lstore(0, 0); }
+  __syncthreads();
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int rt = 0; rt < ntiles; ++rt) {
+    const int buf = rt & 1;
+    if (rt + 1 < ntiles) gload(rt + 1);
+    const float* as = As + buf * BK * SA + wm0 + lrow;
+    const float* bs = Bs + buf * BK * SB + wn0 + lrow;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lk) * SA + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lk) * SB + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (rt + 1 < ntiles) lstore(rt + 1, buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int k = k0 + wn0 + 32 * j + lrow;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (n < a.Nout && k < a.Kin) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
+      }
+    }
+
+  if (a.db != nullptr && (blockIdx.x % tiles_k) == 0) {
+    // threads with equal (tid % TPRA) hold partial sums of the same 4 columns
+#pragma unroll
+    for (int off = TPRA; off < 64; off <<= 1) {
+      dbacc.x += __shfl_xor(dbacc.x, off, 64); dbacc.y += __shfl_xor(dbacc.y, off, 64);
+      dbacc.z += __shfl_xor(dbacc.z, off, 64); dbacc.w += __shfl_xor(dbacc.w, off, 64);
+    }
+    if (lane < TPRA && lane == (tid % TPRA)) {
+      const int n = n0 + ca;
+      if (n + 0 < a.Nout) atomicAdd(a.db + n + 0, dbacc.x);
+      if (n + 1 < a.Nout) atomicAdd(a.db + n + 1, dbacc.y);
+      if (n + 2 < a.Nout) atomicAdd(a.db + n + 2, dbacc.z);
+      if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, dbacc.w);
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, bool G_X2>
+int launch_tn(const GemmTNArgs& a, hipStream_t st) {
+  const size_t smem = (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + 4 + BN + 4) * 4;
+  const int gx = sln_cdiv(a.Nout, BM) * sln_cdiv(a.Kin, BN);
+  const int gy = sln_cdiv(a.R, a.rows_per_block);
+  if (gx <= 0 || gy <= 0) return 0;
+  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, G_X2>), dim3(gx, gy), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+// Raise the dynamic-LDS limit of every instantiation once (must not happen inside a stream capture).
+template <int BM, int BN, int WM, int WN>
+static int init_nt_tile() {
+  hipError_t e = hipSuccess;
+#define SLN_SET(X2, EPI)                                                                                          \
+  if (e == hipSuccess)                                                                                            \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI>),              \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  SLN_SET(false, EPI_PLAIN) SLN_SET(false, EPI_STATS) SLN_SET(false, EPI_MASK)
+  SLN_SET(true, EPI_PLAIN) SLN_SET(true, EPI_STATS) SLN_SET(true, EPI_MASK)
+#undef SLN_SET
+  return (int)e;
+}
+
+int sln_gemm_init() {
+  static bool done = false;
+  if (done) return 0;
+  int r = init_nt_tile<64, 64, 2, 2>();
+  if (!r) r = init_nt_tile<128, 64, 2, 2>();
+  if (!r) r = init_nt_tile<128, 128, 2, 2>();
+  if (!r) r = init_nt_tile<64, 128, 2, 2>();
+  if (!r) r = init_nt_tile<32, 128, 1, 4>();
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  done = r == 0;
+  return r;
+}
+
+int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
+  bool x2 = false;
+  for (int s = 0; s < a.A.nseg; ++s) x2 |= a.A.seg[s].x2 != nullptr;
+  if (tile < 0) {   // heuristic: enough blocks to cover 256 CUs, otherwise the biggest tile
+    const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
+    const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
+    tile = b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
+  }
+  if (x2) {
+    if (epi == EPI_MASK) return dispatch_nt_tile<true, EPI_MASK>(a, st, tile);
+    if (epi == EPI_STATS) return dispatch_nt_tile<true, EPI_STATS>(a, st, tile);
+    return dispatch_nt_tile<true, EPI_PLAIN>(a, st, tile);
+  }
+  if (epi == EPI_MASK) return dispatch_nt_tile<false, EPI_MASK>(a, st, tile);
+  if (epi == EPI_STATS) return dispatch_nt_tile<false, EPI_STATS>(a, st, tile);
+  return dispatch_nt_tile<false, EPI_PLAIN>(a, st, tile);
+}
+
+int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
+  GemmTNArgs a = a0;
+  bool x2 = false;
+  for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
+  if (a.rows_per_block <= 0) {
+    // aim for >= ~512 blocks in total, chunks a multiple of BK rows
+    const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
+    int chunks = sln_cdiv(768, tiles);
+    int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
+    a.rows_per_block = rpb < 64 ? 64 : rpb;
+  }
+  (void)tile;
+  if (x2) return launch_tn<64, 64, 2, 2, true>(a, st);
+  return launch_tn<64, 64, 2, 2, false>(a, st);
+}

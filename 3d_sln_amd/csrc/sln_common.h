@@ -1,0 +1,140 @@
+// Shared device/host declarations for the 3D_SLN hot-path kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SLN_WAVE 64
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm view.  All hot-path MLPs are Linear -> [BatchNorm1d] -> ReLU (reference
+// models/graph.py:10-27).  The kernels never materialise the normalised tensor: producers store the
+// Linear output ("pre-activation") and accumulate column sums; consumers rebuild
+// h = relu(scale*x + shift) while loading.  mode selects where (mean, 1/std) come from.
+// ---------------------------------------------------------------------------------------------
+enum { SLN_BN_NONE = 0, SLN_BN_TRAIN = 1, SLN_BN_EVAL = 2 };
+
+struct BnView {
+  const double* sums;    // [2][cstride]: sum x, sum x^2 over rows (train mode), offset to first column
+  const double* gsums;   // [2][cstride]: sum g, sum g*xhat (backward), offset to first column
+  const float* gamma;    // offset to first column (nullptr when mode == NONE)
+  const float* beta;
+  const float* rmean;
+  const float* rvar;
+  int cstride;           // distance between the two rows of sums / gsums
+  int mode;
+  float inv_n;           // 1 / rows
+  float eps;
+};
+
+__device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean, float& istd) {
+  if (b.mode == SLN_BN_TRAIN) {
+    double m = b.sums[c] * (double)b.inv_n;
+    double v = b.sums[b.cstride + c] * (double)b.inv_n - m * m;
+    v = v < 0.0 ? 0.0 : v;
+    mean = (float)m;
+    istd = (float)(1.0 / sqrt(v + (double)b.eps));
+  } else if (b.mode == SLN_BN_EVAL) {
+    mean = b.rmean[c];
+    istd = 1.0f / sqrtf(b.rvar[c] + b.eps);
+  } else {
+    mean = 0.f;
+    istd = 1.f;
+  }
+}
+// forward coefficients: h = max(scale*x + shift, 0)
+__device__ __forceinline__ void bn_fwd_coef(const BnView& b, int c, float& scale, float& shift) {
+  if (b.mode == SLN_BN_NONE) { scale = 1.f; shift = 0.f; return; }
+  float mean, istd;
+  bn_mean_istd(b, c, mean, istd);
+  scale = b.gamma[c] * istd;
+  shift = b.beta[c] - mean * scale;
+}
+// backward coefficients: dX = p0*g + p1*x + p2  (g = relu-masked incoming gradient)
+//   train: dX = scale*(g - mean(g) - xhat*mean(g*xhat)), xhat = (x-mean)*istd
+__device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, float& p1, float& p2) {
+  if (b.mode == SLN_BN_NONE) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
+  float mean, istd;
+  bn_mean_istd(b, c, mean, istd);
+  float scale = b.gamma[c] * istd;
+  p0 = scale;
+  if (b.mode == SLN_BN_TRAIN) {
+    float c1 = (float)(b.gsums[c] * (double)b.inv_n);
+    float c2 = (float)(b.gsums[b.cstride + c] * (double)b.inv_n);
+    p1 = -scale * istd * c2;
+    p2 = -scale * c1 - p1 * mean;
+  } else {
+    p1 = 0.f; p2 = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Logical GEMM operand: up to three column segments of row-major sources, each optionally
+// row-gathered (GraphTripleConv's [obj[s] | pred | obj[o]] concat, models/graph.py:74-80) and
+// transformed on load as   v = max(c0*x1 + c1*x2 + c2, floor)   with per-column coefficients.
+// Every segment except the last must have len % 32 == 0; all lens % 4 == 0.
+// ---------------------------------------------------------------------------------------------
+enum { SLN_COEF_IDENT = 0, SLN_COEF_FWD = 1, SLN_COEF_FWD_NORELU = 2, SLN_COEF_BWD = 3 };
+
+struct Seg {
+  const float* x1;
+  const float* x2;   // second source (pre-activation for BWD coefficients); nullptr otherwise
+  int ld1, ld2;      // row strides in floats
+  int c1, c2;        // first source column
+  int len;           // logical columns in this segment
+  int which;         // 0: identity rows, 1: rows = idx_a[row], 2: rows = idx_b[row]
+  int coef;          // SLN_COEF_*
+  int pad_;
+  BnView bn;         // statistics/parameters aligned with the segment's first column
+};
+
+struct Operand {
+  Seg seg[3];
+  const int* idx_a;
+  const int* idx_b;
+  int nseg;
+  int rows;          // logical rows
+  int cols;          // logical columns (sum of seg lens)
+  int pad_;
+};
+
+__device__ __forceinline__ float4 sln_coef_for(const Seg& s, int c) {
+  // returns (c0, c1, c2, floor) for logical column c of this segment
+  float4 r;
+  const float NEG = -3.0e38f;
+  if (s.coef == SLN_COEF_IDENT) { r = make_float4(1.f, 0.f, 0.f, NEG); }
+  else if (s.coef == SLN_COEF_BWD) {
+    float p0, p1, p2; bn_bwd_coef(s.bn, c, p0, p1, p2);
+    r = make_float4(p0, p1, p2, NEG);
+  } else {
+    float sc, sh; bn_fwd_coef(s.bn, c, sc, sh);
+    r = make_float4(sc, 0.f, sh, s.coef == SLN_COEF_FWD ? 0.f : NEG);
+  }
+  return r;
+}
+
+// Fill an LDS table coef[0..cols) for the whole operand (all threads of the block participate).
+__device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, int tid, int nthreads) {
+  int base = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    if (s < op.nseg) {
+      for (int c = tid; c < op.seg[s].len; c += nthreads) coef[base + c] = sln_coef_for(op.seg[s], c);
+      base += op.seg[s].len;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_sum_halves(float v) {   // lanes l and l^32 -> both hold the sum
+  return v + __shfl_xor(v, 32, 64);
+}
+
+static inline int sln_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+#define SLN_CHECK_LAUNCH()                                                  \
+  do {                                                                      \
+    hipError_t e__ = hipGetLastError();                                     \
+    if (e__ != hipSuccess) return (int)e__;                                 \
+  } while (0)

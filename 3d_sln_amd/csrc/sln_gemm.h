@@ -1,0 +1,41 @@
+// Argument blocks of the fused fp32 GEMM kernels (see gemm_f32.hip).
+#pragma once
+#include "sln_common.h"
+
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_MASK = 2 };
+
+struct GemmNTArgs {
+  Operand A;            // logical [M, K]
+  const float* W;       // [N, K] row-major, leading dimension ldw
+  const float* bias;    // [N] or nullptr
+  float* Y;             // output rows of length ldy, written at column ycol0
+  int ldy, ycol0;
+  int M, N, K, ldw;
+  // optional addend (another gradient contribution to the same tensor): y += addend[row, addcol0 + col]
+  const float* addend;
+  int ldadd, addcol0;
+  // EPI_STATS: column sums of y / y^2 (train-mode BatchNorm statistics of the produced tensor)
+  double* osums;
+  int ocstride;
+  // EPI_MASK: y is the gradient w.r.t. h = relu(bn(xprev)); writes g = y * [h > 0] and accumulates
+  // sum g, sum g*xhat per column into ogsums (uses ocstride)
+  int ldx, xcol0;
+  const float* xprev;
+  double* ogsums;
+  BnView obn;           // aligned with output column 0
+};
+
+struct GemmTNArgs {
+  Operand G;            // logical [R, Nout]: gradient w.r.t. the Linear output, rebuilt on load
+  Operand X;            // logical [R, Kin]: the Linear input, rebuilt on load
+  float* dW;            // [Nout, Kin] (+=)
+  float* db;            // [Nout] (+=) or nullptr
+  int lddw;
+  int R, Nout, Kin;
+  int rows_per_block;   // <= 0: choose
+};
+
+// epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 32x128
+int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st);
+int sln_launch_gemm_tn(const GemmTNArgs& a, int tile, hipStream_t st);
+int sln_gemm_init();   // raises dynamic-LDS limits; call once outside any stream capture

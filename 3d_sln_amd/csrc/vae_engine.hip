@@ -1,0 +1,905 @@
+// Scene-graph VAE engine: owns the kernel plan for Sg2ScVAEModel (reference
+// models/Sg2ScVAE_model.py:115-188, models/graph.py:57-143, utils.py:12-33, train.py:62-84) and
+// exposes it through the C ABI of include/sln_hip.h.  One engine per process/GPU; every call
+// enqueues kernels on the caller's stream.  A whole training iteration (zero_grad, forward, loss,
+// backward, Adam) is ~200 launches, captured once into a hipGraph and replayed.
+#include <new>
+#include <vector>
+#include <cstring>
+
+#include "../../include/sln_hip.h"
+#include "sln_gemm.h"
+#include "vae_kernels.h"
+
+namespace {
+
+constexpr float kBnEps = 1e-5f;
+constexpr float kBnMomentum = 0.1f;
+
+inline int rup(int x, int a) { return (x + a - 1) / a * a; }
+
+struct Unit {
+  SlnVaeUnit p;
+  int out = 0, in = 0;
+  bool bn = false;
+  float* wt = nullptr;   // [in][wt_ld] transposed copy for dgrad
+  int wt_ld = 0;
+};
+
+struct BnInst {
+  int unit = -1;
+  int C = 0, rows = 0;
+  double* sums = nullptr;   // [2][C]
+  double* gsums = nullptr;  // [2][C]
+};
+
+struct Layer {              // one GraphTripleConv application
+  float *A1 = nullptr, *A2 = nullptr, *M = nullptr, *A3 = nullptr, *A4 = nullptr;
+  int bn[4] = {-1, -1, -1, -1};
+  int u0 = 0;               // unit index of net1.0
+  int D = 0;
+  bool first = false, last = false;
+  int net = 0;              // 0 encoder, 1 decoder
+};
+
+struct Bump {
+  char* base; size_t off = 0; bool dry;
+  explicit Bump(void* b) : base(static_cast<char*>(b)), dry(b == nullptr) {}
+  template <typename T> T* take(size_t n) {
+    off = (off + 255) & ~size_t(255);
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+}  // namespace
+
+struct SlnVae {
+  SlnVaeConfig cfg;
+  int E, H, L, nmod, n_obj_e, n_attr_e, n_box_e, n_angle_e, Dec, Ddc;
+  std::vector<Unit> units;
+  SlnVaeTensors t;
+  bool bound = false;
+  int maxO = 0, maxT = 0, O = 0, T = 0;
+  SlnVaeBatch batch;
+  bool batch_set = false;
+
+  std::vector<Layer> layers;      // 2L
+  std::vector<BnInst> bns;
+  int bn_head[6] = {-1, -1, -1, -1, -1, -1};   // bmv0,bmv1,amv0,amv1, boxnet0, anglenet0
+  int n_bn_enc = 0;
+
+  // workspace
+  GraphCsr g;
+  int* attrs32 = nullptr; int* err_flag = nullptr;
+  double* stats_base = nullptr; size_t stats_doubles = 0, enc_stats_doubles = 0;   // [enc sums | dec sums]
+  double* gstats_base = nullptr;                                                   // [enc gsums | dec gsums]
+  BnTableEntry* bn_table_dev = nullptr;
+  TransposeEntry* tr_table_dev = nullptr; int n_tr = 0, tr_max_tiles = 0;
+  AdamScalars* scalars = nullptr; double* loss_acc = nullptr; float* losses = nullptr;
+  float *X0e = nullptr, *P0e = nullptr, *X0d = nullptr, *P0d = nullptr;
+  float *hbA1 = nullptr, *hbA2 = nullptr, *haA1 = nullptr, *haA2 = nullptr;
+  float *mu = nullptr, *logvar = nullptr, *z = nullptr, *eps_buf = nullptr;
+  float *bnA1 = nullptr, *anA1 = nullptr, *boxes_pred = nullptr, *logits = nullptr, *angles_pred = nullptr;
+  // backward temporaries
+  float *dbp = nullptr, *dlogits = nullptr, *g_bn = nullptr, *g_an = nullptr, *d_bx = nullptr, *d_ax = nullptr;
+  float *g4 = nullptr, *g3 = nullptr, *dM = nullptr, *g2 = nullptr, *g1 = nullptr, *dG[2] = {nullptr, nullptr};
+  float *dX0 = nullptr, *dz = nullptr, *dmu = nullptr, *dlv = nullptr;
+  float *g_h2 = nullptr, *g_h1 = nullptr, *d_xb = nullptr, *d_xa = nullptr, *tmp_d = nullptr;
+  int dbp_ld = 8;
+
+  bool enc_training = false, dec_training = false, have_enc = false, have_dec = false, have_loss_grads = false;
+  const float* z_src = nullptr;   // z given to decoder() (external) or nullptr when computed from mu/logvar/eps
+  bool z_from_latent = false;
+  bool wt_fresh = false;          // transposed weights valid for the current parameters
+  float host_kl = 0.f, host_lr = 0.f; int64_t host_step = 0; bool host_scalars_valid = false;
+
+  // hipGraph of one training iteration
+  hipGraphExec_t graph_exec = nullptr; int graph_O = -1, graph_T = -1;
+
+  // ------------------------------------------------------------------------------------------
+  int unit_of(int net, int l, int k) const { return 8 + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
+  int unit_boxnet(int k) const { return 8 + 2 * nmod * 4 + k; }
+  int unit_anglenet(int k) const { return 8 + 2 * nmod * 4 + 2 + k; }
+
+  int bn_mode(const BnInst& b, bool training) const {
+    if (b.unit < 0 || !units[b.unit].bn) return SLN_BN_NONE;
+    return training ? SLN_BN_TRAIN : SLN_BN_EVAL;
+  }
+  BnView view(int inst, int col0, bool training) const {
+    BnView v; std::memset(&v, 0, sizeof(v));
+    v.eps = kBnEps; v.inv_n = 1.f; v.mode = SLN_BN_NONE;
+    if (inst < 0) return v;
+    const BnInst& b = bns[inst];
+    const Unit& u = units[b.unit];
+    v.mode = bn_mode(b, training);
+    if (v.mode == SLN_BN_NONE) return v;
+    v.sums = b.sums + col0; v.gsums = b.gsums + col0; v.cstride = b.C;
+    v.gamma = u.p.bn_weight + col0; v.beta = u.p.bn_bias + col0;
+    v.rmean = u.p.bn_running_mean + col0; v.rvar = u.p.bn_running_var + col0;
+    v.inv_n = 1.0f / (float)(b.rows > 0 ? b.rows : 1);
+    return v;
+  }
+  static Seg seg_ident(const float* x, int ld, int col0, int len, int which) {
+    Seg s; std::memset(&s, 0, sizeof(s));
+    s.x1 = x; s.ld1 = ld; s.c1 = col0; s.len = len; s.which = which; s.coef = SLN_COEF_IDENT;
+    return s;
+  }
+  Seg seg_act(const float* x, int ld, int col0, int len, int inst, int which, bool training) const {
+    // relu(bn(x)) of a stored pre-activation
+    Seg s = seg_ident(x, ld, col0, len, which);
+    s.coef = SLN_COEF_FWD; s.bn = view(inst, col0, training);
+    return s;
+  }
+  Seg seg_bwd(const float* gmask, int ldg, const float* x, int ldx, int len, int inst, bool training) const {
+    // gradient w.r.t. the Linear output, rebuilt from the relu-masked gradient and the pre-activation
+    Seg s = seg_ident(gmask, ldg, 0, len, 0);
+    s.bn = view(inst, 0, training);
+    s.coef = SLN_COEF_BWD;
+    if (s.bn.mode == SLN_BN_TRAIN) { s.x2 = x; s.ld2 = ldx; s.c2 = 0; }
+    return s;
+  }
+  static Operand op1(const Seg& s, int rows) {
+    Operand o; std::memset(&o, 0, sizeof(o));
+    o.seg[0] = s; o.nseg = 1; o.rows = rows; o.cols = s.len;
+    return o;
+  }
+  Operand layer_input(int gi, bool training) const {
+    const Layer& ly = layers[gi];
+    Operand o; std::memset(&o, 0, sizeof(o));
+    const int D = ly.D;
+    if (ly.first) {
+      const float* X0 = ly.net == 0 ? X0e : X0d;
+      const float* P0 = ly.net == 0 ? P0e : P0d;
+      o.seg[0] = seg_ident(X0, D, 0, D, 1);
+      o.seg[1] = seg_ident(P0, D, 0, D, 0);
+      o.seg[2] = seg_ident(X0, D, 0, D, 2);
+    } else {
+      const Layer& pv = layers[gi - 1];
+      o.seg[0] = seg_act(pv.A4, D, 0, D, pv.bn[3], 1, training);
+      o.seg[1] = seg_act(pv.A2, 2 * H + D, H, D, pv.bn[1], 0, training);
+      o.seg[2] = seg_act(pv.A4, D, 0, D, pv.bn[3], 2, training);
+    }
+    o.nseg = 3; o.rows = T; o.cols = 3 * D; o.idx_a = g.s; o.idx_b = g.o;
+    return o;
+  }
+  Operand layer_output(int gi, bool training) const {
+    const Layer& ly = layers[gi];
+    return op1(seg_act(ly.A4, ly.D, 0, ly.D, ly.bn[3], 0, training), O);
+  }
+
+  int linear_fwd(const Operand& A, int ui, float* Y, int ldy, int ycol0, int M, int inst, bool training, hipStream_t st) {
+    const Unit& u = units[ui];
+    GemmNTArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = A; a.W = u.p.weight; a.bias = u.p.bias; a.Y = Y; a.ldy = ldy; a.ycol0 = ycol0;
+    a.M = M; a.N = u.out; a.K = u.in; a.ldw = u.in;
+    int epi = EPI_PLAIN;
+    if (inst >= 0 && bn_mode(bns[inst], training) == SLN_BN_TRAIN) { epi = EPI_STATS; a.osums = bns[inst].sums; a.ocstride = bns[inst].C; }
+    return sln_launch_gemm_nt(a, epi, -1, st);
+  }
+  // dIn[M, in] = G[M, out] * W ; optional relu/BN mask of the producing stage (xprev, inst) and addend
+  int linear_dgrad(const Operand& G, int ui, float* Y, int ldy, int M, const float* xprev, int ldx, int mask_inst,
+                   bool masked, const float* addend, int ldadd, bool training, hipStream_t st) {
+    const Unit& u = units[ui];
+    GemmNTArgs a; std::memset(&a, 0, sizeof(a));
+    a.A = G; a.W = u.wt; a.bias = nullptr; a.Y = Y; a.ldy = ldy; a.ycol0 = 0;
+    a.M = M; a.N = u.in; a.K = G.cols; a.ldw = u.wt_ld;
+    a.addend = addend; a.ldadd = ldadd; a.addcol0 = 0;
+    int epi = EPI_PLAIN;
+    if (masked) {
+      epi = EPI_MASK; a.xprev = xprev; a.ldx = ldx; a.xcol0 = 0;
+      a.obn = view(mask_inst, 0, training);
+      if (a.obn.mode != SLN_BN_NONE) { a.ogsums = bns[mask_inst].gsums; a.ocstride = bns[mask_inst].C; }
+    }
+    return sln_launch_gemm_nt(a, epi, -1, st);
+  }
+  int linear_wgrad(const Operand& G, const Operand& X, int ui, int R, hipStream_t st) {
+    const Unit& u = units[ui];
+    GemmTNArgs a; std::memset(&a, 0, sizeof(a));
+    a.G = G; a.X = X; a.dW = u.p.d_weight; a.db = u.p.d_bias; a.lddw = u.in;
+    a.R = R; a.Nout = u.out; a.Kin = u.in; a.rows_per_block = 0;
+    return sln_launch_gemm_tn(a, -1, st);
+  }
+
+  size_t carve(void* base, int mo, int mt);
+  int refresh_transposes(hipStream_t st);
+  int gconv_forward(int gi, bool training, hipStream_t st);
+  int gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int slot, bool training, hipStream_t st);
+  int encoder_forward(bool training, hipStream_t st);
+  int decoder_forward(const float* z_ext, const float* eps, bool training, hipStream_t st);
+  int decoder_backward(hipStream_t st);
+  int encoder_backward(hipStream_t st);
+  int loss(const float* bp, const float* ap, const float* mu_, const float* lv_, bool with_grads, hipStream_t st);
+  int run_bn_updates(int first, int count, hipStream_t st);
+  int train_iteration(const float* eps, SlnHostHook hook, void* user, hipStream_t st);
+};
+
+#define RET_IF(x) do { int r__ = (x); if (r__ != 0) return r__; } while (0)
+#define HIP_RET(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return (int)e__; } while (0)
+
+size_t SlnVae::carve(void* base, int mo, int mt) {
+  Bump b(base);
+  const size_t Om = (size_t)mo, Tm = (size_t)mt;
+  g.s = b.take<int>(Tm); g.p = b.take<int>(Tm); g.o = b.take<int>(Tm);
+  g.deg = b.take<int>(Om); g.invdeg = b.take<float>(Om); g.rowptr = b.take<int>(Om + 1);
+  g.cursor = b.take<int>(Om); g.ent = b.take<int>(2 * Tm);
+  attrs32 = b.take<int>(Om); err_flag = b.take<int>(4);
+  scalars = b.take<AdamScalars>(1); loss_acc = b.take<double>(4); losses = b.take<float>(4);
+  // BatchNorm statistics arena
+  size_t nd = 0, nd_enc = 0;
+  for (size_t i = 0; i < bns.size(); ++i) { if ((int)i == n_bn_enc) nd_enc = nd; nd += 2 * (size_t)bns[i].C; }
+  if ((int)bns.size() == n_bn_enc) nd_enc = nd;
+  stats_doubles = nd; enc_stats_doubles = nd_enc;
+  stats_base = b.take<double>(nd); gstats_base = b.take<double>(nd);
+  size_t o = 0;
+  for (auto& bi : bns) { bi.sums = stats_base ? stats_base + o : nullptr; bi.gsums = gstats_base ? gstats_base + o : nullptr; o += 2 * (size_t)bi.C; }
+  bn_table_dev = b.take<BnTableEntry>(bns.size() + 1);
+  tr_table_dev = b.take<TransposeEntry>(units.size() + 1);
+  for (auto& u : units) { u.wt_ld = rup(u.out, 4); u.wt = b.take<float>((size_t)u.in * u.wt_ld); }
+  const size_t W = 2 * (size_t)E;
+  X0e = b.take<float>(Om * Dec); P0e = b.take<float>(Tm * Dec);
+  X0d = b.take<float>(Om * Ddc); P0d = b.take<float>(Tm * Ddc);
+  for (auto& ly : layers) {
+    const size_t D = ly.D;
+    ly.A1 = b.take<float>(Tm * H); ly.A2 = b.take<float>(Tm * (2 * H + D)); ly.M = b.take<float>(Om * H);
+    ly.A3 = b.take<float>(Om * H); ly.A4 = b.take<float>(Om * D);
+  }
+  hbA1 = b.take<float>(Om * H); hbA2 = b.take<float>(Om * W); haA1 = b.take<float>(Om * H); haA2 = b.take<float>(Om * W);
+  mu = b.take<float>(Om * E); logvar = b.take<float>(Om * E); z = b.take<float>(Om * E); eps_buf = b.take<float>(Om * E);
+  bnA1 = b.take<float>(Om * H); anA1 = b.take<float>(Om * H);
+  boxes_pred = b.take<float>(Om * cfg.box_dim); logits = b.take<float>(Om * cfg.n_angle);
+  angles_pred = b.take<float>(Om * cfg.n_angle);
+  dbp_ld = rup(cfg.box_dim, 4);
+  dbp = b.take<float>(Om * dbp_ld); dlogits = b.take<float>(Om * cfg.n_angle);
+  g_bn = b.take<float>(Om * H); g_an = b.take<float>(Om * H);
+  d_bx = b.take<float>(Om * (W + n_attr_e)); d_ax = b.take<float>(Om * W);
+  const size_t Dm = W;
+  g4 = b.take<float>(Om * Dm); g3 = b.take<float>(Om * H); dM = b.take<float>(Om * H);
+  g2 = b.take<float>(Tm * (2 * H + Dm)); g1 = b.take<float>(Tm * H);
+  dG[0] = b.take<float>(Tm * 3 * Dm); dG[1] = b.take<float>(Tm * 3 * Dm);
+  dX0 = b.take<float>(Om * Dm); dz = b.take<float>(Om * E); dmu = b.take<float>(Om * E); dlv = b.take<float>(Om * E);
+  g_h2 = b.take<float>(Om * W); g_h1 = b.take<float>(Om * H); d_xb = b.take<float>(Om * W); d_xa = b.take<float>(Om * W);
+  tmp_d = b.take<float>(Om * W);
+  return (b.off + 255) & ~size_t(255);
+}
+
+int SlnVae::refresh_transposes(hipStream_t st) {
+  if (wt_fresh) return 0;
+  RET_IF(sln_launch_transpose_table(tr_table_dev, n_tr, tr_max_tiles, st));
+  wt_fresh = true;
+  return 0;
+}
+
+int SlnVae::run_bn_updates(int first, int count, hipStream_t st) {
+  if (count <= 0) return 0;
+  int maxc = 0;
+  for (int i = first; i < first + count; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
+  return sln_launch_bn_running_update(bn_table_dev + first, count, maxc, kBnMomentum, st);
+}
+
+// One GraphTripleConv forward (models/graph.py:57-111) as 5 launches.
+int SlnVae::gconv_forward(int gi, bool training, hipStream_t st) {
+  Layer& ly = layers[gi];
+  const int D = ly.D;
+  RET_IF(linear_fwd(layer_input(gi, training), ly.u0 + 0, ly.A1, H, 0, T, ly.bn[0], training, st));
+  RET_IF(linear_fwd(op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, training), T), ly.u0 + 1, ly.A2, 2 * H + D, 0, T, ly.bn[1],
+                    training, st));
+  RET_IF(sln_launch_scatter_avg_fwd(ly.A2, 2 * H + D, H, D, view(ly.bn[1], 0, training), g, O, ly.M, st));
+  RET_IF(linear_fwd(op1(seg_ident(ly.M, H, 0, H, 0), O), ly.u0 + 2, ly.A3, H, 0, O, ly.bn[2], training, st));
+  RET_IF(linear_fwd(op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, training), O), ly.u0 + 3, ly.A4, D, 0, O, ly.bn[3], training,
+                    st));
+  return 0;
+}
+
+// Backward of one GraphTripleConv.  On entry g4 holds the relu-masked gradient w.r.t. this layer's
+// object output (and bn[3].gsums its column sums); dP the gradient w.r.t. its predicate output
+// (a column slice of the next layer's dG) or nullptr.  Writes dG[slot] = gradient w.r.t. the
+// gathered [obj[s] | pred | obj[o]] input.
+int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int slot, bool tr, hipStream_t st) {
+  Layer& ly = layers[gi];
+  const int D = ly.D, C2 = 2 * H + D;
+  // net2.1 : h3 -> A4
+  Operand G4 = op1(seg_bwd(g4, D, ly.A4, D, D, ly.bn[3], tr), O);
+  RET_IF(linear_wgrad(G4, op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, tr), O), ly.u0 + 3, O, st));
+  RET_IF(linear_dgrad(G4, ly.u0 + 3, g3, H, O, ly.A3, H, ly.bn[2], true, nullptr, 0, tr, st));
+  // net2.0 : pooled -> A3
+  Operand G3 = op1(seg_bwd(g3, H, ly.A3, H, H, ly.bn[2], tr), O);
+  RET_IF(linear_wgrad(G3, op1(seg_ident(ly.M, H, 0, H, 0), O), ly.u0 + 2, O, st));
+  RET_IF(linear_dgrad(G3, ly.u0 + 2, dM, H, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  // avg-pool backward (a gather) + relu/BN mask of A2
+  BnView v2 = view(ly.bn[1], 0, tr);
+  RET_IF(sln_launch_scatter_avg_bwd(dM, dP, lddp, dpcol0, ly.A2, C2, H, D, v2, g, T, g2,
+                                    v2.mode != SLN_BN_NONE ? bns[ly.bn[1]].gsums : nullptr, C2, st));
+  // net1.1 : h1 -> A2
+  Operand G2 = op1(seg_bwd(g2, C2, ly.A2, C2, C2, ly.bn[1], tr), T);
+  RET_IF(linear_wgrad(G2, op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, tr), T), ly.u0 + 1, T, st));
+  RET_IF(linear_dgrad(G2, ly.u0 + 1, g1, H, T, ly.A1, H, ly.bn[0], true, nullptr, 0, tr, st));
+  // net1.0 : gathered concat -> A1
+  Operand G1 = op1(seg_bwd(g1, H, ly.A1, H, H, ly.bn[0], tr), T);
+  RET_IF(linear_wgrad(G1, layer_input(gi, tr), ly.u0 + 0, T, st));
+  RET_IF(linear_dgrad(G1, ly.u0 + 0, dG[slot], 3 * D, T, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  return 0;
+}
+
+int SlnVae::encoder_forward(bool training, hipStream_t st) {
+  if (training && enc_stats_doubles) HIP_RET(hipMemsetAsync(stats_base, 0, enc_stats_doubles * sizeof(double), st));
+  EncAssemble ea; std::memset(&ea, 0, sizeof(ea));
+  ea.objs = batch.objs; ea.attrs = batch.attributes; ea.angles = batch.angles; ea.boxes = batch.boxes;
+  ea.obj_emb = t.obj_emb_ec; ea.attr_emb = t.attr_emb_ec; ea.angle_emb = t.angle_emb; ea.wb = t.box_emb_w; ea.bb = t.box_emb_b;
+  ea.O = O; ea.n_obj = n_obj_e; ea.n_attr = n_attr_e; ea.n_box = n_box_e; ea.n_angle = n_angle_e; ea.box_dim = cfg.box_dim;
+  ea.x0 = X0e;
+  RET_IF(sln_launch_enc_assemble(ea, st));
+  RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_ec, T, Dec, P0e, st));
+  for (int l = 0; l < L; ++l) RET_IF(gconv_forward(l, training, st));
+  const Operand XL = layer_output(L - 1, training);
+  const int W = 2 * E;
+  // box_mean_var / box_mean / box_var  (Sg2ScVAE_model.py:134-136)
+  RET_IF(linear_fwd(XL, 0, hbA1, H, 0, O, bn_head[0], training, st));
+  RET_IF(linear_fwd(op1(seg_act(hbA1, H, 0, H, bn_head[0], 0, training), O), 1, hbA2, W, 0, O, bn_head[1], training, st));
+  const Operand HB = op1(seg_act(hbA2, W, 0, W, bn_head[1], 0, training), O);
+  RET_IF(linear_fwd(HB, 2, mu, E, 0, O, -1, training, st));
+  RET_IF(linear_fwd(HB, 3, logvar, E, 0, O, -1, training, st));
+  // angle_mean_var / angle_mean / angle_var  (:138-140)
+  RET_IF(linear_fwd(XL, 4, haA1, H, 0, O, bn_head[2], training, st));
+  RET_IF(linear_fwd(op1(seg_act(haA1, H, 0, H, bn_head[2], 0, training), O), 5, haA2, W, 0, O, bn_head[3], training, st));
+  const Operand HA = op1(seg_act(haA2, W, 0, W, bn_head[3], 0, training), O);
+  RET_IF(linear_fwd(HA, 6, mu, E, n_box_e, O, -1, training, st));
+  RET_IF(linear_fwd(HA, 7, logvar, E, n_box_e, O, -1, training, st));
+  if (training) RET_IF(run_bn_updates(0, n_bn_enc, st));
+  enc_training = training; have_enc = true;
+  return 0;
+}
+
+int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training, hipStream_t st) {
+  const size_t dec_doubles = stats_doubles - enc_stats_doubles;
+  if (training && dec_doubles) HIP_RET(hipMemsetAsync(stats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  DecAssemble da; std::memset(&da, 0, sizeof(da));
+  da.objs = batch.objs; da.attrs = batch.attributes; da.obj_emb = t.obj_emb_dc; da.attr_emb = t.attr_emb_dc;
+  da.mu = mu; da.logvar = logvar; da.eps = eps; da.z_in = z_ext;
+  da.O = O; da.n_obj = n_obj_e; da.n_attr = n_attr_e; da.n_z = E; da.use_ae = cfg.use_ae;
+  da.z = z; da.x0 = X0d;
+  RET_IF(sln_launch_dec_assemble(da, st));
+  RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
+  for (int l = 0; l < L; ++l) RET_IF(gconv_forward(L + l, training, st));
+  // box_net([obj_vecs | attr_vecs]) and angle_net(obj_vecs)  (Sg2ScVAE_model.py:166-171)
+  const Layer& ll = layers[2 * L - 1];
+  Operand XA; std::memset(&XA, 0, sizeof(XA));
+  XA.seg[0] = seg_act(ll.A4, Ddc, 0, Ddc, ll.bn[3], 0, training);
+  XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
+  XA.nseg = 2; XA.rows = O; XA.cols = Ddc + n_attr_e; XA.idx_a = attrs32;
+  RET_IF(linear_fwd(XA, unit_boxnet(0), bnA1, H, 0, O, bn_head[4], training, st));
+  RET_IF(linear_fwd(op1(seg_act(bnA1, H, 0, H, bn_head[4], 0, training), O), unit_boxnet(1), boxes_pred, cfg.box_dim, 0, O, -1,
+                    training, st));
+  RET_IF(linear_fwd(layer_output(2 * L - 1, training), unit_anglenet(0), anA1, H, 0, O, bn_head[5], training, st));
+  RET_IF(linear_fwd(op1(seg_act(anA1, H, 0, H, bn_head[5], 0, training), O), unit_anglenet(1), logits, cfg.n_angle, 0, O, -1,
+                    training, st));
+  RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));
+  if (training) RET_IF(run_bn_updates(n_bn_enc, (int)bns.size() - n_bn_enc, st));
+  dec_training = training; have_dec = true; z_from_latent = (z_ext == nullptr);
+  return 0;
+}
+
+int SlnVae::loss(const float* bp, const float* ap, const float* mu_, const float* lv_, bool with_grads, hipStream_t st) {
+  LossArgs a; std::memset(&a, 0, sizeof(a));
+  a.boxes = batch.boxes; a.boxes_pred = bp; a.box_dim = cfg.box_dim;
+  a.angles = batch.angles; a.logits = logits; a.angles_pred = const_cast<float*>(ap); a.n_angle = cfg.n_angle;
+  a.mu = mu_; a.logvar = lv_; a.n_z = E; a.use_ae = cfg.use_ae; a.kl_weight = &scalars->kl_weight;
+  a.O = O; a.acc = loss_acc; a.losses = losses;
+  a.d_boxes_pred = with_grads ? dbp : nullptr; a.d_logits = with_grads ? dlogits : nullptr; a.ld_dbp = dbp_ld;
+  RET_IF(sln_launch_loss(a, st));
+  have_loss_grads = with_grads;
+  return 0;
+}
+
+// Backward of decoder(): expects dbp (padded) and dlogits filled.
+int SlnVae::decoder_backward(hipStream_t st) {
+  const bool tr = dec_training;
+  const size_t dec_doubles = stats_doubles - enc_stats_doubles;
+  if (dec_doubles) HIP_RET(hipMemsetAsync(gstats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  RET_IF(refresh_transposes(st));
+  const int last = 2 * L - 1;
+  const Layer& ll = layers[last];
+  const int W = Ddc, WA = Ddc + n_attr_e;
+  // box_net.1
+  Operand Gb = op1(seg_ident(dbp, dbp_ld, 0, dbp_ld, 0), O); Gb.cols = dbp_ld;
+  {
+    Operand Gw = Gb; Gw.seg[0].len = cfg.box_dim; Gw.cols = cfg.box_dim;   // wgrad masks the padded columns itself
+    RET_IF(linear_wgrad(Gw, op1(seg_act(bnA1, H, 0, H, bn_head[4], 0, tr), O), unit_boxnet(1), O, st));
+  }
+  RET_IF(linear_dgrad(Gb, unit_boxnet(1), g_bn, H, O, bnA1, H, bn_head[4], true, nullptr, 0, tr, st));
+  // box_net.0
+  Operand G0 = op1(seg_bwd(g_bn, H, bnA1, H, H, bn_head[4], tr), O);
+  Operand XA; std::memset(&XA, 0, sizeof(XA));
+  XA.seg[0] = seg_act(ll.A4, W, 0, W, ll.bn[3], 0, tr);
+  XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
+  XA.nseg = 2; XA.rows = O; XA.cols = WA; XA.idx_a = attrs32;
+  RET_IF(linear_wgrad(G0, XA, unit_boxnet(0), O, st));
+  RET_IF(linear_dgrad(G0, unit_boxnet(0), d_bx, WA, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  // angle_net.1 / angle_net.0
+  Operand Ga = op1(seg_ident(dlogits, cfg.n_angle, 0, cfg.n_angle, 0), O);
+  RET_IF(linear_wgrad(Ga, op1(seg_act(anA1, H, 0, H, bn_head[5], 0, tr), O), unit_anglenet(1), O, st));
+  RET_IF(linear_dgrad(Ga, unit_anglenet(1), g_an, H, O, anA1, H, bn_head[5], true, nullptr, 0, tr, st));
+  Operand Ga0 = op1(seg_bwd(g_an, H, anA1, H, H, bn_head[5], tr), O);
+  RET_IF(linear_wgrad(Ga0, layer_output(last, tr), unit_anglenet(0), O, st));
+  RET_IF(linear_dgrad(Ga0, unit_anglenet(0), d_ax, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
+  {
+    BnView v = view(ll.bn[3], 0, tr);
+    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, W, ll.A4, W, v, O, W, g4, W,
+                                  v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
+  }
+  RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, W, O, n_attr_e, t.d_attr_emb_dc, st));
+  // gconv layers, last to first
+  for (int l = L - 1; l >= 0; --l) {
+    const int gi = L + l, slot = l & 1;
+    const float* dP = (l == L - 1) ? nullptr : dG[slot ^ 1];
+    RET_IF(gconv_backward(gi, dP, 3 * W, W, slot, tr, st));
+    if (l > 0) {
+      const Layer& pv = layers[gi - 1];
+      BnView v = view(pv.bn[3], 0, tr);
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, g4, W,
+                                   v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
+    } else {
+      BnView none = view(-1, 0, tr);
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
+      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, t.d_pred_emb_dc, st));
+    }
+  }
+  DecAssembleBwd db; std::memset(&db, 0, sizeof(db));
+  db.objs = batch.objs; db.attrs = batch.attributes; db.dx0 = dX0; db.O = O; db.n_obj = n_obj_e; db.n_attr = n_attr_e; db.n_z = E;
+  db.d_obj_emb = t.d_obj_emb_dc; db.d_attr_emb = t.d_attr_emb_dc; db.dz = dz;
+  RET_IF(sln_launch_dec_assemble_bwd(db, st));
+  const int nb = (int)bns.size() - n_bn_enc;
+  if (nb > 0) {
+    int maxc = 0;
+    for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
+    RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, st));
+  }
+  return 0;
+}
+
+// Backward of encoder(): expects dmu / dlv filled.
+int SlnVae::encoder_backward(hipStream_t st) {
+  const bool tr = enc_training;
+  if (enc_stats_doubles) HIP_RET(hipMemsetAsync(gstats_base, 0, enc_stats_doubles * sizeof(double), st));
+  RET_IF(refresh_transposes(st));
+  const int last = L - 1, W = 2 * E;
+  const Layer& ll = layers[last];
+  const Operand XL = layer_output(last, tr);
+  float* d_x[2] = {d_xb, d_xa};
+  for (int br = 0; br < 2; ++br) {         // 0: box branch (units 0..3), 1: angle branch (units 4..7)
+    const int u = br * 4;
+    float* hA1 = br ? haA1 : hbA1; float* hA2 = br ? haA2 : hbA2;
+    const int b0 = bn_head[br * 2], b1 = bn_head[br * 2 + 1];
+    const int c0 = br ? n_box_e : 0, n = br ? n_angle_e : n_box_e;
+    const Operand Hh = op1(seg_act(hA2, W, 0, W, b1, 0, tr), O);
+    Operand Gm = op1(seg_ident(dmu, E, c0, n, 0), O);
+    Operand Gv = op1(seg_ident(dlv, E, c0, n, 0), O);
+    RET_IF(linear_wgrad(Gm, Hh, u + 2, O, st));
+    RET_IF(linear_wgrad(Gv, Hh, u + 3, O, st));
+    RET_IF(linear_dgrad(Gm, u + 2, tmp_d, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+    RET_IF(linear_dgrad(Gv, u + 3, g_h2, W, O, hA2, W, b1, true, tmp_d, W, tr, st));
+    Operand G2 = op1(seg_bwd(g_h2, W, hA2, W, W, b1, tr), O);
+    RET_IF(linear_wgrad(G2, op1(seg_act(hA1, H, 0, H, b0, 0, tr), O), u + 1, O, st));
+    RET_IF(linear_dgrad(G2, u + 1, g_h1, H, O, hA1, H, b0, true, nullptr, 0, tr, st));
+    Operand G1 = op1(seg_bwd(g_h1, H, hA1, H, H, b0, tr), O);
+    RET_IF(linear_wgrad(G1, XL, u + 0, O, st));
+    RET_IF(linear_dgrad(G1, u + 0, d_x[br], W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  }
+  {
+    BnView v = view(ll.bn[3], 0, tr);
+    RET_IF(sln_launch_mask_gstats(d_xb, W, d_xa, W, ll.A4, W, v, O, W, g4, W,
+                                  v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int gi = l, slot = l & 1;
+    const float* dP = (l == L - 1) ? nullptr : dG[slot ^ 1];
+    RET_IF(gconv_backward(gi, dP, 3 * W, W, slot, tr, st));
+    if (l > 0) {
+      const Layer& pv = layers[gi - 1];
+      BnView v = view(pv.bn[3], 0, tr);
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, g4, W,
+                                   v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
+    } else {
+      BnView none = view(-1, 0, tr);
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
+      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, t.d_pred_emb_ec, st));
+    }
+  }
+  EncAssembleBwd eb; std::memset(&eb, 0, sizeof(eb));
+  eb.objs = batch.objs; eb.attrs = batch.attributes; eb.angles = batch.angles; eb.boxes = batch.boxes; eb.dx0 = dX0;
+  eb.O = O; eb.n_obj = n_obj_e; eb.n_attr = n_attr_e; eb.n_box = n_box_e; eb.n_angle = n_angle_e; eb.box_dim = cfg.box_dim;
+  eb.d_obj_emb = t.d_obj_emb_ec; eb.d_attr_emb = t.d_attr_emb_ec; eb.d_angle_emb = t.d_angle_emb;
+  eb.d_wb = t.d_box_emb_w; eb.d_bb = t.d_box_emb_b;
+  RET_IF(sln_launch_enc_assemble_bwd(eb, st));
+  if (n_bn_enc > 0) {
+    int maxc = 0;
+    for (int i = 0; i < n_bn_enc; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
+    RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, st));
+  }
+  return 0;
+}
+
+int SlnVae::train_iteration(const float* eps, SlnHostHook hook, void* user, hipStream_t st) {
+  HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
+  RET_IF(encoder_forward(true, st));
+  RET_IF(decoder_forward(nullptr, eps, true, st));
+  RET_IF(loss(boxes_pred, angles_pred, mu, logvar, true, st));
+  RET_IF(decoder_backward(st));
+  RET_IF(sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st));
+  RET_IF(encoder_backward(st));
+  if (hook) hook(user);
+  RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
+  wt_fresh = false;                    // transposed copies are rebuilt at the start of the next backward
+  return 0;
+}
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int sln_version(void) { return 1; }
+const char* sln_build_arch(void) { return "gfx950"; }
+int sln_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SLN_E_NOGPU;
+  hipDeviceProp_t p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return SLN_E_NOGPU;
+  return std::strncmp(p.gcnArchName, "gfx950", 6) == 0 ? 0 : SLN_E_NOGPU;
+}
+
+static int cfg_check(const SlnVaeConfig* c) {
+  if (!c) return SLN_E_BADARG;
+  if (c->embedding_dim <= 0 || c->embedding_dim % 16 != 0) return SLN_E_UNSUPPORTED;
+  if (c->gconv_num_layers < 1 || !c->decoder_cat) return SLN_E_UNSUPPORTED;
+  if (c->box_dim != 6 && c->box_dim != 4) return SLN_E_UNSUPPORTED;
+  if (c->n_angle % 4 != 0 || c->n_angle <= 0) return SLN_E_UNSUPPORTED;
+  return 0;
+}
+
+int sln_vae_num_units(const SlnVaeConfig* c) {
+  if (cfg_check(c) != 0) return cfg_check(c);
+  const int nmod = c->recurrent ? 1 : c->gconv_num_layers;
+  return 8 + 2 * nmod * 4 + 4;
+}
+
+int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
+  if (!out) return SLN_E_BADARG;
+  int r = cfg_check(c);
+  if (r != 0) return r;
+  SlnVae* h = new (std::nothrow) SlnVae();
+  if (!h) return SLN_E_BADARG;
+  h->cfg = *c;
+  const int E = c->embedding_dim;
+  h->E = E; h->H = 4 * E; h->L = c->gconv_num_layers; h->nmod = c->recurrent ? 1 : h->L;
+  h->n_obj_e = E * 3 / 4; h->n_attr_e = E / 4; h->n_box_e = E * 3 / 4; h->n_angle_e = E / 4;
+  h->Dec = 2 * E; h->Ddc = 2 * E;
+  const int H = h->H, W = 2 * E, n = sln_vae_num_units(c);
+  h->units.resize(n);
+  auto set = [&](int i, int out_, int in_, bool bn) { h->units[i].out = out_; h->units[i].in = in_; h->units[i].bn = bn && c->batch_norm; };
+  set(0, H, W, true); set(1, W, H, true); set(2, h->n_box_e, W, false); set(3, h->n_box_e, W, false);
+  set(4, H, W, true); set(5, W, H, true); set(6, h->n_angle_e, W, false); set(7, h->n_angle_e, W, false);
+  for (int net = 0; net < 2; ++net)
+    for (int m = 0; m < h->nmod; ++m) {
+      const int u = 8 + (net * h->nmod + m) * 4, D = W;
+      set(u + 0, H, 3 * D, true); set(u + 1, 2 * H + D, H, true); set(u + 2, H, H, true); set(u + 3, D, H, true);
+    }
+  set(h->unit_boxnet(0), H, W + h->n_attr_e, true); set(h->unit_boxnet(1), c->box_dim, H, false);
+  set(h->unit_anglenet(0), H, W, true); set(h->unit_anglenet(1), c->n_angle, H, false);
+  // layers and BatchNorm applications, in execution order
+  h->layers.resize(2 * h->L);
+  for (int net = 0; net < 2; ++net) {
+    for (int l = 0; l < h->L; ++l) {
+      Layer& ly = h->layers[net * h->L + l];
+      ly.net = net; ly.first = l == 0; ly.last = l == h->L - 1; ly.D = W; ly.u0 = h->unit_of(net, l, 0);
+      const int Cs[4] = {H, 2 * H + W, H, W};
+      for (int k = 0; k < 4; ++k) {
+        if (!h->units[ly.u0 + k].bn) continue;
+        BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;   // -1: T rows, -2: O rows (set per batch)
+        ly.bn[k] = (int)h->bns.size(); h->bns.push_back(b);
+      }
+    }
+    auto head = [&](int slot, int unit, int C) {
+      if (!h->units[unit].bn) return;
+      BnInst b; b.unit = unit; b.C = C; b.rows = -2;
+      h->bn_head[slot] = (int)h->bns.size(); h->bns.push_back(b);
+    };
+    if (net == 0) { head(0, 0, H); head(1, 1, W); head(2, 4, H); head(3, 5, W); h->n_bn_enc = (int)h->bns.size(); }
+    else { head(4, h->unit_boxnet(0), H); head(5, h->unit_anglenet(0), H); }
+  }
+  if (!c->batch_norm) h->n_bn_enc = 0;
+  *out = h;
+  return 0;
+}
+
+void sln_vae_destroy(SlnVae* h) {
+  if (!h) return;
+  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  delete h;
+}
+
+int64_t sln_vae_workspace_bytes(const SlnVae* h, int max_objs, int max_triples) {
+  if (!h || max_objs <= 0 || max_triples < 0) return SLN_E_BADARG;
+  SlnVae tmp = *h;                 // carve() on a copy in dry-run mode
+  tmp.graph_exec = nullptr;
+  return (int64_t)tmp.carve(nullptr, max_objs, max_triples < 1 ? 1 : max_triples);
+}
+
+int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t workspace_bytes, int max_objs, int max_triples) {
+  if (!h || !t || !workspace || !t->units_host) return SLN_E_BADARG;
+  if (max_triples < 1) max_triples = 1;
+  const int64_t need = sln_vae_workspace_bytes(h, max_objs, max_triples);
+  if (need < 0 || workspace_bytes < need) return SLN_E_BADARG;
+  h->t = *t;
+  for (size_t i = 0; i < h->units.size(); ++i) {
+    h->units[i].p = t->units_host[i];
+    if (!h->units[i].p.weight || !h->units[i].p.bias) return SLN_E_BADARG;
+    if (h->units[i].bn && (!h->units[i].p.bn_weight || !h->units[i].p.bn_bias || !h->units[i].p.bn_running_mean ||
+                           !h->units[i].p.bn_running_var)) return SLN_E_BADARG;
+  }
+  h->carve(workspace, max_objs, max_triples);
+  h->maxO = max_objs; h->maxT = max_triples;
+  // transposition table (weights needed by dgrad)
+  std::vector<TransposeEntry> tr;
+  int maxt = 0;
+  for (auto& u : h->units) {
+    TransposeEntry e; e.src = u.p.weight; e.dst = u.wt; e.rows = u.out; e.cols = u.in; e.dst_ld = u.wt_ld; e.pad_ = 0;
+    tr.push_back(e);
+    const int tiles = sln_cdiv(u.out, 32) * sln_cdiv(u.in, 32);
+    maxt = tiles > maxt ? tiles : maxt;
+  }
+  h->n_tr = (int)tr.size(); h->tr_max_tiles = maxt;
+  HIP_RET(hipMemcpy(h->tr_table_dev, tr.data(), sizeof(TransposeEntry) * tr.size(), hipMemcpyHostToDevice));
+  AdamScalars sc; std::memset(&sc, 0, sizeof(sc));
+  sc.step = 0; sc.lr = 1e-4f; sc.beta1 = 0.9f; sc.beta2 = 0.999f; sc.eps = 1e-8f; sc.kl_weight = 0.1f; sc.bc1 = 1.f; sc.bc2 = 1.f;
+  HIP_RET(hipMemcpy(h->scalars, &sc, sizeof(sc), hipMemcpyHostToDevice));
+  RET_IF(sln_gemm_init());
+  h->host_scalars_valid = false;
+  h->bound = true; h->batch_set = false; h->wt_fresh = false; h->have_enc = h->have_dec = false;
+  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  return 0;
+}
+
+static int upload_bn_table(SlnVae* h) {
+  std::vector<BnTableEntry> tab(h->bns.size());
+  for (size_t i = 0; i < h->bns.size(); ++i) {
+    BnInst& b = h->bns[i];
+    const Unit& u = h->units[b.unit];
+    BnTableEntry e; std::memset(&e, 0, sizeof(e));
+    e.sums = b.sums; e.gsums = b.gsums; e.cstride = b.C; e.C = b.C; e.rows = b.rows;
+    e.rmean = u.p.bn_running_mean; e.rvar = u.p.bn_running_var; e.nbt = u.p.bn_num_batches_tracked;
+    e.dgamma = u.p.d_bn_weight; e.dbeta = u.p.d_bn_bias;
+    tab[i] = e;
+  }
+  if (!tab.empty()) HIP_RET(hipMemcpy(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
+  if (!h || !b || !h->bound) return SLN_E_BADARG;
+  if (b->O <= 0 || b->T < 0 || b->O > h->maxO || b->T > h->maxT) return SLN_E_BADARG;
+  if (!b->objs || !b->boxes || !b->angles || !b->attributes || (b->T > 0 && !b->triples)) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool shape_changed = (b->O != h->O) || (b->T != h->T) || !h->batch_set;
+  h->batch = *b; h->O = b->O; h->T = b->T;
+  h->g.T = b->T; h->g.O = b->O;
+  if (shape_changed) {
+    // BatchNorm row counts: instances over triples (net1) use T rows, the others O rows
+    for (auto& ly : h->layers)
+      for (int k = 0; k < 4; ++k)
+        if (ly.bn[k] >= 0) h->bns[ly.bn[k]].rows = k < 2 ? b->T : b->O;
+    for (int s = 0; s < 6; ++s)
+      if (h->bn_head[s] >= 0) h->bns[h->bn_head[s]].rows = b->O;
+    hipError_t e = hipStreamSynchronize(st);       // table upload below is a blocking copy
+    if (e != hipSuccess) return (int)e;
+    RET_IF(upload_bn_table(h));
+    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  }
+  RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->g, h->err_flag, st));
+  RET_IF(sln_launch_i64_to_i32(b->attributes, h->attrs32, b->O, st));
+  h->batch_set = true; h->have_enc = h->have_dec = false;
+  return 0;
+}
+
+static int copy_out(float* dst, const float* src, size_t n, hipStream_t st) {
+  if (!dst || dst == src) return 0;
+  return (int)hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+}
+
+int sln_vae_encoder(SlnVae* h, float* mu, float* logvar, int training, void* stream) {
+  if (!h || !h->batch_set) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(h->encoder_forward(training != 0, st));
+  RET_IF(copy_out(mu, h->mu, (size_t)h->O * h->E, st));
+  RET_IF(copy_out(logvar, h->logvar, (size_t)h->O * h->E, st));
+  return 0;
+}
+
+int sln_vae_decoder(SlnVae* h, const float* z, float* boxes_pred, float* angles_pred, int training, void* stream) {
+  if (!h || !h->batch_set) return SLN_E_STATE;
+  if (!z) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(h->decoder_forward(z, nullptr, training != 0, st));
+  RET_IF(copy_out(boxes_pred, h->boxes_pred, (size_t)h->O * h->cfg.box_dim, st));
+  RET_IF(copy_out(angles_pred, h->angles_pred, (size_t)h->O * h->cfg.n_angle, st));
+  return 0;
+}
+
+int sln_vae_forward(SlnVae* h, const float* eps, float* mu, float* logvar, float* z_out, float* boxes_pred,
+                    float* angles_pred, int training, void* stream) {
+  if (!h || !h->batch_set) return SLN_E_STATE;
+  if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+  RET_IF(h->encoder_forward(training != 0, st));
+  RET_IF(h->decoder_forward(nullptr, h->eps_buf, training != 0, st));
+  RET_IF(copy_out(mu, h->mu, (size_t)h->O * h->E, st));
+  RET_IF(copy_out(logvar, h->logvar, (size_t)h->O * h->E, st));
+  RET_IF(copy_out(z_out, h->z, (size_t)h->O * h->E, st));
+  RET_IF(copy_out(boxes_pred, h->boxes_pred, (size_t)h->O * h->cfg.box_dim, st));
+  RET_IF(copy_out(angles_pred, h->angles_pred, (size_t)h->O * h->cfg.n_angle, st));
+  return 0;
+}
+
+static int set_kl(SlnVae* h, float kl_weight, float lr, hipStream_t st) {
+  // two floats inside the device scalar block (kept out of kernel arguments so a captured graph sees updates)
+  if (kl_weight != h->host_kl || !h->host_scalars_valid) {
+    h->host_kl = kl_weight;
+    HIP_RET(hipMemcpyAsync(&h->scalars->kl_weight, &h->host_kl, sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  if (lr > 0.f && (lr != h->host_lr || !h->host_scalars_valid)) {
+    h->host_lr = lr;
+    HIP_RET(hipMemcpyAsync(&h->scalars->lr, &h->host_lr, sizeof(float), hipMemcpyHostToDevice, st));
+  }
+  h->host_scalars_valid = true;
+  return 0;
+}
+
+int sln_vae_loss(SlnVae* h, const float* boxes_pred, const float* angles_pred, const float* mu, const float* logvar,
+                 float kl_weight, float* losses_out, int with_grads, void* stream) {
+  if (!h || !h->batch_set) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(set_kl(h, kl_weight, -1.f, st));
+  RET_IF(h->loss(boxes_pred ? boxes_pred : h->boxes_pred, angles_pred ? angles_pred : h->angles_pred,
+                 mu ? mu : h->mu, logvar ? logvar : h->logvar, with_grads != 0, st));
+  RET_IF(copy_out(losses_out, h->losses, 4, st));
+  return 0;
+}
+
+int sln_vae_decoder_backward(SlnVae* h, const float* d_boxes_pred, const float* d_angles_pred, float* dz, void* stream) {
+  if (!h || !h->have_dec) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  if (d_boxes_pred)
+    HIP_RET(hipMemcpy2DAsync(h->dbp, sizeof(float) * h->dbp_ld, d_boxes_pred, sizeof(float) * h->cfg.box_dim,
+                             sizeof(float) * h->cfg.box_dim, (size_t)h->O, hipMemcpyDeviceToDevice, st));
+  else HIP_RET(hipMemsetAsync(h->dbp, 0, sizeof(float) * (size_t)h->O * h->dbp_ld, st));
+  if (d_angles_pred) RET_IF(sln_launch_log_softmax_bwd(h->angles_pred, d_angles_pred, h->dlogits, h->O, h->cfg.n_angle, st));
+  else HIP_RET(hipMemsetAsync(h->dlogits, 0, sizeof(float) * (size_t)h->O * h->cfg.n_angle, st));
+  RET_IF(h->decoder_backward(st));
+  RET_IF(copy_out(dz, h->dz, (size_t)h->O * h->E, st));
+  return 0;
+}
+
+int sln_vae_encoder_backward(SlnVae* h, const float* d_mu, const float* d_logvar, void* stream) {
+  if (!h || !h->have_enc) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)h->O * h->E;
+  if (d_mu) RET_IF(copy_out(h->dmu, d_mu, n, st)); else HIP_RET(hipMemsetAsync(h->dmu, 0, n * sizeof(float), st));
+  if (d_logvar) RET_IF(copy_out(h->dlv, d_logvar, n, st)); else HIP_RET(hipMemsetAsync(h->dlv, 0, n * sizeof(float), st));
+  RET_IF(h->encoder_backward(st));
+  return 0;
+}
+
+int sln_vae_backward(SlnVae* h, void* stream) {
+  if (!h || !h->have_enc || !h->have_dec || !h->have_loss_grads || !h->z_from_latent) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(h->decoder_backward(st));
+  RET_IF(sln_launch_latent_bwd(h->mu, h->logvar, h->eps_buf, h->dz, &h->scalars->kl_weight, h->O, h->E, h->cfg.use_ae,
+                               h->dmu, h->dlv, st));
+  RET_IF(h->encoder_backward(st));
+  return 0;
+}
+
+int sln_vae_zero_grad(SlnVae* h, void* stream) {
+  if (!h || !h->bound) return SLN_E_STATE;
+  return (int)hipMemsetAsync(h->t.flat_grads, 0, sizeof(float) * (size_t)h->t.n_flat, (hipStream_t)stream);
+}
+
+int sln_vae_adam_step(SlnVae* h, float lr, void* stream) {
+  if (!h || !h->bound || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(set_kl(h, h->host_scalars_valid ? h->host_kl : 0.1f, lr, st));
+  RET_IF(sln_launch_adam(h->t.flat_params, h->t.flat_grads, h->t.adam_m, h->t.adam_v, (long)h->t.n_flat, h->scalars, st));
+  h->wt_fresh = false;
+  return 0;
+}
+
+int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream) {
+  if (!h || !h->bound) return SLN_E_STATE;
+  h->host_step = step;
+  return (int)hipMemcpyAsync(&h->scalars->step, &h->host_step, sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream);
+}
+
+int sln_vae_params_changed(SlnVae* h) {       // parameters were modified outside the engine (load_state_dict, SGD)
+  if (!h) return SLN_E_BADARG;
+  h->wt_fresh = false;
+  return 0;
+}
+
+int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
+                       SlnHostHook hook, void* user, void* stream) {
+  if (!h || !h->batch_set || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
+  if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  RET_IF(set_kl(h, kl_weight, lr, st));
+  if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+  if (use_graph && !hook && st != nullptr) {
+    if (!h->graph_exec || h->graph_O != h->O || h->graph_T != h->T) {
+      if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+      HIP_RET(hipStreamSynchronize(st));
+      h->wt_fresh = false;         // the captured iteration always rebuilds the transposed weights itself
+      hipGraph_t graph = nullptr;
+      HIP_RET(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      const int r = h->train_iteration(h->eps_buf, nullptr, nullptr, st);
+      hipError_t e = hipStreamEndCapture(st, &graph);
+      if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+      if (e != hipSuccess) return (int)e;
+      e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (e != hipSuccess) { h->graph_exec = nullptr; return (int)e; }
+      h->graph_O = h->O; h->graph_T = h->T;
+    }
+    HIP_RET(hipGraphLaunch(h->graph_exec, st));
+    h->enc_training = h->dec_training = true; h->have_enc = h->have_dec = true; h->z_from_latent = true; h->wt_fresh = false;
+  } else {
+    RET_IF(h->train_iteration(h->eps_buf, hook, user, st));
+  }
+  RET_IF(copy_out(losses_out, h->losses, 4, st));
+  return 0;
+}
+
+int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream) {
+  if (!h || layer < 0 || layer >= (int)h->layers.size() || !dst) return SLN_E_BADARG;
+  const Layer& ly = h->layers[layer];
+  const int H = h->H, D = ly.D;
+  const float* src; size_t n;
+  switch (what) {
+    case 0: src = ly.A1; n = (size_t)h->T * H; break;
+    case 1: src = ly.A2; n = (size_t)h->T * (2 * H + D); break;
+    case 2: src = ly.M; n = (size_t)h->O * H; break;
+    case 3: src = ly.A3; n = (size_t)h->O * H; break;
+    case 4: src = ly.A4; n = (size_t)h->O * D; break;
+    default: return SLN_E_BADARG;
+  }
+  hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return e == hipSuccess ? (int64_t)n : -(int64_t)e;
+}
+
+int sln_linear_forward(const float* x, int M, int K, const float* W, const float* bias, float* y, int N, double* sums,
+                       int tile, void* stream) {
+  if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || (K & 3)) return SLN_E_BADARG;
+  GemmNTArgs a; std::memset(&a, 0, sizeof(a));
+  Seg s; std::memset(&s, 0, sizeof(s));
+  s.x1 = x; s.ld1 = K; s.len = K; s.coef = SLN_COEF_IDENT;
+  a.A.seg[0] = s; a.A.nseg = 1; a.A.rows = M; a.A.cols = K;
+  a.W = W; a.bias = bias; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.ldw = K;
+  a.osums = sums; a.ocstride = N;
+  return sln_launch_gemm_nt(a, sums ? EPI_STATS : EPI_PLAIN, tile, (hipStream_t)stream);
+}
+
+int sln_linear_wgrad(const float* gq, const float* x, int R, int N, int K, float* dW, float* db, void* stream) {
+  if (!gq || !x || !dW || R <= 0 || N <= 0 || K <= 0 || (K & 3) || (N & 3)) return SLN_E_BADARG;
+  GemmTNArgs a; std::memset(&a, 0, sizeof(a));
+  Seg sg; std::memset(&sg, 0, sizeof(sg));
+  sg.x1 = gq; sg.ld1 = N; sg.len = N; sg.coef = SLN_COEF_IDENT;
+  Seg sx = sg; sx.x1 = x; sx.ld1 = K; sx.len = K;
+  a.G.seg[0] = sg; a.G.nseg = 1; a.G.rows = R; a.G.cols = N;
+  a.X.seg[0] = sx; a.X.nseg = 1; a.X.rows = R; a.X.cols = K;
+  a.dW = dW; a.db = db; a.lddw = K; a.R = R; a.Nout = N; a.Kin = K;
+  return sln_launch_gemm_tn(a, -1, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,652 @@
+// Non-GEMM kernels of the scene-graph VAE path (gfx950): graph CSR, edge aggregation
+// (scatter/gather), embedding assembly, loss, BatchNorm bookkeeping, transposes, Adam.
+//
+// These are HBM/L2-bound streaming kernels: coalesced 64-column row segments per wave, per-column
+// statistics reduced in registers -> LDS -> one fp64 atomic per column per block.
+#include "vae_kernels.h"
+
+namespace {
+
+constexpr int CB = 64;   // columns per block
+constexpr int RL = 4;    // row lanes per block
+constexpr int RB = 32;   // rows per block
+
+__device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid, double* out, int cstride, int col) {
+  __shared__ float red[2][RL][CB];
+  red[0][threadIdx.y][threadIdx.x] = s1;
+  red[1][threadIdx.y][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.y == 0 && valid && out != nullptr) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < RL; ++i) { a += red[0][i][threadIdx.x]; b += red[1][i][threadIdx.x]; }
+    atomicAdd(out + col, (double)a);
+    atomicAdd(out + cstride + col, (double)b);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// graph CSR
+// ----------------------------------------------------------------------------------------------
+__global__ void prep_split_kernel(const int64_t* __restrict__ tri, int T, int O, GraphCsr g, int* err) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int64_t s = tri[3 * t], p = tri[3 * t + 1], o = tri[3 * t + 2];
+  if (s < 0 || s >= O || o < 0 || o >= O) { if (err) atomicOr(err, 1); g.s[t] = 0; g.p[t] = 0; g.o[t] = 0; return; }
+  g.s[t] = (int)s; g.p[t] = (int)p; g.o[t] = (int)o;
+  atomicAdd(g.deg + (int)s, 1);
+  atomicAdd(g.deg + (int)o, 1);
+}
+
+__global__ __launch_bounds__(1024) void csr_scan_kernel(GraphCsr g, int O) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < O; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int d = i < O ? g.deg[i] : 0;
+    part[threadIdx.x] = d;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+      int v = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    const int excl = carry + part[threadIdx.x] - d;
+    if (i < O) {
+      g.rowptr[i] = excl; g.cursor[i] = excl;
+      g.invdeg[i] = 1.0f / (float)(d > 1 ? d : 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) g.rowptr[O] = carry;
+}
+
+__global__ void csr_fill_kernel(GraphCsr g, int T) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 2 * T) return;
+  const int node = e < T ? g.s[e] : g.o[e - T];
+  const int pos = atomicAdd(g.cursor + node, 1);
+  g.ent[pos] = e;
+}
+
+__global__ void csr_sort_kernel(GraphCsr g, int O) {
+  // ascending entry id inside each row == reference scatter_add order (all subject rows in triple
+  // order, then all object rows, models/graph.py:97-98); rows are short (<= ~2x objects per room).
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  const int b = g.rowptr[i], e = g.rowptr[i + 1];
+  for (int a = b + 1; a < e; ++a) {
+    const int key = g.ent[a];
+    int j = a - 1;
+    while (j >= b && g.ent[j] > key) { g.ent[j + 1] = g.ent[j]; --j; }
+    g.ent[j + 1] = key;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// edge aggregation
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CB* RL) void scatter_avg_fwd_kernel(const float* __restrict__ A2, int ld, int H, int D,
+                                                                 BnView bn, GraphCsr g, int O, int T,
+                                                                 float* __restrict__ pooled) {
+  const int c = blockIdx.x * CB + threadIdx.x;
+  if (c >= H) return;
+  float scs, shs, sco, sho;
+  bn_fwd_coef(bn, c, scs, shs);
+  bn_fwd_coef(bn, H + D + c, sco, sho);
+  const int r1 = min(O, (int)(blockIdx.y + 1) * RB);
+  for (int i = blockIdx.y * RB + threadIdx.y; i < r1; i += RL) {
+    const int b = g.rowptr[i], e = g.rowptr[i + 1];
+    float acc = 0.f;
+    for (int k = b; k < e; ++k) {
+      const int en = g.ent[k];
+      const bool isobj = en >= T;
+      const int t = isobj ? en - T : en;
+      const float x = A2[(size_t)t * ld + (isobj ? H + D + c : c)];
+      acc += fmaxf(fmaf(isobj ? sco : scs, x, isobj ? sho : shs), 0.f);
+    }
+    pooled[(size_t)i * H + c] = acc * g.invdeg[i];
+  }
+}
+
+__global__ __launch_bounds__(CB* RL) void scatter_avg_bwd_kernel(const float* __restrict__ dM, const float* __restrict__ dP,
+                                                                 int lddp, int dpcol0, const float* __restrict__ A2,
+                                                                 int ld, int H, int D, BnView bn, GraphCsr g, int T,
+                                                                 float* __restrict__ g2, double* gsums, int cstride) {
+  const int c = blockIdx.x * CB + threadIdx.x;
+  const int C = 2 * H + D;
+  const bool cv = c < C;
+  float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
+  if (cv) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
+  const int part = c < H ? 0 : (c < H + D ? 1 : 2);
+  float s1 = 0.f, s2 = 0.f;
+  const int r1 = min(T, (int)(blockIdx.y + 1) * RB);
+  if (cv) {
+    for (int t = blockIdx.y * RB + threadIdx.y; t < r1; t += RL) {
+      float d;
+      if (part == 1) d = dP ? dP[(size_t)t * lddp + dpcol0 + (c - H)] : 0.f;
+      else {
+        const int node = part == 0 ? g.s[t] : g.o[t];
+        d = dM[(size_t)node * H + (part == 0 ? c : c - H - D)] * g.invdeg[node];
+      }
+      const float x = A2[(size_t)t * ld + c];
+      const float gv = fmaf(sc, x, sh) > 0.f ? d : 0.f;
+      g2[(size_t)t * ld + c] = gv;
+      s1 += gv; s2 = fmaf(gv, (x - mean) * istd, s2);
+    }
+  }
+  commit_col_stats(s1, s2, cv, gsums, cstride, c);
+}
+
+__global__ __launch_bounds__(CB* RL) void gather_bwd_kernel(const float* __restrict__ dG, int ldg, int D, GraphCsr g,
+                                                            int O, int T, const float* __restrict__ add1, int ldadd1,
+                                                            const float* __restrict__ xprev, int ldx, BnView bn,
+                                                            int masked, float* __restrict__ out, int ldo,
+                                                            double* gsums, int cstride) {
+  const int c = blockIdx.x * CB + threadIdx.x;
+  const bool cv = c < D;
+  float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
+  if (cv && masked) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
+  float s1 = 0.f, s2 = 0.f;
+  const int r1 = min(O, (int)(blockIdx.y + 1) * RB);
+  if (cv) {
+    for (int i = blockIdx.y * RB + threadIdx.y; i < r1; i += RL) {
+      const int b = g.rowptr[i], e = g.rowptr[i + 1];
+      float d = 0.f;
+      for (int k = b; k < e; ++k) {
+        const int en = g.ent[k];
+        const bool isobj = en >= T;
+        const int t = isobj ? en - T : en;
+        d += dG[(size_t)t * ldg + (isobj ? 2 * D + c : c)];
+      }
+      if (add1) d += add1[(size_t)i * ldadd1 + c];
+      if (masked) {
+        const float x = xprev[(size_t)i * ldx + c];
+        d = fmaf(sc, x, sh) > 0.f ? d : 0.f;
+        s1 += d; s2 = fmaf(d, (x - mean) * istd, s2);
+      }
+      out[(size_t)i * ldo + c] = d;
+    }
+  }
+  if (masked) commit_col_stats(s1, s2, cv, gsums, cstride, c);
+}
+
+__global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __restrict__ d1, int ld1,
+                                                             const float* __restrict__ d2, int ld2,
+                                                             const float* __restrict__ xprev, int ldx, BnView bn,
+                                                             int rows, int cols, float* __restrict__ out, int ldo,
+                                                             double* gsums, int cstride) {
+  const int c = blockIdx.x * CB + threadIdx.x;
+  const bool cv = c < cols;
+  float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
+  if (cv) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
+  float s1 = 0.f, s2 = 0.f;
+  const int r1 = min(rows, (int)(blockIdx.y + 1) * RB);
+  if (cv) {
+    for (int r = blockIdx.y * RB + threadIdx.y; r < r1; r += RL) {
+      float d = d1[(size_t)r * ld1 + c];
+      if (d2) d += d2[(size_t)r * ld2 + c];
+      const float x = xprev[(size_t)r * ldx + c];
+      d = fmaf(sc, x, sh) > 0.f ? d : 0.f;
+      out[(size_t)r * ldo + c] = d;
+      s1 += d; s2 = fmaf(d, (x - mean) * istd, s2);
+    }
+  }
+  commit_col_stats(s1, s2, cv, gsums, cstride, c);
+}
+
+// ----------------------------------------------------------------------------------------------
+// embeddings
+// ----------------------------------------------------------------------------------------------
+__global__ void enc_assemble_kernel(EncAssemble a) {
+  const int W = a.n_obj + a.n_attr + a.n_box + a.n_angle;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.O * W) return;
+  const int r = (int)(idx / W);
+  int c = (int)(idx % W);
+  float v;
+  if (c < a.n_obj) v = a.obj_emb[(size_t)a.objs[r] * a.n_obj + c];
+  else if ((c -= a.n_obj) < a.n_attr) v = a.attr_emb[(size_t)a.attrs[r] * a.n_attr + c];
+  else if ((c -= a.n_attr) < a.n_box) {
+    v = a.bb[c];
+    for (int k = 0; k < a.box_dim; ++k) v = fmaf(a.boxes[(size_t)r * a.box_dim + k], a.wb[c * a.box_dim + k], v);
+  } else { c -= a.n_box; v = a.angle_emb[(size_t)a.angles[r] * a.n_angle + c]; }
+  a.x0[idx] = v;
+}
+
+__global__ void enc_assemble_bwd_kernel(EncAssembleBwd a) {
+  // embedding parts: atomics straight into the (small) tables
+  const int W = a.n_obj + a.n_attr + a.n_box + a.n_angle;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.O * W) return;
+  const int r = (int)(idx / W);
+  int c = (int)(idx % W);
+  const float d = a.dx0[idx];
+  if (c < a.n_obj) atomicAdd(a.d_obj_emb + (size_t)a.objs[r] * a.n_obj + c, d);
+  else if ((c -= a.n_obj) < a.n_attr) atomicAdd(a.d_attr_emb + (size_t)a.attrs[r] * a.n_attr + c, d);
+  else if ((c -= a.n_attr) < a.n_box) { /* Linear(box_dim -> n_box): box_embed_bwd_kernel */ }
+  else { c -= a.n_box; atomicAdd(a.d_angle_emb + (size_t)a.angles[r] * a.n_angle + c, d); }
+}
+
+__global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a) {
+  // d_bb[j] += sum_r d[r,j];  d_wb[j,k] += sum_r d[r,j]*boxes[r,k]   (box_dim <= 6)
+  const int W = a.n_obj + a.n_attr + a.n_box + a.n_angle, off = a.n_obj + a.n_attr;
+  const int j = blockIdx.x * CB + threadIdx.x;
+  const bool jv = j < a.n_box;
+  float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int r1 = min(a.O, (int)(blockIdx.y + 1) * 64);
+  if (jv) {
+    for (int r = blockIdx.y * 64 + threadIdx.y; r < r1; r += RL) {
+      const float d = a.dx0[(size_t)r * W + off + j];
+      acc[6] += d;
+      for (int k = 0; k < a.box_dim; ++k) acc[k] = fmaf(d, a.boxes[(size_t)r * a.box_dim + k], acc[k]);
+    }
+  }
+  __shared__ float red[7][RL][CB];
+  for (int k = 0; k < 7; ++k) red[k][threadIdx.y][threadIdx.x] = acc[k];
+  __syncthreads();
+  if (threadIdx.y == 0 && jv) {
+    for (int k = 0; k < 7; ++k) {
+      float s = 0.f;
+      for (int i = 0; i < RL; ++i) s += red[k][i][threadIdx.x];
+      if (k == 6) atomicAdd(a.d_bb + j, s);
+      else if (k < a.box_dim) atomicAdd(a.d_wb + j * a.box_dim + k, s);
+    }
+  }
+}
+
+__global__ void dec_assemble_kernel(DecAssemble a) {
+  const int W = a.n_obj + a.n_attr + a.n_z;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.O * W) return;
+  const int r = (int)(idx / W);
+  int c = (int)(idx % W);
+  float v;
+  if (c < a.n_obj) v = a.obj_emb[(size_t)a.objs[r] * a.n_obj + c];
+  else if ((c -= a.n_obj) < a.n_attr) v = a.attr_emb[(size_t)a.attrs[r] * a.n_attr + c];
+  else {
+    c -= a.n_attr;
+    const size_t zi = (size_t)r * a.n_z + c;
+    if (a.z_in) v = a.z_in[zi];
+    else if (a.use_ae) v = a.mu[zi];
+    else v = a.eps[zi] * expf(0.5f * a.logvar[zi]) + a.mu[zi];     // Sg2ScVAE_model.py:180-183
+    if (a.z) a.z[zi] = v;
+  }
+  a.x0[idx] = v;
+}
+
+__global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
+  const int W = a.n_obj + a.n_attr + a.n_z;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)a.O * W) return;
+  const int r = (int)(idx / W);
+  int c = (int)(idx % W);
+  const float d = a.dx0[idx];
+  if (c < a.n_obj) atomicAdd(a.d_obj_emb + (size_t)a.objs[r] * a.n_obj + c, d);
+  else if ((c -= a.n_obj) < a.n_attr) atomicAdd(a.d_attr_emb + (size_t)a.attrs[r] * a.n_attr + c, d);
+  else { c -= a.n_attr; if (a.dz) a.dz[(size_t)r * a.n_z + c] = d; }
+}
+
+template <typename IdxT>
+__global__ void embed_bwd_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows,
+                                 int n, float* __restrict__ d_emb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * n) return;
+  const int r = (int)(i / n), c = (int)(i % n);
+  atomicAdd(d_emb + (size_t)idx[r] * n + c, d[(size_t)r * ld + col0 + c]);
+}
+
+__global__ void embed_gather_kernel(const int* __restrict__ idx, const float* __restrict__ emb, int rows, int n,
+                                    float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * n) return;
+  const int r = (int)(i / n), c = (int)(i % n);
+  out[i] = emb[(size_t)idx[r] * n + c];
+}
+
+__global__ void i64_to_i32_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (int)src[i];
+}
+
+// ----------------------------------------------------------------------------------------------
+// loss
+// ----------------------------------------------------------------------------------------------
+__global__ void log_softmax_bwd_kernel(const float* __restrict__ lp, const float* __restrict__ dlp,
+                                       float* __restrict__ dx, int O, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= O) return;
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += dlp[(size_t)r * n + k];
+  for (int k = 0; k < n; ++k) dx[(size_t)r * n + k] = dlp[(size_t)r * n + k] - expf(lp[(size_t)r * n + k]) * s;
+}
+
+__global__ void log_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int O, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= O) return;
+  const float* xr = x + (size_t)r * n;
+  float m = xr[0];
+  for (int k = 1; k < n; ++k) m = fmaxf(m, xr[k]);
+  float s = 0.f;
+  for (int k = 0; k < n; ++k) s += expf(xr[k] - m);
+  const float ls = logf(s) + m;
+  for (int k = 0; k < n; ++k) y[(size_t)r * n + k] = xr[k] - ls;
+}
+
+__global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  double l1 = 0.0, nll = 0.0, kl = 0.0;
+  if (r < a.O) {
+    const float gb = 1.0f / ((float)a.O * (float)a.box_dim);
+    for (int k = 0; k < a.box_dim; ++k) {
+      const float diff = a.boxes_pred[(size_t)r * a.box_dim + k] - a.boxes[(size_t)r * a.box_dim + k];
+      l1 += fabsf(diff);
+      if (a.d_boxes_pred) a.d_boxes_pred[(size_t)r * a.ld_dbp + k] = diff > 0.f ? gb : (diff < 0.f ? -gb : 0.f);
+    }
+    const int tgt = (int)a.angles[r];
+    nll = -(double)a.angles_pred[(size_t)r * a.n_angle + tgt];
+    if (a.d_logits) {
+      const float go = 1.0f / (float)a.O;
+      for (int k = 0; k < a.n_angle; ++k)
+        a.d_logits[(size_t)r * a.n_angle + k] = (expf(a.angles_pred[(size_t)r * a.n_angle + k]) - (k == tgt ? 1.f : 0.f)) * go;
+    }
+    if (!a.use_ae) {
+      float s = 0.f;
+      for (int k = 0; k < a.n_z; ++k) {
+        const float m = a.mu[(size_t)r * a.n_z + k], lv = a.logvar[(size_t)r * a.n_z + k];
+        s += 1.f + lv - m * m - expf(lv);
+      }
+      kl = s;
+    }
+  }
+  __shared__ double red[3][256];
+  red[0][threadIdx.x] = l1; red[1][threadIdx.x] = nll; red[2][threadIdx.x] = kl;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) atomicAdd(a.acc + threadIdx.x, red[threadIdx.x][0]);
+}
+
+__global__ void loss_finalize_kernel(LossArgs a) {
+  const double O = (double)a.O;
+  const float lb = (float)(a.acc[0] / (O * a.box_dim));
+  const float la = (float)(a.acc[1] / O);
+  float lk = 0.f;
+  if (!a.use_ae) lk = (float)(-0.5 * a.acc[2] / O) * a.kl_weight[0];
+  a.losses[0] = lb; a.losses[1] = la; a.losses[2] = lk; a.losses[3] = lb + la + lk;
+}
+
+__global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
+                                  const float* __restrict__ eps, const float* __restrict__ dz,
+                                  const float* __restrict__ klw, int O, int nz, int use_ae, float* __restrict__ dmu,
+                                  float* __restrict__ dlv) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)O * nz) return;
+  const float g = dz[i];
+  if (use_ae) { dmu[i] = g; dlv[i] = 0.f; return; }
+  const float w = klw[0] / (float)O;
+  const float l = lv[i];
+  dmu[i] = fmaf(w, mu[i], g);
+  dlv[i] = w * 0.5f * (expf(l) - 1.f) + g * eps[i] * 0.5f * expf(0.5f * l);
+}
+
+// ----------------------------------------------------------------------------------------------
+// BatchNorm bookkeeping, transposes, Adam
+// ----------------------------------------------------------------------------------------------
+__global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, int n, float mom) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int e = 0; e < n; ++e) {               // in application order: shared modules see ordered updates
+    const BnTableEntry t = tab[e];
+    if (c == 0 && t.nbt) t.nbt[0] += 1;
+    if (c >= t.C || t.rmean == nullptr) continue;
+    const double N = (double)t.rows;
+    const double m = t.sums[c] / N;
+    double v = t.sums[t.cstride + c] / N - m * m;
+    v = v < 0.0 ? 0.0 : v;
+    const double vu = t.rows > 1 ? v * N / (N - 1.0) : v;
+    t.rmean[c] = (1.f - mom) * t.rmean[c] + mom * (float)m;
+    t.rvar[c] = (1.f - mom) * t.rvar[c] + mom * (float)vu;
+  }
+}
+
+__global__ void bn_param_grads_kernel(const BnTableEntry* __restrict__ tab, int n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int e = 0; e < n; ++e) {
+    const BnTableEntry t = tab[e];
+    if (c >= t.C || t.dgamma == nullptr) continue;
+    t.dbeta[c] += (float)t.gsums[c];
+    t.dgamma[c] += (float)t.gsums[t.cstride + c];
+  }
+}
+
+__global__ __launch_bounds__(256) void transpose_table_kernel(const TransposeEntry* __restrict__ tab) {
+  __shared__ float tile[32][33];
+  const TransposeEntry t = tab[blockIdx.y];
+  const int tr = (t.rows + 31) / 32, tc = (t.cols + 31) / 32;
+  if ((int)blockIdx.x >= tr * tc) return;
+  const int r0 = (blockIdx.x / tc) * 32, c0 = (blockIdx.x % tc) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < t.rows && c < t.cols) ? t.src[(size_t)r * t.cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < t.rows && c < t.cols) t.dst[(size_t)c * t.dst_ld + r] = tile[tx][i];
+  }
+}
+
+__global__ void adam_tick_kernel(AdamScalars* s) {
+  s->step += 1;
+  s->bc1 = (float)(1.0 - pow((double)s->beta1, (double)s->step));
+  s->bc2 = (float)(1.0 - pow((double)s->beta2, (double)s->step));
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, const AdamScalars* __restrict__ sc) {
+  // torch.optim.Adam defaults (train.py:15): no weight decay, no amsgrad
+  const float b1 = sc->beta1, b2 = sc->beta2, eps = sc->eps;
+  const float step_size = sc->lr / sc->bc1, rs2 = 1.0f / sqrtf(sc->bc2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+  }
+}
+
+inline dim3 colgrid(int cols, int rows) { return dim3(sln_cdiv(cols, CB), sln_cdiv(rows, RB)); }
+
+}  // namespace
+
+int sln_launch_graph_prep(const int64_t* triples, int T, int O, GraphCsr g, int* err_flag, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
+  if (e != hipSuccess) return (int)e;
+  if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, g, err_flag);
+  hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, g, O);
+  if (T > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(sln_cdiv(2 * T, 256)), dim3(256), 0, st, g, T);
+  hipLaunchKernelGGL(csr_sort_kernel, dim3(sln_cdiv(O, 64)), dim3(64), 0, st, g, O);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2, GraphCsr g, int O, float* pooled,
+                               hipStream_t st) {
+  if (O <= 0) return 0;
+  hipLaunchKernelGGL(scatter_avg_fwd_kernel, colgrid(H, O), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int dpcol0, const float* A2, int ld, int H,
+                               int D, BnView bn2, GraphCsr g, int T, float* g2, double* gsums, int cstride,
+                               hipStream_t st) {
+  if (T <= 0) return 0;
+  hipLaunchKernelGGL(scatter_avg_bwd_kernel, colgrid(2 * H + D, T), dim3(CB, RL), 0, st, dM, dP, lddp, dpcol0, A2, ld, H,
+                     D, bn2, g, T, g2, gsums, cstride);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, const float* add1, int ldadd1,
+                          const float* xprev, int ldx, BnView bn, int masked, float* out, int ldo, double* gsums,
+                          int cstride, hipStream_t st) {
+  if (O <= 0) return 0;
+  hipLaunchKernelGGL(gather_bwd_kernel, colgrid(D, O), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
+                     ldx, bn, masked, out, ldo, gsums, cstride);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_mask_gstats(const float* d1, int ld1, const float* d2, int ld2, const float* xprev, int ldx, BnView bn,
+                           int rows, int cols, float* out, int ldo, double* gsums, int cstride, hipStream_t st) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(mask_gstats_kernel, colgrid(cols, rows), dim3(CB, RL), 0, st, d1, ld1, d2, ld2, xprev, ldx, bn, rows,
+                     cols, out, ldo, gsums, cstride);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_enc_assemble(EncAssemble a, hipStream_t st) {
+  const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_box + a.n_angle);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(enc_assemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st) {
+  const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_box + a.n_angle);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(enc_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, 64)), dim3(CB, RL), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_dec_assemble(DecAssemble a, hipStream_t st) {
+  const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_z);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dec_assemble_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st) {
+  const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_z);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(dec_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
+                             hipStream_t st) {
+  const long tot = (long)rows * n;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel<int>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, idx, d, ld, col0, rows,
+                     n, d_emb);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
+                             hipStream_t st) {
+  const long tot = (long)rows * n;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(embed_bwd_kernel<int64_t>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, idx, d, ld, col0,
+                     rows, n, d_emb);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_embed_gather_i32(const int* idx, const float* emb, int rows, int n, float* out, hipStream_t st) {
+  const long tot = (long)rows * n;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, idx, emb, rows, n, out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_i64_to_i32(const int64_t* src, int* dst, int n, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(i64_to_i32_kernel, dim3(sln_cdiv(n, 256)), dim3(256), 0, st, src, dst, n);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_log_softmax_bwd(const float* logprob, const float* d_logprob, float* d_logits, int O, int n,
+                               hipStream_t st) {
+  if (O <= 0) return 0;
+  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(sln_cdiv(O, 128)), dim3(128), 0, st, logprob, d_logprob, d_logits, O, n);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_log_softmax(const float* logits, float* out, int O, int n, hipStream_t st) {
+  if (O <= 0) return 0;
+  hipLaunchKernelGGL(log_softmax_kernel, dim3(sln_cdiv(O, 128)), dim3(128), 0, st, logits, out, O, n);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_loss(LossArgs a, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(double) * 4, st);
+  if (e != hipSuccess) return (int)e;
+  if (a.O > 0) hipLaunchKernelGGL(loss_kernel, dim3(sln_cdiv(a.O, 256)), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_latent_bwd(const float* mu, const float* logvar, const float* eps, const float* dz, const float* kl_weight,
+                          int O, int n_z, int use_ae, float* dmu, float* dlogvar, hipStream_t st) {
+  const long n = (long)O * n_z;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, mu, logvar, eps, dz,
+                     kl_weight, O, n_z, use_ae, dmu, dlogvar);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(sln_cdiv(max_c, 256)), dim3(256), 0, st, table, n, momentum);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, hipStream_t st) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(sln_cdiv(max_c, 256)), dim3(256), 0, st, table, n);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles, hipStream_t st) {
+  if (n <= 0 || max_tiles <= 0) return 0;
+  hipLaunchKernelGGL(transpose_table_kernel, dim3(max_tiles, n), dim3(256), 0, st, table);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, hipStream_t st) {
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, scalars);
+  if (n > 0) {
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars);
+  }
+  SLN_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,420 @@
+"""HIP-backed drop-in for the reference's ``models/Sg2ScVAE_model.py::Sg2ScVAEModel``.
+
+Same constructor keywords (build_dataset_model.py:40-52), same sub-module / parameter names
+(so ``state_dict`` / ``load_state_dict`` interoperate with reference checkpoints), same
+``encoder`` / ``decoder`` / ``forward`` call surfaces (models/Sg2ScVAE_model.py:115-188).
+All arithmetic runs in libsln_hip.so through the C ABI (include/sln_hip.h); this file only
+owns the parameters (packed into one flat fp32 buffer, which is also what the data-parallel
+trainer all-reduces and what the fused Adam kernel walks) and wires autograd.
+
+There is no CPU path: calling the model before ``.cuda()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .graph import GraphTripleConvNet, _init_weights, make_mlp, mlp_linears
+
+_ALIGN = 64   # floats; keeps every tensor 256-byte aligned inside the flat buffers
+
+
+class _ForwardFn(torch.autograd.Function):
+    """mu, logvar, boxes_pred, angles_pred = model(...) with gradients routed to the engine."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, eps, training):
+        mu, lv, z, bp, ap = model._engine_forward(eps, training)
+        ctx.model, ctx.gen = model, model._generation
+        ctx.save_for_backward(eps, lv)
+        return mu, lv, bp, ap
+
+    @staticmethod
+    def backward(ctx, dmu, dlv, dbp, dap):
+        model = ctx.model
+        eps, lv = ctx.saved_tensors
+        model._check_generation(ctx.gen)
+        model._alias_grads()
+        dz = model._engine_decoder_backward(dbp, dap)
+        if model.use_AE:
+            dmu_t = dz if dmu is None else dmu + dz
+            dlv_t = dlv
+        else:
+            dmu_t = dz if dmu is None else dmu + dz
+            dlv_z = dz * eps * (0.5 * torch.exp(0.5 * lv))
+            dlv_t = dlv_z if dlv is None else dlv + dlv_z
+        model._engine_encoder_backward(dmu_t, dlv_t)
+        return None, None, None, None
+
+
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, model, training):
+        mu, lv = model._engine_encoder(training)
+        ctx.model, ctx.gen = model, model._generation
+        return mu, lv
+
+    @staticmethod
+    def backward(ctx, dmu, dlv):
+        model = ctx.model
+        model._check_generation(ctx.gen)
+        model._alias_grads()
+        model._engine_encoder_backward(dmu, dlv)
+        return None, None, None
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, z, model, training):
+        bp, ap = model._engine_decoder(z, training)
+        ctx.model, ctx.gen = model, model._generation
+        return bp, ap
+
+    @staticmethod
+    def backward(ctx, dbp, dap):
+        model = ctx.model
+        model._check_generation(ctx.gen)
+        model._alias_grads()
+        dz = model._engine_decoder_backward(dbp, dap)
+        return None, dz, None, None
+
+
+class Sg2ScVAEModel(nn.Module):
+    def __init__(self, vocab, embedding_dim=128, batch_size=32, train_3d=True, decoder_cat=False, Nangle=24,
+                 gconv_mode='feedforward', gconv_pooling='avg', gconv_num_layers=5, mlp_normalization='none',
+                 vec_noise_dim=0, layout_noise_dim=0, use_AE=False, use_attr=True):
+        super().__init__()
+        if not use_attr:
+            raise NotImplementedError("use_attr=False is never reached in the reference (build_model does not pass it)")
+        if not decoder_cat:
+            raise NotImplementedError("the HIP path implements decoder_cat=True (train.py's default, options.py:55)")
+        if gconv_num_layers < 1:
+            raise NotImplementedError("gconv_num_layers must be >= 1 on the HIP path")
+        if embedding_dim % 16:
+            raise NotImplementedError("embedding_dim must be a multiple of 16 on the HIP path")
+        E = embedding_dim
+        hidden = E * 4
+        box_e, angle_e, obj_e, attr_e = int(E * 3 / 4), int(E / 4), int(E * 3 / 4), int(E / 4)
+        self.use_attr, self.batch_size, self.train_3d, self.decoder_cat = use_attr, batch_size, train_3d, decoder_cat
+        self.vocab, self.vec_noise_dim, self.layout_noise_dim, self.use_AE = vocab, vec_noise_dim, layout_noise_dim, use_AE
+        self.embedding_dim, self.Nangle, self.gconv_mode = E, Nangle, gconv_mode
+        self.gconv_num_layers, self.mlp_normalization = gconv_num_layers, mlp_normalization
+        num_objs, num_preds = len(vocab['object_idx_to_name']), len(vocab['pred_idx_to_name'])
+        num_attrs = len(vocab['attrib_idx_to_name'])
+        self.box_dim = 6 if train_3d else 4
+
+        # registration order == reference (Sg2ScVAE_model.py:44-103): it is the parameter order
+        self.obj_embeddings_ec = nn.Embedding(num_objs + 1, obj_e)
+        self.pred_embeddings_ec = nn.Embedding(num_preds, E * 2)
+        self.obj_embeddings_dc = nn.Embedding(num_objs + 1, obj_e)
+        self.pred_embeddings_dc = nn.Embedding(num_preds, E * 2)
+        self.attr_embedding_ec = nn.Embedding(num_attrs, attr_e)
+        self.attr_embedding_dc = nn.Embedding(num_attrs, attr_e)
+        self.box_embeddings = nn.Linear(self.box_dim, box_e)
+        self.angle_embeddings = nn.Embedding(Nangle, angle_e)
+        n = mlp_normalization
+        self.box_mean_var = make_mlp([E * 2, hidden, E * 2], batch_norm=n)
+        self.box_mean = make_mlp([E * 2, box_e], batch_norm=n, norelu=True)
+        self.box_var = make_mlp([E * 2, box_e], batch_norm=n, norelu=True)
+        self.angle_mean_var = make_mlp([E * 2, hidden, E * 2], batch_norm=n)
+        self.angle_mean = make_mlp([E * 2, angle_e], batch_norm=n, norelu=True)
+        self.angle_var = make_mlp([E * 2, angle_e], batch_norm=n, norelu=True)
+        kw = dict(hidden_dim=hidden, pooling=gconv_pooling, num_layers=gconv_num_layers, mode=gconv_mode,
+                  mlp_normalization=n)
+        self.gconv_net_ec = GraphTripleConvNet(input_dim=E * 2, **kw)
+        self.gconv_net_dc = GraphTripleConvNet(input_dim=E * 2, **kw)
+        self.box_net = make_mlp([E * 2 + attr_e, hidden, self.box_dim], batch_norm=n, norelu=True)
+        self.angle_net = make_mlp([E * 2, hidden, Nangle], batch_norm=n, norelu=True)
+        for m in (self.box_embeddings, self.box_mean_var, self.box_mean, self.box_var, self.angle_mean_var,
+                  self.angle_mean, self.angle_var, self.box_net):
+            m.apply(_init_weights)
+
+        self._eng = None
+        self._generation = 0
+        self._batch_key = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flatten(self):
+        params = list(self.parameters())
+        for p in params:
+            if p.dtype != torch.float32:
+                raise NotImplementedError("the HIP path is fp32 only (bit-for-tolerance parity with the reference)")
+        dev = params[0].device
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        views = []
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                v = flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+                gv = gflat[o:o + p.numel()].view(p.shape)
+                if p.grad is not None:
+                    gv.copy_(p.grad)
+                p.grad = gv
+                views.append(gv)
+        self._flat, self._gflat, self._gviews, self._params = flat, gflat, views, params
+        self._adam_m = self._adam_v = None
+        self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
+        self._drop_engine()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)     # copies in place: the flat views stay valid
+        if self._eng is not None:
+            _lib.check(_lib.lib().sln_vae_params_changed(self._eng), "sln_vae_params_changed")
+        return out
+
+    @property
+    def flat_params(self):
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        return self._gflat
+
+    def params_changed(self):
+        """Call after modifying parameters outside the engine (e.g. a torch optimizer step)."""
+        if self._eng is not None:
+            _lib.check(_lib.lib().sln_vae_params_changed(self._eng), "sln_vae_params_changed")
+
+    def _alias_grads(self):
+        # optimizer.zero_grad(set_to_none=True) detaches p.grad from the flat buffer: restart those
+        for p, gv in zip(self._params, self._gviews):
+            g = p.grad
+            if g is None or g.data_ptr() != gv.data_ptr():
+                gv.zero_()
+                p.grad = gv
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _drop_engine(self):
+        if getattr(self, "_eng", None) is not None:
+            _lib.lib().sln_vae_destroy(self._eng)
+        self._eng = None
+        self._maxO = self._maxT = 0
+        self._batch_key = None
+
+    def __del__(self):
+        try:
+            self._drop_engine()
+        except Exception:
+            pass
+
+    def _config(self):
+        c = _lib.SlnVaeConfig()
+        c.embedding_dim, c.gconv_num_layers = self.embedding_dim, self.gconv_num_layers
+        c.recurrent = int(self.gconv_mode == 'recurrent')
+        c.batch_norm = int(self.mlp_normalization == 'batch')
+        c.decoder_cat, c.use_ae, c.box_dim, c.n_angle = 1, int(self.use_AE), self.box_dim, self.Nangle
+        c.num_objs = self.obj_embeddings_ec.num_embeddings
+        c.num_preds = self.pred_embeddings_ec.num_embeddings
+        c.num_attrs = self.attr_embedding_ec.num_embeddings
+        return c
+
+    def _unit_modules(self):
+        seqs = [self.box_mean_var, self.box_mean, self.box_var, self.angle_mean_var, self.angle_mean, self.angle_var]
+        for net in (self.gconv_net_ec, self.gconv_net_dc):
+            for gc in net.gconvs:
+                seqs += [gc.net1, gc.net2]
+        seqs += [self.box_net, self.angle_net]
+        out = []
+        for s in seqs:
+            out += mlp_linears(s)
+        return out
+
+    def _ensure_engine(self, O, T):
+        if self._flat.device.type != 'cuda':
+            raise _lib.SlnError("Sg2ScVAEModel runs on the MI355X only: call model.cuda() first (no CPU fallback)")
+        L = _lib.lib()
+        if self._eng is not None and O <= self._maxO and T <= self._maxT:
+            return
+        self._drop_engine()
+        cfg = self._config()
+        h = C.c_void_p()
+        _lib.check(L.sln_vae_create(C.byref(cfg), C.byref(h)), "sln_vae_create")
+        self._eng = h
+        maxO, maxT = max(O, 64), max(T, 64)
+        nbytes = L.sln_vae_workspace_bytes(h, maxO, maxT)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "sln_vae_workspace_bytes")
+        dev = self._flat.device
+        self._ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self._flat)
+            self._adam_v = torch.zeros_like(self._flat)
+        units = self._unit_modules()
+        n_units = L.sln_vae_num_units(C.byref(cfg))
+        assert n_units == len(units), (n_units, len(units))
+        arr = (_lib.SlnVaeUnit * n_units)()
+        gptr = {id(p): gv.data_ptr() for p, gv in zip(self._params, self._gviews)}
+        for u, (lin, bn) in zip(arr, units):
+            u.weight, u.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
+            u.d_weight, u.d_bias = gptr[id(lin.weight)], gptr[id(lin.bias)]
+            if bn is not None:
+                u.bn_weight, u.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+                u.bn_running_mean, u.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                u.bn_num_batches_tracked = bn.num_batches_tracked.data_ptr()
+                u.d_bn_weight, u.d_bn_bias = gptr[id(bn.weight)], gptr[id(bn.bias)]
+        t = _lib.SlnVaeTensors()
+        embs = dict(obj_emb_ec=self.obj_embeddings_ec.weight, pred_emb_ec=self.pred_embeddings_ec.weight,
+                    obj_emb_dc=self.obj_embeddings_dc.weight, pred_emb_dc=self.pred_embeddings_dc.weight,
+                    attr_emb_ec=self.attr_embedding_ec.weight, attr_emb_dc=self.attr_embedding_dc.weight,
+                    box_emb_w=self.box_embeddings.weight, box_emb_b=self.box_embeddings.bias,
+                    angle_emb=self.angle_embeddings.weight)
+        for k, p in embs.items():
+            setattr(t, k, p.data_ptr())
+            setattr(t, "d_" + k, gptr[id(p)])
+        t.units_host = arr
+        t.flat_params, t.flat_grads = self._flat.data_ptr(), self._gflat.data_ptr()
+        t.adam_m, t.adam_v, t.n_flat = self._adam_m.data_ptr(), self._adam_v.data_ptr(), self._flat.numel()
+        self._units_keepalive = arr
+        _lib.check(L.sln_vae_bind(h, C.byref(t), C.c_void_p(self._ws.data_ptr()), int(nbytes), maxO, maxT), "sln_vae_bind")
+        self._maxO, self._maxT = maxO, maxT
+        self._batch_key = None
+
+    def _set_batch(self, objs, triples, boxes, angles, attributes):
+        O, T = int(objs.shape[0]), int(triples.shape[0])
+        self._ensure_engine(O, T)
+        dev = self._flat.device
+
+        def prep(x, dt):
+            if x.device != dev:
+                raise _lib.SlnError("inputs must live on the model's GPU")
+            return x.to(dt).contiguous()
+        objs, triples, attributes = prep(objs, torch.int64), prep(triples, torch.int64), prep(attributes, torch.int64)
+        boxes = prep(boxes, torch.float32) if boxes is not None else torch.zeros(O, self.box_dim, device=dev)
+        angles = prep(angles, torch.int64) if angles is not None else torch.zeros(O, dtype=torch.int64, device=dev)
+        key = tuple((x.data_ptr(), tuple(x.shape), x._version) for x in (objs, triples, boxes, angles, attributes))
+        if key == self._batch_key:
+            return
+        b = _lib.SlnVaeBatch()
+        b.objs, b.triples, b.boxes = objs.data_ptr(), triples.data_ptr(), boxes.data_ptr()
+        b.angles, b.attributes, b.O, b.T = angles.data_ptr(), attributes.data_ptr(), O, T
+        _lib.check(_lib.lib().sln_vae_set_batch(self._eng, C.byref(b), _lib.current_stream_ptr()), "sln_vae_set_batch")
+        self._batch_refs = (objs, triples, boxes, angles, attributes)
+        self._batch_key, self._O, self._T = key, O, T
+
+    def _new(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self._flat.device)
+
+    def _check_generation(self, gen):
+        if gen != self._generation:
+            raise _lib.SlnError("backward() through a stale forward: another forward ran on this model in between")
+
+    def _engine_forward(self, eps, training):
+        O, E = self._O, self.embedding_dim
+        mu, lv, z = self._new(O, E), self._new(O, E), self._new(O, E)
+        bp, ap = self._new(O, self.box_dim), self._new(O, self.Nangle)
+        self._generation += 1
+        _lib.check(_lib.lib().sln_vae_forward(self._eng, _lib.ptr(eps), _lib.ptr(mu), _lib.ptr(lv), _lib.ptr(z), _lib.ptr(bp),
+                                              _lib.ptr(ap), int(training), _lib.current_stream_ptr()), "sln_vae_forward")
+        return mu, lv, z, bp, ap
+
+    def _engine_encoder(self, training):
+        O, E = self._O, self.embedding_dim
+        mu, lv = self._new(O, E), self._new(O, E)
+        self._generation += 1
+        _lib.check(_lib.lib().sln_vae_encoder(self._eng, _lib.ptr(mu), _lib.ptr(lv), int(training),
+                                              _lib.current_stream_ptr()), "sln_vae_encoder")
+        return mu, lv
+
+    def _engine_decoder(self, z, training):
+        O = self._O
+        z = z.detach().to(torch.float32).contiguous()
+        bp, ap = self._new(O, self.box_dim), self._new(O, self.Nangle)
+        self._generation += 1
+        _lib.check(_lib.lib().sln_vae_decoder(self._eng, _lib.ptr(z), _lib.ptr(bp), _lib.ptr(ap), int(training),
+                                              _lib.current_stream_ptr()), "sln_vae_decoder")
+        return bp, ap
+
+    def _engine_decoder_backward(self, dbp, dap):
+        dz = self._new(self._O, self.embedding_dim)
+        dbp = None if dbp is None else dbp.to(torch.float32).contiguous()
+        dap = None if dap is None else dap.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().sln_vae_decoder_backward(self._eng, _lib.ptr(dbp), _lib.ptr(dap), _lib.ptr(dz),
+                                                       _lib.current_stream_ptr()), "sln_vae_decoder_backward")
+        return dz
+
+    def _engine_encoder_backward(self, dmu, dlv):
+        dmu = None if dmu is None else dmu.to(torch.float32).contiguous()
+        dlv = None if dlv is None else dlv.to(torch.float32).contiguous()
+        _lib.check(_lib.lib().sln_vae_encoder_backward(self._eng, _lib.ptr(dmu), _lib.ptr(dlv), _lib.current_stream_ptr()),
+                   "sln_vae_encoder_backward")
+
+    # ------------------------------------------------------------------ reference call surfaces
+    def encoder(self, objs, triples, boxes_gt, angles_gt, attributes):
+        self._set_batch(objs, triples, boxes_gt, angles_gt, attributes)
+        if torch.is_grad_enabled():
+            return _EncoderFn.apply(self._anchor, self, self.training)
+        return self._engine_encoder(self.training)
+
+    def decoder(self, z, objs, triples, attributes):
+        boxes, angles = (self._batch_refs[2], self._batch_refs[3]) if self._batch_key is not None and \
+            self._batch_refs[0].shape[0] == objs.shape[0] else (None, None)
+        self._set_batch(objs, triples, boxes, angles, attributes)
+        if torch.is_grad_enabled():
+            return _DecoderFn.apply(self._anchor, z, self, self.training)
+        return self._engine_decoder(z, self.training)
+
+    def forward(self, objs, triples, boxes_gt, angles_gt, attributes, obj_to_img=None, eps=None):
+        """Returns (mu, logvar, boxes_pred, angles_pred).  ``eps`` (optional, [O, embedding_dim]) pins the
+        N(0,1) draw that the reference takes with torch.randn_like (Sg2ScVAE_model.py:182)."""
+        self._set_batch(objs, triples, boxes_gt, angles_gt, attributes)
+        if eps is None and not self.use_AE:
+            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
+        if eps is not None:
+            eps = eps.to(torch.float32).contiguous()
+        if torch.is_grad_enabled():
+            return _ForwardFn.apply(self._anchor, self, eps, self.training)
+        mu, lv, z, bp, ap = self._engine_forward(eps, self.training)
+        return mu, lv, bp, ap
+
+    # ------------------------------------------------------------------ fused training iteration
+    def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None,
+                   use_graph=True, hook=None):
+        """train.py:62-84 in one call: zero_grad, forward (train-mode BN), losses, backward, Adam.
+
+        Returns a 4-element device tensor [bbox_pred, angle_pred, KLD_Gauss*w, total_loss] (no host sync).
+        ``hook``: optional Python callable run after backward / before Adam (the data-parallel
+        all-reduce of ``flat_grads``); disables hipGraph replay.
+        """
+        self._set_batch(objs, triples, boxes, angles, attributes)
+        if eps is None and not self.use_AE:
+            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
+        losses = self._new(4)
+        cb = _lib.HOST_HOOK(lambda _u: hook()) if hook is not None else None
+        self._generation += 1
+        _lib.check(_lib.lib().sln_vae_train_step(
+            self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph),
+            C.cast(cb, C.c_void_p) if cb is not None else None, None, _lib.current_stream_ptr()), "sln_vae_train_step")
+        self._alias_grads()
+        return losses
+
+    def loss(self, kl_weight=0.1, with_grads=False):
+        """calculate_model_losses (utils.py:12-33) on the outputs of the last forward, on device."""
+        losses = self._new(4)
+        _lib.check(_lib.lib().sln_vae_loss(self._eng, None, None, None, None, float(kl_weight), _lib.ptr(losses),
+                                           int(with_grads), _lib.current_stream_ptr()), "sln_vae_loss")
+        return losses
+
+    def tap(self, layer, what):
+        """Debug: copy of an internal pre-activation (see sln_vae_tap)."""
+        H, D = self.embedding_dim * 4, self.embedding_dim * 2
+        shape = {0: (self._T, H), 1: (self._T, 2 * H + D), 2: (self._O, H), 3: (self._O, H), 4: (self._O, D)}[what]
+        out = self._new(*shape)
+        n = _lib.lib().sln_vae_tap(self._eng, layer, what, _lib.ptr(out), _lib.current_stream_ptr())
+        if n < 0:
+            _lib.check(int(n), "sln_vae_tap")
+        return out

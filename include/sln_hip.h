@@ -1,0 +1,168 @@
+/* sln_hip.h - C ABI of libsln_hip.so, the MI355X (gfx950) implementation of the 3D_SLN hot path.
+ *
+ * The reference (aluo-x/3D_SLN) has no FFI layer: its boundary for this path is a set of Python
+ * call surfaces.  This header is what those surfaces bind to; the Python mirror
+ * in 3d_sln_amd/host/ loads the library with ctypes and passes raw device pointers
+ * (torch.Tensor.data_ptr()) plus the current HIP stream.  No torch types cross this boundary.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense
+ *     row-major fp32 unless stated; index tensors are int64 exactly as the reference's
+ *     suncg_collate_fn produces them (data/suncg_dataset.py:295-337);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued, nothing synchronises;
+ *   - every function returns 0 on success, a hipError_t value (>0) for a HIP failure, or a
+ *     negative SLN_E_* code for a contract violation (nothing is launched in that case).
+ *
+ * Each entry point cites the reference interface it stands behind (paths relative to the
+ * reference repository root).
+ */
+#ifndef SLN_HIP_H
+#define SLN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLN_E_BADARG (-1)      /* null pointer / size that violates the contract below            */
+#define SLN_E_UNSUPPORTED (-2) /* configuration outside the HIP path (e.g. gconv_num_layers == 0) */
+#define SLN_E_STATE (-3)       /* call order violated (e.g. backward before forward)             */
+#define SLN_E_NOGPU (-4)       /* no gfx950 device visible                                       */
+
+int sln_version(void);                 /* ABI version, bumped on any signature change */
+const char* sln_build_arch(void);      /* "gfx950" */
+int sln_device_ok(void);               /* 0 when a gfx950 device is usable, SLN_E_NOGPU otherwise */
+
+/* =============================================================================================
+ * A. Scene-graph VAE  (models/graph.py:10-143, models/Sg2ScVAE_model.py:7-188, utils.py:12-33,
+ *    train.py:62-84)
+ * ============================================================================================= */
+
+typedef struct SlnVaeConfig {
+  int embedding_dim;     /* Sg2ScVAE_model.py:8; must be a multiple of 16                         */
+  int gconv_num_layers;  /* >= 1                                                                   */
+  int recurrent;         /* gconv_mode == 'recurrent' (weights shared by all layers)               */
+  int batch_norm;        /* mlp_normalization == 'batch' (1) or 'none' (0)                         */
+  int decoder_cat;       /* must be 1 on this path (train.py default, options/options.py:55)       */
+  int use_ae;            /* use_AE: z = mu, no KL term                                             */
+  int box_dim;           /* 6 (train_3d) or 4                                                      */
+  int n_angle;           /* Nangle = 24                                                            */
+  int num_objs;          /* rows of obj_embeddings_* (len(object_idx_to_name) + 1)                 */
+  int num_preds;         /* rows of pred_embeddings_*                                              */
+  int num_attrs;         /* rows of attr_embedding_*                                               */
+  int reserved;
+} SlnVaeConfig;
+
+/* Number of Linear(+BatchNorm) units and their canonical order:
+ *   box_mean_var.{0,1}, box_mean.0, box_var.0, angle_mean_var.{0,1}, angle_mean.0, angle_var.0,
+ *   gconv_net_ec.gconvs.i.{net1.0, net1.1, net2.0, net2.1} for each module i,
+ *   gconv_net_dc.gconvs.i.{...}, box_net.{0,1}, angle_net.{0,1}
+ * ("X.1" is the second Linear of the MLP, state_dict index 3 with BatchNorm, 2 without). */
+int sln_vae_num_units(const SlnVaeConfig* cfg);
+
+typedef struct SlnVaeUnit {        /* one Linear [+ BatchNorm1d] */
+  float* weight;  float* bias;                 /* [out, in], [out]                               */
+  float* bn_weight; float* bn_bias;            /* [out] or NULL                                  */
+  float* bn_running_mean; float* bn_running_var; int64_t* bn_num_batches_tracked;
+  float* d_weight; float* d_bias; float* d_bn_weight; float* d_bn_bias;   /* gradients (+=)      */
+} SlnVaeUnit;
+
+typedef struct SlnVaeTensors {
+  /* embeddings, Sg2ScVAE_model.py:44-58 (parameter, gradient) */
+  float* obj_emb_ec;  float* d_obj_emb_ec;
+  float* pred_emb_ec; float* d_pred_emb_ec;
+  float* obj_emb_dc;  float* d_obj_emb_dc;
+  float* pred_emb_dc; float* d_pred_emb_dc;
+  float* attr_emb_ec; float* d_attr_emb_ec;
+  float* attr_emb_dc; float* d_attr_emb_dc;
+  float* box_emb_w;   float* d_box_emb_w;
+  float* box_emb_b;   float* d_box_emb_b;
+  float* angle_emb;   float* d_angle_emb;
+  const SlnVaeUnit* units_host;    /* HOST array of sln_vae_num_units() entries                  */
+  /* flat views used by zero_grad / Adam / the data-parallel all-reduce: every parameter above
+   * must live inside [flat_params, flat_params + n_flat) at the same offset as its gradient in
+   * flat_grads.  adam_m / adam_v may be NULL when sln_vae_train_step is never called.           */
+  float* flat_params; float* flat_grads; float* adam_m; float* adam_v; int64_t n_flat;
+} SlnVaeTensors;
+
+typedef struct SlnVaeBatch {       /* suncg_collate_fn's tuple, data/suncg_dataset.py:327-337     */
+  const int64_t* objs;       /* [O]                                                              */
+  const int64_t* triples;    /* [T,3] (s, p, o) with global row ids                              */
+  const float*   boxes;      /* [O, box_dim]                                                     */
+  const int64_t* angles;     /* [O]                                                              */
+  const int64_t* attributes; /* [O]                                                              */
+  int O, T;
+} SlnVaeBatch;
+
+typedef struct SlnVae SlnVae;      /* opaque engine: kernel plan + workspace carve-up             */
+
+int sln_vae_create(const SlnVaeConfig* cfg, SlnVae** out);
+void sln_vae_destroy(SlnVae* h);
+/* bytes of device workspace needed for batches up to (max_objs, max_triples) */
+int64_t sln_vae_workspace_bytes(const SlnVae* h, int max_objs, int max_triples);
+/* workspace must be zero-filled once by the caller and stay alive while the engine is used */
+int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t workspace_bytes,
+                 int max_objs, int max_triples);
+
+/* Build the per-batch graph structure (int32 ids, degrees, CSR of incident triples).  Must
+ * precede encoder/decoder calls for a new batch.  Replaces the index/scatter_add bookkeeping of
+ * GraphTripleConv.forward (models/graph.py:70-72,89-108), hoisted out of the 10 layers. */
+int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream);
+
+/* Sg2ScVAEModel.encoder (Sg2ScVAE_model.py:115-143): writes mu, logvar [O, embedding_dim].
+ * training != 0: BatchNorm uses batch statistics and updates running stats (train()). */
+int sln_vae_encoder(SlnVae* h, float* mu, float* logvar, int training, void* stream);
+/* Sg2ScVAEModel.decoder (:145-172).  z [O, embedding_dim]; boxes_pred [O, box_dim];
+ * angles_pred [O, n_angle] = log_softmax. */
+int sln_vae_decoder(SlnVae* h, const float* z, float* boxes_pred, float* angles_pred, int training, void* stream);
+/* Sg2ScVAEModel.forward (:174-188) with the N(0,1) draw supplied by the caller (eps [O, E];
+ * torch.randn_like in the reference).  z_out may be NULL. */
+int sln_vae_forward(SlnVae* h, const float* eps, float* mu, float* logvar, float* z_out, float* boxes_pred,
+                    float* angles_pred, int training, void* stream);
+
+/* calculate_model_losses (utils.py:12-33): losses_out[4] = {bbox_pred, angle_pred, KLD*w, total}.
+ * When with_grads != 0 the gradients w.r.t. boxes_pred / logits are kept for sln_vae_backward. */
+int sln_vae_loss(SlnVae* h, const float* boxes_pred, const float* angles_pred, const float* mu,
+                 const float* logvar, float kl_weight, float* losses_out, int with_grads, void* stream);
+
+/* Backward of the decoder given d(boxes_pred) [O, box_dim] and d(angles_pred) [O, n_angle]
+ * (gradient w.r.t. the log-softmax OUTPUT).  Accumulates parameter gradients, writes dz [O, E]. */
+int sln_vae_decoder_backward(SlnVae* h, const float* d_boxes_pred, const float* d_angles_pred, float* dz, void* stream);
+/* Backward of the encoder given d(mu), d(logvar) [O, E]; accumulates parameter gradients. */
+int sln_vae_encoder_backward(SlnVae* h, const float* d_mu, const float* d_logvar, void* stream);
+/* total_loss.backward() of train.py:83 after sln_vae_forward + sln_vae_loss(with_grads=1). */
+int sln_vae_backward(SlnVae* h, void* stream);
+
+/* Tell the engine that parameters were modified outside of it (load_state_dict, a torch optimizer):
+ * cached transposed weights are rebuilt before the next backward. */
+int sln_vae_params_changed(SlnVae* h);
+int sln_vae_zero_grad(SlnVae* h, void* stream);                       /* optimizer.zero_grad(), train.py:82 */
+/* torch.optim.Adam(lr).step(), train.py:15,84 (betas .9/.999, eps 1e-8, no weight decay) */
+int sln_vae_adam_step(SlnVae* h, float lr, void* stream);
+int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream);       /* restore the step counter (checkpoint resume) */
+
+/* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward,
+ * [hook], Adam.  `use_graph`: replay a captured hipGraph when shapes are unchanged.
+ * `between_bwd_and_step` (may be NULL) is called on the host after the backward kernels are
+ * enqueued and before Adam - the data-parallel trainer enqueues its RCCL all-reduce there
+ * (disables graph replay). */
+typedef void (*SlnHostHook)(void* user);
+int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
+                       SlnHostHook between_bwd_and_step, void* hook_user, void* stream);
+
+/* Debug/test tap: copy an internal activation to `dst` (device).  what: 0 A1,1 A2,2 M,3 A3,4 A4 of
+ * gconv instance `layer` (0..L-1 encoder, L..2L-1 decoder).  Returns the element count or <0. */
+int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream);
+
+/* Standalone Linear kernels (parity tests of the GEMM family):
+ *   y[M,N] = x[M,K] W[N,K]^T + bias, optional fp64 column sums of y and y^2 in sums[2][N] */
+int sln_linear_forward(const float* x, int M, int K, const float* W, const float* bias, float* y, int N, double* sums,
+                       int tile, void* stream);
+/*   dW[N,K] += g[R,N]^T x[R,K];  db[N] += colsum(g) */
+int sln_linear_wgrad(const float* g, const float* x, int R, int N, int K, float* dW, float* db, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLN_HIP_H */

@@ -34,6 +34,7 @@ import torch
 import torch.nn.functional as F
 
 State = Dict[str, torch.Tensor]
+TRACE = None     # set to a dict to record every Linear output ("pre-activation") by state_dict prefix
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
@@ -188,6 +189,8 @@ def mlp_apply(sd: State, prefix: str, n_lin: int, x: torch.Tensor, norm: str,
     for i in range(n_lin):
         base = "%s.%d" % (prefix, i * per)
         x = F.linear(x, sd[base + ".weight"], sd[base + ".bias"])
+        if TRACE is not None:
+            TRACE.setdefault(base, []).append(x.detach().clone())
         if norelu and i == n_lin - 1:
             break
         if norm == "batch":
@@ -216,6 +219,8 @@ def gconv_apply(sd: State, prefix: str, obj: torch.Tensor, pred: torch.Tensor,
     ones = torch.ones(edges.shape[0], dtype=obj.dtype)
     deg = deg.index_add(0, s_idx, ones).index_add(0, o_idx, ones).clamp(min=1)
     pooled = pooled / deg[:, None]
+    if TRACE is not None:
+        TRACE.setdefault(prefix + ".pooled", []).append(pooled.detach().clone())
     new_obj = mlp_apply(sd, prefix + ".net2", 2, pooled, norm, training)
     return new_obj, new_p
 

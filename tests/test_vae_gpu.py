@@ -1,0 +1,251 @@
+"""GPU parity tests of the scene-graph VAE path (run with -m gpu on an MI355X).
+
+Everything goes through the C ABI (libsln_hip.so via ctypes); the checker is the CPU oracle
+(oracle/vae_ref.py) and the fixtures the reference itself produced (tests/golden/).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, pkg
+from parity import assert_adam_close, assert_close, assert_close_conditioned, max_err
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_ref                                   # noqa: E402
+from oracle.gen_golden import KL_WEIGHT, VAE_CASES           # noqa: E402
+
+HIP_CASES = [n for n, (over, *_rest) in VAE_CASES.items() if over.get("decoder_cat", True)]
+
+
+def _lib():
+    return pkg("_lib")
+
+
+def _model(cfg, sd):
+    M = pkg("host.Sg2ScVAE_model")
+    m = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m.cuda()
+
+
+def _dev(*ts):
+    return [t.cuda() for t in ts]
+
+
+# ----------------------------------------------------------------------------- GEMM family
+@pytest.mark.parametrize("M,N,K", [(4096, 256, 384), (4096, 640, 256), (2048, 128, 256), (12, 640, 256),
+                                   (8, 6, 256), (100, 48, 128), (333, 24, 36)])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4])
+def test_linear_forward(M, N, K, tile):
+    L = _lib()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g); W = torch.randn(N, K, generator=g) / K ** 0.5; b = torch.randn(N, generator=g)
+    xd, Wd, bd = _dev(x, W, b)
+    y = torch.empty(M, N, device="cuda"); sums = torch.zeros(2, N, dtype=torch.float64, device="cuda")
+    L.check(L.lib().sln_linear_forward(L.ptr(xd), M, K, L.ptr(Wd), L.ptr(bd), L.ptr(y), N, L.ptr(sums), tile,
+                                       L.current_stream_ptr()), "sln_linear_forward")
+    ref = (x.double() @ W.double().t() + b.double())
+    assert_close(y.cpu().numpy(), ref.numpy(), "y", rtol=2e-6, atol=1e-6)
+    assert_close(sums[0].cpu().numpy(), ref.sum(0).numpy(), "colsum", rtol=1e-5, atol=1e-5)
+    assert_close(sums[1].cpu().numpy(), (ref * ref).sum(0).numpy(), "colsumsq", rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("R,N,K", [(4096, 640, 256), (4096, 256, 384), (2048, 128, 256), (13, 8, 36), (100, 24, 256)])
+def test_linear_wgrad(R, N, K):
+    L = _lib()
+    g = torch.Generator().manual_seed(R + N)
+    gq = torch.randn(R, N, generator=g); x = torch.randn(R, K, generator=g)
+    gd, xd = _dev(gq, x)
+    dW = torch.zeros(N, K, device="cuda"); db = torch.zeros(N, device="cuda")
+    L.check(L.lib().sln_linear_wgrad(L.ptr(gd), L.ptr(xd), R, N, K, L.ptr(dW), L.ptr(db), L.current_stream_ptr()), "wgrad")
+    assert_close(dW.cpu().numpy(), (gq.double().t() @ x.double()).numpy(), "dW", rtol=1e-5, atol=1e-5)
+    assert_close(db.cpu().numpy(), gq.double().sum(0).numpy(), "db", rtol=1e-5, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+def _trace_oracle(sd, cfg, batch, eps, training):
+    vae_ref.TRACE = {}
+    try:
+        out = vae_ref.forward(sd, cfg, *batch, eps, training=training)
+        tr = vae_ref.TRACE
+    finally:
+        vae_ref.TRACE = None
+    return out, tr
+
+
+def _tap_report(model, cfg, trace):
+    """max-abs error of every stored pre-activation against the oracle's trace (debug aid)."""
+    rows = []
+    L = cfg.gconv_num_layers
+    for net, tag in enumerate(("ec", "dc")):
+        seen = {}
+        for l in range(L):
+            j = 0 if cfg.gconv_mode == "recurrent" else l
+            pre = "gconv_net_%s.gconvs.%d" % (tag, j)
+            k = seen.get(pre, 0); seen[pre] = k + 1
+            per = 3 if cfg.mlp_normalization == "batch" else 2
+            names = [pre + ".net1.0", pre + ".net1.%d" % per, pre + ".pooled", pre + ".net2.0", pre + ".net2.%d" % per]
+            for what, nm in enumerate(names):
+                ref = trace[nm][k].numpy()
+                got = model.tap(net * L + l, what).cpu().numpy()
+                e, s = max_err(got, ref)
+                rows.append("%s[%d] %-8s err %.2e scale %.2e" % (tag, l, ["A1", "A2", "M", "A3", "A4"][what], e, s))
+    return "\n".join(rows)
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_golden_eval_and_train(name):
+    g = load_golden(name)
+    cfg = vae_ref.VaeConfig(**VAE_CASES[name][0])
+    sd0 = vae_ref.init_state(cfg, seed=42)
+    model = _model(cfg, sd0)
+    ins = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in:")}
+    objs, triples, boxes, angles, attrs, eps = _dev(ins["objs"], ins["triples"], ins["boxes"], ins["angles"], ins["attrs"], ins["eps"])
+    ill = name == "vae_c1_full"       # BatchNorm over 8 rows: see tests/parity.py
+    batch_cpu = (ins["objs"], ins["triples"], ins["boxes"], ins["angles"], ins["attrs"])
+
+    def cmp(got, key, ref64=None, ref32=None, **kw):
+        if ill and ref64 is not None:
+            assert_close_conditioned(got.detach().cpu().numpy(), ref64, ref32, name + ":" + key, **kw)
+        else:
+            assert_close(got.detach().cpu().numpy(), g[key], name + ":" + key, **kw)
+
+    # fp64 evaluation of the oracle for the conditioned comparison
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    b64 = (ins["objs"], ins["triples"], ins["boxes"].double(), ins["angles"], ins["attrs"])
+
+    # ---- eval mode
+    model.eval()
+    with torch.no_grad():
+        mu, lv, bp, ap = model(objs, triples, boxes, angles, attrs, None, eps=eps)
+        r64 = vae_ref.forward(sd64, cfg, *b64, ins["eps"].double(), training=False)
+    for got, key, r in ((mu, "eval_mu", r64[0]), (lv, "eval_logvar", r64[1]), (bp, "eval_boxes_pred", r64[2]),
+                        (ap, "eval_angles_pred", r64[3])):
+        cmp(got, key, r.numpy(), g[key])
+
+    # ---- train mode forward + loss + backward
+    model.train()
+    mu, lv, bp, ap = model(objs, triples, boxes, angles, attrs, None, eps=eps)
+    (_, trace) = _trace_oracle({k: v.clone() for k, v in sd0.items()}, cfg, batch_cpu, ins["eps"], True)
+    report = _tap_report(model, cfg, trace)
+    sd64t = {k: v.clone() for k, v in sd64.items()}
+    r64 = vae_ref.forward(sd64t, cfg, *b64, ins["eps"].double(), training=True)
+    try:
+        for got, key, r in ((mu, "mu", r64[0]), (lv, "logvar", r64[1]), (bp, "boxes_pred", r64[2]), (ap, "angles_pred", r64[3])):
+            cmp(got, key, r.detach().numpy(), g[key])
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + report)
+    U = pkg("host.utils")
+    import types
+    total, parts = U.calculate_model_losses(types.SimpleNamespace(use_AE=cfg.use_AE), model, boxes, bp, angles, ap,
+                                            mu=mu, logvar=lv, KL_weight=KL_WEIGHT)
+    if not ill:
+        assert_close(total.item(), g["total_loss"], name + ":total")
+        for k, v in parts.items():
+            assert_close(v, g["loss_" + k], name + ":loss_" + k)
+    model.zero_grad()
+    total.backward()
+    torch.cuda.synchronize()
+    if not ill:
+        gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad:"))
+        bad = []
+        for k in g.files:
+            if k.startswith("grad:"):
+                p = dict(model.named_parameters())[k[5:]]
+                try:
+                    assert_close(p.grad.cpu().numpy(), g[k], name + ":" + k, atol=5e-6 * gscale)
+                except AssertionError as e:
+                    bad.append(str(e))
+        assert not bad, "\n".join(bad[:40]) + "\n" + report
+        for k in g.files:
+            if k.startswith("buf:"):
+                assert_close(model.state_dict()[k[4:]].cpu().numpy(), g[k], name + ":" + k)
+
+
+@pytest.mark.parametrize("name", [n for n in HIP_CASES if n != "vae_c1_full"])
+def test_golden_fused_train_step(name):
+    """sln_vae_train_step (zero_grad + fwd + loss + bwd + Adam in one call) against the reference's
+    losses, BatchNorm buffers and Adam-updated parameters."""
+    g = load_golden(name)
+    cfg = vae_ref.VaeConfig(**VAE_CASES[name][0])
+    model = _model(cfg, vae_ref.init_state(cfg, seed=42))
+    ins = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in:")}
+    objs, triples, boxes, angles, attrs, eps = _dev(ins["objs"], ins["triples"], ins["boxes"], ins["angles"], ins["attrs"], ins["eps"])
+    model.train()
+    for use_graph in (False,):
+        losses = model.train_step(objs, triples, boxes, angles, attrs, kl_weight=KL_WEIGHT, lr=1e-4, eps=eps,
+                                  use_graph=use_graph).cpu().numpy()
+    assert_close(losses[3], g["total_loss"], name + ":total")
+    assert_close(losses[0], g["loss_bbox_pred"], name + ":bbox")
+    assert_close(losses[1], g["loss_angle_pred"], name + ":angle")
+    if not cfg.use_AE:
+        assert_close(losses[2], g["loss_KLD_Gauss"], name + ":kld")
+    sd = model.state_dict()
+    for k in g.files:
+        if k.startswith("buf:"):
+            assert_close(sd[k[4:]].cpu().numpy(), g[k], name + ":" + k)
+        elif k.startswith("adam:") and ("grad:" + k[5:]) in g.files:
+            assert_adam_close(sd[k[5:]].cpu().numpy(), g[k], g["grad:" + k[5:]], name + ":" + k)
+
+
+def test_graph_replay_matches_eager():
+    """hipGraph replay of the training iteration == eager launches (same inputs, same state)."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    b = vae_ref.synth_batch(8, 12, 20, seed=3, cfg=cfg)
+    eps = torch.randn(b[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0))
+    outs = []
+    for use_graph in (False, True):
+        model = _model(cfg, vae_ref.init_state(cfg, seed=1)).train()
+        dev = _dev(*b[:5], eps)
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            for _ in range(3):
+                losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-3, eps=dev[5], use_graph=use_graph)
+        torch.cuda.synchronize()
+        outs.append((losses.cpu().numpy(), model.flat_params.cpu().numpy().copy()))
+    assert_close(outs[1][0], outs[0][0], "losses graph vs eager", rtol=1e-5)
+    assert_close(outs[1][1], outs[0][1], "params graph vs eager", rtol=1e-5, atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- BASELINE config c2
+def test_c2_full_size_train_step_vs_oracle():
+    """Batch=64 x (32 objects, 64 triples) at train.py defaults: O=2048, T=4096 (BASELINE.json configs[1])."""
+    cfg = vae_ref.VaeConfig()
+    sd = vae_ref.init_state(cfg, seed=42)
+    batch = vae_ref.synth_batch(64, 32, 64, seed=0, cfg=cfg)
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    model = _model(cfg, sd).train()
+    dev = _dev(*batch[:5], eps)
+    mu, lv, bp, ap = model(*dev[:5], None, eps=dev[5])
+    sdr = {k: v.clone() for k, v in sd.items()}
+    (rmu, rlv, rbp, rap), trace = _trace_oracle(sdr, cfg, batch[:5], eps, True)
+    report = _tap_report(model, cfg, trace)
+    try:
+        for got, ref, nm in ((mu, rmu, "mu"), (lv, rlv, "logvar"), (bp, rbp, "boxes_pred"), (ap, rap, "angles_pred")):
+            assert_close(got.detach().cpu().numpy(), ref.detach().numpy(), "c2:" + nm)
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + report)
+    # gradients of one full step against CPU autograd
+    sdg = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(sdg[k]) for k in vae_ref.trainable_keys(cfg)}
+    v = {k: torch.zeros_like(sdg[k]) for k in vae_ref.trainable_keys(cfg)}
+    total, parts, grads = vae_ref.train_step(sdg, cfg, batch[:5], eps, 0.1, m, v, step=1)
+    model2 = _model(cfg, sd).train()
+    losses = model2.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=False).cpu().numpy()
+    assert_close(losses[3], total.numpy(), "c2:total")
+    gscale = max(float(gr.abs().max()) for gr in grads.values())
+    named = dict(model2.named_parameters())
+    bad = []
+    for k, gr in grads.items():
+        try:
+            assert_close(named[k].grad.cpu().numpy(), gr.numpy(), "c2:grad:" + k, atol=5e-6 * gscale)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad[:40])
+    for k in sdg:
+        if "running" in k:
+            assert_close(model2.state_dict()[k].cpu().numpy(), sdg[k].numpy(), "c2:" + k)
