@@ -50,8 +50,6 @@ class SlnVaeBatch(C.Structure):
                 ("angles", C.c_void_p), ("attributes", C.c_void_p), ("O", C.c_int), ("T", C.c_int)]
 
 
-HOST_HOOK = C.CFUNCTYPE(None, C.c_void_p)
-
 # name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
@@ -75,8 +73,9 @@ SIGNATURES = {
     "sln_vae_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "sln_vae_adam_reset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
-    "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_void_p,
-                                     C.c_void_p, C.c_void_p]),
+    "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    "sln_prof_enable": (C.c_int, [C.c_int]),
+    "sln_prof_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sln_vae_tap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_linear_forward": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p]),
@@ -86,6 +85,24 @@ SIGNATURES = {
 _lib = None
 
 
+def _load_hip_runtime():
+    """libsln_hip.so is linked without a HIP runtime (build.py: -no-hip-rt) so that it binds to
+    the one already in the process.  Under PyTorch-ROCm that is torch/lib/libamdhip64.so: promote
+    it to the global symbol scope.  Without torch fall back to the system ROCm runtime."""
+    cands = []
+    try:
+        import torch
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:          # pragma: no cover - torch is always present in this image
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so"]
+    for c in cands:
+        if os.path.exists(c):
+            C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return c
+    raise SlnError("no HIP runtime (libamdhip64.so) found")
+
+
 def lib():
     """Load the shared library (once).  Raises SlnError when it is not built."""
     global _lib
@@ -93,6 +110,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SlnError("libsln_hip.so is not built (%s); run `python __graft_entry__.py` or "
                            "`python 3d_sln_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+        _load_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError -> missing export: fail loudly

@@ -59,7 +59,11 @@ def build(force=False, verbose=True):
         res = list(ex.map(_compile, names))
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or not os.path.exists(OUT):
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT],
+        # -no-hip-rt: do NOT link /opt/rocm's libamdhip64.so.7.  The process already holds the HIP
+        # runtime PyTorch ships (SONAME libamdhip64.so); a second runtime in the same process cannot
+        # share streams/devices with it.  _lib.py puts torch's runtime into the global symbol scope
+        # before loading this library, which then binds to it.
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt"] + objs + ["-o", OUT],
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n" + r.stderr[-4000:])

@@ -14,6 +14,7 @@
 // through registers (transform on the way), double-buffered so one barrier per K tile.
 #include "sln_common.h"
 #include "sln_gemm.h"
+#include "sln_prof.h"
 
 namespace {
 
@@ -470,6 +471,7 @@ int sln_gemm_init() {
 }
 
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
+  SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
   bool x2 = false;
   for (int s = 0; s < a.A.nseg; ++s) x2 |= a.A.seg[s].x2 != nullptr;
   if (tile < 0) {   // heuristic: enough blocks to cover 256 CUs, otherwise the biggest tile
@@ -488,6 +490,7 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
 }
 
 int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
+  SlnProfScope prof(SLN_FAM_GEMM_TN, 2.0 * a0.R * a0.Nout * a0.Kin, st);
   GemmTNArgs a = a0;
   bool x2 = false;
   for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;

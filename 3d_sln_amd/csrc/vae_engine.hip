@@ -96,7 +96,7 @@ struct SlnVae {
   float host_kl = 0.f, host_lr = 0.f; int64_t host_step = 0; bool host_scalars_valid = false;
 
   // hipGraph of one training iteration
-  hipGraphExec_t graph_exec = nullptr; int graph_O = -1, graph_T = -1;
+  hipGraphExec_t graph_exec = nullptr; int graph_O = -1, graph_T = -1; bool graph_adam = true;
 
   // ------------------------------------------------------------------------------------------
   int unit_of(int net, int l, int k) const { return 8 + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
@@ -212,7 +212,7 @@ struct SlnVae {
   int encoder_backward(hipStream_t st);
   int loss(const float* bp, const float* ap, const float* mu_, const float* lv_, bool with_grads, hipStream_t st);
   int run_bn_updates(int first, int count, hipStream_t st);
-  int train_iteration(const float* eps, SlnHostHook hook, void* user, hipStream_t st);
+  int train_iteration(const float* eps, bool with_adam, hipStream_t st);
 };
 
 #define RET_IF(x) do { int r__ = (x); if (r__ != 0) return r__; } while (0)
@@ -521,7 +521,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
   return 0;
 }
 
-int SlnVae::train_iteration(const float* eps, SlnHostHook hook, void* user, hipStream_t st) {
+int SlnVae::train_iteration(const float* eps, bool with_adam, hipStream_t st) {
   HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
   RET_IF(encoder_forward(true, st));
   RET_IF(decoder_forward(nullptr, eps, true, st));
@@ -529,9 +529,10 @@ int SlnVae::train_iteration(const float* eps, SlnHostHook hook, void* user, hipS
   RET_IF(decoder_backward(st));
   RET_IF(sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st));
   RET_IF(encoder_backward(st));
-  if (hook) hook(user);
-  RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
-  wt_fresh = false;                    // transposed copies are rebuilt at the start of the next backward
+  if (with_adam) {
+    RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
+    wt_fresh = false;                  // transposed copies are rebuilt at the start of the next backward
+  }
   return 0;
 }
 
@@ -617,7 +618,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
 
 void sln_vae_destroy(SlnVae* h) {
   if (!h) return;
-  if (h->graph_exec) hipGraphExecDestroy(h->graph_exec);
+  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
   delete h;
 }
 
@@ -659,7 +660,7 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
   RET_IF(sln_gemm_init());
   h->host_scalars_valid = false;
   h->bound = true; h->batch_set = false; h->wt_fresh = false; h->have_enc = h->have_dec = false;
-  if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   return 0;
 }
 
@@ -696,7 +697,7 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
     hipError_t e = hipStreamSynchronize(st);       // table upload below is a blocking copy
     if (e != hipSuccess) return (int)e;
     RET_IF(upload_bn_table(h));
-    if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   }
   RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->g, h->err_flag, st));
   RET_IF(sln_launch_i64_to_i32(b->attributes, h->attrs32, b->O, st));
@@ -830,32 +831,32 @@ int sln_vae_params_changed(SlnVae* h) {       // parameters were modified outsid
 }
 
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
-                       SlnHostHook hook, void* user, void* stream) {
+                       int with_adam, void* stream) {
   if (!h || !h->batch_set || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
   if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   RET_IF(set_kl(h, kl_weight, lr, st));
   if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
-  if (use_graph && !hook && st != nullptr) {
-    if (!h->graph_exec || h->graph_O != h->O || h->graph_T != h->T) {
-      if (h->graph_exec) { hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  if (use_graph && st != nullptr) {
+    if (!h->graph_exec || h->graph_O != h->O || h->graph_T != h->T || h->graph_adam != (with_adam != 0)) {
+      if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
       HIP_RET(hipStreamSynchronize(st));
       h->wt_fresh = false;         // the captured iteration always rebuilds the transposed weights itself
       hipGraph_t graph = nullptr;
       HIP_RET(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      const int r = h->train_iteration(h->eps_buf, nullptr, nullptr, st);
+      const int r = h->train_iteration(h->eps_buf, with_adam != 0, st);
       hipError_t e = hipStreamEndCapture(st, &graph);
-      if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+      if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
       if (e != hipSuccess) return (int)e;
       e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       if (e != hipSuccess) { h->graph_exec = nullptr; return (int)e; }
-      h->graph_O = h->O; h->graph_T = h->T;
+      h->graph_O = h->O; h->graph_T = h->T; h->graph_adam = with_adam != 0;
     }
     HIP_RET(hipGraphLaunch(h->graph_exec, st));
     h->enc_training = h->dec_training = true; h->have_enc = h->have_dec = true; h->z_from_latent = true; h->wt_fresh = false;
   } else {
-    RET_IF(h->train_iteration(h->eps_buf, hook, user, st));
+    RET_IF(h->train_iteration(h->eps_buf, with_adam != 0, st));
   }
   RET_IF(copy_out(losses_out, h->losses, 4, st));
   return 0;

@@ -4,6 +4,7 @@
 // These are HBM/L2-bound streaming kernels: coalesced 64-column row segments per wave, per-column
 // statistics reduced in registers -> LDS -> one fp64 atomic per column per block.
 #include "vae_kernels.h"
+#include "sln_prof.h"
 
 namespace {
 
@@ -483,6 +484,8 @@ int sln_launch_graph_prep(const int64_t* triples, int T, int O, GraphCsr g, int*
 int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2, GraphCsr g, int O, float* pooled,
                                hipStream_t st) {
   if (O <= 0) return 0;
+  // algorithmic bytes: both halves of A2 once, pooled once, the entry list
+  SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * H + 4.0 * O * H + 16.0 * g.T, st);
   hipLaunchKernelGGL(scatter_avg_fwd_kernel, colgrid(H, O), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -492,6 +495,7 @@ int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int d
                                int D, BnView bn2, GraphCsr g, int T, float* g2, double* gsums, int cstride,
                                hipStream_t st) {
   if (T <= 0) return 0;
+  SlnProfScope prof(SLN_FAM_EDGE, 4.0 * T * (2 * H) + (dP ? 4.0 * T * D : 0.0) + 2.0 * 4.0 * T * (2 * H + D) + 8.0 * T, st);
   hipLaunchKernelGGL(scatter_avg_bwd_kernel, colgrid(2 * H + D, T), dim3(CB, RL), 0, st, dM, dP, lddp, dpcol0, A2, ld, H,
                      D, bn2, g, T, g2, gsums, cstride);
   SLN_CHECK_LAUNCH();
@@ -502,6 +506,7 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
                           const float* xprev, int ldx, BnView bn, int masked, float* out, int ldo, double* gsums,
                           int cstride, hipStream_t st) {
   if (O <= 0) return 0;
+  SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * D + (masked ? 2.0 : 1.0) * 4.0 * O * D + 16.0 * g.T, st);
   hipLaunchKernelGGL(gather_bwd_kernel, colgrid(D, O), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
                      ldx, bn, masked, out, ldo, gsums, cstride);
   SLN_CHECK_LAUNCH();
@@ -511,6 +516,7 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
 int sln_launch_mask_gstats(const float* d1, int ld1, const float* d2, int ld2, const float* xprev, int ldx, BnView bn,
                            int rows, int cols, float* out, int ldo, double* gsums, int cstride, hipStream_t st) {
   if (rows <= 0) return 0;
+  SlnProfScope prof(SLN_FAM_OTHER, 4.0 * rows * cols * (d2 ? 4.0 : 3.0), st);
   hipLaunchKernelGGL(mask_gstats_kernel, colgrid(cols, rows), dim3(CB, RL), 0, st, d1, ld1, d2, ld2, xprev, ldx, bn, rows,
                      cols, out, ldo, gsums, cstride);
   SLN_CHECK_LAUNCH();
@@ -641,6 +647,7 @@ int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles
 }
 
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, hipStream_t st) {
+  SlnProfScope prof(SLN_FAM_OTHER, 28.0 * n, st);
   hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, scalars);
   if (n > 0) {
     long blocks = (n + 255) / 256;

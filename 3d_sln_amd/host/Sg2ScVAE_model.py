@@ -383,24 +383,28 @@ class Sg2ScVAEModel(nn.Module):
 
     # ------------------------------------------------------------------ fused training iteration
     def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None,
-                   use_graph=True, hook=None):
+                   use_graph=True, with_adam=True):
         """train.py:62-84 in one call: zero_grad, forward (train-mode BN), losses, backward, Adam.
 
         Returns a 4-element device tensor [bbox_pred, angle_pred, KLD_Gauss*w, total_loss] (no host sync).
-        ``hook``: optional Python callable run after backward / before Adam (the data-parallel
-        all-reduce of ``flat_grads``); disables hipGraph replay.
+        ``with_adam=False`` stops after backward (gradients in ``flat_grads``): the data-parallel
+        trainer all-reduces them and then calls ``adam_step``.  hipGraph replay needs a non-default
+        current stream.
         """
         self._set_batch(objs, triples, boxes, angles, attributes)
         if eps is None and not self.use_AE:
             eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
         losses = self._new(4)
-        cb = _lib.HOST_HOOK(lambda _u: hook()) if hook is not None else None
         self._generation += 1
         _lib.check(_lib.lib().sln_vae_train_step(
-            self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph),
-            C.cast(cb, C.c_void_p) if cb is not None else None, None, _lib.current_stream_ptr()), "sln_vae_train_step")
+            self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph), int(with_adam),
+            _lib.current_stream_ptr()), "sln_vae_train_step")
         self._alias_grads()
         return losses
+
+    def adam_step(self, lr=1e-4):
+        """torch.optim.Adam(lr).step() over the flat parameter buffer (fused kernel)."""
+        _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")
 
     def loss(self, kl_weight=0.1, with_grads=False):
         """calculate_model_losses (utils.py:12-33) on the outputs of the last forward, on device."""

@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py - headline benchmark of the 3D_SLN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]; per GPU, weak scaling = configs[4] at N=8):
+  one "step" = one full training iteration of the scene-graph VAE (train.py:62-84: zero_grad,
+  forward with train-mode BatchNorm, the three losses, backward, Adam) on a synthetic batch of
+  64 scene graphs x (32 objects, 64 triples) => O=2048 object rows, T=4096 triples, at train.py's
+  default widths (embedding_dim=64: GraphTripleConv 128/256/128, 5+5 layers).  Inputs are resident
+  in HBM before the timed region.  For N>1 every rank trains its own 64 graphs and the flat
+  15.5 MB fp32 gradient buffer is all-reduced (RCCL) between backward and Adam.
+
+Prints ONE JSON line (rank 0).  `value` = graphs/s over all GPUs.  `roofline` describes the
+dominant kernel family (fused fp32-MFMA GEMMs), timed live with HIP events on the launch stream in
+a separate eager pass of the same step; `cpu_baseline` is the CPU oracle (a PyTorch-CPU port proven
+equal to the reference on the golden fixtures) timed on this box's host cores on the same batch.
+"""
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "rsv"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--graphs", type=int, default=64, help="scene graphs per GPU per step")
+    ap.add_argument("--objs", type=int, default=32)
+    ap.add_argument("--triples", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--prof-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def prof_read(lib):
+    n = len(FAMILIES)
+    ms = (C.c_double * n)(); work = (C.c_double * n)(); cnt = (C.c_int64 * n)()
+    lib.check(lib.lib().sln_prof_read(ms, work, cnt, n), "sln_prof_read")
+    return {FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n) if cnt[i]}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    lib = importlib.import_module("3d_sln_amd._lib")
+    lib.check(lib.lib().sln_device_ok(), "sln_device_ok")
+    M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+
+    torch.manual_seed(42)
+    kwargs = dict(vocab=syn.default_vocab(), batch_size=args.graphs, train_3d=True, decoder_cat=True, embedding_dim=64,
+                  gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
+                  layout_noise_dim=32, use_AE=False)      # build_dataset_model.py:40-52 at options.py defaults
+    model = M.Sg2ScVAEModel(**kwargs).cuda().train()
+    if world > 1:
+        dist.broadcast(model.flat_params, 0)
+        model.params_changed()
+    b = syn.scene_graph_batch(args.graphs, args.objs, args.triples, seed=1000 + rank, device="cuda")
+    batch = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
+    O = b["objs"].shape[0]
+    eps = torch.randn(O, 64, device="cuda")
+    stream = torch.cuda.Stream()
+    use_graph = not args.no_graph
+    inv_world = 1.0 / world
+
+    def step():
+        if world == 1:
+            return model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=True)
+        losses = model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=False)
+        dist.all_reduce(model.flat_grads)                 # ONE collective per step: 15.5 MB fp32 over xGMI
+        model.flat_grads.mul_(inv_world)
+        model.adam_step(lr=1e-4)
+        return losses
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            losses = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            losses = step()
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    final_loss = float(losses[3].item())
+    ms_per_step = dt / args.steps * 1e3
+    value = args.graphs * world * args.steps / dt
+
+    out = {
+        "metric": "scene-graph VAE steps/sec + 256² diff-render fps, 1/2/4/8 MI355X",
+        "value": round(value, 1), "unit": "graphs/s (scene-graph VAE fwd+loss+bwd+Adam)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "steps_per_s": round(args.steps / dt, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: batch=%d scene graphs x (%d objects, %d triples) per GPU, "
+                               "Sg2ScVAE train step at train.py defaults (embedding_dim=64, 5+5 GraphTripleConv, BatchNorm)"
+                               % (args.graphs, args.objs, args.triples),
+                   "O": int(O), "T": int(b["triples"].shape[0]), "hipgraph": bool(use_graph),
+                   "parallelism": "dp%d" % world, "final_total_loss": round(final_loss, 5)},
+    }
+
+    if rank == 0:
+        # ---- per-kernel-family timing, eager launches + HIP events on the launch stream -----------
+        with torch.cuda.stream(stream):
+            lib.check(lib.lib().sln_prof_enable(1), "prof")
+            for _ in range(args.prof_steps):
+                model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=False, with_adam=True)
+            torch.cuda.synchronize()
+            fam = prof_read(lib)
+            lib.check(lib.lib().sln_prof_enable(0), "prof")
+        kern = {}
+        for k, v in fam.items():
+            per = v["ms"] / max(v["launches"], 1)
+            rate = v["work"] / (v["ms"] * 1e-3) if v["ms"] > 0 else 0.0
+            kern[k] = {"launches_per_step": v["launches"] // args.prof_steps, "ms_per_step": round(v["ms"] / args.prof_steps, 4),
+                       "avg_us": round(per * 1e3, 2),
+                       ("tflops" if k.startswith("gemm") else "gbs"): round(rate / (1e12 if k.startswith("gemm") else 1e9), 2)}
+        out["kernels"] = kern
+        dom = max((k for k in fam if k.startswith("gemm")), key=lambda k: fam[k]["ms"])
+        ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
+                           "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2)}
+        if "edge" in fam:
+            e = fam["edge"]
+            gbs = e["work"] / (e["ms"] * 1e-3) / 1e9
+            out["roofline_edge"] = {"kernel": "edge scatter/gather", "bound": "hbm", "achieved": round(gbs, 1),
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
+
+        # ---- CPU baseline: the oracle (PyTorch-CPU port of the reference path) on the same batch ----
+        if not args.no_cpu:
+            from oracle import vae_ref
+            cfg = vae_ref.VaeConfig()
+            sd = vae_ref.init_state(cfg, seed=42)
+            cb = tuple(t.cpu() for t in batch)
+            ceps = eps.cpu()
+            keys = vae_ref.trainable_keys(cfg)
+            m = {k: torch.zeros_like(sd[k]) for k in keys}; v = {k: torch.zeros_like(sd[k]) for k in keys}
+            ncores = torch.get_num_threads()
+            for i in range(2):
+                vae_ref.train_step(sd, cfg, cb, ceps, 0.1, m, v, step=i + 1)
+            t0 = time.perf_counter()
+            for i in range(args.cpu_steps):
+                vae_ref.train_step(sd, cfg, cb, ceps, 0.1, m, v, step=i + 3)
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": round(args.graphs * args.cpu_steps / cdt, 1), "unit": "graphs/s", "cores": ncores,
+                                   "kind": "port", "sample": "%d train steps of the same batch (%d graphs), oracle/vae_ref.py, "
+                                   "torch CPU fp32, %.1f ms/step" % (args.cpu_steps, args.graphs, cdt / args.cpu_steps * 1e3)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

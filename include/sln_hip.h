@@ -142,14 +142,19 @@ int sln_vae_zero_grad(SlnVae* h, void* stream);                       /* optimiz
 int sln_vae_adam_step(SlnVae* h, float lr, void* stream);
 int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream);       /* restore the step counter (checkpoint resume) */
 
-/* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward,
- * [hook], Adam.  `use_graph`: replay a captured hipGraph when shapes are unchanged.
- * `between_bwd_and_step` (may be NULL) is called on the host after the backward kernels are
- * enqueued and before Adam - the data-parallel trainer enqueues its RCCL all-reduce there
- * (disables graph replay). */
-typedef void (*SlnHostHook)(void* user);
+/* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward and
+ * (with_adam != 0) the Adam update.  `use_graph`: replay a captured hipGraph while shapes are unchanged
+ * (needs a non-default stream).  The data-parallel trainer calls it with with_adam = 0, enqueues its
+ * RCCL all-reduce of flat_grads on the same stream, then calls sln_vae_adam_step. */
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
-                       SlnHostHook between_bwd_and_step, void* hook_user, void* stream);
+                       int with_adam, void* stream);
+
+/* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline figures).
+ * Families: 0 gemm_nt (forward/dgrad), 1 gemm_tn (wgrad), 2 edge scatter/gather, 3 other.
+ * enable=1 starts recording (eager launches only, not under graph capture); sln_prof_read
+ * synchronises, sums and clears the recorded intervals. work = FLOPs for GEMM families, bytes else. */
+int sln_prof_enable(int enable);
+int sln_prof_read(double* ms_by_family, double* work_by_family, int64_t* launches_by_family, int n_families);
 
 /* Debug/test tap: copy an internal activation to `dst` (device).  what: 0 A1,1 A2,2 M,3 A3,4 A4 of
  * gconv instance `layer` (0..L-1 encoder, L..2L-1 decoder).  Returns the element count or <0. */

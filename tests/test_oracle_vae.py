@@ -55,7 +55,7 @@ def test_oracle_matches_reference_fixture(name):
             _close(sd[k[4:]].numpy(), g[k], name + ":" + k)
         elif k.startswith("adam:"):
             if "grad:" + k[5:] in g.files:
-                assert_adam_close(sd[k[5:]].numpy(), g[k], g["grad:" + k[5:]], name + ":" + k)
+                assert_adam_close(sd[k[5:]].numpy(), g[k], g["grad:" + k[5:]], name + ":" + k, gscale=gscale)
     assert n_checked > 10
 
 
