@@ -16,9 +16,12 @@
 #include "sln_gemm.h"
 #include "sln_prof.h"
 
+#include <cstdlib>
+#include <type_traits>
 namespace {
 
 constexpr int BK = 32;
+inline int env_int(const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -63,15 +66,16 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int SA = BM + 1, SB = BN + 1;
+  constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
   constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
   static_assert(WM * WN == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);
-  float* As = reinterpret_cast<float*>(coef + kpad);
-  float* Bs = As + 2 * BK * SA;
-  float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BK * SB);
+  float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
+  float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
+  float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (a.N + BN - 1) / BN;
@@ -80,8 +84,81 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
+  const int kq = tid & 7, r0 = tid >> 3;
+  int ra_idx[PA], rb_idx[PA];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = min(m0 + r0 + 32 * p, a.M - 1);      // clamped: loads are unconditional, masking happens at the LDS store
+    ra_idx[p] = a.A.idx_a ? a.A.idx_a[row] : row;
+    rb_idx[p] = a.A.idx_b ? a.A.idx_b[row] : row;
+  }
+
+  float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
+  const int ntiles = kpad / BK;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // NOTE: every global load below is unconditional (addresses clamped into the operand); a
+  // `valid ? load : 0` select makes hipcc branch around each load and drain vmcnt(0) per element,
+  // which serialises the whole register pipeline.  Out-of-range lanes are zeroed in lstore().
+  auto gload = [&](int kt, auto stage) {
+    constexpr int S = decltype(stage)::value;
+    const int k0 = kt * BK;
+    const SegSel sg = pick_seg(a.A, k0);
+    const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int row = min(m0 + r0 + 32 * p, a.M - 1);
+      const int r = sg.which == 0 ? row : (sg.which == 1 ? ra_idx[p] : rb_idx[p]);
+      ga1[S][p] = ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + cs);
+      if (HAS_X2) {
+        const float* x2 = sg.x2 ? sg.x2 : sg.x1;                 // block-uniform select
+        const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
+        ga2[S][p] = ld4(x2 + (size_t)r * ld2 + c2 + cs);
+      }
+    }
+    const int cw = min(k0 + 4 * kq, a.K - 4);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const int n = min(n0 + r0 + 32 * p, a.N - 1);
+      gb[S][p] = ld4(a.W + (size_t)n * a.ldw + cw);
+    }
+  };
+  auto lstore = [&](int kt, int buf, auto stage) {
+    constexpr int S = decltype(stage)::value;
+    const int k0 = kt * BK, col = k0 + 4 * kq;
+    const SegSel sg = pick_seg(a.A, k0);
+    const bool cv = col < sg.end;
+    const bool x2v = HAS_X2 && sg.x2 != nullptr;
+    float* as = As + buf * BM * LDT + 4 * kq;
+    float* bs = Bs + buf * BN * LDT + 4 * kq;
+    const float4* cf = coef + min(col, kpad - 4);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+      const int rl = r0 + 32 * p;
+      const bool v = cv && (m0 + rl) < a.M;
+      float4 t = xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+      *reinterpret_cast<float4*>(as + rl * LDT) = t;
+    }
+    const bool kv = col < a.K;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+      const bool v = kv && (n0 + r0 + 32 * p) < a.N;
+      float4 t = gb[S][p];
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+      *reinterpret_cast<float4*>(bs + (r0 + 32 * p) * LDT) = t;
+    }
+  };
+
+  // issue the first tiles' loads before the (dependent, sqrt-heavy) coefficient set-up
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+  const int last = ntiles - 1;
+  gload(0, S0{});
+  gload(min(1, last), S1{});
+  gload(min(2, last), S2{});
+
   sln_fill_coefs(a.A, coef, tid, 256);
-  for (int c = a.K + tid; c < kpad; c += 256) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
   if (EPI == EPI_MASK) {
     for (int c = tid; c < BN; c += 256) {
       float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
@@ -93,60 +170,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     }
   }
 
-  const int kq = tid & 7, r0 = tid >> 3;
-  int ra_idx[PA], rb_idx[PA];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int row = m0 + r0 + 32 * p;
-    const bool v = row < a.M;
-    ra_idx[p] = (v && a.A.idx_a) ? a.A.idx_a[row] : row;
-    rb_idx[p] = (v && a.A.idx_b) ? a.A.idx_b[row] : row;
-  }
-
-  float4 ga1[PA], ga2[PA], gb[PB];
-  const int ntiles = kpad / BK;
-
-  auto gload = [&](int kt) {
-    const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg(a.A, k0);
-    const bool cv = col < sg.end;   // segments start at multiples of BK, so col >= sg.base
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int row = m0 + r0 + 32 * p;
-      const bool v = cv && row < a.M;
-      const int r = sg.which == 0 ? row : (sg.which == 1 ? ra_idx[p] : rb_idx[p]);
-      ga1[p] = v ? ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + (col - sg.base)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (HAS_X2)
-        ga2[p] = (v && sg.x2) ? ld4(sg.x2 + (size_t)r * sg.ld2 + sg.c2 + (col - sg.base)) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int n = n0 + r0 + 32 * p;
-      gb[p] = (n < a.N && col < a.K) ? ld4(a.W + (size_t)n * a.ldw + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto lstore = [&](int kt, int buf) {
-    const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg(a.A, k0);
-    const bool cv = col < sg.end;
-    float* as = As + buf * BK * SA + (4 * kq) * SA;
-    float* bs = Bs + buf * BK * SB + (4 * kq) * SB;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int rl = r0 + 32 * p;
-      const bool v = cv && (m0 + rl) < a.M;
-      float4 t = z;
-      if (v) t = xform(ga1[p], HAS_X2 ? ga2[p] : z, coef + col);
-      as[0 * SA + rl] = t.x; as[1 * SA + rl] = t.y; as[2 * SA + rl] = t.z; as[3 * SA + rl] = t.w;
-    }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int rl = r0 + 32 * p;
-      bs[0 * SB + rl] = gb[p].x; bs[1 * SB + rl] = gb[p].y; bs[2 * SB + rl] = gb[p].z; bs[3 * SB + rl] = gb[p].w;
-    }
-  };
-
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -156,30 +179,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();            // coef tables visible
-  gload(0);
-  lstore(0, 0);
+  lstore(0, 0, S0{});
+  gload(min(3, last), S0{});
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
-  for (int kt = 0; kt < ntiles; ++kt) {
+
+  // tile j lives in register stage j % 3; body(kt) computes tile kt from LDS, stores tile kt+1 from its stage
+  // and refills that stage with tile kt+4.  Every body issues the SAME loads unconditionally (tile
+  // indices clamped; the surplus tiles are never consumed) so that hipcc's s_waitcnt accounting is exact
+  // and the wait in lstore() leaves the two younger stages in flight (vmcnt(8), not vmcnt(0)).
+  auto body = [&](int kt, auto stage_next) {
     const int buf = kt & 1;
-    if (kt + 1 < ntiles) gload(kt + 1);
-    const float* as = As + buf * BK * SA + wm0 + lrow;
-    const float* bs = Bs + buf * BK * SB + wn0 + lrow;
+    const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk;
+    const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TM], bv[TN];
+    for (int kb = 0; kb < BK; kb += 8) {
+      float4 av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lk) * SA + 32 * i];
+      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(as + 32 * i * LDT + kb);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lk) * SB + 32 * j];
+      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(bs + 32 * j * LDT + kb);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
+        }
     }
-    if (kt + 1 < ntiles) lstore(kt + 1, buf ^ 1);
+    lstore(min(kt + 1, last), buf ^ 1, stage_next);
+    gload(min(kt + 4, last), stage_next);
     __syncthreads();
-  }
+  };
+  int kt = 0;
+  for (; kt + 3 <= ntiles; kt += 3) { body(kt, S1{}); body(kt + 1, S2{}); body(kt + 2, S0{}); }
+  if (ntiles - kt == 1) { body(kt, S1{}); }
+  else if (ntiles - kt == 2) { body(kt, S1{}); body(kt + 1, S2{}); }
 
   // ------------------------------- epilogue -------------------------------
   float* red = As;   // [WM][BN][2] (tiles no longer needed: last loop iteration ended on a barrier)
@@ -239,7 +276,7 @@ namespace {
 template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int kpad = (a.K + 31) & ~31;
-  const size_t smem = (size_t)kpad * 16 + (size_t)2 * BK * (BM + 1 + BN + 1) * 4 + (size_t)BN * 16;
+  const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16;
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
@@ -267,11 +304,12 @@ struct ColSel { const float* x1; const float* x2; int ld1, ld2, which; bool vali
 __device__ __forceinline__ ColSel pick_col(const Operand& op, int col) {
   // per-thread (non-uniform) choice of the segment holding logical column `col`
   ColSel r;
+  r.valid = col < op.cols;
+  col = r.valid ? col : 0;                  // keep the address inside the operand; invalid lanes are masked later
   const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
   const int s = (op.nseg > 1 && col >= e0) ? ((op.nseg > 2 && col >= e1) ? 2 : 1) : 0;
   const int base = s == 0 ? 0 : (s == 1 ? e0 : e1);
   const int c = col - base;
-  r.valid = col < op.cols;
   const Seg& g0 = op.seg[0]; const Seg& g1 = op.seg[1]; const Seg& g2 = op.seg[2];
   r.x1 = (s == 0 ? g0.x1 + g0.c1 : (s == 1 ? g1.x1 + g1.c1 : g2.x1 + g2.c1)) + c;
   const float* b2 = s == 0 ? g0.x2 : (s == 1 ? g1.x2 : g2.x2);
@@ -322,44 +360,51 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
   const ColSel gs = pick_col(a.G, n0 + ca);
   const ColSel xs = pick_col(a.X, k0 + cb);
 
-  float4 g1[PA], g2[PA], x1[PB];
+  constexpr int NST = 3;
+  float4 g1[NST][PA], g2[NST][PA], x1[NST][PB];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto gload = [&](int rt) {
+  // unconditional, clamped loads (see the note in gemm_nt_kernel); masking happens in lstore()
+  const bool g_gather = a.G.idx_a != nullptr, x_gather = a.X.idx_a != nullptr;
+  const int* g_ip = gs.which == 2 ? a.G.idx_b : a.G.idx_a;
+  const int* x_ip = xs.which == 2 ? a.X.idx_b : a.X.idx_a;
+  const float* g_x2 = gs.x2 ? gs.x2 : gs.x1;
+  const int g_ld2 = gs.x2 ? gs.ld2 : gs.ld1;
+  auto gload = [&](int rt, auto stage) {
+    constexpr int S = decltype(stage)::value;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int row = rbeg + rt * BK + ra0 + RPA * p;
-      const bool v = gs.valid && row < rend;
+      const int row = min(rbeg + rt * BK + ra0 + RPA * p, rend - 1);
       int r = row;
-      if (v && gs.which) r = (gs.which == 1 ? a.G.idx_a : a.G.idx_b)[row];
-      g1[p] = v ? ld4(gs.x1 + (size_t)r * gs.ld1) : z4;
-      if (G_X2) g2[p] = (v && gs.x2) ? ld4(gs.x2 + (size_t)r * gs.ld2) : z4;
+      if (g_gather) { const int gi = g_ip[row]; r = gs.which ? gi : row; }
+      g1[S][p] = ld4(gs.x1 + (size_t)r * gs.ld1);
+      if (G_X2) g2[S][p] = ld4(g_x2 + (size_t)r * g_ld2);
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const int row = rbeg + rt * BK + rb0 + RPB * p;
-      const bool v = xs.valid && row < rend;
+      const int row = min(rbeg + rt * BK + rb0 + RPB * p, rend - 1);
       int r = row;
-      if (v && xs.which) r = (xs.which == 1 ? a.X.idx_a : a.X.idx_b)[row];
-      x1[p] = v ? ld4(xs.x1 + (size_t)r * xs.ld1) : z4;
+      if (x_gather) { const int gi = x_ip[row]; r = xs.which ? gi : row; }
+      x1[S][p] = ld4(xs.x1 + (size_t)r * xs.ld1);
     }
   };
   float4 dbacc = z4;
-  auto lstore = [&](int rt, int buf) {
+  auto lstore = [&](int rt, int buf, auto stage, bool real) {
+    constexpr int S = decltype(stage)::value;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int rl = ra0 + RPA * p;
       const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = z4;
-      if (v) t = xform(g1[p], G_X2 ? g2[p] : z4, coefG + ca);
-      dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
+      float4 t = xform(g1[S][p], (G_X2 && gs.x2) ? g2[S][p] : z4, coefG + ca);
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+      if (real) { dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w; }   // surplus (clamped) tiles do not count
       *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int rl = rb0 + RPB * p;
       const bool v = xs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = z4;
-      if (v) t = xform(x1[p], z4, coefX + cb);
+      float4 t = xform(x1[S][p], z4, coefX + cb);
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = t;
     }
   };
@@ -373,13 +418,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int ntiles = (rend - rbeg + BK - 1) / BK;
-  __syncthreads();
-  if (ntiles > 0) { gload(0); lstore(0, 0); }
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+  const int last = ntiles - 1;          // ntiles >= 1: every launched block owns at least one row
+  gload(0, S0{});
+  gload(min(1, last), S1{});
+  gload(min(2, last), S2{});
+  __syncthreads();            // coefficient tables visible
+  lstore(0, 0, S0{}, true);
+  gload(min(3, last), S0{});
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
-  for (int rt = 0; rt < ntiles; ++rt) {
+  auto body = [&](int rt, auto stage_next) {
     const int buf = rt & 1;
-    if (rt + 1 < ntiles) gload(rt + 1);
     const float* as = As + buf * BK * SA + wm0 + lrow;
     const float* bs = Bs + buf * BK * SB + wn0 + lrow;
 #pragma unroll
@@ -394,9 +444,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (rt + 1 < ntiles) lstore(rt + 1, buf ^ 1);
+    lstore(min(rt + 1, last), buf ^ 1, stage_next, rt + 1 <= last);
+    gload(min(rt + 4, last), stage_next);
     __syncthreads();
-  }
+  };
+  int rt = 0;
+  for (; rt + 3 <= ntiles; rt += 3) { body(rt, S1{}); body(rt + 1, S2{}); body(rt + 2, S0{}); }
+  if (ntiles - rt == 1) { body(rt, S1{}); }
+  else if (ntiles - rt == 2) { body(rt, S1{}); body(rt + 1, S2{}); }
 
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -406,7 +461,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (n < a.Nout && k < a.Kin) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
+        if (n < a.Nout && k < a.Kin && !a.x_noatomic) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
       }
     }
 
@@ -496,12 +551,15 @@ int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
   for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
   if (a.rows_per_block <= 0) {
     // aim for >= ~512 blocks in total, chunks a multiple of BK rows
+    static const int target = env_int("SLN_X_TN_BLOCKS", 768);
     const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
-    int chunks = sln_cdiv(768, tiles);
+    int chunks = sln_cdiv(target, tiles);
     int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
     a.rows_per_block = rpb < 64 ? 64 : rpb;
   }
   (void)tile;
+  static const int noat = env_int("SLN_X_NOATOMIC", 0);
+  a.x_noatomic = noat;
   if (x2) return launch_tn<64, 64, 2, 2, true>(a, st);
   return launch_tn<64, 64, 2, 2, false>(a, st);
 }

@@ -136,7 +136,9 @@ def main():
                    "parallelism": "dp%d" % world, "final_total_loss": round(final_loss, 5)},
     }
 
-    if rank == 0:
+    if rank == 0 and args.prof_steps <= 0:
+        print(json.dumps(out))
+    elif rank == 0:
         # ---- per-kernel-family timing, eager launches + HIP events on the launch stream -----------
         with torch.cuda.stream(stream):
             lib.check(lib.lib().sln_prof_enable(1), "prof")
