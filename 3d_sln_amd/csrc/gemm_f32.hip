@@ -554,8 +554,9 @@ int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
     static const int target = env_int("SLN_X_TN_BLOCKS", 768);
     const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
     int chunks = sln_cdiv(target, tiles);
+    static const int minrows = env_int("SLN_X_TN_MINROWS", 256);
     int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
-    a.rows_per_block = rpb < 64 ? 64 : rpb;
+    a.rows_per_block = rpb < minrows ? minrows : rpb;
   }
   (void)tile;
   static const int noat = env_int("SLN_X_NOATOMIC", 0);

@@ -6,6 +6,7 @@
 #include <new>
 #include <vector>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/sln_hip.h"
 #include "sln_gemm.h"
@@ -94,6 +95,30 @@ struct SlnVae {
   bool z_from_latent = false;
   bool wt_fresh = false;          // transposed weights valid for the current parameters
   float host_kl = 0.f, host_lr = 0.f; int64_t host_step = 0; bool host_scalars_valid = false;
+
+  // wgrad GEMMs run on a side stream, concurrent with the dgrad chain (both only half-fill the chip at
+  // batch 64); fork after the producer of the wgrad's gradient operand, join before that buffer is reused.
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> events; size_t ev_next = 0; bool use_side = true; bool side_busy = false;
+  hipEvent_t next_event() {
+    if (ev_next == events.size()) { hipEvent_t e = nullptr; (void)hipEventCreateWithFlags(&e, hipEventDisableTiming); events.push_back(e); }
+    return events[ev_next++];
+  }
+  int fork_side(hipStream_t st) {
+    hipEvent_t e = next_event();
+    hipError_t r = hipEventRecord(e, st);
+    if (r == hipSuccess) r = hipStreamWaitEvent(side, e, 0);
+    side_busy = true;
+    return (int)r;
+  }
+  int join_side(hipStream_t st) {
+    if (!side_busy) return 0;
+    hipEvent_t e = next_event();
+    hipError_t r = hipEventRecord(e, side);
+    if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
+    side_busy = false;
+    return (int)r;
+  }
 
   // hipGraph of one training iteration
   hipGraphExec_t graph_exec = nullptr; int graph_O = -1, graph_T = -1; bool graph_adam = true;
@@ -199,6 +224,11 @@ struct SlnVae {
     GemmTNArgs a; std::memset(&a, 0, sizeof(a));
     a.G = G; a.X = X; a.dW = u.p.d_weight; a.db = u.p.d_bias; a.lddw = u.in;
     a.R = R; a.Nout = u.out; a.Kin = u.in; a.rows_per_block = 0;
+    if (use_side && side) {
+      int r = fork_side(st);
+      if (r) return r;
+      return sln_launch_gemm_tn(a, -1, side);
+    }
     return sln_launch_gemm_tn(a, -1, st);
   }
 
@@ -275,7 +305,7 @@ int SlnVae::run_bn_updates(int first, int count, hipStream_t st) {
   if (count <= 0) return 0;
   int maxc = 0;
   for (int i = first; i < first + count; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
-  return sln_launch_bn_running_update(bn_table_dev + first, count, maxc, kBnMomentum, st);
+  return sln_launch_bn_running_update(bn_table_dev + first, count, maxc, kBnMomentum, cfg.recurrent ? 0 : 1, st);
 }
 
 // One GraphTripleConv forward (models/graph.py:57-111) as 5 launches.
@@ -319,6 +349,7 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   Operand G1 = op1(seg_bwd(g1, H, ly.A1, H, H, ly.bn[0], tr), T);
   RET_IF(linear_wgrad(G1, layer_input(gi, tr), ly.u0 + 0, T, st));
   RET_IF(linear_dgrad(G1, ly.u0 + 0, dG[slot], 3 * D, T, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  RET_IF(join_side(st));      // g4/g3/g2/g1 are rewritten by the next (earlier) layer
   return 0;
 }
 
@@ -395,6 +426,7 @@ int SlnVae::loss(const float* bp, const float* ap, const float* mu_, const float
 // Backward of decoder(): expects dbp (padded) and dlogits filled.
 int SlnVae::decoder_backward(hipStream_t st) {
   const bool tr = dec_training;
+  ev_next = 0;
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
   if (dec_doubles) HIP_RET(hipMemsetAsync(gstats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
@@ -423,13 +455,14 @@ int SlnVae::decoder_backward(hipStream_t st) {
   Operand Ga0 = op1(seg_bwd(g_an, H, anA1, H, H, bn_head[5], tr), O);
   RET_IF(linear_wgrad(Ga0, layer_output(last, tr), unit_anglenet(0), O, st));
   RET_IF(linear_dgrad(Ga0, unit_anglenet(0), d_ax, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  RET_IF(join_side(st));      // g_bn / g_an / dbp / dlogits consumers done before g4 is produced
   // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
   {
     BnView v = view(ll.bn[3], 0, tr);
     RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, W, ll.A4, W, v, O, W, g4, W,
                                   v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
   }
-  RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, W, O, n_attr_e, t.d_attr_emb_dc, st));
+  RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, W, O, n_attr_e, cfg.num_attrs, t.d_attr_emb_dc, st));
   // gconv layers, last to first
   for (int l = L - 1; l >= 0; --l) {
     const int gi = L + l, slot = l & 1;
@@ -443,7 +476,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
     } else {
       BnView none = view(-1, 0, tr);
       RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
-      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, t.d_pred_emb_dc, st));
+      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, cfg.num_preds, t.d_pred_emb_dc, st));
     }
   }
   DecAssembleBwd db; std::memset(&db, 0, sizeof(db));
@@ -454,7 +487,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   if (nb > 0) {
     int maxc = 0;
     for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
-    RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, st));
+    RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, cfg.recurrent ? 0 : 1, st));
   }
   return 0;
 }
@@ -462,6 +495,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
 // Backward of encoder(): expects dmu / dlv filled.
 int SlnVae::encoder_backward(hipStream_t st) {
   const bool tr = enc_training;
+  if (ev_next > 4096) ev_next = 0;
   if (enc_stats_doubles) HIP_RET(hipMemsetAsync(gstats_base, 0, enc_stats_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = L - 1, W = 2 * E;
@@ -486,6 +520,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
     Operand G1 = op1(seg_bwd(g_h1, H, hA1, H, H, b0, tr), O);
     RET_IF(linear_wgrad(G1, XL, u + 0, O, st));
     RET_IF(linear_dgrad(G1, u + 0, d_x[br], W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+    RET_IF(join_side(st));    // tmp_d / g_h2 / g_h1 are reused by the angle branch
   }
   {
     BnView v = view(ll.bn[3], 0, tr);
@@ -504,7 +539,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
     } else {
       BnView none = view(-1, 0, tr);
       RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
-      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, t.d_pred_emb_ec, st));
+      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, cfg.num_preds, t.d_pred_emb_ec, st));
     }
   }
   EncAssembleBwd eb; std::memset(&eb, 0, sizeof(eb));
@@ -516,7 +551,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
   if (n_bn_enc > 0) {
     int maxc = 0;
     for (int i = 0; i < n_bn_enc; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
-    RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, st));
+    RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, cfg.recurrent ? 0 : 1, st));
   }
   return 0;
 }
@@ -612,6 +647,11 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     else { head(4, h->unit_boxnet(0), H); head(5, h->unit_anglenet(0), H); }
   }
   if (!c->batch_norm) h->n_bn_enc = 0;
+  {
+    const char* ns = std::getenv("SLN_NO_SIDE_STREAM");
+    h->use_side = !(ns && ns[0] == '1');
+    if (h->use_side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->use_side = false; }
+  }
   *out = h;
   return 0;
 }
@@ -619,6 +659,8 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
 void sln_vae_destroy(SlnVae* h) {
   if (!h) return;
   if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  for (auto e : h->events) (void)hipEventDestroy(e);
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 

@@ -68,10 +68,10 @@ int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st);
 // d_emb[idx[r], :] += d[r, col0 : col0+n]   (embedding backward for predicate / attribute tables)
 // out[r, :] = emb[idx[r], :]
 int sln_launch_embed_gather_i32(const int* idx, const float* emb, int rows, int n, float* out, hipStream_t st);
-int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
-                             hipStream_t st);
-int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
-                             hipStream_t st);
+int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, int rows, int n, int table_rows,
+                             float* d_emb, hipStream_t st);
+int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col0, int rows, int n, int table_rows,
+                             float* d_emb, hipStream_t st);
 
 // ---- loss (utils.py:12-33) --------------------------------------------------------------------
 struct LossArgs {
@@ -102,8 +102,10 @@ struct BnTableEntry {      // one BatchNorm application (module may repeat in 'r
   const double* sums; const double* gsums; int cstride; int C; int rows;
   float* rmean; float* rvar; int64_t* nbt; float* dgamma; float* dbeta;
 };
-int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, hipStream_t st);
-int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, hipStream_t st);
+// independent != 0: no BatchNorm module occurs twice in the table (feedforward mode) -> one block row per entry
+int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, int independent,
+                                 hipStream_t st);
+int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, int independent, hipStream_t st);
 
 struct TransposeEntry { const float* src; float* dst; int rows; int cols; int dst_ld; int pad_; };   // dst[c*dst_ld + r] = src[r*cols + c]
 int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles, hipStream_t st);

@@ -10,7 +10,8 @@ namespace {
 
 constexpr int CB = 64;   // columns per block
 constexpr int RL = 4;    // row lanes per block
-constexpr int RB = 32;   // rows per block
+constexpr int RB = 32;   // rows per block (dense row kernels)
+constexpr int RBG = 8;   // rows per block for the CSR (incident-list) kernels: short, imbalanced rows
 
 __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid, double* out, int cstride, int col) {
   __shared__ float red[2][RL][CB];
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(CB* RL) void scatter_avg_fwd_kernel(const float* __
   float scs, shs, sco, sho;
   bn_fwd_coef(bn, c, scs, shs);
   bn_fwd_coef(bn, H + D + c, sco, sho);
-  const int r1 = min(O, (int)(blockIdx.y + 1) * RB);
-  for (int i = blockIdx.y * RB + threadIdx.y; i < r1; i += RL) {
+  const int r1 = min(O, (int)(blockIdx.y + 1) * RBG);
+  for (int i = blockIdx.y * RBG + threadIdx.y; i < r1; i += RL) {
     const int b = g.rowptr[i], e = g.rowptr[i + 1];
     float acc = 0.f;
     for (int k = b; k < e; ++k) {
@@ -154,9 +155,9 @@ __global__ __launch_bounds__(CB* RL) void gather_bwd_kernel(const float* __restr
   float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
   if (cv && masked) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
   float s1 = 0.f, s2 = 0.f;
-  const int r1 = min(O, (int)(blockIdx.y + 1) * RB);
+  const int r1 = min(O, (int)(blockIdx.y + 1) * RBG);
   if (cv) {
-    for (int i = blockIdx.y * RB + threadIdx.y; i < r1; i += RL) {
+    for (int i = blockIdx.y * RBG + threadIdx.y; i < r1; i += RL) {
       const int b = g.rowptr[i], e = g.rowptr[i + 1];
       float d = 0.f;
       for (int k = b; k < e; ++k) {
@@ -293,6 +294,28 @@ __global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
   else { c -= a.n_attr; if (a.dz) a.dz[(size_t)r * a.n_z + c] = d; }
 }
 
+// Small tables (<= 8192 floats): accumulate the block's rows in an LDS copy of the table, then flush the
+// touched entries with one global atomic each (pred table: 4096x128 adds onto 16x128 entries).
+template <typename IdxT>
+__global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld,
+                                                            int col0, int rows, int n, int table_rows, int rows_per_block,
+                                                            float* __restrict__ d_emb) {
+  extern __shared__ float tab[];
+  const int tsz = table_rows * n;
+  for (int i = threadIdx.x; i < tsz; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+  for (long i = (long)r0 * n + threadIdx.x; i < (long)r1 * n; i += 256) {
+    const int r = (int)(i / n), c = (int)(i % n);
+    atomicAdd(&tab[(int)idx[r] * n + c], d[(size_t)r * ld + col0 + c]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tsz; i += 256) {
+    const float v = tab[i];
+    if (v != 0.f) atomicAdd(d_emb + i, v);
+  }
+}
+
 template <typename IdxT>
 __global__ void embed_bwd_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows,
                                  int n, float* __restrict__ d_emb) {
@@ -402,9 +425,10 @@ __global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __r
 // ----------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping, transposes, Adam
 // ----------------------------------------------------------------------------------------------
-__global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, int n, float mom) {
+__global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, int n, float mom, int per_entry) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int e = 0; e < n; ++e) {               // in application order: shared modules see ordered updates
+  const int e0 = per_entry ? blockIdx.y : 0, e1 = per_entry ? blockIdx.y + 1 : n;
+  for (int e = e0; e < e1; ++e) {             // sequential form: application order, shared modules see ordered updates
     const BnTableEntry t = tab[e];
     if (c == 0 && t.nbt) t.nbt[0] += 1;
     if (c >= t.C || t.rmean == nullptr) continue;
@@ -418,9 +442,10 @@ __global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, i
   }
 }
 
-__global__ void bn_param_grads_kernel(const BnTableEntry* __restrict__ tab, int n) {
+__global__ void bn_param_grads_kernel(const BnTableEntry* __restrict__ tab, int n, int per_entry) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int e = 0; e < n; ++e) {
+  const int e0 = per_entry ? blockIdx.y : 0, e1 = per_entry ? blockIdx.y + 1 : n;
+  for (int e = e0; e < e1; ++e) {
     const BnTableEntry t = tab[e];
     if (c >= t.C || t.dgamma == nullptr) continue;
     t.dbeta[c] += (float)t.gsums[c];
@@ -486,7 +511,7 @@ int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2
   if (O <= 0) return 0;
   // algorithmic bytes: both halves of A2 once, pooled once, the entry list
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * H + 4.0 * O * H + 16.0 * g.T, st);
-  hipLaunchKernelGGL(scatter_avg_fwd_kernel, colgrid(H, O), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
+  hipLaunchKernelGGL(scatter_avg_fwd_kernel, dim3(sln_cdiv(H, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -507,7 +532,7 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
                           int cstride, hipStream_t st) {
   if (O <= 0) return 0;
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * D + (masked ? 2.0 : 1.0) * 4.0 * O * D + 16.0 * g.T, st);
-  hipLaunchKernelGGL(gather_bwd_kernel, colgrid(D, O), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
+  hipLaunchKernelGGL(gather_bwd_kernel, dim3(sln_cdiv(D, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
                      ldx, bn, masked, out, ldo, gsums, cstride);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -556,20 +581,34 @@ int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st) {
   return 0;
 }
 
-int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
-                             hipStream_t st) {
+int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, int rows, int n, int table_rows,
+                             float* d_emb, hipStream_t st) {
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
+  if (table_rows > 0 && (long)table_rows * n <= 8192) {
+    const int rpb = 128;
+    hipLaunchKernelGGL(embed_bwd_lds_kernel<int>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st, idx,
+                       d, ld, col0, rows, n, table_rows, rpb, d_emb);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(embed_bwd_kernel<int>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, idx, d, ld, col0, rows,
                      n, d_emb);
   SLN_CHECK_LAUNCH();
   return 0;
 }
 
-int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col0, int rows, int n, float* d_emb,
-                             hipStream_t st) {
+int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col0, int rows, int n, int table_rows,
+                             float* d_emb, hipStream_t st) {
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
+  if (table_rows > 0 && (long)table_rows * n <= 8192) {
+    const int rpb = 128;
+    hipLaunchKernelGGL(embed_bwd_lds_kernel<int64_t>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st,
+                       idx, d, ld, col0, rows, n, table_rows, rpb, d_emb);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(embed_bwd_kernel<int64_t>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, idx, d, ld, col0,
                      rows, n, d_emb);
   SLN_CHECK_LAUNCH();
@@ -625,16 +664,19 @@ int sln_launch_latent_bwd(const float* mu, const float* logvar, const float* eps
   return 0;
 }
 
-int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, hipStream_t st) {
+int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, int independent,
+                                 hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(bn_running_update_kernel, dim3(sln_cdiv(max_c, 256)), dim3(256), 0, st, table, n, momentum);
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(sln_cdiv(max_c, 256), independent ? n : 1), dim3(256), 0, st, table, n,
+                     momentum, independent);
   SLN_CHECK_LAUNCH();
   return 0;
 }
 
-int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, hipStream_t st) {
+int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, int independent, hipStream_t st) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(sln_cdiv(max_c, 256)), dim3(256), 0, st, table, n);
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(sln_cdiv(max_c, 256), independent ? n : 1), dim3(256), 0, st, table, n,
+                     independent);
   SLN_CHECK_LAUNCH();
   return 0;
 }
