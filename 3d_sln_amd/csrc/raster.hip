@@ -1,0 +1,677 @@
+// Tiled z-buffer rasterizer + its two hand-designed backward passes for gfx950.
+//
+// Semantics: the `neural_renderer` package the reference calls at models/diff_render.py:359-398
+// (camera projection happens on the host side; this file starts at faces[B,F,3,3] = projected x,y in
+// NDC + camera z).  The arithmetic (expression order, float/double mix) is the one restated in
+// oracle/raster_ref.cpp and this file is built with -ffp-contract=off so that the face-index map is
+// bit-identical to that restatement.
+//
+// Forward: a workgroup owns a 16x16 pixel tile (one pixel per lane, 4 wavefronts).  It streams the face
+// set-up records in chunks of 256 (coalesced: one record field per lane), keeps the faces whose pixel
+// bounding box touches the tile by an ORDER-PRESERVING ballot/prefix compaction into LDS (ascending
+// face index == the package's tie rule "lowest index wins"), stages their 18 coefficients in LDS and
+// lets every lane run the edge tests against broadcast LDS reads.  z-min / index / barycentrics live
+// in registers.  The package's 33 passes per scene (1 depth + 32 class masks over the same geometry)
+// collapse into ONE pass that tracks two z-buffers (depth pass near=0.1, class passes near=ctor value).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sln_hip.h"
+#include "sln_common.h"
+#include "sln_prof.h"
+
+namespace {
+
+constexpr int TS = 16;          // tile side
+constexpr int CHUNK = 256;      // faces tested per round
+
+struct FaceRec {                // per-face set-up, 24 floats
+  float f[9];                   // x0 y0 z0 x1 y1 z1 x2 y2 z2
+  float inv[9];                 // pixel-space inverse (w_k = inv[3k] xi + inv[3k+1] yi + inv[3k+2])
+  int x0, x1, y0, y1;           // conservative pixel bounding box (x1 < x0: never drawn)
+  int pad_[2];
+};
+
+__device__ __forceinline__ bool backfacing(const float* f) {
+  return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
+}
+
+__device__ __forceinline__ void face_inverse(const float* f, int is, float* inv) {
+  float p[3][2];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) p[n][d] = (float)(0.5 * (double)(f[3 * n + d] * is + is - 1));
+  const float m[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                      p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                      p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+  const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) inv[k] = m[k] / den;
+}
+
+__global__ void raster_prep_kernel(const float* __restrict__ faces, long n, int is, FaceRec* __restrict__ rec) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  FaceRec r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) r.f[k] = faces[9 * i + k];
+  r.pad_[0] = r.pad_[1] = 0;
+  bool draw = !backfacing(r.f);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) draw = draw && (r.f[k] == r.f[k]);          // NaN vertices never draw
+  if (draw) {
+    face_inverse(r.f, is, r.inv);
+    const float s = 0.5f * is, o = 0.5f * (is - 1);
+    const float xa = fminf(r.f[0], fminf(r.f[3], r.f[6])) * s + o, xb = fmaxf(r.f[0], fmaxf(r.f[3], r.f[6])) * s + o;
+    const float ya = fminf(r.f[1], fminf(r.f[4], r.f[7])) * s + o, yb = fmaxf(r.f[1], fmaxf(r.f[4], r.f[7])) * s + o;
+    // clamp in float first (huge coordinates), pad by one pixel: the exact edge tests decide later
+    r.x0 = (int)fmaxf(floorf(xa) - 1.f, 0.f); r.x1 = (int)fminf(ceilf(xb) + 1.f, (float)(is - 1));
+    r.y0 = (int)fmaxf(floorf(ya) - 1.f, 0.f); r.y1 = (int)fminf(ceilf(yb) + 1.f, (float)(is - 1));
+    if (!(xb >= -2.f && xa <= is + 1.f && yb >= -2.f && ya <= is + 1.f)) { r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) r.inv[k] = 0.f;
+    r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
+  }
+  rec[i] = r;
+}
+
+struct ZState { float z; int idx; float w0, w1, w2; };
+
+// DUAL: track a second z-buffer with its own near plane (the reference's depth pass runs with the package
+// default near=0.1 while its class passes use the constructor's near, SURVEY.md 2.1 "known asymmetry").
+template <bool DUAL>
+__global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ rec, int F, int is, float near_a,
+                                                          float near_b, float far, int32_t* __restrict__ fi_a,
+                                                          float* __restrict__ w_a, float* __restrict__ d_a,
+                                                          int32_t* __restrict__ fi_b, float* __restrict__ w_b,
+                                                          float* __restrict__ d_b) {
+  __shared__ float sf[CHUNK][18];
+  __shared__ int sid[CHUNK];
+  __shared__ int wave_cnt[4];
+  const int tiles_x = (is + TS - 1) / TS;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int xi = tx * TS + (tid & (TS - 1)), yi = ty * TS + (tid >> 4);
+  const bool inimg = xi < is && yi < is;
+  const float yp = (float)((2. * yi + 1 - is) / is), xp = (float)((2. * xi + 1 - is) / is);
+  const float fxi = (float)xi, fyi = (float)yi;
+  const int tx0 = tx * TS, tx1 = tx0 + TS - 1, ty0 = ty * TS, ty1 = ty0 + TS - 1;
+  const FaceRec* rb = rec + (size_t)b * F;
+
+  ZState A = {far, -1, 0.f, 0.f, 0.f}, Bz = {far, -1, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < F; c0 += CHUNK) {
+    const int fn = c0 + tid;
+    bool hit = false;
+    if (fn < F) {
+      const int bx0 = rb[fn].x0, bx1 = rb[fn].x1, by0 = rb[fn].y0, by1 = rb[fn].y1;
+      hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+    }
+    const unsigned long long m = __ballot(hit);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = 0, total = 0;
+#pragma unroll
+    for (int wv = 0; wv < 4; ++wv) { if (wv < wave) off += wave_cnt[wv]; total += wave_cnt[wv]; }
+    if (hit) sid[off + before] = fn;
+    __syncthreads();
+    // stage the kept faces (18 coefficients each), coalesced over (face, field)
+    for (int e = tid; e < total * 18; e += 256) {
+      const int k = e / 18, q = e % 18;
+      const FaceRec& r = rb[sid[k]];
+      sf[k][q] = q < 9 ? r.f[q] : r.inv[q - 9];
+    }
+    __syncthreads();
+    if (inimg) {
+      for (int k = 0; k < total; ++k) {
+        const float* f = sf[k];
+        if (((yp - f[1]) * (f[3] - f[0]) < (xp - f[0]) * (f[4] - f[1])) ||
+            ((yp - f[4]) * (f[6] - f[3]) < (xp - f[3]) * (f[7] - f[4])) ||
+            ((yp - f[7]) * (f[0] - f[6]) < (xp - f[6]) * (f[1] - f[7]))) continue;
+        float w0 = f[9] * fxi + f[10] * fyi + f[11];
+        float w1 = f[12] * fxi + f[13] * fyi + f[14];
+        float w2 = f[15] * fxi + f[16] * fyi + f[17];
+        w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
+        float ws = 0.f; ws += w0; ws += w1; ws += w2;
+        w0 /= ws; w1 /= ws; w2 /= ws;
+        const float zp = (float)(1. / (double)(w0 / f[2] + w1 / f[5] + w2 / f[8]));
+        if (far <= zp) continue;
+        if (!(zp <= near_a) && zp < A.z) { A.z = zp; A.idx = sid[k]; A.w0 = w0; A.w1 = w1; A.w2 = w2; }
+        if (DUAL && !(zp <= near_b) && zp < Bz.z) { Bz.z = zp; Bz.idx = sid[k]; Bz.w0 = w0; Bz.w1 = w1; Bz.w2 = w2; }
+      }
+    }
+    __syncthreads();
+  }
+  if (inimg) {
+    const size_t p = ((size_t)b * is + yi) * is + xi;
+    fi_a[p] = A.idx; d_a[p] = A.idx >= 0 ? A.z : far;
+    w_a[3 * p] = A.w0; w_a[3 * p + 1] = A.w1; w_a[3 * p + 2] = A.w2;
+    if (DUAL) {
+      fi_b[p] = Bz.idx; d_b[p] = Bz.idx >= 0 ? Bz.z : far;
+      w_b[3 * p] = Bz.w0; w_b[3 * p + 1] = Bz.w1; w_b[3 * p + 2] = Bz.w2;
+    }
+  }
+}
+
+// trilinear sample of the winning face's ts^3 texture cube (package's forward_texture_sampling)
+__device__ __forceinline__ void tex_sample(const float* f, const float* tx, int ts, float eps, float w0, float w1, float w2,
+                                           float depth, float* px) {
+  const float wk[3] = {w0, w1, w2};
+  float t[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float v = wk[k] * (ts - 1) * (depth / f[3 * k + 2]);
+    v = fmaxf(v, 0.f);
+    v = fminf(v, (float)(ts - 1) - eps);
+    t[k] = v;
+  }
+  px[0] = px[1] = px[2] = 0.f;
+  for (int c = 0; c < 8; ++c) {
+    float w = 1.f; int ti[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float fr = t[k] - (float)(int)t[k];
+      if (((c >> k) & 1) == 0) { w *= 1.f - fr; ti[k] = (int)t[k]; }
+      else { w *= fr; ti[k] = (int)t[k] + 1; }
+    }
+    const int cell = ti[0] * ts * ts + ti[1] * ts + ti[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) px[k] += w * tx[3 * cell + k];
+  }
+}
+
+__global__ void texture_sample_kernel(const float* __restrict__ faces, const float* __restrict__ textures,
+                                      const int32_t* __restrict__ fi, const float* __restrict__ w,
+                                      const float* __restrict__ depth, int F, int is, int ts, float eps, long npix,
+                                      float* __restrict__ rgb) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const int fn = fi[i];
+  float px[3] = {0.f, 0.f, 0.f};
+  if (fn >= 0) {
+    const long b = i / ((long)is * is);
+    const float* f = faces + 9 * (b * F + fn);
+    tex_sample(f, textures + (size_t)(b * F + fn) * ts * ts * ts * 3, ts, eps, w[3 * i], w[3 * i + 1], w[3 * i + 2], depth[i], px);
+  }
+  rgb[3 * i] = px[0]; rgb[3 * i + 1] = px[1]; rgb[3 * i + 2] = px[2];
+}
+
+// depth backward (package's backward_depth_map): atomics into grad_faces[B,F,9]
+__global__ void depth_backward_kernel(const float* __restrict__ faces, const int32_t* __restrict__ fi,
+                                      const float* __restrict__ w, const float* __restrict__ depth,
+                                      const float* __restrict__ gd, int F, int is, long npix, float* __restrict__ gfaces) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const int fn = fi[i];
+  const float g = gd[i];
+  if (fn < 0 || g == 0.f) return;
+  const long b = i / ((long)is * is);
+  const float* f = faces + 9 * (b * F + fn);
+  float* gf = gfaces + 9 * (b * F + fn);
+  float fl[9], iv[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) fl[k] = f[k];
+  face_inverse(fl, is, iv);
+  const float d2 = depth[i] * depth[i];
+  float tmp[2] = {0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < 2; ++l)
+#pragma unroll
+    for (int m = 0; m < 3; ++m) tmp[l] += -iv[3 * m + l] / fl[3 * m + 2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float wk = w[3 * i + k];
+    atomicAdd(gf + 3 * k + 2, g * wk * d2 / (fl[3 * k + 2] * fl[3 * k + 2]));
+#pragma unroll
+    for (int l = 0; l < 2; ++l) atomicAdd(gf + 3 * k + l, -g * tmp[l] * wk * d2 * is / 2);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------------
+// pixel-map backward.  One wavefront per face: the (edge, axis, d0) walk is sequential, the outward /
+// inward scans along d1 are spread over the 64 lanes; per-lane partial sums are combined by a fixed
+// butterfly at the end (no atomics: one writer per face).
+// PIX is a policy giving diff(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
+// ----------------------------------------------------------------------------------------------------
+struct PixDense {            // C-channel image: one positive-part test over the channel sum (package's rgb mode, C=3)
+  const float* rgb; const float* grad; int C;
+  __device__ __forceinline__ float contrib(long q, long ref, int, int) const {
+    float diff = 0.f;
+    for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref * C + k]) * grad[q * C + k];
+    return diff > 0.f ? diff : 0.f;
+  }
+};
+
+// The reference's 32 class passes fused (models/diff_render.py:381-398): pass c renders value(pixel) where the
+// winning face belongs to class c and 0 elsewhere, into three equal rgb channels whose mean is the class
+// image; every pass applies its own positive-part test.  The gradient w.r.t. the class images is read
+// straight out of d(final)[B, NCH, is, is] (row-flipped, class c in channel chan[c]).
+struct PixClass {
+  const int32_t* fi; const float* val; int vstride; const int32_t* cls; const float* gfinal; const int32_t* chan;
+  int F, is, nch;
+  __device__ __forceinline__ float grad_of(int b, int c, long pq) const {
+    const int y = (int)(pq / is), x = (int)(pq % is);
+    return gfinal[(((long)b * nch + chan[c]) * is + (is - 1 - y)) * is + x] / 3.0f;
+  }
+  __device__ __forceinline__ float contrib(long q, long ref, int b, int) const {
+    const long pq = q - (long)b * is * is;
+    const int fq = fi[q], fr = fi[ref];
+    const int cq = fq >= 0 ? cls[(long)b * F + fq] : -1, cr = fr >= 0 ? cls[(long)b * F + fr] : -1;
+    const float vq = fq >= 0 ? val[q * vstride] : 0.f, vr = fr >= 0 ? val[ref * vstride] : 0.f;
+    float tot = 0.f;
+    if (cq >= 0) {
+      const float g3 = grad_of(b, cq, pq);
+      const float dv = vq - (cr == cq ? vr : 0.f);
+      float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
+      if (diff > 0.f) tot += diff;
+    }
+    if (cr >= 0 && cr != cq) {
+      const float g3 = grad_of(b, cr, pq);
+      const float dv = 0.f - vr;
+      float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
+      if (diff > 0.f) tot += diff;
+    }
+    return tot;
+  }
+};
+
+template <typename PIX>
+__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces,
+                                                                const int32_t* __restrict__ fi, PIX pix0, int F, int is,
+                                                                float eps, float* __restrict__ gfaces) {
+  const long i = blockIdx.x;                       // face
+  const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
+  float face[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
+  if (backfacing(face)) return;
+  const PIX& pix = pix0;
+  const long base = (long)b * is * is;
+  float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int e = 0; e < 3; ++e) {
+    int pi[3]; float pp[3][2];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) pi[n] = (e + n) % 3;
+#pragma unroll
+    for (int n = 0; n < 3; ++n)
+#pragma unroll
+      for (int d = 0; d < 2; ++d) pp[n][d] = (float)(0.5 * (double)(face[3 * pi[n] + d] * is + is - 1));
+    for (int axis = 0; axis < 2; ++axis) {
+      float p[3][2];
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) p[n][d] = pp[n][(d + axis) % 2];
+      const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
+      const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
+      const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
+      float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
+      for (int d0 = d0_from; d0 <= d0_to; ++d0) {
+        const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+        const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+        const int d1_out = d1_in + dir;
+        if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;
+        const long idx_in = axis == 0 ? base + (long)d1_in * is + d0 : base + (long)d0 * is + d1_in;
+        const long idx_out = axis == 0 ? base + (long)d1_out * is + d0 : base + (long)d0 * is + d1_out;
+        const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
+        const float r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;
+        const float r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
+        auto add = [&](int d1, float diff) {
+          if (use0) {
+            float dist = (float)((double)(r0 * (d1 - d1_cross)) * 2. / is);
+            dist = 0 < dist ? dist + eps : dist - eps;
+            acc0 -= diff / dist;
+          }
+          if (use1) {
+            float dist = (float)((double)(r1 * (d1 - d1_cross)) * 2. / is);
+            dist = 0 < dist ? dist + eps : dist - eps;
+            acc1 -= diff / dist;
+          }
+        };
+        if (fi[idx_in] == fn) {                     // outward scan to the image border
+          const int lim = dir > 0 ? is - 1 : 0;
+          const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
+          for (int d1 = from + lane; d1 <= to; d1 += 64) {
+            const long q = axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1;
+            const float diff = pix.contrib(q, idx_in, b, fn);
+            if (diff > 0.f) add(d1, diff);
+          }
+        }
+        {                                           // inward scan to the opposite edge, this face's pixels only
+          float cross2;
+          if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+          else cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
+          const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
+          const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
+          for (int d1 = from + lane; d1 <= to; d1 += 64) {
+            const long q = axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1;
+            if (fi[q] != fn) continue;
+            const float diff = pix.contrib(q, idx_out, b, fn);
+            if (diff > 0.f) add(d1, diff);
+          }
+        }
+      }
+      g[pi[0] * 3 + (1 - axis)] += acc0;
+      g[pi[1] * 3 + (1 - axis)] += acc1;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float v = g[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    g[k] = v;
+  }
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) gfaces[9 * i + k] += g[k];
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" {
+
+int64_t sln_raster_workspace_bytes(int B, int F) { return (int64_t)sizeof(FaceRec) * B * F + 256; }
+
+int sln_raster_forward(const float* faces, int B, int F, int image_size, float near, float far, void* workspace,
+                       int32_t* face_index, float* weight, float* depth, void* stream) {
+  if (!faces || !workspace || !face_index || !weight || !depth || B <= 0 || F < 0 || image_size <= 0) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  FaceRec* rec = static_cast<FaceRec*>(workspace);
+  const long n = (long)B * F;
+  SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 20.0 * B * image_size * image_size, st);
+  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec);
+  const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
+  hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, F, image_size, near, near, far,
+                     face_index, weight, depth, nullptr, nullptr, nullptr);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_raster_forward_dual(const float* faces, int B, int F, int image_size, float near_a, float near_b, float far,
+                            void* workspace, int32_t* fi_a, float* w_a, float* d_a, int32_t* fi_b, float* w_b,
+                            float* d_b, void* stream) {
+  if (!faces || !workspace || !fi_a || !w_a || !d_a || !fi_b || !w_b || !d_b || B <= 0 || F < 0 || image_size <= 0)
+    return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  FaceRec* rec = static_cast<FaceRec*>(workspace);
+  const long n = (long)B * F;
+  SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 40.0 * B * image_size * image_size, st);
+  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec);
+  const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
+  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, rec, F, image_size, near_a, near_b, far,
+                     fi_a, w_a, d_a, fi_b, w_b, d_b);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_raster_texture_sample(const float* faces, const float* textures, const int32_t* face_index, const float* weight,
+                              const float* depth, int B, int F, int image_size, int texture_size, float eps, float* rgb,
+                              void* stream) {
+  if (!faces || !textures || !face_index || !weight || !depth || !rgb || texture_size < 2) return SLN_E_BADARG;
+  const long npix = (long)B * image_size * image_size;
+  hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces,
+                     textures, face_index, weight, depth, F, image_size, texture_size, eps, npix, rgb);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_raster_backward_depth(const float* faces, const int32_t* face_index, const float* weight, const float* depth,
+                              const float* grad_depth, int B, int F, int image_size, float* grad_faces, void* stream) {
+  if (!faces || !face_index || !weight || !depth || !grad_depth || !grad_faces) return SLN_E_BADARG;
+  const long npix = (long)B * image_size * image_size;
+  hipStream_t st = (hipStream_t)stream;
+  SlnProfScope prof(SLN_FAM_RASTER_BWD, 28.0 * npix, st);
+  hipLaunchKernelGGL(depth_backward_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, face_index, weight,
+                     depth, grad_depth, F, image_size, npix, grad_faces);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const float* rgb, const float* grad_rgb, int B,
+                            int F, int image_size, int channels, float eps, float* grad_faces, void* stream) {
+  if (!faces || !face_index || !rgb || !grad_rgb || !grad_faces || channels <= 0) return SLN_E_BADARG;
+  const long n = (long)B * F;
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
+  PixDense pix{rgb, grad_rgb, channels};
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n), dim3(64), 0, st, faces, face_index, pix, F,
+                     image_size, eps, grad_faces);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"
+
+// ====================================================================================================
+// Fused scene pass: everything models/diff_render.py:359-434 does after the mesh buffers are assembled,
+// in ONE rasterisation instead of 33 (1 depth + 32 class passes over identical geometry).
+//   final[b, 0]           = depth (rows flipped, values > 15 -> -1)
+//   final[b, 1 + chan[c]] = class image of class c (mean of three equal rgb channels of the uniform-texture pass)
+//   final[b, 41 + dch[c]] = where(mask_c, depth, mean_c(depth)) / wall_max      (dch[c] >= 0 only)
+// with mask_c = class image > 0.1, mean_c over mask_c (wall_max when empty), wall_max = max depth over the
+// class-0 ("wall") mask (10 when empty).
+// ====================================================================================================
+namespace {
+
+struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int pad_[2]; };
+
+// order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
+__device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+__device__ __forceinline__ float wall_max_of(const SceneStats& s) { return s.wall_any ? funkey(s.wall_key) : 10.0f; }
+
+__global__ void scene_init_stats_kernel(SceneStats* st, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * 64) return;
+  const int b = i / 64, k = i % 64;
+  st[b].sum[k] = 0.0; st[b].cnt[k] = 0.0; st[b].gsum[k] = 0.0;
+  if (k == 0) { st[b].wall_key = (int)0x80000000; st[b].wall_any = 0; }
+}
+
+__device__ __forceinline__ float class_image_value(float v) { float s = 0.f; s += v; s += v; s += v; return s / 3.0f; }
+__device__ __forceinline__ float depth_value(float d) { return d > 15.f ? -1.f : d; }
+
+__global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val, const float* __restrict__ d_a,
+                                   const int32_t* __restrict__ cls, int F, int is, int NC, SceneStats* __restrict__ st) {
+  const int b = blockIdx.y;
+  const long plane = (long)is * is;
+  __shared__ float ssum[64]; __shared__ int scnt[64];
+  if (threadIdx.x < 64) { ssum[threadIdx.x] = 0.f; scnt[threadIdx.x] = 0; }
+  __syncthreads();
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+    const long q = b * plane + p;
+    const int f = fi_b[q];
+    if (f < 0) continue;
+    const int c = cls[(long)b * F + f];
+    if (c < 0 || c >= NC) continue;
+    if (!(class_image_value(val[3 * q]) > 0.1f)) continue;
+    const float dd = depth_value(d_a[q]);
+    atomicAdd(&ssum[c], dd); atomicAdd(&scnt[c], 1);
+    if (c == 0) {                       // wall_max = max depth over the wall mask (models/diff_render.py:408-411)
+      atomicMax(&st[b].wall_any, 1);
+      atomicMax(&st[b].wall_key, fkey(dd));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NC && scnt[threadIdx.x] > 0) {
+    atomicAdd(&st[b].sum[threadIdx.x], (double)ssum[threadIdx.x]);
+    atomicAdd(&st[b].cnt[threadIdx.x], (double)scnt[threadIdx.x]);
+  }
+}
+
+__global__ void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val, const float* __restrict__ d_a,
+                                     const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
+                                     const int32_t* __restrict__ dch, int F, int is, int NC, int nch,
+                                     const SceneStats* __restrict__ st, float* __restrict__ out) {
+  const int b = blockIdx.z, ch = blockIdx.y;
+  const long plane = (long)is * is;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const int y = (int)(p / is), x = (int)(p % is);
+  const long q = b * plane + p;
+  const float wall_max = wall_max_of(st[b]);
+  const int f = fi_b[q];
+  const int c = f >= 0 ? cls[(long)b * F + f] : -1;
+  const float img = (c >= 0 && c < NC) ? class_image_value(val[3 * q]) : 0.f;
+  const float dd = depth_value(d_a[q]);
+  float v = 0.f;
+  if (ch == 0) v = dd;
+  else if (ch <= 40) v = (c >= 0 && c < NC && chan[c] == ch - 1) ? img : 0.f;
+  else {
+    // which class owns this depth channel? (dch is a small table: linear search)
+    int owner = -1;
+    for (int k = 0; k < NC; ++k) if (dch[k] == ch - 41) { owner = k; break; }
+    if (owner >= 0) {
+      const bool m = (c == owner) && img > 0.1f;
+      const float mean = st[b].cnt[owner] > 0.0 ? (float)(st[b].sum[owner] / st[b].cnt[owner]) : wall_max;
+      v = (m ? dd : mean) / wall_max;
+    }
+  }
+  out[(((long)b * nch + ch) * is + (is - 1 - y)) * is + x] = v;
+}
+
+// sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c)
+__global__ void scene_bwd_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                       const int32_t* __restrict__ cls, const int32_t* __restrict__ dch, int F, int is, int NC,
+                                       int nch, const float* __restrict__ gout, SceneStats* __restrict__ st) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  if (dch[c] < 0) return;
+  const long plane = (long)is * is;
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
+    const long q = b * plane + p;
+    const int f = fi_b[q];
+    const int cc = f >= 0 ? cls[(long)b * F + f] : -1;
+    const bool m = (cc == c) && class_image_value(val[3 * q]) > 0.1f;
+    if (!m) {
+      const int y = (int)(p / is), x = (int)(p % is);
+      acc += gout[(((long)b * nch + 41 + dch[c]) * is + (is - 1 - y)) * is + x];
+    }
+  }
+  __shared__ float red[256];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(&st[b].gsum[c], (double)red[0]);
+}
+
+// d(loss)/d(raw depth map of the depth pass), unflipped [B,is,is]
+__global__ void scene_bwd_depthgrad_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                           const float* __restrict__ d_a, const int32_t* __restrict__ cls,
+                                           const int32_t* __restrict__ dch, int F, int is, int NC, int nch,
+                                           const float* __restrict__ gout, const SceneStats* __restrict__ st,
+                                           float* __restrict__ gd) {
+  const int b = blockIdx.y;
+  const long plane = (long)is * is;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= plane) return;
+  const long q = b * plane + p;
+  const int y = (int)(p / is), x = (int)(p % is);
+  float g = 0.f;
+  if (!(d_a[q] > 15.f)) {
+    const float wall_max = wall_max_of(st[b]);
+    const long o = ((long)b * nch * is + (is - 1 - y)) * is + x;      // channel 0
+    g = gout[o];
+    const int f = fi_b[q];
+    const int c = f >= 0 ? cls[(long)b * F + f] : -1;
+    if (c >= 0 && c < NC && dch[c] >= 0 && class_image_value(val[3 * q]) > 0.1f) {
+      g += gout[o + (long)(41 + dch[c]) * plane] / wall_max;
+      if (st[b].cnt[c] > 0.0) g += (float)(st[b].gsum[c] / st[b].cnt[c]) / wall_max;
+    }
+  }
+  gd[q] = g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sln_scene_workspace_bytes(int B, int F, int image_size) {
+  const int64_t plane = (int64_t)image_size * image_size;
+  // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture
+  return (int64_t)sizeof(FaceRec) * B * F + sizeof(SceneStats) * B + B * plane * (4 + 12 + 4) * 2 + B * plane * 12 + B * plane * 4 +
+         (int64_t)B * F * 24 * 4 + 4096;
+}
+
+struct SceneWs { FaceRec* rec; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones; };
+
+static SceneWs carve_scene(void* ws, int B, int F, int is) {
+  char* p = static_cast<char*>(ws);
+  auto take = [&](size_t n) { char* r = p; p += (n + 255) & ~size_t(255); return r; };
+  const size_t plane = (size_t)is * is;
+  SceneWs w;
+  w.rec = (FaceRec*)take(sizeof(FaceRec) * B * F); w.st = (SceneStats*)take(sizeof(SceneStats) * B);
+  w.fiA = (int32_t*)take(4 * B * plane); w.wA = (float*)take(12 * B * plane); w.dA = (float*)take(4 * B * plane);
+  w.fiB = (int32_t*)take(4 * B * plane); w.wB = (float*)take(12 * B * plane); w.dB = (float*)take(4 * B * plane);
+  w.val = (float*)take(12 * B * plane); w.gd = (float*)take(4 * B * plane); w.ones = (float*)take((size_t)B * F * 24 * 4);
+  return w;
+}
+
+__global__ void fill_ones_kernel(float* p, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 1.0f;
+}
+
+int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                      const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                      float far, float tex_eps, void* workspace, float* final_out, void* stream) {
+  if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !final_out) return SLN_E_BADARG;
+  if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int is = image_size;
+  const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
+  SceneWs w = carve_scene(workspace, B, F, is);
+  SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 70.0 * 4.0 * npix, st);
+  hipLaunchKernelGGL(scene_init_stats_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, st, w.st, B);
+  hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, is, w.rec);
+  hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n * 24 + 255) / 256)), dim3(256), 0, st, w.ones, n * 24);
+  const int tiles = sln_cdiv(is, TS) * sln_cdiv(is, TS);
+  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, F, is, near_depth, near_rgb, far,
+                     w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB);
+  hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
+                     w.dB, F, is, 2, tex_eps, npix, w.val);
+  // wall_max starts at -inf surrogate
+  hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st);
+  hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), 70, B), dim3(256), 0, st, w.fiB, w.val, w.dA,
+                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                       const int32_t* class_channel, const int32_t* class_depth_channel, float pix_eps, void* workspace,
+                       const float* grad_final, float* grad_faces, void* stream) {
+  if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !grad_final || !grad_faces) return SLN_E_BADARG;
+  if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int is = image_size;
+  const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
+  SceneWs w = carve_scene(workspace, B, F, is);
+  SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
+  hipError_t e = hipMemsetAsync(grad_faces, 0, sizeof(float) * 9 * n, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(scene_bwd_stats_kernel, dim3(16, num_classes, B), dim3(256), 0, st, w.fiB, w.val, face_class,
+                     class_depth_channel, F, is, num_classes, 70, grad_final, w.st);
+  hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
+                     face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
+  hipLaunchKernelGGL(depth_backward_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.fiA, w.wA, w.dA, w.gd,
+                     F, is, npix, grad_faces);
+  PixClass pix; pix.fi = w.fiB; pix.val = w.val; pix.vstride = 3; pix.cls = face_class; pix.gfinal = grad_final;
+  pix.chan = class_channel; pix.F = F; pix.is = is; pix.nch = 70;
+  // class_channel holds NYU indices 0..39; the class images live in final channels 1..40
+  pix.gfinal = grad_final + plane;       // shift by one channel so that chan[c] indexes directly
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n), dim3(64), 0, st, faces, w.fiB, pix, F, is, pix_eps,
+                     grad_faces);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

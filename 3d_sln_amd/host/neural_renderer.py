@@ -1,0 +1,147 @@
+"""HIP-backed stand-in for the slice of the third-party ``neural_renderer`` package that the reference
+uses (``import neural_renderer as nr``, models/misc.py:7):
+
+    renderer = nr.Renderer(camera_mode='projection', image_size=256, K=K, R=R, t=t, anti_aliasing=False,
+                           orig_size=512, near=0.001, light_intensity_ambient=1.0,
+                           light_intensity_directional=0.0)              # models/diff_render.py:359-361
+    depth  = renderer(vertices, faces, textures, mode='depth')           # :366   -> [B, is, is]
+    images = renderer(vertices, faces, textures, mode="rgb")             # :398   -> [B, 3, is, is]
+
+Camera projection, fill_back and the vertex->face gather are a handful of small torch ops (autograd
+carries them); rasterisation, texture sampling and both backward passes are HIP kernels behind the
+C ABI (include/sln_hip.h, csrc/raster.hip).  Semantics: oracle/raster_ref.cpp ("parity unpinned").
+To drop it into the reference: ``sys.modules['neural_renderer'] = this module``.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def projection(vertices, K, R, t, dist_coeffs=None, orig_size=512, eps=1e-9):
+    """Pinhole projection to NDC with the reference README's patch applied (no distortion, README.md:12-18)."""
+    v = torch.matmul(vertices, R.transpose(2, 1)) + t
+    x, y, z = v[:, :, 0], v[:, :, 1], v[:, :, 2]
+    h = torch.stack([x / (z + eps), y / (z + eps), torch.ones_like(z)], dim=-1)
+    h = torch.matmul(h, K.transpose(1, 2))
+    u, vv = h[:, :, 0], orig_size - h[:, :, 1]
+    u = 2 * (u - orig_size / 2.) / orig_size
+    vv = 2 * (vv - orig_size / 2.) / orig_size
+    return torch.stack([u, vv, z], dim=-1)
+
+
+def vertices_to_faces(vertices, faces):
+    B, V = vertices.shape[:2]
+    idx = faces.long() + (torch.arange(B, dtype=torch.int64, device=vertices.device) * V)[:, None, None]
+    return vertices.reshape(B * V, 3)[idx]
+
+
+class _RasterizeDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, faces, image_size, near, far):
+        L = _lib.lib()
+        faces = faces.contiguous()
+        B, F = faces.shape[0], faces.shape[1]
+        dev = faces.device
+        fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device=dev)
+        w = torch.empty(B, image_size, image_size, 3, device=dev)
+        d = torch.empty(B, image_size, image_size, device=dev)
+        ws = _ws(L.sln_raster_workspace_bytes(B, F), dev)
+        _lib.check(L.sln_raster_forward(_lib.ptr(faces), B, F, image_size, near, far, _lib.ptr(ws), _lib.ptr(fi), _lib.ptr(w),
+                                        _lib.ptr(d), _lib.current_stream_ptr()), "sln_raster_forward")
+        ctx.save_for_backward(faces, fi, w, d)
+        ctx.image_size = image_size
+        return d.clone()
+
+    @staticmethod
+    def backward(ctx, gd):
+        faces, fi, w, d = ctx.saved_tensors
+        B, F = faces.shape[0], faces.shape[1]
+        g = torch.zeros_like(faces)
+        _lib.check(_lib.lib().sln_raster_backward_depth(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(w), _lib.ptr(d),
+                                                        _lib.ptr(gd.contiguous()), B, F, ctx.image_size, _lib.ptr(g),
+                                                        _lib.current_stream_ptr()), "sln_raster_backward_depth")
+        return g, None, None, None
+
+
+class _RasterizeRgb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, faces, textures, image_size, near, far, eps):
+        L = _lib.lib()
+        faces, textures = faces.contiguous(), textures.contiguous().float()
+        B, F = faces.shape[0], faces.shape[1]
+        dev = faces.device
+        fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device=dev)
+        w = torch.empty(B, image_size, image_size, 3, device=dev)
+        d = torch.empty(B, image_size, image_size, device=dev)
+        rgb = torch.empty(B, image_size, image_size, 3, device=dev)
+        ws = _ws(L.sln_raster_workspace_bytes(B, F), dev)
+        st = _lib.current_stream_ptr()
+        _lib.check(L.sln_raster_forward(_lib.ptr(faces), B, F, image_size, near, far, _lib.ptr(ws), _lib.ptr(fi), _lib.ptr(w),
+                                        _lib.ptr(d), st), "sln_raster_forward")
+        _lib.check(L.sln_raster_texture_sample(_lib.ptr(faces), _lib.ptr(textures), _lib.ptr(fi), _lib.ptr(w), _lib.ptr(d), B, F,
+                                               image_size, textures.shape[2], eps, _lib.ptr(rgb), st), "sln_raster_texture_sample")
+        ctx.save_for_backward(faces, fi, rgb)
+        ctx.image_size, ctx.eps = image_size, eps
+        ctx.maps = (fi, w, d)
+        return rgb.clone()
+
+    @staticmethod
+    def backward(ctx, grgb):
+        faces, fi, rgb = ctx.saved_tensors
+        B, F = faces.shape[0], faces.shape[1]
+        g = torch.zeros_like(faces)
+        _lib.check(_lib.lib().sln_raster_backward_rgb(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(rgb), _lib.ptr(grgb.contiguous()), B,
+                                                      F, ctx.image_size, 3, ctx.eps, _lib.ptr(g), _lib.current_stream_ptr()),
+                   "sln_raster_backward_rgb")
+        return g, None, None, None, None, None     # textures do not require grad in the reference (diff_render.py:397)
+
+
+class Renderer:
+    """Constructor / call signature of ``neural_renderer.Renderer`` restricted to what the reference passes."""
+
+    def __init__(self, image_size=256, anti_aliasing=True, background_color=(0, 0, 0), fill_back=True,
+                 camera_mode='projection', K=None, R=None, t=None, dist_coeffs=None, orig_size=1024, perspective=True,
+                 viewing_angle=30, camera_direction=(0, 0, 1), near=0.1, far=100, light_intensity_ambient=0.5,
+                 light_intensity_directional=0.5, light_color_ambient=(1, 1, 1), light_color_directional=(1, 1, 1),
+                 light_direction=(0, 1, 0)):
+        if camera_mode != 'projection':
+            raise NotImplementedError("only camera_mode='projection' is on the HIP path (the reference uses nothing else)")
+        if anti_aliasing:
+            raise NotImplementedError("anti_aliasing=True is not used by the reference (diff_render.py:360)")
+        if tuple(background_color) != (0, 0, 0) or light_intensity_directional != 0.0:
+            raise NotImplementedError("the reference renders with ambient light only on a black background")
+        self.image_size, self.fill_back, self.K, self.R, self.t = image_size, fill_back, K, R, t
+        self.orig_size, self.near, self.far = orig_size, near, far
+        self.light_intensity_ambient, self.rasterizer_eps = light_intensity_ambient, 1e-3
+
+    def __call__(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        return self.render(vertices, faces, textures, mode, K, R, t, orig_size)
+
+    def render(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None, orig_size=None):
+        K = self.K if K is None else K
+        R = self.R if R is None else R
+        t = self.t if t is None else t
+        orig_size = self.orig_size if orig_size is None else orig_size
+        if vertices.device.type != 'cuda':
+            raise _lib.SlnError("the rasterizer runs on the MI355X only (no CPU fallback)")
+        if self.fill_back:
+            faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)
+        v = projection(vertices.float(), K, R, t, None, orig_size)
+        fxyz = vertices_to_faces(v, faces)
+        if mode == 'depth':
+            # the package's render_depth does not forward near/far: library defaults apply
+            d = _RasterizeDepth.apply(fxyz, self.image_size, 0.1, 100.0)
+            return torch.flip(d, dims=[1])
+        if mode in ('rgb', None):
+            if self.fill_back:
+                textures = torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)
+            textures = textures * self.light_intensity_ambient          # ambient-only lighting, white light
+            rgb = _RasterizeRgb.apply(fxyz, textures, self.image_size, float(self.near), float(self.far), self.rasterizer_eps)
+            return torch.flip(rgb.permute(0, 3, 1, 2), dims=[2])
+        raise NotImplementedError("mode=%r (the reference uses 'depth' and 'rgb')" % (mode,))

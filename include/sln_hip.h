@@ -167,6 +167,48 @@ int sln_linear_forward(const float* x, int M, int K, const float* W, const float
 /*   dW[N,K] += g[R,N]^T x[R,K];  db[N] += colsum(g) */
 int sln_linear_wgrad(const float* g, const float* x, int R, int N, int K, float* dW, float* db, void* stream);
 
+
+/* =============================================================================================
+ * B. Differentiable rasterizer  (third-party `neural_renderer`, un-vendored; reference call sites
+ *    models/misc.py:7, models/diff_render.py:359-361 (ctor), :366 (mode='depth'), :398 (mode="rgb"))
+ *
+ * The host mirror does the camera projection / fill_back / vertices_to_faces with torch ops; the C ABI
+ * starts at faces[B, F, 3, 3] fp32 = (x_ndc, y_ndc, z_cam) of the three vertices of every face.
+ * All maps are [B, is, is] in RASTER order (row 0 = bottom; the package flips rows afterwards).
+ * ============================================================================================= */
+int64_t sln_raster_workspace_bytes(int B, int F);
+/* rasterize / rasterize_depth: face_index int32 (-1 = background), weight [B,is,is,3], depth (far where empty) */
+int sln_raster_forward(const float* faces, int B, int F, int image_size, float near, float far, void* workspace,
+                       int32_t* face_index, float* weight, float* depth, void* stream);
+/* one geometry pass, two z-buffers with different near planes (depth pass 0.1 / rgb passes ctor value) */
+int sln_raster_forward_dual(const float* faces, int B, int F, int image_size, float near_a, float near_b, float far,
+                            void* workspace, int32_t* fi_a, float* w_a, float* d_a, int32_t* fi_b, float* w_b,
+                            float* d_b, void* stream);
+/* forward_texture_sampling: textures [B,F,ts,ts,ts,3] -> rgb [B,is,is,3] (background 0) */
+int sln_raster_texture_sample(const float* faces, const float* textures, const int32_t* face_index, const float* weight,
+                              const float* depth, int B, int F, int image_size, int texture_size, float eps, float* rgb,
+                              void* stream);
+/* backward_depth_map: grad_faces[B,F,3,3] += ... (atomics) */
+int sln_raster_backward_depth(const float* faces, const int32_t* face_index, const float* weight, const float* depth,
+                              const float* grad_depth, int B, int F, int image_size, float* grad_faces, void* stream);
+/* backward_pixel_map for a `channels`-channel image rgb/grad_rgb [B,is,is,channels]: grad_faces += ... */
+int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const float* rgb, const float* grad_rgb, int B,
+                            int F, int image_size, int channels, float eps, float* grad_faces, void* stream);
+
+/* Fused scene pass = models/diff_render.py:359-434 (1 depth + one rgb pass per class, masks, per-class mean
+ * depth, wall_max normalisation, 70-channel layout) in ONE rasterisation.
+ *   face_class [B,F] int32: class id (0 = wall, ids follow the reference's sorted class list) or -1
+ *   class_channel [num_classes]: NYU-40 index of each class (final channel 1 + index)
+ *   class_depth_channel [num_classes]: index into the 29 depth channels (final channel 41 + index) or -1
+ *   final_out [B,70,is,is] image order (rows flipped), grad_faces [B,F,3,3] (overwritten). */
+int64_t sln_scene_workspace_bytes(int B, int F, int image_size);
+int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                      const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                      float far, float tex_eps, void* workspace, float* final_out, void* stream);
+int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                       const int32_t* class_channel, const int32_t* class_depth_channel, float pix_eps, void* workspace,
+                       const float* grad_final, float* grad_faces, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,137 @@
+"""GPU parity tests of the differentiable rasterizer (run with -m gpu).
+
+Checker: oracle/raster_ref.{cpp,py} - the CPU restatement that defines the semantics ("parity unpinned",
+the third-party neural_renderer package is absent).  Indices must be bit-exact, floats within 1e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raster_ref as rr       # noqa: E402
+
+
+def _faces_of_room(seed, target_faces, image_size):
+    V, F, ranges, box = rr.synth_room(seed, n_objects=12 if target_faces > 500 else 4, target_faces=target_faces)
+    K, R, t = rr.get_cam_mat(torch.from_numpy(box))
+    v = torch.from_numpy(V)[None]
+    f = torch.from_numpy(F)[None]
+    f2 = torch.cat((f, f[:, :, [2, 1, 0]]), 1)
+    fxyz = rr.vertices_to_faces(rr.project(v, K, R, t, 512), f2)
+    return fxyz.contiguous(), (V, F, ranges, box)
+
+
+def _hip_forward(fxyz, image_size, near, far):
+    L = pkg("_lib")
+    fd = fxyz.cuda().contiguous()
+    B, F = fd.shape[:2]
+    fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device="cuda")
+    w = torch.empty(B, image_size, image_size, 3, device="cuda"); d = torch.empty(B, image_size, image_size, device="cuda")
+    ws = torch.empty(int(L.lib().sln_raster_workspace_bytes(B, F)), dtype=torch.uint8, device="cuda")
+    L.check(L.lib().sln_raster_forward(L.ptr(fd), B, F, image_size, near, far, L.ptr(ws), L.ptr(fi), L.ptr(w), L.ptr(d),
+                                       L.current_stream_ptr()), "fwd")
+    return fd, fi, w, d
+
+
+@pytest.mark.parametrize("image_size,target", [(256, 2000), (64, 300), (100, 700)])
+def test_forward_bit_exact(image_size, target):
+    fx = torch.cat([_faces_of_room(s, target, image_size)[0] for s in (1, 2)], 0) if target != 700 else _faces_of_room(5, target, image_size)[0]
+    rfi, rw, rd = rr.nmr_forward(fx.numpy(), image_size, 0.001, 100.0)
+    fd, fi, w, d = _hip_forward(fx, image_size, 0.001, 100.0)
+    assert (fi.cpu().numpy() == rfi).all(), "face index map differs at %d pixels" % int((fi.cpu().numpy() != rfi).sum())
+    assert (rfi >= 0).mean() > 0.5
+    assert (w.cpu().numpy() == rw).all() and (d.cpu().numpy() == rd).all()
+
+
+def test_random_soup_bit_exact_and_ties():
+    rng = np.random.default_rng(0)
+    F = 1500
+    xy = rng.uniform(-1.2, 1.2, size=(1, F, 1, 2)) + rng.uniform(-0.25, 0.25, size=(1, F, 3, 2))
+    z = rng.choice([0.5, 1.0, 2.0, 3.0], size=(1, F, 1, 1)) * np.ones((1, F, 3, 1))      # many equal depths -> ties
+    f = np.concatenate([xy, z], -1).astype(np.float32)
+    f[0, :50] = f[0, 50:100]                                                             # exact duplicates
+    rfi, rw, rd = rr.nmr_forward(f, 128, 0.1, 100.0)
+    _, fi, w, d = _hip_forward(torch.from_numpy(f), 128, 0.1, 100.0)
+    assert (fi.cpu().numpy() == rfi).all()
+    assert (d.cpu().numpy() == rd).all()
+
+
+def test_texture_sampling_and_backwards():
+    L = pkg("_lib")
+    IS = 128
+    fx, _ = _faces_of_room(3, 600, IS)
+    fd, fi, w, d = _hip_forward(fx, IS, 0.001, 100.0)
+    B, F = fd.shape[:2]
+    rng = np.random.default_rng(1)
+    tex = rng.uniform(0, 1, size=(B, F, 2, 2, 2, 3)).astype(np.float32)
+    rgb = torch.empty(B, IS, IS, 3, device="cuda")
+    L.check(L.lib().sln_raster_texture_sample(L.ptr(fd), L.ptr(torch.from_numpy(tex).cuda()), L.ptr(fi), L.ptr(w), L.ptr(d), B, F,
+                                              IS, 2, 1e-3, L.ptr(rgb), L.current_stream_ptr()), "tex")
+    rfi, rw, rd = rr.nmr_forward(fx.numpy(), IS, 0.001, 100.0)
+    rrgb = rr.nmr_texture_sample(fx.numpy(), tex, rfi, rw, rd)
+    assert_close(rgb.cpu().numpy(), rrgb, "rgb", rtol=1e-6, atol=1e-7)
+    # depth backward
+    gd = rng.standard_normal((B, IS, IS)).astype(np.float32)
+    g = torch.zeros(B, F, 3, 3, device="cuda")
+    L.check(L.lib().sln_raster_backward_depth(L.ptr(fd), L.ptr(fi), L.ptr(w), L.ptr(d), L.ptr(torch.from_numpy(gd).cuda()), B, F, IS,
+                                              L.ptr(g), L.current_stream_ptr()), "bd")
+    rg = rr.nmr_backward_depth(fx.numpy(), rfi, rw, rd, gd)
+    assert_close(g.cpu().numpy(), rg, "grad depth", rtol=1e-4, atol=1e-4 * np.abs(rg).max())
+    # rgb pixel-map backward
+    grgb = rng.standard_normal((B, IS, IS, 3)).astype(np.float32)
+    g2 = torch.zeros(B, F, 3, 3, device="cuda")
+    L.check(L.lib().sln_raster_backward_rgb(L.ptr(fd), L.ptr(fi), L.ptr(rgb), L.ptr(torch.from_numpy(grgb).cuda()), B, F, IS, 3, 1e-3,
+                                            L.ptr(g2), L.current_stream_ptr()), "br")
+    rg2 = rr.nmr_backward_pixel_map(fx.numpy(), rfi, rrgb, grgb)
+    assert np.abs(rg2).max() > 0
+    assert_close(g2.cpu().numpy(), rg2, "grad rgb", rtol=1e-4, atol=1e-4 * np.abs(rg2).max())
+
+
+def test_renderer_class_matches_restated_renderer():
+    NR = pkg("host.neural_renderer")
+    V, F, ranges, box = rr.synth_room(4, n_objects=6, target_faces=400)
+    K, R, t = rr.get_cam_mat(torch.from_numpy(box))
+    ref = rr.RefRenderer(image_size=96, K=K, R=R, t=t, orig_size=512, near=0.001)
+    hip = NR.Renderer(camera_mode='projection', image_size=96, K=K.cuda(), R=R.cuda(), t=t.cuda(), anti_aliasing=False,
+                      orig_size=512, near=0.001, light_intensity_ambient=1.0, light_intensity_directional=0.0)
+    f = torch.from_numpy(F)[None]
+    tex = torch.zeros(1, F.shape[0], 2, 2, 2, 3); tex[:, ::2] = 1.0
+    for mode in ("depth", "rgb"):
+        v1 = torch.from_numpy(V)[None].requires_grad_(True)
+        v2 = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+        o1 = ref(v1, f, tex, mode=mode)
+        o2 = hip(v2, f.cuda(), tex.cuda(), mode=mode)
+        assert_close(o2.detach().cpu().numpy(), o1.detach().numpy(), mode, rtol=1e-5, atol=1e-6)
+        gen = torch.Generator().manual_seed(0)
+        go = torch.randn(o1.shape, generator=gen)
+        (o1 * go).sum().backward(); (o2 * go.cuda()).sum().backward()
+        assert_close(v2.grad.cpu().numpy(), v1.grad.numpy(), mode + " dV", rtol=1e-4, atol=1e-4 * v1.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("image_size,target", [(96, 500), (256, 2000)])
+def test_fused_scene_matches_33_pass_restatement(image_size, target):
+    DR = pkg("host.diff_render")
+    V, F, ranges, box = rr.synth_room(7, n_objects=12 if target > 1000 else 5, target_faces=target)
+    v1 = torch.from_numpy(V)[None].requires_grad_(True)
+    ref = rr.scene_render(v1, torch.from_numpy(F)[None], ranges, torch.from_numpy(box), image_size=image_size)
+    v2 = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+    out = DR.scene_render(v2, torch.from_numpy(F)[None].cuda(), ranges, torch.from_numpy(box), image_size=image_size)
+    assert out.shape == (1, 70, image_size, image_size)
+    o, r = out.detach().cpu().numpy(), ref.detach().numpy()
+    assert (np.abs(o[0, 1:41] - r[0, 1:41]) > 1e-6).sum() == 0, "class images differ"
+    assert_close(o, r, "final", rtol=1e-5, atol=1e-5)
+    gen = torch.Generator().manual_seed(1)
+    go = torch.randn(ref.shape, generator=gen)
+    (ref * go).sum().backward()
+    (out * go.cuda()).sum().backward()
+    assert_close(v2.grad.cpu().numpy(), v1.grad.numpy(), "dV", rtol=1e-4, atol=2e-4 * v1.grad.abs().max().item())
+    if image_size <= 96:
+        v3 = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+        out3 = DR.scene_render_passes(v3, torch.from_numpy(F)[None].cuda(), ranges, torch.from_numpy(box), image_size=image_size)
+        assert_close(out3.detach().cpu().numpy(), r, "passes", rtol=1e-5, atol=1e-5)
+        (out3 * go.cuda()).sum().backward()
+        assert_close(v3.grad.cpu().numpy(), v1.grad.numpy(), "dV passes", rtol=1e-4, atol=2e-4 * v1.grad.abs().max().item())
