@@ -40,3 +40,62 @@ def default_vocab(num_objs=32, num_preds=16, num_attrs=5):
     return {"object_idx_to_name": ["__room__"] + ["type%02d" % i for i in range(1, num_objs)],
             "pred_idx_to_name": ["pred%02d" % i for i in range(num_preds)],
             "attrib_idx_to_name": ["attr%d" % i for i in range(num_attrs)]}
+
+
+# ----------------------------------------------------------------------------------------------
+# synthetic rooms for the renderer path (BASELINE configs[2]: 16 rooms x ~2k triangles): cuboid furniture
+# on the floor + floor / ceiling / three walls, every quad split into a grid of triangles.  Stand-in for the
+# SUNCG meshes that models/misc.py retrieves (licensed data, out of scope); same buffers as diff_render.py:344.
+# ----------------------------------------------------------------------------------------------
+FURNITURE = ['cabinet', 'bed', 'chair', 'sofa', 'table', 'bookshelf', 'desk', 'shelves', 'dresser', 'night_stand',
+             'television', 'lamp', 'toilet', 'sink', 'bathtub', 'counter', 'refridgerator', 'mirror', 'picture', 'box',
+             'bag', 'books', 'clothes', 'pillow', 'towel', 'paper', 'whiteboard', 'otherprop', 'otherfurniture']
+
+
+def _grid_quad(p0, du, dv, n):
+    a = np.linspace(0, 1, n + 1)
+    g = p0[None, None] + a[:, None, None] * du[None, None] + a[None, :, None] * dv[None, None]
+    idx = np.arange((n + 1) * (n + 1)).reshape(n + 1, n + 1)
+    q = np.stack([idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]], -1).reshape(-1, 4)
+    return g.reshape(-1, 3), np.concatenate([q[:, [0, 1, 2]], q[:, [0, 2, 3]]], 0)
+
+
+def _grid_cuboid(lo, hi, n):
+    lo, hi = np.asarray(lo, np.float64), np.asarray(hi, np.float64)
+    d = hi - lo
+    ex, ey, ez = np.array([d[0], 0, 0]), np.array([0, d[1], 0]), np.array([0, 0, d[2]])
+    vs, fs, off = [], [], 0
+    for p0, du, dv in [(lo, ey, ex), (lo + ez, ex, ey), (lo, ex, ez), (lo + ey, ez, ex), (lo, ez, ey), (lo + ex, ey, ez)]:
+        v, f = _grid_quad(p0, du, dv, n)
+        vs.append(v); fs.append(f + off); off += v.shape[0]
+    return np.concatenate(vs), np.concatenate(fs)
+
+
+def synthetic_room(seed, n_objects=12, target_faces=2000, room=(4.0, 2.7, 5.0)):
+    """-> vertices [V,3] f32, faces [F,3] i32, class_ranges {class: [[a,b],..]} (all 32 classes as keys), room_box [6]."""
+    rng = np.random.default_rng(seed)
+    room = np.asarray(room, np.float64)
+    ranges = {c: [] for c in FURNITURE}
+    ranges.update(wall=[], floor=[], ceiling=[])
+    vs, fs, voff, foff = [], [], 0, 0
+
+    def add(v, f, name):
+        nonlocal voff, foff
+        vs.append(v); fs.append(f + voff)
+        ranges[name].append([foff, foff + f.shape[0]])
+        voff += v.shape[0]; foff += f.shape[0]
+    sub = 2 if target_faces >= 1500 else 1
+    for nm in rng.choice(FURNITURE, size=n_objects, replace=False):
+        size = rng.uniform([0.4, 0.3, 0.4], [1.2, 1.6, 1.2])
+        pos = rng.uniform([0.1, 0.0, 0.3], [room[0] - size[0] - 0.1, 0.0, room[2] - size[2] - 1.2])
+        add(*_grid_cuboid(pos, pos + size, sub), str(nm))
+    shell = [("floor", np.zeros(3), np.array([0, 0, room[2]]), np.array([room[0], 0, 0])),
+             ("ceiling", np.array([0, room[1], 0]), np.array([room[0], 0, 0]), np.array([0, 0, room[2]])),
+             ("wall", np.zeros(3), np.array([room[0], 0, 0]), np.array([0, room[1], 0])),
+             ("wall", np.zeros(3), np.array([0, room[1], 0]), np.array([0, 0, room[2]])),
+             ("wall", np.array([room[0], 0, 0]), np.array([0, 0, room[2]]), np.array([0, room[1], 0]))]
+    per = max(1, int(round(np.sqrt(max(target_faces - foff, 10) / (2.0 * len(shell))))))
+    for nm, p0, du, dv in shell:
+        add(*_grid_quad(p0, du, dv, per), nm)
+    return (np.concatenate(vs).astype(np.float32), np.concatenate(fs).astype(np.int32), ranges,
+            np.array([0, 0, 0, room[0], room[1], room[2]], np.float32))

@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-steps", type=int, default=30)
     ap.add_argument("--prof-steps", type=int, default=5)
+    ap.add_argument("--rooms", type=int, default=16, help="rooms per render batch (BASELINE configs[2])")
+    ap.add_argument("--tris", type=int, default=2000)
+    ap.add_argument("--render-iters", type=int, default=50)
+    ap.add_argument("--no-render", action="store_true")
     return ap.parse_args()
 
 
@@ -53,6 +57,68 @@ def prof_read(lib):
     ms = (C.c_double * n)(); work = (C.c_double * n)(); cnt = (C.c_int64 * n)()
     lib.check(lib.lib().sln_prof_read(ms, work, cnt, n), "sln_prof_read")
     return {FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n) if cnt[i]}
+
+
+def render_leg(args, lib, torch, rank):
+    """BASELINE configs[2]: differentiable render of `rooms` synthetic rooms x ~`tris` triangles at 256x256,
+    forward (70-channel scene tensor of mesh_render_func) + backward to the vertices, fused HIP pass."""
+    DR = importlib.import_module("3d_sln_amd.host.diff_render")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    dev = "cuda"
+    rooms = [syn.synthetic_room(100 + rank * 64 + i, n_objects=12, target_faces=args.tris) for i in range(args.rooms)]
+    Vmax = max(r[0].shape[0] for r in rooms)
+    prepared, Fmax, tri_count = [], 0, 0
+    for V, F, ranges, box in rooms:
+        v = torch.zeros(1, Vmax, 3); v[0, :V.shape[0]] = torch.from_numpy(V)
+        K, R, t = DR.get_cam_mat(torch.from_numpy(box), "cpu")
+        faces, cls, classes, chan, dch = DR.cull_and_classify(torch.from_numpy(V)[None], torch.from_numpy(F)[None], ranges, R, t)
+        tri_count += faces.shape[1]
+        faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), 1)[0]; cls = torch.cat((cls, cls))
+        prepared.append((v[0], faces, cls, K[0], R[0], t[0])); Fmax = max(Fmax, faces.shape[0])
+    Vb = torch.stack([p[0] for p in prepared]).to(dev).requires_grad_(True)
+    Fb = torch.zeros(args.rooms, Fmax, 3, dtype=torch.int32); Cb = torch.full((args.rooms, Fmax), -1, dtype=torch.int32)
+    for i, p in enumerate(prepared):
+        Fb[i, :p[1].shape[0]] = p[1]; Cb[i, :p[2].shape[0]] = p[2]
+    Fb, Cb = Fb.to(dev), Cb.to(dev)
+    Kb = torch.stack([p[3] for p in prepared]).to(dev); Rb = torch.stack([p[4] for p in prepared]).to(dev)
+    tb = torch.stack([p[5] for p in prepared]).to(dev)
+    chan_t = torch.tensor(chan, dtype=torch.int32, device=dev); dch_t = torch.tensor(dch, dtype=torch.int32, device=dev)
+    gout = torch.randn(args.rooms, 70, 256, 256, device=dev)
+
+    def it():
+        Vb.grad = None
+        out = DR.scene_render_batch(Vb, Fb, Cb, chan_t, dch_t, Kb, Rb, tb, 256, 0.001)
+        out.backward(gout)
+        return out
+    for _ in range(5):
+        out = it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.render_iters):
+        it()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.check(lib.lib().sln_prof_enable(1), "prof")
+    for _ in range(5):
+        it()
+    torch.cuda.synchronize()
+    fam = prof_read(lib)
+    lib.check(lib.lib().sln_prof_enable(0), "prof")
+    per_render = dt / args.render_iters / args.rooms
+    res = {"renders_per_s": round(1.0 / per_render, 1), "ms_per_room_fwd_bwd": round(per_render * 1e3, 4),
+           "nmr_equivalent_raster_passes_per_s": round(33.0 / per_render, 1),
+           "workload": "BASELINE configs[2]: %d rooms x %d triangles (%.0f after near-plane cull, x2 fill_back), 256x256, "
+                       "70-channel scene tensor fwd + bwd to vertices" % (args.rooms, args.tris, tri_count / args.rooms),
+           "covered_pixels": round(float((out[:, 0] > 0).float().mean().item()), 3)}
+    bytes_per_render = 2 * 70 * 256 * 256 * 4 + 2 * (tri_count / args.rooms) * 36 * 2     # SURVEY.md 8d: out + grad + faces
+    for k, name in (("raster_fwd", "scene_forward"), ("raster_bwd", "scene_backward")):
+        if k in fam:
+            ms = fam[k]["ms"] / fam[k]["launches"]
+            algo = (70 * 256 * 256 * 4 + (tri_count / args.rooms) * 72) * args.rooms
+            res[name] = {"avg_ms_per_batch": round(ms, 4), "gbs_algorithmic": round(algo / (ms * 1e-3) / 1e9, 1),
+                         "frac_hbm": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    res["algorithmic_bytes_per_render"] = int(bytes_per_render)
+    return res
 
 
 def main():
@@ -136,6 +202,8 @@ def main():
                    "parallelism": "dp%d" % world, "final_total_loss": round(final_loss, 5)},
     }
 
+    if rank == 0 and not args.no_render:
+        out["render"] = render_leg(args, lib, torch, rank)
     if rank == 0 and args.prof_steps <= 0:
         print(json.dumps(out))
     elif rank == 0:
