@@ -1,0 +1,167 @@
+"""Training loop of the scene-graph VAE on MI355X: counterpart of the reference's ``train.py`` (:10-122).
+
+Single GPU:   python -m 3d_sln_amd.host.train ...        (module name is not an identifier: use
+              ``python 3d_sln_amd/host/train.py`` or ``runpy``)
+One node, N GPUs (the reference asserts ``Multi-GPU not supported``, build_dataset_model.py:54-55):
+              python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+                     3d_sln_amd/host/train.py --batch_size 512
+
+Data parallelism: one process per GPU; every rank owns a contiguous block of whole scene graphs
+(graphs never share rows, data/suncg_dataset.py:318-325), runs the fused forward/loss/backward, then
+ONE all-reduce (RCCL over xGMI; ``backend='nccl'``) of the flat 15.5 MB fp32 gradient buffer, divides by
+the world size and applies the fused Adam.  BatchNorm statistics stay per replica (standard DDP
+semantics; a shard of 64 graphs behaves exactly like a single-GPU run at batch 64).
+
+Flag names follow options/options.py:20-57.  The SUNCG metadata is not distributable, so batches come
+from ``synthetic.scene_graph_batch`` unless a ``batch_fn`` is supplied.
+"""
+import argparse
+import math
+import os
+import sys
+from collections import defaultdict
+
+import torch
+import torch.distributed as dist
+
+if __package__ in (None, ""):                      # executed as a script
+    import importlib
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    synthetic = importlib.import_module("3d_sln_amd.host.synthetic")
+else:
+    from . import synthetic
+
+
+def bool_flag(s):
+    if s in ('1', '0'):
+        return s == '1'
+    raise ValueError('Invalid value "%s" for bool flag (should be 0 or 1)' % s)
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument('--embedding_dim', default=64, type=int)
+    p.add_argument('--gconv_mode', default='feedforward')
+    p.add_argument('--gconv_num_layers', default=5, type=int)
+    p.add_argument('--mlp_normalization', default='batch', type=str)
+    p.add_argument('--vec_noise_dim', default=0, type=int)
+    p.add_argument('--layout_noise_dim', default=32, type=int)
+    p.add_argument('--batch_size', default=128, type=int, help="GLOBAL batch (scene graphs per step over all GPUs)")
+    p.add_argument('--num_iterations', default=600000, type=int)
+    p.add_argument('--eval_mode_after', default=-1, type=int)
+    p.add_argument('--learning_rate', default=1e-4, type=float)
+    p.add_argument('--print_every', default=100, type=int)
+    p.add_argument('--checkpoint_every', default=1000, type=int)
+    p.add_argument('--snapshot_every', default=10000, type=int)
+    p.add_argument('--output_dir', default='./checkpoints')
+    p.add_argument('--checkpoint_name', default='latest_checkpoint')
+    p.add_argument('--restore_from_checkpoint', default=False, type=bool_flag)
+    p.add_argument('--KL_loss_weight', default=0.1, type=float)
+    p.add_argument('--use_AE', default=False, type=bool_flag)
+    p.add_argument('--decoder_cat', default=True, type=bool_flag)
+    p.add_argument('--train_3d', default=True, type=bool_flag)
+    p.add_argument('--KL_linear_decay', default=False, type=bool_flag)
+    p.add_argument('--manual_seed', default=42, type=int)
+    p.add_argument('--objs_per_graph', default=32, type=int)
+    p.add_argument('--triples_per_graph', default=64, type=int)
+    return p
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of whole graphs owned by ``rank`` (remainder spread over the first ranks)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class FlatGradAllReduce:
+    """The ONE collective of a data-parallel step: sum the flat fp32 gradient buffer, divide by world size."""
+
+    def __init__(self, world):
+        self.world = world
+
+    def __call__(self, flat_grads):
+        if self.world > 1:
+            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+            flat_grads.mul_(1.0 / self.world)
+        return flat_grads
+
+
+def kl_weight_at(args, t):
+    return 10 ** (t // 1e5 - 6) if args.KL_linear_decay else args.KL_loss_weight        # train.py:73-76
+
+
+def train(args, model, batch_fn, rank=0, world=1, log=print):
+    """train.py:56-114.  ``model`` exposes train_step(..., with_adam=False) / adam_step / flat_params / flat_grads
+    (Sg2ScVAEModel on the GPU; tests plug a CPU stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs."""
+    reduce_grads = FlatGradAllReduce(world)
+    if world > 1:
+        dist.broadcast(model.flat_params, 0)                      # identical replicas
+        if hasattr(model, "params_changed"):
+            model.params_changed()
+    lo, hi = shard_range(args.batch_size, rank, world)
+    checkpoint = {'args': dict(vars(args)), 'losses_ts': [], 'losses': defaultdict(list), 'checkpoint_ts': [],
+                  'counters': {'t': None, 'epoch': None}, 'model_state': None, 'optim_state': None}
+    t = 0
+    while t < args.num_iterations:
+        if t == args.eval_mode_after:
+            model.eval()
+        t += 1
+        b = batch_fn(t, lo, hi)
+        w = kl_weight_at(args, t)
+        if world == 1:
+            losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
+                                      lr=args.learning_rate, with_adam=True)
+        else:
+            losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
+                                      lr=args.learning_rate, with_adam=False)
+            reduce_grads(model.flat_grads)
+            model.adam_step(lr=args.learning_rate)
+        if t % args.print_every == 0 or t == args.num_iterations:
+            vals = [float(x) for x in losses.detach().cpu()]          # the only host sync, every print_every steps
+            if not math.isfinite(vals[3]):
+                log('WARNING: Got loss = NaN')                       # train.py:79-81 (the fused step has already been applied)
+            if rank == 0:
+                log("On batch {} out of {}".format(t, args.num_iterations))
+                for name, v in zip(('bbox_pred', 'angle_pred', 'KLD_Gauss', 'total_loss'), vals):
+                    log(' [%s]: %.4f' % (name, v))
+                    checkpoint['losses'][name].append(v)
+                checkpoint['losses_ts'].append(t)
+        if rank == 0 and t % args.checkpoint_every == 0:
+            checkpoint['model_state'] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            checkpoint['counters']['t'] = t
+            os.makedirs(args.output_dir, exist_ok=True)
+            torch.save(checkpoint, os.path.join(args.output_dir, 'latest_%s_with_model.pt' % args.checkpoint_name))
+    return checkpoint
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.manual_seed(args.manual_seed)
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    import importlib
+    M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
+    model = M.Sg2ScVAEModel(vocab=synthetic.default_vocab(), batch_size=args.batch_size, train_3d=args.train_3d,
+                            decoder_cat=args.decoder_cat, embedding_dim=args.embedding_dim, gconv_mode=args.gconv_mode,
+                            gconv_num_layers=args.gconv_num_layers, mlp_normalization=args.mlp_normalization,
+                            vec_noise_dim=args.vec_noise_dim, layout_noise_dim=args.layout_noise_dim,
+                            use_AE=args.use_AE).cuda().train()
+
+    def batch_fn(t, lo, hi):
+        return synthetic.scene_graph_batch(hi - lo, args.objs_per_graph, args.triples_per_graph, seed=t * 100003 + lo,
+                                           box_dim=6 if args.train_3d else 4, device="cuda")
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        train(args, model, batch_fn, rank, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,126 @@
+"""World-size-2 test of the data-parallel step on CPU (gloo): sharding of whole scene graphs across ranks,
+ONE all-reduce of the flat gradient buffer, identical replicas after the update.  The compute on each rank is
+the CPU oracle (the HIP model cannot run without a GPU); what is under test is host/train.py's plumbing."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, pkg
+
+from oracle import vae_ref
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+class CpuStandIn:
+    """Same surface as Sg2ScVAEModel for train(): flat_params / flat_grads / train_step(with_adam) / adam_step."""
+
+    def __init__(self, cfg, seed):
+        self.cfg, self.sd = cfg, vae_ref.init_state(cfg, seed)
+        self.keys = vae_ref.trainable_keys(cfg)
+        self.sizes = [self.sd[k].numel() for k in self.keys]
+        self.flat_params = torch.cat([self.sd[k].reshape(-1) for k in self.keys]).clone()
+        self.flat_grads = torch.zeros_like(self.flat_params)
+        self.m = torch.zeros_like(self.flat_params); self.v = torch.zeros_like(self.flat_params); self.t = 0
+        self._views()
+
+    def _views(self):
+        o = 0
+        for k, n in zip(self.keys, self.sizes):
+            self.sd[k] = self.flat_params[o:o + n].view(self.sd[k].shape); o += n
+
+    def params_changed(self):
+        self._views()
+
+    def train(self):
+        return self
+
+    def state_dict(self):
+        return self.sd
+
+    def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, with_adam=True, eps=None):
+        for k in self.keys:
+            self.sd[k].requires_grad_(True); self.sd[k].grad = None
+        eps = torch.zeros(objs.shape[0], self.cfg.embedding_dim)
+        mu, lv, bp, ap = vae_ref.forward(self.sd, self.cfg, objs, triples, boxes, angles, attributes, eps, True)
+        total, parts = vae_ref.losses(self.cfg, boxes, bp, angles, ap, mu, lv, kl_weight)
+        grads = torch.autograd.grad(total, [self.sd[k] for k in self.keys], allow_unused=True)
+        for k in self.keys:
+            self.sd[k].requires_grad_(False)
+        self.flat_grads.copy_(torch.cat([(g if g is not None else torch.zeros(n)).reshape(-1) for g, n in zip(grads, self.sizes)]))
+        if with_adam:
+            self.adam_step(lr)
+        return torch.stack([parts["bbox_pred"], parts["angle_pred"], parts.get("KLD_Gauss", torch.zeros(())), total]).detach()
+
+    def adam_step(self, lr=1e-4):
+        self.t += 1
+        g = self.flat_grads
+        self.m.mul_(0.9).add_(g, alpha=0.1); self.v.mul_(0.999).addcmul_(g, g, value=0.001)
+        denom = (self.v.sqrt() / (1 - 0.999 ** self.t) ** 0.5).add_(1e-8)
+        self.flat_params.addcdiv_(self.m, denom, value=-lr / (1 - 0.9 ** self.t))
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    model = CpuStandIn(cfg, seed=5 + rank)                       # different init: the broadcast must fix it
+    args = T.build_parser().parse_args(["--batch_size", "24", "--num_iterations", "1", "--print_every", "1000"])
+    full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
+
+    def batch_fn(t, lo, hi):
+        o0, o1, t0, t1 = lo * 5, hi * 5, lo * 8, hi * 8
+        tr = full[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+        return dict(objs=full[0][o0:o1], triples=tr, boxes=full[2][o0:o1], angles=full[3][o0:o1], attributes=full[4][o0:o1])
+    T.train(args, model, batch_fn, rank, world, log=lambda *_: None)
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), model.flat_params.numpy())
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), model.flat_grads.numpy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_gradient_average(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert (p0 == p1).all() and (g0 == g1).all(), "replicas diverged"
+    # single-process recomputation: average of the two shard gradients, two steps
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    ref = CpuStandIn(cfg, seed=5)
+    full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
+    for _ in range(1):
+        gs = []
+        for rank in range(2):
+            lo, hi = T.shard_range(24, rank, 2)
+            o0, o1, t0, t1 = lo * 5, hi * 5, lo * 8, hi * 8
+            tr = full[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+            ref.train_step(full[0][o0:o1], tr, full[2][o0:o1], full[3][o0:o1], full[4][o0:o1], with_adam=False)
+            gs.append(ref.flat_grads.clone())
+        ref.flat_grads.copy_((gs[0] + gs[1]) / 2)
+        ref.adam_step(1e-4)
+    # averaged gradient of the last step (tight); parameters: Adam turns the rounding noise of exactly-zero
+    # gradients (biases in front of BatchNorm) into +-lr steps, so bound those and require the bulk to agree
+    gr = ref.flat_grads.numpy()
+    assert np.abs(g0 - gr).max() <= 1e-4 * np.abs(gr).max() + 1e-7
+    d = np.abs(p0 - ref.flat_params.numpy())
+    assert d.max() <= 2.05 * 1e-4 and np.mean(d > 1e-6) < 0.08
+
+
+def test_shard_ranges_cover_batch():
+    T = pkg("host.train")
+    for n, w in ((512, 8), (10, 3), (7, 8), (64, 1)):
+        r = [T.shard_range(n, k, w) for k in range(w)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
