@@ -94,6 +94,16 @@ SIGNATURES = {
     "sln_scene_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sln_scene_forward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_spade_conv": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_float, c_f32p, C.c_void_p]),
+    "sln_spade_modulate": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,
+                                     C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "sln_layernorm_stats": (C.c_int, [c_f32p, C.c_int, C.c_int64, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_resize": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "sln_spade_depth_concat": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "sln_se_scale_add": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_upsample2x": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "sln_conv_img_tanh": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
 }

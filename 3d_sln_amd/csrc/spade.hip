@@ -1,0 +1,490 @@
+// SPADEGenerator4 forward (reference models/SPADE_related.py:70-85,128-149,1404-1605) on gfx950.
+//
+// 152.6 GMAC per 256x256 image, 98 % of it 3x3 reflect-padded convolutions, 72 % in the per-SPADE
+// gamma/beta/shared convs whose outputs only exist to modulate the normalised activation.  The workhorse
+// is one implicit-GEMM kernel on v_mfma_f32_32x32x2_f32 (exact fp32, the 1e-4 budget of the north star
+// leaves no room for bf16):
+//     out[co, pixel] = sum_{ci, tap} Wp[tap][ci][co] * x[ci, reflect(pixel + tap)]
+//   * M = output channels (A operand = packed weights), N = pixels (B operand = activations): the MFMA
+//     result then has lanes = 32 consecutive pixels, i.e. coalesced NCHW stores and epilogue loads;
+//   * a workgroup owns an (8 x 16)-pixel patch x 128 (or 64) channels; per chunk of 8 input channels it stages
+//     the (8+2)x(16+2) halo once in LDS and reuses it for all 9 taps (9x fewer global loads than im2col)
+//     together with the [9][8][channels] weight slab; next chunk is prefetched into registers during the
+//     144 MFMAs of the current one;
+//   * epilogues: bias + {none, ReLU, LeakyReLU(s)}; or the SPADE modulation - the gamma and beta channels
+//     of one feature land in the same lane/register of two accumulators (weights are packed [32 gamma | 32
+//     beta] per 64 rows), so out = (x - mu_b) * inv_b * (1 + gamma) + beta [-> LeakyReLU(0.2)] is computed in
+//     registers and gamma/beta never touch HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sln_hip.h"
+#include "sln_common.h"
+#include "sln_prof.h"
+
+namespace {
+
+constexpr int CK = 8;                  // input channels per LDS chunk
+constexpr int TH = 8, TW = 16;         // pixel patch per workgroup (128 pixels)
+constexpr int HALO = (TH + 2) * (TW + 2);
+
+enum { CEPI_BIAS_ACT = 0, CEPI_MODULATE = 1 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+
+struct ConvArgs {
+  const float* x;        // [B, Cin, H, W]
+  const float* wp;       // packed weights [KS*KS][Cin][rows_pad]
+  const float* bias;     // [rows_pad] packed like the rows (or nullptr)
+  float* y;              // BIAS_ACT: [B, Cout, H, W];  MODULATE: [B, C, H, W]
+  int B, Cin, H, W, rows, rows_pad;   // rows = logical output rows (Cout, or 2C packed for MODULATE)
+  int act; float slope;
+  // MODULATE
+  const float* xin;      // tensor being normalised [B, C, H, W]
+  const float* stats;    // [B, 2] = (mean, 1/(std+eps))
+  int C;
+};
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {      // ReflectionPad2d(1) (pad < n)
+  i = i < 0 ? -i : i;
+  return i >= n ? 2 * n - 2 - i : i;
+}
+
+// BMC: channels (rows) per block (64 or 128); KS: 1 or 3.  4 waves: WM x WN over (rows, pixels).
+template <int BMC, int KS, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int TAPS = KS * KS;
+  constexpr int WM = BMC / 64;                 // waves along rows (each wave: 64 rows = 2 tiles)
+  constexpr int WN = 4 / WM;                   // waves along pixels
+  constexpr int TN = 128 / WN / 32;            // pixel tiles per wave (128 pixels per block)
+  constexpr int TM = 2;
+  constexpr int HS = KS == 3 ? HALO : TH * TW; // floats per channel in the LDS patch
+  constexpr int WSLAB = TAPS * CK * BMC;
+  constexpr int NW4 = (WSLAB / 4 + 255) / 256; // float4 weight loads per thread per chunk (tail slots clamped)
+  constexpr int NH = (CK * HS + 255) / 256;    // scalar patch loads per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                             // [TAPS][CK][BMC]
+  float* xl = lds + WSLAB;                     // [CK][HS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int r0 = blockIdx.y * BMC;             // first packed row of this block
+  const int x0 = tx * TW, y0 = ty * TH;
+  const size_t plane = (size_t)a.H * a.W;
+  const float* xb = a.x + (size_t)b * a.Cin * plane;
+
+  // per-thread patch positions (constant over chunks): element e -> (channel-in-chunk, pos) -> global offset
+  int h_off[NH], h_lds[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int e = tid + 256 * j;
+    const int c = e / HS, p = e % HS;
+    int gy, gx;
+    if (KS == 3) { gy = reflect_idx(y0 + p / (TW + 2) - 1, a.H); gx = reflect_idx(x0 + p % (TW + 2) - 1, a.W); }
+    else { gy = min(y0 + p / TW, a.H - 1); gx = min(x0 + p % TW, a.W - 1); }
+    gy = min(max(gy, 0), a.H - 1); gx = min(max(gx, 0), a.W - 1);
+    h_off[j] = e < CK * HS ? (int)(c * plane + (size_t)gy * a.W + gx) : 0;     // tail slots load a valid address, never stored
+    h_lds[j] = e;
+  }
+  float hreg[NH];
+  float4 wreg[NW4];
+  const int nchunks = (a.Cin + CK - 1) / CK;
+
+  auto gload = [&](int ch) {
+    const int ci0 = ch * CK;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int c = min((tid + 256 * j) / HS, CK - 1);
+      // unconditional load (clamped channel); surplus channels / tail slots are dropped at the LDS store
+      const int cc = min(ci0 + c, a.Cin - 1) - c;
+      hreg[j] = xb[(ptrdiff_t)cc * (ptrdiff_t)plane + h_off[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e4 = min(tid + 256 * j, WSLAB / 4 - 1);     // float4 index inside the slab [TAPS][CK][BMC/4]
+      const int col4 = e4 % (BMC / 4), rr = e4 / (BMC / 4); // rr = tap*CK + c
+      const int tap = rr / CK, c = rr % CK;
+      const int ci = min(ci0 + c, a.Cin - 1);
+      wreg[j] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Cin + ci) * a.rows_pad + r0 + 4 * col4);
+    }
+  };
+  auto lstore = [&](int ch) {
+    const int ci0 = ch * CK;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int e = h_lds[j];
+      if (e < CK * HS) xl[e] = (ci0 + e / HS) < a.Cin ? hreg[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e4 = tid + 256 * j;
+      const int c = (e4 / (BMC / 4)) % CK;
+      float4 v = wreg[j];
+      if (ci0 + c >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e4 < WSLAB / 4) *reinterpret_cast<float4*>(wl + 4 * e4) = v;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wr = (wave / WN) * 64;                 // wave's first row inside the block
+  const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
+  const int li = lane & 31, lk = lane >> 5;
+  // pixel of this lane for pixel-tile j: m = wp0 + 32 j + li -> (py, px)
+  int pbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int m = wp0 + 32 * j + li;
+    pbase[j] = KS == 3 ? (m / TW) * (TW + 2) + (m % TW) : m;
+  }
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) gload(ch + 1);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int toff = KS == 3 ? (tap / 3) * (TW + 2) + (tap % 3) : 0;
+#pragma unroll
+      for (int kk = 0; kk < CK; kk += 2) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = wl[(tap * CK + kk + lk) * BMC + wr + 32 * i + li];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                     // everyone done reading the LDS slab
+    if (ch + 1 < nchunks) { lstore(ch + 1); __syncthreads(); }
+  }
+
+  // ---- epilogue: lane = pixel (li), register r = row (r&3) + 8 (r>>2) + 4 lk inside the 32-row tile
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int m = wp0 + 32 * j + li;
+    const int py = y0 + m / TW, px = x0 + m % TW;
+    const bool pv = py < a.H && px < a.W;
+    const size_t pix = (size_t)py * a.W + px;
+    if (EPI == CEPI_BIAS_ACT) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          if (pv && row < a.rows) {
+            float v = acc[i][j][r] + (a.bias ? a.bias[row] : 0.f);
+            if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
+            else if (a.act == ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
+            a.y[((size_t)b * a.rows + row) * plane + pix] = v;
+          }
+        }
+    } else {
+      // rows of this wave: [32 gamma | 32 beta] of channels cbase .. cbase+31
+      const int cbase = (r0 + wr) / 2;
+      const float mean = a.stats[2 * b], inv = a.stats[2 * b + 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const int c = cbase + cl;
+        if (pv && c < a.C) {
+          const float gamma = acc[0][j][r] + a.bias[r0 + wr + cl];
+          const float beta = acc[1][j][r] + a.bias[r0 + wr + 32 + cl];
+          const size_t o = ((size_t)b * a.C + c) * plane + pix;
+          float v = (a.xin[o] - mean) * inv;
+          v = v * (1.f + gamma) + beta;
+          if (a.act == ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
+          a.y[o] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BMC, int KS, int EPI>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int TAPS = KS * KS;
+  constexpr int HS = KS == 3 ? HALO : TH * TW;
+  const size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
+  static bool raised = false;
+  if (!raised && smem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BMC, KS, EPI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B;
+  hipLaunchKernelGGL((conv_mfma_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ acc) {
+  const int b = blockIdx.y;
+  const float* xb = x + (size_t)b * n;
+  double s = 0.0, q = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const double v = xb[i];
+    s += v; q += v * v;
+  }
+  __shared__ double rs[256], rq[256];
+  rs[threadIdx.x] = s; rq[threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { atomicAdd(acc + 2 * b, rs[0]); atomicAdd(acc + 2 * b + 1, rq[0]); }
+}
+__global__ void ln_finalize_kernel(const double* __restrict__ acc, long n, int B, float eps, float* __restrict__ stats) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double mean = acc[2 * b] / (double)n;
+  double var = (acc[2 * b + 1] - (double)n * mean * mean) / (double)(n - 1);     // unbiased (torch.std default)
+  var = var < 0.0 ? 0.0 : var;
+  stats[2 * b] = (float)mean;
+  stats[2 * b + 1] = 1.0f / ((float)sqrt(var) + eps);                           // LayerNorm2D adds eps to sigma
+}
+
+// F.interpolate(seg, size) : mode 0 nearest (src = floor(dst * in/out)), mode 1 bilinear align_corners=False
+__global__ void resize_kernel(const float* __restrict__ src, int C, int Hi, int Wi, int Ho, int Wo, int mode, long n,
+                              float* __restrict__ dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+  const long bc = i / ((long)Wo * Ho);
+  const float* s = src + bc * (long)Hi * Wi;
+  if (mode == 0) {
+    const int ys = min((int)floorf(yo * ((float)Hi / Ho)), Hi - 1), xs = min((int)floorf(xo * ((float)Wi / Wo)), Wi - 1);
+    dst[i] = s[(long)ys * Wi + xs];
+    return;
+  }
+  const float sy = (float)Hi / Ho, sx = (float)Wi / Wo;
+  float fy = (yo + 0.5f) * sy - 0.5f, fx = (xo + 0.5f) * sx - 0.5f;
+  fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+  const int ya = min((int)fy, Hi - 1), xa = min((int)fx, Wi - 1);
+  const int yb = min(ya + 1, Hi - 1), xb = min(xa + 1, Wi - 1);
+  const float ly = fy - ya, lx = fx - xa;
+  dst[i] = (1.f - ly) * ((1.f - lx) * s[(long)ya * Wi + xa] + lx * s[(long)ya * Wi + xb]) +
+           ly * ((1.f - lx) * s[(long)yb * Wi + xa] + lx * s[(long)yb * Wi + xb]);
+  (void)C;
+}
+
+// [leaky_0.01(conv3x3_reflect(seg[:,0], 1->nd)) | seg[:,1:]]  ->  out [B, nd + Cs - 1, H, W]   (SPADE4 :1445-1446)
+__global__ void depth_concat_kernel(const float* __restrict__ seg, int Cs, int H, int W, const float* __restrict__ wpd,
+                                    const float* __restrict__ bpd, int nd, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const int Co = nd + Cs - 1;
+  const int c = (int)((i / ((long)W * H)) % Co);
+  const long b = i / ((long)W * H * Co);
+  const float* sb = seg + b * (long)Cs * H * W;
+  if (c >= nd) { out[i] = sb[(long)(c - nd + 1) * H * W + (long)y * W + x]; return; }
+  float v = bpd[c];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+      v = fmaf(wpd[c * 9 + ky * 3 + kx], sb[(long)reflect_idx(y + ky - 1, H) * W + reflect_idx(x + kx - 1, W)], v);
+  out[i] = v > 0.f ? v : 0.01f * v;
+}
+
+__global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restrict__ out) {   // one block per (b, c)
+  const float* p = x + (size_t)blockIdx.x * hw;
+  float s = 0.f;
+  for (long i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (float)hw;
+}
+// scale[b, :] = sigmoid(W2 relu(W0 gap[b, :]))   (SEBlock2, :70-85; reduction 8)
+__global__ void se_fc_kernel(const float* __restrict__ gap, const float* __restrict__ w0, const float* __restrict__ w2, int C,
+                             int Cr, float* __restrict__ scale) {
+  extern __shared__ float sm[];
+  float* g = sm; float* hdn = sm + C;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gap[(size_t)b * C + c];
+  __syncthreads();
+  for (int r = threadIdx.x; r < Cr; r += blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s = fmaf(w0[(size_t)r * C + c], g[c], s);
+    hdn[r] = fmaxf(s, 0.f);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < Cr; ++r) s = fmaf(w2[(size_t)c * Cr + r], hdn[r], s);
+    scale[(size_t)b * C + c] = 1.f / (1.f + expf(-s));
+  }
+}
+__global__ void se_scale_add_kernel(const float* __restrict__ xs, const float* __restrict__ dx, const float* __restrict__ scale,
+                                    long hw, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = xs[i] + dx[i] * scale[i / hw];
+}
+
+// nn.Upsample(scale_factor=2): mode 0 nearest, mode 1 bilinear (align_corners=False)
+__global__ void upsample2x_kernel(const float* __restrict__ x, int H, int W, int mode, long n, float* __restrict__ y) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+  const float* s = x + (i / ((long)Wo * Ho)) * (long)H * W;
+  if (mode == 0) { y[i] = s[(long)(yo >> 1) * W + (xo >> 1)]; return; }
+  float fy = (yo + 0.5f) * 0.5f - 0.5f, fx = (xo + 0.5f) * 0.5f - 0.5f;
+  fy = fy < 0.f ? 0.f : fy; fx = fx < 0.f ? 0.f : fx;
+  const int ya = min((int)fy, H - 1), xa = min((int)fx, W - 1), yb = min(ya + 1, H - 1), xb = min(xa + 1, W - 1);
+  const float ly = fy - ya, lx = fx - xa;
+  y[i] = (1.f - ly) * ((1.f - lx) * s[(long)ya * W + xa] + lx * s[(long)ya * W + xb]) +
+         ly * ((1.f - lx) * s[(long)yb * W + xa] + lx * s[(long)yb * W + xb]);
+}
+
+// tanh(conv5x5_zero_pad(leaky_0.2(x)))  (:1602-1603); Cout is tiny (3): plain FMA, weights in LDS
+__global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ x, int Cin, int H, int W,
+                                                       const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                       float* __restrict__ y) {
+  extern __shared__ float ws[];                 // [Cout][Cin][25]
+  for (int i = threadIdx.x; i < Cout * Cin * 25; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const long plane = (long)H * W;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= plane) return;
+  const int yy = (int)(p / W), xx = (int)(p % W);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int ci = 0; ci < Cin; ++ci) {
+    const float* xc = x + ((size_t)b * Cin + ci) * plane;
+#pragma unroll
+    for (int ky = 0; ky < 5; ++ky) {
+      const int sy = yy + ky - 2;
+      if (sy < 0 || sy >= H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 5; ++kx) {
+        const int sx = xx + kx - 2;
+        if (sx < 0 || sx >= W) continue;
+        float v = xc[(long)sy * W + sx];
+        v = v > 0.f ? v : 0.2f * v;
+        for (int co = 0; co < Cout; ++co) acc[co] = fmaf(ws[(co * Cin + ci) * 25 + ky * 5 + kx], v, acc[co]);
+      }
+    }
+  }
+  for (int co = 0; co < Cout; ++co) y[((size_t)b * Cout + co) * plane + p] = tanhf(acc[co] + bias[co]);
+}
+
+}  // namespace
+
+extern "C" {
+
+// conv KSxKS (KS = 3 reflect pad 1, KS = 1) with packed weights wp[KS*KS][Cin][rows_pad]; rows_pad % 64 == 0.
+int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
+                   int ksize, int act, float slope, float* y, void* stream) {
+  if (!x || !wp || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || rows <= 0 || rows_pad % 64 != 0 || rows > rows_pad) return SLN_E_BADARG;
+  if (ksize != 1 && ksize != 3) return SLN_E_UNSUPPORTED;
+  if (ksize == 3 && (H < 2 || W < 2)) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  ConvArgs a; a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = rows; a.rows_pad = rows_pad;
+  a.act = act; a.slope = slope; a.xin = nullptr; a.stats = nullptr; a.C = 0;
+  SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * ksize * ksize * rows, st);
+  const bool big = rows_pad % 128 == 0;
+  if (ksize == 3) return big ? launch_conv<128, 3, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 3, CEPI_BIAS_ACT>(a, st);
+  return big ? launch_conv<128, 1, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 1, CEPI_BIAS_ACT>(a, st);
+}
+
+// out = LN(xin) * (1 + gamma) + beta [-> LeakyReLU(slope) when act == 2], gamma/beta = conv3x3_reflect(actv) with
+// weights packed [32 gamma | 32 beta] per 64 rows (rows_pad = 64 * ceil(C / 32)).
+int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
+                       const float* xin, const float* stats, int act, float slope, float* out, void* stream) {
+  if (!actv || !wp || !bias || !xin || !stats || !out || B <= 0 || C <= 0 || rows_pad % 64 != 0 || rows_pad < 64 * ((C + 31) / 32))
+    return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  ConvArgs a; a.x = actv; a.wp = wp; a.bias = bias; a.y = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = 2 * C; a.rows_pad = rows_pad;
+  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C;
+  SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * 9 * 2 * C, st);
+  return rows_pad % 128 == 0 ? launch_conv<128, 3, CEPI_MODULATE>(a, st) : launch_conv<64, 3, CEPI_MODULATE>(a, st);
+}
+
+// stats[b] = (mean, 1/(std_unbiased + eps)) over the n = C*H*W elements of sample b; scratch: 2*B doubles
+int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream) {
+  if (!x || !scratch || !stats || B <= 0 || n < 2) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B, st);
+  if (e != hipSuccess) return (int)e;
+  int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+  hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, B, eps, stats);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mode, float* dst, void* stream) {
+  if (!src || !dst || BC <= 0) return SLN_E_BADARG;
+  const long n = (long)BC * Ho * Wo;
+  hipLaunchKernelGGL(resize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, 0, Hi, Wi, Ho, Wo, mode,
+                     n, dst);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_spade_depth_concat(const float* seg, int B, int Cs, int H, int W, const float* wpd, const float* bpd, int nd, float* out,
+                           void* stream) {
+  if (!seg || !wpd || !bpd || !out) return SLN_E_BADARG;
+  const long n = (long)B * (nd + Cs - 1) * H * W;
+  hipLaunchKernelGGL(depth_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg, Cs, H, W, wpd, bpd,
+                     nd, n, out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// out = xs + dx * sigmoid(W2 relu(W0 GAP(dx)))      scratch: B*C (gap) + B*C (scale) floats
+int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw, const float* w0, const float* w2, float* scratch,
+                     float* out, void* stream) {
+  if (!xs || !dx || !w0 || !w2 || !scratch || !out || C % 8 != 0) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* gap = scratch; float* scale = scratch + (size_t)B * C;
+  hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, (long)hw, gap);
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, w0, w2, C, C / 8, scale);
+  const long n = (long)B * C * hw;
+  hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xs, dx, scale, (long)hw, n, out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_upsample2x(const float* x, int BC, int H, int W, int mode, float* y, void* stream) {
+  if (!x || !y) return SLN_E_BADARG;
+  const long n = (long)BC * 4 * H * W;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, H, W, mode, n, y);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_conv_img_tanh(const float* x, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout, float* y, void* stream) {
+  if (!x || !w || !bias || !y || Cout > 4 || Cout <= 0) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * H * W * (Cin + Cout), st);
+  hipLaunchKernelGGL(conv_img_kernel, dim3(sln_cdiv(H * W, 256), B), dim3(256), sizeof(float) * Cout * Cin * 25, st, x, Cin, H, W, w,
+                     bias, Cout, y);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+"""HIP-backed drop-in for the part of the reference's ``models/SPADE_related.py`` that is alive:
+``SPADEGenerator4`` (:1507-1605) with ``SPADEResnetBlock4`` (:1457-1505), ``SPADE4`` (:1404-1454),
+``LayerNorm2D`` (:128-149) and ``SEBlock2`` (:70-85) as instantiated by testing/test_SPADE_shade.py:9
+(``SPADEGenerator4(41, 3, 256, 64, 'spectralspadelayer3x3', 256, 'normal')``, inference only, README.md:60-61).
+
+The module tree only owns parameters with the reference's names (230 ``state_dict`` keys incl. the
+spectral-norm triplets ``weight_orig / weight_u / weight_v``) so the authors' ``latest_net_G_AB.pth`` loads
+unchanged; ``forward`` runs on libsln_hip.so (csrc/spade.hip).  Weights are folded (spectral sigma) and packed
+into the kernels' layout once per parameter version.
+"""
+import ctypes as C
+import re
+
+import torch
+import torch.nn as nn
+from torch.nn.utils import spectral_norm
+
+from .. import _lib
+
+NHIDDEN = 128
+
+
+class SEBlock2(nn.Module):
+    def __init__(self, channel, reduction=4):
+        super().__init__()
+        self.fc = nn.Sequential(nn.Linear(channel, channel // reduction, bias=False), nn.ReLU(inplace=True),
+                                nn.Linear(channel // reduction, channel, bias=False), nn.Sigmoid())
+
+
+class SPADE4(nn.Module):
+    def __init__(self, config_text, norm_nc, label_nc):
+        super().__init__()
+        parsed = re.search(r'spade(\D+)(\d)x\d', config_text)
+        if parsed is None or parsed.group(1) != 'layer' or int(parsed.group(2)) != 3:
+            raise NotImplementedError("only 'spadelayer3x3' (LayerNorm2D, 3x3) is on the HIP path: %r" % config_text)
+        self.mlp_preshared_depth = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(1, NHIDDEN // 8, 3), nn.LeakyReLU(inplace=True))
+        self.mlp_shared = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(NHIDDEN // 8 + label_nc - 1, NHIDDEN, 3), nn.ReLU(inplace=True))
+        self.mlp_gamma = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(NHIDDEN, norm_nc, 3))
+        self.mlp_beta = nn.Sequential(nn.ReflectionPad2d(1), nn.Conv2d(NHIDDEN, norm_nc, 3))
+        self.norm_nc = norm_nc
+
+
+class SPADEResnetBlock4(nn.Module):
+    def __init__(self, fin, fout, norm, semantic_nc):
+        super().__init__()
+        if 'spectral' not in norm:
+            raise NotImplementedError("the reference instantiates the spectral variant only")
+        self.fin, self.fout, self.fmiddle = fin, fout, min(fin, fout)
+        self.learned_shortcut = fin != fout
+        self.conv_0 = nn.Sequential(nn.ReflectionPad2d(1), spectral_norm(nn.Conv2d(fin, self.fmiddle, 3)))
+        self.conv_1 = nn.Sequential(nn.ReflectionPad2d(1), spectral_norm(nn.Conv2d(self.fmiddle, fout, 3)))
+        self.se = SEBlock2(fout, reduction=8)
+        if self.learned_shortcut:
+            self.conv_s = spectral_norm(nn.Conv2d(fin, fout, 1, bias=False))
+        cfg = norm.replace('spectral', '')
+        self.norm_0 = SPADE4(cfg, fin, semantic_nc)
+        self.norm_1 = SPADE4(cfg, self.fmiddle, semantic_nc)
+        if self.learned_shortcut:
+            self.norm_s = SPADE4(cfg, fin, semantic_nc)
+
+
+def _fold_sn(sd, prefix):
+    w = sd[prefix + ".weight_orig"]
+    sigma = torch.dot(sd[prefix + ".weight_u"], torch.mv(w.reshape(w.shape[0], -1), sd[prefix + ".weight_v"]))
+    return w / sigma
+
+
+def _pack(w, rows_pad=None):
+    """[Cout, Cin, k, k] -> [k*k, Cin, rows_pad] (rows contiguous, zero padded to a multiple of 64)."""
+    co, ci, k, _ = w.shape
+    rp = rows_pad or (co + 63) // 64 * 64
+    out = torch.zeros(k * k, ci, rp, dtype=torch.float32, device=w.device)
+    out[:, :, :co] = w.permute(2, 3, 1, 0).reshape(k * k, ci, co)
+    return out.contiguous(), rp
+
+
+def _pack_gamma_beta(wg, bg, wb, bb):
+    """rows [64g, 64g+32) = gamma of channels [32g, 32g+32), rows [64g+32, 64g+64) = their beta."""
+    c = wg.shape[0]
+    groups = (c + 31) // 32
+    rp = 64 * groups
+    idx = torch.arange(c, device=wg.device)
+    rg, rb = (idx // 32) * 64 + idx % 32, (idx // 32) * 64 + 32 + idx % 32
+    w = torch.zeros(9, wg.shape[1], rp, dtype=torch.float32, device=wg.device)
+    w[:, :, rg] = wg.permute(2, 3, 1, 0).reshape(9, wg.shape[1], c)
+    w[:, :, rb] = wb.permute(2, 3, 1, 0).reshape(9, wb.shape[1], c)
+    b = torch.zeros(rp, dtype=torch.float32, device=wg.device)
+    b[rg], b[rb] = bg, bb
+    return w.contiguous(), b.contiguous(), rp
+
+
+class SPADEGenerator4(nn.Module):
+    def __init__(self, semantic_nc, target_nc, nz, ngf, norm, crop_size, n_up):
+        super().__init__()
+        if n_up != 'normal':
+            raise NotImplementedError("n_up='more'/'most' crash in the reference itself (self.up is never defined, :1587,1600)")
+        if nz <= 0:
+            raise NotImplementedError("the reference instantiates the z-conditioned generator (nz=256)")
+        nf = ngf
+        self.nf, self.n_up, self.nz, self.has_z = ngf, n_up, nz, True
+        self.semantic_nc, self.target_nc, self.crop_size = semantic_nc, target_nc, crop_size
+        self.sw = self.sh = crop_size // 32
+        self.fc = nn.Linear(nz, 16 * nf * self.sw * self.sh)
+        self.head_0 = SPADEResnetBlock4(16 * nf, 16 * nf, norm, semantic_nc)
+        self.G_middle_0 = SPADEResnetBlock4(16 * nf, 16 * nf, norm, semantic_nc)
+        self.G_middle_1 = SPADEResnetBlock4(16 * nf, 16 * nf, norm, semantic_nc)
+        self.up_0 = SPADEResnetBlock4(16 * nf, 8 * nf, norm, semantic_nc)
+        self.up_1 = SPADEResnetBlock4(8 * nf, 4 * nf, norm, semantic_nc)
+        self.up_2 = SPADEResnetBlock4(4 * nf, 2 * nf, norm, semantic_nc)
+        self.up_3 = SPADEResnetBlock4(2 * nf, 1 * nf, norm, semantic_nc)
+        self.conv_img = nn.Conv2d(nf, target_nc, 5, padding=2)
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ weight packing
+    def _pack_all(self):
+        sd = {k: v.detach().float() for k, v in self.state_dict().items()}
+        key = tuple((v.data_ptr(), v._version) for v in self.state_dict().values())
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        P = {}
+        for name in ("head_0", "G_middle_0", "G_middle_1", "up_0", "up_1", "up_2", "up_3"):
+            blk = getattr(self, name)
+            e = {}
+            for cn in ("conv_0", "conv_1"):
+                w, rp = _pack(_fold_sn(sd, "%s.%s.1" % (name, cn)))
+                b = torch.zeros(rp, device=w.device); b[:sd["%s.%s.1.bias" % (name, cn)].numel()] = sd["%s.%s.1.bias" % (name, cn)]
+                e[cn] = (w, b, rp)
+            if blk.learned_shortcut:
+                w, rp = _pack(_fold_sn(sd, name + ".conv_s"))
+                e["conv_s"] = (w, None, rp)
+            for nn_ in ("norm_0", "norm_1", "norm_s"):
+                if not hasattr(blk, nn_):
+                    continue
+                p = "%s.%s" % (name, nn_)
+                wsh, rps = _pack(sd[p + ".mlp_shared.1.weight"])
+                bsh = torch.zeros(rps, device=wsh.device); bsh[:NHIDDEN] = sd[p + ".mlp_shared.1.bias"]
+                wgb, bgb, rpg = _pack_gamma_beta(sd[p + ".mlp_gamma.1.weight"], sd[p + ".mlp_gamma.1.bias"],
+                                                 sd[p + ".mlp_beta.1.weight"], sd[p + ".mlp_beta.1.bias"])
+                e[nn_] = dict(wpd=sd[p + ".mlp_preshared_depth.1.weight"].reshape(NHIDDEN // 8, 9).contiguous(),
+                              bpd=sd[p + ".mlp_preshared_depth.1.bias"].contiguous(), wsh=wsh, bsh=bsh, rps=rps,
+                              wgb=wgb, bgb=bgb, rpg=rpg)
+            e["se0"], e["se2"] = sd[name + ".se.fc.0.weight"].contiguous(), sd[name + ".se.fc.2.weight"].contiguous()
+            P[name] = e
+        P["fc_w"], P["fc_b"] = sd["fc.weight"].contiguous(), sd["fc.bias"].contiguous()
+        P["img_w"], P["img_b"] = sd["conv_img.weight"].contiguous(), sd["conv_img.bias"].contiguous()
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ HIP launches
+    @staticmethod
+    def _st():
+        return _lib.current_stream_ptr()
+
+    def _ln_stats(self, x):
+        B = x.shape[0]
+        stats = torch.empty(B, 2, device=x.device)
+        scratch = torch.empty(2 * B, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.lib().sln_layernorm_stats(_lib.ptr(x), B, x[0].numel(), 1e-5, _lib.ptr(scratch), _lib.ptr(stats), self._st()),
+                   "sln_layernorm_stats")
+        return stats
+
+    def _spade(self, e, x, stats, seg, leaky):
+        """SPADE4.forward (:1438-1454) + the following actvn (:1503-1505) fused into the modulation conv."""
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        nd = NHIDDEN // 8
+        cat = torch.empty(B, nd + seg.shape[1] - 1, H, W, device=x.device)
+        _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), B, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
+                                            _lib.ptr(cat), self._st()), "sln_spade_depth_concat")
+        actv = torch.empty(B, NHIDDEN, H, W, device=x.device)
+        _lib.check(L.sln_spade_conv(_lib.ptr(cat), B, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
+                                    1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
+        out = torch.empty_like(x)
+        _lib.check(L.sln_spade_modulate(_lib.ptr(actv), B, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), C, e["rpg"],
+                                        _lib.ptr(x), _lib.ptr(stats), 2 if leaky else 0, 0.2, _lib.ptr(out), self._st()),
+                   "sln_spade_modulate")
+        return out
+
+    def _conv(self, x, wbr, cout, ks):
+        w, b, rp = wbr
+        B, _, H, W = x.shape
+        y = torch.empty(B, cout, H, W, device=x.device)
+        _lib.check(_lib.lib().sln_spade_conv(_lib.ptr(x), B, x.shape[1], H, W, _lib.ptr(w), _lib.ptr(b), cout, rp, ks, 0, 0.0,
+                                             _lib.ptr(y), self._st()), "sln_spade_conv")
+        return y
+
+    def _block(self, name, x, seg):
+        """SPADEResnetBlock4.forward (:1487-1502)."""
+        blk, e = getattr(self, name), self._packed[name]
+        stats_x = self._ln_stats(x)                                  # norm_0 and norm_s normalise the same tensor
+        if blk.learned_shortcut:
+            x_s = self._conv(self._spade(e["norm_s"], x, stats_x, seg, leaky=False), e["conv_s"], blk.fout, 1)
+        else:
+            x_s = x
+        dx = self._conv(self._spade(e["norm_0"], x, stats_x, seg, leaky=True), e["conv_0"], blk.fmiddle, 3)
+        dx = self._conv(self._spade(e["norm_1"], dx, self._ln_stats(dx), seg, leaky=True), e["conv_1"], blk.fout, 3)
+        B, Cc, H, W = dx.shape
+        out = torch.empty_like(dx)
+        scratch = torch.empty(2 * B * Cc, device=dx.device)
+        _lib.check(_lib.lib().sln_se_scale_add(_lib.ptr(x_s), _lib.ptr(dx), B, Cc, H * W, _lib.ptr(e["se0"]), _lib.ptr(e["se2"]),
+                                               _lib.ptr(scratch), _lib.ptr(out), self._st()), "sln_se_scale_add")
+        return out
+
+    def _resize(self, t, size, mode):
+        B, Cc, H, W = t.shape
+        if (H, W) == (size, size):
+            return t
+        out = torch.empty(B, Cc, size, size, device=t.device)
+        _lib.check(_lib.lib().sln_resize(_lib.ptr(t), B * Cc, H, W, size, size, mode, _lib.ptr(out), self._st()), "sln_resize")
+        return out
+
+    def _up(self, t, mode):
+        B, Cc, H, W = t.shape
+        out = torch.empty(B, Cc, 2 * H, 2 * W, device=t.device)
+        _lib.check(_lib.lib().sln_upsample2x(_lib.ptr(t), B * Cc, H, W, mode, _lib.ptr(out), self._st()), "sln_upsample2x")
+        return out
+
+    def forward(self, input, z=None, taps=None):
+        """seg [B, semantic_nc, S, S] (channel 0 depth, 1.. masks), z [B, nz] -> image [B, target_nc, S, S] in (-1, 1)."""
+        if input.device.type != 'cuda':
+            raise _lib.SlnError("SPADEGenerator4 runs on the MI355X only (no CPU fallback)")
+        with torch.no_grad():
+            seg = input.float().contiguous()
+            B = seg.shape[0]
+            if z is None:
+                print("Missing z vector, sampling from normal")
+                z = torch.randn(B, self.nz, dtype=torch.float32, device=seg.device)
+            P = self._pack_all()
+            L = _lib.lib()
+            nfc = 16 * self.nf * self.sw * self.sh
+            x = torch.empty(B, nfc, device=seg.device)
+            _lib.check(L.sln_linear_forward(_lib.ptr(z.float().contiguous()), B, self.nz, _lib.ptr(P["fc_w"]), _lib.ptr(P["fc_b"]),
+                                            _lib.ptr(x), nfc, None, -1, self._st()), "sln_linear_forward(fc)")
+            x = x.view(B, 16 * self.nf, self.sh, self.sw)
+            S = seg.shape[2]
+            pyr = {S: seg}
+            for r in (self.sw * 2, self.sw * 4, self.sw * 8, self.sw * 16):
+                pyr[r] = self._resize(seg, r, 1)                      # SPADE4's bilinear resize of the full-size map (:1444)
+            seg_1 = self._resize(seg, self.sw, 0)                     # nearest (:1579); SPADE4's bilinear to the same size is identity
+
+            def run(name, t, s):
+                t = self._block(name, t, s)
+                if taps is not None:
+                    taps[name] = t
+                return t
+            x = run("head_0", x.contiguous(), seg_1)
+            x = run("G_middle_0", self._up(x, 0), pyr[self.sw * 2])
+            x = run("G_middle_1", x, pyr[self.sw * 2])
+            x = run("up_0", self._up(x, 0), pyr[self.sw * 4])
+            x = run("up_1", self._up(x, 0), pyr[self.sw * 8])
+            x = run("up_2", self._up(x, 0), pyr[self.sw * 16])
+            x = run("up_3", self._up(x, 1), pyr[S])
+            out = torch.empty(B, self.target_nc, S, S, device=seg.device)
+            _lib.check(L.sln_conv_img_tanh(_lib.ptr(x), B, self.nf, S, S, _lib.ptr(P["img_w"]), _lib.ptr(P["img_b"]), self.target_nc,
+                                           _lib.ptr(out), self._st()), "sln_conv_img_tanh")
+            return out

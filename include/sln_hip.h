@@ -209,6 +209,36 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                        const int32_t* class_channel, const int32_t* class_depth_channel, float pix_eps, void* workspace,
                        const float* grad_final, float* grad_faces, void* stream);
 
+
+/* =============================================================================================
+ * C. SPADE generator (models/SPADE_related.py: SPADEGenerator4 :1507-1605, SPADEResnetBlock4 :1457-1505,
+ *    SPADE4 :1404-1454, LayerNorm2D :128-149, SEBlock2 :70-85; driver testing/test_SPADE_shade.py:9-13,77-79)
+ * Tensors are NCHW fp32.  Conv weights are PRE-PACKED by the host once per checkpoint:
+ *   wp[ks*ks][Cin][rows_pad] (output rows contiguous, rows_pad % 64 == 0), spectral norm already folded
+ *   (W = W_orig / (u . (W_mat v))); for the modulation conv the rows of gamma and beta are interleaved in
+ *   groups of 32: rows [64 g, 64 g + 32) = gamma of channels [32 g, 32 g + 32), the next 32 rows their beta.
+ * ============================================================================================= */
+/* y = act(conv_ks(x) + bias): ks = 3 (ReflectionPad2d(1)) or 1; act 0 none, 1 ReLU, 2 LeakyReLU(slope) */
+int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
+                   int ksize, int act, float slope, float* y, void* stream);
+/* SPADE4 tail fused: out = LayerNorm2D(xin) * (1 + gamma) + beta [LeakyReLU(slope) when act == 2] with
+ * [gamma | beta] = conv3x3_reflect(actv); stats[b] = (mean, 1 / (std + eps)) from sln_layernorm_stats */
+int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
+                       const float* xin, const float* stats, int act, float slope, float* out, void* stream);
+int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream);
+/* F.interpolate(size=...): mode 0 nearest, 1 bilinear(align_corners=False) over BC planes */
+int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mode, float* dst, void* stream);
+/* [LeakyReLU_0.01(conv3x3_reflect(seg[:,0:1])) | seg[:,1:]] (SPADE4.mlp_preshared_depth + cat, :1445-1446) */
+int sln_spade_depth_concat(const float* seg, int B, int Cs, int H, int W, const float* wpd, const float* bpd, int nd, float* out,
+                           void* stream);
+/* x_s + SEBlock2(dx) (:1492-1493); scratch 2*B*C floats */
+int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw, const float* w0, const float* w2, float* scratch,
+                     float* out, void* stream);
+/* nn.Upsample(scale_factor=2): mode 0 nearest, 1 bilinear */
+int sln_upsample2x(const float* x, int BC, int H, int W, int mode, float* y, void* stream);
+/* tanh(conv5x5_zero_pad(LeakyReLU_0.2(x))) (:1602-1603); w [Cout,Cin,5,5], Cout <= 4 */
+int sln_conv_img_tanh(const float* x, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

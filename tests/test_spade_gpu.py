@@ -1,0 +1,103 @@
+"""GPU parity tests of the SPADE generator path (run with -m gpu): csrc/spade.hip through the C ABI against the
+CPU oracle (oracle/spade_ref.py) and the fixtures produced by the reference's own SPADEGenerator4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, pkg
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+from oracle import spade_ref                       # noqa: E402
+from oracle.gen_golden_spade import CASES          # noqa: E402
+
+
+def _checks(t):
+    t = t.detach().double().cpu()
+    return np.array([t.sum().item(), t.abs().sum().item(), (t * t).sum().item()])
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(2, 56, 128, 16, 16, 3), (1, 128, 64, 40, 24, 3), (2, 16, 8, 8, 8, 3),
+                                                (1, 64, 32, 2, 2, 3), (2, 128, 64, 16, 32, 1), (1, 8, 200, 9, 17, 3)])
+def test_conv_against_torch_cpu(B, Cin, Cout, H, W, ks):
+    L = pkg("_lib"); S = pkg("host.SPADE_related")
+    g = torch.Generator().manual_seed(Cin * 31 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect") if ks == 3 else x, w, b)
+    for act, fn in ((0, lambda t: t), (1, F.relu), (2, lambda t: F.leaky_relu(t, 0.2))):
+        wp, rp = S._pack(w.cuda())
+        bp = torch.zeros(rp, device="cuda"); bp[:Cout] = b.cuda()
+        y = torch.empty(B, Cout, H, W, device="cuda")
+        L.check(L.lib().sln_spade_conv(L.ptr(x.cuda()), B, Cin, H, W, L.ptr(wp), L.ptr(bp), Cout, rp, ks, act, 0.2, L.ptr(y),
+                                       L.current_stream_ptr()), "conv")
+        assert_close(y.cpu().numpy(), fn(ref).numpy(), "conv act=%d" % act, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 16, 16), (8, 8, 24), (100, 10, 10)])
+def test_fused_spade_modulation_against_oracle(C, H, W):
+    """SPADE4 (:1438-1454): LayerNorm2D stats + depth conv/concat + shared conv + fused gamma/beta modulation."""
+    S = pkg("host.SPADE_related")
+    g = torch.Generator().manual_seed(C)
+    B = 2
+    sd = {}
+    p = "n"
+    sd[p + ".mlp_preshared_depth.1.weight"] = torch.randn(16, 1, 3, 3, generator=g) / 3
+    sd[p + ".mlp_preshared_depth.1.bias"] = torch.randn(16, generator=g) * 0.1
+    sd[p + ".mlp_shared.1.weight"] = torch.randn(128, 56, 3, 3, generator=g) / (56 * 9) ** 0.5
+    sd[p + ".mlp_shared.1.bias"] = torch.randn(128, generator=g) * 0.1
+    for nm in ("gamma", "beta"):
+        sd[p + ".mlp_%s.1.weight" % nm] = torch.randn(C, 128, 3, 3, generator=g) / (128 * 9) ** 0.5
+        sd[p + ".mlp_%s.1.bias" % nm] = torch.randn(C, generator=g) * 0.1
+    x = torch.randn(B, C, H, W, generator=g) * 3 + 1
+    seg = torch.rand(B, 41, H, W, generator=g)
+    ref = spade_ref.spade4(sd, p, x, seg)
+    gen = S.SPADEGenerator4.__new__(S.SPADEGenerator4)
+    wsh, rps = S._pack(sd[p + ".mlp_shared.1.weight"].cuda())
+    bsh = torch.zeros(rps, device="cuda"); bsh[:128] = sd[p + ".mlp_shared.1.bias"].cuda()
+    wgb, bgb, rpg = S._pack_gamma_beta(sd[p + ".mlp_gamma.1.weight"].cuda(), sd[p + ".mlp_gamma.1.bias"].cuda(),
+                                       sd[p + ".mlp_beta.1.weight"].cuda(), sd[p + ".mlp_beta.1.bias"].cuda())
+    e = dict(wpd=sd[p + ".mlp_preshared_depth.1.weight"].reshape(16, 9).cuda().contiguous(), bpd=sd[p + ".mlp_preshared_depth.1.bias"].cuda(),
+             wsh=wsh, bsh=bsh, rps=rps, wgb=wgb, bgb=bgb, rpg=rpg)
+    xd = x.cuda()
+    stats = S.SPADEGenerator4._ln_stats(gen, xd)
+    flat = x.reshape(B, -1)
+    assert_close(stats[:, 0].cpu().numpy(), flat.mean(1).numpy(), "mean", rtol=1e-6)
+    assert_close(stats[:, 1].cpu().numpy(), (1.0 / (flat.std(1) + 1e-5)).numpy(), "inv", rtol=1e-5)
+    for leaky in (False, True):
+        out = S.SPADEGenerator4._spade(gen, e, xd, stats, seg.cuda(), leaky)
+        r = F.leaky_relu(ref, 0.2) if leaky else ref
+        assert_close(out.cpu().numpy(), r.numpy(), "spade4 leaky=%s" % leaky, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_generator_against_reference_fixture(name):
+    S = pkg("host.SPADE_related")
+    g = load_golden(name)
+    over, B = CASES[name]
+    cfg = spade_ref.SpadeConfig(**over)
+    sd = spade_ref.init_state(cfg, seed=7)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    assert set(G.state_dict().keys()) == set(sd.keys())
+    G.load_state_dict(sd)
+    G = G.cuda().eval()
+    seg, z = spade_ref.synth_input(cfg, B, seed=3)
+    taps = {}
+    out = G(seg.cuda(), z.cuda(), taps=taps)
+    report = []
+    for n, t in taps.items():
+        got, ref = _checks(t), g["check:" + n]
+        report.append("%s: abs-sum rel err %.2e, sq-sum rel err %.2e" % (n, abs(got[1] - ref[1]) / ref[1], abs(got[2] - ref[2]) / ref[2]))
+    try:
+        for n, t in taps.items():
+            assert_close(_checks(t)[1:], g["check:" + n][1:], name + ":" + n, rtol=1e-4)
+        assert_close(_checks(out)[1:], g["out_check"][1:], name + ":out", rtol=1e-4)
+        if "out" in g.files:
+            assert_close(out.cpu().numpy(), g["out"], name + ":image")
+            assert_close(taps["head_0"].cpu().numpy(), g["tap:head_0"], name + ":head_0")
+        else:
+            assert_close(out[:, :, 100:132, 60:92].cpu().numpy(), g["out_crop"], name + ":crop")
+    except AssertionError as e:
+        raise AssertionError(str(e) + "\n" + "\n".join(report))
