@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--tris", type=int, default=2000)
     ap.add_argument("--render-iters", type=int, default=50)
     ap.add_argument("--no-render", action="store_true")
+    ap.add_argument("--spade-batch", type=int, default=32, help="images per SPADE call (BASELINE configs[3])")
+    ap.add_argument("--spade-iters", type=int, default=3)
+    ap.add_argument("--no-spade", action="store_true")
     return ap.parse_args()
 
 
@@ -118,6 +121,45 @@ def render_leg(args, lib, torch, rank):
             res[name] = {"avg_ms_per_batch": round(ms, 4), "gbs_algorithmic": round(algo / (ms * 1e-3) / 1e9, 1),
                          "frac_hbm": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     res["algorithmic_bytes_per_render"] = int(bytes_per_render)
+    return res
+
+
+def spade_leg(args, lib, torch):
+    """BASELINE configs[3]: SPADEGenerator4(41,3,256,64,'spectralspadelayer3x3',256,'normal') forward, batch 32,
+    256x256 semantic+depth -> RGB, seeded random weights (the authors' checkpoint is not distributable), eval."""
+    S = importlib.import_module("3d_sln_amd.host.SPADE_related")
+    torch.manual_seed(0)
+    G = S.SPADEGenerator4(41, 3, 256, 64, 'spectralspadelayer3x3', 256, 'normal').cuda().eval()
+    B = args.spade_batch
+    g = torch.Generator(device="cuda").manual_seed(0)
+    low = torch.rand(B, 1, 16, 16, device="cuda", generator=g) * 2 - 1
+    depth = torch.nn.functional.interpolate(low, size=(256, 256), mode="bilinear", align_corners=False)
+    lab = torch.nn.functional.interpolate(torch.randn(B, 40, 16, 16, device="cuda", generator=g), size=(256, 256), mode="bilinear",
+                                          align_corners=False).argmax(1)
+    seg = torch.cat([depth, torch.nn.functional.one_hot(lab, 40).permute(0, 3, 1, 2).float()], 1).contiguous()
+    z = torch.randn(B, 256, device="cuda", generator=g)
+    out = G(seg, z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.spade_iters):
+        out = G(seg, z)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.spade_iters
+    lib.check(lib.lib().sln_prof_enable(1), "prof")
+    G(seg, z)
+    torch.cuda.synchronize()
+    fam = prof_read(lib)
+    lib.check(lib.lib().sln_prof_enable(0), "prof")
+    flop_img = 2 * 152.61e9                                       # SURVEY.md Appendix A: 152.6 GMAC per 256x256 image
+    res = {"images_per_s": round(B / dt, 2), "ms_per_batch": round(dt * 1e3, 2), "batch": B,
+           "tflops_end_to_end": round(flop_img * B / dt / 1e12, 2), "frac_mfma_end_to_end": round(flop_img * B / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+           "workload": "BASELINE configs[3]: SPADEGenerator4 256x256 semantic+depth -> RGB, batch %d, fp32, seeded random weights" % B,
+           "finite": bool(torch.isfinite(out).all().item())}
+    if "conv" in fam:
+        c = fam["conv"]
+        tf = c["work"] / (c["ms"] * 1e-3) / 1e12
+        res["conv_kernels"] = {"launches": c["launches"], "ms": round(c["ms"], 2), "tflops": round(tf, 2),
+                               "frac_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
     return res
 
 
@@ -204,6 +246,8 @@ def main():
 
     if rank == 0 and not args.no_render:
         out["render"] = render_leg(args, lib, torch, rank)
+    if rank == 0 and not args.no_spade:
+        out["spade"] = spade_leg(args, lib, torch)
     if rank == 0 and args.prof_steps <= 0:
         print(json.dumps(out))
     elif rank == 0:
