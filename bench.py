@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--triples", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-steps", type=int, default=30)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--prof-steps", type=int, default=5)
     ap.add_argument("--rooms", type=int, default=16, help="rooms per render batch (BASELINE configs[2])")
     ap.add_argument("--tris", type=int, default=2000)
@@ -288,7 +288,8 @@ def main():
             ceps = eps.cpu()
             keys = vae_ref.trainable_keys(cfg)
             m = {k: torch.zeros_like(sd[k]) for k in keys}; v = {k: torch.zeros_like(sd[k]) for k in keys}
-            ncores = torch.get_num_threads()
+            ncores = min(16, os.cpu_count() or 1)      # beyond ~16 threads the small CPU GEMMs of this step slow down
+            torch.set_num_threads(ncores)
             for i in range(2):
                 vae_ref.train_step(sd, cfg, cb, ceps, 0.1, m, v, step=i + 1)
             t0 = time.perf_counter()
