@@ -1,0 +1,171 @@
+"""Layout refinement on the MI355X: counterpart of ``testing/test_render_refine.py::finetune_VAE`` (:243-359)
+and of the scene assembly inside ``models/diff_render.py::mesh_render_func`` (:48-342).
+
+What is reproduced from the reference
+  * object placement (diff_render.py:76-159): box -> centre/size in room units, ``theta = -angle * 2pi/24``,
+    isotropic scale ``min(size / model_size)``, rotation about y, translation ``centre - scale * R @ model_centre``;
+    non-furniture classes are skipped (:93-97); the size loss (:98-100,160-165);
+  * the room box of the last row is frozen to the first iteration's value (:55-60);
+  * ``softargmax`` (test_render_refine.py:20-25), the ``fix_grad`` / ``quad_grad`` hooks (:217-228), the null-fill,
+    ``PSP_pool_new`` multi-scale pooling (:192-215), ``loss = 100*0.5*L1(depth) + 100*sum CE/800 + 2*size_loss``
+    and the per-iteration ``SGD(lr=2e-4, momentum=0.1, nesterov)`` over ``z`` (model parameters at lr/10) (:286-359).
+What is replaced
+  * mesh retrieval (models/misc.py: SUNCG meshes + pywavefront + pymesh, out of scope): every object class gets a
+    procedural cuboid "model" with a fixed aspect ratio; walls / floor / ceiling are quads built from the room box;
+    meshes stay resident on the GPU instead of being re-read from disk every iteration (models/misc.py:111-121);
+  * the 33 raster passes per call: one fused HIP pass (diff_render.scene_render semantics).
+``render_fn`` is injectable so that the tests can run the very same loss graph on the CPU oracle.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import diff_render as DR
+from . import synthetic
+
+DO_NOT_VIS = ["wall", "ceiling", "floor", "person", "door", "window", "curtain", "blinds"]
+
+
+def softargmax(input_vec, sum_dim, beta=2.0):
+    idx = torch.cumsum(torch.ones_like(input_vec), dim=sum_dim)
+    return torch.sum(F.softmax(input_vec * beta, dim=sum_dim) * idx, dim=sum_dim) - 1.0
+
+
+def fix_grad(g):
+    avg = g[:, 3:] / 2.0 + g[:, :3] / 2.0
+    return torch.cat([avg, avg], dim=1)
+
+
+def quad_grad(g):
+    return g * 4.0
+
+
+def psp_pool(feats, sizes=(32, 48, 64, 96), as_list=False):
+    """PSP_pool_new: bilinear(align_corners=True) to each size, then bilinear (default) to the largest."""
+    outs = [F.interpolate(F.interpolate(feats, size=(s, s), mode='bilinear', align_corners=True), size=(sizes[-1], sizes[-1]),
+                          mode='bilinear', align_corners=False) for s in sizes]
+    return outs if as_list else torch.cat(outs, 1)
+
+
+class MeshBank:
+    """Procedural stand-in for the SUNCG model table: one cuboid model per class, resident on the device."""
+
+    def __init__(self, class_names, device, subdiv=2, seed=0):
+        rng = np.random.default_rng(seed)
+        self.models = {}
+        for name in class_names:
+            size = rng.uniform(0.5, 1.5, size=3)
+            v, f = synthetic._grid_cuboid(-size / 2 + rng.uniform(-0.1, 0.1, size=3), size / 2, subdiv)
+            v = torch.from_numpy(v.astype(np.float32)).to(device)
+            self.models[name] = dict(v=v, f=torch.from_numpy(f.astype(np.int32)).to(device),
+                                     bbox_min=v.min(0).values, bbox_max=v.max(0).values)
+
+
+def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=None):
+    """diff_render.py:76-165 for one room: returns vertices_buf [1,V,3] (differentiable w.r.t. boxes / angles),
+    face_buf [1,F,3] int32, class_ranges, obj sizes, size_loss.  ``boxes`` [n,6] in room-normalised units with the
+    room row last, ``angles`` [n] in bins, ``room_box`` the frozen room row (6,)."""
+    dev = boxes.device
+    ranges = {c: [] for c in synthetic.FURNITURE}
+    ranges.update(wall=[], floor=[], ceiling=[])
+    verts, faces, sizes, voff, foff = [], [], [], 0, 0
+    size_loss = boxes.new_zeros(())
+    k = 0
+    for i, name in enumerate(class_names[:-1]):
+        if name in DO_NOT_VIS or name not in bank.models:
+            continue
+        m = bank.models[name]
+        bmin, bmax = boxes[i][:3] * room_box[3:], boxes[i][3:] * room_box[3:]
+        center, size = (bmax + bmin) / 2, bmax - bmin
+        if obj_size_target is not None:
+            size_loss = size_loss + F.mse_loss(size, obj_size_target[k])
+        sizes.append(size.detach())
+        k += 1
+        theta = -angles[i] * (2 * math.pi / 24)
+        msize, mcenter = m["bbox_max"] - m["bbox_min"], (m["bbox_min"] + m["bbox_max"]) / 2.0
+        scale = torch.min(size / msize)
+        c, s = torch.cos(theta), torch.sin(theta)
+        zero, one = torch.zeros_like(c), torch.ones_like(c)
+        rot = torch.stack([torch.stack([c, zero, s]), torch.stack([zero, one, zero]), torch.stack([-s, zero, c])])
+        trans = center - scale * torch.matmul(rot, mcenter)
+        v = torch.matmul(m["v"], (rot * scale).t()) + trans
+        verts.append(v); faces.append(m["f"] + voff)
+        ranges[name].append([foff, foff + m["f"].shape[0]])
+        voff += v.shape[0]; foff += m["f"].shape[0]
+    # room shell from the frozen room box (the reference retrieves wall/floor/ceiling meshes and scales them to it)
+    room = [float(x) for x in room_box[3:]]
+    shell = [("floor", (0, 0, 0), (0, 0, room[2]), (room[0], 0, 0)), ("ceiling", (0, room[1], 0), (room[0], 0, 0), (0, 0, room[2])),
+             ("wall", (0, 0, 0), (room[0], 0, 0), (0, room[1], 0)), ("wall", (0, 0, 0), (0, room[1], 0), (0, 0, room[2])),
+             ("wall", (room[0], 0, 0), (0, 0, room[2]), (0, room[1], 0))]
+    for nm, p0, du, dv in shell:
+        v, f = synthetic._grid_quad(np.array(p0, np.float64), np.array(du, np.float64), np.array(dv, np.float64), 6)
+        verts.append(torch.from_numpy(v.astype(np.float32)).to(dev)); faces.append(torch.from_numpy(f.astype(np.int32)).to(dev) + voff)
+        ranges[nm].append([foff, foff + f.shape[0]])
+        voff += v.shape[0]; foff += f.shape[0]
+    return torch.cat(verts)[None], torch.cat(faces)[None], ranges, sizes, size_loss
+
+
+def refinement_loss(iter_image, target, target_container, size_loss):
+    """test_render_refine.py:332-356 (target_container = per-scale argmax labels of the target, -100 where empty)."""
+    iter_image = iter_image.clone()
+    null = torch.sum(iter_image[:, 41:], dim=1) < 0.5
+    last = iter_image[:, -1]
+    iter_image[:, -1] = torch.where(null, torch.ones_like(last), last)
+    depth_loss = F.l1_loss(psp_pool(iter_image[:, 41:]), psp_pool(target[:, 41:])) * 0.5
+    sem = iter_image.new_zeros(())
+    for pooled, tgt in zip(psp_pool(iter_image[:, 1:41], as_list=True), target_container):
+        sem = sem + F.cross_entropy(pooled, tgt[:, 0]) / 800.0
+    return depth_loss * 100 + sem * 100 + size_loss * 2.0, depth_loss, sem
+
+
+def target_labels(target):
+    out = []
+    for pooled in psp_pool(target[:, 1:41], as_list=True):
+        flat = torch.argmax(pooled, dim=1, keepdim=True)
+        flat[torch.sum(pooled, dim=1, keepdim=True) < 0.5] = -100
+        out.append(flat.detach())
+    return out
+
+
+def finetune_vae(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, render_fn=None, bank=None,
+                 learning_rate=1e-4, noise_seed=13, image_size=256, log=None):
+    """finetune_VAE's inner loop for ONE room (test_render_refine.py:265-359) on synthetic meshes.
+    Returns the list of per-iteration losses and the final (boxes_pred, angles_idx)."""
+    render_fn = render_fn or DR.scene_render
+    dev = boxes_gt.device
+    bank = bank or MeshBank([n for n in set(class_names) if n not in DO_NOT_VIS], dev)
+    model.eval()
+    with torch.no_grad():
+        mu, logvar = model.encoder(objs, triples, boxes_gt, angles_gt, attributes)
+    gen = torch.Generator(device="cpu").manual_seed(noise_seed)
+    z = (mu + torch.randn(mu.shape, generator=gen).to(dev) * torch.exp(0.5 * logvar)).detach().requires_grad_(True)
+    room_box = boxes_gt[-1].detach().clone()
+    v, f, ranges, sizes, _ = assemble_scene(boxes_gt, angles_gt.float(), class_names, bank, room_box)
+    with torch.no_grad():
+        target = render_fn(v, f, ranges, room_box, image_size=image_size)
+    labels = target_labels(target)
+    size_target = [s.clone() for s in sizes]
+    losses = []
+    for k in range(iters):
+        opt = torch.optim.SGD([{'params': [z]}, {'params': list(model.parameters()), 'lr': learning_rate / 10.0}], lr=2e-4,
+                              nesterov=True, momentum=0.1)
+        boxes_pred, angles_pred = model.decoder(z, objs, triples, attributes)
+        boxes_pred.register_hook(fix_grad)
+        boxes_pred = torch.cat([boxes_pred[:-1], boxes_gt[-1:]], 0)
+        idx = softargmax(angles_pred, sum_dim=1) + torch.randn(angles_pred.shape[0], generator=gen).to(dev) / 10.0
+        idx.register_hook(quad_grad)
+        idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
+        v, f, ranges, _, size_loss = assemble_scene(boxes_pred, idx, class_names, bank, room_box, size_target)
+        image = render_fn(v, f, ranges, room_box, image_size=image_size)
+        loss, dl, sl = refinement_loss(image, target, labels, size_loss)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if hasattr(model, "params_changed"):
+            model.params_changed()
+        losses.append(float(loss.detach()))
+        if log:
+            log("iter %d: loss %.4f (depth %.4f, semantic %.4f)" % (k, losses[-1], float(dl), float(sl)))
+    return losses, (boxes_pred.detach(), idx.detach())

@@ -1,0 +1,77 @@
+"""Layout-refinement path on the GPU (rows B2, B7 and 'next' row f1 of SURVEY.md §8): the placement algebra and the
+refinement loss are the same torch code on both sides; the renderer underneath is the fused HIP pass on the GPU and the
+33-pass CPU restatement (oracle/raster_ref.py) in the check."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+from oracle import raster_ref as rr, vae_ref     # noqa: E402
+
+NAMES = ["bed", "chair", "table", "sofa", "door", "desk", "__room__"]       # 'door' is skipped by the reference (DO_NOT_VIS)
+
+
+def _inputs(dev):
+    g = torch.Generator().manual_seed(0)
+    lo = torch.rand(len(NAMES), 3, generator=g) * 0.45 + 0.05
+    lo[:, 1] = 0.0; lo[:, 2] = lo[:, 2] * 0.6
+    hi = lo + torch.rand(len(NAMES), 3, generator=g) * 0.2 + 0.12
+    boxes = torch.cat([lo, hi], 1)
+    boxes[-1] = torch.tensor([0, 0, 0, 4.0, 2.7, 5.0])
+    angles = torch.randint(0, 24, (len(NAMES),), generator=g).float()
+    return boxes.to(dev), angles.to(dev)
+
+
+def test_scene_assembly_and_refinement_loss_match_cpu_restatement():
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    res = {}
+    for dev, render in (("cpu", rr.scene_render), ("cuda", DR.scene_render)):
+        boxes, angles = _inputs(dev)
+        bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], dev, seed=3)
+        room = boxes[-1].clone()
+        v0, f0, ranges, sizes, _ = R.assemble_scene(boxes, angles, NAMES, bank, room)
+        with torch.no_grad():
+            target = render(v0, f0, ranges, room, image_size=96)
+        labels = R.target_labels(target)
+        b2 = (boxes + 0.02).detach().requires_grad_(True)
+        a2 = (angles + 0.7).detach().requires_grad_(True)
+        v, f, ranges, _, size_loss = R.assemble_scene(b2, a2, NAMES, bank, room, [s.clone() for s in sizes])
+        img = render(v, f, ranges, room, image_size=96)
+        loss, dl, sl = R.refinement_loss(img, target, labels, size_loss)
+        loss.backward()
+        res[dev] = (loss.item(), dl.item(), sl.item(), b2.grad.cpu().numpy(), a2.grad.cpu().numpy(), target.cpu().numpy())
+    c, g = res["cpu"], res["cuda"]
+    assert (np.abs(c[5] - g[5]) > 1e-4).mean() < 1e-3            # a few silhouette pixels may flip (CPU vs GPU projection rounding)
+    assert abs(c[0] - g[0]) <= 2e-3 * abs(c[0]), (c[0], g[0])
+    assert abs(c[1] - g[1]) <= 2e-3 * abs(c[1]) and abs(c[2] - g[2]) <= 2e-3 * abs(c[2])
+    assert_close(g[3], c[3], "d loss / d boxes", rtol=2e-2, atol=2e-2 * np.abs(c[3]).max())
+    assert_close(g[4], c[4], "d loss / d angles", rtol=2e-2, atol=2e-2 * np.abs(c[4]).max())
+    assert np.abs(c[3]).max() > 0 and np.abs(c[4]).max() > 0
+
+
+def test_finetune_loop_runs_on_device_and_reduces_the_loss():
+    """decoder -> softargmax -> placement -> fused render -> PSP losses -> SGD on z, 10 iterations on the device.
+    The tiny VAE is first over-fitted to the room (a random decoder puts every object outside the view)."""
+    R = pkg("host.refine"); M = pkg("host.Sg2ScVAE_model")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    model = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    model.load_state_dict(vae_ref.init_state(cfg, seed=1))
+    model = model.cuda().train()
+    boxes, angles = _inputs("cuda")
+    n = len(NAMES)
+    objs = torch.tensor([3, 4, 6, 5, 7, 13, 0], device="cuda")
+    triples = torch.tensor([[0, 1, 1], [2, 3, 3], [1, 2, 5]] + [[i, 0, n - 1] for i in range(n - 1)], device="cuda")
+    attrs = torch.zeros(n, dtype=torch.int64, device="cuda")
+    nb = boxes.clone(); nb[-1] = torch.tensor([0, 0, 0, 1.0, 1.0, 1.0], device="cuda")      # dataset boxes are room-normalised
+    for _ in range(400):
+        model.train_step(objs, triples, nb, angles.long(), attrs, kl_weight=1e-3, lr=2e-3, use_graph=False)
+    losses, (bp, idx) = R.finetune_vae(model, objs, triples, boxes, angles.long(), attrs, NAMES, iters=10, image_size=96,
+                                        learning_rate=1e-3)
+    assert len(losses) == 10 and all(np.isfinite(losses))
+    assert torch.isfinite(bp).all() and torch.isfinite(idx).all()
+    assert len(set(losses)) > 1, "no gradient reached z"
+    assert min(losses[2:]) < losses[0]
