@@ -62,6 +62,7 @@ SIGNATURES = {
     "sln_vae_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int]),
     "sln_vae_bind": (C.c_int, [C.c_void_p, C.POINTER(SlnVaeTensors), C.c_void_p, C.c_int64, C.c_int, C.c_int]),
     "sln_vae_set_batch": (C.c_int, [C.c_void_p, C.POINTER(SlnVaeBatch), C.c_void_p]),
+    "sln_vae_check_batch": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_encoder": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
     "sln_vae_decoder": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
     "sln_vae_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),

@@ -741,10 +741,22 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
     RET_IF(upload_bn_table(h));
     if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
   }
-  RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->g, h->err_flag, st));
+  HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
+  RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->cfg.num_preds, h->g, h->err_flag, st));
+  RET_IF(sln_launch_validate_ids(b->objs, b->attributes, b->angles, b->O, h->cfg.num_objs, h->cfg.num_attrs, h->cfg.n_angle,
+                                 h->err_flag, st));
   RET_IF(sln_launch_i64_to_i32(b->attributes, h->attrs32, b->O, st));
   h->batch_set = true; h->have_enc = h->have_dec = false;
   return 0;
+}
+
+// Blocking check of the ids of the bound batch (the reference's embedding / index ops raise IndexError for these).
+int sln_vae_check_batch(SlnVae* h, void* stream) {
+  if (!h || !h->batch_set) return SLN_E_STATE;
+  int flag = 0;
+  HIP_RET(hipMemcpyAsync(&flag, h->err_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_RET(hipStreamSynchronize((hipStream_t)stream));
+  return flag ? SLN_E_BADARG : 0;
 }
 
 static int copy_out(float* dst, const float* src, size_t n, hipStream_t st) {

@@ -30,11 +30,17 @@ __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid,
 // ----------------------------------------------------------------------------------------------
 // graph CSR
 // ----------------------------------------------------------------------------------------------
-__global__ void prep_split_kernel(const int64_t* __restrict__ tri, int T, int O, GraphCsr g, int* err) {
+__global__ void prep_split_kernel(const int64_t* __restrict__ tri, int T, int O, int num_preds, GraphCsr g, int* err) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   const int64_t s = tri[3 * t], p = tri[3 * t + 1], o = tri[3 * t + 2];
-  if (s < 0 || s >= O || o < 0 || o >= O) { if (err) atomicOr(err, 1); g.s[t] = 0; g.p[t] = 0; g.o[t] = 0; return; }
+  // out-of-range ids (the reference's index ops would raise): flag them and neutralise the triple
+  if (s < 0 || s >= O || o < 0 || o >= O || p < 0 || p >= num_preds) {
+    if (err) atomicOr(err, 1);
+    g.s[t] = 0; g.p[t] = 0; g.o[t] = 0;
+    atomicAdd(g.deg, 2);
+    return;
+  }
   g.s[t] = (int)s; g.p[t] = (int)p; g.o[t] = (int)o;
   atomicAdd(g.deg + (int)s, 1);
   atomicAdd(g.deg + (int)o, 1);
@@ -495,10 +501,28 @@ inline dim3 colgrid(int cols, int rows) { return dim3(sln_cdiv(cols, CB), sln_cd
 
 }  // namespace
 
-int sln_launch_graph_prep(const int64_t* triples, int T, int O, GraphCsr g, int* err_flag, hipStream_t st) {
+__global__ void validate_ids_kernel(const int64_t* __restrict__ objs, const int64_t* __restrict__ attrs,
+                                    const int64_t* __restrict__ angles, int O, int n_objs, int n_attrs, int n_angle, int* err) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= O) return;
+  if (objs[i] < 0 || objs[i] >= n_objs) atomicOr(err, 2);
+  if (attrs[i] < 0 || attrs[i] >= n_attrs) atomicOr(err, 4);
+  if (angles && (angles[i] < 0 || angles[i] >= n_angle)) atomicOr(err, 8);
+}
+
+int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int64_t* angles, int O, int n_objs, int n_attrs,
+                            int n_angle, int* err_flag, hipStream_t st) {
+  if (O <= 0) return 0;
+  hipLaunchKernelGGL(validate_ids_kernel, dim3(sln_cdiv(O, 256)), dim3(256), 0, st, objs, attrs, angles, O, n_objs, n_attrs, n_angle,
+                     err_flag);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st) {
   hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
   if (e != hipSuccess) return (int)e;
-  if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, g, err_flag);
+  if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, num_preds, g, err_flag);
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, g, O);
   if (T > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(sln_cdiv(2 * T, 256)), dim3(256), 0, st, g, T);
   hipLaunchKernelGGL(csr_sort_kernel, dim3(sln_cdiv(O, 64)), dim3(64), 0, st, g, O);

@@ -132,6 +132,7 @@ class Sg2ScVAEModel(nn.Module):
                   self.angle_mean, self.angle_var, self.box_net):
             m.apply(_init_weights)
 
+        self.validate_inputs = True      # one host sync per NEW batch; set False in a tuned training loop
         self._eng = None
         self._generation = 0
         self._batch_key = None
@@ -305,6 +306,12 @@ class Sg2ScVAEModel(nn.Module):
         _lib.check(_lib.lib().sln_vae_set_batch(self._eng, C.byref(b), _lib.current_stream_ptr()), "sln_vae_set_batch")
         self._batch_refs = (objs, triples, boxes, angles, attributes)
         self._batch_key, self._O, self._T = key, O, T
+        if self.validate_inputs:
+            rc = _lib.lib().sln_vae_check_batch(self._eng, _lib.current_stream_ptr())
+            if rc == -1:
+                self._batch_key = None
+                raise IndexError("scene-graph batch holds an out-of-range object class / predicate / attribute / angle / row id")
+            _lib.check(rc, "sln_vae_check_batch")
 
     def _new(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self._flat.device)

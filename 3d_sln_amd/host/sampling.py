@@ -1,0 +1,57 @@
+"""Posterior statistics and batched layout sampling on the device - the tensor work of the reference's
+``testing/test_VAE.py`` (:34-117) and ``testing/test_heatmap.py`` (:52-64) without the per-room Python loops.
+
+  * ``posterior_stats``  - mean / covariance of the encoder means over a set of batches (test_VAE.py:34-54; the
+    reference accumulates n outer products in a numpy loop);
+  * ``sample_layouts``   - ``Nsample`` decodes of the same scene graphs in ONE engine call: the graph batch is
+    replicated ``n_samples`` times with shifted row ids (the decoder only sees disjoint graphs), z is drawn from
+    N(mean, cov) per object as ``np.random.multivariate_normal`` does (test_VAE.py:83-84), BatchNorm runs on its
+    running statistics (``model.eval()``).
+"""
+import torch
+
+
+def posterior_stats(model, batches):
+    """batches: iterable of (objs, triples, boxes, angles, attributes).  -> (mean [E], cov [E,E]) float64 on the CPU."""
+    mus = []
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        for objs, triples, boxes, angles, attributes in batches:
+            mu, _ = model.encoder(objs, triples, boxes, angles, attributes)
+            mus.append(mu.double())
+    model.train(was_training)
+    m = torch.cat(mus, 0)
+    mean = m.mean(0)
+    c = m - mean
+    cov = c.t().matmul(c) / (m.shape[0] - 1.0)
+    return mean.cpu(), cov.cpu()
+
+
+def replicate_graphs(objs, triples, attributes, n):
+    """n shifted copies of a collated batch (suncg_collate_fn layout): rows of copy k are offset by k*O."""
+    O = objs.shape[0]
+    off = (torch.arange(n, device=objs.device) * O)
+    tr = triples[None].repeat(n, 1, 1)
+    tr[:, :, 0] += off[:, None]
+    tr[:, :, 2] += off[:, None]
+    return objs.repeat(n), tr.reshape(-1, 3), attributes.repeat(n)
+
+
+def sample_layouts(model, objs, triples, attributes, n_samples=4, mean=None, cov=None, generator=None):
+    """-> boxes_pred [n_samples, O, box_dim], angle_bins [n_samples, O] (argmax of the log-probabilities)."""
+    dev = objs.device
+    E, O = model.embedding_dim, objs.shape[0]
+    ro, rt, ra = replicate_graphs(objs, triples, attributes, n_samples)
+    eps = torch.randn(n_samples * O, E, generator=generator, device="cpu").to(dev)
+    if mean is None:
+        z = eps
+    else:
+        L = torch.linalg.cholesky(cov.double() + 1e-9 * torch.eye(E, dtype=torch.float64)).float().to(dev)
+        z = mean.float().to(dev)[None] + eps.matmul(L.t())
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        bp, ap = model.decoder(z, ro, rt, ra)
+    model.train(was_training)
+    return bp.view(n_samples, O, -1), ap.view(n_samples, O, -1).argmax(2), z.view(n_samples, O, E)

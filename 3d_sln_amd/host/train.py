@@ -99,6 +99,8 @@ def train(args, model, batch_fn, rank=0, world=1, log=print):
         dist.broadcast(model.flat_params, 0)                      # identical replicas
         if hasattr(model, "params_changed"):
             model.params_changed()
+    if hasattr(model, "validate_inputs"):
+        model.validate_inputs = False             # no per-batch host sync inside the loop
     lo, hi = shard_range(args.batch_size, rank, world)
     checkpoint = {'args': dict(vars(args)), 'losses_ts': [], 'losses': defaultdict(list), 'checkpoint_ts': [],
                   'counters': {'t': None, 'epoch': None}, 'model_state': None, 'optim_state': None}

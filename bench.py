@@ -273,6 +273,20 @@ def main():
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
                            "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
                            "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2)}
+        # HBM traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+        # separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); launch-weighted mean over its variants
+        try:
+            import csv
+            tot, cnt = 0.0, 0
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_vae_render_kernel_stats.csv"))):
+                if r["kernel"].startswith(dom + "_kernel") and r["hbm_MB_per_launch_corrected"]:
+                    tot += float(r["hbm_MB_per_launch_corrected"]) * int(r["calls"]); cnt += int(r["calls"])
+            if cnt:
+                out["roofline"]["traffic"] = round(tot / cnt * 1e6)
+                out["roofline"]["traffic_source"] = "profiles/r01_vae_render_kernel_stats.csv (bytes per launch)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = "operands+output of a 0.5 GFLOP fp32 GEMM: ~3-11 MB (shape dependent)"
+        except Exception:
+            pass
         if "edge" in fam:
             e = fam["edge"]
             gbs = e["work"] / (e["ms"] * 1e-3) / 1e9

@@ -109,6 +109,9 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
  * precede encoder/decoder calls for a new batch.  Replaces the index/scatter_add bookkeeping of
  * GraphTripleConv.forward (models/graph.py:70-72,89-108), hoisted out of the 10 layers. */
 int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream);
+/* Synchronising check of the bound batch: SLN_E_BADARG when a triple / class / attribute / angle id is out of range
+ * (the reference's embedding and index ops raise IndexError there; the kernels neutralise such rows). */
+int sln_vae_check_batch(SlnVae* h, void* stream);
 
 /* Sg2ScVAEModel.encoder (Sg2ScVAE_model.py:115-143): writes mu, logvar [O, embedding_dim].
  * training != 0: BatchNorm uses batch statistics and updates running stats (train()). */

@@ -268,3 +268,43 @@ def test_c2_full_size_train_step_vs_oracle():
     for k in sdg:
         if "running" in k:
             assert_close(model2.state_dict()[k].cpu().numpy(), sdg[k].numpy(), "c2:" + k)
+
+
+def test_out_of_range_ids_raise_like_the_reference():
+    """The reference's embedding / index ops raise IndexError on bad ids; the HIP path must not read out of bounds."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=1)
+    model = _model(cfg, vae_ref.init_state(cfg, seed=0)).eval()
+    b = [t.clone() for t in vae_ref.synth_batch(2, 4, 5, seed=1, cfg=cfg)[:5]]
+    for which, val in ((0, 33), (1, None), (3, 24), (4, 5)):
+        bad = [t.clone() for t in b]
+        if which == 1:
+            bad[1][0, 1] = 16                      # predicate id out of range
+        else:
+            bad[which][0] = val
+        with pytest.raises(IndexError):
+            model(*_dev(*bad), None, eps=torch.zeros(8, 16, device="cuda"))
+    out = model(*_dev(*b), None, eps=torch.zeros(8, 16, device="cuda"))      # the engine still works afterwards
+    assert torch.isfinite(out[2]).all()
+
+
+def test_batched_sampling_matches_per_sample_decoding():
+    """host/sampling.py (tensor work of testing/test_VAE.py:83-84): n decodes in one engine call == n separate ones
+    == the oracle's eval-mode decoder."""
+    S = pkg("host.sampling")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=2)
+    model = _model(cfg, sd).eval()
+    objs, triples, boxes, angles, attrs, _ = vae_ref.synth_batch(3, 5, 7, seed=4, cfg=cfg)
+    bp, ang, z = S.sample_layouts(model, objs.cuda(), triples.cuda(), attrs.cuda(), n_samples=5,
+                                  generator=torch.Generator().manual_seed(0))
+    assert bp.shape == (5, 15, 6) and ang.shape == (5, 15)
+    for k in range(5):
+        with torch.no_grad():
+            rb, ra = vae_ref.decoder({k_: v.clone() for k_, v in sd.items()}, cfg, z[k].cpu(), objs, triples, attrs, training=False)
+        assert_close(bp[k].cpu().numpy(), rb.numpy(), "boxes sample %d" % k)
+        assert (ang[k].cpu() == ra.argmax(1)).float().mean() > 0.9
+    mean, cov = S.posterior_stats(model, [(objs.cuda(), triples.cuda(), boxes.cuda(), angles.cuda(), attrs.cuda())])
+    with torch.no_grad():
+        mu, _ = vae_ref.encoder({k_: v.clone() for k_, v in sd.items()}, cfg, objs, triples, boxes, angles, attrs, training=False)
+    assert_close(mean.numpy(), mu.double().mean(0).numpy(), "posterior mean", rtol=1e-4, atol=1e-5)
+    assert_close(cov.numpy(), np.cov(mu.double().numpy().T), "posterior cov", rtol=1e-3, atol=1e-5)
