@@ -48,6 +48,7 @@ VAE_CASES = {
     "vae_small_recurrent": (dict(embedding_dim=16, gconv_num_layers=3, gconv_mode="recurrent"), 16, 5, 8),
     "vae_small_nocat": (dict(embedding_dim=16, gconv_num_layers=2, decoder_cat=False), 16, 5, 8),
     "vae_small_ae": (dict(embedding_dim=16, gconv_num_layers=2, use_AE=True), 16, 5, 8),
+    "vae_small_2d": (dict(embedding_dim=16, gconv_num_layers=2, train_3d=False), 16, 5, 8),
     # ragged: graphs of different sizes concatenated like suncg_collate_fn does
     "vae_small_ragged": (dict(embedding_dim=16, gconv_num_layers=2), -1, 0, 0),
 }
