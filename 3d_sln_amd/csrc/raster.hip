@@ -293,40 +293,43 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
 // butterfly at the end (no atomics: one writer per face).
 // PIX is a policy giving diff(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
 // ----------------------------------------------------------------------------------------------------
-struct PixDense {            // C-channel image: one positive-part test over the channel sum (package's rgb mode, C=3)
-  const float* rgb; const float* grad; int C;
-  __device__ __forceinline__ float contrib(long q, long ref, int, int) const {
+// A policy exposes, per scan axis, a view with: fi (face index map addressed by the view's own linear index),
+// idx(base, d0, d1) and contrib(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
+struct PixDenseView {
+  const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;
+  __device__ __forceinline__ long idx(long base, int d0, int d1) const { return axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1; }
+  __device__ __forceinline__ float contrib(long q, long ref, int) const {
     float diff = 0.f;
     for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref * C + k]) * grad[q * C + k];
     return diff > 0.f ? diff : 0.f;
   }
 };
+struct PixDense {            // C-channel image: one positive-part test over the channel sum (package's rgb mode, C=3)
+  const int32_t* fi; const float* rgb; const float* grad; int C, is;
+  __device__ __forceinline__ PixDenseView view(int axis) const { return PixDenseView{fi, rgb, grad, C, is, axis}; }
+};
 
 // The reference's 32 class passes fused (models/diff_render.py:381-398): pass c renders value(pixel) where the
 // winning face belongs to class c and 0 elsewhere, into three equal rgb channels whose mean is the class
-// image; every pass applies its own positive-part test.  The gradient w.r.t. the class images is read
-// straight out of d(final)[B, NCH, is, is] (row-flipped, class c in channel chan[c]).
-struct PixClass {
-  const int32_t* fi; const float* val; int vstride; const int32_t* cls; const float* gfinal; const int32_t* chan;
-  int F, is, nch;
-  __device__ __forceinline__ float grad_of(int b, int c, long pq) const {
-    const int y = (int)(pq / is), x = (int)(pq % is);
-    return gfinal[(((long)b * nch + chan[c]) * is + (is - 1 - y)) * is + x] / 3.0f;
-  }
-  __device__ __forceinline__ float contrib(long q, long ref, int b, int) const {
-    const long pq = q - (long)b * is * is;
-    const int fq = fi[q], fr = fi[ref];
-    const int cq = fq >= 0 ? cls[(long)b * F + fq] : -1, cr = fr >= 0 ? cls[(long)b * F + fr] : -1;
-    const float vq = fq >= 0 ? val[q * vstride] : 0.f, vr = fr >= 0 ? val[ref * vstride] : 0.f;
+// image; every pass applies its own positive-part test (at most two classes contribute per pixel pair).
+// Vertical scans (axis 0) read TRANSPOSED copies of the per-pixel maps and of the class-gradient planes so that
+// the 64 lanes of a scan touch consecutive addresses (the strided version fetched 5.8 GB per 16 rooms).
+struct PixClassView {
+  const int32_t* fi; const int32_t* cp; const float* v; const float* g; int is, NC; long plane;
+  __device__ __forceinline__ long idx(long base, int d0, int d1) const { return base + (long)d0 * is + d1; }
+  __device__ __forceinline__ float contrib(long q, long ref, int b) const {
+    const int cq = cp[q], cr = cp[ref];
+    const float vq = cq >= 0 ? v[q] : 0.f, vr = cr >= 0 ? v[ref] : 0.f;
+    const long pq = q - (long)b * plane;
     float tot = 0.f;
     if (cq >= 0) {
-      const float g3 = grad_of(b, cq, pq);
+      const float g3 = g[((long)b * NC + cq) * plane + pq];
       const float dv = vq - (cr == cq ? vr : 0.f);
       float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
       if (diff > 0.f) tot += diff;
     }
     if (cr >= 0 && cr != cq) {
-      const float g3 = grad_of(b, cr, pq);
+      const float g3 = g[((long)b * NC + cr) * plane + pq];
       const float dv = 0.f - vr;
       float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
       if (diff > 0.f) tot += diff;
@@ -334,10 +337,15 @@ struct PixClass {
     return tot;
   }
 };
+struct PixClass {
+  const int32_t *fi, *fiT, *cp, *cpT; const float *v, *vT, *g, *gT; int is, NC;
+  __device__ __forceinline__ PixClassView view(int axis) const {
+    return axis == 0 ? PixClassView{fiT, cpT, vT, gT, is, NC, (long)is * is} : PixClassView{fi, cp, v, g, is, NC, (long)is * is};
+  }
+};
 
 template <typename PIX>
-__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces,
-                                                                const int32_t* __restrict__ fi, PIX pix0, int F, int is,
+__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int F, int is,
                                                                 float eps, float* __restrict__ gfaces) {
   const long i = blockIdx.x;                       // face
   const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
@@ -345,7 +353,6 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 #pragma unroll
   for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
   if (backfacing(face)) return;
-  const PIX& pix = pix0;
   const long base = (long)b * is * is;
   float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int e = 0; e < 3; ++e) {
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 #pragma unroll
       for (int d = 0; d < 2; ++d) pp[n][d] = (float)(0.5 * (double)(face[3 * pi[n] + d] * is + is - 1));
     for (int axis = 0; axis < 2; ++axis) {
+      const auto V = pix.view(axis);
       float p[3][2];
 #pragma unroll
       for (int n = 0; n < 3; ++n)
@@ -371,8 +379,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
         const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
         const int d1_out = d1_in + dir;
         if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;
-        const long idx_in = axis == 0 ? base + (long)d1_in * is + d0 : base + (long)d0 * is + d1_in;
-        const long idx_out = axis == 0 ? base + (long)d1_out * is + d0 : base + (long)d0 * is + d1_out;
+        const long idx_in = V.idx(base, d0, d1_in), idx_out = V.idx(base, d0, d1_out);
         const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
         const float r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;
         const float r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
@@ -388,12 +395,11 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
             acc1 -= diff / dist;
           }
         };
-        if (fi[idx_in] == fn) {                     // outward scan to the image border
+        if (V.fi[idx_in] == fn) {                   // outward scan to the image border
           const int lim = dir > 0 ? is - 1 : 0;
           const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
           for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const long q = axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1;
-            const float diff = pix.contrib(q, idx_in, b, fn);
+            const float diff = V.contrib(V.idx(base, d0, d1), idx_in, b);
             if (diff > 0.f) add(d1, diff);
           }
         }
@@ -404,9 +410,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
           const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
           const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
           for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const long q = axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1;
-            if (fi[q] != fn) continue;
-            const float diff = pix.contrib(q, idx_out, b, fn);
+            const long q = V.idx(base, d0, d1);
+            if (V.fi[q] != fn) continue;
+            const float diff = V.contrib(q, idx_out, b);
             if (diff > 0.f) add(d1, diff);
           }
         }
@@ -500,9 +506,9 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
-  PixDense pix{rgb, grad_rgb, channels};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n), dim3(64), 0, st, faces, face_index, pix, F,
-                     image_size, eps, grad_faces);
+  PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n), dim3(64), 0, st, faces, pix, F, image_size, eps,
+                     grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -622,6 +628,59 @@ __global__ void scene_bwd_stats_kernel(const int32_t* __restrict__ fi_b, const f
   if (threadIdx.x == 0) atomicAdd(&st[b].gsum[c], (double)red[0]);
 }
 
+// per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
+__global__ __launch_bounds__(256) void scene_bwd_maps_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                             const int32_t* __restrict__ cls, int F, int is, int NC,
+                                                             int32_t* __restrict__ cp, int32_t* __restrict__ cpT,
+                                                             float* __restrict__ v, float* __restrict__ vT, int32_t* __restrict__ fiT) {
+  __shared__ int tc[32][33]; __shared__ float tv[32][33]; __shared__ int tf[32][33];
+  const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const long plane = (long)is * is;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = y0 + r, x = x0 + tx;
+    int c = -1, f = -1; float vv = 0.f;
+    if (y < is && x < is) {
+      const long q = b * plane + (long)y * is + x;
+      f = fi_b[q];
+      if (f >= 0) { c = cls[(long)b * F + f]; if (c >= NC) c = -1; }
+      vv = c >= 0 ? val[3 * q] : 0.f;
+      cp[q] = c; v[q] = vv;
+    }
+    tc[r][tx] = c; tv[r][tx] = vv; tf[r][tx] = f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int x = x0 + r, y = y0 + tx;
+    if (x < is && y < is) {
+      const long qt = b * plane + (long)x * is + y;
+      cpT[qt] = tc[tx][r]; vT[qt] = tv[tx][r]; fiT[qt] = tf[tx][r];
+    }
+  }
+}
+
+// g[b,c,y,x] = d final[b, 1+chan[c], flip(y), x] / 3  and its transpose
+__global__ __launch_bounds__(256) void scene_bwd_grad_planes_kernel(const float* __restrict__ gout, const int32_t* __restrict__ chan,
+                                                                    int is, int NC, int nch, float* __restrict__ g,
+                                                                    float* __restrict__ gT) {
+  __shared__ float t[32][33];
+  const int bc = blockIdx.z, b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const long plane = (long)is * is;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* src = gout + ((long)b * nch + 1 + chan[c]) * plane;
+  for (int r = ty; r < 32; r += 8) {
+    const int y = y0 + r, x = x0 + tx;
+    float vv = 0.f;
+    if (y < is && x < is) { vv = src[(long)(is - 1 - y) * is + x] / 3.0f; g[(long)bc * plane + (long)y * is + x] = vv; }
+    t[r][tx] = vv;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int x = x0 + r, y = y0 + tx;
+    if (x < is && y < is) gT[(long)bc * plane + (long)x * is + y] = t[tx][r];
+  }
+}
+
 // d(loss)/d(raw depth map of the depth pass), unflipped [B,is,is]
 __global__ void scene_bwd_depthgrad_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
                                            const float* __restrict__ d_a, const int32_t* __restrict__ cls,
@@ -655,12 +714,13 @@ extern "C" {
 
 int64_t sln_scene_workspace_bytes(int B, int F, int image_size) {
   const int64_t plane = (int64_t)image_size * image_size;
-  // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture
+  // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture | cp cpT v vT fiT | g gT (64 class planes max)
   return (int64_t)sizeof(FaceRec) * B * F + sizeof(SceneStats) * B + B * plane * (4 + 12 + 4) * 2 + B * plane * 12 + B * plane * 4 +
-         (int64_t)B * F * 24 * 4 + 4096;
+         (int64_t)B * F * 24 * 4 + B * plane * 4 * 5 + (int64_t)B * 64 * plane * 4 * 2 + 8192;
 }
 
-struct SceneWs { FaceRec* rec; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones; };
+struct SceneWs { FaceRec* rec; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones;
+                 int32_t *cp, *cpT, *fiT; float *v, *vT, *g, *gT; };
 
 static SceneWs carve_scene(void* ws, int B, int F, int is) {
   char* p = static_cast<char*>(ws);
@@ -671,6 +731,9 @@ static SceneWs carve_scene(void* ws, int B, int F, int is) {
   w.fiA = (int32_t*)take(4 * B * plane); w.wA = (float*)take(12 * B * plane); w.dA = (float*)take(4 * B * plane);
   w.fiB = (int32_t*)take(4 * B * plane); w.wB = (float*)take(12 * B * plane); w.dB = (float*)take(4 * B * plane);
   w.val = (float*)take(12 * B * plane); w.gd = (float*)take(4 * B * plane); w.ones = (float*)take((size_t)B * F * 24 * 4);
+  w.cp = (int32_t*)take(4 * B * plane); w.cpT = (int32_t*)take(4 * B * plane); w.fiT = (int32_t*)take(4 * B * plane);
+  w.v = (float*)take(4 * B * plane); w.vT = (float*)take(4 * B * plane);
+  w.g = (float*)take((size_t)4 * B * 64 * plane); w.gT = (float*)take((size_t)4 * B * 64 * plane);
   return w;
 }
 
@@ -722,12 +785,13 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
-  PixClass pix; pix.fi = w.fiB; pix.val = w.val; pix.vstride = 3; pix.cls = face_class; pix.gfinal = grad_final;
-  pix.chan = class_channel; pix.F = F; pix.is = is; pix.nch = 70;
-  // class_channel holds NYU indices 0..39; the class images live in final channels 1..40
-  pix.gfinal = grad_final + plane;       // shift by one channel so that chan[c] indexes directly
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n), dim3(64), 0, st, faces, w.fiB, pix, F, is, pix_eps,
-                     grad_faces);
+  const int t32 = sln_cdiv(is, 32);
+  hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, F, is, num_classes, w.cp,
+                     w.cpT, w.v, w.vT, w.fiT);
+  hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
+                     num_classes, 70, w.g, w.gT);
+  PixClass pix{w.fiB, w.fiT, w.cp, w.cpT, w.v, w.vT, w.g, w.gT, is, num_classes};
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n), dim3(64), 0, st, faces, pix, F, is, pix_eps, grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
 }
