@@ -78,6 +78,9 @@ SIGNATURES = {
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_prof_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sln_vae_tap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
+    "sln_gconv_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sln_gconv_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlnVaeUnit), c_f32p, c_f32p,
+                                    C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, c_f32p, c_f32p, C.c_void_p]),
     "sln_linear_forward": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "sln_linear_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),

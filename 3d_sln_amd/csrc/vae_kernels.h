@@ -14,7 +14,10 @@ struct GraphCsr {          // device pointers, all int32 unless noted
   int* ent;                // [2T] incident entries: e < T -> triple e as subject, e >= T -> triple e-T as object
   int T, O;
 };
-int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st);
+int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st,
+                          int edges_only = 0);
+// bn view must be aligned with column col0 of x
+int sln_launch_bn_relu_apply(const float* x, int ld, int col0, int cols, int rows, BnView bn, float* out, int ldo, hipStream_t st);
 // err_flag bits: 1 triple ids, 2 object class, 4 attribute, 8 angle bin out of range
 int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int64_t* angles, int O, int n_objs, int n_attrs,
                             int n_angle, int* err_flag, hipStream_t st);

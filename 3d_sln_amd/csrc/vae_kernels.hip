@@ -30,10 +30,12 @@ __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid,
 // ----------------------------------------------------------------------------------------------
 // graph CSR
 // ----------------------------------------------------------------------------------------------
-__global__ void prep_split_kernel(const int64_t* __restrict__ tri, int T, int O, int num_preds, GraphCsr g, int* err) {
+__global__ void prep_split_kernel(const int64_t* __restrict__ tri, int T, int O, int num_preds, GraphCsr g, int* err, int stride,
+                                  int poff, int ooff) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
-  const int64_t s = tri[3 * t], p = tri[3 * t + 1], o = tri[3 * t + 2];
+  // triples [T,3] = (s, p, o) (stride 3) or edges [T,2] = (s, o) (stride 2, no predicate)
+  const int64_t s = tri[stride * t], p = poff >= 0 ? tri[stride * t + poff] : 0, o = tri[stride * t + ooff];
   // out-of-range ids (the reference's index ops would raise): flag them and neutralise the triple
   if (s < 0 || s >= O || o < 0 || o >= O || p < 0 || p >= num_preds) {
     if (err) atomicOr(err, 1);
@@ -497,6 +499,17 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// out[r, c] = relu(bn(x[r, col0 + c]))  (materialise a post-activation, standalone GraphTripleConv API only)
+__global__ void bn_relu_apply_kernel(const float* __restrict__ x, int ld, int col0, int cols, long n, BnView bn,
+                                     float* __restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long r = i / cols; const int c = (int)(i % cols);
+  float sc, sh;
+  bn_fwd_coef(bn, c, sc, sh);
+  out[r * ldo + c] = fmaxf(fmaf(sc, x[r * ld + col0 + c], sh), 0.f);
+}
+
 inline dim3 colgrid(int cols, int rows) { return dim3(sln_cdiv(cols, CB), sln_cdiv(rows, RB)); }
 
 }  // namespace
@@ -519,13 +532,23 @@ int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int
   return 0;
 }
 
-int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st) {
+int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st,
+                          int edges_only) {
   hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
   if (e != hipSuccess) return (int)e;
-  if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, num_preds, g, err_flag);
+  if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, num_preds, g, err_flag,
+                              edges_only ? 2 : 3, edges_only ? -1 : 1, edges_only ? 1 : 2);
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, g, O);
   if (T > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(sln_cdiv(2 * T, 256)), dim3(256), 0, st, g, T);
   hipLaunchKernelGGL(csr_sort_kernel, dim3(sln_cdiv(O, 64)), dim3(64), 0, st, g, O);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_bn_relu_apply(const float* x, int ld, int col0, int cols, int rows, BnView bn, float* out, int ldo, hipStream_t st) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(bn_relu_apply_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld, col0, cols, n, bn, out, ldo);
   SLN_CHECK_LAUNCH();
   return 0;
 }

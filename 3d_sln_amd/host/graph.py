@@ -7,8 +7,12 @@ the arithmetic runs in the HIP engine (csrc/vae_engine.hip), which the owning
 ``Sg2ScVAEModel`` drives.  A GraphTripleConv(Net) used on its own also runs on the
 engine's kernels through ``forward`` below.
 """
+import ctypes as C
+
 import torch
 import torch.nn as nn
+
+from .. import _lib
 
 
 def make_mlp(dim_list, activation='relu', batch_norm='none', dropout=0, norelu=False):
@@ -61,9 +65,8 @@ class GraphTripleConv(nn.Module):
         self.net2.apply(_init_weights)
 
     def forward(self, obj_vecs, pred_vecs, edges):
-        raise NotImplementedError(
-            "standalone GraphTripleConv.forward is not part of the HIP path yet; the layers run "
-            "inside Sg2ScVAEModel.encoder/decoder (csrc/vae_engine.hip::gconv_forward)")
+        """(new_obj_vecs [O, Dout], new_pred_vecs [T, Dout]) - inference only (see _gconv_forward)."""
+        return _gconv_forward([self], 1, obj_vecs, pred_vecs, edges, self.training)
 
 
 class GraphTripleConvNet(nn.Module):
@@ -79,4 +82,41 @@ class GraphTripleConvNet(nn.Module):
                             mlp_normalization=mlp_normalization) for _ in range(n_mod)])
 
     def forward(self, obj_vecs, pred_vecs, edges):
-        raise NotImplementedError("see GraphTripleConv.forward")
+        return _gconv_forward(list(self.gconvs), self.num_layers, obj_vecs, pred_vecs, edges, self.training)
+
+
+def _gconv_forward(modules, num_layers, obj_vecs, pred_vecs, edges, training):
+    """Standalone GraphTripleConv(Net).forward on the HIP kernels (sln_gconv_forward).  No autograd: training runs
+    through Sg2ScVAEModel (fused forward/backward in csrc/vae_engine.hip)."""
+    if torch.is_grad_enabled() and (obj_vecs.requires_grad or pred_vecs.requires_grad or
+                                    any(p.requires_grad for m in modules for p in m.parameters())):
+        raise NotImplementedError("standalone GraphTripleConv(Net).forward is inference-only on the HIP path "
+                                  "(wrap the call in torch.no_grad(); train through Sg2ScVAEModel)")
+    if obj_vecs.device.type != 'cuda':
+        raise _lib.SlnError("GraphTripleConv runs on the MI355X only (no CPU fallback)")
+    m0 = modules[0]
+    D, H, Do = m0.input_dim, m0.hidden_dim, m0.output_dim
+    units = (_lib.SlnVaeUnit * (4 * len(modules)))()
+    bn_any = False
+    for mi, m in enumerate(modules):
+        for k, (lin, bn) in enumerate(mlp_linears(m.net1) + mlp_linears(m.net2)):
+            u = units[4 * mi + k]
+            u.weight, u.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
+            if bn is not None:
+                bn_any = True
+                u.bn_weight, u.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+                u.bn_running_mean, u.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                u.bn_num_batches_tracked = bn.num_batches_tracked.data_ptr()
+    L = _lib.lib()
+    x = obj_vecs.detach().float().contiguous(); p = pred_vecs.detach().float().contiguous()
+    e = edges.to(torch.int64).contiguous()
+    O, T = x.shape[0], p.shape[0]
+    nbytes = L.sln_gconv_workspace_bytes(D, H, Do, O, T, num_layers)
+    if nbytes < 0:
+        _lib.check(int(nbytes), "sln_gconv_workspace_bytes")
+    ws = torch.empty(int(nbytes), dtype=torch.uint8, device=x.device)
+    new_obj = torch.empty(O, Do, device=x.device); new_pred = torch.empty(T, Do, device=x.device)
+    _lib.check(L.sln_gconv_forward(D, H, Do, num_layers, len(modules), int(bn_any), units, _lib.ptr(x), _lib.ptr(p), _lib.ptr(e), O, T,
+                                   int(training), _lib.ptr(ws), int(nbytes), _lib.ptr(new_obj), _lib.ptr(new_pred),
+                                   _lib.current_stream_ptr()), "sln_gconv_forward")
+    return new_obj, new_pred

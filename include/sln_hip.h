@@ -163,6 +163,15 @@ int sln_prof_read(double* ms_by_family, double* work_by_family, int64_t* launche
  * gconv instance `layer` (0..L-1 encoder, L..2L-1 decoder).  Returns the element count or <0. */
 int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream);
 
+/* GraphTripleConv.forward / GraphTripleConvNet.forward (models/graph.py:57-111,136-143) on their own (inference /
+ * feature extraction; training goes through the VAE engine).  units_host: 4 SlnVaeUnit per module in the order
+ * net1.0, net1.1, net2.0, net2.1 (gradient fields unused); layer l uses module (n_modules == 1 ? 0 : l).
+ * edges [T,2] int64 (s, o).  D % 32 == 0; num_layers > 1 requires Dout == D. */
+int64_t sln_gconv_workspace_bytes(int D, int H, int Dout, int O, int T, int num_layers);
+int sln_gconv_forward(int D, int H, int Dout, int num_layers, int n_modules, int batch_norm, const SlnVaeUnit* units_host,
+                      const float* obj_vecs, const float* pred_vecs, const int64_t* edges, int O, int T, int training, void* workspace,
+                      int64_t workspace_bytes, float* new_obj, float* new_pred, void* stream);
+
 /* Standalone Linear kernels (parity tests of the GEMM family):
  *   y[M,N] = x[M,K] W[N,K]^T + bias, optional fp64 column sums of y and y^2 in sums[2][N] */
 int sln_linear_forward(const float* x, int M, int K, const float* W, const float* bias, float* y, int N, double* sums,

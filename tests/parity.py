@@ -41,7 +41,7 @@ def assert_close_conditioned(got, ref64, ref32, name, rtol=RTOL, atol=ATOL, k=8.
         name, err, scale, noise)
 
 
-def assert_adam_close(p_new, p_ref, grad_ref, name, lr=1e-4, rtol=1e-5, gscale=None):
+def assert_adam_close(p_new, p_ref, grad_ref, name, lr=1e-4, rtol=1e-5, gscale=None, gnoise=0.0):
     """Adam's first step is +-lr*g/(|g|+eps): chaotic where the true gradient is 0
     (every Linear bias in front of a BatchNorm).  Compare tightly where |g| is
     meaningful and bound the move by lr elsewhere."""
@@ -49,7 +49,8 @@ def assert_adam_close(p_new, p_ref, grad_ref, name, lr=1e-4, rtol=1e-5, gscale=N
     g = np.abs(np.asarray(grad_ref, np.float64))
     # "meaningful" is judged against the model-wide gradient scale when given: a tensor whose true
     # gradient is identically zero only holds ~1e-7 rounding noise
-    solid = g > (1e-4 * gscale if gscale is not None else 1e-5 * max(g.max(), 1e-30)) + 1e-7
+    # ... and against the reference fp32 path's own gradient error (gnoise = |g_fp32 - g_fp64|, ill-conditioned cases)
+    solid = g > max(1e-4 * gscale if gscale is not None else 1e-5 * max(g.max(), 1e-30), 8.0 * gnoise) + 1e-7
     d = np.abs(p_new - p_ref)
     if solid.any():
         assert d[solid].max() <= 2e-7 + rtol * np.abs(p_ref).max(), name + ": adam mismatch %.3e" % d[solid].max()

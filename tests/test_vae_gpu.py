@@ -66,6 +66,14 @@ def test_linear_wgrad(R, N, K):
 
 
 # ----------------------------------------------------------------------------- golden fixtures
+def _fp64_grads(cfg, sd64, b64, eps64):
+    s = {k: v.clone() for k, v in sd64.items()}
+    m = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
+    v = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
+    _, _, grads = vae_ref.train_step(s, cfg, b64, eps64, KL_WEIGHT, m, v, 1)
+    return {k: (grads[k].numpy() if k in grads else np.zeros(tuple(s[k].shape))) for k in vae_ref.trainable_keys(cfg)}
+
+
 def _trace_oracle(sd, cfg, batch, eps, training):
     vae_ref.TRACE = {}
     try:
@@ -151,12 +159,15 @@ def test_golden_eval_and_train(name):
     torch.cuda.synchronize()
     if not ill:
         gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad:"))
+        g64 = _fp64_grads(cfg, sd64, b64, ins["eps"].double())
         bad = []
         for k in g.files:
             if k.startswith("grad:"):
                 p = dict(model.named_parameters())[k[5:]]
                 try:
-                    assert_close(p.grad.cpu().numpy(), g[k], name + ":" + k, atol=5e-6 * gscale)
+                    # the reference's own fp32 gradient can be 1e-2 off in a fixture with a near-constant BatchNorm
+                    # column (vae_small_2d): hold HIP to the fp64 result within the reference's own distance from it
+                    assert_close_conditioned(p.grad.cpu().numpy(), g64[k[5:]], g[k], name + ":" + k, atol=5e-6 * gscale, k=4.0)
                 except AssertionError as e:
                     bad.append(str(e))
         assert not bad, "\n".join(bad[:40]) + "\n" + report
@@ -185,11 +196,15 @@ def test_golden_fused_train_step(name):
         assert_close(losses[2], g["loss_KLD_Gauss"], name + ":kld")
     sd = model.state_dict()
     gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad:"))
+    sd0 = vae_ref.init_state(cfg, seed=42)
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+    g64 = _fp64_grads(cfg, sd64, (ins["objs"], ins["triples"], ins["boxes"].double(), ins["angles"], ins["attrs"]), ins["eps"].double())
     for k in g.files:
         if k.startswith("buf:"):
             assert_close(sd[k[4:]].cpu().numpy(), g[k], name + ":" + k)
         elif k.startswith("adam:") and ("grad:" + k[5:]) in g.files:
-            assert_adam_close(sd[k[5:]].cpu().numpy(), g[k], g["grad:" + k[5:]], name + ":" + k, gscale=gscale)
+            gnoise = float(np.abs(g["grad:" + k[5:]] - g64[k[5:]]).max())
+            assert_adam_close(sd[k[5:]].cpu().numpy(), g[k], g["grad:" + k[5:]], name + ":" + k, gscale=gscale, gnoise=gnoise)
 
 
 def test_graph_replay_matches_eager():
@@ -308,3 +323,35 @@ def test_batched_sampling_matches_per_sample_decoding():
         mu, _ = vae_ref.encoder({k_: v.clone() for k_, v in sd.items()}, cfg, objs, triples, boxes, angles, attrs, training=False)
     assert_close(mean.numpy(), mu.double().mean(0).numpy(), "posterior mean", rtol=1e-4, atol=1e-5)
     assert_close(cov.numpy(), np.cov(mu.double().numpy().T), "posterior cov", rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("norm,mode,layers", [("batch", "feedforward", 3), ("none", "recurrent", 2), ("batch", "recurrent", 2)])
+def test_standalone_graph_triple_conv_net(norm, mode, layers):
+    """models/graph.py boundary row: GraphTripleConvNet(...).forward(obj_vecs, pred_vecs, edges) on its own, train-mode
+    BatchNorm (running statistics updated) and eval mode, against the oracle's gconv_net_apply."""
+    G = pkg("host.graph")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=layers, gconv_mode=mode, mlp_normalization=norm)
+    sd = vae_ref.init_state(cfg, seed=9)
+    net = G.GraphTripleConvNet(32, num_layers=layers, hidden_dim=64, mode=mode, mlp_normalization=norm)
+    sub = {k[len("gconv_net_ec."):]: v.clone() for k, v in sd.items() if k.startswith("gconv_net_ec.")}
+    net.load_state_dict(sub)
+    net = net.cuda()
+    g = torch.Generator().manual_seed(0)
+    O, T = 150, 260
+    x = torch.randn(O, 32, generator=g); p = torch.randn(T, 32, generator=g)
+    edges = torch.randint(0, O, (T, 2), generator=g)
+    for training in (True, False):
+        net.train(training)
+        sdr = {k: v.clone() for k, v in sd.items()}
+        with torch.no_grad():
+            ro, rp = vae_ref.gconv_net_apply(sdr, cfg, "ec", x, p, edges, training)
+            ho, hp = net(x.cuda(), p.cuda(), edges.cuda())
+        assert_close(ho.cpu().numpy(), ro.numpy(), "new_obj training=%s" % training)
+        assert_close(hp.cpu().numpy(), rp.numpy(), "new_pred training=%s" % training)
+        if training and norm == "batch":
+            for k, v in net.state_dict().items():
+                if "running" in k or "num_batches" in k:
+                    assert_close(v.cpu().numpy(), sdr["gconv_net_ec." + k].numpy(), k)
+            sd = sdr                       # carry the updated running statistics into the eval comparison
+    with pytest.raises(NotImplementedError):
+        net(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
