@@ -174,8 +174,12 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
-    if world > 1:
+    # SLN_BENCH_FORCE_DP=1 exercises the data-parallel code path (graph without Adam + RCCL all-reduce + fused Adam)
+    # on a single GPU; used to test that path on a 1-GPU box
+    force_dp = os.environ.get("SLN_BENCH_FORCE_DP", "0") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)
 
     lib = importlib.import_module("3d_sln_amd._lib")
@@ -188,8 +192,10 @@ def main():
                   gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
                   layout_noise_dim=32, use_AE=False)      # build_dataset_model.py:40-52 at options.py defaults
     model = M.Sg2ScVAEModel(**kwargs).cuda().train()
-    if world > 1:
+    dp = world > 1 or force_dp
+    if dp:
         dist.broadcast(model.flat_params, 0)
+        torch.cuda.synchronize()               # the timed loop runs on a side stream
         model.params_changed()
     b = syn.scene_graph_batch(args.graphs, args.objs, args.triples, seed=1000 + rank, device="cuda")
     batch = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
@@ -200,7 +206,7 @@ def main():
     inv_world = 1.0 / world
 
     def step():
-        if world == 1:
+        if not dp:
             return model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=True)
         losses = model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=False)
         dist.all_reduce(model.flat_grads)                 # ONE collective per step: 15.5 MB fp32 over xGMI
@@ -210,7 +216,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -223,7 +229,7 @@ def main():
             losses = step()
         barrier()
         dt = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -241,7 +247,7 @@ def main():
                                "Sg2ScVAE train step at train.py defaults (embedding_dim=64, 5+5 GraphTripleConv, BatchNorm)"
                                % (args.graphs, args.objs, args.triples),
                    "O": int(O), "T": int(b["triples"].shape[0]), "hipgraph": bool(use_graph),
-                   "parallelism": "dp%d" % world, "final_total_loss": round(final_loss, 5)},
+                   "parallelism": "dp%d" % world, "collective": ("1 all-reduce of %d fp32 grads/step" % model.flat_grads.numel()) if dp else None, "final_total_loss": round(final_loss, 5)},
     }
 
     if rank == 0 and not args.no_render:
@@ -314,7 +320,7 @@ def main():
                                    "kind": "port", "sample": "%d train steps of the same batch (%d graphs), oracle/vae_ref.py, "
                                    "torch CPU fp32, %.1f ms/step" % (args.cpu_steps, args.graphs, cdt / args.cpu_steps * 1e3)}
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 
