@@ -359,36 +359,52 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, int H, int W, int
          ly * ((1.f - lx) * s[(long)yb * W + xa] + lx * s[(long)yb * W + xb]);
 }
 
-// tanh(conv5x5_zero_pad(leaky_0.2(x)))  (:1602-1603); Cout is tiny (3): plain FMA, weights in LDS
+// tanh(conv5x5_zero_pad(leaky_0.2(x)))  (:1602-1603).  Cout is tiny (3): VALU FMAs.  A workgroup owns a 16x16 output
+// tile; per chunk of 8 input channels the zero-padded, LeakyReLU'ed (16+4)^2 halo goes to LDS once and is read 25x;
+// the weights are addressed with loop counters only, so hipcc fetches them through the scalar cache.
+constexpr int IT = 16, IH = IT + 4, ICK = 8;
+template <int COUT>
 __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ x, int Cin, int H, int W,
-                                                       const float* __restrict__ w, const float* __restrict__ bias, int Cout,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
                                                        float* __restrict__ y) {
-  extern __shared__ float ws[];                 // [Cout][Cin][25]
-  for (int i = threadIdx.x; i < Cout * Cin * 25; i += 256) ws[i] = w[i];
-  __syncthreads();
+  __shared__ float halo[ICK][IH * IH];
+  const int tiles_x = (W + IT - 1) / IT;
+  const int tx0 = (blockIdx.x % tiles_x) * IT, ty0 = (blockIdx.x / tiles_x) * IT, b = blockIdx.y;
+  const int lx = threadIdx.x & (IT - 1), ly = threadIdx.x >> 4;
   const long plane = (long)H * W;
-  const long p = (long)blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (p >= plane) return;
-  const int yy = (int)(p / W), xx = (int)(p % W);
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int ci = 0; ci < Cin; ++ci) {
-    const float* xc = x + ((size_t)b * Cin + ci) * plane;
+  float acc[COUT];
 #pragma unroll
-    for (int ky = 0; ky < 5; ++ky) {
-      const int sy = yy + ky - 2;
-      if (sy < 0 || sy >= H) continue;
-#pragma unroll
-      for (int kx = 0; kx < 5; ++kx) {
-        const int sx = xx + kx - 2;
-        if (sx < 0 || sx >= W) continue;
-        float v = xc[(long)sy * W + sx];
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += ICK) {
+    for (int e = threadIdx.x; e < ICK * IH * IH; e += 256) {
+      const int c = e / (IH * IH), p = e % (IH * IH);
+      const int sy = ty0 + p / IH - 2, sx = tx0 + p % IH - 2;
+      float v = 0.f;
+      if (c0 + c < Cin && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+        v = x[((size_t)b * Cin + c0 + c) * plane + (long)sy * W + sx];
         v = v > 0.f ? v : 0.2f * v;
-        for (int co = 0; co < Cout; ++co) acc[co] = fmaf(ws[(co * Cin + ci) * 25 + ky * 5 + kx], v, acc[co]);
       }
+      halo[c][p] = v;
     }
+    __syncthreads();
+    const int cn = min(ICK, Cin - c0);
+    for (int c = 0; c < cn; ++c) {
+      const float* wc = w + (size_t)(c0 + c) * 25;          // + co * Cin * 25 below: uniform -> scalar loads
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float v = halo[c][(ly + ky) * IH + lx + kx];
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) acc[co] = fmaf(wc[(size_t)co * Cin * 25 + ky * 5 + kx], v, acc[co]);
+        }
+    }
+    __syncthreads();
   }
-  for (int co = 0; co < Cout; ++co) y[((size_t)b * Cout + co) * plane + p] = tanhf(acc[co] + bias[co]);
+  const int yy = ty0 + ly, xx = tx0 + lx;
+  if (yy < H && xx < W)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) y[((size_t)b * COUT + co) * plane + (long)yy * W + xx] = tanhf(acc[co] + bias[co]);
 }
 
 }  // namespace
@@ -481,8 +497,13 @@ int sln_conv_img_tanh(const float* x, int B, int Cin, int H, int W, const float*
   if (!x || !w || !bias || !y || Cout > 4 || Cout <= 0) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * H * W * (Cin + Cout), st);
-  hipLaunchKernelGGL(conv_img_kernel, dim3(sln_cdiv(H * W, 256), B), dim3(256), sizeof(float) * Cout * Cin * 25, st, x, Cin, H, W, w,
-                     bias, Cout, y);
+  const dim3 grid(sln_cdiv(W, IT) * sln_cdiv(H, IT), B);
+  switch (Cout) {
+    case 1: hipLaunchKernelGGL(conv_img_kernel<1>, grid, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+    case 2: hipLaunchKernelGGL(conv_img_kernel<2>, grid, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+    case 3: hipLaunchKernelGGL(conv_img_kernel<3>, grid, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+    default: hipLaunchKernelGGL(conv_img_kernel<4>, grid, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+  }
   SLN_CHECK_LAUNCH();
   return 0;
 }
