@@ -144,3 +144,39 @@ def test_fused_scene_matches_33_pass_restatement(image_size, target):
         assert_close(out3.detach().cpu().numpy(), r, "passes", rtol=1e-5, atol=1e-5)
         (out3 * go.cuda()).sum().backward()
         assert_close(v3.grad.cpu().numpy(), v1.grad.numpy(), "dV passes", rtol=1e-4, atol=2e-4 * v1.grad.abs().max().item())
+
+
+def test_batched_rooms_with_padding_equal_single_room_renders():
+    """Ragged rooms (different V / F) are batched by padding with degenerate faces of class -1: the padded batch must
+    reproduce each room's own render and vertex gradients."""
+    DR = pkg("host.diff_render")
+    rooms = [rr.synth_room(s, n_objects=n, target_faces=t) for s, n, t in ((11, 4, 300), (12, 7, 600), (13, 3, 200))]
+    IS = 96
+    singles, grads = [], []
+    go = torch.randn(3, 70, IS, IS, generator=torch.Generator().manual_seed(2)).cuda()
+    for i, (V, F, ranges, box) in enumerate(rooms):
+        v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+        out = DR.scene_render(v, torch.from_numpy(F)[None].cuda(), ranges, torch.from_numpy(box), image_size=IS)
+        (out * go[i:i + 1]).sum().backward()
+        singles.append(out.detach()); grads.append(v.grad[0])
+    Vmax = max(r[0].shape[0] for r in rooms)
+    prepared, Fmax = [], 0
+    for V, F, ranges, box in rooms:
+        K, R, t = DR.get_cam_mat(torch.from_numpy(box), "cpu")
+        faces, cls, classes, chan, dch = DR.cull_and_classify(torch.from_numpy(V)[None], torch.from_numpy(F)[None], ranges, R, t)
+        faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), 1)[0]; cls = torch.cat((cls, cls))
+        vp = torch.zeros(Vmax, 3); vp[:V.shape[0]] = torch.from_numpy(V)
+        prepared.append((vp, faces, cls, K[0], R[0], t[0])); Fmax = max(Fmax, faces.shape[0])
+    Vb = torch.stack([p[0] for p in prepared]).cuda().requires_grad_(True)
+    Fb = torch.zeros(3, Fmax, 3, dtype=torch.int32); Cb = torch.full((3, Fmax), -1, dtype=torch.int32)
+    for i, p in enumerate(prepared):
+        Fb[i, :p[1].shape[0]] = p[1]; Cb[i, :p[2].shape[0]] = p[2]
+    out = DR.scene_render_batch(Vb, Fb.cuda(), Cb.cuda(), torch.tensor(chan, dtype=torch.int32).cuda(),
+                                torch.tensor(dch, dtype=torch.int32).cuda(), torch.stack([p[3] for p in prepared]).cuda(),
+                                torch.stack([p[4] for p in prepared]).cuda(), torch.stack([p[5] for p in prepared]).cuda(), IS, 0.001)
+    (out * go).sum().backward()
+    for i, (V, F, ranges, box) in enumerate(rooms):
+        assert_close(out[i:i + 1].detach().cpu().numpy(), singles[i].cpu().numpy(), "room %d" % i, rtol=1e-6, atol=1e-6)
+        assert_close(Vb.grad[i, :V.shape[0]].cpu().numpy(), grads[i].cpu().numpy(), "room %d dV" % i, rtol=1e-4,
+                     atol=1e-4 * grads[i].abs().max().item())
+    assert torch.isfinite(Vb.grad).all()
