@@ -21,7 +21,6 @@
 namespace {
 
 constexpr int BK = 32;
-inline int env_int(const char* k, int d) { const char* v = std::getenv(k); return v ? std::atoi(v) : d; }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -63,8 +62,10 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 // ---------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
+  constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
+  constexpr bool IDENT = AMODE == 2;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
   constexpr int PA = BM / 32, PB = BN / 32;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     for (int p = 0; p < PA; ++p) {
       const int rl = r0 + 32 * p;
       const bool v = cv && (m0 + rl) < a.M;
-      float4 t = xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
+      float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(as + rl * LDT) = t;
     }
@@ -157,8 +158,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   gload(min(1, last), S1{});
   gload(min(2, last), S2{});
 
-  sln_fill_coefs(a.A, coef, tid, 256);
-  for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+  if (!IDENT) {
+    sln_fill_coefs(a.A, coef, tid, 256);
+    for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+  }
   if (EPI == EPI_MASK) {
     for (int c = tid; c < BN; c += 256) {
       float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
@@ -273,26 +276,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
 int sln_gemm_init();
 namespace {
 
-template <int BM, int BN, int WM, int WN, bool HAS_X2, int EPI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int kpad = (a.K + 31) & ~31;
   const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16;
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, HAS_X2, EPI>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
 
-template <bool HAS_X2, int EPI>
+template <int AMODE, int EPI>
 int dispatch_nt_tile(const GemmNTArgs& a, hipStream_t st, int tile) {
   switch (tile) {
-    case 1: return launch_nt<128, 64, 2, 2, HAS_X2, EPI>(a, st);
-    case 2: return launch_nt<128, 128, 2, 2, HAS_X2, EPI>(a, st);
-    case 3: return launch_nt<64, 128, 2, 2, HAS_X2, EPI>(a, st);
-    case 4: return launch_nt<32, 128, 1, 4, HAS_X2, EPI>(a, st);
-    default: return launch_nt<64, 64, 2, 2, HAS_X2, EPI>(a, st);
+    case 1: return launch_nt<128, 64, 2, 2, AMODE, EPI>(a, st);
+    case 2: return launch_nt<128, 128, 2, 2, AMODE, EPI>(a, st);
+    case 3: return launch_nt<64, 128, 2, 2, AMODE, EPI>(a, st);
+    case 4: return launch_nt<32, 128, 1, 4, AMODE, EPI>(a, st);
+    default: return launch_nt<64, 64, 2, 2, AMODE, EPI>(a, st);
   }
 }
 
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (n < a.Nout && k < a.Kin && !a.x_noatomic) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
+        if (n < a.Nout && k < a.Kin) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
       }
     }
 
@@ -503,8 +506,9 @@ static int init_nt_tile() {
   if (e == hipSuccess)                                                                                            \
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  SLN_SET(false, EPI_PLAIN) SLN_SET(false, EPI_STATS) SLN_SET(false, EPI_MASK)
-  SLN_SET(true, EPI_PLAIN) SLN_SET(true, EPI_STATS) SLN_SET(true, EPI_MASK)
+  SLN_SET(0, EPI_PLAIN) SLN_SET(0, EPI_STATS) SLN_SET(0, EPI_MASK)
+  SLN_SET(1, EPI_PLAIN) SLN_SET(1, EPI_STATS) SLN_SET(1, EPI_MASK)
+  SLN_SET(2, EPI_PLAIN) SLN_SET(2, EPI_STATS) SLN_SET(2, EPI_MASK)
 #undef SLN_SET
   return (int)e;
 }
@@ -534,14 +538,18 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
     const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
     tile = b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
   }
-  if (x2) {
-    if (epi == EPI_MASK) return dispatch_nt_tile<true, EPI_MASK>(a, st, tile);
-    if (epi == EPI_STATS) return dispatch_nt_tile<true, EPI_STATS>(a, st, tile);
-    return dispatch_nt_tile<true, EPI_PLAIN>(a, st, tile);
+  bool ident = !x2;
+  for (int s = 0; s < a.A.nseg; ++s) ident = ident && a.A.seg[s].coef == SLN_COEF_IDENT;
+  const int amode = x2 ? 1 : (ident ? 2 : 0);
+#define SLN_DISPATCH(AM)                                                              \
+  if (amode == AM) {                                                                  \
+    if (epi == EPI_MASK) return dispatch_nt_tile<AM, EPI_MASK>(a, st, tile);          \
+    if (epi == EPI_STATS) return dispatch_nt_tile<AM, EPI_STATS>(a, st, tile);        \
+    return dispatch_nt_tile<AM, EPI_PLAIN>(a, st, tile);                              \
   }
-  if (epi == EPI_MASK) return dispatch_nt_tile<false, EPI_MASK>(a, st, tile);
-  if (epi == EPI_STATS) return dispatch_nt_tile<false, EPI_STATS>(a, st, tile);
-  return dispatch_nt_tile<false, EPI_PLAIN>(a, st, tile);
+  SLN_DISPATCH(0) SLN_DISPATCH(1) SLN_DISPATCH(2)
+#undef SLN_DISPATCH
+  return -1;
 }
 
 int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
@@ -551,16 +559,16 @@ int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
   for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
   if (a.rows_per_block <= 0) {
     // aim for >= ~512 blocks in total, chunks a multiple of BK rows
-    static const int target = env_int("SLN_X_TN_BLOCKS", 768);
+    // measured on MI355X (tools/gemm_bench.py): ~768 blocks in flight, but never fewer than 256 rows per block -
+    // below that the per-block prologue and the dW atomics (64x64 per block) dominate
+    const int target = 768;
     const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
     int chunks = sln_cdiv(target, tiles);
-    static const int minrows = env_int("SLN_X_TN_MINROWS", 256);
+    const int minrows = 256;
     int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
     a.rows_per_block = rpb < minrows ? minrows : rpb;
   }
   (void)tile;
-  static const int noat = env_int("SLN_X_NOATOMIC", 0);
-  a.x_noatomic = noat;
   if (x2) return launch_tn<64, 64, 2, 2, true>(a, st);
   return launch_tn<64, 64, 2, 2, false>(a, st);
 }

@@ -33,7 +33,6 @@ struct GemmTNArgs {
   int lddw;
   int R, Nout, Kin;
   int rows_per_block;   // <= 0: choose
-  int x_noatomic;       // experiment switch (never set in production)
 };
 
 // epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 32x128
