@@ -62,13 +62,18 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 // ---------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
+// WK: wave groups splitting every K tile between them (intra-block split-K, reduced through LDS at the end): WK = 2 gives
+// 8 waves per 64x64 tile, i.e. finer SIMD balance and twice the waves per CU when the grid has only 0.5-2.5 blocks per CU.
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK>
+__global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
+  constexpr int NT = 256 * WK;
   constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
   constexpr bool IDENT = AMODE == 2;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
-  constexpr int PA = BM / 32, PB = BN / 32;
+  constexpr int RP = 32 * WK;                  // rows staged per pass
+  constexpr int PA = BM / RP, PB = BN / RP;
+  static_assert(BM % RP == 0 && BN % RP == 0, "tile too small for WK");
   constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
   static_assert(WM * WN == 4, "4 waves per block");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,8 +82,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
   float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
+  float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kgroup = tid >> 8;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int nwg = gridDim.x;
   const int lb = xcd_remap(blockIdx.x, nwg);
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   int ra_idx[PA], rb_idx[PA];
 #pragma unroll
   for (int p = 0; p < PA; ++p) {
-    const int row = min(m0 + r0 + 32 * p, a.M - 1);      // clamped: loads are unconditional, masking happens at the LDS store
+    const int row = min(m0 + r0 + RP * p, a.M - 1);      // clamped: loads are unconditional, masking happens at the LDS store
     ra_idx[p] = a.A.idx_a ? a.A.idx_a[row] : row;
     rb_idx[p] = a.A.idx_b ? a.A.idx_b[row] : row;
   }
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int row = min(m0 + r0 + 32 * p, a.M - 1);
+      const int row = min(m0 + r0 + RP * p, a.M - 1);
       const int r = sg.which == 0 ? row : (sg.which == 1 ? ra_idx[p] : rb_idx[p]);
       ga1[S][p] = ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + cs);
       if (HAS_X2) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     const int cw = min(k0 + 4 * kq, a.K - 4);
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const int n = min(n0 + r0 + 32 * p, a.N - 1);
+      const int n = min(n0 + r0 + RP * p, a.N - 1);
       gb[S][p] = ld4(a.W + (size_t)n * a.ldw + cw);
     }
   };
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     const float4* cf = coef + min(col, kpad - 4);
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int rl = r0 + 32 * p;
+      const int rl = r0 + RP * p;
       const bool v = cv && (m0 + rl) < a.M;
       float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
@@ -144,10 +150,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     const bool kv = col < a.K;
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const bool v = kv && (n0 + r0 + 32 * p) < a.N;
+      const bool v = kv && (n0 + r0 + RP * p) < a.N;
       float4 t = gb[S][p];
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(bs + (r0 + 32 * p) * LDT) = t;
+      *reinterpret_cast<float4*>(bs + (r0 + RP * p) * LDT) = t;
     }
   };
 
@@ -159,11 +165,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   gload(min(2, last), S2{});
 
   if (!IDENT) {
-    sln_fill_coefs(a.A, coef, tid, 256);
-    for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+    sln_fill_coefs(a.A, coef, tid, NT);
+    for (int c = a.K + tid; c < kpad; c += NT) coef[c] = z4;
   }
   if (EPI == EPI_MASK) {
-    for (int c = tid; c < BN; c += 256) {
+    for (int c = tid; c < BN; c += NT) {
       float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
       if (n0 + c < a.N) {
         bn_fwd_coef(a.obn, n0 + c, e.x, e.y);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
     const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk;
     const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk;
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
+    for (int kb = kgroup * (BK / WK); kb < (kgroup + 1) * (BK / WK); kb += 8) {
       float4 av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(as + 32 * i * LDT + kb);
@@ -222,7 +228,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   else if (ntiles - kt == 2) { body(kt, S1{}); body(kt + 1, S2{}); }
 
   // ------------------------------- epilogue -------------------------------
-  float* red = As;   // [WM][BN][2] (tiles no longer needed: last loop iteration ended on a barrier)
+  if (WK > 1) {           // fold the K groups: group 1 parks its accumulators in the (now idle) tile region
+    float* xr = As;       // [4 waves][TM*TN][16][64]
+    if (kgroup == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xr[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kgroup == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += xr[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane];
+    }
+  }
+  if (kgroup == 0) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
@@ -255,11 +281,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
       if (lk == 0) { red[((wave / WN) * BN + cl) * 2 + 0] = s1; red[((wave / WN) * BN + cl) * 2 + 1] = s2; }
     }
   }
+  }   // kgroup == 0
   if (EPI != EPI_PLAIN) {
     __syncthreads();
     double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
     if (out != nullptr) {
-      for (int c = tid; c < BN; c += 256) {
+      for (int c = tid; c < BN; c += NT) {
         if (n0 + c < a.N) {
           float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -276,14 +303,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
 int sln_gemm_init();
 namespace {
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK = 1>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int kpad = (a.K + 31) & ~31;
-  const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16;
+  const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, WK>), dim3(grid), dim3(256 * WK), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -295,6 +322,7 @@ int dispatch_nt_tile(const GemmNTArgs& a, hipStream_t st, int tile) {
     case 2: return launch_nt<128, 128, 2, 2, AMODE, EPI>(a, st);
     case 3: return launch_nt<64, 128, 2, 2, AMODE, EPI>(a, st);
     case 4: return launch_nt<32, 128, 1, 4, AMODE, EPI>(a, st);
+    case 5: return launch_nt<64, 64, 2, 2, AMODE, EPI, 2>(a, st);
     default: return launch_nt<64, 64, 2, 2, AMODE, EPI>(a, st);
   }
 }
@@ -499,12 +527,12 @@ int launch_tn(const GemmTNArgs& a, hipStream_t st) {
 }  // namespace
 
 // Raise the dynamic-LDS limit of every instantiation once (must not happen inside a stream capture).
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int WK = 1>
 static int init_nt_tile() {
   hipError_t e = hipSuccess;
 #define SLN_SET(X2, EPI)                                                                                          \
   if (e == hipSuccess)                                                                                            \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI>),              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, WK>),              \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET(0, EPI_PLAIN) SLN_SET(0, EPI_STATS) SLN_SET(0, EPI_MASK)
   SLN_SET(1, EPI_PLAIN) SLN_SET(1, EPI_STATS) SLN_SET(1, EPI_MASK)
@@ -517,6 +545,7 @@ int sln_gemm_init() {
   static bool done = false;
   if (done) return 0;
   int r = init_nt_tile<64, 64, 2, 2>();
+  if (!r) r = init_nt_tile<64, 64, 2, 2, 2>();
   if (!r) r = init_nt_tile<128, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 128, 2, 2>();
   if (!r) r = init_nt_tile<64, 128, 2, 2>();
