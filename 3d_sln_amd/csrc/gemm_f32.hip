@@ -65,7 +65,7 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 // WK: wave groups splitting every K tile between them (intra-block split-K, reduced through LDS at the end): WK = 2 gives
 // 8 waves per 64x64 tile, i.e. finer SIMD balance and twice the waves per CU when the grid has only 0.5-2.5 blocks per CU.
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK>
-__global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
+__device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
   constexpr int NT = 256 * WK;
   constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
   constexpr bool IDENT = AMODE == 2;
@@ -76,7 +76,6 @@ __global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
   static_assert(BM % RP == 0 && BN % RP == 0, "tile too small for WK");
   constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
   static_assert(WM * WN == 4, "4 waves per block");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);
   float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
@@ -86,8 +85,7 @@ __global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kgroup = tid >> 8;
   const int tiles_n = (a.N + BN - 1) / BN;
-  const int nwg = gridDim.x;
-  const int lb = xcd_remap(blockIdx.x, nwg);
+  const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
@@ -299,6 +297,12 @@ __global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK>
+__global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, WK>(a, blockIdx.x, gridDim.x, smem);
+}
+
 }  // namespace
 int sln_gemm_init();
 namespace {
@@ -363,13 +367,12 @@ __device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
 }
 
 template <int BM, int BN, int WM, int WN, bool G_X2>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
+__device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, const int by, char* smem) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int SA = BM + 4, SB = BN + 4;
   constexpr int TPRA = BM / 4, TPRB = BN / 4;         // threads per row
   constexpr int RPA = 256 / TPRA, RPB = 256 / TPRB;   // rows per pass
   constexpr int PA = BK / RPA, PB = BK / RPB;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* coefG = reinterpret_cast<float4*>(smem);          // [BM]
   float4* coefX = coefG + BM;                               // [BN]
   float* As = reinterpret_cast<float*>(coefX + BN);         // [2][BK][SA]
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_k = (a.Kin + BN - 1) / BN;
-  const int n0 = (blockIdx.x / tiles_k) * BM, k0 = (blockIdx.x % tiles_k) * BN;
-  const int rbeg = blockIdx.y * a.rows_per_block;
+  const int n0 = (bx / tiles_k) * BM, k0 = (bx % tiles_k) * BN;
+  const int rbeg = by * a.rows_per_block;
   const int rend = min(a.R, rbeg + a.rows_per_block);
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
       }
     }
 
-  if (a.db != nullptr && (blockIdx.x % tiles_k) == 0) {
+  if (a.db != nullptr && (bx % tiles_k) == 0) {
     // threads with equal (tid % TPRA) hold partial sums of the same 4 columns
 #pragma unroll
     for (int off = TPRA; off < 64; off <<= 1) {
@@ -511,6 +514,44 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
       if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, dbacc.w);
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN, bool G_X2>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_tn_body<BM, BN, WM, WN, G_X2>(a, blockIdx.x, blockIdx.y, smem);
+}
+
+// One launch for the two GEMMs that consume the same output gradient G of a Linear: the dgrad (NT, 64x64 tiles, blocks
+// [0, nt_blocks)) and the wgrad (TN, the remaining tn_gx * tn_gy blocks).  At batch 64 either one fills less than half of
+// the chip and a launch costs about as much as its work, so the pair shares one dispatch.
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, const GemmTNArgs b, const int nt_blocks, const int tn_gx) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if ((int)blockIdx.x < nt_blocks) {
+    gemm_nt_body<64, 64, 2, 2, AMODE, EPI, 1>(a, blockIdx.x, nt_blocks, smem);
+  } else {
+    const int id = blockIdx.x - nt_blocks;
+    gemm_tn_body<64, 64, 2, 2, AMODE == 1>(b, id % tn_gx, id / tn_gx, smem);
+  }
+}
+
+inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
+  const int kpad = (K + 31) & ~31;
+  return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
+}
+inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + 4 + BN + 4) * 4; }
+
+template <int AMODE, int EPI>
+int launch_dual(const GemmNTArgs& a, const GemmTNArgs& b, hipStream_t st) {
+  const size_t s1 = nt_smem_bytes(a.K, 64, 64, 2), s2 = tn_smem_bytes(64, 64);
+  const size_t smem = s1 > s2 ? s1 : s2;
+  const int nt_blocks = sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64);
+  const int gx = sln_cdiv(b.Nout, 64) * sln_cdiv(b.Kin, 64), gy = sln_cdiv(b.R, b.rows_per_block);
+  if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  hipLaunchKernelGGL((gemm_dual_kernel<AMODE, EPI>), dim3(nt_blocks + gx * gy), dim3(256), smem, st, a, b, nt_blocks, gx);
+  SLN_CHECK_LAUNCH();
+  return 0;
 }
 
 template <int BM, int BN, int WM, int WN, bool G_X2>
@@ -554,22 +595,50 @@ int sln_gemm_init() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SLN_SET_DUAL(AM, EPI)                                                                                     \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dual_kernel<AM, EPI>),                \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  SLN_SET_DUAL(0, EPI_PLAIN) SLN_SET_DUAL(0, EPI_MASK) SLN_SET_DUAL(1, EPI_PLAIN) SLN_SET_DUAL(1, EPI_MASK)
+  SLN_SET_DUAL(2, EPI_PLAIN) SLN_SET_DUAL(2, EPI_MASK)
+#undef SLN_SET_DUAL
   done = r == 0;
   return r;
 }
 
-int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
-  SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
+static int nt_heuristic_tile(const GemmNTArgs& a) {   // enough blocks to cover 256 CUs, otherwise the biggest tile
+  const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
+  const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
+  return b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
+}
+
+static int nt_amode(const GemmNTArgs& a) {
   bool x2 = false;
   for (int s = 0; s < a.A.nseg; ++s) x2 |= a.A.seg[s].x2 != nullptr;
-  if (tile < 0) {   // heuristic: enough blocks to cover 256 CUs, otherwise the biggest tile
-    const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
-    const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
-    tile = b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
-  }
   bool ident = !x2;
   for (int s = 0; s < a.A.nseg; ++s) ident = ident && a.A.seg[s].coef == SLN_COEF_IDENT;
-  const int amode = x2 ? 1 : (ident ? 2 : 0);
+  return x2 ? 1 : (ident ? 2 : 0);
+}
+
+static bool tn_prepare(GemmTNArgs& a) {   // fills rows_per_block; returns whether G carries a second source
+  bool x2 = false;
+  for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
+  if (a.rows_per_block <= 0) {
+    // measured on MI355X (tools/gemm_bench.py): ~768 blocks in flight, but never fewer than 256 rows per block -
+    // below that the per-block prologue and the dW atomics (64x64 per block) dominate; chunks a multiple of BK rows
+    const int target = 768;
+    const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
+    int chunks = sln_cdiv(target, tiles);
+    const int minrows = 256;
+    int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
+    a.rows_per_block = rpb < minrows ? minrows : rpb;
+  }
+  return x2;
+}
+
+int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
+  SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
+  if (tile < 0) tile = nt_heuristic_tile(a);
+  const int amode = nt_amode(a);
 #define SLN_DISPATCH(AM)                                                              \
   if (amode == AM) {                                                                  \
     if (epi == EPI_MASK) return dispatch_nt_tile<AM, EPI_MASK>(a, st, tile);          \
@@ -584,20 +653,25 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
 int sln_launch_gemm_tn(const GemmTNArgs& a0, int tile, hipStream_t st) {
   SlnProfScope prof(SLN_FAM_GEMM_TN, 2.0 * a0.R * a0.Nout * a0.Kin, st);
   GemmTNArgs a = a0;
-  bool x2 = false;
-  for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
-  if (a.rows_per_block <= 0) {
-    // aim for >= ~512 blocks in total, chunks a multiple of BK rows
-    // measured on MI355X (tools/gemm_bench.py): ~768 blocks in flight, but never fewer than 256 rows per block -
-    // below that the per-block prologue and the dW atomics (64x64 per block) dominate
-    const int target = 768;
-    const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
-    int chunks = sln_cdiv(target, tiles);
-    const int minrows = 256;
-    int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
-    a.rows_per_block = rpb < minrows ? minrows : rpb;
-  }
+  const bool x2 = tn_prepare(a);
   (void)tile;
   if (x2) return launch_tn<64, 64, 2, 2, true>(a, st);
   return launch_tn<64, 64, 2, 2, false>(a, st);
+}
+
+int sln_launch_gemm_dual(const GemmNTArgs& a, int epi, const GemmTNArgs& b0, hipStream_t st) {
+  GemmTNArgs b = b0;
+  const bool x2 = tn_prepare(b);
+  const int amode = nt_amode(a);
+  const bool nonempty = a.M > 0 && a.N > 0 && b.R > 0 && b.Nout > 0 && b.Kin > 0;
+  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1)) {   // big or odd shapes: separate launches
+    int r = sln_launch_gemm_tn(b0, -1, st);
+    return r ? r : sln_launch_gemm_nt(a, epi, -1, st);
+  }
+  SlnProfScope prof(SLN_FAM_GEMM_DUAL, 2.0 * a.M * a.N * a.K + 2.0 * b.R * b.Nout * b.Kin, st);
+#define SLN_DISPATCH(AM)                                                              \
+  if (amode == AM) return epi == EPI_MASK ? launch_dual<AM, EPI_MASK>(a, b, st) : launch_dual<AM, EPI_PLAIN>(a, b, st);
+  SLN_DISPATCH(0) SLN_DISPATCH(1) SLN_DISPATCH(2)
+#undef SLN_DISPATCH
+  return -1;
 }

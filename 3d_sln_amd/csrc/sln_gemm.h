@@ -38,4 +38,6 @@ struct GemmTNArgs {
 // epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 32x128
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st);
 int sln_launch_gemm_tn(const GemmTNArgs& a, int tile, hipStream_t st);
+// dgrad (NT) and wgrad (TN) of the same Linear in one launch when both are small; falls back to two launches otherwise
+int sln_launch_gemm_dual(const GemmNTArgs& nt, int epi, const GemmTNArgs& tn, hipStream_t st);
 int sln_gemm_init();   // raises dynamic-LDS limits; call once outside any stream capture

@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 
 enum { SLN_FAM_GEMM_NT = 0, SLN_FAM_GEMM_TN = 1, SLN_FAM_EDGE = 2, SLN_FAM_OTHER = 3, SLN_FAM_RASTER = 4,
-       SLN_FAM_RASTER_BWD = 5, SLN_FAM_CONV = 6, SLN_FAM_COUNT = 8 };
+       SLN_FAM_RASTER_BWD = 5, SLN_FAM_CONV = 6, SLN_FAM_GEMM_DUAL = 7, SLN_FAM_COUNT = 8 };
 
 extern bool g_sln_prof_on;
 void sln_prof_begin(int family, double work, hipStream_t st);

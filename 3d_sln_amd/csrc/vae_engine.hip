@@ -111,7 +111,17 @@ struct SlnVae {
     side_busy = true;
     return (int)r;
   }
+  // Pairing: a wgrad is held back and shares the launch of the next dgrad (sln_launch_gemm_dual); this replaced the
+  // side stream as the default (SLN_NO_DUAL=1 goes back to it) - one dispatch instead of two, and no event edges.
+  bool use_dual = true;
+  std::vector<GemmTNArgs> pending;
+  int flush_pending(hipStream_t st) {
+    for (const GemmTNArgs& t : pending) { int r = sln_launch_gemm_tn(t, -1, st); if (r) { pending.clear(); return r; } }
+    pending.clear();
+    return 0;
+  }
   int join_side(hipStream_t st) {
+    { int r = flush_pending(st); if (r) return r; }
     if (!side_busy) return 0;
     hipEvent_t e = next_event();
     hipError_t r = hipEventRecord(e, side);
@@ -217,6 +227,11 @@ struct SlnVae {
       a.obn = view(mask_inst, 0, training);
       if (a.obn.mode != SLN_BN_NONE) { a.ogsums = bns[mask_inst].gsums; a.ocstride = bns[mask_inst].C; }
     }
+    if (!pending.empty()) {
+      const GemmTNArgs t = pending.front();
+      pending.erase(pending.begin());
+      return sln_launch_gemm_dual(a, epi, t, st);
+    }
     return sln_launch_gemm_nt(a, epi, -1, st);
   }
   int linear_wgrad(const Operand& G, const Operand& X, int ui, int R, hipStream_t st) {
@@ -224,6 +239,7 @@ struct SlnVae {
     GemmTNArgs a; std::memset(&a, 0, sizeof(a));
     a.G = G; a.X = X; a.dW = u.p.d_weight; a.db = u.p.d_bias; a.lddw = u.in;
     a.R = R; a.Nout = u.out; a.Kin = u.in; a.rows_per_block = 0;
+    if (use_dual) { pending.push_back(a); return 0; }
     if (use_side && side) {
       int r = fork_side(st);
       if (r) return r;
@@ -649,7 +665,9 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
   if (!c->batch_norm) h->n_bn_enc = 0;
   {
     const char* ns = std::getenv("SLN_NO_SIDE_STREAM");
-    h->use_side = !(ns && ns[0] == '1');
+    const char* nd = std::getenv("SLN_NO_DUAL");
+    h->use_dual = !(nd && nd[0] == '1');
+    h->use_side = !h->use_dual && !(ns && ns[0] == '1');
     if (h->use_side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->use_side = false; }
   }
   *out = h;
