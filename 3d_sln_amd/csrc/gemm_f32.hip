@@ -43,10 +43,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 struct SegSel {   // block-uniform view of the segment that holds logical column k0
   const float* x1; const float* x2; int ld1, ld2, c1, c2, which, base, end;
 };
+
+// MULTI = false: the operand has a single segment, so its fields are loop invariants that hipcc keeps in SGPRs.  With
+// the select chain below it re-reads the chosen segment's fields from the kernarg segment (s_load_dword) in every K
+// tile, and each such read is followed by s_waitcnt lgkmcnt(0), which also drains the LDS queue.
+template <bool MULTI>
 __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
+  SegSel r;
+  if (!MULTI) {
+    const Seg& g = op.seg[0];
+    r.x1 = g.x1; r.x2 = g.x2; r.ld1 = g.ld1; r.ld2 = g.ld2; r.c1 = g.c1; r.c2 = g.c2; r.which = g.which; r.base = 0; r.end = g.len;
+    return r;
+  }
   const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
   const int s = (op.nseg > 1 && k0 >= e0) ? ((op.nseg > 2 && k0 >= e1) ? 2 : 1) : 0;
-  SegSel r;
   r.x1 = s == 0 ? op.seg[0].x1 : (s == 1 ? op.seg[1].x1 : op.seg[2].x1);
   r.x2 = s == 0 ? op.seg[0].x2 : (s == 1 ? op.seg[1].x2 : op.seg[2].x2);
   r.ld1 = s == 0 ? op.seg[0].ld1 : (s == 1 ? op.seg[1].ld1 : op.seg[2].ld1);
@@ -62,18 +72,16 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 // ---------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------
-// WK: wave groups splitting every K tile between them (intra-block split-K, reduced through LDS at the end): WK = 2 gives
-// 8 waves per 64x64 tile, i.e. finer SIMD balance and twice the waves per CU when the grid has only 0.5-2.5 blocks per CU.
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK>
+// // (An intra-block split-K variant, 8 waves per 64x64 tile, was measured and dropped: same time, see DESIGN.md.)
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
 __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
-  constexpr int NT = 256 * WK;
+  constexpr int NT = 256;
   constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
   constexpr bool IDENT = AMODE == 2;
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
-  constexpr int RP = 32 * WK;                  // rows staged per pass
+  constexpr int RP = 32;                       // rows staged per pass
   constexpr int PA = BM / RP, PB = BN / RP;
-  static_assert(BM % RP == 0 && BN % RP == 0, "tile too small for WK");
   constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
   static_assert(WM * WN == 4, "4 waves per block");
   const int kpad = (a.K + 31) & ~31;
@@ -83,7 +91,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
   float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kgroup = tid >> 8;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (a.N + BN - 1) / BN;
   const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
@@ -98,8 +106,16 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     rb_idx[p] = a.A.idx_b ? a.A.idx_b[row] : row;
   }
 
+  int rid[PA];                                // source row of each staged row (single segment: gather resolved once)
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = min(m0 + r0 + RP * p, a.M - 1);
+    const int w0 = a.A.seg[0].which;
+    rid[p] = MULTI ? row : (w0 == 0 ? row : (w0 == 1 ? ra_idx[p] : rb_idx[p]));
+  }
   float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
   const int ntiles = kpad / BK;
+  const float* Wp = a.W; const int ldw = a.ldw, Mr = a.M, Nr = a.N, Kr = a.K;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
   // NOTE: every global load below is unconditional (addresses clamped into the operand); a
@@ -108,12 +124,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   auto gload = [&](int kt, auto stage) {
     constexpr int S = decltype(stage)::value;
     const int k0 = kt * BK;
-    const SegSel sg = pick_seg(a.A, k0);
+    const SegSel sg = pick_seg<MULTI>(a.A, k0);
     const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
-      const int row = min(m0 + r0 + RP * p, a.M - 1);
-      const int r = sg.which == 0 ? row : (sg.which == 1 ? ra_idx[p] : rb_idx[p]);
+      const int r = MULTI ? (sg.which == 0 ? rid[p] : (sg.which == 1 ? ra_idx[p] : rb_idx[p])) : rid[p];
       ga1[S][p] = ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + cs);
       if (HAS_X2) {
         const float* x2 = sg.x2 ? sg.x2 : sg.x1;                 // block-uniform select
@@ -121,17 +136,17 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
         ga2[S][p] = ld4(x2 + (size_t)r * ld2 + c2 + cs);
       }
     }
-    const int cw = min(k0 + 4 * kq, a.K - 4);
+    const int cw = min(k0 + 4 * kq, Kr - 4);
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const int n = min(n0 + r0 + RP * p, a.N - 1);
-      gb[S][p] = ld4(a.W + (size_t)n * a.ldw + cw);
+      const int n = min(n0 + r0 + RP * p, Nr - 1);
+      gb[S][p] = ld4(Wp + (size_t)n * ldw + cw);
     }
   };
   auto lstore = [&](int kt, int buf, auto stage) {
     constexpr int S = decltype(stage)::value;
     const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg(a.A, k0);
+    const SegSel sg = pick_seg<MULTI>(a.A, k0);
     const bool cv = col < sg.end;
     const bool x2v = HAS_X2 && sg.x2 != nullptr;
     float* as = As + buf * BM * LDT + 4 * kq;
@@ -140,15 +155,15 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int rl = r0 + RP * p;
-      const bool v = cv && (m0 + rl) < a.M;
+      const bool v = cv && (m0 + rl) < Mr;
       float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(as + rl * LDT) = t;
     }
-    const bool kv = col < a.K;
+    const bool kv = col < Kr;
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
-      const bool v = kv && (n0 + r0 + RP * p) < a.N;
+      const bool v = kv && (n0 + r0 + RP * p) < Nr;
       float4 t = gb[S][p];
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(bs + (r0 + RP * p) * LDT) = t;
@@ -191,34 +206,51 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
 
+  // Fragments ping-pong between two register sets; on entry to body(kt) set 0 already holds the first 8-wide k chunk of
+  // tile kt.  It was read right after the barrier that ended body(kt-1), under the MFMAs of that tile's last chunk, so
+  // neither the barrier nor the LDS read latency leaves the matrix pipe idle (each wave has a single dependent MFMA
+  // chain when the wave tile is 32x32, nothing else could cover them).
+  float4 fa[2][TM], fb[2][TN];
+  auto rd = [&](int buf, int kb, auto set) {
+    constexpr int F = decltype(set)::value;
+    const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk + kb;
+    const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk + kb;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[F][i] = *reinterpret_cast<const float4*>(as + 32 * i * LDT);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[F][j] = *reinterpret_cast<const float4*>(bs + 32 * j * LDT);
+  };
+  auto mma = [&](auto set) {
+    constexpr int F = decltype(set)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].x, fb[F][j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].y, fb[F][j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].z, fb[F][j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].w, fb[F][j].w, acc[i][j], 0, 0, 0);
+      }
+  };
+  rd(0, 0, S0{});
+
   // tile j lives in register stage j % 3; body(kt) computes tile kt from LDS, stores tile kt+1 from its stage
   // and refills that stage with tile kt+4.  Every body issues the SAME loads unconditionally (tile
   // indices clamped; the surplus tiles are never consumed) so that hipcc's s_waitcnt accounting is exact
   // and the wait in lstore() leaves the two younger stages in flight (vmcnt(8), not vmcnt(0)).
   auto body = [&](int kt, auto stage_next) {
     const int buf = kt & 1;
-    const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk;
-    const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk;
-#pragma unroll
-    for (int kb = kgroup * (BK / WK); kb < (kgroup + 1) * (BK / WK); kb += 8) {
-      float4 av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const float4*>(as + 32 * i * LDT + kb);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const float4*>(bs + 32 * j * LDT + kb);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[j].w, acc[i][j], 0, 0, 0);
-        }
-    }
+    rd(buf, 8, S1{});
+    mma(S0{});
     lstore(min(kt + 1, last), buf ^ 1, stage_next);
+    rd(buf, 16, S0{});
+    mma(S1{});
+    rd(buf, 24, S1{});
+    mma(S0{});
     gload(min(kt + 4, last), stage_next);
     __syncthreads();
+    rd(buf ^ 1, 0, S0{});
+    mma(S1{});
   };
   int kt = 0;
   for (; kt + 3 <= ntiles; kt += 3) { body(kt, S1{}); body(kt + 1, S2{}); body(kt + 2, S0{}); }
@@ -226,27 +258,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   else if (ntiles - kt == 2) { body(kt, S1{}); body(kt + 1, S2{}); }
 
   // ------------------------------- epilogue -------------------------------
-  if (WK > 1) {           // fold the K groups: group 1 parks its accumulators in the (now idle) tile region
-    float* xr = As;       // [4 waves][TM*TN][16][64]
-    if (kgroup == 1) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) xr[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (kgroup == 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += xr[(((wave * TM + i) * TN + j) * 16 + r) * 64 + lane];
-    }
-  }
-  if (kgroup == 0) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
@@ -279,7 +290,6 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       if (lk == 0) { red[((wave / WN) * BN + cl) * 2 + 0] = s1; red[((wave / WN) * BN + cl) * 2 + 1] = s2; }
     }
   }
-  }   // kgroup == 0
   if (EPI != EPI_PLAIN) {
     __syncthreads();
     double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
@@ -297,24 +307,25 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   }
 }
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK>
-__global__ __launch_bounds__(256 * WK) void gemm_nt_kernel(const GemmNTArgs a) {
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, WK>(a, blockIdx.x, gridDim.x, smem);
+  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI>(a, blockIdx.x, gridDim.x, smem);
 }
 
 }  // namespace
 int sln_gemm_init();
 namespace {
 
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int WK = 1>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int kpad = (a.K + 31) & ~31;
   const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, WK>), dim3(grid), dim3(256 * WK), smem, st, a);
+  if (a.A.nseg > 1) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, true>), dim3(grid), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, false>), dim3(grid), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -324,9 +335,6 @@ int dispatch_nt_tile(const GemmNTArgs& a, hipStream_t st, int tile) {
   switch (tile) {
     case 1: return launch_nt<128, 64, 2, 2, AMODE, EPI>(a, st);
     case 2: return launch_nt<128, 128, 2, 2, AMODE, EPI>(a, st);
-    case 3: return launch_nt<64, 128, 2, 2, AMODE, EPI>(a, st);
-    case 4: return launch_nt<32, 128, 1, 4, AMODE, EPI>(a, st);
-    case 5: return launch_nt<64, 64, 2, 2, AMODE, EPI, 2>(a, st);
     default: return launch_nt<64, 64, 2, 2, AMODE, EPI>(a, st);
   }
 }
@@ -529,7 +537,7 @@ template <int AMODE, int EPI>
 __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, const GemmTNArgs b, const int nt_blocks, const int tn_gx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < nt_blocks) {
-    gemm_nt_body<64, 64, 2, 2, AMODE, EPI, 1>(a, blockIdx.x, nt_blocks, smem);
+    gemm_nt_body<64, 64, 2, 2, AMODE, EPI, false>(a, blockIdx.x, nt_blocks, smem);
   } else {
     const int id = blockIdx.x - nt_blocks;
     gemm_tn_body<64, 64, 2, 2, AMODE == 1>(b, id % tn_gx, id / tn_gx, smem);
@@ -568,12 +576,15 @@ int launch_tn(const GemmTNArgs& a, hipStream_t st) {
 }  // namespace
 
 // Raise the dynamic-LDS limit of every instantiation once (must not happen inside a stream capture).
-template <int BM, int BN, int WM, int WN, int WK = 1>
+template <int BM, int BN, int WM, int WN>
 static int init_nt_tile() {
   hipError_t e = hipSuccess;
 #define SLN_SET(X2, EPI)                                                                                          \
   if (e == hipSuccess)                                                                                            \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, WK>),              \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, false>),       \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+  if (e == hipSuccess)                                                                                            \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, true>),        \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET(0, EPI_PLAIN) SLN_SET(0, EPI_STATS) SLN_SET(0, EPI_MASK)
   SLN_SET(1, EPI_PLAIN) SLN_SET(1, EPI_STATS) SLN_SET(1, EPI_MASK)
@@ -586,11 +597,8 @@ int sln_gemm_init() {
   static bool done = false;
   if (done) return 0;
   int r = init_nt_tile<64, 64, 2, 2>();
-  if (!r) r = init_nt_tile<64, 64, 2, 2, 2>();
   if (!r) r = init_nt_tile<128, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 128, 2, 2>();
-  if (!r) r = init_nt_tile<64, 128, 2, 2>();
-  if (!r) r = init_nt_tile<32, 128, 1, 4>();
   if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, false>),
@@ -664,7 +672,7 @@ int sln_launch_gemm_dual(const GemmNTArgs& a, int epi, const GemmTNArgs& b0, hip
   const bool x2 = tn_prepare(b);
   const int amode = nt_amode(a);
   const bool nonempty = a.M > 0 && a.N > 0 && b.R > 0 && b.Nout > 0 && b.Kin > 0;
-  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1)) {   // big or odd shapes: separate launches
+  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1) || a.A.nseg > 1) {   // big or odd shapes: separate launches
     int r = sln_launch_gemm_tn(b0, -1, st);
     return r ? r : sln_launch_gemm_nt(a, epi, -1, st);
   }

@@ -35,7 +35,7 @@ struct GemmTNArgs {
   int rows_per_block;   // <= 0: choose
 };
 
-// epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128, 3 = 64x128, 4 = 32x128
+// epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st);
 int sln_launch_gemm_tn(const GemmTNArgs& a, int tile, hipStream_t st);
 // dgrad (NT) and wgrad (TN) of the same Linear in one launch when both are small; falls back to two launches otherwise

@@ -38,7 +38,7 @@ def _dev(*ts):
 # ----------------------------------------------------------------------------- GEMM family
 @pytest.mark.parametrize("M,N,K", [(4096, 256, 384), (4096, 640, 256), (2048, 128, 256), (12, 640, 256),
                                    (8, 6, 256), (100, 48, 128), (333, 24, 36)])
-@pytest.mark.parametrize("tile", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [-1, 0, 1, 2])
 def test_linear_forward(M, N, K, tile):
     L = _lib()
     g = torch.Generator().manual_seed(M * 7 + N)
