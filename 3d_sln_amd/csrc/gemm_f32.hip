@@ -374,7 +374,10 @@ __device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool G_X2>
+// XG: the X operand has row-gathered segments (GraphTripleConv input).  Its row indices then run through their own
+// three-stage register pipeline, one tile ahead of the data loads that use them, so that no load waits on another.
+// G (a gradient) is never gathered.
+template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
 __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, const int by, char* smem) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int SA = BM + 4, SB = BN + 4;
@@ -405,29 +408,32 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   constexpr int NST = 3;
   float4 g1[NST][PA], g2[NST][PA], x1[NST][PB];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // unconditional, clamped loads (see the note in gemm_nt_kernel); masking happens in lstore()
-  const bool g_gather = a.G.idx_a != nullptr, x_gather = a.X.idx_a != nullptr;
-  const int* g_ip = gs.which == 2 ? a.G.idx_b : a.G.idx_a;
+  // unconditional, clamped loads (see the note in gemm_nt_body); masking happens in lstore()
   const int* x_ip = xs.which == 2 ? a.X.idx_b : a.X.idx_a;
+  if (x_ip == nullptr) x_ip = a.X.idx_a ? a.X.idx_a : a.X.idx_b;   // plain-row columns still issue the (unused) index loads
   const float* g_x2 = gs.x2 ? gs.x2 : gs.x1;
   const int g_ld2 = gs.x2 ? gs.ld2 : gs.ld1;
-  auto gload = [&](int rt, auto stage) {
+  int xi[NST][PB];
+  auto iload = [&](int rt, auto stage) {
+    constexpr int S = decltype(stage)::value;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) xi[S][p] = x_ip[min(rbeg + rt * BK + rb0 + RPB * p, rend - 1)];
+  };
+  auto gload = [&](int rt, int rt_idx, auto stage) {
     constexpr int S = decltype(stage)::value;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int row = min(rbeg + rt * BK + ra0 + RPA * p, rend - 1);
-      int r = row;
-      if (g_gather) { const int gi = g_ip[row]; r = gs.which ? gi : row; }
-      g1[S][p] = ld4(gs.x1 + (size_t)r * gs.ld1);
-      if (G_X2) g2[S][p] = ld4(g_x2 + (size_t)r * g_ld2);
+      g1[S][p] = ld4(gs.x1 + (size_t)row * gs.ld1);
+      if (G_X2) g2[S][p] = ld4(g_x2 + (size_t)row * g_ld2);
     }
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int row = min(rbeg + rt * BK + rb0 + RPB * p, rend - 1);
-      int r = row;
-      if (x_gather) { const int gi = x_ip[row]; r = xs.which ? gi : row; }
+      const int r = XG ? (xs.which ? xi[S][p] : row) : row;
       x1[S][p] = ld4(xs.x1 + (size_t)r * xs.ld1);
     }
+    if (XG) iload(rt_idx, stage);          // indices of the tile this stage will load next
   };
   float4 dbacc = z4;
   auto lstore = [&](int rt, int buf, auto stage, bool real) {
@@ -462,33 +468,53 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   const int ntiles = (rend - rbeg + BK - 1) / BK;
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
   const int last = ntiles - 1;          // ntiles >= 1: every launched block owns at least one row
-  gload(0, S0{});
-  gload(min(1, last), S1{});
-  gload(min(2, last), S2{});
+  if (XG) { iload(0, S0{}); iload(min(1, last), S1{}); iload(min(2, last), S2{}); }
+  gload(0, min(3, last), S0{});
+  gload(min(1, last), min(4, last), S1{});
+  gload(min(2, last), min(5, last), S2{});
   __syncthreads();            // coefficient tables visible
   lstore(0, 0, S0{}, true);
-  gload(min(3, last), S0{});
+  gload(min(3, last), min(6, last), S0{});
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
-  auto body = [&](int rt, auto stage_next) {
-    const int buf = rt & 1;
-    const float* as = As + buf * BK * SA + wm0 + lrow;
-    const float* bs = Bs + buf * BK * SB + wn0 + lrow;
+  // fragments of 4 k-steps (8 rows of the tile) ping-pong between two register sets; set 0 is refilled with the next
+  // tile's first chunk right after the barrier, under the MFMAs of the current tile's last chunk (as in gemm_nt_body)
+  float fa[2][4][TM], fb[2][4][TN];
+  auto rd = [&](int buf, int kk0, auto set) {
+    constexpr int F = decltype(set)::value;
+    const float* as = As + buf * BK * SA + wm0 + lrow + (kk0 + lk) * SA;
+    const float* bs = Bs + buf * BK * SB + wn0 + lrow + (kk0 + lk) * SB;
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      float av[TM], bv[TN];
+    for (int q = 0; q < 4; ++q) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = as[(kk + lk) * SA + 32 * i];
+      for (int i = 0; i < TM; ++i) fa[F][q][i] = as[2 * q * SA + 32 * i];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + lk) * SB + 32 * j];
+      for (int j = 0; j < TN; ++j) fb[F][q][j] = bs[2 * q * SB + 32 * j];
+    }
+  };
+  auto mma = [&](auto set) {
+    constexpr int F = decltype(set)::value;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    }
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q][i], fb[F][q][j], acc[i][j], 0, 0, 0);
+  };
+  rd(0, 0, S0{});
+  auto body = [&](int rt, auto stage_next) {
+    const int buf = rt & 1;
+    rd(buf, 8, S1{});
+    mma(S0{});
     lstore(min(rt + 1, last), buf ^ 1, stage_next, rt + 1 <= last);
-    gload(min(rt + 4, last), stage_next);
+    rd(buf, 16, S0{});
+    mma(S1{});
+    rd(buf, 24, S1{});
+    mma(S0{});
+    gload(min(rt + 4, last), min(rt + 7, last), stage_next);
     __syncthreads();
+    rd(buf ^ 1, 0, S0{});
+    mma(S1{});
   };
   int rt = 0;
   for (; rt + 3 <= ntiles; rt += 3) { body(rt, S1{}); body(rt + 1, S2{}); body(rt + 2, S0{}); }
@@ -524,26 +550,35 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool G_X2>
+template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_tn_body<BM, BN, WM, WN, G_X2>(a, blockIdx.x, blockIdx.y, smem);
+  gemm_tn_body<BM, BN, WM, WN, G_X2, XG>(a, blockIdx.x, blockIdx.y, smem);
 }
 
 // One launch for the two GEMMs that consume the same output gradient G of a Linear: the dgrad (NT, 64x64 tiles, blocks
 // [0, nt_blocks)) and the wgrad (TN, the remaining tn_gx * tn_gy blocks).  At batch 64 either one fills less than half of
 // the chip and a launch costs about as much as its work, so the pair shares one dispatch.
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, bool XG>
 __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, const GemmTNArgs b, const int nt_blocks, const int tn_gx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < nt_blocks) {
     gemm_nt_body<64, 64, 2, 2, AMODE, EPI, false>(a, blockIdx.x, nt_blocks, smem);
   } else {
     const int id = blockIdx.x - nt_blocks;
-    gemm_tn_body<64, 64, 2, 2, AMODE == 1>(b, id % tn_gx, id / tn_gx, smem);
+    gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(b, id % tn_gx, id / tn_gx, smem);
   }
 }
 
+inline bool tn_gathers(const GemmTNArgs& a) {
+  bool g = false;
+  for (int s = 0; s < a.X.nseg; ++s) g |= a.X.seg[s].which != 0;
+  return g;
+}
+inline bool tn_supported(const GemmTNArgs& a) {     // the gradient operand is addressed by plain rows
+  for (int s = 0; s < a.G.nseg; ++s) if (a.G.seg[s].which != 0) return false;
+  return true;
+}
 inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
   const int kpad = (K + 31) & ~31;
   return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
@@ -557,7 +592,8 @@ int launch_dual(const GemmNTArgs& a, const GemmTNArgs& b, hipStream_t st) {
   const int nt_blocks = sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64);
   const int gx = sln_cdiv(b.Nout, 64) * sln_cdiv(b.Kin, 64), gy = sln_cdiv(b.R, b.rows_per_block);
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_dual_kernel<AMODE, EPI>), dim3(nt_blocks + gx * gy), dim3(256), smem, st, a, b, nt_blocks, gx);
+  if (tn_gathers(b)) hipLaunchKernelGGL((gemm_dual_kernel<AMODE, EPI, true>), dim3(nt_blocks + gx * gy), dim3(256), smem, st, a, b, nt_blocks, gx);
+  else hipLaunchKernelGGL((gemm_dual_kernel<AMODE, EPI, false>), dim3(nt_blocks + gx * gy), dim3(256), smem, st, a, b, nt_blocks, gx);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -568,7 +604,9 @@ int launch_tn(const GemmTNArgs& a, hipStream_t st) {
   const int gx = sln_cdiv(a.Nout, BM) * sln_cdiv(a.Kin, BN);
   const int gy = sln_cdiv(a.R, a.rows_per_block);
   if (gx <= 0 || gy <= 0) return 0;
-  hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, G_X2>), dim3(gx, gy), dim3(256), smem, st, a);
+  if (!tn_supported(a)) return -1;
+  if (tn_gathers(a)) hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, G_X2, true>), dim3(gx, gy), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((gemm_tn_kernel<BM, BN, WM, WN, G_X2, false>), dim3(gx, gy), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -599,12 +637,15 @@ int sln_gemm_init() {
   int r = init_nt_tile<64, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 128, 2, 2>();
-  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, true>),
+#define SLN_SET_TN(X2, XG)                                                                                        \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, X2, XG>),     \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<64, 64, 2, 2, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  SLN_SET_TN(true, true) SLN_SET_TN(true, false) SLN_SET_TN(false, true) SLN_SET_TN(false, false)
+#undef SLN_SET_TN
 #define SLN_SET_DUAL(AM, EPI)                                                                                     \
-  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dual_kernel<AM, EPI>),                \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dual_kernel<AM, EPI, false>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dual_kernel<AM, EPI, true>),          \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET_DUAL(0, EPI_PLAIN) SLN_SET_DUAL(0, EPI_MASK) SLN_SET_DUAL(1, EPI_PLAIN) SLN_SET_DUAL(1, EPI_MASK)
   SLN_SET_DUAL(2, EPI_PLAIN) SLN_SET_DUAL(2, EPI_MASK)
@@ -672,7 +713,7 @@ int sln_launch_gemm_dual(const GemmNTArgs& a, int epi, const GemmTNArgs& b0, hip
   const bool x2 = tn_prepare(b);
   const int amode = nt_amode(a);
   const bool nonempty = a.M > 0 && a.N > 0 && b.R > 0 && b.Nout > 0 && b.Kin > 0;
-  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1) || a.A.nseg > 1) {   // big or odd shapes: separate launches
+  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1) || a.A.nseg > 1 || !tn_supported(b)) {   // big or odd shapes: separate launches
     int r = sln_launch_gemm_tn(b0, -1, st);
     return r ? r : sln_launch_gemm_nt(a, epi, -1, st);
   }
