@@ -290,7 +290,8 @@ def main():
             if cnt:
                 out["roofline"]["traffic"] = round(tot / cnt * 1e6)
                 out["roofline"]["traffic_source"] = "profiles/r01_vae_render_kernel_stats.csv (bytes per launch)"
-                out["roofline"]["algorithmic_bytes_per_launch"] = "operands+output of a 0.5 GFLOP fp32 GEMM: ~3-11 MB (shape dependent)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = ("dgrad+wgrad pair of one Linear: G (two sources under BatchNorm), X, W^T, "
+                                                                   "xprev, dX: 4-56 MB (shape dependent)")
         except Exception:
             pass
         if "edge" in fam:
