@@ -161,3 +161,9 @@ def scene_render_passes(vertices_buf, face_buf, class_ranges, room_box, image_si
     oh = torch.stack([planes_oh.get(i, one_hot[i]) for i in range(41)])
     dh = torch.stack([planes_dh.get(i, depth_hot[i]) for i in range(depth_hot.shape[0])])
     return torch.cat((depth, oh[1:], dh), dim=0)[None]
+
+
+def mesh_render_func(boxes, angles, objs, model_ids_old=None, obj_size_target=None):
+    """The reference's entry point name and signature (diff_render.py:48); implementation in ``host/refine.py``."""
+    from . import refine
+    return refine.mesh_render_func(boxes, angles, objs, model_ids_old, obj_size_target)

@@ -107,6 +107,53 @@ def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=N
     return torch.cat(verts)[None], torch.cat(faces)[None], ranges, sizes, size_loss
 
 
+_MESH_SOURCE = {"object_idx_to_name": None, "bank": None}
+
+
+def configure_meshes(object_idx_to_name, bank=None, device="cuda"):
+    """Stands in for the module globals of models/misc.py (:17-31: vocabulary + SUNCG model tables) that
+    ``mesh_render_func`` reads.  ``bank`` defaults to one procedural model per furniture class."""
+    _MESH_SOURCE["object_idx_to_name"] = list(object_idx_to_name)
+    _MESH_SOURCE["bank"] = bank or MeshBank([n for n in set(object_idx_to_name) if n not in DO_NOT_VIS and n != "__room__"], device)
+
+
+def mesh_render_func(boxes, angles, objs, model_ids_old=None, obj_size_target=None):
+    """Same call contract as the reference (models/diff_render.py:48-435):
+    ``boxes``: list of b tensors [6] (room-normalised, room row last), ``angles``: list of b scalar tensors (bins),
+    ``objs``: list of b class indices -> ``(final[1,70,256,256], model_ids_return, obj_size_return, size_loss)``.
+    First call (``model_ids_old is None``) caches the room box ("box_info"), the retrieved model id per object and the
+    object sizes; later calls reuse them, overload the room box (:55-57) and add the size / wall-drift penalties
+    (:98-100,160-165).  Mesh retrieval is the procedural ``MeshBank`` (see the module docstring)."""
+    src = _MESH_SOURCE
+    if src["bank"] is None:
+        raise RuntimeError("call refine.configure_meshes(object_idx_to_name) first (stands in for models/misc.py globals)")
+    names, bank = src["object_idx_to_name"], src["bank"]
+    boxes = list(boxes)
+    dev = boxes[0].device
+    model_ids_return, obj_size_return = {}, []
+    old_wall = boxes[-1].clone()
+    if model_ids_old is not None:
+        boxes[-1] = torch.from_numpy(np.asarray(model_ids_old["box_info"])).float().to(dev)
+    else:
+        model_ids_return["box_info"] = boxes[-1].detach().cpu().numpy()
+    class_names = [names[int(o)] for o in objs]
+    for i, n in enumerate(class_names[:-1]):
+        if model_ids_old is None:
+            model_ids_return[i] = n + "#0"                       # one procedural model per class
+    target = None
+    if obj_size_target is not None:
+        target = [torch.from_numpy(np.asarray(t)).float().to(dev) for t in obj_size_target[:-1]]
+    v, f, ranges, sizes, size_loss = assemble_scene(torch.stack(boxes), torch.stack([a.reshape(()) for a in angles]).float(),
+                                                    class_names, bank, boxes[-1].detach(), target)
+    if obj_size_target is not None:
+        size_loss = size_loss + F.mse_loss(old_wall, torch.from_numpy(np.asarray(obj_size_target[-1])).float().to(dev))
+    else:
+        obj_size_return = [x.cpu().numpy() for x in sizes] + [boxes[-1].detach().cpu().numpy()]
+        model_ids_return["wall"] = {"wall_bbox_min": [0.0, 0.0, 0.0], "wall_bbox_max": [float(x) for x in boxes[-1][3:]]}
+    final = DR.scene_render(v, f, ranges, boxes[-1].detach())
+    return final, model_ids_return, obj_size_return, size_loss
+
+
 def refinement_loss(iter_image, target, target_container, size_loss):
     """test_render_refine.py:332-356 (target_container = per-scale argmax labels of the target, -100 where empty)."""
     iter_image = iter_image.clone()

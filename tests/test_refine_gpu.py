@@ -75,3 +75,35 @@ def test_finetune_loop_runs_on_device_and_reduces_the_loss():
     assert torch.isfinite(bp).all() and torch.isfinite(idx).all()
     assert len(set(losses)) > 1, "no gradient reached z"
     assert min(losses[2:]) < losses[0]
+
+
+def test_mesh_render_func_call_contract():
+    """models/diff_render.py:48,435: list inputs, 4-tuple output, first call caches ids / sizes / room box, later calls
+    reuse them and return the size + wall-drift penalty; the image equals assemble_scene + scene_render."""
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    boxes, angles = _inputs("cuda")
+    vocab = ["__pad__"] + NAMES
+    objs = [vocab.index(n) for n in NAMES]
+    bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
+    R.configure_meshes(vocab, bank)
+    final, ids, sizes, size_loss = DR.mesh_render_func([b for b in boxes], [a for a in angles], objs)
+    assert final.shape == (1, 70, 256, 256) and float(size_loss) == 0.0
+    n_vis = sum(1 for n in NAMES[:-1] if n not in R.DO_NOT_VIS)
+    assert len(sizes) == n_vis + 1 and np.allclose(ids["box_info"], boxes[-1].cpu().numpy())
+    assert all(i in ids for i in range(len(NAMES) - 1)) and "wall" in ids
+    v, f, ranges, _, _ = R.assemble_scene(boxes, angles, NAMES, bank, boxes[-1])
+    assert torch.equal(final, DR.scene_render(v, f, ranges, boxes[-1]))
+    # second call: perturbed layout, drifting room row is overloaded by the cached one and penalised
+    b2 = [(b + 0.01).detach().requires_grad_(True) for b in boxes]
+    a2 = [a.detach().clone().requires_grad_(True) for a in angles]
+    final2, ids2, sizes2, loss2 = DR.mesh_render_func(b2, a2, objs, model_ids_old=ids, obj_size_target=sizes)
+    assert ids2 == {} and sizes2 == []
+    room = boxes[-1]
+    want = sum(torch.nn.functional.mse_loss(((boxes[i] + 0.01)[3:] - (boxes[i] + 0.01)[:3]) * room[3:],
+                                            torch.from_numpy(sizes[k]).cuda())
+               for k, i in enumerate(j for j, n in enumerate(NAMES[:-1]) if n not in R.DO_NOT_VIS))
+    want = want + torch.nn.functional.mse_loss(boxes[-1] + 0.01, boxes[-1])
+    assert abs(float(loss2.detach()) - float(want)) <= 1e-6 + 1e-5 * float(want)
+    (final2[:, 41:].sum() + loss2).backward()
+    assert all(b.grad is not None and torch.isfinite(b.grad).all() for b in b2[:-1])
+    assert any(float(b.grad.abs().max()) > 0 for b in b2[:-1])
