@@ -50,6 +50,19 @@ class SlnVaeBatch(C.Structure):
                 ("angles", C.c_void_p), ("attributes", C.c_void_p), ("O", C.c_int), ("T", C.c_int)]
 
 
+class SlnRoomTable(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("room_off", "cls", "bbox", "rot", "room_bbox", "room_id", "size_thr", "has_size")] + \
+               [(n, C.c_int) for n in ("n_rooms", "n_classes", "use_attr_30", "reserved")]
+
+
+class SlnGraphDraws(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("other", "swap", "attr_mode")]
+
+
+class SlnGraphBatch(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ids", "objs", "boxes", "triples", "angles", "attributes", "obj_to_img", "triple_to_img")]
+
+
 # name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
@@ -108,6 +121,9 @@ SIGNATURES = {
     "sln_se_scale_add": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sln_upsample2x": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_conv_img_tanh": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
+    "sln_graph_plan": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sln_graph_emit": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(SlnGraphDraws),
+                                 C.POINTER(SlnGraphBatch), C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
 }

@@ -1,0 +1,214 @@
+"""HIP-backed counterpart of the reference's ``data/suncg_dataset.py``.
+
+Same surface: ``SuncgDataset(data_dir, train_3d, touching_relations=True, use_attr_30=False)`` reading the same json
+files (:9-97), ``__len__``, ``__getitem__`` -> ``(room_id, objs, boxes, triples, angles, attributes)``,
+``return_room_ids``, ``get_by_room_id``, ``total_objects`` and ``suncg_collate_fn``.
+
+MI355X-first formulation: the room table (classes, raw boxes, rotations, room boxes, size thresholds) is uploaded
+ONCE and stays in HBM; ``build_batch(indices)`` produces the collated batch of ``suncg_collate_fn`` directly on the
+device with two small launches + one emit (csrc/graph_build.hip) instead of a python loop per object pair per room.
+The random decisions of ``__getitem__`` (partner, subject/object order, size attribute) are explicit inputs: drawn from
+python's ``random`` in the reference's order (``draw``; bit-identical batches under ``random.seed``) or on the device
+from a torch generator (``device_draws``; the fast path that feeds training).
+
+Reference behaviour that is kept on purpose: the intended "skip pairs already linked by 'on'" test
+(suncg_dataset.py:202) never fires there (``on_rels`` is keyed by 0-dim tensors, hashed by identity), so an 'on' pair
+drawn in the second loop is emitted twice; rooms need at least two objects (``random.choice`` of an empty list raises
+IndexError in the reference, and so does this module).
+"""
+import ctypes as C
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+PRED_NAMES = ['__in_room__', 'left of', 'right of', 'behind', 'in front of', 'inside', 'surrounding', 'left touching',
+              'right touching', 'front touching', 'behind touching', 'front left', 'front right', 'back left', 'back right', 'on']
+ATTR_NAMES = ['none', 'tall', 'short', 'large', 'small']
+
+
+def _load_json(path):
+    with open(path, 'r') as f:
+        return json.load(f)
+
+
+class SuncgDataset(torch.utils.data.Dataset):
+    def __init__(self, data_dir, train_3d, touching_relations=True, use_attr_30=False, device="cuda", metadata_dir="metadata"):
+        assert train_3d, "the reference asserts train_3d (suncg_dataset.py:12)"
+        data = _load_json(data_dir)
+        valid_types = _load_json(os.path.join(metadata_dir, "valid_types.json"))
+        names = ['__room__'] + valid_types
+        name_to_idx = {n: i for i, n in enumerate(names)}
+        rooms, ids = [], []
+        for room_id in data:
+            room = data[room_id]
+            objs = room["valid_objects"]
+            rooms.append(dict(objs=[name_to_idx[o["type"]] for o in objs],
+                              boxes=np.asarray([list(o["new_bbox"][0]) + list(o["new_bbox"][1]) for o in objs], np.float32).reshape(-1, 6),
+                              rot=[int(o["rotation"]) for o in objs], bbox=np.asarray(room["bbox"], np.float32)))
+            ids.append(int(room_id))
+        self._setup(rooms, names, _load_json(os.path.join(metadata_dir, "size_info_many.json")),
+                    _load_json(os.path.join(metadata_dir, "30_size_info_many.json")), use_attr_30, ids, device)
+        self.train_3d, self.touching_relations = train_3d, touching_relations
+
+    @classmethod
+    def from_tables(cls, rooms, object_idx_to_name, size_data, size_data_30, use_attr_30=False, room_ids=None, device="cuda"):
+        """rooms: list of {"objs": [n] class idx, "boxes": [n,6] raw f32, "rot": [n], "bbox": [3]} (no json on disk)."""
+        self = cls.__new__(cls)
+        self._setup(rooms, list(object_idx_to_name), size_data, size_data_30, use_attr_30,
+                    list(room_ids) if room_ids is not None else list(range(len(rooms))), device)
+        self.train_3d, self.touching_relations = True, True
+        return self
+
+    # ------------------------------------------------------------------------------------------
+    def _setup(self, rooms, names, size_data, size_data_30, use_attr_30, room_ids, device):
+        _lib.lib()                                              # no CPU fallback: fail here without the HIP library
+        self.use_attr_30 = bool(use_attr_30)
+        self.room_ids = [int(r) for r in room_ids]
+        self.size_data, self.size_data_30 = size_data, size_data_30
+        self.vocab = {'object_idx_to_name': names, 'object_name_to_idx': {n: i for i, n in enumerate(names)},
+                      'pred_idx_to_name': PRED_NAMES, 'pred_name_to_idx': {n: i for i, n in enumerate(PRED_NAMES)},
+                      'attrib_idx_to_name': ATTR_NAMES, 'attrib_name_to_idx': {n: i for i, n in enumerate(ATTR_NAMES)}}
+        counts = np.asarray([len(r["objs"]) for r in rooms], np.int64)
+        self._n = counts
+        off = np.zeros(len(rooms) + 1, np.int32); off[1:] = np.cumsum(counts)
+        cat = lambda k, dt, w: (np.concatenate([np.asarray(r[k], dt).reshape(-1, w) for r in rooms]) if len(rooms) else np.zeros((0, w), dt))
+        self._cls_host = cat("objs", np.int32, 1).reshape(-1)
+        C_ = len(names)
+        thr = np.zeros((C_, 4), np.float32); has = np.zeros(C_, np.uint8)
+        src = size_data_30 if self.use_attr_30 else size_data
+        for nm, v in src.items():
+            if nm not in self.vocab['object_name_to_idx']:
+                continue
+            c = self.vocab['object_name_to_idx'][nm]
+            has[c] = 1
+            thr[c] = [v["height_7"], v["height_3"], v["volume_7"], v["volume_3"]] if self.use_attr_30 else [v[0][1], v[1], 0, 0]
+        self._has_host = has
+        dev = torch.device(device)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self._t = dict(room_off=up(off), cls=up(self._cls_host), bbox=up(cat("boxes", np.float32, 6)), rot=up(cat("rot", np.int32, 1).reshape(-1)),
+                       room_bbox=up(np.stack([np.asarray(r["bbox"], np.float32) for r in rooms]) if len(rooms) else np.zeros((0, 3), np.float32)),
+                       room_id=up(np.asarray(self.room_ids, np.int64)), size_thr=up(thr), has_size=up(has))
+        self._tab = _lib.SlnRoomTable(*[_lib.ptr(self._t[k]) for k in ("room_off", "cls", "bbox", "rot", "room_bbox", "room_id", "size_thr", "has_size")],
+                                      len(rooms), C_, int(self.use_attr_30), 0)
+        self.device = dev
+        self._room_off_host = off
+
+    # ---- reference surface ---------------------------------------------------------------------
+    def __len__(self):
+        return len(self.room_ids)
+
+    def return_room_ids(self):
+        return self.room_ids
+
+    def total_objects(self):
+        return int(self._n.sum())
+
+    def get_by_room_id(self, room_id):
+        try:
+            idx = self.room_ids.index(int(room_id))
+        except ValueError:
+            print("Get by room id failed! Defaulting to 0.")
+            idx = 0
+        return self.__getitem__(idx)
+
+    def __getitem__(self, index):
+        """One room as CPU tensors, random decisions from python's ``random`` in the reference's order."""
+        ids, objs, boxes, triples, angles, attrs, _, _ = self.build_batch([index], draws=self.draw([index]))
+        return self.room_ids[index], objs.cpu(), boxes.cpu(), triples.cpu(), angles.cpu(), attrs.cpu()
+
+    # ---- random decisions ------------------------------------------------------------------------
+    def draw(self, indices, rng=random):
+        """python-``random`` stream of consecutive ``__getitem__`` calls (suncg_dataset.py:189-196, 236-282)."""
+        other, swap, mode = [], [], []
+        for idx in indices:
+            n = int(self._n[idx]); first = int(self._room_off_host[idx])
+            if n < 2:
+                raise IndexError("Cannot choose from an empty sequence (room %d has %d objects; the reference needs >= 2)" % (idx, n))
+            for cur in range(n):
+                k = rng.choice(range(n - 1))                     # position in [obj for obj in real_objs if obj != cur]
+                other.append(k if k < cur else k + 1)
+                swap.append(rng.random() > 0.5)
+            for i in range(n):
+                u1 = rng.random()
+                if u1 > 0.5 or not self._has_host[self._cls_host[first + i]]:
+                    mode.append(0)
+                else:
+                    mode.append(1 if rng.random() > 0.5 else 2)
+        return (np.asarray(other, np.int32), np.asarray(swap, np.uint8), np.asarray(mode, np.uint8))
+
+    def device_draws(self, idx_t, row_off, O, generator=None):
+        """The same decisions drawn on the device (torch generator); no host loop, no sync."""
+        B = idx_t.shape[0]
+        dev = self.device
+        n_room = (row_off[1:B + 1] - row_off[:B] - 1).long()
+        g = torch.repeat_interleave(torch.arange(B, device=dev), n_room, output_size=O - B)
+        cur = torch.arange(O - B, device=dev) - (row_off[:B].long()[g] - g)
+        n = n_room[g]
+        u = torch.rand(4, O - B, device=dev, generator=generator)
+        k = torch.minimum((u[0] * (n - 1)).long(), n - 2)
+        other = (k + (k >= cur).long()).int()
+        swap = (u[1] > 0.5).to(torch.uint8)
+        first = self._t["room_off"].long()[idx_t.long()][g]
+        known = self._t["has_size"][self._t["cls"].long()[first + cur].long()] != 0
+        mode = torch.where((u[2] > 0.5) | ~known, 0, torch.where(u[3] > 0.5, 1, 2)).to(torch.uint8)
+        return other, swap, mode
+
+    # ---- the device builder ------------------------------------------------------------------------
+    def build_batch(self, indices, draws=None, generator=None):
+        """-> (ids, objs, boxes, triples, angles, attributes, obj_to_img, triple_to_img) on the device, the tuple of
+        ``suncg_collate_fn`` (suncg_dataset.py:310-353) for ``[dataset[i] for i in indices]``."""
+        L = _lib.lib()
+        dev = self.device
+        if torch.is_tensor(indices):
+            idx_t = indices.to(device=dev, dtype=torch.int32).contiguous()
+        else:
+            idx_t = torch.as_tensor(np.asarray(indices, np.int32), device=dev)
+        B = int(idx_t.shape[0])
+        st = _lib.current_stream_ptr()
+        counts = torch.empty(2 * B, dtype=torch.int32, device=dev)
+        off = torch.empty(2 * B + 3, dtype=torch.int32, device=dev)
+        _lib.check(L.sln_graph_plan(C.byref(self._tab), _lib.ptr(idx_t), B, _lib.ptr(counts), _lib.ptr(off), st), "sln_graph_plan")
+        O, T, bad = (int(x) for x in off[[B, 2 * B + 1, 2 * B + 2]].tolist()) if B else (0, 0, 0)
+        if bad:
+            raise IndexError("%d room indices outside the table of %d rooms" % (bad, len(self)))
+        if B and int(counts[0::2].min()) < 3:
+            raise IndexError("Cannot choose from an empty sequence (a room of the batch has fewer than 2 objects)")
+        if draws is None:
+            other, swap, mode = self.device_draws(idx_t, off, O, generator)
+        else:
+            other, swap, mode = (torch.as_tensor(np.ascontiguousarray(a), device=dev) if not torch.is_tensor(a) else a.to(dev) for a in draws)
+            other, swap, mode = other.int().contiguous(), swap.to(torch.uint8).contiguous(), mode.to(torch.uint8).contiguous()
+            if other.numel() != O - B or swap.numel() != O - B or mode.numel() != O - B:
+                raise ValueError("draws need one entry per non-room object of the batch (%d), got %d" % (O - B, other.numel()))
+        i64 = lambda *s: torch.empty(*s, dtype=torch.int64, device=dev)
+        out = dict(ids=i64(B), objs=i64(O), boxes=torch.empty(O, 6, dtype=torch.float32, device=dev), triples=i64(T, 3), angles=i64(O),
+                   attributes=i64(O), obj_to_img=i64(O), triple_to_img=i64(T))
+        d = _lib.SlnGraphDraws(_lib.ptr(other), _lib.ptr(swap), _lib.ptr(mode))
+        ob = _lib.SlnGraphBatch(*[_lib.ptr(out[k]) for k in ("ids", "objs", "boxes", "triples", "angles", "attributes", "obj_to_img", "triple_to_img")])
+        _lib.check(L.sln_graph_emit(C.byref(self._tab), _lib.ptr(idx_t), B, _lib.ptr(off), C.byref(d), C.byref(ob), st), "sln_graph_emit")
+        return tuple(out[k] for k in ("ids", "objs", "boxes", "triples", "angles", "attributes", "obj_to_img", "triple_to_img"))
+
+
+def suncg_collate_fn(batch):
+    """List-of-samples collate with the reference's semantics (suncg_dataset.py:310-353); ``SuncgDataset.build_batch``
+    produces the same tuple on the device without materialising the samples."""
+    all_ids, all_objs, all_boxes, all_triples, all_angles, all_attributes, o2r, t2r = [], [], [], [], [], [], [], []
+    obj_offset = 0
+    for i, (room_id, objs, boxes, triples, angles, attributes) in enumerate(batch):
+        if objs.dim() == 0 or triples.dim() == 0:
+            continue
+        O, T = objs.size(0), triples.size(0)
+        all_objs.append(objs); all_angles.append(angles); all_attributes.append(attributes); all_boxes.append(boxes); all_ids.append(room_id)
+        triples = triples.clone()
+        triples[:, 0] += obj_offset
+        triples[:, 2] += obj_offset
+        all_triples.append(triples)
+        o2r.append(torch.full((O,), i, dtype=torch.int64)); t2r.append(torch.full((T,), i, dtype=torch.int64))
+        obj_offset += O
+    return (torch.tensor(all_ids, dtype=torch.int64), torch.cat(all_objs), torch.cat(all_boxes), torch.cat(all_triples),
+            torch.cat(all_angles), torch.cat(all_attributes), torch.cat(o2r), torch.cat(t2r))

@@ -251,6 +251,52 @@ int sln_upsample2x(const float* x, int BC, int H, int W, int mode, float* y, voi
 /* tanh(conv5x5_zero_pad(LeakyReLU_0.2(x))) (:1602-1603); w [Cout,Cin,5,5], Cout <= 4 */
 int sln_conv_img_tanh(const float* x, int B, int Cin, int H, int W, const float* w, const float* bias, int Cout, float* y, void* stream);
 
+/* =============================================================================================
+ * Scene-graph builder: SuncgDataset.__getitem__ + suncg_collate_fn for a batch of rooms
+ * (reference data/suncg_dataset.py:110-353; compute_rel utils.py:36-80).  The reference builds one room at a
+ * time in python; here the room table is resident in HBM and a batch of B rooms is two launches + one emit.
+ * All pointers are device pointers unless noted.
+ * ============================================================================================= */
+typedef struct {
+  const int* room_off;            /* [n_rooms+1] first object of each room in the flat arrays */
+  const int* cls;                 /* [N] vocabulary index of every object (>= 1; 0 is '__room__') */
+  const float* bbox;              /* [N,6] raw x0,y0,z0,x1,y1,z1 ('new_bbox', suncg_dataset.py:116-123) */
+  const int* rot;                 /* [N] 'rotation' bin */
+  const float* room_bbox;         /* [n_rooms,3] (suncg_dataset.py:131-137) */
+  const int64_t* room_id;         /* [n_rooms] ids returned as all_ids, or NULL: the table index */
+  const float* size_thr;          /* [n_classes,4]: use_attr_30 = 0: (height, volume, -, -) of size_info_many.json;
+                                     = 1: (height_7, height_3, volume_7, volume_3) of 30_size_info_many.json */
+  const unsigned char* has_size;  /* [n_classes] class present in that json */
+  int n_rooms, n_classes, use_attr_30, reserved;
+} SlnRoomTable;
+
+/* The random decisions of __getitem__, one entry per NON-room object of the batch, batch order
+ * (suncg_dataset.py:189-196: random.choice / random.random; :236-282: attribute draws). */
+typedef struct {
+  const int* other;               /* partner, as an object index inside its room (!= the object itself) */
+  const unsigned char* swap;      /* 1: (s, o) = (cur, other)  [random.random() > 0.5],  0: (other, cur) */
+  const unsigned char* attr_mode; /* 0: 'none' [first draw > 0.5 or class without statistics], 1: height test, 2: volume test */
+} SlnGraphDraws;
+
+/* Outputs with the dtypes of suncg_collate_fn (suncg_dataset.py:310-353). */
+typedef struct {
+  int64_t* ids;                   /* [B] or NULL */
+  int64_t* objs;                  /* [O] */
+  float* boxes;                   /* [O,6] room-normalised, the room row last in every graph */
+  int64_t* triples;               /* [T,3] (s, p, o) with batch-global rows */
+  int64_t* angles;                /* [O] */
+  int64_t* attributes;            /* [O] */
+  int64_t* obj_to_img;            /* [O] */
+  int64_t* triple_to_img;         /* [T] */
+} SlnGraphBatch;
+
+/* counts [2B] (rows, triples per room; rows < 0 marks a room index outside the table); offsets [2B+3]:
+ * [0..B] exclusive scan of rows (offsets[B] = O), [B+1..2B+1] of triples (offsets[2B+1] = T), [2B+2] = bad room indices.
+ * room_idx [B] indexes the table.  The caller reads O and T back (3 ints) to size the outputs. */
+int sln_graph_plan(const SlnRoomTable* tab /* host struct */, const int* room_idx, int B, int* counts, int* offsets, void* stream);
+int sln_graph_emit(const SlnRoomTable* tab /* host struct */, const int* room_idx, int B, const int* offsets,
+                   const SlnGraphDraws* draws /* host struct */, const SlnGraphBatch* out /* host struct */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
