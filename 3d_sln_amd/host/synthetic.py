@@ -99,3 +99,29 @@ def synthetic_room(seed, n_objects=12, target_faces=2000, room=(4.0, 2.7, 5.0)):
         add(*_grid_quad(p0, du, dv, per), nm)
     return (np.concatenate(vs).astype(np.float32), np.concatenate(fs).astype(np.int32), ranges,
             np.array([0, 0, 0, room[0], room[1], room[2]], np.float32))
+
+
+def scene_rooms(n_rooms, objs_per_room=31, seed=0, n_classes=31):
+    """Synthetic room table in the structure of data_rot_*.json (reference data/suncg_dataset.py:84-90): raw boxes of
+    floor-standing / stacked / nested objects in a room, one class and rotation bin each.
+    -> (rooms, object_idx_to_name, size_data, size_data_30) for ``SuncgDataset.from_tables``."""
+    rng = np.random.default_rng(seed)
+    names = ["__room__"] + ["type%02d" % i for i in range(1, n_classes + 1)]
+    rooms = []
+    for _ in range(n_rooms):
+        room = rng.uniform([3, 2.5, 3], [7, 3.2, 8])
+        n = objs_per_room
+        size = rng.uniform([0.2, 0.2, 0.2], [1.6, 1.4, 1.6], size=(n, 3))
+        lo = rng.uniform(0, 1, size=(n, 3)) * np.maximum(room - size, 0.1)
+        lo[:, 1] = 0.0
+        for i in range(1, n):                                   # every fifth object stands exactly on an earlier one
+            if i % 5 == 0:
+                j = int(rng.integers(0, i))
+                size[i, 0] = min(size[i, 0], size[j, 0]); size[i, 2] = min(size[i, 2], size[j, 2])
+                lo[i] = [lo[j, 0] + (size[j, 0] - size[i, 0]) / 2, lo[j, 1] + size[j, 1], lo[j, 2] + (size[j, 2] - size[i, 2]) / 2]
+        rooms.append(dict(objs=rng.integers(1, n_classes + 1, size=n).tolist(), boxes=np.concatenate([lo, lo + size], 1).astype(np.float32),
+                          rot=rng.integers(0, 24, size=n).tolist(), bbox=room.astype(np.float32)))
+    size_data = {nm: [[0.1, float(rng.uniform(0.1, 0.4))], float(rng.uniform(0.001, 0.02))] for nm in names[1::2]}
+    size_data_30 = {nm: dict(height_7=float(rng.uniform(0.25, 0.5)), height_3=float(rng.uniform(0.0, 0.25)),
+                             volume_7=float(rng.uniform(0.01, 0.03)), volume_3=float(rng.uniform(0.0005, 0.01))) for nm in names[1::2]}
+    return rooms, names, size_data, size_data_30

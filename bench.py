@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--spade-batch", type=int, default=32, help="images per SPADE call (BASELINE configs[3])")
     ap.add_argument("--spade-iters", type=int, default=3)
     ap.add_argument("--no-spade", action="store_true")
+    ap.add_argument("--graph-batch", type=int, default=512, help="rooms per scene-graph builder call")
+    ap.add_argument("--graph-iters", type=int, default=50)
+    ap.add_argument("--no-graph-build", action="store_true")
     return ap.parse_args()
 
 
@@ -121,6 +124,49 @@ def render_leg(args, lib, torch, rank):
             res[name] = {"avg_ms_per_batch": round(ms, 4), "gbs_algorithmic": round(algo / (ms * 1e-3) / 1e9, 1),
                          "frac_hbm": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     res["algorithmic_bytes_per_render"] = int(bytes_per_render)
+    return res
+
+
+def graph_build_leg(args, lib, torch):
+    """SuncgDataset.__getitem__ + suncg_collate_fn for a batch of rooms on the device
+    (csrc/graph_build.hip): 512 rooms x 31 objects (+ room row = the 32 objects/graph of configs[1]) per call,
+    random decisions drawn on the device; the timed region includes the 3-int read-back that sizes the outputs."""
+    D = importlib.import_module("3d_sln_amd.host.suncg_dataset")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    rooms, names, sd, sd30 = syn.scene_rooms(2048, objs_per_room=args.objs - 1, seed=0)
+    ds = D.SuncgDataset.from_tables(rooms, names, sd, sd30)
+    B = args.graph_batch
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    idx = torch.randint(0, len(rooms), (B,), generator=torch.Generator().manual_seed(0)).cuda()
+    for _ in range(5):
+        out = ds.build_batch(idx, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.graph_iters):
+        out = ds.build_batch(idx, generator=gen)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.graph_iters
+    O, T = int(out[1].shape[0]), int(out[3].shape[0])
+    nbytes = sum(int(t.numel()) * t.element_size() for t in out) + O * 6 * 4          # outputs + the raw boxes read
+    res = {"graphs_per_s": round(B / dt, 1), "us_per_batch": round(dt * 1e6, 1), "batch": B, "objects": O, "triples": T,
+           "algorithmic_bytes_per_batch": nbytes,
+           "workload": "%d rooms x %d objects: 'on' pairs over all ordered pairs, one drawn relation per object, in-room rows, "
+                       "normalised boxes, size attributes, collate offsets" % (B, args.objs - 1)}
+    if not args.no_cpu:
+        from oracle import graph_build_ref as G                  # CPU baseline = the oracle (python restatement of the reference loop)
+        import random as _r
+        table = G.RoomTable(rooms, names, sd, sd30)
+        _r.seed(0)
+        n_cpu = 48
+        t0 = time.perf_counter()
+        batch = []
+        for i in range(n_cpu):
+            room = rooms[i]
+            batch.append((i,) + G.build_room(room, table, G.draw_room(len(room["objs"]), room["objs"], table)))
+        G.collate(batch)
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(n_cpu / cdt, 1), "unit": "graphs/s", "cores": 1, "kind": "port",
+                               "sample": "%d rooms through oracle/graph_build_ref.py (python loop per object pair, as the reference)" % n_cpu}
     return res
 
 
@@ -254,6 +300,8 @@ def main():
         out["render"] = render_leg(args, lib, torch, rank)
     if rank == 0 and not args.no_spade:
         out["spade"] = spade_leg(args, lib, torch)
+    if rank == 0 and not args.no_graph_build:
+        out["graph_build"] = graph_build_leg(args, lib, torch)
     if rank == 0 and args.prof_steps <= 0:
         print(json.dumps(out))
     elif rank == 0:
