@@ -186,6 +186,198 @@ __global__ __launch_bounds__(CB* RL) void gather_bwd_kernel(const float* __restr
   if (masked) commit_col_stats(s1, s2, cv, gsums, cstride, c);
 }
 
+// ----------------------------------------------------------------------------------------------
+// Vectorised edge kernels (the default when every row stride / column offset is a multiple of 4 floats and the base
+// pointers are 16-byte aligned).  These kernels are chains of dependent loads (rowptr -> entry -> row data), not
+// bandwidth: the scalar versions above spend ~20 us on ~20 MB.  Here a thread owns 4 consecutive columns (float4
+// loads, a block of XT x YT threads covers 4*XT columns x YT rows), every row lane walks ONE row (CSR kernels) or a
+// short unrolled run of rows (dense kernel), entry indices and row data of 4 entries are in flight together, and the
+// BatchNorm coefficients are computed once per block (one column per thread) and shared through LDS.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// coefficient table of the block's columns [c0, c0 + 4*XT): (scale, shift, mean, istd); one column per thread
+template <int XT, int YT>
+__device__ __forceinline__ void fill_coef_table(float4* tab, const BnView& bn, int c0, int ncols, int coloff) {
+  const int tid = threadIdx.y * XT + threadIdx.x;
+  for (int j = tid; j < 4 * XT; j += XT * YT) {
+    float4 v = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (c0 + j < ncols) { bn_fwd_coef(bn, coloff + c0 + j, v.x, v.y); bn_mean_istd(bn, coloff + c0 + j, v.z, v.w); }
+    tab[j] = v;
+  }
+}
+
+// Column statistics of a block: reduce over the row lanes in LDS, then ONE column per thread so that a wavefront's
+// atomics hit consecutive doubles (the memory side serialises same-line atomics: lanes owning 4 columns each would
+// touch every 128-byte line from four different instructions).
+template <int XT, int YT>
+__device__ __forceinline__ void commit_col_stats4(const float4& s1, const float4& s2, int ncols_valid, double* out, int cstride, int col0) {
+  __shared__ float red[2][YT][4 * XT];
+  *reinterpret_cast<float4*>(&red[0][threadIdx.y][4 * threadIdx.x]) = s1;
+  *reinterpret_cast<float4*>(&red[1][threadIdx.y][4 * threadIdx.x]) = s2;
+  __syncthreads();
+  if (out == nullptr) return;
+  const int tid = threadIdx.y * XT + threadIdx.x;
+  for (int j = tid; j < 8 * XT; j += XT * YT) {
+    const int which = j / (4 * XT), cj = j % (4 * XT);
+    if (cj < ncols_valid) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < YT; ++i) a += red[which][i][cj];
+      atomicAdd(out + which * cstride + col0 + cj, (double)a);
+    }
+  }
+}
+
+// entry list of the block's YT rows, cached in LDS (coalesced) so that the per-entry chain is one level of row loads;
+// rows longer than ECACHE (only the room node of a big graph) read the tail from global memory
+constexpr int ECACHE = 64;
+constexpr int EB = 8;                      // row loads in flight per thread
+
+template <int XT, int YT>
+__device__ __forceinline__ void cache_entries(int (*ents)[ECACHE], const GraphCsr& g, int row, int nrows, int& b, int& e) {
+  b = 0; e = 0;
+  if (row < nrows) { b = g.rowptr[row]; e = g.rowptr[row + 1]; }
+  for (int k = threadIdx.x; k < min(e - b, ECACHE); k += XT) ents[threadIdx.y][k] = g.ent[b + k];
+  __syncthreads();
+}
+
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float* __restrict__ A2, int ld, int H, int D, BnView bn,
+                                                                    GraphCsr g, int O, int T, float* __restrict__ pooled) {
+  __shared__ float4 cs[4 * XT], co[4 * XT];
+  __shared__ int ents[YT][ECACHE];
+  const int c0 = blockIdx.x * 4 * XT;
+  const int i = blockIdx.y * YT + threadIdx.y;
+  int b, e;
+  fill_coef_table<XT, YT>(cs, bn, c0, H, 0);
+  fill_coef_table<XT, YT>(co, bn, c0, H, H + D);
+  cache_entries<XT, YT>(ents, g, i, O, b, e);
+  const int c = c0 + 4 * threadIdx.x;
+  if (c >= H || i >= O) return;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* ks = cs + 4 * threadIdx.x; const float4* ko = co + 4 * threadIdx.x;
+  const int deg = e - b;
+  for (int k = 0; k < deg; k += EB) {
+    int en[EB]; float4 x[EB];
+#pragma unroll
+    for (int u = 0; u < EB; ++u) { const int kk = min(k + u, deg - 1); en[u] = kk < ECACHE ? ents[threadIdx.y][kk] : g.ent[b + kk]; }
+#pragma unroll
+    for (int u = 0; u < EB; ++u) {
+      const bool isobj = en[u] >= T;
+      x[u] = ld4g(A2 + (size_t)(isobj ? en[u] - T : en[u]) * ld + (isobj ? H + D : 0) + c);
+    }
+#pragma unroll
+    for (int u = 0; u < EB; ++u) {
+      if (k + u < deg) {                     // same accumulation order as the scalar kernel / the reference scatter_add
+        const float4* kk = en[u] >= T ? ko : ks;
+        acc.x += fmaxf(fmaf(kk[0].x, x[u].x, kk[0].y), 0.f); acc.y += fmaxf(fmaf(kk[1].x, x[u].y, kk[1].y), 0.f);
+        acc.z += fmaxf(fmaf(kk[2].x, x[u].z, kk[2].y), 0.f); acc.w += fmaxf(fmaf(kk[3].x, x[u].w, kk[3].y), 0.f);
+      }
+    }
+  }
+  const float w = g.invdeg[i];
+  st4g(pooled + (size_t)i * H + c, make_float4(acc.x * w, acc.y * w, acc.z * w, acc.w * w));
+}
+
+template <int XT, int YT, int RPT, int NIT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float* __restrict__ dM, const float* __restrict__ dP, int lddp,
+                                                                    int dpcol0, const float* __restrict__ A2, int ld, int H, int D,
+                                                                    BnView bn, GraphCsr g, int T, float* __restrict__ g2,
+                                                                    double* gsums, int cstride) {
+  __shared__ float4 cf[4 * XT];
+  const int C = 2 * H + D;
+  const int c0 = blockIdx.x * 4 * XT;
+  fill_coef_table<XT, YT>(cf, bn, c0, C, 0);
+  __syncthreads();
+  const int c = c0 + 4 * threadIdx.x;
+  const bool cv = c < C;
+  const int part = c < H ? 0 : (c < H + D ? 1 : 2);
+  const float4* kk = cf + 4 * threadIdx.x;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (cv) {
+   for (int it = 0; it < NIT; ++it) {
+    const int t0 = ((blockIdx.y * NIT + it) * YT + threadIdx.y) * RPT;
+    if (t0 >= T) break;
+    int node[RPT]; float4 d[RPT], x[RPT]; float w[RPT];
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) { const int t = min(t0 + r, T - 1); node[r] = part == 0 ? g.s[t] : (part == 2 ? g.o[t] : 0); }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      const int t = min(t0 + r, T - 1);
+      w[r] = 1.f;
+      if (part == 1) d[r] = dP ? ld4g(dP + (size_t)t * lddp + dpcol0 + (c - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else { d[r] = ld4g(dM + (size_t)node[r] * H + (part == 0 ? c : c - H - D)); w[r] = g.invdeg[node[r]]; }
+      x[r] = ld4g(A2 + (size_t)t * ld + c);
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      if (t0 + r < T) {
+        float4 gv;
+        gv.x = fmaf(kk[0].x, x[r].x, kk[0].y) > 0.f ? d[r].x * w[r] : 0.f; gv.y = fmaf(kk[1].x, x[r].y, kk[1].y) > 0.f ? d[r].y * w[r] : 0.f;
+        gv.z = fmaf(kk[2].x, x[r].z, kk[2].y) > 0.f ? d[r].z * w[r] : 0.f; gv.w = fmaf(kk[3].x, x[r].w, kk[3].y) > 0.f ? d[r].w * w[r] : 0.f;
+        st4g(g2 + (size_t)(t0 + r) * ld + c, gv);
+        s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
+        s2.x = fmaf(gv.x, (x[r].x - kk[0].z) * kk[0].w, s2.x); s2.y = fmaf(gv.y, (x[r].y - kk[1].z) * kk[1].w, s2.y);
+        s2.z = fmaf(gv.z, (x[r].z - kk[2].z) * kk[2].w, s2.z); s2.w = fmaf(gv.w, (x[r].w - kk[3].z) * kk[3].w, s2.w);
+      }
+    }
+   }
+  }
+  commit_col_stats4<XT, YT>(s1, s2, min(4 * XT, C - c0), gsums, cstride, c0);
+}
+
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __restrict__ dG, int ldg, int D, GraphCsr g, int O, int T,
+                                                               const float* __restrict__ add1, int ldadd1,
+                                                               const float* __restrict__ xprev, int ldx, BnView bn, int masked,
+                                                               float* __restrict__ out, int ldo, double* gsums, int cstride) {
+  __shared__ float4 cf[4 * XT];
+  __shared__ int ents[YT][ECACHE];
+  const int c0 = blockIdx.x * 4 * XT;
+  const int i = blockIdx.y * YT + threadIdx.y;
+  int b, e;
+  if (masked) fill_coef_table<XT, YT>(cf, bn, c0, D, 0);
+  cache_entries<XT, YT>(ents, g, i, O, b, e);
+  const int c = c0 + 4 * threadIdx.x;
+  const bool cv = c < D && i < O;
+  const float4* kk = cf + 4 * threadIdx.x;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (cv) {
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 xp = d, ad = d;
+    if (masked) xp = ld4g(xprev + (size_t)i * ldx + c);
+    if (add1) ad = ld4g(add1 + (size_t)i * ldadd1 + c);
+    const int deg = e - b;
+    for (int k = 0; k < deg; k += EB) {
+      int en[EB]; float4 x[EB];
+#pragma unroll
+      for (int u = 0; u < EB; ++u) { const int q = min(k + u, deg - 1); en[u] = q < ECACHE ? ents[threadIdx.y][q] : g.ent[b + q]; }
+#pragma unroll
+      for (int u = 0; u < EB; ++u) {
+        const bool isobj = en[u] >= T;
+        x[u] = ld4g(dG + (size_t)(isobj ? en[u] - T : en[u]) * ldg + (isobj ? 2 * D : 0) + c);
+      }
+#pragma unroll
+      for (int u = 0; u < EB; ++u)
+        if (k + u < deg) { d.x += x[u].x; d.y += x[u].y; d.z += x[u].z; d.w += x[u].w; }
+    }
+    if (add1) { d.x += ad.x; d.y += ad.y; d.z += ad.z; d.w += ad.w; }
+    if (masked) {
+      d.x = fmaf(kk[0].x, xp.x, kk[0].y) > 0.f ? d.x : 0.f; d.y = fmaf(kk[1].x, xp.y, kk[1].y) > 0.f ? d.y : 0.f;
+      d.z = fmaf(kk[2].x, xp.z, kk[2].y) > 0.f ? d.z : 0.f; d.w = fmaf(kk[3].x, xp.w, kk[3].y) > 0.f ? d.w : 0.f;
+      s1 = d;
+      s2.x = d.x * ((xp.x - kk[0].z) * kk[0].w); s2.y = d.y * ((xp.y - kk[1].z) * kk[1].w);
+      s2.z = d.z * ((xp.z - kk[2].z) * kk[2].w); s2.w = d.w * ((xp.w - kk[3].z) * kk[3].w);
+    }
+    st4g(out + (size_t)i * ldo + c, d);
+  }
+  if (masked) commit_col_stats4<XT, YT>(s1, s2, min(4 * XT, D - c0), gsums, cstride, c0);
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 __global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __restrict__ d1, int ld1,
                                                              const float* __restrict__ d2, int ld2,
                                                              const float* __restrict__ xprev, int ldx, BnView bn,
@@ -558,6 +750,12 @@ int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2
   if (O <= 0) return 0;
   // algorithmic bytes: both halves of A2 once, pooled once, the entry list
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * H + 4.0 * O * H + 16.0 * g.T, st);
+  if (H % 4 == 0 && D % 4 == 0 && ld % 4 == 0 && al16(A2) && al16(pooled)) {
+    if (H > 128) hipLaunchKernelGGL((scatter_avg_fwd_v4_kernel<64, 4>), dim3(sln_cdiv(H, 256), sln_cdiv(O, 4)), dim3(64, 4), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
+    else hipLaunchKernelGGL((scatter_avg_fwd_v4_kernel<32, 8>), dim3(sln_cdiv(H, 128), sln_cdiv(O, 8)), dim3(32, 8), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(scatter_avg_fwd_kernel, dim3(sln_cdiv(H, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -568,6 +766,13 @@ int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int d
                                hipStream_t st) {
   if (T <= 0) return 0;
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * T * (2 * H) + (dP ? 4.0 * T * D : 0.0) + 2.0 * 4.0 * T * (2 * H + D) + 8.0 * T, st);
+  if (H % 4 == 0 && D % 4 == 0 && ld % 4 == 0 && (!dP || (lddp % 4 == 0 && dpcol0 % 4 == 0 && al16(dP))) && al16(dM) && al16(A2) && al16(g2)) {
+    constexpr int RPT = 4, NIT = 2;         // 32 rows per block: as many column-statistics atomics as the scalar kernel
+    hipLaunchKernelGGL((scatter_avg_bwd_v4_kernel<64, 4, RPT, NIT>), dim3(sln_cdiv(2 * H + D, 256), sln_cdiv(T, 4 * RPT * NIT)), dim3(64, 4), 0, st, dM, dP,
+                       lddp, dpcol0, A2, ld, H, D, bn2, g, T, g2, gsums, cstride);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(scatter_avg_bwd_kernel, colgrid(2 * H + D, T), dim3(CB, RL), 0, st, dM, dP, lddp, dpcol0, A2, ld, H,
                      D, bn2, g, T, g2, gsums, cstride);
   SLN_CHECK_LAUNCH();
@@ -579,6 +784,15 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
                           int cstride, hipStream_t st) {
   if (O <= 0) return 0;
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * D + (masked ? 2.0 : 1.0) * 4.0 * O * D + 16.0 * g.T, st);
+  if (D % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && (!add1 || (ldadd1 % 4 == 0 && al16(add1))) && (!masked || (ldx % 4 == 0 && al16(xprev))) &&
+      al16(dG) && al16(out)) {
+    if (D > 64) hipLaunchKernelGGL((gather_bwd_v4_kernel<32, 8>), dim3(sln_cdiv(D, 128), sln_cdiv(O, 8)), dim3(32, 8), 0, st, dG, ldg, D, g, O, g.T, add1,
+                                   ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
+    else hipLaunchKernelGGL((gather_bwd_v4_kernel<16, 16>), dim3(sln_cdiv(D, 64), sln_cdiv(O, 16)), dim3(16, 16), 0, st, dG, ldg, D, g, O, g.T, add1,
+                            ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(gather_bwd_kernel, dim3(sln_cdiv(D, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
                      ldx, bn, masked, out, ldo, gsums, cstride);
   SLN_CHECK_LAUNCH();
