@@ -407,9 +407,51 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
     for (int co = 0; co < COUT; ++co) y[((size_t)b * COUT + co) * plane + (long)yy * W + xx] = tanhf(acc[co] + bias[co]);
 }
 
+// SPADE modulation with gamma/beta shared by the whole batch (one semantic map, many z): gb [rows_pad, plane] is the
+// output of the packed [32 gamma | 32 beta] conv for that map; out[b,c,p] = ((x - mu_b) * inv_b) * (1 + gamma) + beta.
+// HBM-bound: x read once, out written once, gb stays in L2/MALL across the batch (blockIdx.y = sample is the slow index).
+__global__ __launch_bounds__(256) void spade_apply_kernel(const float* __restrict__ x, const float* __restrict__ gb, int C, long plane,
+                                                          const float* __restrict__ stats, int act, float slope, float* __restrict__ out) {
+  const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  const long n = (long)C * plane;
+  if (i4 >= n) return;
+  const int b = blockIdx.y;
+  const int c = (int)(i4 / plane);
+  const long pix = i4 - (long)c * plane;
+  const float mean = stats[2 * b], inv = stats[2 * b + 1];
+  const long grow = (long)(c / 32) * 64 + (c % 32);
+  const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * n + i4);
+  const float4 g = *reinterpret_cast<const float4*>(gb + grow * plane + pix);
+  const float4 be = *reinterpret_cast<const float4*>(gb + (grow + 32) * plane + pix);
+  float4 v;
+  v.x = (xv.x - mean) * inv; v.x = v.x * (1.f + g.x) + be.x;
+  v.y = (xv.y - mean) * inv; v.y = v.y * (1.f + g.y) + be.y;
+  v.z = (xv.z - mean) * inv; v.z = v.z * (1.f + g.z) + be.z;
+  v.w = (xv.w - mean) * inv; v.w = v.w * (1.f + g.w) + be.w;
+  if (act == ACT_LEAKY) {
+    v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+    v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)b * n + i4) = v;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Batch-shared modulation (see spade_apply_kernel): gb = sln_spade_conv(actv of the ONE map, packed gamma|beta weights).
+int sln_spade_apply(const float* x, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act, float slope,
+                    float* out, void* stream) {
+  if (!x || !gb || !stats || !out || B <= 0 || C <= 0 || rows_pad < 64 * ((C + 31) / 32)) return SLN_E_BADARG;
+  const long plane = (long)H * W;
+  if (plane % 4 != 0) return SLN_E_UNSUPPORTED;
+  const long n4 = (long)C * plane / 4;
+  SlnProfScope prof(SLN_FAM_OTHER, 4.0 * (2.0 * B * C * plane + 2.0 * C * plane), (hipStream_t)stream);
+  hipLaunchKernelGGL(spade_apply_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, gb, C, plane, stats, act,
+                     slope, out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
 
 // conv KSxKS (KS = 3 reflect pad 1, KS = 1) with packed weights wp[KS*KS][Cin][rows_pad]; rows_pad % 64 == 0.
 int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,

@@ -165,6 +165,10 @@ class SPADEGenerator4(nn.Module):
         L = _lib.lib()
         B, C, H, W = x.shape
         nd = NHIDDEN // 8
+        if seg.shape[0] == 1 and B > 1 and (H * W) % 4 == 0:
+            return self._spade_shared(e, x, stats, seg, leaky)
+        if seg.shape[0] != B:
+            seg = seg.expand(B, -1, -1, -1).contiguous()
         cat = torch.empty(B, nd + seg.shape[1] - 1, H, W, device=x.device)
         _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), B, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
                                             _lib.ptr(cat), self._st()), "sln_spade_depth_concat")
@@ -175,6 +179,27 @@ class SPADEGenerator4(nn.Module):
         _lib.check(L.sln_spade_modulate(_lib.ptr(actv), B, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), C, e["rpg"],
                                         _lib.ptr(x), _lib.ptr(stats), 2 if leaky else 0, 0.2, _lib.ptr(out), self._st()),
                    "sln_spade_modulate")
+        return out
+
+    def _spade_shared(self, e, x, stats, seg, leaky):
+        """One semantic map for the whole batch (the reference broadcasts gamma/beta [1,C,H,W] in that case, and
+        colorize_with_spade is exactly that use: 50 z per room).  gamma/beta - 72 % of the generator's MACs - are computed
+        once per map instead of once per sample; the per-sample part is an HBM-bound elementwise pass."""
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        nd = NHIDDEN // 8
+        cat = torch.empty(1, nd + seg.shape[1] - 1, H, W, device=x.device)
+        _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), 1, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
+                                            _lib.ptr(cat), self._st()), "sln_spade_depth_concat")
+        actv = torch.empty(1, NHIDDEN, H, W, device=x.device)
+        _lib.check(L.sln_spade_conv(_lib.ptr(cat), 1, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
+                                    1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
+        gb = torch.empty(1, e["rpg"], H, W, device=x.device)
+        _lib.check(L.sln_spade_conv(_lib.ptr(actv), 1, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), e["rpg"], e["rpg"], 3,
+                                    0, 0.0, _lib.ptr(gb), self._st()), "sln_spade_conv(gamma|beta)")
+        out = torch.empty_like(x)
+        _lib.check(L.sln_spade_apply(_lib.ptr(x), _lib.ptr(gb), B, C, H, W, e["rpg"], _lib.ptr(stats), 2 if leaky else 0, 0.2,
+                                     _lib.ptr(out), self._st()), "sln_spade_apply")
         return out
 
     def _conv(self, x, wbr, cout, ks):
@@ -223,6 +248,10 @@ class SPADEGenerator4(nn.Module):
         with torch.no_grad():
             seg = input.float().contiguous()
             B = seg.shape[0]
+            if z is not None and seg.shape[0] == 1 and z.shape[0] > 1:
+                B = z.shape[0]                                          # one map, many z: gamma/beta broadcast as in the reference
+            elif z is not None and z.shape[0] != B:
+                raise RuntimeError("z has %d rows for %d semantic maps" % (z.shape[0], B))
             if z is None:
                 print("Missing z vector, sampling from normal")
                 z = torch.randn(B, self.nz, dtype=torch.float32, device=seg.device)

@@ -206,6 +206,20 @@ def spade_leg(args, lib, torch):
         tf = c["work"] / (c["ms"] * 1e-3) / 1e12
         res["conv_kernels"] = {"launches": c["launches"], "ms": round(c["ms"], 2), "tflops": round(tf, 2),
                                "frac_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+    # colorize_with_spade's own shape (testing/test_SPADE_shade.py:30-79): ONE semantic map, 50 z vectors.  gamma/beta depend
+    # on the map only, so they are computed once (sln_spade_apply does the per-sample part).
+    nz = 50
+    z50 = torch.randn(nz, 256, device="cuda", generator=g)
+    G(seg[:1], z50)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2):
+        o50 = G(seg[:1], z50)
+    torch.cuda.synchronize()
+    dt50 = (time.perf_counter() - t0) / 2
+    res["colorize_one_map_50z"] = {"images_per_s": round(nz / dt50, 1), "ms_per_room": round(dt50 * 1e3, 2),
+                                   "speedup_vs_per_sample_path": round((nz / dt50) / (B / dt), 2),
+                                   "finite": bool(torch.isfinite(o50).all().item())}
     return res
 
 

@@ -237,6 +237,11 @@ int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp
  * [gamma | beta] = conv3x3_reflect(actv); stats[b] = (mean, 1 / (std + eps)) from sln_layernorm_stats */
 int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
                        const float* xin, const float* stats, int act, float slope, float* out, void* stream);
+/* The same modulation when ONE semantic map drives the whole batch (colorize_with_spade, testing/test_SPADE_shade.py:30-79:
+ * 50 z vectors per room): gb [rows_pad, H, W] = sln_spade_conv(actv of that map, the packed gamma|beta weights, act 0) is
+ * computed once, then out[b] = LayerNorm2D(xin[b]) * (1 + gamma) + beta for every sample.  H*W % 4 == 0. */
+int sln_spade_apply(const float* xin, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act,
+                    float slope, float* out, void* stream);
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream);
 /* F.interpolate(size=...): mode 0 nearest, 1 bilinear(align_corners=False) over BC planes */
 int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mode, float* dst, void* stream);

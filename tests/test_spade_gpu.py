@@ -101,3 +101,28 @@ def test_generator_against_reference_fixture(name):
             assert_close(out[:, :, 100:132, 60:92].cpu().numpy(), g["out_crop"], name + ":crop")
     except AssertionError as e:
         raise AssertionError(str(e) + "\n" + "\n".join(report))
+
+
+def test_one_semantic_map_many_z_equals_the_broadcast_of_the_reference():
+    """colorize_with_spade (testing/test_SPADE_shade.py:30-79) draws many z for ONE map; the reference module
+    broadcasts gamma/beta [1,C,H,W] over the batch.  The shared path (gamma/beta computed once, sln_spade_apply per sample)
+    must equal the oracle's broadcast and the per-sample path on the expanded map."""
+    S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
+    sd = spade_ref.init_state(cfg, seed=7)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, _ = spade_ref.synth_input(cfg, 1, seed=5)
+    z = torch.from_numpy(np.random.default_rng(2).standard_normal((5, cfg.nz)).astype(np.float32))
+    taps_ref = {}
+    ref = spade_ref.generator(sd, cfg, seg, z, taps_ref)            # torch broadcasting, as the reference module does
+    taps = {}
+    out = G(seg.cuda(), z.cuda(), taps=taps)
+    assert out.shape == (5, cfg.target_nc, cfg.crop_size, cfg.crop_size)
+    for n in taps:
+        assert_close(taps[n].cpu().numpy(), taps_ref[n].numpy(), "shared:" + n, rtol=1e-4, atol=1e-4 * float(taps_ref[n].abs().max()))
+    assert_close(out.cpu().numpy(), ref.numpy(), "shared:image", rtol=1e-4, atol=1e-4)
+    per_sample = G(seg.expand(5, -1, -1, -1).contiguous().cuda(), z.cuda())
+    assert_close(out.cpu().numpy(), per_sample.cpu().numpy(), "shared vs per-sample", rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        G(seg.expand(2, -1, -1, -1).contiguous().cuda(), z.cuda())
