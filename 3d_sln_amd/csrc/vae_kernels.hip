@@ -11,7 +11,6 @@ namespace {
 constexpr int CB = 64;   // columns per block
 constexpr int RL = 4;    // row lanes per block
 constexpr int RB = 32;   // rows per block (dense row kernels)
-constexpr int RBG = 8;   // rows per block for the CSR (incident-list) kernels: short, imbalanced rows
 
 __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid, double* out, int cstride, int col) {
   __shared__ float red[2][RL][CB];
@@ -101,95 +100,10 @@ __global__ void csr_sort_kernel(GraphCsr g, int O) {
 // ----------------------------------------------------------------------------------------------
 // edge aggregation
 // ----------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(CB* RL) void scatter_avg_fwd_kernel(const float* __restrict__ A2, int ld, int H, int D,
-                                                                 BnView bn, GraphCsr g, int O, int T,
-                                                                 float* __restrict__ pooled) {
-  const int c = blockIdx.x * CB + threadIdx.x;
-  if (c >= H) return;
-  float scs, shs, sco, sho;
-  bn_fwd_coef(bn, c, scs, shs);
-  bn_fwd_coef(bn, H + D + c, sco, sho);
-  const int r1 = min(O, (int)(blockIdx.y + 1) * RBG);
-  for (int i = blockIdx.y * RBG + threadIdx.y; i < r1; i += RL) {
-    const int b = g.rowptr[i], e = g.rowptr[i + 1];
-    float acc = 0.f;
-    for (int k = b; k < e; ++k) {
-      const int en = g.ent[k];
-      const bool isobj = en >= T;
-      const int t = isobj ? en - T : en;
-      const float x = A2[(size_t)t * ld + (isobj ? H + D + c : c)];
-      acc += fmaxf(fmaf(isobj ? sco : scs, x, isobj ? sho : shs), 0.f);
-    }
-    pooled[(size_t)i * H + c] = acc * g.invdeg[i];
-  }
-}
-
-__global__ __launch_bounds__(CB* RL) void scatter_avg_bwd_kernel(const float* __restrict__ dM, const float* __restrict__ dP,
-                                                                 int lddp, int dpcol0, const float* __restrict__ A2,
-                                                                 int ld, int H, int D, BnView bn, GraphCsr g, int T,
-                                                                 float* __restrict__ g2, double* gsums, int cstride) {
-  const int c = blockIdx.x * CB + threadIdx.x;
-  const int C = 2 * H + D;
-  const bool cv = c < C;
-  float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
-  if (cv) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
-  const int part = c < H ? 0 : (c < H + D ? 1 : 2);
-  float s1 = 0.f, s2 = 0.f;
-  const int r1 = min(T, (int)(blockIdx.y + 1) * RB);
-  if (cv) {
-    for (int t = blockIdx.y * RB + threadIdx.y; t < r1; t += RL) {
-      float d;
-      if (part == 1) d = dP ? dP[(size_t)t * lddp + dpcol0 + (c - H)] : 0.f;
-      else {
-        const int node = part == 0 ? g.s[t] : g.o[t];
-        d = dM[(size_t)node * H + (part == 0 ? c : c - H - D)] * g.invdeg[node];
-      }
-      const float x = A2[(size_t)t * ld + c];
-      const float gv = fmaf(sc, x, sh) > 0.f ? d : 0.f;
-      g2[(size_t)t * ld + c] = gv;
-      s1 += gv; s2 = fmaf(gv, (x - mean) * istd, s2);
-    }
-  }
-  commit_col_stats(s1, s2, cv, gsums, cstride, c);
-}
-
-__global__ __launch_bounds__(CB* RL) void gather_bwd_kernel(const float* __restrict__ dG, int ldg, int D, GraphCsr g,
-                                                            int O, int T, const float* __restrict__ add1, int ldadd1,
-                                                            const float* __restrict__ xprev, int ldx, BnView bn,
-                                                            int masked, float* __restrict__ out, int ldo,
-                                                            double* gsums, int cstride) {
-  const int c = blockIdx.x * CB + threadIdx.x;
-  const bool cv = c < D;
-  float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
-  if (cv && masked) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
-  float s1 = 0.f, s2 = 0.f;
-  const int r1 = min(O, (int)(blockIdx.y + 1) * RBG);
-  if (cv) {
-    for (int i = blockIdx.y * RBG + threadIdx.y; i < r1; i += RL) {
-      const int b = g.rowptr[i], e = g.rowptr[i + 1];
-      float d = 0.f;
-      for (int k = b; k < e; ++k) {
-        const int en = g.ent[k];
-        const bool isobj = en >= T;
-        const int t = isobj ? en - T : en;
-        d += dG[(size_t)t * ldg + (isobj ? 2 * D + c : c)];
-      }
-      if (add1) d += add1[(size_t)i * ldadd1 + c];
-      if (masked) {
-        const float x = xprev[(size_t)i * ldx + c];
-        d = fmaf(sc, x, sh) > 0.f ? d : 0.f;
-        s1 += d; s2 = fmaf(d, (x - mean) * istd, s2);
-      }
-      out[(size_t)i * ldo + c] = d;
-    }
-  }
-  if (masked) commit_col_stats(s1, s2, cv, gsums, cstride, c);
-}
-
 // ----------------------------------------------------------------------------------------------
-// Vectorised edge kernels (the default when every row stride / column offset is a multiple of 4 floats and the base
-// pointers are 16-byte aligned).  These kernels are chains of dependent loads (rowptr -> entry -> row data), not
-// bandwidth: the scalar versions above spend ~20 us on ~20 MB.  Here a thread owns 4 consecutive columns (float4
+// Edge kernels (every row stride / column offset is a multiple of 4 floats - the engine's configurations guarantee it -
+// and the base pointers are 16-byte aligned).  These kernels are chains of dependent loads (rowptr -> entry -> row
+// data), not bandwidth: a scalar one-column-per-thread version spent ~20 us on ~20 MB.  Here a thread owns 4 consecutive columns (float4
 // loads, a block of XT x YT threads covers 4*XT columns x YT rows), every row lane walks ONE row (CSR kernels) or a
 // short unrolled run of rows (dense kernel), entry indices and row data of 4 entries are in flight together, and the
 // BatchNorm coefficients are computed once per block (one column per thread) and shared through LDS.
@@ -756,9 +670,7 @@ int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2
     SLN_CHECK_LAUNCH();
     return 0;
   }
-  hipLaunchKernelGGL(scatter_avg_fwd_kernel, dim3(sln_cdiv(H, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, A2, ld, H, D, bn2, g, O, g.T, pooled);
-  SLN_CHECK_LAUNCH();
-  return 0;
+  return -2;   // SLN_E_UNSUPPORTED: misaligned rows (the engine never produces them)
 }
 
 int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int dpcol0, const float* A2, int ld, int H,
@@ -773,10 +685,7 @@ int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int d
     SLN_CHECK_LAUNCH();
     return 0;
   }
-  hipLaunchKernelGGL(scatter_avg_bwd_kernel, colgrid(2 * H + D, T), dim3(CB, RL), 0, st, dM, dP, lddp, dpcol0, A2, ld, H,
-                     D, bn2, g, T, g2, gsums, cstride);
-  SLN_CHECK_LAUNCH();
-  return 0;
+  return -2;   // SLN_E_UNSUPPORTED: misaligned rows (the engine never produces them)
 }
 
 int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, const float* add1, int ldadd1,
@@ -793,10 +702,7 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
     SLN_CHECK_LAUNCH();
     return 0;
   }
-  hipLaunchKernelGGL(gather_bwd_kernel, dim3(sln_cdiv(D, CB), sln_cdiv(O, RBG)), dim3(CB, RL), 0, st, dG, ldg, D, g, O, g.T, add1, ldadd1, xprev,
-                     ldx, bn, masked, out, ldo, gsums, cstride);
-  SLN_CHECK_LAUNCH();
-  return 0;
+  return -2;   // SLN_E_UNSUPPORTED: misaligned rows (the engine never produces them)
 }
 
 int sln_launch_mask_gstats(const float* d1, int ld1, const float* d2, int ld2, const float* xprev, int ldx, BnView bn,
