@@ -55,3 +55,26 @@ def sample_layouts(model, objs, triples, attributes, n_samples=4, mean=None, cov
         bp, ap = model.decoder(z, ro, rt, ra)
     model.train(was_training)
     return bp.view(n_samples, O, -1), ap.view(n_samples, O, -1).argmax(2), z.view(n_samples, O, E)
+
+
+def layout_heatmap(boxes_pred, container_size=100, clip_coor=True):
+    """testing/test_heatmap.py:80-99 for all objects at once: ``boxes_pred`` [n_trials, O, 6] (room row last) ->
+    [O-1, container_size, container_size] histograms of the object centres in the room's own frame, each normalised
+    to sum 1 (``container[rd[2], rd[0]] += 1`` per trial, then ``/ max(sum, 1)``)."""
+    n, O, _ = boxes_pred.shape
+    room = boxes_pred[:, -1:, :]
+    ext = room[..., 3:] - room[..., :3]
+    b = boxes_pred[:, :-1, :] * torch.cat([ext, ext], -1)
+    ct = (b[..., :3] + b[..., 3:]) * 0.5
+    if clip_coor:
+        keep = torch.ones(ct.shape[:2], dtype=torch.bool, device=ct.device)
+        ct = ct.clamp(0.0, 1.0)
+    else:
+        keep = ((ct > 0.0) & (ct < 1.0)).all(-1)
+        ct = ct.clamp(0.0, 1.0)
+    rd = torch.floor(ct * (container_size - 1)).long()
+    flat = (torch.arange(O - 1, device=ct.device)[None] * container_size + rd[..., 2]) * container_size + rd[..., 0]
+    hist = torch.zeros((O - 1) * container_size * container_size, dtype=torch.float32, device=ct.device)
+    hist.scatter_add_(0, flat.reshape(-1), keep.reshape(-1).float())
+    hist = hist.view(O - 1, container_size, container_size)
+    return hist / hist.sum((1, 2), keepdim=True).clamp(min=1.0)
