@@ -176,6 +176,158 @@ def target_labels(target):
     return out
 
 
+class RefineScene:
+    """The same placement + render as ``assemble_scene`` + ``DR.scene_render`` with every per-object python loop of
+    diff_render.py:76-159 turned into ONE batched tensor expression over the visible objects, and fixed tensor shapes:
+    the near-plane cull (:346-356) degenerates the culled faces (all three corners collapse to a point, so they never
+    cover a pixel) instead of compacting the face list.  Nothing in ``render`` synchronises with the host, which is what
+    lets a whole refinement iteration be captured into one hipGraph (``finetune_vae(..., capture=True)``).
+    Built once per room: the room box is frozen (:55-60) and so are K, R, t."""
+
+    def __init__(self, class_names, bank, room_box, image_size=DR.final_out):
+        dev = room_box.device
+        self.image_size = image_size
+        self.room = room_box.detach().clone()
+        vis = [i for i, nm in enumerate(class_names[:-1]) if nm not in DO_NOT_VIS and nm in bank.models]
+        self.vis = torch.tensor(vis, dtype=torch.int64, device=dev)
+        models = [bank.models[class_names[i]] for i in vis]
+        self.n_vis = len(vis)
+        Vm = max([m["v"].shape[0] for m in models] + [1])
+        mv = torch.zeros(max(self.n_vis, 1), Vm, 3, device=dev)
+        for k, m in enumerate(models):
+            mv[k, :m["v"].shape[0]] = m["v"]
+        self.model_v = mv
+        self.msize = torch.stack([m["bbox_max"] - m["bbox_min"] for m in models]) if models else torch.ones(1, 3, device=dev)
+        self.mcenter = torch.stack([(m["bbox_min"] + m["bbox_max"]) / 2.0 for m in models]) if models else torch.zeros(1, 3, device=dev)
+        ranges = {c: [] for c in synthetic.FURNITURE}
+        ranges.update(wall=[], floor=[], ceiling=[])
+        faces, foff = [], 0
+        for k, (i, m) in enumerate(zip(vis, models)):
+            faces.append(m["f"].long() + k * Vm)
+            ranges.setdefault(class_names[i], []).append([foff, foff + m["f"].shape[0]]); foff += m["f"].shape[0]
+        room = [float(x) for x in room_box[3:]]
+        shell = [("floor", (0, 0, 0), (0, 0, room[2]), (room[0], 0, 0)), ("ceiling", (0, room[1], 0), (room[0], 0, 0), (0, 0, room[2])),
+                 ("wall", (0, 0, 0), (room[0], 0, 0), (0, room[1], 0)), ("wall", (0, 0, 0), (0, room[1], 0), (0, 0, room[2])),
+                 ("wall", (room[0], 0, 0), (0, 0, room[2]), (0, room[1], 0))]
+        sv, voff = [], self.n_vis * Vm
+        for nm, p0, du, dv in shell:
+            v, f = synthetic._grid_quad(np.array(p0, np.float64), np.array(du, np.float64), np.array(dv, np.float64), 6)
+            sv.append(torch.from_numpy(v.astype(np.float32)).to(dev)); faces.append(torch.from_numpy(f.astype(np.int64)).to(dev) + voff)
+            ranges[nm].append([foff, foff + f.shape[0]]); voff += v.shape[0]; foff += f.shape[0]
+        self.shell_v = torch.cat(sv)
+        self.faces = torch.cat(faces)                                        # [F,3] into the flattened vertex list
+        classes, chan, dch = DR.class_tables(ranges.keys())
+        cls = torch.full((foff,), -1, dtype=torch.int32)
+        for ci, name in enumerate(classes):
+            for a, b in ranges[name]:
+                cls[a:b] = ci
+        self.cls2 = torch.cat((cls, cls))[None].contiguous().to(dev)          # fill_back doubles the faces
+        self.chan = torch.tensor(chan, dtype=torch.int32, device=dev)
+        self.dch = torch.tensor(dch, dtype=torch.int32, device=dev)
+        self.K, self.R, self.t = DR.get_cam_mat(room_box, dev)
+
+    def place(self, boxes, angles):
+        """-> vertices [1,V,3] (differentiable), object sizes [n_vis,3]"""
+        ext = self.room[3:]
+        b = boxes[self.vis]
+        bmin, bmax = b[:, :3] * ext, b[:, 3:] * ext
+        center, size = (bmax + bmin) / 2, bmax - bmin
+        theta = -angles[self.vis] * (2 * math.pi / 24)
+        scale = (size / self.msize).min(dim=1).values
+        c, s_ = torch.cos(theta), torch.sin(theta)
+        z, o = torch.zeros_like(c), torch.ones_like(c)
+        rot = torch.stack([torch.stack([c, z, s_], 1), torch.stack([z, o, z], 1), torch.stack([-s_, z, c], 1)], 1)     # [n,3,3]
+        trans = center - scale[:, None] * torch.matmul(rot, self.mcenter[:, :, None])[:, :, 0]
+        v = torch.matmul(self.model_v, (rot * scale[:, None, None]).transpose(1, 2)) + trans[:, None, :]
+        return torch.cat([v.reshape(-1, 3), self.shell_v])[None], size
+
+    def render(self, boxes, angles, obj_size_target=None):
+        """-> final [1,70,is,is], size_loss, sizes"""
+        verts, size = self.place(boxes, angles)
+        size_loss = boxes.new_zeros(())
+        if obj_size_target is not None and self.n_vis:
+            size_loss = ((size - obj_size_target) ** 2).mean(1).sum()
+        cam_z = (torch.matmul(verts, self.R.transpose(1, 2)) + self.t)[0, :, 2]
+        culled = (cam_z[self.faces] < DR.CULL_EPS).any(1).detach()
+        v = DR.nr.projection(verts, self.K, self.R, self.t, None, DR.inter_out)[0]
+        fxyz = v[self.faces]                                                  # [F,3,3]
+        fxyz = torch.where(culled[:, None, None], torch.zeros_like(fxyz), fxyz)
+        fxyz = torch.cat((fxyz, torch.flip(fxyz, [1])), 0)[None]              # fill_back: corners (2, 1, 0)
+        img = DR._SceneFn.apply(fxyz, self.cls2, self.chan, self.dch, self.image_size, 0.001)
+        return img, size_loss, size
+
+
+def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, bank=None, learning_rate=1e-4,
+                      noise_seed=13, image_size=256, capture=False, log=None):
+    """``finetune_vae`` with the batched ``RefineScene`` and no per-iteration python optimiser objects: the reference builds a
+    NEW SGD(momentum=0.1, nesterov) every iteration (test_render_refine.py:286-292), so its step is exactly
+    ``p -= lr * (1 + momentum) * grad``; that closed form is applied to ``z`` (lr 2e-4) and to the flat parameter buffer
+    (lr ``learning_rate``/10).  ``capture=True`` records one iteration (decoder, placement, fused render, PSP losses,
+    backward, both updates) into a hipGraph and replays it; the noise of the angle soft-argmax is then drawn on the device.
+    Returns (losses [iters] tensor on the device, (boxes_pred, angle_idx))."""
+    dev = boxes_gt.device
+    bank = bank or MeshBank([n for n in set(class_names) if n not in DO_NOT_VIS], dev)
+    model.eval()
+    with torch.no_grad():
+        mu, logvar = model.encoder(objs, triples, boxes_gt, angles_gt, attributes)
+    gen = torch.Generator(device="cpu").manual_seed(noise_seed)
+    z = (mu + torch.randn(mu.shape, generator=gen).to(dev) * torch.exp(0.5 * logvar)).detach().clone().requires_grad_(True)
+    room_box = boxes_gt[-1].detach().clone()
+    scene = RefineScene(class_names, bank, room_box, image_size)
+    with torch.no_grad():
+        target, _, sizes = scene.render(boxes_gt, angles_gt.float())
+    labels = target_labels(target)
+    size_target = sizes.detach().clone()
+    n = boxes_gt.shape[0]
+    noise = torch.zeros(n, device=dev)
+    losses = torch.zeros(iters, device=dev)
+    flat, flat_grad = model.flat_params, model.flat_grads
+    state = {}
+
+    def iteration():
+        boxes_pred, angles_pred = model.decoder(z, objs, triples, attributes)
+        boxes_pred.register_hook(fix_grad)
+        boxes_full = torch.cat([boxes_pred[:-1], boxes_gt[-1:]], 0)
+        idx = softargmax(angles_pred, sum_dim=1) + noise / 10.0
+        idx.register_hook(quad_grad)
+        idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
+        image, size_loss, _ = scene.render(boxes_full, idx, size_target)
+        loss, _, _ = refinement_loss(image, target, labels, size_loss)
+        z.grad = None
+        flat_grad.zero_()
+        loss.backward()
+        with torch.no_grad():
+            z.add_(z.grad, alpha=-2e-4 * 1.1)
+            flat.add_(flat_grad, alpha=-(learning_rate / 10.0) * 1.1)
+        model.params_changed()
+        state["boxes"], state["idx"] = boxes_full.detach(), idx.detach()
+        return loss.detach()
+
+    graph = None
+    for k in range(iters):
+        if capture:
+            noise.copy_(torch.randn(n, generator=gen).to(dev))
+            if graph is None:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):                      # warm-up outside the capture (allocator, lazy init)
+                    state["loss"] = iteration()
+                torch.cuda.current_stream().wait_stream(side)
+                losses[k] = state["loss"]
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    state["loss"] = iteration()
+                continue
+            graph.replay()
+            losses[k] = state["loss"]
+        else:
+            noise.copy_(torch.randn(n, generator=gen).to(dev))
+            losses[k] = iteration()
+        if log:
+            log("iter %d: loss %.4f" % (k, float(losses[k])))
+    return losses, (state["boxes"], state["idx"])
+
+
 def finetune_vae(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, render_fn=None, bank=None,
                  learning_rate=1e-4, noise_seed=13, image_size=256, log=None):
     """finetune_VAE's inner loop for ONE room (test_render_refine.py:265-359) on synthetic meshes.

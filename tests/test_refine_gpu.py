@@ -107,3 +107,68 @@ def test_mesh_render_func_call_contract():
     (final2[:, 41:].sum() + loss2).backward()
     assert all(b.grad is not None and torch.isfinite(b.grad).all() for b in b2[:-1])
     assert any(float(b.grad.abs().max()) > 0 for b in b2[:-1])
+
+
+def _pretrained_room():
+    M = pkg("host.Sg2ScVAE_model")
+    torch.manual_seed(0)                                            # train_step draws eps from the global device generator
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    model = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    model.load_state_dict(vae_ref.init_state(cfg, seed=1))
+    model = model.cuda().train()
+    boxes, angles = _inputs("cuda")
+    n = len(NAMES)
+    objs = torch.tensor([3, 4, 6, 5, 7, 13, 0], device="cuda")
+    triples = torch.tensor([[0, 1, 1], [2, 3, 3], [1, 2, 5]] + [[i, 0, n - 1] for i in range(n - 1)], device="cuda")
+    attrs = torch.zeros(n, dtype=torch.int64, device="cuda")
+    nb = boxes.clone(); nb[-1] = torch.tensor([0, 0, 0, 1.0, 1.0, 1.0], device="cuda")
+    for _ in range(400):
+        model.train_step(objs, triples, nb, angles.long(), attrs, kl_weight=1e-3, lr=2e-3, use_graph=False)
+    return model, objs, triples, boxes, angles, attrs
+
+
+def test_batched_scene_equals_per_object_assembly():
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    boxes, angles = _inputs("cuda")
+    bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
+    room = boxes[-1].clone()
+    b1 = boxes.clone().requires_grad_(True); a1 = (angles + 0.3).clone().requires_grad_(True)
+    v, f, ranges, sizes, _ = R.assemble_scene(b1, a1, NAMES, bank, room)
+    img1 = DR.scene_render(v, f, ranges, room, image_size=128)
+    scene = R.RefineScene(NAMES, bank, room, image_size=128)
+    b2 = boxes.clone().requires_grad_(True); a2 = (angles + 0.3).clone().requires_grad_(True)
+    img2, _, size2 = scene.render(b2, a2)
+    assert torch.equal(torch.stack(sizes), size2.detach())
+    assert ((img1 - img2).abs() > 1e-4).float().mean() < 1e-3   # batched vs per-object matmul rounding: a few silhouette pixels
+    w = torch.randn(img1.shape, generator=torch.Generator().manual_seed(0)).cuda()
+    (img1 * w).sum().backward(); (img2 * w).sum().backward()
+    assert_close(b2.grad.cpu().numpy(), b1.grad.cpu().numpy(), "d/d boxes", rtol=2e-3, atol=2e-3 * float(b1.grad.abs().max()))
+    assert_close(a2.grad.cpu().numpy(), a1.grad.cpu().numpy(), "d/d angles", rtol=2e-3, atol=2e-3 * float(a1.grad.abs().max()))
+
+
+def test_fast_finetune_loop_matches_the_reference_shaped_loop_and_its_graph_replay():
+    R = pkg("host.refine")
+    bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
+    runs = {}
+    model0, objs, triples, boxes, angles, attrs = _pretrained_room()
+    sd0 = {k: v.detach().clone() for k, v in model0.state_dict().items()}     # fp32 atomics make two trainings differ in the last bits
+    M = pkg("host.Sg2ScVAE_model")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    for mode in ("slow", "fast", "graph"):
+        model = M.Sg2ScVAEModel(**cfg.model_kwargs()); model.load_state_dict(sd0); model = model.cuda().train()
+        if mode == "slow":
+            losses, (bp, idx) = R.finetune_vae(model, objs, triples, boxes, angles.long(), attrs, NAMES, iters=6, image_size=96,
+                                               learning_rate=1e-3, bank=bank)
+        else:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                losses, (bp, idx) = R.finetune_vae_fast(model, objs, triples, boxes, angles.long(), attrs, NAMES, iters=6, image_size=96,
+                                                        learning_rate=1e-3, bank=bank, capture=(mode == "graph"))
+                losses = losses.tolist()
+            torch.cuda.synchronize()
+        runs[mode] = (np.asarray(losses), bp.cpu().numpy(), model.flat_params.detach().cpu().numpy().copy())
+    for mode in ("fast", "graph"):
+        assert_close(runs[mode][0], runs["slow"][0], mode + ": losses", rtol=2e-3)
+        assert_close(runs[mode][1], runs["slow"][1], mode + ": boxes", rtol=1e-3, atol=1e-4)
+        assert_close(runs[mode][2], runs["slow"][2], mode + ": parameters", rtol=1e-3, atol=1e-5)
+    assert len(set(runs["graph"][0].tolist())) > 1
