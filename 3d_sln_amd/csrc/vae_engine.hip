@@ -76,6 +76,7 @@ struct SlnVae {
   int* attrs32 = nullptr; int* err_flag = nullptr;
   double* stats_base = nullptr; size_t stats_doubles = 0, enc_stats_doubles = 0;   // [enc sums | dec sums]
   double* gstats_base = nullptr;                                                   // [enc gsums | dec gsums]
+  char* zero_begin = nullptr; size_t zero_bytes = 0; bool bulk_zeroed = false;     // see carve() / train_iteration()
   BnTableEntry* bn_table_dev = nullptr;
   TransposeEntry* tr_table_dev = nullptr; int n_tr = 0, tr_max_tiles = 0;
   AdamScalars* scalars = nullptr; double* loss_acc = nullptr; float* losses = nullptr;
@@ -271,13 +272,16 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   g.deg = b.take<int>(Om); g.invdeg = b.take<float>(Om); g.rowptr = b.take<int>(Om + 1);
   g.cursor = b.take<int>(Om); g.ent = b.take<int>(2 * Tm);
   attrs32 = b.take<int>(Om); err_flag = b.take<int>(4);
-  scalars = b.take<AdamScalars>(1); loss_acc = b.take<double>(4); losses = b.take<float>(4);
+  scalars = b.take<AdamScalars>(1); losses = b.take<float>(4);
   // BatchNorm statistics arena
   size_t nd = 0, nd_enc = 0;
   for (size_t i = 0; i < bns.size(); ++i) { if ((int)i == n_bn_enc) nd_enc = nd; nd += 2 * (size_t)bns[i].C; }
   if ((int)bns.size() == n_bn_enc) nd_enc = nd;
   stats_doubles = nd; enc_stats_doubles = nd_enc;
-  stats_base = b.take<double>(nd); gstats_base = b.take<double>(nd);
+  // [loss accumulators | forward sums | backward sums]: one region, cleared by ONE memset per training iteration
+  loss_acc = b.take<double>(4); stats_base = b.take<double>(nd); gstats_base = b.take<double>(nd);
+  zero_begin = reinterpret_cast<char*>(loss_acc);
+  zero_bytes = (size_t)(reinterpret_cast<char*>(gstats_base + nd) - zero_begin);
   size_t o = 0;
   for (auto& bi : bns) { bi.sums = stats_base ? stats_base + o : nullptr; bi.gsums = gstats_base ? gstats_base + o : nullptr; o += 2 * (size_t)bi.C; }
   bn_table_dev = b.take<BnTableEntry>(bns.size() + 1);
@@ -370,7 +374,7 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
 }
 
 int SlnVae::encoder_forward(bool training, hipStream_t st) {
-  if (training && enc_stats_doubles) HIP_RET(hipMemsetAsync(stats_base, 0, enc_stats_doubles * sizeof(double), st));
+  if (training && enc_stats_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(stats_base, 0, enc_stats_doubles * sizeof(double), st));
   EncAssemble ea; std::memset(&ea, 0, sizeof(ea));
   ea.objs = batch.objs; ea.attrs = batch.attributes; ea.angles = batch.angles; ea.boxes = batch.boxes;
   ea.obj_emb = t.obj_emb_ec; ea.attr_emb = t.attr_emb_ec; ea.angle_emb = t.angle_emb; ea.wb = t.box_emb_w; ea.bb = t.box_emb_b;
@@ -400,7 +404,7 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
 
 int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training, hipStream_t st) {
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
-  if (training && dec_doubles) HIP_RET(hipMemsetAsync(stats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  if (training && dec_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(stats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
   DecAssemble da; std::memset(&da, 0, sizeof(da));
   da.objs = batch.objs; da.attrs = batch.attributes; da.obj_emb = t.obj_emb_dc; da.attr_emb = t.attr_emb_dc;
   da.mu = mu; da.logvar = logvar; da.eps = eps; da.z_in = z_ext;
@@ -432,7 +436,7 @@ int SlnVae::loss(const float* bp, const float* ap, const float* mu_, const float
   a.boxes = batch.boxes; a.boxes_pred = bp; a.box_dim = cfg.box_dim;
   a.angles = batch.angles; a.logits = logits; a.angles_pred = const_cast<float*>(ap); a.n_angle = cfg.n_angle;
   a.mu = mu_; a.logvar = lv_; a.n_z = E; a.use_ae = cfg.use_ae; a.kl_weight = &scalars->kl_weight;
-  a.O = O; a.acc = loss_acc; a.losses = losses;
+  a.O = O; a.acc = loss_acc; a.losses = losses; a.acc_prezeroed = bulk_zeroed ? 1 : 0;
   a.d_boxes_pred = with_grads ? dbp : nullptr; a.d_logits = with_grads ? dlogits : nullptr; a.ld_dbp = dbp_ld;
   RET_IF(sln_launch_loss(a, st));
   have_loss_grads = with_grads;
@@ -444,7 +448,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   const bool tr = dec_training;
   ev_next = 0;
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
-  if (dec_doubles) HIP_RET(hipMemsetAsync(gstats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  if (dec_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(gstats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = 2 * L - 1;
   const Layer& ll = layers[last];
@@ -512,7 +516,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
 int SlnVae::encoder_backward(hipStream_t st) {
   const bool tr = enc_training;
   if (ev_next > 4096) ev_next = 0;
-  if (enc_stats_doubles) HIP_RET(hipMemsetAsync(gstats_base, 0, enc_stats_doubles * sizeof(double), st));
+  if (enc_stats_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(gstats_base, 0, enc_stats_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = L - 1, W = 2 * E;
   const Layer& ll = layers[last];
@@ -574,12 +578,16 @@ int SlnVae::encoder_backward(hipStream_t st) {
 
 int SlnVae::train_iteration(const float* eps, bool with_adam, hipStream_t st) {
   HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
-  RET_IF(encoder_forward(true, st));
-  RET_IF(decoder_forward(nullptr, eps, true, st));
-  RET_IF(loss(boxes_pred, angles_pred, mu, logvar, true, st));
-  RET_IF(decoder_backward(st));
-  RET_IF(sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st));
-  RET_IF(encoder_backward(st));
+  HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
+  bulk_zeroed = true;
+  int r = encoder_forward(true, st);
+  if (!r) r = decoder_forward(nullptr, eps, true, st);
+  if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
+  if (!r) r = decoder_backward(st);
+  if (!r) r = sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st);
+  if (!r) r = encoder_backward(st);
+  bulk_zeroed = false;
+  RET_IF(r);
   if (with_adam) {
     RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
     wt_fresh = false;                  // transposed copies are rebuilt at the start of the next backward

@@ -90,7 +90,7 @@ struct LossArgs {
   float* losses;           // [4]: bbox, angle, kl*w, total  (written by finalize)
   float* d_boxes_pred; float* d_logits;   // may be nullptr (forward only)
   int ld_dbp;              // row stride of d_boxes_pred (padded to a multiple of 4)
-  int pad_;
+  int acc_prezeroed;       // the caller already cleared acc (one bulk memset per training iteration)
 };
 // d_logits = d_logprob - softmax * rowsum(d_logprob)   (backward of log_softmax given grad of its output)
 int sln_launch_log_softmax_bwd(const float* logprob, const float* d_logprob, float* d_logits, int O, int n, hipStream_t st);

@@ -419,9 +419,19 @@ __global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restri
   for (int i = threadIdx.x; i < tsz; i += 256) tab[i] = 0.f;
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-  for (long i = (long)r0 * n + threadIdx.x; i < (long)r1 * n; i += 256) {
-    const int r = (int)(i / n), c = (int)(i % n);
-    atomicAdd(&tab[(int)idx[r] * n + c], d[(size_t)r * ld + col0 + c]);
+  const long iend = (long)r1 * n;
+  for (long i = (long)r0 * n + threadIdx.x; i < iend; i += 256 * 8) {       // 8 independent loads per thread before the LDS atomics
+    float v[8]; int slot[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long q = min(i + 256L * u, iend - 1);
+      const int r = (int)(q / n), c = (int)(q % n);
+      slot[u] = (int)idx[r] * n + c;
+      v[u] = d[(size_t)r * ld + col0 + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i + 256L * u < iend) atomicAdd(&tab[slot[u]], v[u]);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < tsz; i += 256) {
@@ -476,31 +486,34 @@ __global__ void log_softmax_kernel(const float* __restrict__ x, float* __restric
   for (int k = 0; k < n; ++k) y[(size_t)r * n + k] = xr[k] - ls;
 }
 
+// element-parallel (coalesced) over the three parts of the loss; LOSS_BLOCKS blocks stride over the elements so that the
+// three fp64 accumulators see few same-address atomics
+constexpr int LOSS_BLOCKS = 64;
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * 256;
+  const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
   double l1 = 0.0, nll = 0.0, kl = 0.0;
-  if (r < a.O) {
-    const float gb = 1.0f / ((float)a.O * (float)a.box_dim);
-    for (int k = 0; k < a.box_dim; ++k) {
-      const float diff = a.boxes_pred[(size_t)r * a.box_dim + k] - a.boxes[(size_t)r * a.box_dim + k];
-      l1 += fabsf(diff);
-      if (a.d_boxes_pred) a.d_boxes_pred[(size_t)r * a.ld_dbp + k] = diff > 0.f ? gb : (diff < 0.f ? -gb : 0.f);
-    }
+  const float gb = 1.0f / ((float)a.O * (float)a.box_dim), go = 1.0f / (float)a.O;
+  for (long i = i0; i < (long)a.O * a.box_dim; i += stride) {
+    const int r = (int)(i / a.box_dim), k = (int)(i % a.box_dim);
+    const float diff = a.boxes_pred[i] - a.boxes[i];
+    l1 += fabsf(diff);
+    if (a.d_boxes_pred) a.d_boxes_pred[(size_t)r * a.ld_dbp + k] = diff > 0.f ? gb : (diff < 0.f ? -gb : 0.f);
+  }
+  for (long i = i0; i < (long)a.O * a.n_angle; i += stride) {
+    const int r = (int)(i / a.n_angle), k = (int)(i % a.n_angle);
     const int tgt = (int)a.angles[r];
-    nll = -(double)a.angles_pred[(size_t)r * a.n_angle + tgt];
-    if (a.d_logits) {
-      const float go = 1.0f / (float)a.O;
-      for (int k = 0; k < a.n_angle; ++k)
-        a.d_logits[(size_t)r * a.n_angle + k] = (expf(a.angles_pred[(size_t)r * a.n_angle + k]) - (k == tgt ? 1.f : 0.f)) * go;
+    const float lp = a.angles_pred[i];
+    if (k == tgt) nll -= (double)lp;
+    if (a.d_logits) a.d_logits[i] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+  }
+  if (!a.use_ae) {
+    float s = 0.f;
+    for (long i = i0; i < (long)a.O * a.n_z; i += stride) {
+      const float m = a.mu[i], lv = a.logvar[i];
+      s += 1.f + lv - m * m - expf(lv);
     }
-    if (!a.use_ae) {
-      float s = 0.f;
-      for (int k = 0; k < a.n_z; ++k) {
-        const float m = a.mu[(size_t)r * a.n_z + k], lv = a.logvar[(size_t)r * a.n_z + k];
-        s += 1.f + lv - m * m - expf(lv);
-      }
-      kl = s;
-    }
+    kl = s;
   }
   __shared__ double red[3][256];
   red[0][threadIdx.x] = l1; red[1][threadIdx.x] = nll; red[2][threadIdx.x] = kl;
@@ -753,7 +766,7 @@ int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, i
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
-    const int rpb = 128;
+    const int rpb = 64;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st, idx,
                        d, ld, col0, rows, n, table_rows, rpb, d_emb);
     SLN_CHECK_LAUNCH();
@@ -770,7 +783,7 @@ int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
-    const int rpb = 128;
+    const int rpb = 64;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int64_t>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st,
                        idx, d, ld, col0, rows, n, table_rows, rpb, d_emb);
     SLN_CHECK_LAUNCH();
@@ -813,9 +826,11 @@ int sln_launch_log_softmax(const float* logits, float* out, int O, int n, hipStr
 }
 
 int sln_launch_loss(LossArgs a, hipStream_t st) {
-  hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(double) * 4, st);
-  if (e != hipSuccess) return (int)e;
-  if (a.O > 0) hipLaunchKernelGGL(loss_kernel, dim3(sln_cdiv(a.O, 256)), dim3(256), 0, st, a);
+  if (!a.acc_prezeroed) {
+    hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(double) * 4, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (a.O > 0) hipLaunchKernelGGL(loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, a);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
