@@ -287,23 +287,27 @@ __global__ void resize_kernel(const float* __restrict__ src, int C, int Hi, int 
 }
 
 // [leaky_0.01(conv3x3_reflect(seg[:,0], 1->nd)) | seg[:,1:]]  ->  out [B, nd + Cs - 1, H, W]   (SPADE4 :1445-1446)
+// cw = channels written per sample: nd + Cs - 1 (everything) or nd (the mask channels of `out` were filled once for this
+// resolution and only the depth features change from one SPADE layer to the next)
 __global__ void depth_concat_kernel(const float* __restrict__ seg, int Cs, int H, int W, const float* __restrict__ wpd,
-                                    const float* __restrict__ bpd, int nd, long n, float* __restrict__ out) {
+                                    const float* __restrict__ bpd, int nd, int cw, long n, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int x = (int)(i % W), y = (int)((i / W) % H);
   const int Co = nd + Cs - 1;
-  const int c = (int)((i / ((long)W * H)) % Co);
-  const long b = i / ((long)W * H * Co);
+  const long plane = (long)W * H;
+  const int c = (int)((i / plane) % cw);
+  const long b = i / (plane * cw);
   const float* sb = seg + b * (long)Cs * H * W;
-  if (c >= nd) { out[i] = sb[(long)(c - nd + 1) * H * W + (long)y * W + x]; return; }
+  float* o = out + (b * Co + c) * plane + (long)y * W + x;
+  if (c >= nd) { *o = sb[(long)(c - nd + 1) * H * W + (long)y * W + x]; return; }
   float v = bpd[c];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx)
       v = fmaf(wpd[c * 9 + ky * 3 + kx], sb[(long)reflect_idx(y + ky - 1, H) * W + reflect_idx(x + kx - 1, W)], v);
-  out[i] = v > 0.f ? v : 0.01f * v;
+  *o = v > 0.f ? v : 0.01f * v;
 }
 
 __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restrict__ out) {   // one block per (b, c)
@@ -504,11 +508,12 @@ int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mod
 }
 
 int sln_spade_depth_concat(const float* seg, int B, int Cs, int H, int W, const float* wpd, const float* bpd, int nd, float* out,
-                           void* stream) {
+                           int copy_masks, void* stream) {
   if (!seg || !wpd || !bpd || !out) return SLN_E_BADARG;
-  const long n = (long)B * (nd + Cs - 1) * H * W;
+  const int cw = copy_masks ? nd + Cs - 1 : nd;
+  const long n = (long)B * cw * H * W;
   hipLaunchKernelGGL(depth_concat_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seg, Cs, H, W, wpd, bpd,
-                     nd, n, out);
+                     nd, cw, n, out);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -169,9 +169,9 @@ class SPADEGenerator4(nn.Module):
             return self._spade_shared(e, x, stats, seg, leaky)
         if seg.shape[0] != B:
             seg = seg.expand(B, -1, -1, -1).contiguous()
-        cat = torch.empty(B, nd + seg.shape[1] - 1, H, W, device=x.device)
+        cat = self._cat_buffer(seg, nd)
         _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), B, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
-                                            _lib.ptr(cat), self._st()), "sln_spade_depth_concat")
+                                            _lib.ptr(cat), 0, self._st()), "sln_spade_depth_concat")
         actv = torch.empty(B, NHIDDEN, H, W, device=x.device)
         _lib.check(L.sln_spade_conv(_lib.ptr(cat), B, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
                                     1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
@@ -181,6 +181,20 @@ class SPADEGenerator4(nn.Module):
                    "sln_spade_modulate")
         return out
 
+    def _cat_buffer(self, seg, nd):
+        """[depth features (nd) | masks] input of mlp_shared for this resolution.  The mask channels are the same for every
+        SPADE layer of a resolution: they are copied once per forward, later layers only overwrite the nd depth features."""
+        key = (seg.data_ptr(), tuple(seg.shape))
+        cache = getattr(self, "_cat_cache", None)                # a dict only while forward() runs (the pyramid is alive)
+        buf = cache.get(key) if cache is not None else None
+        if buf is None:
+            B, Cs, H, W = seg.shape
+            buf = torch.empty(B, nd + Cs - 1, H, W, device=seg.device)
+            buf[:, nd:] = seg[:, 1:]
+            if cache is not None:
+                cache[key] = buf
+        return buf
+
     def _spade_shared(self, e, x, stats, seg, leaky):
         """One semantic map for the whole batch (the reference broadcasts gamma/beta [1,C,H,W] in that case, and
         colorize_with_spade is exactly that use: 50 z per room).  gamma/beta - 72 % of the generator's MACs - are computed
@@ -188,9 +202,9 @@ class SPADEGenerator4(nn.Module):
         L = _lib.lib()
         B, C, H, W = x.shape
         nd = NHIDDEN // 8
-        cat = torch.empty(1, nd + seg.shape[1] - 1, H, W, device=x.device)
+        cat = self._cat_buffer(seg, nd)
         _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), 1, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
-                                            _lib.ptr(cat), self._st()), "sln_spade_depth_concat")
+                                            _lib.ptr(cat), 0, self._st()), "sln_spade_depth_concat")
         actv = torch.empty(1, NHIDDEN, H, W, device=x.device)
         _lib.check(L.sln_spade_conv(_lib.ptr(cat), 1, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
                                     1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
@@ -257,6 +271,7 @@ class SPADEGenerator4(nn.Module):
                 z = torch.randn(B, self.nz, dtype=torch.float32, device=seg.device)
             P = self._pack_all()
             L = _lib.lib()
+            self._cat_cache = {}                                      # per-forward: keyed by the pyramid level's storage
             nfc = 16 * self.nf * self.sw * self.sh
             x = torch.empty(B, nfc, device=seg.device)
             _lib.check(L.sln_linear_forward(_lib.ptr(z.float().contiguous()), B, self.nz, _lib.ptr(P["fc_w"]), _lib.ptr(P["fc_b"]),
@@ -283,4 +298,5 @@ class SPADEGenerator4(nn.Module):
             out = torch.empty(B, self.target_nc, S, S, device=seg.device)
             _lib.check(L.sln_conv_img_tanh(_lib.ptr(x), B, self.nf, S, S, _lib.ptr(P["img_w"]), _lib.ptr(P["img_b"]), self.target_nc,
                                            _lib.ptr(out), self._st()), "sln_conv_img_tanh")
+            self._cat_cache = None
             return out

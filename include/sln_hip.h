@@ -245,9 +245,11 @@ int sln_spade_apply(const float* xin, const float* gb, int B, int C, int H, int 
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream);
 /* F.interpolate(size=...): mode 0 nearest, 1 bilinear(align_corners=False) over BC planes */
 int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mode, float* dst, void* stream);
-/* [LeakyReLU_0.01(conv3x3_reflect(seg[:,0:1])) | seg[:,1:]] (SPADE4.mlp_preshared_depth + cat, :1445-1446) */
+/* [LeakyReLU_0.01(conv3x3_reflect(seg[:,0:1])) | seg[:,1:]] (SPADE4.mlp_preshared_depth + cat, :1445-1446) into
+ * out [B, nd + Cs - 1, H, W].  copy_masks = 0 writes the nd depth features only: the mask channels of a per-resolution
+ * buffer are filled once (copy_masks = 1) and shared by every SPADE layer of that resolution. */
 int sln_spade_depth_concat(const float* seg, int B, int Cs, int H, int W, const float* wpd, const float* bpd, int nd, float* out,
-                           void* stream);
+                           int copy_masks, void* stream);
 /* x_s + SEBlock2(dx) (:1492-1493); scratch 2*B*C floats */
 int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw, const float* w0, const float* w2, float* scratch,
                      float* out, void* stream);
