@@ -126,3 +126,23 @@ def test_one_semantic_map_many_z_equals_the_broadcast_of_the_reference():
     assert_close(out.cpu().numpy(), per_sample.cpu().numpy(), "shared vs per-sample", rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError):
         G(seg.expand(2, -1, -1, -1).contiguous().cuda(), z.cuda())
+
+
+def test_colorize_pipeline_from_raw_maps():
+    """depth + class masks -> 41-channel tensor (host/spade_input.py) -> several z for the one map -> uint8 images"""
+    S = pkg("host.SPADE_related"); I = pkg("host.spade_input")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(spade_ref.init_state(cfg, seed=7)); G = G.cuda().eval()
+    n = 4 * cfg.crop_size
+    yy, xx = torch.meshgrid(torch.arange(n) / n, torch.arange(n) / n, indexing="ij")
+    depth = 2.0 + 3.0 * yy + torch.sin(6 * xx)
+    m = torch.zeros(n, n); m[n // 4:n // 2, n // 4:n // 2] = 255
+    total = I.build_input(depth.cuda(), {"bed": m.cuda(), "wall": 255 - m.cuda()}, size=cfg.crop_size)
+    assert total.shape == (1, 41, cfg.crop_size, cfg.crop_size) and total.is_cuda
+    imgs = I.colorize(G, total, 4, generator=torch.Generator(device="cuda").manual_seed(0))
+    ref = spade_ref.generator(spade_ref.init_state(cfg, seed=7), cfg, total.cpu(),
+                              torch.randn(4, cfg.nz, device="cuda", generator=torch.Generator(device="cuda").manual_seed(0)).cpu())
+    assert_close(imgs.cpu().numpy(), ref.numpy(), "colorize", rtol=1e-4, atol=1e-4)
+    u8 = I.to_uint8(imgs)
+    assert u8.shape == (4, cfg.crop_size, cfg.crop_size, 3) and u8.dtype == torch.uint8
