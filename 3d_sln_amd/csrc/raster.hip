@@ -572,35 +572,54 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   }
 }
 
-__global__ void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val, const float* __restrict__ d_a,
-                                     const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
-                                     const int32_t* __restrict__ dch, int F, int is, int NC, int nch,
-                                     const SceneStats* __restrict__ st, float* __restrict__ out) {
-  const int b = blockIdx.z, ch = blockIdx.y;
+// One thread per pixel writes all nch channels: the per-pixel inputs are read once (a thread per (pixel, channel) re-read
+// them 70 times), every store instruction of a wavefront covers 64 consecutive pixels of one channel plane.
+__global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                            const float* __restrict__ d_a, const int32_t* __restrict__ cls,
+                                                            const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
+                                                            int is, int NC, int nch, const SceneStats* __restrict__ st,
+                                                            float* __restrict__ out) {
+  __shared__ int s_chan[64];          // image channel (0-based among the 40) of class c
+  __shared__ int s_owner[32];         // class owning depth channel k, -1 if none
+  __shared__ float s_fill[32];        // mean_c / wall_max of that class
+  __shared__ float s_wall;
+  const int b = blockIdx.y;
+  const int ndch = nch - 41;
+  if (threadIdx.x < 64) s_chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x;
+    int owner = -1;
+    if (k < ndch)
+      for (int c = 0; c < NC; ++c) if (dch[c] == k) { owner = c; break; }
+    s_owner[k] = owner;
+    const float wall_max = wall_max_of(st[b]);
+    float fill = 0.f;
+    if (owner >= 0) fill = (st[b].cnt[owner] > 0.0 ? (float)(st[b].sum[owner] / st[b].cnt[owner]) : wall_max);
+    s_fill[k] = fill;
+    if (k == 0) s_wall = wall_max;
+  }
+  __syncthreads();
   const long plane = (long)is * is;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int y = (int)(p / is), x = (int)(p % is);
   const long q = b * plane + p;
-  const float wall_max = wall_max_of(st[b]);
+  const float wall_max = s_wall;
   const int f = fi_b[q];
   const int c = f >= 0 ? cls[(long)b * F + f] : -1;
-  const float img = (c >= 0 && c < NC) ? class_image_value(val[3 * q]) : 0.f;
+  const bool cvalid = c >= 0 && c < NC;
+  const float img = cvalid ? class_image_value(val[3 * q]) : 0.f;
   const float dd = depth_value(d_a[q]);
-  float v = 0.f;
-  if (ch == 0) v = dd;
-  else if (ch <= 40) v = (c >= 0 && c < NC && chan[c] == ch - 1) ? img : 0.f;
-  else {
-    // which class owns this depth channel? (dch is a small table: linear search)
-    int owner = -1;
-    for (int k = 0; k < NC; ++k) if (dch[k] == ch - 41) { owner = k; break; }
-    if (owner >= 0) {
-      const bool m = (c == owner) && img > 0.1f;
-      const float mean = st[b].cnt[owner] > 0.0 ? (float)(st[b].sum[owner] / st[b].cnt[owner]) : wall_max;
-      v = (m ? dd : mean) / wall_max;
-    }
+  float* o = out + ((long)b * nch * is + (is - 1 - y)) * is + x;       // channel stride = plane
+  o[0] = dd;
+  const int mych = cvalid ? s_chan[c] : -1;
+  for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
+  for (int k = 0; k < ndch; ++k) {
+    const int owner = s_owner[k];
+    float v = 0.f;
+    if (owner >= 0) v = ((c == owner && img > 0.1f) ? dd : s_fill[k]) / wall_max;
+    o[(long)(41 + k) * plane] = v;
   }
-  out[(((long)b * nch + ch) * is + (is - 1 - y)) * is + x] = v;
 }
 
 // sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c)
@@ -762,7 +781,7 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
                      w.dB, F, is, 2, tex_eps, npix, w.val);
   // wall_max starts at -inf surrogate
   hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st);
-  hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), 70, B), dim3(256), 0, st, w.fiB, w.val, w.dA,
+  hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
   SLN_CHECK_LAUNCH();
   return 0;
