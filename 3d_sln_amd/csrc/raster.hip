@@ -41,7 +41,7 @@ __device__ __forceinline__ void face_inverse(const float* f, int is, float* inv)
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int d = 0; d < 2; ++d) p[n][d] = (float)(0.5 * (double)(f[3 * n + d] * is + is - 1));
+    for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (f[3 * n + d] * is + is - 1);      // == (float)(0.5 * (double)(...)): x0.5 is exact
   const float m[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
                       p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
                       p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
         w0 = fminf(fmaxf(w0, 0.f), 1.f); w1 = fminf(fmaxf(w1, 0.f), 1.f); w2 = fminf(fmaxf(w2, 0.f), 1.f);
         float ws = 0.f; ws += w0; ws += w1; ws += w2;
         w0 /= ws; w1 /= ws; w2 /= ws;
-        const float zp = (float)(1. / (double)(w0 / f[2] + w1 / f[5] + w2 / f[8]));
+        // the package computes 1. / x in double and rounds to float; with a 53-bit intermediate that double rounding is
+        // innocuous for a division (53 >= 2*24+2), so the correctly rounded fp32 division gives the same bits
+        const float zp = 1.0f / (w0 / f[2] + w1 / f[5] + w2 / f[8]);
         if (far <= zp) continue;
         if (!(zp <= near_a) && zp < A.z) { A.z = zp; A.idx = sid[k]; A.w0 = w0; A.w1 = w1; A.w2 = w2; }
         if (DUAL && !(zp <= near_b) && zp < Bz.z) { Bz.z = zp; Bz.idx = sid[k]; Bz.w0 = w0; Bz.w1 = w1; Bz.w2 = w2; }
@@ -344,93 +346,99 @@ struct PixClass {
   }
 };
 
+// x * 2. / is of the package (double arithmetic, rounded to float): x*2 is exact and the quotient by an integer that is
+// exact in fp32 survives the double rounding (see raster_tile_kernel), so fp32 gives the same bits; for a power-of-two
+// image size the division is an exact scaling.
+__device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2) { return pow2 ? x * s2 : x * 2.0f / (float)is; }
+
+// Work unit = (face, edge x axis, chunk of PMB_DC consecutive d0 values): blockIdx = (face, 6, chunks).  One wavefront per
+// face serialised up to 3*2*image_size edge steps for a wall / floor triangle that spans the image while thousands of
+// small faces had finished - the kernel ran as long as its largest face.  Units outside the edge's d0 range exit at
+// once; each unit adds its two partial sums to the face gradient with two atomics.
+constexpr int PMB_DC = 64;
+
 template <typename PIX>
 __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int F, int is,
                                                                 float eps, float* __restrict__ gfaces) {
   const long i = blockIdx.x;                       // face
   const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
+  const int e = blockIdx.y >> 1, axis = blockIdx.y & 1;
   float face[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
   if (backfacing(face)) return;
   const long base = (long)b * is * is;
-  float g[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int e = 0; e < 3; ++e) {
-    int pi[3]; float pp[3][2];
+  const bool pow2 = (is & (is - 1)) == 0;
+  const float s2 = 2.0f / (float)is;
+  int pi[3]; float pp[3][2];
 #pragma unroll
-    for (int n = 0; n < 3; ++n) pi[n] = (e + n) % 3;
+  for (int n = 0; n < 3; ++n) pi[n] = (e + n) % 3;
 #pragma unroll
-    for (int n = 0; n < 3; ++n)
+  for (int n = 0; n < 3; ++n)
 #pragma unroll
-      for (int d = 0; d < 2; ++d) pp[n][d] = (float)(0.5 * (double)(face[3 * pi[n] + d] * is + is - 1));
-    for (int axis = 0; axis < 2; ++axis) {
-      const auto V = pix.view(axis);
-      float p[3][2];
+    for (int d = 0; d < 2; ++d) pp[n][d] = 0.5f * (face[3 * pi[n] + d] * is + is - 1);
+  const auto V = pix.view(axis);
+  float p[3][2];
 #pragma unroll
-      for (int n = 0; n < 3; ++n)
+  for (int n = 0; n < 3; ++n)
 #pragma unroll
-        for (int d = 0; d < 2; ++d) p[n][d] = pp[n][(d + axis) % 2];
-      const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
-      const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
-      const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
-      float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
-      for (int d0 = d0_from; d0 <= d0_to; ++d0) {
-        const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-        const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-        const int d1_out = d1_in + dir;
-        if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;
-        const long idx_in = V.idx(base, d0, d1_in), idx_out = V.idx(base, d0, d1_out);
-        const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
-        const float r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;
-        const float r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-        auto add = [&](int d1, float diff) {
-          if (use0) {
-            float dist = (float)((double)(r0 * (d1 - d1_cross)) * 2. / is);
-            dist = 0 < dist ? dist + eps : dist - eps;
-            acc0 -= diff / dist;
-          }
-          if (use1) {
-            float dist = (float)((double)(r1 * (d1 - d1_cross)) * 2. / is);
-            dist = 0 < dist ? dist + eps : dist - eps;
-            acc1 -= diff / dist;
-          }
-        };
-        if (V.fi[idx_in] == fn) {                   // outward scan to the image border
-          const int lim = dir > 0 ? is - 1 : 0;
-          const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
-          for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const float diff = V.contrib(V.idx(base, d0, d1), idx_in, b);
-            if (diff > 0.f) add(d1, diff);
-          }
-        }
-        {                                           // inward scan to the opposite edge, this face's pixels only
-          float cross2;
-          if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
-          else cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
-          const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
-          const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
-          for (int d1 = from + lane; d1 <= to; d1 += 64) {
-            const long q = V.idx(base, d0, d1);
-            if (V.fi[q] != fn) continue;
-            const float diff = V.contrib(q, idx_out, b);
-            if (diff > 0.f) add(d1, diff);
-          }
-        }
+    for (int d = 0; d < 2; ++d) p[n][d] = pp[n][(d + axis) % 2];
+  const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
+  const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
+  const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
+  const int c_from = d0_from + (int)blockIdx.z * PMB_DC;
+  const int c_to = min(d0_to, c_from + PMB_DC - 1);
+  if (c_from > c_to) return;
+  float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
+  for (int d0 = c_from; d0 <= c_to; ++d0) {
+    const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+    const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+    const int d1_out = d1_in + dir;
+    if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;
+    const long idx_in = V.idx(base, d0, d1_in), idx_out = V.idx(base, d0, d1_out);
+    const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
+    const float r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;
+    const float r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
+    auto add = [&](int d1, float diff) {
+      if (use0) {
+        float dist = pix_scale(r0 * (d1 - d1_cross), is, pow2, s2);
+        dist = 0 < dist ? dist + eps : dist - eps;
+        acc0 -= diff / dist;
       }
-      g[pi[0] * 3 + (1 - axis)] += acc0;
-      g[pi[1] * 3 + (1 - axis)] += acc1;
+      if (use1) {
+        float dist = pix_scale(r1 * (d1 - d1_cross), is, pow2, s2);
+        dist = 0 < dist ? dist + eps : dist - eps;
+        acc1 -= diff / dist;
+      }
+    };
+    if (V.fi[idx_in] == fn) {                   // outward scan to the image border
+      const int lim = dir > 0 ? is - 1 : 0;
+      const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
+      for (int d1 = from + lane; d1 <= to; d1 += 64) {
+        const float diff = V.contrib(V.idx(base, d0, d1), idx_in, b);
+        if (diff > 0.f) add(d1, diff);
+      }
+    }
+    {                                           // inward scan to the opposite edge, this face's pixels only
+      float cross2;
+      if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+      else cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
+      const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
+      const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
+      for (int d1 = from + lane; d1 <= to; d1 += 64) {
+        const long q = V.idx(base, d0, d1);
+        if (V.fi[q] != fn) continue;
+        const float diff = V.contrib(q, idx_out, b);
+        if (diff > 0.f) add(d1, diff);
+      }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    float v = g[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    g[k] = v;
+  for (int off = 32; off > 0; off >>= 1) { acc0 += __shfl_xor(acc0, off, 64); acc1 += __shfl_xor(acc1, off, 64); }
+  if (lane == 0) {
+    if (acc0 != 0.f) atomicAdd(gfaces + 9 * i + pi[0] * 3 + (1 - axis), acc0);
+    if (acc1 != 0.f) atomicAdd(gfaces + 9 * i + pi[1] * 3 + (1 - axis), acc1);
   }
-  if (lane == 0)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) gfaces[9 * i + k] += g[k];
 }
 
 }  // namespace
@@ -507,7 +515,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n), dim3(64), 0, st, faces, pix, F, image_size, eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6, sln_cdiv(image_size, PMB_DC)), dim3(64), 0, st, faces, pix, F, image_size, eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -810,7 +818,8 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
                      num_classes, 70, w.g, w.gT);
   PixClass pix{w.fiB, w.fiT, w.cp, w.cpT, w.v, w.vT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n), dim3(64), 0, st, faces, pix, F, is, pix_eps, grad_faces);
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6, sln_cdiv(is, PMB_DC)), dim3(64), 0, st, faces, pix, F, is, pix_eps,
+                     grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
 }
