@@ -12,301 +12,8 @@
 // LDS tiles are k-major ([BK][rows+pad]); each lane feeds the MFMA with one ds_read_b32 per
 // operand (conflict-free: consecutive lanes -> consecutive rows).  Global->LDS staging goes
 // through registers (transform on the way), double-buffered so one barrier per K tile.
-#include "sln_common.h"
-#include "sln_gemm.h"
-#include "sln_prof.h"
-
-#include <cstdlib>
-#include <type_traits>
+#include "gemm_bodies.h"
 namespace {
-
-constexpr int BK = 32;
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-
-__device__ __forceinline__ float4 xform(float4 x1, float4 x2, const float4* cf) {
-  float4 r;
-  float4 c;
-  c = cf[0]; r.x = fmaxf(fmaf(c.x, x1.x, fmaf(c.y, x2.x, c.z)), c.w);
-  c = cf[1]; r.y = fmaxf(fmaf(c.x, x1.y, fmaf(c.y, x2.y, c.z)), c.w);
-  c = cf[2]; r.z = fmaxf(fmaf(c.x, x1.z, fmaf(c.y, x2.z, c.z)), c.w);
-  c = cf[3]; r.w = fmaxf(fmaf(c.x, x1.w, fmaf(c.y, x2.w, c.z)), c.w);
-  return r;
-}
-
-// XCD-aware bijective remap of a linear block id: consecutive logical ids share an XCD (and its L2).
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
-
-struct SegSel {   // block-uniform view of the segment that holds logical column k0
-  const float* x1; const float* x2; int ld1, ld2, c1, c2, which, base, end;
-};
-
-// MULTI = false: the operand has a single segment, so its fields are loop invariants that hipcc keeps in SGPRs.  With
-// the select chain below it re-reads the chosen segment's fields from the kernarg segment (s_load_dword) in every K
-// tile, and each such read is followed by s_waitcnt lgkmcnt(0), which also drains the LDS queue.
-template <bool MULTI>
-__device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
-  SegSel r;
-  if (!MULTI) {
-    const Seg& g = op.seg[0];
-    r.x1 = g.x1; r.x2 = g.x2; r.ld1 = g.ld1; r.ld2 = g.ld2; r.c1 = g.c1; r.c2 = g.c2; r.which = g.which; r.base = 0; r.end = g.len;
-    return r;
-  }
-  const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
-  const int s = (op.nseg > 1 && k0 >= e0) ? ((op.nseg > 2 && k0 >= e1) ? 2 : 1) : 0;
-  r.x1 = s == 0 ? op.seg[0].x1 : (s == 1 ? op.seg[1].x1 : op.seg[2].x1);
-  r.x2 = s == 0 ? op.seg[0].x2 : (s == 1 ? op.seg[1].x2 : op.seg[2].x2);
-  r.ld1 = s == 0 ? op.seg[0].ld1 : (s == 1 ? op.seg[1].ld1 : op.seg[2].ld1);
-  r.ld2 = s == 0 ? op.seg[0].ld2 : (s == 1 ? op.seg[1].ld2 : op.seg[2].ld2);
-  r.c1 = s == 0 ? op.seg[0].c1 : (s == 1 ? op.seg[1].c1 : op.seg[2].c1);
-  r.c2 = s == 0 ? op.seg[0].c2 : (s == 1 ? op.seg[1].c2 : op.seg[2].c2);
-  r.which = s == 0 ? op.seg[0].which : (s == 1 ? op.seg[1].which : op.seg[2].which);
-  r.base = s == 0 ? 0 : (s == 1 ? e0 : e1);
-  r.end = r.base + (s == 0 ? op.seg[0].len : (s == 1 ? op.seg[1].len : op.seg[2].len));
-  return r;
-}
-
-// ---------------------------------------------------------------------------------------------
-// NT kernel
-// ---------------------------------------------------------------------------------------------
-// // (An intra-block split-K variant, 8 waves per 64x64 tile, was measured and dropped: same time, see DESIGN.md.)
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
-__device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
-  constexpr int NT = 256;
-  constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
-  constexpr bool IDENT = AMODE == 2;
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
-  constexpr int RP = 32;                       // rows staged per pass
-  constexpr int PA = BM / RP, PB = BN / RP;
-  constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
-  static_assert(WM * WN == 4, "4 waves per block");
-  const int kpad = (a.K + 31) & ~31;
-  float4* coef = reinterpret_cast<float4*>(smem);
-  float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
-  float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
-  float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
-  float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int lb = xcd_remap(bid, nwg);
-  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-
-  const int kq = tid & 7, r0 = tid >> 3;
-  int ra_idx[PA], rb_idx[PA];
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int row = min(m0 + r0 + RP * p, a.M - 1);      // clamped: loads are unconditional, masking happens at the LDS store
-    ra_idx[p] = a.A.idx_a ? a.A.idx_a[row] : row;
-    rb_idx[p] = a.A.idx_b ? a.A.idx_b[row] : row;
-  }
-
-  int rid[PA];                                // source row of each staged row (single segment: gather resolved once)
-#pragma unroll
-  for (int p = 0; p < PA; ++p) {
-    const int row = min(m0 + r0 + RP * p, a.M - 1);
-    const int w0 = a.A.seg[0].which;
-    rid[p] = MULTI ? row : (w0 == 0 ? row : (w0 == 1 ? ra_idx[p] : rb_idx[p]));
-  }
-  float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
-  const int ntiles = kpad / BK;
-  const float* Wp = a.W; const int ldw = a.ldw, Mr = a.M, Nr = a.N, Kr = a.K;
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-
-  // NOTE: every global load below is unconditional (addresses clamped into the operand); a
-  // `valid ? load : 0` select makes hipcc branch around each load and drain vmcnt(0) per element,
-  // which serialises the whole register pipeline.  Out-of-range lanes are zeroed in lstore().
-  auto gload = [&](int kt, auto stage) {
-    constexpr int S = decltype(stage)::value;
-    const int k0 = kt * BK;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0);
-    const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int r = MULTI ? (sg.which == 0 ? rid[p] : (sg.which == 1 ? ra_idx[p] : rb_idx[p])) : rid[p];
-      ga1[S][p] = ld4(sg.x1 + (size_t)r * sg.ld1 + sg.c1 + cs);
-      if (HAS_X2) {
-        const float* x2 = sg.x2 ? sg.x2 : sg.x1;                 // block-uniform select
-        const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
-        ga2[S][p] = ld4(x2 + (size_t)r * ld2 + c2 + cs);
-      }
-    }
-    const int cw = min(k0 + 4 * kq, Kr - 4);
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int n = min(n0 + r0 + RP * p, Nr - 1);
-      gb[S][p] = ld4(Wp + (size_t)n * ldw + cw);
-    }
-  };
-  auto lstore = [&](int kt, int buf, auto stage) {
-    constexpr int S = decltype(stage)::value;
-    const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0);
-    const bool cv = col < sg.end;
-    const bool x2v = HAS_X2 && sg.x2 != nullptr;
-    float* as = As + buf * BM * LDT + 4 * kq;
-    float* bs = Bs + buf * BN * LDT + 4 * kq;
-    const float4* cf = coef + min(col, kpad - 4);
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int rl = r0 + RP * p;
-      const bool v = cv && (m0 + rl) < Mr;
-      float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(as + rl * LDT) = t;
-    }
-    const bool kv = col < Kr;
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const bool v = kv && (n0 + r0 + RP * p) < Nr;
-      float4 t = gb[S][p];
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(bs + (r0 + RP * p) * LDT) = t;
-    }
-  };
-
-  // issue the first tiles' loads before the (dependent, sqrt-heavy) coefficient set-up
-  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
-  const int last = ntiles - 1;
-  gload(0, S0{});
-  gload(min(1, last), S1{});
-  gload(min(2, last), S2{});
-
-  if (!IDENT) {
-    sln_fill_coefs(a.A, coef, tid, NT);
-    for (int c = a.K + tid; c < kpad; c += NT) coef[c] = z4;
-  }
-  if (EPI == EPI_MASK) {
-    for (int c = tid; c < BN; c += NT) {
-      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-      if (n0 + c < a.N) {
-        bn_fwd_coef(a.obn, n0 + c, e.x, e.y);
-        bn_mean_istd(a.obn, n0 + c, e.z, e.w);
-      }
-      ecoef[c] = e;
-    }
-  }
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  __syncthreads();            // coef tables visible
-  lstore(0, 0, S0{});
-  gload(min(3, last), S0{});
-  __syncthreads();
-  const int lrow = lane & 31, lk = lane >> 5;
-
-  // Fragments ping-pong between two register sets; on entry to body(kt) set 0 already holds the first 8-wide k chunk of
-  // tile kt.  It was read right after the barrier that ended body(kt-1), under the MFMAs of that tile's last chunk, so
-  // neither the barrier nor the LDS read latency leaves the matrix pipe idle (each wave has a single dependent MFMA
-  // chain when the wave tile is 32x32, nothing else could cover them).
-  float4 fa[2][TM], fb[2][TN];
-  auto rd = [&](int buf, int kb, auto set) {
-    constexpr int F = decltype(set)::value;
-    const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk + kb;
-    const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk + kb;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) fa[F][i] = *reinterpret_cast<const float4*>(as + 32 * i * LDT);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[F][j] = *reinterpret_cast<const float4*>(bs + 32 * j * LDT);
-  };
-  auto mma = [&](auto set) {
-    constexpr int F = decltype(set)::value;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].x, fb[F][j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].y, fb[F][j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].z, fb[F][j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][i].w, fb[F][j].w, acc[i][j], 0, 0, 0);
-      }
-  };
-  rd(0, 0, S0{});
-
-  // tile j lives in register stage j % 3; body(kt) computes tile kt from LDS, stores tile kt+1 from its stage
-  // and refills that stage with tile kt+4.  Every body issues the SAME loads unconditionally (tile
-  // indices clamped; the surplus tiles are never consumed) so that hipcc's s_waitcnt accounting is exact
-  // and the wait in lstore() leaves the two younger stages in flight (vmcnt(8), not vmcnt(0)).
-  auto body = [&](int kt, auto stage_next) {
-    const int buf = kt & 1;
-    rd(buf, 8, S1{});
-    mma(S0{});
-    lstore(min(kt + 1, last), buf ^ 1, stage_next);
-    rd(buf, 16, S0{});
-    mma(S1{});
-    rd(buf, 24, S1{});
-    mma(S0{});
-    gload(min(kt + 4, last), stage_next);
-    __syncthreads();
-    rd(buf ^ 1, 0, S0{});
-    mma(S1{});
-  };
-  int kt = 0;
-  for (; kt + 3 <= ntiles; kt += 3) { body(kt, S1{}); body(kt + 1, S2{}); body(kt + 2, S0{}); }
-  if (ntiles - kt == 1) { body(kt, S1{}); }
-  else if (ntiles - kt == 2) { body(kt, S1{}); body(kt + 1, S2{}); }
-
-  // ------------------------------- epilogue -------------------------------
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
-    const int col = n0 + cl;
-    const bool cvalid = col < a.N;
-    const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
-    float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
-    if (EPI == EPI_MASK) ec = ecoef[cl];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (cvalid && row < a.M) {
-          float y = acc[i][j][r] + bias;
-          if (a.addend) y += a.addend[(size_t)row * a.ldadd + a.addcol0 + col];
-          if (EPI == EPI_STATS) { s1 += y; s2 = fmaf(y, y, s2); }
-          if (EPI == EPI_MASK) {
-            const float xp = a.xprev[(size_t)row * a.ldx + a.xcol0 + col];
-            y = fmaf(ec.x, xp, ec.y) > 0.f ? y : 0.f;
-            s1 += y; s2 = fmaf(y, (xp - ec.z) * ec.w, s2);
-          }
-          a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
-        }
-      }
-    }
-    if (EPI != EPI_PLAIN) {
-      s1 = wave_sum_halves(s1); s2 = wave_sum_halves(s2);
-      if (lk == 0) { red[((wave / WN) * BN + cl) * 2 + 0] = s1; red[((wave / WN) * BN + cl) * 2 + 1] = s2; }
-    }
-  }
-  if (EPI != EPI_PLAIN) {
-    __syncthreads();
-    double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
-    if (out != nullptr) {
-      for (int c = tid; c < BN; c += NT) {
-        if (n0 + c < a.N) {
-          float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-          for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + c) * 2]; s2 += red[(w * BN + c) * 2 + 1]; }
-          atomicAdd(out + n0 + c, (double)s1);
-          atomicAdd(out + a.ocstride + n0 + c, (double)s2);
-        }
-      }
-    }
-  }
-}
-
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -339,217 +46,6 @@ int dispatch_nt_tile(const GemmNTArgs& a, hipStream_t st, int tile) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// TN kernel (wgrad)
-// ---------------------------------------------------------------------------------------------
-struct ColSel { const float* x1; const float* x2; int ld1, ld2, which; bool valid; };
-
-__device__ __forceinline__ ColSel pick_col(const Operand& op, int col) {
-  // per-thread (non-uniform) choice of the segment holding logical column `col`
-  ColSel r;
-  r.valid = col < op.cols;
-  col = r.valid ? col : 0;                  // keep the address inside the operand; invalid lanes are masked later
-  const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
-  const int s = (op.nseg > 1 && col >= e0) ? ((op.nseg > 2 && col >= e1) ? 2 : 1) : 0;
-  const int base = s == 0 ? 0 : (s == 1 ? e0 : e1);
-  const int c = col - base;
-  const Seg& g0 = op.seg[0]; const Seg& g1 = op.seg[1]; const Seg& g2 = op.seg[2];
-  r.x1 = (s == 0 ? g0.x1 + g0.c1 : (s == 1 ? g1.x1 + g1.c1 : g2.x1 + g2.c1)) + c;
-  const float* b2 = s == 0 ? g0.x2 : (s == 1 ? g1.x2 : g2.x2);
-  r.x2 = b2 ? b2 + (s == 0 ? g0.c2 : (s == 1 ? g1.c2 : g2.c2)) + c : nullptr;
-  r.ld1 = s == 0 ? g0.ld1 : (s == 1 ? g1.ld1 : g2.ld1);
-  r.ld2 = s == 0 ? g0.ld2 : (s == 1 ? g1.ld2 : g2.ld2);
-  r.which = s == 0 ? g0.which : (s == 1 ? g1.which : g2.which);
-  return r;
-}
-
-__device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (col < op.cols) {
-    const int e0 = op.seg[0].len, e1 = e0 + op.seg[1].len;
-    if (op.nseg > 2 && col >= e1) v = sln_coef_for(op.seg[2], col - e1);
-    else if (op.nseg > 1 && col >= e0) v = sln_coef_for(op.seg[1], col - e0);
-    else v = sln_coef_for(op.seg[0], col);
-  }
-  return v;
-}
-
-// XG: the X operand has row-gathered segments (GraphTripleConv input).  Its row indices then run through their own
-// three-stage register pipeline, one tile ahead of the data loads that use them, so that no load waits on another.
-// G (a gradient) is never gathered.
-template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
-__device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, const int by, char* smem) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int SA = BM + 4, SB = BN + 4;
-  constexpr int TPRA = BM / 4, TPRB = BN / 4;         // threads per row
-  constexpr int RPA = 256 / TPRA, RPB = 256 / TPRB;   // rows per pass
-  constexpr int PA = BK / RPA, PB = BK / RPB;
-  float4* coefG = reinterpret_cast<float4*>(smem);          // [BM]
-  float4* coefX = coefG + BM;                               // [BN]
-  float* As = reinterpret_cast<float*>(coefX + BN);         // [2][BK][SA]
-  float* Bs = As + 2 * BK * SA;                             // [2][BK][SB]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_k = (a.Kin + BN - 1) / BN;
-  const int n0 = (bx / tiles_k) * BM, k0 = (bx % tiles_k) * BN;
-  const int rbeg = by * a.rows_per_block;
-  const int rend = min(a.R, rbeg + a.rows_per_block);
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
-
-  // per-column coefficient tables for this block's column ranges
-  for (int c = tid; c < BM; c += 256) coefG[c] = coef_for_col(a.G, n0 + c);
-  for (int c = tid; c < BN; c += 256) coefX[c] = coef_for_col(a.X, k0 + c);
-
-  const int ca = 4 * (tid % TPRA), ra0 = tid / TPRA;
-  const int cb = 4 * (tid % TPRB), rb0 = tid / TPRB;
-  const ColSel gs = pick_col(a.G, n0 + ca);
-  const ColSel xs = pick_col(a.X, k0 + cb);
-
-  constexpr int NST = 3;
-  float4 g1[NST][PA], g2[NST][PA], x1[NST][PB];
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  // unconditional, clamped loads (see the note in gemm_nt_body); masking happens in lstore()
-  const int* x_ip = xs.which == 2 ? a.X.idx_b : a.X.idx_a;
-  if (x_ip == nullptr) x_ip = a.X.idx_a ? a.X.idx_a : a.X.idx_b;   // plain-row columns still issue the (unused) index loads
-  const float* g_x2 = gs.x2 ? gs.x2 : gs.x1;
-  const int g_ld2 = gs.x2 ? gs.ld2 : gs.ld1;
-  int xi[NST][PB];
-  auto iload = [&](int rt, auto stage) {
-    constexpr int S = decltype(stage)::value;
-#pragma unroll
-    for (int p = 0; p < PB; ++p) xi[S][p] = x_ip[min(rbeg + rt * BK + rb0 + RPB * p, rend - 1)];
-  };
-  auto gload = [&](int rt, int rt_idx, auto stage) {
-    constexpr int S = decltype(stage)::value;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int row = min(rbeg + rt * BK + ra0 + RPA * p, rend - 1);
-      g1[S][p] = ld4(gs.x1 + (size_t)row * gs.ld1);
-      if (G_X2) g2[S][p] = ld4(g_x2 + (size_t)row * g_ld2);
-    }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int row = min(rbeg + rt * BK + rb0 + RPB * p, rend - 1);
-      const int r = XG ? (xs.which ? xi[S][p] : row) : row;
-      x1[S][p] = ld4(xs.x1 + (size_t)r * xs.ld1);
-    }
-    if (XG) iload(rt_idx, stage);          // indices of the tile this stage will load next
-  };
-  float4 dbacc = z4;
-  auto lstore = [&](int rt, int buf, auto stage, bool real) {
-    constexpr int S = decltype(stage)::value;
-#pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int rl = ra0 + RPA * p;
-      const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = xform(g1[S][p], (G_X2 && gs.x2) ? g2[S][p] : z4, coefG + ca);
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      if (real) { dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w; }   // surplus (clamped) tiles do not count
-      *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
-    }
-#pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const int rl = rb0 + RPB * p;
-      const bool v = xs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = xform(x1[S][p], z4, coefX + cb);
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = t;
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int ntiles = (rend - rbeg + BK - 1) / BK;
-  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
-  const int last = ntiles - 1;          // ntiles >= 1: every launched block owns at least one row
-  if (XG) { iload(0, S0{}); iload(min(1, last), S1{}); iload(min(2, last), S2{}); }
-  gload(0, min(3, last), S0{});
-  gload(min(1, last), min(4, last), S1{});
-  gload(min(2, last), min(5, last), S2{});
-  __syncthreads();            // coefficient tables visible
-  lstore(0, 0, S0{}, true);
-  gload(min(3, last), min(6, last), S0{});
-  __syncthreads();
-  const int lrow = lane & 31, lk = lane >> 5;
-  // fragments of 4 k-steps (8 rows of the tile) ping-pong between two register sets; set 0 is refilled with the next
-  // tile's first chunk right after the barrier, under the MFMAs of the current tile's last chunk (as in gemm_nt_body)
-  float fa[2][4][TM], fb[2][4][TN];
-  auto rd = [&](int buf, int kk0, auto set) {
-    constexpr int F = decltype(set)::value;
-    const float* as = As + buf * BK * SA + wm0 + lrow + (kk0 + lk) * SA;
-    const float* bs = Bs + buf * BK * SB + wn0 + lrow + (kk0 + lk) * SB;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[F][q][i] = as[2 * q * SA + 32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[F][q][j] = bs[2 * q * SB + 32 * j];
-    }
-  };
-  auto mma = [&](auto set) {
-    constexpr int F = decltype(set)::value;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q][i], fb[F][q][j], acc[i][j], 0, 0, 0);
-  };
-  rd(0, 0, S0{});
-  auto body = [&](int rt, auto stage_next) {
-    const int buf = rt & 1;
-    rd(buf, 8, S1{});
-    mma(S0{});
-    lstore(min(rt + 1, last), buf ^ 1, stage_next, rt + 1 <= last);
-    rd(buf, 16, S0{});
-    mma(S1{});
-    rd(buf, 24, S1{});
-    mma(S0{});
-    gload(min(rt + 4, last), min(rt + 7, last), stage_next);
-    __syncthreads();
-    rd(buf ^ 1, 0, S0{});
-    mma(S1{});
-  };
-  int rt = 0;
-  for (; rt + 3 <= ntiles; rt += 3) { body(rt, S1{}); body(rt + 1, S2{}); body(rt + 2, S0{}); }
-  if (ntiles - rt == 1) { body(rt, S1{}); }
-  else if (ntiles - rt == 2) { body(rt, S1{}); body(rt + 1, S2{}); }
-
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = k0 + wn0 + 32 * j + lrow;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (n < a.Nout && k < a.Kin) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
-      }
-    }
-
-  if (a.db != nullptr && (bx % tiles_k) == 0) {
-    // threads with equal (tid % TPRA) hold partial sums of the same 4 columns
-#pragma unroll
-    for (int off = TPRA; off < 64; off <<= 1) {
-      dbacc.x += __shfl_xor(dbacc.x, off, 64); dbacc.y += __shfl_xor(dbacc.y, off, 64);
-      dbacc.z += __shfl_xor(dbacc.z, off, 64); dbacc.w += __shfl_xor(dbacc.w, off, 64);
-    }
-    if (lane < TPRA && lane == (tid % TPRA)) {
-      const int n = n0 + ca;
-      if (n + 0 < a.Nout) atomicAdd(a.db + n + 0, dbacc.x);
-      if (n + 1 < a.Nout) atomicAdd(a.db + n + 1, dbacc.y);
-      if (n + 2 < a.Nout) atomicAdd(a.db + n + 2, dbacc.z);
-      if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, dbacc.w);
-    }
-  }
-}
-
 template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTNArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -570,20 +66,6 @@ __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, cons
   }
 }
 
-inline bool tn_gathers(const GemmTNArgs& a) {
-  bool g = false;
-  for (int s = 0; s < a.X.nseg; ++s) g |= a.X.seg[s].which != 0;
-  return g;
-}
-inline bool tn_supported(const GemmTNArgs& a) {     // the gradient operand is addressed by plain rows
-  for (int s = 0; s < a.G.nseg; ++s) if (a.G.seg[s].which != 0) return false;
-  return true;
-}
-inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
-  const int kpad = (K + 31) & ~31;
-  return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
-}
-inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + 4 + BN + 4) * 4; }
 
 template <int AMODE, int EPI>
 int launch_dual(const GemmNTArgs& a, const GemmTNArgs& b, hipStream_t st) {
@@ -631,6 +113,7 @@ static int init_nt_tile() {
   return (int)e;
 }
 
+int sln_gemm_group_init();
 int sln_gemm_init() {
   static bool done = false;
   if (done) return 0;
@@ -650,39 +133,13 @@ int sln_gemm_init() {
   SLN_SET_DUAL(0, EPI_PLAIN) SLN_SET_DUAL(0, EPI_MASK) SLN_SET_DUAL(1, EPI_PLAIN) SLN_SET_DUAL(1, EPI_MASK)
   SLN_SET_DUAL(2, EPI_PLAIN) SLN_SET_DUAL(2, EPI_MASK)
 #undef SLN_SET_DUAL
+  if (!r) r = sln_gemm_group_init();
   done = r == 0;
   return r;
 }
 
-static int nt_heuristic_tile(const GemmNTArgs& a) {   // enough blocks to cover 256 CUs, otherwise the biggest tile
-  const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
-  const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
-  return b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
-}
 
-static int nt_amode(const GemmNTArgs& a) {
-  bool x2 = false;
-  for (int s = 0; s < a.A.nseg; ++s) x2 |= a.A.seg[s].x2 != nullptr;
-  bool ident = !x2;
-  for (int s = 0; s < a.A.nseg; ++s) ident = ident && a.A.seg[s].coef == SLN_COEF_IDENT;
-  return x2 ? 1 : (ident ? 2 : 0);
-}
 
-static bool tn_prepare(GemmTNArgs& a) {   // fills rows_per_block; returns whether G carries a second source
-  bool x2 = false;
-  for (int s = 0; s < a.G.nseg; ++s) x2 |= a.G.seg[s].x2 != nullptr;
-  if (a.rows_per_block <= 0) {
-    // measured on MI355X (tools/gemm_bench.py): ~768 blocks in flight, but never fewer than 256 rows per block -
-    // below that the per-block prologue and the dW atomics (64x64 per block) dominate; chunks a multiple of BK rows
-    const int target = 768;
-    const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
-    int chunks = sln_cdiv(target, tiles);
-    const int minrows = 256;
-    int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
-    a.rows_per_block = rpb < minrows ? minrows : rpb;
-  }
-  return x2;
-}
 
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
   SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);

@@ -40,4 +40,7 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st);
 int sln_launch_gemm_tn(const GemmTNArgs& a, int tile, hipStream_t st);
 // dgrad (NT) and wgrad (TN) of the same Linear in one launch when both are small; falls back to two launches otherwise
 int sln_launch_gemm_dual(const GemmNTArgs& nt, int epi, const GemmTNArgs& tn, hipStream_t st);
+// up to two independent NT problems + up to two independent TN problems in one launch (gemm_group.hip); returns 1 without
+// launching anything when the problems cannot share a kernel - the caller launches them separately then
+int sln_launch_gemm_group(const GemmNTArgs* nt, const int* epi, int n_nt, const GemmTNArgs* tn, int n_tn, hipStream_t st);
 int sln_gemm_init();   // raises dynamic-LDS limits; call once outside any stream capture

@@ -89,6 +89,7 @@ struct SlnVae {
   float *g4 = nullptr, *g3 = nullptr, *dM = nullptr, *g2 = nullptr, *g1 = nullptr, *dG[2] = {nullptr, nullptr};
   float *dX0 = nullptr, *dz = nullptr, *dmu = nullptr, *dlv = nullptr;
   float *g_h2 = nullptr, *g_h1 = nullptr, *d_xb = nullptr, *d_xa = nullptr, *tmp_d = nullptr;
+  float *g_h2b = nullptr, *g_h1b = nullptr, *tmp_db = nullptr;     // the angle branch's copies (both branches run grouped)
   int dbp_ld = 8;
 
   bool enc_training = false, dec_training = false, have_enc = false, have_dec = false, have_loss_grads = false;
@@ -205,6 +206,34 @@ struct SlnVae {
     return op1(seg_act(ly.A4, ly.D, 0, ly.D, ly.bn[3], 0, training), O);
   }
 
+  // Group mode: between begin_group() and end_group() the Linear launches are recorded instead of issued; end_group()
+  // issues them two at a time through sln_launch_gemm_group (the recorded problems must be independent of each other:
+  // the two posterior heads of the encoder, box_net / angle_net of the decoder).
+  struct GroupItem { GemmNTArgs nt; int epi; bool has_tn; GemmTNArgs tn; };
+  bool grouping = false, use_group = true;
+  std::vector<GroupItem> group_items;
+  void begin_group() { grouping = use_group; group_items.clear(); }
+  int launch_item(const GroupItem& it, hipStream_t st) {
+    return it.has_tn ? sln_launch_gemm_dual(it.nt, it.epi, it.tn, st) : sln_launch_gemm_nt(it.nt, it.epi, -1, st);
+  }
+  int end_group(hipStream_t st) {
+    grouping = false;
+    for (size_t i = 0; i < group_items.size(); i += 2) {
+      const GroupItem& a = group_items[i];
+      if (i + 1 == group_items.size()) { int r = launch_item(a, st); if (r) return r; break; }
+      const GroupItem& b2 = group_items[i + 1];
+      GemmNTArgs nt[2] = {a.nt, b2.nt}; int epi[2] = {a.epi, b2.epi};
+      GemmTNArgs tn[2]; int ntn = 0;
+      if (a.has_tn) tn[ntn++] = a.tn;
+      if (b2.has_tn) tn[ntn++] = b2.tn;
+      int r = sln_launch_gemm_group(nt, epi, 2, tn, ntn, st);
+      if (r == 1) { r = launch_item(a, st); if (!r) r = launch_item(b2, st); }
+      if (r) return r;
+    }
+    group_items.clear();
+    return 0;
+  }
+
   int linear_fwd(const Operand& A, int ui, float* Y, int ldy, int ycol0, int M, int inst, bool training, hipStream_t st) {
     const Unit& u = units[ui];
     GemmNTArgs a; std::memset(&a, 0, sizeof(a));
@@ -212,6 +241,7 @@ struct SlnVae {
     a.M = M; a.N = u.out; a.K = u.in; a.ldw = u.in;
     int epi = EPI_PLAIN;
     if (inst >= 0 && bn_mode(bns[inst], training) == SLN_BN_TRAIN) { epi = EPI_STATS; a.osums = bns[inst].sums; a.ocstride = bns[inst].C; }
+    if (grouping) { GroupItem it; it.nt = a; it.epi = epi; it.has_tn = false; group_items.push_back(it); return 0; }
     return sln_launch_gemm_nt(a, epi, -1, st);
   }
   // dIn[M, in] = G[M, out] * W ; optional relu/BN mask of the producing stage (xprev, inst) and addend
@@ -227,6 +257,12 @@ struct SlnVae {
       epi = EPI_MASK; a.xprev = xprev; a.ldx = ldx; a.xcol0 = 0;
       a.obn = view(mask_inst, 0, training);
       if (a.obn.mode != SLN_BN_NONE) { a.ogsums = bns[mask_inst].gsums; a.ocstride = bns[mask_inst].C; }
+    }
+    if (grouping) {
+      GroupItem it; it.nt = a; it.epi = epi; it.has_tn = !pending.empty();
+      if (it.has_tn) { it.tn = pending.front(); pending.erase(pending.begin()); }
+      group_items.push_back(it);
+      return 0;
     }
     if (!pending.empty()) {
       const GemmTNArgs t = pending.front();
@@ -311,6 +347,7 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   dX0 = b.take<float>(Om * Dm); dz = b.take<float>(Om * E); dmu = b.take<float>(Om * E); dlv = b.take<float>(Om * E);
   g_h2 = b.take<float>(Om * W); g_h1 = b.take<float>(Om * H); d_xb = b.take<float>(Om * W); d_xa = b.take<float>(Om * W);
   tmp_d = b.take<float>(Om * W);
+  g_h2b = b.take<float>(Om * W); g_h1b = b.take<float>(Om * H); tmp_db = b.take<float>(Om * W);
   return (b.off + 255) & ~size_t(255);
 }
 
@@ -385,18 +422,24 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
   for (int l = 0; l < L; ++l) RET_IF(gconv_forward(l, training, st));
   const Operand XL = layer_output(L - 1, training);
   const int W = 2 * E;
-  // box_mean_var / box_mean / box_var  (Sg2ScVAE_model.py:134-136)
+  // box_mean_var / box_mean / box_var (Sg2ScVAE_model.py:134-136) and angle_mean_var / angle_mean / angle_var (:138-140):
+  // two identical-shape branches, issued stage by stage as grouped launches
+  begin_group();
   RET_IF(linear_fwd(XL, 0, hbA1, H, 0, O, bn_head[0], training, st));
-  RET_IF(linear_fwd(op1(seg_act(hbA1, H, 0, H, bn_head[0], 0, training), O), 1, hbA2, W, 0, O, bn_head[1], training, st));
-  const Operand HB = op1(seg_act(hbA2, W, 0, W, bn_head[1], 0, training), O);
-  RET_IF(linear_fwd(HB, 2, mu, E, 0, O, -1, training, st));
-  RET_IF(linear_fwd(HB, 3, logvar, E, 0, O, -1, training, st));
-  // angle_mean_var / angle_mean / angle_var  (:138-140)
   RET_IF(linear_fwd(XL, 4, haA1, H, 0, O, bn_head[2], training, st));
+  RET_IF(end_group(st));
+  begin_group();
+  RET_IF(linear_fwd(op1(seg_act(hbA1, H, 0, H, bn_head[0], 0, training), O), 1, hbA2, W, 0, O, bn_head[1], training, st));
   RET_IF(linear_fwd(op1(seg_act(haA1, H, 0, H, bn_head[2], 0, training), O), 5, haA2, W, 0, O, bn_head[3], training, st));
+  RET_IF(end_group(st));
+  const Operand HB = op1(seg_act(hbA2, W, 0, W, bn_head[1], 0, training), O);
   const Operand HA = op1(seg_act(haA2, W, 0, W, bn_head[3], 0, training), O);
+  begin_group();
+  RET_IF(linear_fwd(HB, 2, mu, E, 0, O, -1, training, st));
   RET_IF(linear_fwd(HA, 6, mu, E, n_box_e, O, -1, training, st));
+  RET_IF(linear_fwd(HB, 3, logvar, E, 0, O, -1, training, st));
   RET_IF(linear_fwd(HA, 7, logvar, E, n_box_e, O, -1, training, st));
+  RET_IF(end_group(st));
   if (training) RET_IF(run_bn_updates(0, n_bn_enc, st));
   enc_training = training; have_enc = true;
   return 0;
@@ -419,12 +462,16 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   XA.seg[0] = seg_act(ll.A4, Ddc, 0, Ddc, ll.bn[3], 0, training);
   XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
   XA.nseg = 2; XA.rows = O; XA.cols = Ddc + n_attr_e; XA.idx_a = attrs32;
+  begin_group();
   RET_IF(linear_fwd(XA, unit_boxnet(0), bnA1, H, 0, O, bn_head[4], training, st));
+  RET_IF(linear_fwd(layer_output(2 * L - 1, training), unit_anglenet(0), anA1, H, 0, O, bn_head[5], training, st));
+  RET_IF(end_group(st));
+  begin_group();
   RET_IF(linear_fwd(op1(seg_act(bnA1, H, 0, H, bn_head[4], 0, training), O), unit_boxnet(1), boxes_pred, cfg.box_dim, 0, O, -1,
                     training, st));
-  RET_IF(linear_fwd(layer_output(2 * L - 1, training), unit_anglenet(0), anA1, H, 0, O, bn_head[5], training, st));
   RET_IF(linear_fwd(op1(seg_act(anA1, H, 0, H, bn_head[5], 0, training), O), unit_anglenet(1), logits, cfg.n_angle, 0, O, -1,
                     training, st));
+  RET_IF(end_group(st));
   RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));
   if (training) RET_IF(run_bn_updates(n_bn_enc, (int)bns.size() - n_bn_enc, st));
   dec_training = training; have_dec = true; z_from_latent = (z_ext == nullptr);
@@ -453,28 +500,30 @@ int SlnVae::decoder_backward(hipStream_t st) {
   const int last = 2 * L - 1;
   const Layer& ll = layers[last];
   const int W = Ddc, WA = Ddc + n_attr_e;
-  // box_net.1
+  // box_net.1 and angle_net.1 (grouped), then box_net.0 and angle_net.0 (grouped)
   Operand Gb = op1(seg_ident(dbp, dbp_ld, 0, dbp_ld, 0), O); Gb.cols = dbp_ld;
+  Operand Ga = op1(seg_ident(dlogits, cfg.n_angle, 0, cfg.n_angle, 0), O);
+  begin_group();
   {
     Operand Gw = Gb; Gw.seg[0].len = cfg.box_dim; Gw.cols = cfg.box_dim;   // wgrad masks the padded columns itself
     RET_IF(linear_wgrad(Gw, op1(seg_act(bnA1, H, 0, H, bn_head[4], 0, tr), O), unit_boxnet(1), O, st));
   }
   RET_IF(linear_dgrad(Gb, unit_boxnet(1), g_bn, H, O, bnA1, H, bn_head[4], true, nullptr, 0, tr, st));
-  // box_net.0
+  RET_IF(linear_wgrad(Ga, op1(seg_act(anA1, H, 0, H, bn_head[5], 0, tr), O), unit_anglenet(1), O, st));
+  RET_IF(linear_dgrad(Ga, unit_anglenet(1), g_an, H, O, anA1, H, bn_head[5], true, nullptr, 0, tr, st));
+  RET_IF(end_group(st));
   Operand G0 = op1(seg_bwd(g_bn, H, bnA1, H, H, bn_head[4], tr), O);
   Operand XA; std::memset(&XA, 0, sizeof(XA));
   XA.seg[0] = seg_act(ll.A4, W, 0, W, ll.bn[3], 0, tr);
   XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
   XA.nseg = 2; XA.rows = O; XA.cols = WA; XA.idx_a = attrs32;
+  Operand Ga0 = op1(seg_bwd(g_an, H, anA1, H, H, bn_head[5], tr), O);
+  begin_group();
   RET_IF(linear_wgrad(G0, XA, unit_boxnet(0), O, st));
   RET_IF(linear_dgrad(G0, unit_boxnet(0), d_bx, WA, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
-  // angle_net.1 / angle_net.0
-  Operand Ga = op1(seg_ident(dlogits, cfg.n_angle, 0, cfg.n_angle, 0), O);
-  RET_IF(linear_wgrad(Ga, op1(seg_act(anA1, H, 0, H, bn_head[5], 0, tr), O), unit_anglenet(1), O, st));
-  RET_IF(linear_dgrad(Ga, unit_anglenet(1), g_an, H, O, anA1, H, bn_head[5], true, nullptr, 0, tr, st));
-  Operand Ga0 = op1(seg_bwd(g_an, H, anA1, H, H, bn_head[5], tr), O);
   RET_IF(linear_wgrad(Ga0, layer_output(last, tr), unit_anglenet(0), O, st));
   RET_IF(linear_dgrad(Ga0, unit_anglenet(0), d_ax, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  RET_IF(end_group(st));
   RET_IF(join_side(st));      // g_bn / g_an / dbp / dlogits consumers done before g4 is produced
   // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
   {
@@ -522,26 +571,45 @@ int SlnVae::encoder_backward(hipStream_t st) {
   const Layer& ll = layers[last];
   const Operand XL = layer_output(last, tr);
   float* d_x[2] = {d_xb, d_xa};
-  for (int br = 0; br < 2; ++br) {         // 0: box branch (units 0..3), 1: angle branch (units 4..7)
-    const int u = br * 4;
-    float* hA1 = br ? haA1 : hbA1; float* hA2 = br ? haA2 : hbA2;
-    const int b0 = bn_head[br * 2], b1 = bn_head[br * 2 + 1];
-    const int c0 = br ? n_box_e : 0, n = br ? n_angle_e : n_box_e;
-    const Operand Hh = op1(seg_act(hA2, W, 0, W, b1, 0, tr), O);
-    Operand Gm = op1(seg_ident(dmu, E, c0, n, 0), O);
-    Operand Gv = op1(seg_ident(dlv, E, c0, n, 0), O);
-    RET_IF(linear_wgrad(Gm, Hh, u + 2, O, st));
-    RET_IF(linear_wgrad(Gv, Hh, u + 3, O, st));
-    RET_IF(linear_dgrad(Gm, u + 2, tmp_d, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
-    RET_IF(linear_dgrad(Gv, u + 3, g_h2, W, O, hA2, W, b1, true, tmp_d, W, tr, st));
-    Operand G2 = op1(seg_bwd(g_h2, W, hA2, W, W, b1, tr), O);
-    RET_IF(linear_wgrad(G2, op1(seg_act(hA1, H, 0, H, b0, 0, tr), O), u + 1, O, st));
-    RET_IF(linear_dgrad(G2, u + 1, g_h1, H, O, hA1, H, b0, true, nullptr, 0, tr, st));
-    Operand G1 = op1(seg_bwd(g_h1, H, hA1, H, H, b0, tr), O);
-    RET_IF(linear_wgrad(G1, XL, u + 0, O, st));
-    RET_IF(linear_dgrad(G1, u + 0, d_x[br], W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
-    RET_IF(join_side(st));    // tmp_d / g_h2 / g_h1 are reused by the angle branch
+  // 0: box branch (units 0..3), 1: angle branch (units 4..7); the branches are independent and identical in shape, so every
+  // stage issues both of them as one grouped launch (each branch has its own temporaries)
+  float* hA1v[2] = {hbA1, haA1}; float* hA2v[2] = {hbA2, haA2};
+  float* tmpv[2] = {tmp_d, tmp_db}; float* gh2v[2] = {g_h2, g_h2b}; float* gh1v[2] = {g_h1, g_h1b};
+  const int c0v[2] = {0, n_box_e}, nv[2] = {n_box_e, n_angle_e};
+  begin_group();
+  for (int br = 0; br < 2; ++br) {
+    const Operand Hh = op1(seg_act(hA2v[br], W, 0, W, bn_head[br * 2 + 1], 0, tr), O);
+    Operand Gm = op1(seg_ident(dmu, E, c0v[br], nv[br], 0), O);
+    RET_IF(linear_wgrad(Gm, Hh, br * 4 + 2, O, st));
+    RET_IF(linear_dgrad(Gm, br * 4 + 2, tmpv[br], W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
   }
+  RET_IF(end_group(st));
+  begin_group();
+  for (int br = 0; br < 2; ++br) {
+    const int b1 = bn_head[br * 2 + 1];
+    const Operand Hh = op1(seg_act(hA2v[br], W, 0, W, b1, 0, tr), O);
+    Operand Gv = op1(seg_ident(dlv, E, c0v[br], nv[br], 0), O);
+    RET_IF(linear_wgrad(Gv, Hh, br * 4 + 3, O, st));
+    RET_IF(linear_dgrad(Gv, br * 4 + 3, gh2v[br], W, O, hA2v[br], W, b1, true, tmpv[br], W, tr, st));
+  }
+  RET_IF(end_group(st));
+  begin_group();
+  for (int br = 0; br < 2; ++br) {
+    const int b0 = bn_head[br * 2], b1 = bn_head[br * 2 + 1];
+    Operand G2 = op1(seg_bwd(gh2v[br], W, hA2v[br], W, W, b1, tr), O);
+    RET_IF(linear_wgrad(G2, op1(seg_act(hA1v[br], H, 0, H, b0, 0, tr), O), br * 4 + 1, O, st));
+    RET_IF(linear_dgrad(G2, br * 4 + 1, gh1v[br], H, O, hA1v[br], H, b0, true, nullptr, 0, tr, st));
+  }
+  RET_IF(end_group(st));
+  begin_group();
+  for (int br = 0; br < 2; ++br) {
+    const int b0 = bn_head[br * 2];
+    Operand G1 = op1(seg_bwd(gh1v[br], H, hA1v[br], H, H, b0, tr), O);
+    RET_IF(linear_wgrad(G1, XL, br * 4 + 0, O, st));
+    RET_IF(linear_dgrad(G1, br * 4 + 0, d_x[br], W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  }
+  RET_IF(end_group(st));
+  RET_IF(join_side(st));
   {
     BnView v = view(ll.bn[3], 0, tr);
     RET_IF(sln_launch_mask_gstats(d_xb, W, d_xa, W, ll.A4, W, v, O, W, g4, W,
@@ -675,6 +743,8 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     const char* ns = std::getenv("SLN_NO_SIDE_STREAM");
     const char* nd = std::getenv("SLN_NO_DUAL");
     h->use_dual = !(nd && nd[0] == '1');
+    const char* ng = std::getenv("SLN_NO_GROUP");
+    h->use_group = h->use_dual && !(ng && ng[0] == '1');
     h->use_side = !h->use_dual && !(ns && ns[0] == '1');
     if (h->use_side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->use_side = false; }
   }
