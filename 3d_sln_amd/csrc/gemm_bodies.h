@@ -12,6 +12,7 @@ namespace {
 
 
 constexpr int BK = 32;
+constexpr int TN_PAD = 32;     // LDS row padding of the TN (wgrad) tiles, see gemm_tn_body
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -340,7 +341,9 @@ __device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
 template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
 __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, const int by, char* smem) {
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int SA = BM + 4, SB = BN + 4;
+  // row stride = 32 (mod 64) floats: the two k rows a wavefront reads per ds_read (lanes 0-31 / 32-63) then fall into
+  // disjoint bank halves; with +4 they overlapped on 28 banks (2-way conflict on every fragment read)
+  constexpr int SA = BM + TN_PAD, SB = BN + TN_PAD;
   constexpr int TPRA = BM / 4, TPRB = BN / 4;         // threads per row
   constexpr int RPA = 256 / TPRA, RPB = 256 / TPRB;   // rows per pass
   constexpr int PA = BK / RPA, PB = BK / RPB;
@@ -527,7 +530,7 @@ inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
   return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
 }
 
-inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + 4 + BN + 4) * 4; }
+inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + TN_PAD + BN + TN_PAD) * 4; }
 
 inline int nt_heuristic_tile(const GemmNTArgs& a) {   // enough blocks to cover 256 CUs, otherwise the biggest tile
   const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);

@@ -82,7 +82,7 @@ int launch_dual(const GemmNTArgs& a, const GemmTNArgs& b, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN, bool G_X2>
 int launch_tn(const GemmTNArgs& a, hipStream_t st) {
-  const size_t smem = (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + 4 + BN + 4) * 4;
+  const size_t smem = tn_smem_bytes(BM, BN);
   const int gx = sln_cdiv(a.Nout, BM) * sln_cdiv(a.Kin, BN);
   const int gy = sln_cdiv(a.R, a.rows_per_block);
   if (gx <= 0 || gy <= 0) return 0;
