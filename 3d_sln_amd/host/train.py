@@ -62,6 +62,11 @@ def build_parser():
     p.add_argument('--train_3d', default=True, type=bool_flag)
     p.add_argument('--KL_linear_decay', default=False, type=bool_flag)
     p.add_argument('--manual_seed', default=42, type=int)
+    p.add_argument('--suncg_train_dir', default=None,
+                   help="data_rot_train.json (options.py:19); when given, batches come from the device scene-graph builder "
+                        "(host/suncg_dataset.py) instead of the synthetic generator")
+    p.add_argument('--metadata_dir', default='metadata', help="valid_types.json / size_info_many.json / 30_size_info_many.json")
+    p.add_argument('--use_attr_30', default=True, type=bool_flag)
     p.add_argument('--objs_per_graph', default=32, type=int)
     p.add_argument('--triples_per_graph', default=64, type=int)
     return p
@@ -91,7 +96,7 @@ def kl_weight_at(args, t):
     return 10 ** (t // 1e5 - 6) if args.KL_linear_decay else args.KL_loss_weight        # train.py:73-76
 
 
-def train(args, model, batch_fn, rank=0, world=1, log=print):
+def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
     """train.py:56-114.  ``model`` exposes train_step(..., with_adam=False) / adam_step / flat_params / flat_grads
     (Sg2ScVAEModel on the GPU; tests plug a CPU stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs."""
     reduce_grads = FlatGradAllReduce(world)
@@ -113,10 +118,10 @@ def train(args, model, batch_fn, rank=0, world=1, log=print):
         w = kl_weight_at(args, t)
         if world == 1:
             losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
-                                      lr=args.learning_rate, with_adam=True)
+                                      lr=args.learning_rate, with_adam=True, use_graph=use_graph)
         else:
             losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
-                                      lr=args.learning_rate, with_adam=False)
+                                      lr=args.learning_rate, with_adam=False, use_graph=use_graph)
             reduce_grads(model.flat_grads)
             model.adam_step(lr=args.learning_rate)
         if t % args.print_every == 0 or t == args.num_iterations:
@@ -138,6 +143,7 @@ def train(args, model, batch_fn, rank=0, world=1, log=print):
 
 
 def main(argv=None):
+    import importlib
     args = build_parser().parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -146,20 +152,33 @@ def main(argv=None):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    import importlib
     M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
-    model = M.Sg2ScVAEModel(vocab=synthetic.default_vocab(), batch_size=args.batch_size, train_3d=args.train_3d,
+    dataset = None
+    if args.suncg_train_dir:
+        suncg_dataset = importlib.import_module("3d_sln_amd.host.suncg_dataset")
+        dataset = suncg_dataset.SuncgDataset(args.suncg_train_dir, args.train_3d, use_attr_30=args.use_attr_30,
+                                             metadata_dir=args.metadata_dir)
+        if rank == 0:
+            print('Training dataset has %d scenes and %d objects' % (len(dataset), dataset.total_objects()))
+    model = M.Sg2ScVAEModel(vocab=dataset.vocab if dataset is not None else synthetic.default_vocab(), batch_size=args.batch_size,
+                            train_3d=args.train_3d,
                             decoder_cat=args.decoder_cat, embedding_dim=args.embedding_dim, gconv_mode=args.gconv_mode,
                             gconv_num_layers=args.gconv_num_layers, mlp_normalization=args.mlp_normalization,
                             vec_noise_dim=args.vec_noise_dim, layout_noise_dim=args.layout_noise_dim,
                             use_AE=args.use_AE).cuda().train()
 
     def batch_fn(t, lo, hi):
+        if dataset is not None:                                  # shuffled rooms, built on the device (DataLoader + collate of train.py:17-22)
+            g = torch.Generator().manual_seed(args.manual_seed + t)
+            idx = torch.randint(0, len(dataset), (args.batch_size,), generator=g)[lo:hi]        # the same draw on every rank
+            _, objs, boxes, triples, angles, attrs, _, _ = dataset.build_batch(idx)
+            return dict(objs=objs, triples=triples, boxes=boxes, angles=angles, attributes=attrs)
         return synthetic.scene_graph_batch(hi - lo, args.objs_per_graph, args.triples_per_graph, seed=t * 100003 + lo,
                                            box_dim=6 if args.train_3d else 4, device="cuda")
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
-        train(args, model, batch_fn, rank, world)
+        # real rooms differ in size from batch to batch: eager launches (a hipGraph is tied to one (O, T) pair)
+        train(args, model, batch_fn, rank, world, use_graph=dataset is None)
     torch.cuda.synchronize()
     if world > 1:
         dist.destroy_process_group()

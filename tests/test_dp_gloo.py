@@ -47,7 +47,7 @@ class CpuStandIn:
     def state_dict(self):
         return self.sd
 
-    def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, with_adam=True, eps=None):
+    def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, with_adam=True, eps=None, use_graph=True):
         for k in self.keys:
             self.sd[k].requires_grad_(True); self.sd[k].grad = None
         eps = torch.zeros(objs.shape[0], self.cfg.embedding_dim)
