@@ -355,3 +355,31 @@ def test_standalone_graph_triple_conv_net(norm, mode, layers):
             sd = sdr                       # carry the updated running statistics into the eval comparison
     with pytest.raises(NotImplementedError):
         net(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
+
+
+def test_high_degree_room_node_beyond_the_lds_entry_cache():
+    """One graph with 150 objects: the room node is incident to >= 149 triples, past the 64-entry LDS cache of the CSR
+    edge kernels (vae_kernels.hip: ECACHE), so the tail of its entry list is read from global memory."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    sd = vae_ref.init_state(cfg, seed=5)
+    parts = [vae_ref.synth_batch(1, 150, 420, seed=3, cfg=cfg), vae_ref.synth_batch(1, 9, 14, seed=4, cfg=cfg)]
+    off = parts[0][0].shape[0]
+    tr1 = parts[1][1].clone(); tr1[:, 0] += off; tr1[:, 2] += off
+    batch = (torch.cat([parts[0][0], parts[1][0]]), torch.cat([parts[0][1], tr1]), torch.cat([parts[0][2], parts[1][2]]),
+             torch.cat([parts[0][3], parts[1][3]]), torch.cat([parts[0][4], parts[1][4]]))
+    deg = torch.bincount(torch.cat([batch[1][:, 0], batch[1][:, 2]]))
+    assert int(deg.max()) > 128
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(2).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    sdg = {k: v.clone() for k, v in sd.items()}
+    m = {k: torch.zeros_like(sdg[k]) for k in vae_ref.trainable_keys(cfg)}
+    v = {k: torch.zeros_like(sdg[k]) for k in vae_ref.trainable_keys(cfg)}
+    total, parts_l, grads = vae_ref.train_step(sdg, cfg, batch, eps, 0.1, m, v, step=1)
+    model = _model(cfg, sd).train()
+    dev = _dev(*batch, eps)
+    losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=False).cpu().numpy()
+    assert_close(losses[3], total.detach().numpy(), "total loss", rtol=1e-4)
+    named = dict(model.named_parameters())
+    gscale = max(float(g.abs().max()) for g in grads.values())
+    for k, g in grads.items():
+        assert_close(named[k].grad.cpu().numpy(), g.numpy(), "grad:" + k, rtol=1e-4, atol=1e-5 * gscale)
