@@ -630,29 +630,54 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   }
 }
 
-// sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c)
-__global__ void scene_bwd_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
-                                       const int32_t* __restrict__ cls, const int32_t* __restrict__ dch, int F, int is, int NC,
-                                       int nch, const float* __restrict__ gout, SceneStats* __restrict__ st) {
-  const int b = blockIdx.z, c = blockIdx.y;
-  if (dch[c] < 0) return;
+// sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c).  One pass over the pixels:
+// a thread reads its pixel's class / mask once and walks the (<= 32) depth-hot channels, adding the channel's gradient
+// unless the pixel lies in the mask of the class that owns the channel (a block per (class, pixel range) re-read the
+// per-pixel inputs once per class).
+__global__ __launch_bounds__(256) void scene_bwd_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                              const int32_t* __restrict__ cls, const int32_t* __restrict__ dch, int F,
+                                                              int is, int NC, int nch, const float* __restrict__ gout,
+                                                              SceneStats* __restrict__ st) {
+  constexpr int MAXK = 32;
+  __shared__ int s_owner[MAXK];
+  __shared__ float s_red[4][MAXK];
+  const int b = blockIdx.y;
+  const int ndch = min(nch - 41, MAXK);
+  if (threadIdx.x < MAXK) {
+    int owner = -1;
+    for (int c = 0; c < NC; ++c) if (dch[c] == (int)threadIdx.x) { owner = c; break; }
+    s_owner[threadIdx.x] = owner;
+  }
+  __syncthreads();
   const long plane = (long)is * is;
-  float acc = 0.f;
+  float acc[MAXK];
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
     const long q = b * plane + p;
     const int f = fi_b[q];
     const int cc = f >= 0 ? cls[(long)b * F + f] : -1;
-    const bool m = (cc == c) && class_image_value(val[3 * q]) > 0.1f;
-    if (!m) {
-      const int y = (int)(p / is), x = (int)(p % is);
-      acc += gout[(((long)b * nch + 41 + dch[c]) * is + (is - 1 - y)) * is + x];
-    }
+    const bool m = cc >= 0 && cc < NC && class_image_value(val[3 * q]) > 0.1f;
+    const int mydch = m ? dch[cc] : -1;
+    const int y = (int)(p / is), x = (int)(p % is);
+    const float* gp = gout + (((long)b * nch + 41) * is + (is - 1 - y)) * is + x;
+#pragma unroll
+    for (int k = 0; k < MAXK; ++k)
+      if (k < ndch) { const float gk = gp[(long)k * plane]; acc[k] += (k == mydch) ? 0.f : gk; }
   }
-  __shared__ float red[256];
-  red[threadIdx.x] = acc;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < MAXK; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) s_red[wave][k] = v;
+  }
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-  if (threadIdx.x == 0) atomicAdd(&st[b].gsum[c], (double)red[0]);
+  if (threadIdx.x < ndch && s_owner[threadIdx.x] >= 0) {
+    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+    atomicAdd(&st[b].gsum[s_owner[threadIdx.x]], (double)v);
+  }
 }
 
 // per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
@@ -807,7 +832,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
   hipError_t e = hipMemsetAsync(grad_faces, 0, sizeof(float) * 9 * n, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(scene_bwd_stats_kernel, dim3(16, num_classes, B), dim3(256), 0, st, w.fiB, w.val, face_class,
+  hipLaunchKernelGGL(scene_bwd_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, face_class,
                      class_depth_channel, F, is, num_classes, 70, grad_final, w.st);
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
