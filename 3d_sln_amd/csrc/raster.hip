@@ -357,9 +357,19 @@ __device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2)
 // once; each unit adds its two partial sums to the face gradient with two atomics.
 constexpr int PMB_DC = 64;
 
+// Inside a unit the serial form of the edge walk (for each d0: load the face index under the edge, then scan) is a
+// chain of three dependent memory round trips per edge step.  Here the walk is flattened:
+//   phase 1 - lane l owns edge step d0 = c_from + l: crossing, reference pixels, the face index under the edge and
+//             the two scan ranges, all 64 steps in ONE round trip; parameters + an exclusive prefix of the scan
+//             lengths go to LDS;
+//   phase 2 - the lanes stride over the concatenated scan pixels of all steps (binary search of the prefix), every
+//             iteration is independent of the others, so their loads overlap.
 template <typename PIX>
 __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int F, int is,
                                                                 float eps, float* __restrict__ gfaces) {
+  __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
+  __shared__ int s_ofrom[PMB_DC], s_lo[PMB_DC], s_ifrom[PMB_DC];
+  __shared__ float s_cross[PMB_DC], s_r0[PMB_DC], s_r1[PMB_DC];
   const long i = blockIdx.x;                       // face
   const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
   const int e = blockIdx.y >> 1, axis = blockIdx.y & 1;
@@ -386,53 +396,78 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
   const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
   const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
-  const int c_from = d0_from + (int)blockIdx.z * PMB_DC;
-  const int c_to = min(d0_to, c_from + PMB_DC - 1);
-  if (c_from > c_to) return;
   float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
-  for (int d0 = c_from; d0 <= c_to; ++d0) {
-    const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+  // an edge longer than PMB_DC steps takes several rounds (chunks) in the same wavefront: one workgroup per chunk filled the
+  // grid with empty workgroups (three out of four), whose dispatch alone cost ~0.25 ms per batch
+  for (int c_from = d0_from; c_from <= d0_to; c_from += PMB_DC) {
+  const int c_to = min(d0_to, c_from + PMB_DC - 1);
+  __syncthreads();                              // the LDS tables of the previous round are no longer read
+
+  // ---- phase 1: one edge step per lane ----
+  const int d0 = c_from + lane;
+  int lo = 0, li = 0, ofrom = 0, ifrom = 0;
+  float d1_cross = 0.f, r0 = 0.f, r1 = 0.f;
+  if (d0 <= c_to) {
+    d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
     const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
     const int d1_out = d1_in + dir;
-    if (d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out) continue;
-    const long idx_in = V.idx(base, d0, d1_in), idx_out = V.idx(base, d0, d1_out);
-    const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
-    const float r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;
-    const float r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-    auto add = [&](int d1, float diff) {
-      if (use0) {
-        float dist = pix_scale(r0 * (d1 - d1_cross), is, pow2, s2);
-        dist = 0 < dist ? dist + eps : dist - eps;
-        acc0 -= diff / dist;
+    if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
+      const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
+      r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;         // 0 marks "slot not used" (a used ratio is never 0)
+      r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
+      if (V.fi[V.idx(base, d0, d1_in)] == fn) {                        // outward scan to the image border
+        const int lim = dir > 0 ? is - 1 : 0;
+        const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
+        ofrom = from; lo = max(to - from + 1, 0);
       }
-      if (use1) {
-        float dist = pix_scale(r1 * (d1 - d1_cross), is, pow2, s2);
-        dist = 0 < dist ? dist + eps : dist - eps;
-        acc1 -= diff / dist;
-      }
-    };
-    if (V.fi[idx_in] == fn) {                   // outward scan to the image border
-      const int lim = dir > 0 ? is - 1 : 0;
-      const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
-      for (int d1 = from + lane; d1 <= to; d1 += 64) {
-        const float diff = V.contrib(V.idx(base, d0, d1), idx_in, b);
-        if (diff > 0.f) add(d1, diff);
-      }
-    }
-    {                                           // inward scan to the opposite edge, this face's pixels only
-      float cross2;
+      float cross2;                                                    // inward scan to the opposite edge
       if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
       else cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
       const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
       const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
-      for (int d1 = from + lane; d1 <= to; d1 += 64) {
-        const long q = V.idx(base, d0, d1);
-        if (V.fi[q] != fn) continue;
-        const float diff = V.contrib(q, idx_out, b);
-        if (diff > 0.f) add(d1, diff);
+      ifrom = from; li = max(to - from + 1, 0);
+    }
+  }
+  int incl = lo + li;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+  s_pre[lane + 1] = incl;
+  if (lane == 0) s_pre[0] = 0;
+  s_ofrom[lane] = ofrom; s_lo[lane] = lo; s_ifrom[lane] = ifrom;
+  s_cross[lane] = d1_cross; s_r0[lane] = r0; s_r1[lane] = r1;
+  __syncthreads();
+  const int W = s_pre[64];
+
+  // ---- phase 2: the scan pixels of all steps, flattened ----
+  for (int w = lane; w < W; w += 64) {
+    int l = 0;                                   // largest l with s_pre[l] <= w
+#pragma unroll
+    for (int step = 32; step > 0; step >>= 1) if (s_pre[l + step] <= w) l += step;
+    const int t = w - s_pre[l];
+    const int step_d0 = c_from + l;
+    const float cr = s_cross[l];
+    const int d1_in = dir > 0 ? (int)floorf(cr) : (int)ceilf(cr);
+    const bool outward = t < s_lo[l];
+    const int d1 = outward ? s_ofrom[l] + t : s_ifrom[l] + (t - s_lo[l]);
+    const long q = V.idx(base, step_d0, d1);
+    const long ref = V.idx(base, step_d0, outward ? d1_in : d1_in + dir);
+    if (!outward && V.fi[q] != fn) continue;     // inward: this face's pixels only
+    const float diff = V.contrib(q, ref, b);
+    if (diff > 0.f) {
+      const float q0 = s_r0[l], q1 = s_r1[l];
+      if (q0 != 0.f) {
+        float dist = pix_scale(q0 * (d1 - cr), is, pow2, s2);
+        dist = 0 < dist ? dist + eps : dist - eps;
+        acc0 -= diff / dist;
+      }
+      if (q1 != 0.f) {
+        float dist = pix_scale(q1 * (d1 - cr), is, pow2, s2);
+        dist = 0 < dist ? dist + eps : dist - eps;
+        acc1 -= diff / dist;
       }
     }
   }
+  }   // rounds
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { acc0 += __shfl_xor(acc0, off, 64); acc1 += __shfl_xor(acc1, off, 64); }
   if (lane == 0) {
@@ -515,7 +550,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6, sln_cdiv(image_size, PMB_DC)), dim3(64), 0, st, faces, pix, F, image_size, eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, image_size, eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -843,7 +878,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
                      num_classes, 70, w.g, w.gT);
   PixClass pix{w.fiB, w.fiT, w.cp, w.cpT, w.v, w.vT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6, sln_cdiv(is, PMB_DC)), dim3(64), 0, st, faces, pix, F, is, pix_eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, is, pix_eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
