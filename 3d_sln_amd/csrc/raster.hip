@@ -300,7 +300,9 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
 struct PixDenseView {
   const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;
   __device__ __forceinline__ long idx(long base, int d0, int d1) const { return axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1; }
-  __device__ __forceinline__ float contrib(long q, long ref, int) const {
+  __device__ __forceinline__ int face_at(long q) const { return fi[q]; }
+  __device__ __forceinline__ float contrib(long q, long ref, int, int& fq) const {
+    fq = fi[q];
     float diff = 0.f;
     for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref * C + k]) * grad[q * C + k];
     return diff > 0.f ? diff : 0.f;
@@ -316,16 +318,23 @@ struct PixDense {            // C-channel image: one positive-part test over the
 // image; every pass applies its own positive-part test (at most two classes contribute per pixel pair).
 // Vertical scans (axis 0) read TRANSPOSED copies of the per-pixel maps and of the class-gradient planes so that
 // the 64 lanes of a scan touch consecutive addresses (the strided version fetched 5.8 GB per 16 rooms).
+// One 16-byte record per pixel = everything a scan needs about that pixel: winning face, its class, the class-image value
+// and the incoming gradient of the pixel's OWN class plane.  A scan step is then one 16-byte load per lane (four separate
+// 4-byte streams before); only when the reference pixel's class differs is the gradient plane of that class read as well.
+struct PixRec { int fi; int cp; float v; float gown; };
 struct PixClassView {
-  const int32_t* fi; const int32_t* cp; const float* v; const float* g; int is, NC; long plane;
+  const PixRec* rec; const float* g; int is, NC; long plane;
   __device__ __forceinline__ long idx(long base, int d0, int d1) const { return base + (long)d0 * is + d1; }
-  __device__ __forceinline__ float contrib(long q, long ref, int b) const {
-    const int cq = cp[q], cr = cp[ref];
-    const float vq = cq >= 0 ? v[q] : 0.f, vr = cr >= 0 ? v[ref] : 0.f;
+  __device__ __forceinline__ int face_at(long q) const { return rec[q].fi; }
+  __device__ __forceinline__ float contrib(long q, long ref, int b, int& fq) const {
+    const PixRec rq = rec[q], rr = rec[ref];
+    fq = rq.fi;
+    const int cq = rq.cp, cr = rr.cp;
+    const float vq = cq >= 0 ? rq.v : 0.f, vr = cr >= 0 ? rr.v : 0.f;
     const long pq = q - (long)b * plane;
     float tot = 0.f;
     if (cq >= 0) {
-      const float g3 = g[((long)b * NC + cq) * plane + pq];
+      const float g3 = rq.gown;
       const float dv = vq - (cr == cq ? vr : 0.f);
       float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
       if (diff > 0.f) tot += diff;
@@ -340,9 +349,9 @@ struct PixClassView {
   }
 };
 struct PixClass {
-  const int32_t *fi, *fiT, *cp, *cpT; const float *v, *vT, *g, *gT; int is, NC;
+  const PixRec *rec, *recT; const float *g, *gT; int is, NC;
   __device__ __forceinline__ PixClassView view(int axis) const {
-    return axis == 0 ? PixClassView{fiT, cpT, vT, gT, is, NC, (long)is * is} : PixClassView{fi, cp, v, g, is, NC, (long)is * is};
+    return axis == 0 ? PixClassView{recT, gT, is, NC, (long)is * is} : PixClassView{rec, g, is, NC, (long)is * is};
   }
 };
 
@@ -415,7 +424,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
       r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;         // 0 marks "slot not used" (a used ratio is never 0)
       r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-      if (V.fi[V.idx(base, d0, d1_in)] == fn) {                        // outward scan to the image border
+      if (V.face_at(V.idx(base, d0, d1_in)) == fn) {                   // outward scan to the image border
         const int lim = dir > 0 ? is - 1 : 0;
         const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
         ofrom = from; lo = max(to - from + 1, 0);
@@ -451,8 +460,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
     const int d1 = outward ? s_ofrom[l] + t : s_ifrom[l] + (t - s_lo[l]);
     const long q = V.idx(base, step_d0, d1);
     const long ref = V.idx(base, step_d0, outward ? d1_in : d1_in + dir);
-    if (!outward && V.fi[q] != fn) continue;     // inward: this face's pixels only
-    const float diff = V.contrib(q, ref, b);
+    int fq;
+    const float diff = V.contrib(q, ref, b, fq);
+    if (!outward && fq != fn) continue;          // inward: this face's pixels only
     if (diff > 0.f) {
       const float q0 = s_r0[l], q1 = s_r1[l];
       if (q0 != 0.f) {
@@ -717,32 +727,32 @@ __global__ __launch_bounds__(256) void scene_bwd_stats_kernel(const int32_t* __r
 
 // per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
 __global__ __launch_bounds__(256) void scene_bwd_maps_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
-                                                             const int32_t* __restrict__ cls, int F, int is, int NC,
-                                                             int32_t* __restrict__ cp, int32_t* __restrict__ cpT,
-                                                             float* __restrict__ v, float* __restrict__ vT, int32_t* __restrict__ fiT) {
-  __shared__ int tc[32][33]; __shared__ float tv[32][33]; __shared__ int tf[32][33];
+                                                             const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
+                                                             const float* __restrict__ gout, int F, int is, int NC, int nch,
+                                                             PixRec* __restrict__ rec, PixRec* __restrict__ recT) {
+  __shared__ PixRec tile[32][33];
   const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   const long plane = (long)is * is;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8) {
     const int y = y0 + r, x = x0 + tx;
-    int c = -1, f = -1; float vv = 0.f;
+    PixRec pr; pr.fi = -1; pr.cp = -1; pr.v = 0.f; pr.gown = 0.f;
     if (y < is && x < is) {
       const long q = b * plane + (long)y * is + x;
-      f = fi_b[q];
-      if (f >= 0) { c = cls[(long)b * F + f]; if (c >= NC) c = -1; }
-      vv = c >= 0 ? val[3 * q] : 0.f;
-      cp[q] = c; v[q] = vv;
+      pr.fi = fi_b[q];
+      if (pr.fi >= 0) { pr.cp = cls[(long)b * F + pr.fi]; if (pr.cp >= NC) pr.cp = -1; }
+      if (pr.cp >= 0) {
+        pr.v = val[3 * q];
+        pr.gown = gout[(((long)b * nch + 1 + chan[pr.cp]) * is + (is - 1 - y)) * is + x] / 3.0f;     // == g[b, cp, y, x]
+      }
+      rec[q] = pr;
     }
-    tc[r][tx] = c; tv[r][tx] = vv; tf[r][tx] = f;
+    tile[r][tx] = pr;
   }
   __syncthreads();
   for (int r = ty; r < 32; r += 8) {
     const int x = x0 + r, y = y0 + tx;
-    if (x < is && y < is) {
-      const long qt = b * plane + (long)x * is + y;
-      cpT[qt] = tc[tx][r]; vT[qt] = tv[tx][r]; fiT[qt] = tf[tx][r];
-    }
+    if (x < is && y < is) recT[b * plane + (long)x * is + y] = tile[tx][r];
   }
 }
 
@@ -801,13 +811,13 @@ extern "C" {
 
 int64_t sln_scene_workspace_bytes(int B, int F, int image_size) {
   const int64_t plane = (int64_t)image_size * image_size;
-  // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture | cp cpT v vT fiT | g gT (64 class planes max)
+  // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture | pixel records + transpose | g gT (64 class planes max)
   return (int64_t)sizeof(FaceRec) * B * F + sizeof(SceneStats) * B + B * plane * (4 + 12 + 4) * 2 + B * plane * 12 + B * plane * 4 +
-         (int64_t)B * F * 24 * 4 + B * plane * 4 * 5 + (int64_t)B * 64 * plane * 4 * 2 + 8192;
+         (int64_t)B * F * 24 * 4 + B * plane * 16 * 2 + (int64_t)B * 64 * plane * 4 * 2 + 8192;
 }
 
 struct SceneWs { FaceRec* rec; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones;
-                 int32_t *cp, *cpT, *fiT; float *v, *vT, *g, *gT; };
+                 PixRec *prec, *precT; float *g, *gT; };
 
 static SceneWs carve_scene(void* ws, int B, int F, int is) {
   char* p = static_cast<char*>(ws);
@@ -818,8 +828,7 @@ static SceneWs carve_scene(void* ws, int B, int F, int is) {
   w.fiA = (int32_t*)take(4 * B * plane); w.wA = (float*)take(12 * B * plane); w.dA = (float*)take(4 * B * plane);
   w.fiB = (int32_t*)take(4 * B * plane); w.wB = (float*)take(12 * B * plane); w.dB = (float*)take(4 * B * plane);
   w.val = (float*)take(12 * B * plane); w.gd = (float*)take(4 * B * plane); w.ones = (float*)take((size_t)B * F * 24 * 4);
-  w.cp = (int32_t*)take(4 * B * plane); w.cpT = (int32_t*)take(4 * B * plane); w.fiT = (int32_t*)take(4 * B * plane);
-  w.v = (float*)take(4 * B * plane); w.vT = (float*)take(4 * B * plane);
+  w.prec = (PixRec*)take(16 * B * plane); w.precT = (PixRec*)take(16 * B * plane);
   w.g = (float*)take((size_t)4 * B * 64 * plane); w.gT = (float*)take((size_t)4 * B * 64 * plane);
   return w;
 }
@@ -873,11 +882,11 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
   const int t32 = sln_cdiv(is, 32);
-  hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, F, is, num_classes, w.cp,
-                     w.cpT, w.v, w.vT, w.fiT);
+  hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
+                     num_classes, 70, w.prec, w.precT);
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
                      num_classes, 70, w.g, w.gT);
-  PixClass pix{w.fiB, w.fiT, w.cp, w.cpT, w.v, w.vT, w.g, w.gT, is, num_classes};
+  PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, is, pix_eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
