@@ -32,6 +32,10 @@ struct FaceRec {                // per-face set-up, 24 floats
   int pad_[2];
 };
 
+// the bounding boxes once more as a compact array: every tile scans ALL faces of its image, and reading 16 bytes out of each
+// 96-byte FaceRec touched twelve times the cache lines an 8-byte stream needs
+struct BBox8 { unsigned short x0, x1, y0, y1; };
+
 __device__ __forceinline__ bool backfacing(const float* f) {
   return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]);
 }
@@ -50,7 +54,7 @@ __device__ __forceinline__ void face_inverse(const float* f, int is, float* inv)
   for (int k = 0; k < 9; ++k) inv[k] = m[k] / den;
 }
 
-__global__ void raster_prep_kernel(const float* __restrict__ faces, long n, int is, FaceRec* __restrict__ rec) {
+__global__ void raster_prep_kernel(const float* __restrict__ faces, long n, int is, FaceRec* __restrict__ rec, BBox8* __restrict__ bbox) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   FaceRec r;
@@ -75,6 +79,8 @@ __global__ void raster_prep_kernel(const float* __restrict__ faces, long n, int 
     r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
   }
   rec[i] = r;
+  BBox8 bb; bb.x0 = (unsigned short)r.x0; bb.x1 = (unsigned short)r.x1; bb.y0 = (unsigned short)r.y0; bb.y1 = (unsigned short)r.y1;
+  bbox[i] = bb;
 }
 
 struct ZState { float z; int idx; float w0, w1, w2; };
@@ -82,7 +88,7 @@ struct ZState { float z; int idx; float w0, w1, w2; };
 // DUAL: track a second z-buffer with its own near plane (the reference's depth pass runs with the package
 // default near=0.1 while its class passes use the constructor's near, SURVEY.md 2.1 "known asymmetry").
 template <bool DUAL>
-__global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ rec, int F, int is, float near_a,
+__global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ rec, const BBox8* __restrict__ bbox, int F, int is, float near_a,
                                                           float near_b, float far, int32_t* __restrict__ fi_a,
                                                           float* __restrict__ w_a, float* __restrict__ d_a,
                                                           int32_t* __restrict__ fi_b, float* __restrict__ w_b,
@@ -98,7 +104,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
   const float yp = (float)((2. * yi + 1 - is) / is), xp = (float)((2. * xi + 1 - is) / is);
   const float fxi = (float)xi, fyi = (float)yi;
   const int tx0 = tx * TS, tx1 = tx0 + TS - 1, ty0 = ty * TS, ty1 = ty0 + TS - 1;
+  // NDC coordinates of the tile's corner pixel centres (same formula as xp / yp)
+  const float cx_lo = (float)((2. * tx0 + 1 - is) / is), cx_hi = (float)((2. * min(tx1, is - 1) + 1 - is) / is);
+  const float cy_lo = (float)((2. * ty0 + 1 - is) / is), cy_hi = (float)((2. * min(ty1, is - 1) + 1 - is) / is);
   const FaceRec* rb = rec + (size_t)b * F;
+  const BBox8* bb = bbox + (size_t)b * F;
 
   ZState A = {far, -1, 0.f, 0.f, 0.f}, Bz = {far, -1, 0.f, 0.f, 0.f};
 
@@ -106,8 +116,23 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     const int fn = c0 + tid;
     bool hit = false;
     if (fn < F) {
-      const int bx0 = rb[fn].x0, bx1 = rb[fn].x1, by0 = rb[fn].y0, by1 = rb[fn].y1;
+      const BBox8 q = bb[fn];
+      const int bx0 = q.x0, bx1 = q.x1, by0 = q.y0, by1 = q.y1;
       hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
+      if (hit) {
+        // the bounding box of a triangle is twice its area: drop the face when the whole tile lies outside one of its
+        // edges (the edge function is linear, so its maximum over the tile is at a corner).  The margin keeps the cull
+        // conservative against the rounding of the per-pixel test below, which stays the only exact decision.
+        const float* f = rb[fn].f;
+        const float ax[3] = {f[0], f[3], f[6]}, ay[3] = {f[1], f[4], f[7]};
+#pragma unroll
+        for (int e3 = 0; e3 < 3; ++e3) {
+          const float x0 = ax[e3], y0 = ay[e3], dx = ax[(e3 + 1) % 3] - x0, dy = ay[(e3 + 1) % 3] - y0;
+          const float e00 = (cy_lo - y0) * dx - (cx_lo - x0) * dy, e01 = (cy_lo - y0) * dx - (cx_hi - x0) * dy;
+          const float e10 = (cy_hi - y0) * dx - (cx_lo - x0) * dy, e11 = (cy_hi - y0) * dx - (cx_hi - x0) * dy;
+          if (fmaxf(fmaxf(e00, e01), fmaxf(e10, e11)) < -1e-4f) hit = false;
+        }
+      }
     }
     const unsigned long long m = __ballot(hit);
     const int before = __popcll(m & ((1ull << lane) - 1ull));
@@ -493,7 +518,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 // ====================================================================================================
 extern "C" {
 
-int64_t sln_raster_workspace_bytes(int B, int F) { return (int64_t)sizeof(FaceRec) * B * F + 256; }
+int64_t sln_raster_workspace_bytes(int B, int F) { return (int64_t)(sizeof(FaceRec) + sizeof(BBox8)) * B * F + 512; }
 
 int sln_raster_forward(const float* faces, int B, int F, int image_size, float near, float far, void* workspace,
                        int32_t* face_index, float* weight, float* depth, void* stream) {
@@ -501,10 +526,11 @@ int sln_raster_forward(const float* faces, int B, int F, int image_size, float n
   hipStream_t st = (hipStream_t)stream;
   FaceRec* rec = static_cast<FaceRec*>(workspace);
   const long n = (long)B * F;
+  BBox8* bbox = reinterpret_cast<BBox8*>(static_cast<char*>(workspace) + ((sizeof(FaceRec) * (size_t)n + 255) & ~size_t(255)));
   SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 20.0 * B * image_size * image_size, st);
-  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec);
+  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec, bbox);
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
-  hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, F, image_size, near, near, far,
+  hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near, near, far,
                      face_index, weight, depth, nullptr, nullptr, nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -518,10 +544,11 @@ int sln_raster_forward_dual(const float* faces, int B, int F, int image_size, fl
   hipStream_t st = (hipStream_t)stream;
   FaceRec* rec = static_cast<FaceRec*>(workspace);
   const long n = (long)B * F;
+  BBox8* bbox = reinterpret_cast<BBox8*>(static_cast<char*>(workspace) + ((sizeof(FaceRec) * (size_t)n + 255) & ~size_t(255)));
   SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 40.0 * B * image_size * image_size, st);
-  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec);
+  if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec, bbox);
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
-  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, rec, F, image_size, near_a, near_b, far,
+  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near_a, near_b, far,
                      fi_a, w_a, d_a, fi_b, w_b, d_b);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -812,11 +839,11 @@ extern "C" {
 int64_t sln_scene_workspace_bytes(int B, int F, int image_size) {
   const int64_t plane = (int64_t)image_size * image_size;
   // FaceRec | stats | fiA wA dA | fiB wB dB | val(3) | gd | ones texture | pixel records + transpose | g gT (64 class planes max)
-  return (int64_t)sizeof(FaceRec) * B * F + sizeof(SceneStats) * B + B * plane * (4 + 12 + 4) * 2 + B * plane * 12 + B * plane * 4 +
+  return (int64_t)(sizeof(FaceRec) + sizeof(BBox8)) * B * F + sizeof(SceneStats) * B + B * plane * (4 + 12 + 4) * 2 + B * plane * 12 + B * plane * 4 +
          (int64_t)B * F * 24 * 4 + B * plane * 16 * 2 + (int64_t)B * 64 * plane * 4 * 2 + 8192;
 }
 
-struct SceneWs { FaceRec* rec; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones;
+struct SceneWs { FaceRec* rec; BBox8* bbox; SceneStats* st; int32_t *fiA, *fiB; float *wA, *dA, *wB, *dB, *val, *gd, *ones;
                  PixRec *prec, *precT; float *g, *gT; };
 
 static SceneWs carve_scene(void* ws, int B, int F, int is) {
@@ -824,7 +851,7 @@ static SceneWs carve_scene(void* ws, int B, int F, int is) {
   auto take = [&](size_t n) { char* r = p; p += (n + 255) & ~size_t(255); return r; };
   const size_t plane = (size_t)is * is;
   SceneWs w;
-  w.rec = (FaceRec*)take(sizeof(FaceRec) * B * F); w.st = (SceneStats*)take(sizeof(SceneStats) * B);
+  w.rec = (FaceRec*)take(sizeof(FaceRec) * B * F); w.bbox = (BBox8*)take(sizeof(BBox8) * B * F); w.st = (SceneStats*)take(sizeof(SceneStats) * B);
   w.fiA = (int32_t*)take(4 * B * plane); w.wA = (float*)take(12 * B * plane); w.dA = (float*)take(4 * B * plane);
   w.fiB = (int32_t*)take(4 * B * plane); w.wB = (float*)take(12 * B * plane); w.dB = (float*)take(4 * B * plane);
   w.val = (float*)take(12 * B * plane); w.gd = (float*)take(4 * B * plane); w.ones = (float*)take((size_t)B * F * 24 * 4);
@@ -849,10 +876,10 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
   SceneWs w = carve_scene(workspace, B, F, is);
   SlnProfScope prof(SLN_FAM_RASTER, 36.0 * n + 70.0 * 4.0 * npix, st);
   hipLaunchKernelGGL(scene_init_stats_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, st, w.st, B);
-  hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, is, w.rec);
+  hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, is, w.rec, w.bbox);
   hipLaunchKernelGGL(fill_ones_kernel, dim3((unsigned)((n * 24 + 255) / 256)), dim3(256), 0, st, w.ones, n * 24);
   const int tiles = sln_cdiv(is, TS) * sln_cdiv(is, TS);
-  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, F, is, near_depth, near_rgb, far,
+  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
                      w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB);
   hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
                      w.dB, F, is, 2, tex_eps, npix, w.val);
