@@ -404,9 +404,26 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
   __shared__ int s_ofrom[PMB_DC], s_lo[PMB_DC], s_ifrom[PMB_DC];
   __shared__ float s_cross[PMB_DC], s_r0[PMB_DC], s_r1[PMB_DC];
-  const long i = blockIdx.x;                       // face
-  const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
-  const int e = blockIdx.y >> 1, axis = blockIdx.y & 1;
+  // Image -> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the
+  // plain (face, edge) order all XCDs scan the SAME image at a time and each L2 fetches that image's maps for itself (measured:
+  // 1.07 GB from memory per launch for 0.28 GB of maps).  With at least 8 images, XCD x takes the images x, x+8, ...
+  const int lane = threadIdx.x;
+  const int B = (int)(gridDim.x / (unsigned)F);
+  long i; int ea;
+  if (B >= 8) {
+    const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    const int xcd = (int)(lin & 7); const long j = lin >> 3;
+    const long per_img = (long)F * 6;
+    const long img_local = j / per_img, rem = j % per_img;
+    const long img = xcd + 8 * img_local;
+    if (img >= B) return;
+    ea = (int)(rem / F);
+    i = img * F + rem % F;
+  } else {
+    i = blockIdx.x; ea = blockIdx.y;
+  }
+  const int b = (int)(i / F), fn = (int)(i % F);
+  const int e = ea >> 1, axis = ea & 1;
   float face[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
@@ -473,10 +490,13 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int W = s_pre[64];
 
   // ---- phase 2: the scan pixels of all steps, flattened ----
-  for (int w = lane; w < W; w += 64) {
-    int l = 0;                                   // largest l with s_pre[l] <= w
-#pragma unroll
-    for (int step = 32; step > 0; step >>= 1) if (s_pre[l + step] <= w) l += step;
+  int l0 = 0;                                    // row of the previous window's last pixel: rows only move forward
+  for (int w0 = 0; w0 < W; w0 += 64) {
+    const int w = min(w0 + lane, W - 1);
+    int l = l0;                                  // largest l with s_pre[l] <= w: a short walk instead of a 6-step bisection
+    while (s_pre[l + 1] <= w) ++l;
+    l0 = __shfl(l, 63, 64);
+    if (w0 + lane >= W) continue;
     const int t = w - s_pre[l];
     const int step_d0 = c_from + l;
     const float cr = s_cross[l];
