@@ -97,6 +97,9 @@ SIGNATURES = {
     "sln_linear_forward": (C.c_int, [c_f32p, C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p,
                                      C.c_int, C.c_void_p]),
     "sln_linear_wgrad": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_void_p]),
+    "sln_project_faces": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p, C.c_void_p]),
+    "sln_project_faces_backward": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, c_f32p,
+                                             c_f32p, C.c_void_p]),
     "sln_raster_workspace_bytes": (C.c_int64, [C.c_int, C.c_int]),
     "sln_raster_forward": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                      c_f32p, c_f32p, C.c_void_p]),

@@ -531,6 +531,71 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   }
 }
 
+// ----------------------------------------------------------------------------------------------------
+// projection + vertex->face gather (neural_renderer.projection with the reference README's patch - no distortion - followed by
+// vertices_to_faces), forward and backward, one thread per face corner.  In torch this is ~30 small kernels around the
+// rasterizer (a quarter of a fused scene iteration); the arithmetic follows the torch expression order of
+// host/neural_renderer.py::projection.
+// ----------------------------------------------------------------------------------------------------
+struct Cam { float K[9], R[9], t[3]; };
+__device__ __forceinline__ Cam load_cam(const float* K, const float* R, const float* t, int b) {
+  Cam c;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { c.K[k] = K[9 * b + k]; c.R[k] = R[9 * b + k]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) c.t[k] = t[3 * b + k];
+  return c;
+}
+
+__global__ void project_faces_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, const float* __restrict__ K,
+                                     const float* __restrict__ R, const float* __restrict__ t, int V, int F, long n, float os,
+                                     float eps, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;       // (b, f, corner)
+  if (i >= n) return;
+  const int b = (int)(i / (3L * F));
+  int vi = faces[i];
+  vi = min(max(vi, 0), V - 1);
+  const float* p = verts + ((long)b * V + vi) * 3;
+  const Cam c = load_cam(K, R, t, b);
+  const float x = p[0] * c.R[0] + p[1] * c.R[1] + p[2] * c.R[2] + c.t[0];
+  const float y = p[0] * c.R[3] + p[1] * c.R[4] + p[2] * c.R[5] + c.t[1];
+  const float z = p[0] * c.R[6] + p[1] * c.R[7] + p[2] * c.R[8] + c.t[2];
+  const float xh = x / (z + eps), yh = y / (z + eps);
+  float u = xh * c.K[0] + yh * c.K[1] + c.K[2];
+  float v = os - (xh * c.K[3] + yh * c.K[4] + c.K[5]);
+  u = 2.f * (u - os / 2.f) / os;
+  v = 2.f * (v - os / 2.f) / os;
+  out[3 * i] = u; out[3 * i + 1] = v; out[3 * i + 2] = z;
+}
+
+__global__ void project_faces_bwd_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, const float* __restrict__ K,
+                                         const float* __restrict__ R, const float* __restrict__ t, int V, int F, long n, float os,
+                                         float eps, const float* __restrict__ gout, float* __restrict__ gverts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = (int)(i / (3L * F));
+  int vi = faces[i];
+  if (vi < 0 || vi >= V) return;
+  const float gu = gout[3 * i], gv = gout[3 * i + 1], gz = gout[3 * i + 2];
+  if (gu == 0.f && gv == 0.f && gz == 0.f) return;                    // most faces are hidden: nothing to scatter
+  const float* p = verts + ((long)b * V + vi) * 3;
+  const Cam c = load_cam(K, R, t, b);
+  const float x = p[0] * c.R[0] + p[1] * c.R[1] + p[2] * c.R[2] + c.t[0];
+  const float y = p[0] * c.R[3] + p[1] * c.R[4] + p[2] * c.R[5] + c.t[1];
+  const float z = p[0] * c.R[6] + p[1] * c.R[7] + p[2] * c.R[8] + c.t[2];
+  const float iz = 1.f / (z + eps);
+  // u = 2 (K0 xh + K1 yh + K2 - os/2) / os ; v = 2 (os - (K3 xh + K4 yh + K5) - os/2) / os
+  const float s = 2.f / os;
+  const float gxh = s * (gu * c.K[0] - gv * c.K[3]);
+  const float gyh = s * (gu * c.K[1] - gv * c.K[4]);
+  const float gx = gxh * iz, gy = gyh * iz;
+  const float gzc = gz - (gxh * x + gyh * y) * iz * iz;
+  float* g = gverts + ((long)b * V + vi) * 3;
+  atomicAdd(g + 0, gx * c.R[0] + gy * c.R[3] + gzc * c.R[6]);
+  atomicAdd(g + 1, gx * c.R[1] + gy * c.R[4] + gzc * c.R[7]);
+  atomicAdd(g + 2, gx * c.R[2] + gy * c.R[5] + gzc * c.R[8]);
+}
+
 }  // namespace
 
 // ====================================================================================================
@@ -552,6 +617,34 @@ int sln_raster_forward(const float* faces, int B, int F, int image_size, float n
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
   hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near, near, far,
                      face_index, weight, depth, nullptr, nullptr, nullptr);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// faces_xyz[B,F,3,3] = (x_ndc, y_ndc, z_cam) of every face corner: projection (K, R, t, orig_size; no distortion) of
+// vertices[B,V,3] gathered by faces[B,F,3]
+int sln_project_faces(const float* vertices, const int32_t* faces, const float* K, const float* R, const float* t, int B, int V, int F,
+                      float orig_size, float eps, float* faces_xyz, void* stream) {
+  if (!vertices || !faces || !K || !R || !t || !faces_xyz || B <= 0 || V <= 0 || F < 0) return SLN_E_BADARG;
+  const long n = (long)B * F * 3;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(project_faces_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vertices, faces, K, R, t, V, F, n,
+                     orig_size, eps, faces_xyz);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// grad_vertices[B,V,3] = the adjoint of sln_project_faces applied to grad_faces_xyz (overwritten, fp32 atomics over shared corners)
+int sln_project_faces_backward(const float* vertices, const int32_t* faces, const float* K, const float* R, const float* t, int B, int V,
+                               int F, float orig_size, float eps, const float* grad_faces_xyz, float* grad_vertices, void* stream) {
+  if (!vertices || !faces || !K || !R || !t || !grad_faces_xyz || !grad_vertices || B <= 0 || V <= 0 || F < 0) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(grad_vertices, 0, sizeof(float) * 3 * (size_t)B * V, st);
+  if (e != hipSuccess) return (int)e;
+  const long n = (long)B * F * 3;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(project_faces_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vertices, faces, K, R, t, V, F, n, orig_size,
+                     eps, grad_faces_xyz, grad_vertices);
   SLN_CHECK_LAUNCH();
   return 0;
 }

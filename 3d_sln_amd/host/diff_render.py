@@ -109,8 +109,7 @@ def scene_render(vertices_buf, face_buf, class_ranges, room_box, image_size=fina
     faces, cls, classes, chan, dch = cull_and_classify(vertices_buf, face_buf, class_ranges, R, t)
     faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)                 # fill_back
     cls = torch.cat((cls, cls))[None].contiguous()
-    v = nr.projection(vertices_buf.float(), K, R, t, None, inter_out)
-    fxyz = nr.vertices_to_faces(v, faces)
+    fxyz = nr.project_faces(vertices_buf, faces, K, R, t, inter_out)
     chan_t = torch.tensor(chan, dtype=torch.int32, device=dev)
     dch_t = torch.tensor(dch, dtype=torch.int32, device=dev)
     return _SceneFn.apply(fxyz, cls, chan_t, dch_t, image_size, near)
@@ -119,8 +118,7 @@ def scene_render(vertices_buf, face_buf, class_ranges, room_box, image_size=fina
 def scene_render_batch(vertices, faces, face_class, chan, dch, K, R, t, image_size=final_out, near=0.001):
     """Batched fused pass for B rooms with equal (padded) V and F: vertices [B,V,3], faces [B,F,3] int32 (already
     culled, fill_back applied by the caller or not at all), face_class [B,F] int32, K/R/t [B,...]."""
-    v = nr.projection(vertices.float(), K, R, t, None, inter_out)
-    fxyz = nr.vertices_to_faces(v, faces)
+    fxyz = nr.project_faces(vertices, faces, K, R, t, inter_out)
     return _SceneFn.apply(fxyz, face_class.contiguous(), chan, dch, image_size, near)
 
 

@@ -41,6 +41,39 @@ def vertices_to_faces(vertices, faces):
     return vertices.reshape(B * V, 3)[idx]
 
 
+class _ProjectFaces(torch.autograd.Function):
+    """projection + vertices_to_faces in one HIP launch each way (sln_project_faces / _backward)."""
+
+    @staticmethod
+    def forward(ctx, vertices, faces, K, R, t, orig_size, eps):
+        vertices = vertices.float().contiguous()
+        B, V = vertices.shape[:2]
+        F = faces.shape[1]
+        faces = faces.to(torch.int32).contiguous()
+        cam = [x.float().expand(B, *x.shape[1:]).contiguous() for x in (K, R, t)]
+        out = torch.empty(B, F, 3, 3, device=vertices.device)
+        _lib.check(_lib.lib().sln_project_faces(_lib.ptr(vertices), _lib.ptr(faces), _lib.ptr(cam[0]), _lib.ptr(cam[1]), _lib.ptr(cam[2]), B, V, F,
+                                                float(orig_size), float(eps), _lib.ptr(out), _lib.current_stream_ptr()), "sln_project_faces")
+        ctx.save_for_backward(vertices, faces, *cam)
+        ctx.orig_size, ctx.eps = float(orig_size), float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        vertices, faces, K, R, t = ctx.saved_tensors
+        B, V = vertices.shape[:2]
+        g = torch.empty_like(vertices)
+        _lib.check(_lib.lib().sln_project_faces_backward(_lib.ptr(vertices), _lib.ptr(faces), _lib.ptr(K), _lib.ptr(R), _lib.ptr(t), B, V,
+                                                         faces.shape[1], ctx.orig_size, ctx.eps, _lib.ptr(gout.contiguous()), _lib.ptr(g),
+                                                         _lib.current_stream_ptr()), "sln_project_faces_backward")
+        return g, None, None, None, None, None, None
+
+
+def project_faces(vertices, faces, K, R, t, orig_size=512, eps=1e-9):
+    """``vertices_to_faces(projection(vertices, K, R, t, None, orig_size), faces)`` -> [B,F,3,3] (x_ndc, y_ndc, z_cam)."""
+    return _ProjectFaces.apply(vertices, faces, K, R, t, orig_size, eps)
+
+
 class _RasterizeDepth(torch.autograd.Function):
     @staticmethod
     def forward(ctx, faces, image_size, near, far):
@@ -132,8 +165,7 @@ class Renderer:
             raise _lib.SlnError("the rasterizer runs on the MI355X only (no CPU fallback)")
         if self.fill_back:
             faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)
-        v = projection(vertices.float(), K, R, t, None, orig_size)
-        fxyz = vertices_to_faces(v, faces)
+        fxyz = project_faces(vertices, faces, K, R, t, orig_size)
         if mode == 'depth':
             # the package's render_depth does not forward near/far: library defaults apply
             d = _RasterizeDepth.apply(fxyz, self.image_size, 0.1, 100.0)

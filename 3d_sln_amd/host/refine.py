@@ -216,6 +216,7 @@ class RefineScene:
             ranges[nm].append([foff, foff + f.shape[0]]); voff += v.shape[0]; foff += f.shape[0]
         self.shell_v = torch.cat(sv)
         self.faces = torch.cat(faces)                                        # [F,3] into the flattened vertex list
+        self.faces32 = self.faces.to(torch.int32)[None].contiguous()
         classes, chan, dch = DR.class_tables(ranges.keys())
         cls = torch.full((foff,), -1, dtype=torch.int32)
         for ci, name in enumerate(classes):
@@ -249,8 +250,7 @@ class RefineScene:
             size_loss = ((size - obj_size_target) ** 2).mean(1).sum()
         cam_z = (torch.matmul(verts, self.R.transpose(1, 2)) + self.t)[0, :, 2]
         culled = (cam_z[self.faces] < DR.CULL_EPS).any(1).detach()
-        v = DR.nr.projection(verts, self.K, self.R, self.t, None, DR.inter_out)[0]
-        fxyz = v[self.faces]                                                  # [F,3,3]
+        fxyz = DR.nr.project_faces(verts, self.faces32, self.K, self.R, self.t, DR.inter_out)[0]      # [F,3,3]
         fxyz = torch.where(culled[:, None, None], torch.zeros_like(fxyz), fxyz)
         fxyz = torch.cat((fxyz, torch.flip(fxyz, [1])), 0)[None]              # fill_back: corners (2, 1, 0)
         img = DR._SceneFn.apply(fxyz, self.cls2, self.chan, self.dch, self.image_size, 0.001)

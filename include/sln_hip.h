@@ -188,6 +188,12 @@ int sln_linear_wgrad(const float* g, const float* x, int R, int N, int K, float*
  * starts at faces[B, F, 3, 3] fp32 = (x_ndc, y_ndc, z_cam) of the three vertices of every face.
  * All maps are [B, is, is] in RASTER order (row 0 = bottom; the package flips rows afterwards).
  * ============================================================================================= */
+/* neural_renderer.projection (K [B,3,3], R [B,3,3], t [B,1,3], orig_size; dist_coeffs dropped as the reference README asks,
+ * README.md:12-18) followed by vertices_to_faces: faces_xyz [B,F,3,3] = (x_ndc, y_ndc, z_cam) per corner; and its adjoint. */
+int sln_project_faces(const float* vertices, const int32_t* faces, const float* K, const float* R, const float* t, int B, int V, int F,
+                      float orig_size, float eps, float* faces_xyz, void* stream);
+int sln_project_faces_backward(const float* vertices, const int32_t* faces, const float* K, const float* R, const float* t, int B, int V,
+                               int F, float orig_size, float eps, const float* grad_faces_xyz, float* grad_vertices, void* stream);
 int64_t sln_raster_workspace_bytes(int B, int F);
 /* rasterize / rasterize_depth: face_index int32 (-1 = background), weight [B,is,is,3], depth (far where empty) */
 int sln_raster_forward(const float* faces, int B, int F, int image_size, float near, float far, void* workspace,

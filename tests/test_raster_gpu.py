@@ -180,3 +180,21 @@ def test_batched_rooms_with_padding_equal_single_room_renders():
         assert_close(Vb.grad[i, :V.shape[0]].cpu().numpy(), grads[i].cpu().numpy(), "room %d dV" % i, rtol=1e-4,
                      atol=1e-4 * grads[i].abs().max().item())
     assert torch.isfinite(Vb.grad).all()
+
+
+def test_fused_projection_and_gather_equal_the_torch_ops():
+    """sln_project_faces(+_backward) against neural_renderer.projection + vertices_to_faces evaluated by torch on the same device"""
+    N = pkg("host.neural_renderer"); DR = pkg("host.diff_render")
+    g = torch.Generator().manual_seed(0)
+    B, V, F = 3, 200, 500
+    verts = (torch.rand(B, V, 3, generator=g) * torch.tensor([4.0, 2.7, 4.0])).cuda()
+    faces = torch.randint(0, V, (B, F, 3), generator=g, dtype=torch.int32).cuda()
+    K, R, t = DR.get_cam_mat(torch.tensor([0, 0, 0, 4.0, 2.7, 5.0]), "cuda")
+    K, R, t = K.expand(B, 3, 3), R.expand(B, 3, 3), t.expand(B, 1, 3)
+    v1 = verts.clone().requires_grad_(True); v2 = verts.clone().requires_grad_(True)
+    ref = N.vertices_to_faces(N.projection(v1, K, R, t, None, 512), faces)
+    got = N.project_faces(v2, faces, K, R, t, 512)
+    assert_close(got.detach().cpu().numpy(), ref.detach().cpu().numpy(), "faces_xyz", rtol=1e-5, atol=1e-5)
+    w = torch.randn(ref.shape, generator=g).cuda()
+    (ref * w).sum().backward(); (got * w).sum().backward()
+    assert_close(v2.grad.cpu().numpy(), v1.grad.cpu().numpy(), "d/d vertices", rtol=1e-4, atol=1e-4 * float(v1.grad.abs().max()))
