@@ -898,10 +898,13 @@ __global__ __launch_bounds__(256) void scene_bwd_maps_kernel(const int32_t* __re
 
 // g[b,c,y,x] = d final[b, 1+chan[c], flip(y), x] / 3  and its transpose
 __global__ __launch_bounds__(256) void scene_bwd_grad_planes_kernel(const float* __restrict__ gout, const int32_t* __restrict__ chan,
-                                                                    int is, int NC, int nch, float* __restrict__ g,
-                                                                    float* __restrict__ gT) {
+                                                                    int is, int NC, int nch, const SceneStats* __restrict__ st,
+                                                                    float* __restrict__ g, float* __restrict__ gT) {
   __shared__ float t[32][33];
   const int bc = blockIdx.z, b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  // a plane is only ever read for the class of a VISIBLE pixel (the reference pixel of a scan): classes without a single
+  // visible pixel in this image (typically half of the 32) are skipped
+  if (!(st[b].cnt[c] > 0.0)) return;
   const long plane = (long)is * is;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* src = gout + ((long)b * nch + 1 + chan[c]) * plane;
@@ -1025,7 +1028,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
                      num_classes, 70, w.prec, w.precT);
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
-                     num_classes, 70, w.g, w.gT);
+                     num_classes, 70, w.st, w.g, w.gT);
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, is, pix_eps,
                      grad_faces);
