@@ -815,54 +815,60 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   }
 }
 
-// sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c).  One pass over the pixels:
-// a thread reads its pixel's class / mask once and walks the (<= 32) depth-hot channels, adding the channel's gradient
-// unless the pixel lies in the mask of the class that owns the channel (a block per (class, pixel range) re-read the
-// per-pixel inputs once per class).
-__global__ __launch_bounds__(256) void scene_bwd_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
-                                                              const int32_t* __restrict__ cls, const int32_t* __restrict__ dch, int F,
-                                                              int is, int NC, int nch, const float* __restrict__ gout,
-                                                              SceneStats* __restrict__ st) {
-  constexpr int MAXK = 32;
-  __shared__ int s_owner[MAXK];
-  __shared__ float s_red[4][MAXK];
-  const int b = blockIdx.y;
-  const int ndch = min(nch - 41, MAXK);
-  if (threadIdx.x < MAXK) {
-    int owner = -1;
-    for (int c = 0; c < NC; ++c) if (dch[c] == (int)threadIdx.x) { owner = c; break; }
-    s_owner[threadIdx.x] = owner;
-  }
-  __syncthreads();
+// sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c), as (sum over ALL pixels of the
+// channel) - (sum over the pixels inside the owner class's mask): the first part is a plain streaming reduction of each
+// channel plane, the second reads one value per masked pixel.  (A block per (class, pixel range) re-read the per-pixel
+// inputs once per class; a single pass with one accumulator per channel had 29 strided streams per thread and was no faster.)
+__global__ void scene_zero_gsum_kernel(SceneStats* st, int B) {      // backward may run more than once per forward
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B * 64) st[i / 64].gsum[i % 64] = 0.0;
+}
+
+__global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t* __restrict__ dch, int is, int NC, int nch,
+                                                                   const float* __restrict__ gout, SceneStats* __restrict__ st) {
+  const int b = blockIdx.z, k = blockIdx.y;                       // depth-hot channel k
+  int owner = -1;
+  for (int c = 0; c < NC; ++c) if (dch[c] == k) { owner = c; break; }
+  if (owner < 0) return;
   const long plane = (long)is * is;
-  float acc[MAXK];
+  const float4* src = reinterpret_cast<const float4*>(gout + ((long)b * nch + 41 + k) * plane);
+  const long n4 = plane / 4;
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = src[i];
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  if (blockIdx.x == 0)                                             // tail when the plane size is not a multiple of 4
+    for (long i = n4 * 4 + threadIdx.x; i < plane; i += blockDim.x) acc += gout[((long)b * nch + 41 + k) * plane + i];
+  __shared__ float red[4];
 #pragma unroll
-  for (int k = 0; k < MAXK; ++k) acc[k] = 0.f;
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&st[b].gsum[owner], (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+__global__ __launch_bounds__(256) void scene_bwd_masked_sums_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                                    const int32_t* __restrict__ cls, const int32_t* __restrict__ dch,
+                                                                    int F, int is, int NC, int nch, const float* __restrict__ gout,
+                                                                    SceneStats* __restrict__ st) {
+  const int b = blockIdx.y;
+  const long plane = (long)is * is;
+  __shared__ float ssum[64];
+  if (threadIdx.x < 64) ssum[threadIdx.x] = 0.f;
+  __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
     const long q = b * plane + p;
     const int f = fi_b[q];
-    const int cc = f >= 0 ? cls[(long)b * F + f] : -1;
-    const bool m = cc >= 0 && cc < NC && class_image_value(val[3 * q]) > 0.1f;
-    const int mydch = m ? dch[cc] : -1;
+    if (f < 0) continue;
+    const int c = cls[(long)b * F + f];
+    if (c < 0 || c >= NC || dch[c] < 0) continue;
+    if (!(class_image_value(val[3 * q]) > 0.1f)) continue;
     const int y = (int)(p / is), x = (int)(p % is);
-    const float* gp = gout + (((long)b * nch + 41) * is + (is - 1 - y)) * is + x;
-#pragma unroll
-    for (int k = 0; k < MAXK; ++k)
-      if (k < ndch) { const float gk = gp[(long)k * plane]; acc[k] += (k == mydch) ? 0.f : gk; }
-  }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < MAXK; ++k) {
-    float v = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) s_red[wave][k] = v;
+    atomicAdd(&ssum[c], gout[(((long)b * nch + 41 + dch[c]) * is + (is - 1 - y)) * is + x]);
   }
   __syncthreads();
-  if (threadIdx.x < ndch && s_owner[threadIdx.x] >= 0) {
-    const float v = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
-    atomicAdd(&st[b].gsum[s_owner[threadIdx.x]], (double)v);
-  }
+  if (threadIdx.x < NC && ssum[threadIdx.x] != 0.f) atomicAdd(&st[b].gsum[threadIdx.x], -(double)ssum[threadIdx.x]);
 }
 
 // per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
@@ -1019,8 +1025,11 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
   hipError_t e = hipMemsetAsync(grad_faces, 0, sizeof(float) * 9 * n, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(scene_bwd_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, face_class,
-                     class_depth_channel, F, is, num_classes, 70, grad_final, w.st);
+  hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, st, w.st, B);
+  hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, st, class_depth_channel, is, num_classes, 70, grad_final,
+                     w.st);
+  hipLaunchKernelGGL(scene_bwd_masked_sums_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_depth_channel, F, is,
+                     num_classes, 70, grad_final, w.st);
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
