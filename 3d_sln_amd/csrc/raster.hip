@@ -288,8 +288,11 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
     for (int m = 0; m < 3; ++m) tmp[l] += -iv[3 * m + l] / fl[3 * m + 2];
   float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const long base = (long)b * is * is;
-  for (int y = y0; y <= y1; ++y)
-    for (int x = x0 + lane; x <= x1; x += 64) {
+  // the bounding box as one flat pixel range: narrow boxes keep all 64 lanes busy (a row per iteration used a third of them)
+  const int bw = x1 - x0 + 1, npx = bw * (y1 - y0 + 1);
+  for (int pidx = lane; pidx < npx; pidx += 64) {
+    {
+      const int y = y0 + pidx / bw, x = x0 + pidx % bw;
       const long q = base + (long)y * is + x;
       if (fi[q] != fn) continue;
       const float g = gd[q];
@@ -302,6 +305,7 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
         for (int l = 0; l < 2; ++l) acc[3 * k + l] += -g * tmp[l] * wk * d2 * is / 2;
       }
     }
+  }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
     float v = acc[k];
