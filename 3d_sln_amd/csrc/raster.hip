@@ -329,11 +329,13 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
 struct PixDenseView {
   const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;
   __device__ __forceinline__ long idx(long base, int d0, int d1) const { return axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1; }
-  __device__ __forceinline__ int face_at(long q) const { return fi[q]; }
-  __device__ __forceinline__ float contrib(long q, long ref, int, int& fq) const {
+  // Ref: what a scan needs to know about its reference pixel, fetched once per edge step (phase 1)
+  struct Ref { long q; int fi; };
+  __device__ __forceinline__ Ref ref_at(long q) const { Ref r; r.q = q; r.fi = fi[q]; return r; }
+  __device__ __forceinline__ float contrib(long q, const Ref& ref, int, int& fq) const {
     fq = fi[q];
     float diff = 0.f;
-    for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref * C + k]) * grad[q * C + k];
+    for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref.q * C + k]) * grad[q * C + k];
     return diff > 0.f ? diff : 0.f;
   }
 };
@@ -354,24 +356,32 @@ struct PixRec { int fi; int cp; float v; float gown; };
 struct PixClassView {
   const PixRec* rec; const float* g; int is, NC; long plane;
   __device__ __forceinline__ long idx(long base, int d0, int d1) const { return base + (long)d0 * is + d1; }
-  __device__ __forceinline__ int face_at(long q) const { return rec[q].fi; }
-  __device__ __forceinline__ float contrib(long q, long ref, int b, int& fq) const {
-    const PixRec rq = rec[q], rr = rec[ref];
-    fq = rq.fi;
-    const int cq = rq.cp, cr = rr.cp;
-    const float vq = cq >= 0 ? rq.v : 0.f, vr = cr >= 0 ? rr.v : 0.f;
+  // Ref: class and value of the reference pixel of an edge step (phase 1).  Knowing the class up front makes the address of
+  // the second gradient plane independent of the scanned pixel's record, so both loads of a scan pixel go out together.
+  struct Ref { int fi, cp; float v; };
+  __device__ __forceinline__ Ref ref_at(long q) const {
+    const int4 ir = *reinterpret_cast<const int4*>(rec + q);
+    Ref r; r.fi = ir.x; r.cp = ir.y; r.v = __int_as_float(ir.z);
+    return r;
+  }
+  __device__ __forceinline__ float contrib(long q, const Ref& ref, int b, int& fq) const {
     const long pq = q - (long)b * plane;
+    const int cr = ref.cp;
+    const int4 iq = *reinterpret_cast<const int4*>(rec + q);                       // one 16-byte load
+    const float g_cr = g[((long)b * NC + max(cr, 0)) * plane + pq];                // unconditional, independent of iq
+    fq = iq.x;
+    const int cq = iq.y;
+    const float vq = cq >= 0 ? __int_as_float(iq.z) : 0.f, vr = cr >= 0 ? ref.v : 0.f;
     float tot = 0.f;
     if (cq >= 0) {
-      const float g3 = rq.gown;
+      const float g3 = __int_as_float(iq.w);
       const float dv = vq - (cr == cq ? vr : 0.f);
       float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
       if (diff > 0.f) tot += diff;
     }
     if (cr >= 0 && cr != cq) {
-      const float g3 = g[((long)b * NC + cr) * plane + pq];
       const float dv = 0.f - vr;
-      float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
+      float diff = 0.f; diff += dv * g_cr; diff += dv * g_cr; diff += dv * g_cr;
       if (diff > 0.f) tot += diff;
     }
     return tot;
@@ -408,6 +418,8 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
   __shared__ int s_ofrom[PMB_DC], s_lo[PMB_DC], s_ifrom[PMB_DC];
   __shared__ float s_cross[PMB_DC], s_r0[PMB_DC], s_r1[PMB_DC];
+  typedef decltype(pix.view(0)) View;
+  __shared__ typename View::Ref s_rin[PMB_DC], s_rout[PMB_DC];     // reference pixel of the outward / inward scan of a step
   // Image -> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the
   // plain (face, edge) order all XCDs scan the SAME image at a time and each L2 fetches that image's maps for itself (measured:
   // 1.07 GB from memory per launch for 0.28 GB of maps).  With at least 8 images, XCD x takes the images x, x+8, ...
@@ -470,7 +482,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
       r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;         // 0 marks "slot not used" (a used ratio is never 0)
       r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-      if (V.face_at(V.idx(base, d0, d1_in)) == fn) {                   // outward scan to the image border
+      const typename View::Ref rin = V.ref_at(V.idx(base, d0, d1_in));
+      s_rin[lane] = rin; s_rout[lane] = V.ref_at(V.idx(base, d0, d1_out));
+      if (rin.fi == fn) {                                              // outward scan to the image border
         const int lim = dir > 0 ? is - 1 : 0;
         const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
         ofrom = from; lo = max(to - from + 1, 0);
@@ -508,9 +522,8 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
     const bool outward = t < s_lo[l];
     const int d1 = outward ? s_ofrom[l] + t : s_ifrom[l] + (t - s_lo[l]);
     const long q = V.idx(base, step_d0, d1);
-    const long ref = V.idx(base, step_d0, outward ? d1_in : d1_in + dir);
     int fq;
-    const float diff = V.contrib(q, ref, b, fq);
+    const float diff = V.contrib(q, outward ? s_rin[l] : s_rout[l], b, fq);
     if (!outward && fq != fn) continue;          // inward: this face's pixels only
     if (diff > 0.f) {
       const float q0 = s_r0[l], q1 = s_r1[l];
