@@ -78,3 +78,37 @@ def layout_heatmap(boxes_pred, container_size=100, clip_coor=True):
     hist.scatter_add_(0, flat.reshape(-1), keep.reshape(-1).float())
     hist = hist.view(O - 1, container_size, container_size)
     return hist / hist.sum((1, 2), keepdim=True).clamp(min=1.0)
+
+
+RELATIONSHIPS = ['__in_room__', 'left of', 'right of', 'behind', 'in front of', 'inside', 'surrounding', 'left touching', 'right touching',
+                 'front touching', 'behind touching', 'front left', 'front right', 'back left', 'back right', 'on']
+VALID_CLASSES = ["__room__", "curtain", "shower_curtain", "dresser", "counter", "bookshelf", "picture", "mirror", "floor_mat", "chair", "sink",
+                 "desk", "table", "lamp", "door", "clothes", "person", "toilet", "cabinet", "floor", "window", "blinds", "wall", "pillow",
+                 "whiteboard", "bathtub", "television", "night_stand", "sofa", "refridgerator", "bed", "shelves"]
+
+
+def scene_graph_from_words(objs_in_scene, rels_in_scene, valid_classes=None, device="cpu"):
+    """testing/test_utils.py:43-90: ``["bed", "desk", "chair:1", ...]`` + ``[("bed", "behind", "desk"), ...]`` ->
+    (objs [n+1], triples [r+n, 3], attributes [n+1]) with the '__room__' row and the in-room triples appended."""
+    classes = VALID_CLASSES if valid_classes is None else list(valid_classes)
+    objs = [classes.index(name.split(":")[0]) for name in objs_in_scene]
+    triples = [[objs_in_scene.index(s), RELATIONSHIPS.index(p), objs_in_scene.index(o)] for s, p, o in rels_in_scene]
+    triples += [[i, 0, len(objs_in_scene)] for i in range(len(objs_in_scene))]
+    objs.append(0)
+    t = lambda x: torch.tensor(x, dtype=torch.int64, device=device)
+    return t(objs), t(triples).reshape(-1, 3), torch.zeros(len(objs), dtype=torch.int64, device=device)
+
+
+def heatmap_from_words(model, objs_in_scene, rels_in_scene, mean, cov, num_iter=20000, chunk=2000, container_size=100, generator=None):
+    """testing/test_heatmap.py:52-99 without the 20 000 single-graph decodes: ``chunk`` posterior samples of the scene are decoded
+    per engine call (replicated disjoint graphs) and accumulated into the per-object centre histograms."""
+    dev = next(model.parameters()).device
+    objs, triples, attrs = scene_graph_from_words(objs_in_scene, rels_in_scene, device=dev)
+    hist, done = None, 0
+    while done < num_iter:
+        n = min(chunk, num_iter - done)
+        bp, _, _ = sample_layouts(model, objs, triples, attrs, n_samples=n, mean=mean, cov=cov, generator=generator)
+        h = layout_heatmap(bp, container_size) * n                       # back to counts
+        hist = h if hist is None else hist + h
+        done += n
+    return hist / hist.sum((1, 2), keepdim=True).clamp(min=1.0)

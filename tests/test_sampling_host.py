@@ -34,3 +34,15 @@ def test_layout_heatmap_equals_reference_loop():
         want = _reference_loop(boxes, 50, clip)
         assert np.allclose(got, want, atol=1e-7), clip
         assert np.allclose(got.sum((1, 2))[want.sum((1, 2)) > 0], 1.0)
+
+
+def test_scene_graph_from_words_layout():
+    """testing/test_utils.py:43-90 on the example of test_heatmap.py:41-44"""
+    S = pkg("host.sampling")
+    objs5 = ["bed", "desk", "cabinet", "chair", "lamp"]
+    rels5 = [("bed", "behind", "desk"), ("cabinet", "left of", "bed"), ("chair", "left of", "desk"), ("lamp", "on", "desk")]
+    objs, triples, attrs = S.scene_graph_from_words(objs5, rels5)
+    assert objs.tolist() == [30, 11, 18, 9, 13, 0] and attrs.tolist() == [0] * 6
+    assert triples.tolist() == [[0, 3, 1], [2, 1, 0], [3, 1, 1], [4, 15, 1]] + [[i, 0, 5] for i in range(5)]
+    o2, t2, _ = S.scene_graph_from_words(["chair:0", "chair:1"], [("chair:0", "left of", "chair:1")])
+    assert o2.tolist() == [9, 9, 0] and t2.tolist() == [[0, 1, 1], [0, 0, 2], [1, 0, 2]]

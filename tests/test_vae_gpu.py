@@ -383,3 +383,22 @@ def test_high_degree_room_node_beyond_the_lds_entry_cache():
     gscale = max(float(g.abs().max()) for g in grads.values())
     for k, g in grads.items():
         assert_close(named[k].grad.cpu().numpy(), g.numpy(), "grad:" + k, rtol=1e-4, atol=1e-5 * gscale)
+
+
+def test_heatmap_from_words_runs_chunked_decodes():
+    """testing/test_heatmap.py:52-99: posterior samples of a worded scene graph, decoded in chunks, accumulated on the device"""
+    S = pkg("host.sampling")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    model = _model(cfg, vae_ref.init_state(cfg, seed=2)).eval()
+    E = cfg.embedding_dim
+    mean = torch.zeros(E, dtype=torch.float64); cov = torch.eye(E, dtype=torch.float64) * 0.25
+    objs5 = ["bed", "desk", "cabinet", "chair", "lamp"]
+    rels5 = [("bed", "behind", "desk"), ("cabinet", "left of", "bed"), ("chair", "left of", "desk"), ("lamp", "on", "desk")]
+    h = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=700, chunk=256, container_size=40, generator=torch.Generator().manual_seed(0))
+    assert h.shape == (5, 40, 40) and torch.isfinite(h).all()
+    assert_close(h.sum((1, 2)).cpu().numpy(), np.ones(5), "every object's histogram sums to one", rtol=1e-5)
+    # one chunk == the plain pipeline
+    objs, triples, attrs = S.scene_graph_from_words(objs5, rels5, device="cuda")
+    bp, _, _ = S.sample_layouts(model, objs, triples, attrs, n_samples=64, mean=mean, cov=cov, generator=torch.Generator().manual_seed(3))
+    h1 = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=64, chunk=64, container_size=40, generator=torch.Generator().manual_seed(3))
+    assert_close(h1.cpu().numpy(), S.layout_heatmap(bp, 40).cpu().numpy(), "single chunk", rtol=1e-6, atol=1e-7)
