@@ -99,7 +99,7 @@ def scene_graph_from_words(objs_in_scene, rels_in_scene, valid_classes=None, dev
     return t(objs), t(triples).reshape(-1, 3), torch.zeros(len(objs), dtype=torch.int64, device=device)
 
 
-def heatmap_from_words(model, objs_in_scene, rels_in_scene, mean, cov, num_iter=20000, chunk=2000, container_size=100, generator=None):
+def heatmap_from_words(model, objs_in_scene, rels_in_scene, mean, cov, num_iter=20000, chunk=10000, container_size=100, generator=None):
     """testing/test_heatmap.py:52-99 without the 20 000 single-graph decodes: ``chunk`` posterior samples of the scene are decoded
     per engine call (replicated disjoint graphs) and accumulated into the per-object centre histograms."""
     dev = next(model.parameters()).device
