@@ -226,40 +226,8 @@ __global__ void texture_sample_kernel(const float* __restrict__ faces, const flo
   rgb[3 * i] = px[0]; rgb[3 * i + 1] = px[1]; rgb[3 * i + 2] = px[2];
 }
 
-// depth backward (package's backward_depth_map): atomics into grad_faces[B,F,9]
-__global__ void depth_backward_kernel(const float* __restrict__ faces, const int32_t* __restrict__ fi,
-                                      const float* __restrict__ w, const float* __restrict__ depth,
-                                      const float* __restrict__ gd, int F, int is, long npix, float* __restrict__ gfaces) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= npix) return;
-  const int fn = fi[i];
-  const float g = gd[i];
-  if (fn < 0 || g == 0.f) return;
-  const long b = i / ((long)is * is);
-  const float* f = faces + 9 * (b * F + fn);
-  float* gf = gfaces + 9 * (b * F + fn);
-  float fl[9], iv[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) fl[k] = f[k];
-  face_inverse(fl, is, iv);
-  const float d2 = depth[i] * depth[i];
-  float tmp[2] = {0.f, 0.f};
-#pragma unroll
-  for (int l = 0; l < 2; ++l)
-#pragma unroll
-    for (int m = 0; m < 3; ++m) tmp[l] += -iv[3 * m + l] / fl[3 * m + 2];
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const float wk = w[3 * i + k];
-    atomicAdd(gf + 3 * k + 2, g * wk * d2 / (fl[3 * k + 2] * fl[3 * k + 2]));
-#pragma unroll
-    for (int l = 0; l < 2; ++l) atomicAdd(gf + 3 * k + l, -g * tmp[l] * wk * d2 * is / 2);
-  }
-}
-
-
 // depth backward, atomic-free: one wavefront per face gathers the pixels it won inside its bounding box
-// (the per-pixel scatter above serialises on the 9 atomics of large wall / floor faces: 1.45 ms per 16 rooms).
+// (a per-pixel scatter serialises on the 9 atomics of large wall / floor faces: 1.45 ms per 16 rooms).
 __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __restrict__ faces, const int32_t* __restrict__ fi,
                                                                  const float* __restrict__ w, const float* __restrict__ depth,
                                                                  const float* __restrict__ gd, int F, int is,
@@ -319,9 +287,7 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
 }
 
 // ----------------------------------------------------------------------------------------------------
-// pixel-map backward.  One wavefront per face: the (edge, axis, d0) walk is sequential, the outward /
-// inward scans along d1 are spread over the 64 lanes; per-lane partial sums are combined by a fixed
-// butterfly at the end (no atomics: one writer per face).
+// pixel-map backward.  One wavefront per (face, edge, axis): see pixel_map_backward_kernel for the two-phase walk.
 // PIX is a policy giving diff(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
 // ----------------------------------------------------------------------------------------------------
 // A policy exposes, per scan axis, a view with: fi (face index map addressed by the view's own linear index),
@@ -518,7 +484,6 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
     const int t = w - s_pre[l];
     const int step_d0 = c_from + l;
     const float cr = s_cross[l];
-    const int d1_in = dir > 0 ? (int)floorf(cr) : (int)ceilf(cr);
     const bool outward = t < s_lo[l];
     const int d1 = outward ? s_ofrom[l] + t : s_ifrom[l] + (t - s_lo[l]);
     const long q = V.idx(base, step_d0, d1);
