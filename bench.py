@@ -310,11 +310,12 @@ def main():
                    "parallelism": "dp%d" % world, "collective": ("1 all-reduce of %d fp32 grads/step" % model.flat_grads.numel()) if dp else None, "final_total_loss": round(final_loss, 5)},
     }
 
-    if rank == 0 and not args.no_render:
+    solo = world == 1          # the side legs and the CPU baseline are single-GPU measurements (rank 0 at N = 1 only)
+    if rank == 0 and solo and not args.no_render:
         out["render"] = render_leg(args, lib, torch, rank)
-    if rank == 0 and not args.no_spade:
+    if rank == 0 and solo and not args.no_spade:
         out["spade"] = spade_leg(args, lib, torch)
-    if rank == 0 and not args.no_graph_build:
+    if rank == 0 and solo and not args.no_graph_build:
         out["graph_build"] = graph_build_leg(args, lib, torch)
     if rank == 0 and args.prof_steps <= 0:
         print(json.dumps(out))
@@ -363,7 +364,7 @@ def main():
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
 
         # ---- CPU baseline: the oracle (PyTorch-CPU port of the reference path) on the same batch ----
-        if not args.no_cpu:
+        if solo and not args.no_cpu:
             from oracle import vae_ref
             cfg = vae_ref.VaeConfig()
             sd = vae_ref.init_state(cfg, seed=42)
