@@ -133,7 +133,8 @@ struct SlnVae {
   }
 
   // hipGraph of one training iteration
-  hipGraphExec_t graph_exec = nullptr; int graph_O = -1, graph_T = -1; bool graph_adam = true;
+  // one per mode of train_iteration (TRAIN_*)
+  hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_O[4] = {-1, -1, -1, -1}, graph_T[4] = {-1, -1, -1, -1};
 
   // ------------------------------------------------------------------------------------------
   int unit_of(int net, int l, int k) const { return 8 + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
@@ -295,7 +296,12 @@ struct SlnVae {
   int encoder_backward(hipStream_t st);
   int loss(const float* bp, const float* ap, const float* mu_, const float* lv_, bool with_grads, hipStream_t st);
   int run_bn_updates(int first, int count, hipStream_t st);
-  int train_iteration(const float* eps, bool with_adam, hipStream_t st);
+  enum { TRAIN_BACKWARD = 0, TRAIN_FULL = 1, TRAIN_UPTO_DECODER = 2, TRAIN_ENCODER_BWD = 3 };   // = SLN_TRAIN_* of sln_hip.h
+  int train_iteration(const float* eps, int mode, hipStream_t st);
+  void drop_graphs() {
+    for (int i = 0; i < 4; ++i)
+      if (graph_exec[i]) { (void)hipGraphExecDestroy(graph_exec[i]); graph_exec[i] = nullptr; }
+  }
 };
 
 #define RET_IF(x) do { int r__ = (x); if (r__ != 0) return r__; } while (0)
@@ -644,19 +650,28 @@ int SlnVae::encoder_backward(hipStream_t st) {
   return 0;
 }
 
-int SlnVae::train_iteration(const float* eps, bool with_adam, hipStream_t st) {
-  HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
-  HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
-  bulk_zeroed = true;
-  int r = encoder_forward(true, st);
-  if (!r) r = decoder_forward(nullptr, eps, true, st);
-  if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
-  if (!r) r = decoder_backward(st);
-  if (!r) r = sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st);
-  if (!r) r = encoder_backward(st);
+// mode: TRAIN_BACKWARD (zero_grad .. backward), TRAIN_FULL (+ Adam), or the same iteration in two halves for the
+// data-parallel trainer: TRAIN_UPTO_DECODER ends when every decoder-side gradient is final (the all-reduce of that half of the
+// flat buffer can start), TRAIN_ENCODER_BWD is the rest of the backward pass.
+int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
+  int r = 0;
+  if (mode != TRAIN_ENCODER_BWD) {
+    HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
+    HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
+    bulk_zeroed = true;
+    r = encoder_forward(true, st);
+    if (!r) r = decoder_forward(nullptr, eps, true, st);
+    if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
+    if (!r) r = decoder_backward(st);
+    if (!r) r = sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st);
+  }
+  if (mode != TRAIN_UPTO_DECODER) {
+    bulk_zeroed = true;                // zeroed by the first half of this iteration
+    if (!r) r = encoder_backward(st);
+  }
   bulk_zeroed = false;
   RET_IF(r);
-  if (with_adam) {
+  if (mode == TRAIN_FULL) {
     RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
     wt_fresh = false;                  // transposed copies are rebuilt at the start of the next backward
   }
@@ -754,7 +769,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
 
 void sln_vae_destroy(SlnVae* h) {
   if (!h) return;
-  if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
+  h->drop_graphs();
   for (auto e : h->events) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
@@ -763,7 +778,7 @@ void sln_vae_destroy(SlnVae* h) {
 int64_t sln_vae_workspace_bytes(const SlnVae* h, int max_objs, int max_triples) {
   if (!h || max_objs <= 0 || max_triples < 0) return SLN_E_BADARG;
   SlnVae tmp = *h;                 // carve() on a copy in dry-run mode
-  tmp.graph_exec = nullptr;
+  for (int i = 0; i < 4; ++i) tmp.graph_exec[i] = nullptr;
   return (int64_t)tmp.carve(nullptr, max_objs, max_triples < 1 ? 1 : max_triples);
 }
 
@@ -798,7 +813,7 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
   RET_IF(sln_gemm_init());
   h->host_scalars_valid = false;
   h->bound = true; h->batch_set = false; h->wt_fresh = false; h->have_enc = h->have_dec = false;
-  if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+  h->drop_graphs();
   return 0;
 }
 
@@ -835,7 +850,7 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
     hipError_t e = hipStreamSynchronize(st);       // table upload below is a blocking copy
     if (e != hipSuccess) return (int)e;
     RET_IF(upload_bn_table(h));
-    if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    h->drop_graphs();
   }
   HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
   RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->cfg.num_preds, h->g, h->err_flag, st));
@@ -983,31 +998,41 @@ int sln_vae_params_changed(SlnVae* h) {       // parameters were modified outsid
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
                        int with_adam, void* stream) {
   if (!h || !h->batch_set || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
-  if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
+  const int mode = with_adam;
+  if (mode < 0 || mode > 3) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  RET_IF(set_kl(h, kl_weight, lr, st));
-  if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+  if (mode == SlnVae::TRAIN_ENCODER_BWD) {
+    if (!(h->have_dec && h->dec_training && h->z_from_latent)) return SLN_E_STATE;       // needs the first half
+  } else {
+    if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
+    RET_IF(set_kl(h, kl_weight, lr, st));
+    if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+  }
   if (use_graph && st != nullptr) {
-    if (!h->graph_exec || h->graph_O != h->O || h->graph_T != h->T || h->graph_adam != (with_adam != 0)) {
-      if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+    hipGraphExec_t& ge = h->graph_exec[mode];
+    if (!ge || h->graph_O[mode] != h->O || h->graph_T[mode] != h->T) {
+      if (ge) { (void)hipGraphExecDestroy(ge); ge = nullptr; }
       HIP_RET(hipStreamSynchronize(st));
-      h->wt_fresh = false;         // the captured iteration always rebuilds the transposed weights itself
+      // the captured iteration always rebuilds the transposed weights itself (the second half relies on the first one's)
+      if (mode != SlnVae::TRAIN_ENCODER_BWD) h->wt_fresh = false;
       hipGraph_t graph = nullptr;
       HIP_RET(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      const int r = h->train_iteration(h->eps_buf, with_adam != 0, st);
+      const int r = h->train_iteration(h->eps_buf, mode, st);
       hipError_t e = hipStreamEndCapture(st, &graph);
       if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
       if (e != hipSuccess) return (int)e;
-      e = hipGraphInstantiate(&h->graph_exec, graph, nullptr, nullptr, 0);
+      e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
-      if (e != hipSuccess) { h->graph_exec = nullptr; return (int)e; }
-      h->graph_O = h->O; h->graph_T = h->T; h->graph_adam = with_adam != 0;
+      if (e != hipSuccess) { ge = nullptr; return (int)e; }
+      h->graph_O[mode] = h->O; h->graph_T[mode] = h->T;
     }
-    HIP_RET(hipGraphLaunch(h->graph_exec, st));
-    h->enc_training = h->dec_training = true; h->have_enc = h->have_dec = true; h->z_from_latent = true; h->wt_fresh = false;
+    HIP_RET(hipGraphLaunch(ge, st));
+    h->enc_training = h->dec_training = true; h->have_enc = h->have_dec = true; h->z_from_latent = true;
+    h->wt_fresh = mode == SlnVae::TRAIN_UPTO_DECODER || mode == SlnVae::TRAIN_ENCODER_BWD;   // rebuilt by the graph, no Adam yet
   } else {
-    RET_IF(h->train_iteration(h->eps_buf, with_adam != 0, st));
+    RET_IF(h->train_iteration(h->eps_buf, mode, st));
   }
+  if (mode == SlnVae::TRAIN_ENCODER_BWD) return 0;       // the losses were handed out by the first half
   RET_IF(copy_out(losses_out, h->losses, 4, st));
   return 0;
 }

@@ -409,6 +409,42 @@ class Sg2ScVAEModel(nn.Module):
         self._alias_grads()
         return losses
 
+    # -- the same iteration in two halves, for the data-parallel trainer (host/train.py::DataParallelStep) ------------
+    _DECODER_ONLY = ("gconv_net_dc.", "box_net.", "angle_net.")
+
+    @property
+    def decoder_grad_offset(self):
+        """First element of ``flat_grads`` that belongs to the trailing run of decoder-only parameters: everything from
+        here on is final when ``train_step_begin`` has been executed."""
+        off, o = [], 0
+        for name, p in self.named_parameters():
+            off.append((name, o))
+            o += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        split = o
+        for name, start in reversed(off):
+            if not name.startswith(self._DECODER_ONLY):
+                break
+            split = start
+        return split
+
+    def train_step_begin(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None, use_graph=True):
+        """zero_grad, forward, losses and the decoder's half of backward (SLN_TRAIN_UPTO_DECODER); returns the losses."""
+        self._set_batch(objs, triples, boxes, angles, attributes)
+        if eps is None and not self.use_AE:
+            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
+        losses = self._new(4)
+        self._generation += 1
+        _lib.check(_lib.lib().sln_vae_train_step(
+            self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph), 2,
+            _lib.current_stream_ptr()), "sln_vae_train_step(begin)")
+        return losses
+
+    def train_step_finish(self, use_graph=True):
+        """The encoder's half of backward (SLN_TRAIN_ENCODER_BWD) of the iteration ``train_step_begin`` started."""
+        _lib.check(_lib.lib().sln_vae_train_step(
+            self._eng, None, 0.0, 0.0, None, int(use_graph), 3, _lib.current_stream_ptr()), "sln_vae_train_step(finish)")
+        self._alias_grads()
+
     def adam_step(self, lr=1e-4):
         """torch.optim.Adam(lr).step() over the flat parameter buffer (fused kernel)."""
         _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")

@@ -79,17 +79,53 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class FlatGradAllReduce:
-    """The ONE collective of a data-parallel step: sum the flat fp32 gradient buffer, divide by world size."""
+class DataParallelStep:
+    """One data-parallel iteration: every rank runs the step on its own graphs, the flat fp32 gradient buffer is averaged
+    over the ranks (RCCL over xGMI, the only exchange of the path), then the fused Adam update runs on identical gradients.
 
-    def __init__(self, world):
-        self.world = world
+    ``overlap`` (or SLN_DP_OVERLAP=1): the backward pass is issued in two halves (``train_step_begin`` /
+    ``train_step_finish``): when the decoder's backward is done the gradients of ``gconv_net_dc`` / ``box_net`` /
+    ``angle_net`` - the contiguous upper half of the flat buffer - are final, so their all-reduce runs on the collective's
+    stream while the encoder's backward still computes; the lower half follows.  Off by default: on one GPU (world of one,
+    where the collective itself is almost free) the two-half sequence costs 0.10 ms per step more than the plain one
+    (second graph launch, second collective, RCCL's kernel sharing the CUs with the encoder's GEMMs), about what hiding
+    half of a 15.5 MB all-reduce can win back - it has to be measured on an 8-GPU node before it becomes the default."""
 
-    def __call__(self, flat_grads):
-        if self.world > 1:
-            dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
-            flat_grads.mul_(1.0 / self.world)
-        return flat_grads
+    def __init__(self, model, world, overlap=None, force=False):
+        self.model, self.world = model, world
+        self.dp = world > 1 or force                # force: the collective path with a world of one (single-GPU test of it)
+        if overlap is None:
+            overlap = os.environ.get("SLN_DP_OVERLAP", "0") == "1"
+        self.split = int(getattr(model, "decoder_grad_offset", 0)) if hasattr(model, "train_step_begin") else 0
+        self.overlap = bool(overlap) and self.dp and 0 < self.split < model.flat_grads.numel()
+        # RCCL divides inside the collective; gloo (CPU tests) has no AVG
+        self.avg_in_collective = self.dp and dist.get_backend() == "nccl"
+
+    def _reduce(self, buf, async_op):
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
+        return dist.all_reduce(buf, op=op, async_op=async_op)
+
+    def __call__(self, b, kl_weight, lr, use_graph=True, eps=None):
+        m, g = self.model, self.model.flat_grads
+        kw = dict(kl_weight=kl_weight, lr=lr, use_graph=use_graph)
+        if eps is not None:
+            kw["eps"] = eps
+        args = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
+        if not self.dp:
+            return m.train_step(*args, with_adam=True, **kw)
+        if self.overlap:
+            losses = m.train_step_begin(*args, **kw)
+            w_dec = self._reduce(g[self.split:], True)          # waits for the first half, runs beside the second
+            m.train_step_finish(use_graph=use_graph)
+            w_enc = self._reduce(g[:self.split], True)
+            w_dec.wait(); w_enc.wait()                          # stream-side waits on the GPU; blocking on gloo
+        else:
+            losses = m.train_step(*args, with_adam=False, **kw)
+            self._reduce(g, False)
+        if not self.avg_in_collective:
+            g.mul_(1.0 / self.world)
+        m.adam_step(lr=lr)
+        return losses
 
 
 def kl_weight_at(args, t):
@@ -97,13 +133,14 @@ def kl_weight_at(args, t):
 
 
 def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
-    """train.py:56-114.  ``model`` exposes train_step(..., with_adam=False) / adam_step / flat_params / flat_grads
-    (Sg2ScVAEModel on the GPU; tests plug a CPU stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs."""
-    reduce_grads = FlatGradAllReduce(world)
+    """train.py:56-114.  ``model`` exposes train_step(..., with_adam=False) / adam_step / flat_params / flat_grads and,
+    optionally, train_step_begin / train_step_finish / decoder_grad_offset (Sg2ScVAEModel on the GPU; tests plug a CPU
+    stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs."""
     if world > 1:
         dist.broadcast(model.flat_params, 0)                      # identical replicas
         if hasattr(model, "params_changed"):
             model.params_changed()
+    step = DataParallelStep(model, world)
     if hasattr(model, "validate_inputs"):
         model.validate_inputs = False             # no per-batch host sync inside the loop
     lo, hi = shard_range(args.batch_size, rank, world)
@@ -114,16 +151,7 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
         if t == args.eval_mode_after:
             model.eval()
         t += 1
-        b = batch_fn(t, lo, hi)
-        w = kl_weight_at(args, t)
-        if world == 1:
-            losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
-                                      lr=args.learning_rate, with_adam=True, use_graph=use_graph)
-        else:
-            losses = model.train_step(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], kl_weight=w,
-                                      lr=args.learning_rate, with_adam=False, use_graph=use_graph)
-            reduce_grads(model.flat_grads)
-            model.adam_step(lr=args.learning_rate)
+        losses = step(batch_fn(t, lo, hi), kl_weight_at(args, t), args.learning_rate, use_graph=use_graph)
         if t % args.print_every == 0 or t == args.num_iterations:
             vals = [float(x) for x in losses.detach().cpu()]          # the only host sync, every print_every steps
             if not math.isfinite(vals[3]):

@@ -263,16 +263,14 @@ def main():
     eps = torch.randn(O, 64, device="cuda")
     stream = torch.cuda.Stream()
     use_graph = not args.no_graph
-    inv_world = 1.0 / world
+    T = importlib.import_module("3d_sln_amd.host.train")
+    # N > 1: backward, ONE all-reduce of the 15.5 MB flat gradient buffer (averaging inside RCCL), fused Adam - the trainer's
+    # own step (host/train.py::DataParallelStep; SLN_DP_OVERLAP=1 ships the decoder half under the encoder's backward)
+    dp_step = T.DataParallelStep(model, world, force=force_dp)
+    bdict = dict(objs=batch[0], triples=batch[1], boxes=batch[2], angles=batch[3], attributes=batch[4])
 
     def step():
-        if not dp:
-            return model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=True)
-        losses = model.train_step(*batch, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=use_graph, with_adam=False)
-        dist.all_reduce(model.flat_grads)                 # ONE collective per step: 15.5 MB fp32 over xGMI
-        model.flat_grads.mul_(inv_world)
-        model.adam_step(lr=1e-4)
-        return losses
+        return dp_step(bdict, 0.1, 1e-4, use_graph=use_graph, eps=eps)
 
     def barrier():
         torch.cuda.synchronize()
@@ -293,6 +291,17 @@ def main():
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+    coll_us = None
+    if dp:                                     # the same collective on its own, after the timed region
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(25):
+                if i == 5:
+                    e0.record()
+                dp_step._reduce(model.flat_grads, False)
+            e1.record()
+        torch.cuda.synchronize()
+        coll_us = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
     final_loss = float(losses[3].item())
     ms_per_step = dt / args.steps * 1e3
     value = args.graphs * world * args.steps / dt
@@ -307,7 +316,7 @@ def main():
                                "Sg2ScVAE train step at train.py defaults (embedding_dim=64, 5+5 GraphTripleConv, BatchNorm)"
                                % (args.graphs, args.objs, args.triples),
                    "O": int(O), "T": int(b["triples"].shape[0]), "hipgraph": bool(use_graph),
-                   "parallelism": "dp%d" % world, "collective": ("1 all-reduce of %d fp32 grads/step" % model.flat_grads.numel()) if dp else None, "final_total_loss": round(final_loss, 5)},
+                   "parallelism": "dp%d" % world, "collective": ("all-reduce(avg) of %d fp32 grads/step%s" % (model.flat_grads.numel(), " in 2 buckets, decoder half overlapped with the encoder backward" if dp_step.overlap else "")) if dp else None, "allreduce_us_standalone": coll_us, "final_total_loss": round(final_loss, 5)},
     }
 
     solo = world == 1          # the side legs and the CPU baseline are single-GPU measurements (rank 0 at N = 1 only)

@@ -146,9 +146,13 @@ int sln_vae_adam_step(SlnVae* h, float lr, void* stream);
 int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream);       /* restore the step counter (checkpoint resume) */
 
 /* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward and
- * (with_adam != 0) the Adam update.  `use_graph`: replay a captured hipGraph while shapes are unchanged
- * (needs a non-default stream).  The data-parallel trainer calls it with with_adam = 0, enqueues its
- * RCCL all-reduce of flat_grads on the same stream, then calls sln_vae_adam_step. */
+ * (with_adam == SLN_TRAIN_FULL) the Adam update.  `use_graph`: replay a captured hipGraph while shapes are unchanged
+ * (needs a non-default stream).  The data-parallel trainer either calls it with SLN_TRAIN_BACKWARD, all-reduces
+ * flat_grads and calls sln_vae_adam_step, or - to overlap the collective with the backward pass - runs the iteration
+ * in two halves: SLN_TRAIN_UPTO_DECODER returns (enqueues) everything up to the point where the gradients of the
+ * decoder-side parameters are final, SLN_TRAIN_ENCODER_BWD the rest; the all-reduce of the decoder half of flat_grads
+ * runs on another stream in between.  `losses_out` is written by every mode except SLN_TRAIN_ENCODER_BWD. */
+enum { SLN_TRAIN_BACKWARD = 0, SLN_TRAIN_FULL = 1, SLN_TRAIN_UPTO_DECODER = 2, SLN_TRAIN_ENCODER_BWD = 3 };
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
                        int with_adam, void* stream);
 

@@ -21,8 +21,9 @@ def _free_port():
     return p
 
 
-class CpuStandIn:
-    """Same surface as Sg2ScVAEModel for train(): flat_params / flat_grads / train_step(with_adam) / adam_step."""
+class CpuStandInPlain:
+    """Same surface as Sg2ScVAEModel for train(): flat_params / flat_grads / train_step(with_adam) / adam_step.  Without the
+    two-half iteration: DataParallelStep must fall back to one all-reduce after the whole backward."""
 
     def __init__(self, cfg, seed):
         self.cfg, self.sd = cfg, vae_ref.init_state(cfg, seed)
@@ -69,14 +70,47 @@ class CpuStandIn:
         self.flat_params.addcdiv_(self.m, denom, value=-lr / (1 - 0.9 ** self.t))
 
 
-def _worker(rank, world, port, out_dir):
+class CpuStandIn(CpuStandInPlain):
+    """... plus the two-half iteration (train_step_begin / train_step_finish / decoder_grad_offset) of the overlapped all-reduce."""
+
+    @property
+    def decoder_grad_offset(self):
+        split, o, offs = sum(self.sizes), 0, []
+        for k, n in zip(self.keys, self.sizes):
+            offs.append((k, o)); o += n
+        for k, start in reversed(offs):
+            if not k.startswith(("gconv_net_dc.", "box_net.", "angle_net.")):
+                break
+            split = start
+        return split
+
+    def train_step_begin(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None, use_graph=True):
+        """everything is computed here, but only the decoder half of the gradients is handed out (as on the GPU, where
+        the encoder half does not exist yet); a trainer that reduces the lower half too early averages zeros"""
+        keep = self.flat_grads
+        self.flat_grads = torch.zeros_like(keep)
+        losses = self.train_step(objs, triples, boxes, angles, attributes, kl_weight=kl_weight, lr=lr, with_adam=False)
+        self._late, self.flat_grads = self.flat_grads, keep
+        s = self.decoder_grad_offset
+        self.flat_grads[:s] = 0.0
+        self.flat_grads[s:] = self._late[s:]
+        return losses
+
+    def train_step_finish(self, use_graph=True):
+        s = self.decoder_grad_offset
+        self.flat_grads[:s] = self._late[:s]
+
+
+def _worker(rank, world, port, out_dir, two_halves):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     T = pkg("host.train")
     cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
-    model = CpuStandIn(cfg, seed=5 + rank)                       # different init: the broadcast must fix it
+    model = (CpuStandIn if two_halves else CpuStandInPlain)(cfg, seed=5 + rank)      # different init: the broadcast must fix it
+    os.environ["SLN_DP_OVERLAP"] = "1"                          # opt in; a model without the two-half API must still fall back
+    assert T.DataParallelStep(model, world).overlap == two_halves
     args = T.build_parser().parse_args(["--batch_size", "24", "--num_iterations", "1", "--print_every", "1000"])
     full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
 
@@ -90,9 +124,12 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_step_matches_gradient_average(tmp_path):
+@pytest.mark.parametrize("two_halves", [True, False])
+def test_two_rank_step_matches_gradient_average(tmp_path, two_halves):
+    """two_halves: all-reduce of the decoder half between the two halves of backward, then the rest (the default on the
+    GPU); otherwise one all-reduce after the whole backward."""
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, str(tmp_path), two_halves), nprocs=2, join=True)
     p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
     g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
     assert (p0 == p1).all() and (g0 == g1).all(), "replicas diverged"

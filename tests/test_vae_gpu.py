@@ -231,6 +231,41 @@ def test_graph_replay_matches_eager():
     assert np.mean(d > 1e-5) < 0.02, np.mean(d > 1e-5)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_half_iteration_equals_the_whole_one(use_graph):
+    """SLN_TRAIN_UPTO_DECODER + SLN_TRAIN_ENCODER_BWD == SLN_TRAIN_BACKWARD, and after the first half the decoder-side
+    gradients (the upper part of flat_grads, what the overlapped all-reduce ships first) are already final."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    b = vae_ref.synth_batch(8, 12, 20, seed=4, cfg=cfg)
+    eps = torch.randn(b[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(1))
+    dev = _dev(*b[:5], eps)
+    model = _model(cfg, vae_ref.init_state(cfg, seed=2)).train()
+    split = model.decoder_grad_offset
+    names = [n for n, _ in model.named_parameters()]
+    assert 0 < split < model.flat_grads.numel() and any(n.startswith("gconv_net_dc.") for n in names)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for rep in range(2):                                          # second round replays the captured graphs
+            l0 = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-3, eps=dev[5], use_graph=use_graph, with_adam=False)
+            whole = model.flat_grads.clone()
+            model.flat_grads.fill_(7.0)                               # the first half must zero and rewrite everything it owns
+            l1 = model.train_step_begin(*dev[:5], kl_weight=0.1, lr=1e-3, eps=dev[5], use_graph=use_graph)
+            upper = model.flat_grads[split:].clone()
+            model.train_step_finish(use_graph=use_graph)
+            halves = model.flat_grads.clone()
+            torch.cuda.synchronize()
+            gs = float(whole.abs().max())
+            assert_close(l1.cpu().numpy(), l0.cpu().numpy(), "losses", rtol=1e-6)
+            assert_close(upper.cpu().numpy(), whole[split:].cpu().numpy(), "decoder half after the first half", rtol=1e-5, atol=1e-6 * gs)
+            assert_close(halves.cpu().numpy(), whole.cpu().numpy(), "all gradients after both halves", rtol=1e-5, atol=1e-6 * gs)
+            assert float(whole[:split].abs().max()) > 0
+    # the second half alone is refused
+    fresh = _model(cfg, vae_ref.init_state(cfg, seed=2)).train()
+    fresh._set_batch(*dev[:5])
+    with pytest.raises(Exception):
+        fresh.train_step_finish(use_graph=False)
+
+
 # ----------------------------------------------------------------------------- BASELINE config c2
 def test_c2_full_size_train_step_vs_oracle():
     """Batch=64 x (32 objects, 64 triples) at train.py defaults: O=2048, T=4096 (BASELINE.json configs[1])."""
