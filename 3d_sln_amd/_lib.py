@@ -63,6 +63,13 @@ class SlnGraphBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ids", "objs", "boxes", "triples", "angles", "attributes", "obj_to_img", "triple_to_img")]
 
 
+class SlnRefineLoss(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("B", "image_size", "pooled_size", "channels", "sem0", "n_sem", "dep0", "n_dep", "n_scales",
+                                       "stage1_stride")] + \
+               [(n, C.c_void_p) for n in ("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w")] + \
+               [("max_col_entries", C.c_int), ("reserved", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
 # (tests/test_abi.py checks the header against this table and against the built library).
 SIGNATURES = {
@@ -130,6 +137,11 @@ SIGNATURES = {
                                  C.POINTER(SlnGraphBatch), C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_refine_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sln_refine_loss_init": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, C.c_void_p]),
+    "sln_refine_pool": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_refine_loss_forward": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_refine_loss_backward": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,383 @@
+// Refinement loss of the layout-refinement loop (testing/test_render_refine.py:192-215 PSP_pool_new, :332-356 the loss):
+//
+//   iter[:, -1][sum(iter[:, 41:], 1) < 0.5] = 1                                   null regions
+//   depth = L1( cat_s pool_s(iter[:, 41:]), cat_s pool_s(target[:, 41:]) ) * 0.5   pool_s = bilinear(align_corners) to s x s,
+//   sem   = sum_s CE( pool_s(iter[:, 1:41]), argmax labels of the target ) / 800            then bilinear to 96 x 96
+//   loss  = 100 * depth + 100 * sem  (+ 2 * size_loss, added by the caller)
+//
+// In torch this is ~200 small launches per iteration (16 resamples forward and backward, softmax / nll per scale, fills, cats)
+// and was 60 % of a refinement iteration.  Here: null mask, one resampling kernel for the 4 scales x 69 channels (both
+// interpolation stages in registers, same order of operations as upsample_bilinear2d), one loss kernel that leaves
+// d loss / d pooled in place of the pooled maps, and for backward ONE gather kernel through the transposed resampling
+// operator (a bilinear DOWN-sample without anti-aliasing reads few input pixels, so the image gradient is sparse; every
+// input pixel sums the few pooled pixels that read it - no atomics).  The target's pooled depth maps and labels are
+// constants of a room; the host derives them from sln_refine_pool of the target (the same resampling kernel).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sln_common.h"
+#include "sln_hip.h"
+
+namespace {
+
+constexpr int MAX_SCALES = 4;
+
+struct RefineDims {
+  int B, S, P, C;                 // batch, image size, pooled size, image channels (70)
+  int sem0, n_sem, dep0, n_dep;   // semantic channels [sem0, sem0 + n_sem), depth channels [dep0, dep0 + n_dep) (contiguous)
+  int n_scales, pmax;             // pmax: row length of the stage-1 tables (largest intermediate size)
+};
+
+__global__ void null_mask_kernel(const float* __restrict__ img, RefineDims d, unsigned char* __restrict__ null) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long plane = (long)d.S * d.S;
+  if (i >= d.B * plane) return;
+  const long b = i / plane, pix = i % plane;
+  const float* p = img + (b * d.C + d.dep0) * plane + pix;
+  float s = 0.f;
+  for (int c = 0; c < d.n_dep; ++c) s += p[c * plane];
+  null[i] = s < 0.5f ? 1 : 0;
+}
+
+// pooled[b][s][cc][oy][ox], cc = channel - sem0 over the n_sem + n_dep loss channels.  One thread resamples one pooled pixel
+// of CG consecutive channels: the 12 table entries that locate its 16 taps are loaded once per thread, not once per channel.
+constexpr int CG = 8;
+__global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ img, const unsigned char* __restrict__ null, const int null_fill,
+                                                   RefineDims d,
+                                                   const int* __restrict__ s2_k0, const int* __restrict__ s2_k1, const float* __restrict__ s2_l1,
+                                                   const int* __restrict__ s1_i0, const int* __restrict__ s1_i1, const float* __restrict__ s1_l1,
+                                                   float* __restrict__ pooled) {
+  const int nc = d.n_sem + d.n_dep, ng = (nc + CG - 1) / CG;
+  const long pp = (long)d.P * d.P;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)d.B * d.n_scales * ng * pp) return;
+  const int ox = (int)(i % d.P), oy = (int)((i / d.P) % d.P);
+  const int cg = (int)((i / pp) % ng), s = (int)((i / (pp * ng)) % d.n_scales), b = (int)(i / (pp * ng * d.n_scales));
+  const long plane = (long)d.S * d.S;
+  const int ky[2] = {s2_k0[s * d.P + oy], s2_k1[s * d.P + oy]}, kx[2] = {s2_k0[s * d.P + ox], s2_k1[s * d.P + ox]};
+  const float ly1 = s2_l1[s * d.P + oy], lx1 = s2_l1[s * d.P + ox], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  int yy[2][2], xx[2][2]; float hh[2], ww[2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    yy[a][0] = s1_i0[s * d.pmax + ky[a]]; yy[a][1] = s1_i1[s * d.pmax + ky[a]]; hh[a] = s1_l1[s * d.pmax + ky[a]];
+    xx[a][0] = s1_i0[s * d.pmax + kx[a]]; xx[a][1] = s1_i1[s * d.pmax + kx[a]]; ww[a] = s1_l1[s * d.pmax + kx[a]];
+  }
+  const unsigned char* nm = null + (long)b * plane;
+  float* dst = pooled + ((long)(b * d.n_scales + s) * nc) * pp + (long)oy * d.P + ox;
+  for (int cc = cg * CG; cc < min(cg * CG + CG, nc); ++cc) {
+    const int c = d.sem0 + cc;
+    const bool fill = null_fill && c == d.dep0 + d.n_dep - 1;       // the last depth channel is set to 1 where no class has depth
+    const float* src = img + ((long)b * d.C + c) * plane;
+    float inter[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int y0 = yy[a][0], y1 = yy[a][1];
+      const float h1 = hh[a], h0 = 1.f - h1;
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int x0 = xx[e][0], x1 = xx[e][1];
+        const float w1 = ww[e], w0 = 1.f - w1;
+        float v00 = src[(long)y0 * d.S + x0], v01 = src[(long)y0 * d.S + x1], v10 = src[(long)y1 * d.S + x0], v11 = src[(long)y1 * d.S + x1];
+        if (fill) {
+          v00 = nm[(long)y0 * d.S + x0] ? 1.f : v00; v01 = nm[(long)y0 * d.S + x1] ? 1.f : v01;
+          v10 = nm[(long)y1 * d.S + x0] ? 1.f : v10; v11 = nm[(long)y1 * d.S + x1] ? 1.f : v11;
+        }
+        inter[a][e] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);     // upsample_bilinear2d's expression
+      }
+    }
+    dst[(long)cc * pp] = ly0 * (lx0 * inter[0][0] + lx1 * inter[0][1]) + ly1 * (lx0 * inter[1][0] + lx1 * inter[1][1]);
+  }
+}
+
+// one thread per pooled pixel of one scale and part (blockIdx.y: 0 = log-softmax / NLL over the semantic channels, 1.. = |.| over
+// DCH depth channels); overwrites pooled with d loss / d pooled.  partial = per-block {sum |diff|, sum_s CE_s / 800 / valid count}.
+constexpr int DCH = 8;               // depth channels per thread of loss_kernel's parts 1..
+template <int NSEM>
+__global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, RefineDims d, const float* __restrict__ tgt_depth,
+                                                   const int* __restrict__ labels, const float* __restrict__ inv_count,
+                                                   float2* __restrict__ partial) {
+  const int nc = d.n_sem + d.n_dep;
+  const long pp = (long)d.P * d.P;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)d.B * d.n_scales * pp;
+  float l_abs = 0.f, l_ce = 0.f;
+  if (i < total) {
+    const long pix = i % pp;
+    const int s = (int)((i / pp) % d.n_scales), b = (int)(i / (pp * d.n_scales));
+    float* p = pooled + ((long)(b * d.n_scales + s) * nc) * pp + pix;
+    if (blockIdx.y == 0) {
+      const int t = labels[i];
+      float v[NSEM];
+#pragma unroll
+      for (int c = 0; c < NSEM; ++c) v[c] = p[c * pp];
+      if (t >= 0) {
+        float m = v[0];
+#pragma unroll
+        for (int c = 1; c < NSEM; ++c) m = fmaxf(m, v[c]);
+        float z = 0.f;
+#pragma unroll
+        for (int c = 0; c < NSEM; ++c) z += expf(v[c] - m);
+        const float lse = m + logf(z);
+        const float k = inv_count[s] * (1.f / 800.f);
+        float vt = 0.f;
+#pragma unroll
+        for (int c = 0; c < NSEM; ++c) {
+          vt = c == t ? v[c] : vt;
+          p[c * pp] = (expf(v[c] - lse) - (c == t ? 1.f : 0.f)) * (k * 100.f);
+        }
+        l_ce = (lse - vt) * k;
+      } else {
+#pragma unroll
+        for (int c = 0; c < NSEM; ++c) p[c * pp] = 0.f;
+      }
+    } else {                                                                       // depth channels, DCH per thread
+      const float gd = 50.f / (float)((double)d.B * d.n_scales * d.n_dep * pp);      // 100 * 0.5 / numel
+      const float* tg = tgt_depth + ((long)(b * d.n_scales + s) * d.n_dep) * pp + pix;
+      float* q = p + (long)d.n_sem * pp;
+      const int c0 = ((int)blockIdx.y - 1) * DCH;
+      float a[DCH], t[DCH];
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) { const int c = min(c0 + u, d.n_dep - 1); a[u] = q[c * pp]; t[u] = tg[c * pp]; }
+#pragma unroll
+      for (int u = 0; u < DCH; ++u) {
+        if (c0 + u < d.n_dep) {
+          const float diff = a[u] - t[u];
+          l_abs += fabsf(diff);
+          q[(c0 + u) * pp] = diff > 0.f ? gd : (diff < 0.f ? -gd : 0.f);
+        }
+      }
+    }
+  }
+  // block reduction; one partial per block (a same-address atomic per block is serialised on the memory side: with 1440
+  // blocks the three atomics of the first version cost 60 us), summed in a fixed order by loss_finalize_kernel
+  __shared__ float red[2][2];
+  for (int o = 32; o > 0; o >>= 1) { l_abs += __shfl_down(l_abs, o, 64); l_ce += __shfl_down(l_ce, o, 64); }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[wave][0] = l_abs; red[wave][1] = l_ce; }
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = make_float2(red[0][0] + red[1][0], red[0][1] + red[1][1]);
+}
+
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float2* __restrict__ partial, int n, RefineDims d, float* __restrict__ loss_out) {
+  __shared__ double red[4][2];
+  double a = 0.0, c = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) { const float2 v = partial[i]; a += (double)v.x; c += (double)v.y; }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    a = red[0][0] + red[1][0] + red[2][0] + red[3][0]; c = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+    const double depth = 0.5 * a / ((double)d.B * d.n_scales * d.n_dep * d.P * d.P);
+    loss_out[0] = (float)(100.0 * depth + 100.0 * c); loss_out[1] = (float)depth; loss_out[2] = (float)c;
+  }
+}
+
+// d loss / d image[b][c][y][x] = gscale * sum_s sum_{(oy, wy) in col_s(y)} sum_{(ox, wx) in col_s(x)} wy wx dpooled[b][s][c][oy][ox]
+__global__ __launch_bounds__(256) void refine_bwd_kernel(const float* __restrict__ dpooled, const unsigned char* __restrict__ null, RefineDims d,
+                                                         const int* __restrict__ col_ptr, const int* __restrict__ col_out,
+                                                         const float* __restrict__ col_w, const float* __restrict__ gscale,
+                                                         float* __restrict__ dimg) {
+  const long plane = (long)d.S * d.S;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)d.B * d.C * plane) return;
+  const int x = (int)(i % d.S), y = (int)((i / d.S) % d.S);
+  const int c = (int)((i / plane) % d.C), b = (int)(i / (plane * d.C));
+  const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
+  float g = 0.f;
+  if (cc >= 0 && cc < nc && !(c == d.dep0 + d.n_dep - 1 && null[(long)b * plane + (long)y * d.S + x])) {
+    const long pp = (long)d.P * d.P;
+    for (int s = 0; s < d.n_scales; ++s) {
+      const int* cp = col_ptr + s * (d.S + 1);
+      const int yb = cp[y], ye = cp[y + 1], xb = cp[x], xe = cp[x + 1];
+      if (yb == ye || xb == xe) continue;
+      const float* dp = dpooled + ((long)(b * d.n_scales + s) * nc + cc) * pp;
+      for (int e = yb; e < ye; ++e) {
+        const float wy = col_w[e];
+        const float* row = dp + (long)col_out[e] * d.P;
+        float r = 0.f;
+        for (int f = xb; f < xe; ++f) r = fmaf(col_w[f], row[col_out[f]], r);
+        g = fmaf(wy, r, g);
+      }
+    }
+    g *= gscale[0];
+  }
+  dimg[i] = g;
+}
+
+// The same sum, separable, with one workgroup per (strip of ROWS image rows, channel):
+//   stage 1  T[s][r][ox] = sum_{(oy, wy) in col_s(y0 + r)} wy * dpooled[s][c][oy][ox]      rows of dpooled, coalesced, into LDS
+//   stage 2  g[r][x]     = sum_s sum_{(ox, wx) in col_s(x)} wx * T[s][r][ox]                 LDS reads only
+// A lane owns one image column and keeps that column's tap lists (padded to MAXX entries per scale, weight 0) in registers
+// for all rows of the strip.  The generic kernel above walks four CSR ranges per (pixel, channel) through dependent global
+// loads (136 us per 256 x 256 x 70 gradient; 61 us with its inner loop padded, L1-issue bound); this one takes 41 us.
+template <int MAXX, int ROWS, int PMAX>
+__global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __restrict__ dpooled, const unsigned char* __restrict__ null,
+                                                             RefineDims d, const int* __restrict__ col_ptr, const int* __restrict__ col_out,
+                                                             const float* __restrict__ col_w, const float* __restrict__ gscale,
+                                                             float* __restrict__ dimg) {
+  __shared__ float T[MAX_SCALES][ROWS][PMAX];
+  const int x = blockIdx.z * 256 + threadIdx.x;
+  const int c = blockIdx.y % d.C, b = blockIdx.y / d.C;
+  const int y0 = blockIdx.x * ROWS;
+  const bool active = x < d.S;
+  const int xs = active ? x : d.S - 1;
+  const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
+  float* out = dimg + ((long)(b * d.C + c) * d.S) * d.S;
+  if (cc < 0 || cc >= nc) {
+    if (active) for (int r = 0; r < ROWS && y0 + r < d.S; ++r) out[(long)(y0 + r) * d.S + x] = 0.f;
+    return;
+  }
+  int ox[MAX_SCALES][MAXX]; float wx[MAX_SCALES][MAXX];
+#pragma unroll
+  for (int s = 0; s < MAX_SCALES; ++s) {
+    const int sv = s < d.n_scales ? s : 0;
+    const int xb = col_ptr[sv * (d.S + 1) + xs], xe = s < d.n_scales ? col_ptr[sv * (d.S + 1) + xs + 1] : xb;
+#pragma unroll
+    for (int f = 0; f < MAXX; ++f) {
+      const bool v = xb + f < xe;
+      ox[s][f] = v ? col_out[xb + f] : 0;
+      wx[s][f] = v ? col_w[xb + f] : 0.f;
+    }
+  }
+  // the strip's row lists, padded like the column lists, so that stage 1 issues MAXX independent loads per element
+  __shared__ int yo[MAX_SCALES * ROWS][MAXX];
+  __shared__ float yw[MAX_SCALES * ROWS][MAXX];
+  for (int i = threadIdx.x; i < d.n_scales * ROWS * MAXX; i += 256) {
+    const int e = i % MAXX, r = (i / MAXX) % ROWS, s = i / (MAXX * ROWS);
+    const int y = min(y0 + r, d.S - 1);
+    const int yb = col_ptr[s * (d.S + 1) + y], ye = col_ptr[s * (d.S + 1) + y + 1];
+    const bool v = yb + e < ye && y0 + r < d.S;
+    yo[s * ROWS + r][e] = v ? col_out[yb + e] : 0;
+    yw[s * ROWS + r][e] = v ? col_w[yb + e] : 0.f;
+  }
+  __syncthreads();
+  const long pp = (long)d.P * d.P;
+  for (int i = threadIdx.x; i < d.n_scales * ROWS * d.P; i += 256) {
+    const int o = i % d.P, r = (i / d.P) % ROWS, s = i / (d.P * ROWS);
+    const float* dp = dpooled + ((long)(b * d.n_scales + s) * nc + cc) * pp + o;
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < MAXX; ++e) t = fmaf(yw[s * ROWS + r][e], dp[(long)yo[s * ROWS + r][e] * d.P], t);
+    T[s][r][o] = t;
+  }
+  __syncthreads();
+  if (!active) return;
+  const float gs = gscale[0];
+  const bool last = c == d.dep0 + d.n_dep - 1;
+  for (int r = 0; r < ROWS && y0 + r < d.S; ++r) {
+    float g = 0.f;
+#pragma unroll
+    for (int s = 0; s < MAX_SCALES; ++s)
+#pragma unroll
+      for (int f = 0; f < MAXX; ++f) g = fmaf(wx[s][f], T[s][r][ox[s][f]], g);
+    if (last && null[(long)b * d.S * d.S + (long)(y0 + r) * d.S + x]) g = 0.f;
+    out[(long)(y0 + r) * d.S + x] = g * gs;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep) {
+  if (B <= 0 || image_size <= 0 || pooled_size <= 0 || n_scales <= 0 || n_scales > MAX_SCALES || n_sem <= 0 || n_dep <= 0) return SLN_E_BADARG;
+  const int64_t pooled = (int64_t)B * n_scales * (n_sem + n_dep) * pooled_size * pooled_size * 4;
+  const int64_t mask = ((int64_t)B * image_size * image_size + 255) / 256 * 256;
+  const int64_t nblk = (((int64_t)B * n_scales * pooled_size * pooled_size + 127) / 128) * (1 + (n_dep + DCH - 1) / DCH);
+  return pooled + mask + nblk * 8;                    // + one float2 partial per block of loss_kernel
+}
+
+static int carve(const SlnRefineLoss* L, void* workspace, float** pooled, unsigned char** mask, float2** partial) {
+  char* p = (char*)workspace;
+  const int64_t np = (int64_t)L->B * L->n_scales * (L->n_sem + L->n_dep) * L->pooled_size * L->pooled_size * 4;
+  const int64_t nm = ((int64_t)L->B * L->image_size * L->image_size + 255) / 256 * 256;
+  *pooled = (float*)p; *mask = (unsigned char*)(p + np); *partial = (float2*)(p + np + nm);
+  return 0;
+}
+
+static int check(const SlnRefineLoss* L) {
+  if (!L || L->B <= 0 || L->image_size <= 0 || L->pooled_size <= 0 || L->n_scales <= 0 || L->n_scales > MAX_SCALES) return SLN_E_BADARG;
+  if (L->n_sem != 40) return SLN_E_UNSUPPORTED;      // NYU-40 one-hot block of the scene tensor (models/diff_render.py:3)
+  if (L->sem0 < 0 || L->dep0 != L->sem0 + L->n_sem || L->dep0 + L->n_dep > L->channels || L->n_dep <= 0) return SLN_E_BADARG;
+  if (!L->s2_k0 || !L->s2_k1 || !L->s2_l1 || !L->s1_i0 || !L->s1_i1 || !L->s1_l1 || !L->col_ptr || !L->col_out || !L->col_w) return SLN_E_BADARG;
+  return 0;
+}
+
+static RefineDims dims_of(const SlnRefineLoss* L) {
+  RefineDims d;
+  d.B = L->B; d.S = L->image_size; d.P = L->pooled_size; d.C = L->channels; d.sem0 = L->sem0; d.n_sem = L->n_sem; d.dep0 = L->dep0;
+  d.n_dep = L->n_dep; d.n_scales = L->n_scales; d.pmax = L->stage1_stride;
+  return d;
+}
+
+int sln_refine_loss_init(const SlnRefineLoss* L, void* workspace, void* stream) {
+  int r = check(L);
+  if (r) return r;
+  if (!workspace) return SLN_E_BADARG;
+  float* pooled; unsigned char* mask; float2* partial;
+  carve(L, workspace, &pooled, &mask, &partial);
+  (void)pooled; (void)mask; (void)partial; (void)stream;       // nothing to arm: every call rewrites what it reads
+  return 0;
+}
+
+static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float* image, int null_fill, unsigned char* mask, float* pooled,
+                        hipStream_t st) {
+  const long npix = (long)d.B * d.S * d.S;
+  if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask);
+  const long np = (long)d.B * d.n_scales * sln_cdiv(d.n_sem + d.n_dep, CG) * d.P * d.P;
+  hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1, L->s2_l1,
+                     L->s1_i0, L->s1_i1, L->s1_l1, pooled);
+}
+
+int sln_refine_pool(const SlnRefineLoss* L, const float* image, int null_fill, void* workspace, float* pooled_out, void* stream) {
+  int r = check(L);
+  if (r) return r;
+  if (!image || !workspace || !pooled_out) return SLN_E_BADARG;
+  const RefineDims d = dims_of(L);
+  float* pooled; unsigned char* mask; float2* partial;
+  carve(L, workspace, &pooled, &mask, &partial);
+  launch_pool(L, d, image, null_fill, mask, pooled_out, (hipStream_t)stream);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const float* target_depth_pooled, const int32_t* labels,
+                            const float* inv_count, void* workspace, float* loss_out, void* stream) {
+  int r = check(L);
+  if (r) return r;
+  if (!image || !target_depth_pooled || !labels || !inv_count || !workspace || !loss_out) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const RefineDims d = dims_of(L);
+  float* pooled; unsigned char* mask; float2* partial;
+  carve(L, workspace, &pooled, &mask, &partial);
+  launch_pool(L, d, image, 1, mask, pooled, st);
+  const long nl = (long)d.B * d.n_scales * d.P * d.P;
+  const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
+  hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial);
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, const float* grad_scale, float* grad_image, void* stream) {
+  int r = check(L);
+  if (r) return r;
+  if (!workspace || !grad_scale || !grad_image) return SLN_E_BADARG;
+  const RefineDims d = dims_of(L);
+  float* pooled; unsigned char* mask; float2* partial;
+  carve(L, const_cast<void*>(workspace), &pooled, &mask, &partial);
+  if (L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
+    constexpr int ROWS = 16;
+    hipLaunchKernelGGL((refine_bwd_sep_kernel<5, ROWS, 96>), dim3(sln_cdiv(d.S, ROWS), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image);
+  } else {
+    const long n = (long)d.B * d.C * d.S * d.S;
+    hipLaunchKernelGGL(refine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, mask, d, L->col_ptr,
+                       L->col_out, L->col_w, grad_scale, grad_image);
+  }
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 
 from . import diff_render as DR
 from . import synthetic
+from .. import _lib
 
 DO_NOT_VIS = ["wall", "ceiling", "floor", "person", "door", "window", "curtain", "blinds"]
 
@@ -167,13 +168,106 @@ def refinement_loss(iter_image, target, target_container, size_loss):
     return depth_loss * 100 + sem * 100 + size_loss * 2.0, depth_loss, sem
 
 
-def target_labels(target):
+def target_labels(target, sizes=(32, 48, 64, 96)):
     out = []
-    for pooled in psp_pool(target[:, 1:41], as_list=True):
+    for pooled in psp_pool(target[:, 1:41], sizes, as_list=True):
         flat = torch.argmax(pooled, dim=1, keepdim=True)
         flat[torch.sum(pooled, dim=1, keepdim=True) < 0.5] = -100
         out.append(flat.detach())
     return out
+
+
+def _bilinear_taps(in_size, out_size, align_corners):
+    """Source indices and weight of the upper neighbour exactly as upsample_bilinear2d derives them (fp32 arithmetic)."""
+    dst = np.arange(out_size, dtype=np.float32)
+    if align_corners:
+        scale = np.float32(in_size - 1) / np.float32(out_size - 1) if out_size > 1 else np.float32(0)
+        src = scale * dst
+    else:
+        src = np.maximum(np.float32(in_size) / np.float32(out_size) * (dst + np.float32(0.5)) - np.float32(0.5), np.float32(0))
+    i0 = src.astype(np.int32)
+    i1 = i0 + (i0 < in_size - 1)
+    return i0, i1.astype(np.int32), (src - i0.astype(np.float32)).astype(np.float32)
+
+
+class _RefineLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, rl):
+        image = image.contiguous()
+        out = torch.empty(3, device=image.device)
+        _lib.check(_lib.lib().sln_refine_loss_forward(rl.desc, _lib.ptr(image), _lib.ptr(rl.target_depth), _lib.ptr(rl.labels),
+                                                      _lib.ptr(rl.inv_count), _lib.ptr(rl.ws), _lib.ptr(out), _lib.current_stream_ptr()),
+                   "sln_refine_loss_forward")
+        ctx.rl, ctx.shape = rl, image.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        rl = ctx.rl
+        g = torch.empty(ctx.shape, device=gout.device)
+        scale = gout[0:1].contiguous()                  # d/d(out[0]); out[1:] (the two parts) are reporting values
+        _lib.check(_lib.lib().sln_refine_loss_backward(rl.desc, _lib.ptr(rl.ws), _lib.ptr(scale), _lib.ptr(g), _lib.current_stream_ptr()),
+                   "sln_refine_loss_backward")
+        return g, None
+
+
+class RefineLoss:
+    """``refinement_loss`` for a fixed target as two C calls (csrc/refine_loss.hip) instead of ~200 torch launches.
+    ``rl(image)`` -> tensor [100*depth + 100*sem, depth, sem]; gradients flow to ``image`` through element 0.  The
+    workspace holds d loss / d pooled between forward and backward: one outstanding forward per instance."""
+
+    def __init__(self, target, sizes=(32, 48, 64, 96)):
+        dev = target.device
+        B, C, S, _ = target.shape
+        P, ns, pmax = sizes[-1], len(sizes), max(sizes)
+        s2 = [np.zeros((ns, P), np.int32), np.zeros((ns, P), np.int32), np.zeros((ns, P), np.float32)]
+        s1 = [np.zeros((ns, pmax), np.int32), np.zeros((ns, pmax), np.int32), np.zeros((ns, pmax), np.float32)]
+        ptr, outs, ws_ = [], [], []
+        for k, sz in enumerate(sizes):
+            a = _bilinear_taps(S, sz, True)
+            b = _bilinear_taps(sz, P, False)
+            for dst, src in zip(s1, a):
+                dst[k, :sz] = src
+            for dst, src in zip(s2, b):
+                dst[k] = src
+            R1 = np.zeros((sz, S)); R2 = np.zeros((P, sz))
+            np.add.at(R1, (np.arange(sz), a[0]), 1.0 - a[2].astype(np.float64)); np.add.at(R1, (np.arange(sz), a[1]), a[2].astype(np.float64))
+            np.add.at(R2, (np.arange(P), b[0]), 1.0 - b[2].astype(np.float64)); np.add.at(R2, (np.arange(P), b[1]), b[2].astype(np.float64))
+            comp = R2 @ R1                                             # [P, S]: pooled index <- image index
+            base = sum(len(o) for o in outs)
+            cp = [base]
+            for y in range(S):
+                nz = np.nonzero(comp[:, y])[0]
+                outs.append(nz.astype(np.int32)); ws_.append(comp[nz, y].astype(np.float32))
+                cp.append(cp[-1] + len(nz))
+            ptr.append(np.asarray(cp, np.int32))
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self._keep = [t(x) for x in s2 + s1] + [t(np.stack(ptr)), t(np.concatenate(outs)), t(np.concatenate(ws_))]
+        d = _lib.SlnRefineLoss()
+        d.B, d.image_size, d.pooled_size, d.channels = B, S, P, C
+        d.sem0, d.n_sem, d.dep0, d.n_dep, d.n_scales, d.stage1_stride = 1, 40, 41, C - 41, ns, pmax
+        for name, buf in zip(("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w"), self._keep):
+            setattr(d, name, buf.data_ptr())
+        d.max_col_entries = int(max(len(o) for o in outs))
+        self.desc = d
+        L = _lib.lib()
+        self.ws = torch.empty(int(L.sln_refine_loss_workspace_bytes(B, S, P, ns, 40, C - 41)), dtype=torch.uint8, device=dev)
+        _lib.check(L.sln_refine_loss_init(d, _lib.ptr(self.ws), _lib.current_stream_ptr()), "sln_refine_loss_init")
+        # the target goes through the SAME resampling kernel as the iterates (no null-fill, test_render_refine.py:328-331):
+        # where both images agree the pooled difference is exactly 0, as in the reference
+        pooled = torch.empty(B, ns, C - 1, P, P, device=dev)
+        _lib.check(L.sln_refine_pool(d, _lib.ptr(target.contiguous()), 0, _lib.ptr(self.ws), _lib.ptr(pooled), _lib.current_stream_ptr()),
+                   "sln_refine_pool")
+        self.target_depth = pooled[:, :, 40:].contiguous()                                              # [B, ns, 29, P, P]
+        sem = pooled[:, :, :40]
+        lab = torch.argmax(sem, dim=2)
+        lab[sem.sum(dim=2) < 0.5] = -100                                                                # :341-343
+        self.labels = lab.to(torch.int32).contiguous()                                                  # [B, ns, P, P]
+        cnt = (lab >= 0).sum(dim=(0, 2, 3)).to(torch.float32)
+        self.inv_count = (1.0 / cnt).contiguous()                                                       # 1/0: nan loss, as torch's empty mean
+
+    def __call__(self, image):
+        return _RefineLossFn.apply(image, self)
 
 
 class RefineScene:
@@ -258,11 +352,12 @@ class RefineScene:
 
 
 def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, bank=None, learning_rate=1e-4,
-                      noise_seed=13, image_size=256, capture=False, log=None):
+                      noise_seed=13, image_size=256, capture=False, log=None, fused_loss=True):
     """``finetune_vae`` with the batched ``RefineScene`` and no per-iteration python optimiser objects: the reference builds a
     NEW SGD(momentum=0.1, nesterov) every iteration (test_render_refine.py:286-292), so its step is exactly
     ``p -= lr * (1 + momentum) * grad``; that closed form is applied to ``z`` (lr 2e-4) and to the flat parameter buffer
-    (lr ``learning_rate``/10).  ``capture=True`` records one iteration (decoder, placement, fused render, PSP losses,
+    (lr ``learning_rate``/10).  ``fused_loss``: the PSP-pool / L1 / cross-entropy block runs as ``RefineLoss`` (two C calls)
+    instead of torch ops.  ``capture=True`` records one iteration (decoder, placement, fused render, PSP losses,
     backward, both updates) into a hipGraph and replays it; the noise of the angle soft-argmax is then drawn on the device.
     Returns (losses [iters] tensor on the device, (boxes_pred, angle_idx))."""
     dev = boxes_gt.device
@@ -277,6 +372,7 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
     with torch.no_grad():
         target, _, sizes = scene.render(boxes_gt, angles_gt.float())
     labels = target_labels(target)
+    fused = RefineLoss(target) if fused_loss else None             # the PSP / L1 / cross-entropy block as two C calls
     size_target = sizes.detach().clone()
     n = boxes_gt.shape[0]
     noise = torch.zeros(n, device=dev)
@@ -292,7 +388,10 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
         idx.register_hook(quad_grad)
         idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
         image, size_loss, _ = scene.render(boxes_full, idx, size_target)
-        loss, _, _ = refinement_loss(image, target, labels, size_loss)
+        if fused is not None:
+            loss = fused(image)[0] + size_loss * 2.0
+        else:
+            loss, _, _ = refinement_loss(image, target, labels, size_loss)
         z.grad = None
         flat_grad.zero_()
         loss.backward()

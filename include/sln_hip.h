@@ -232,6 +232,39 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                        const float* grad_final, float* grad_faces, void* stream);
 
 
+/* Refinement loss of the layout-refinement loop (testing/test_render_refine.py:192-215 PSP_pool_new, :332-356):
+ * null-fill of the last depth channel, bilinear(align_corners=True) resampling of the 40 semantic and 29 depth channels of
+ * the [B,70,S,S] scene tensor to each scale and bilinear resampling to pooled_size, L1 against the pooled target depth * 0.5,
+ * sum over the scales of cross-entropy against the target's labels / 800;  loss_out = {100 * depth + 100 * sem, depth, sem}
+ * (the caller adds 2 * size_loss).  All table pointers are DEVICE arrays the caller builds once per geometry:
+ *   stage 2 (scale -> pooled, align_corners=False), per scale and pooled index: source rows k0, k1 and the weight of k1;
+ *   stage 1 (image -> scale, align_corners=True), per scale and scale index (row stride stage1_stride): i0, i1, weight of i1;
+ *   transposed composite operator for backward, CSR per scale over the image index: col_ptr [n_scales][S+1] (global offsets),
+ *   col_out (pooled index), col_w.
+ * forward leaves d loss / d pooled in the workspace, backward gathers it into grad_image [B,70,S,S] (overwritten) times
+ * grad_scale[0] (device scalar: the incoming gradient of loss_out[0]). */
+typedef struct {
+  int B, image_size, pooled_size, channels;     /* 70 channels: diff_render.py:400-434 */
+  int sem0, n_sem, dep0, n_dep;                 /* 1, 40, 41, 29 */
+  int n_scales, stage1_stride;                  /* <= 4 scales (32, 48, 64, 96) */
+  const int32_t* s2_k0; const int32_t* s2_k1; const float* s2_l1;     /* [n_scales][pooled_size] */
+  const int32_t* s1_i0; const int32_t* s1_i1; const float* s1_l1;     /* [n_scales][stage1_stride] */
+  const int32_t* col_ptr; const int32_t* col_out; const float* col_w;
+  int max_col_entries, reserved;                /* longest CSR row (selects the register-list backward kernel when <= 5); 0 = unknown */
+} SlnRefineLoss;
+int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
+int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */
+/* The resampling alone: pooled_out [B][n_scales][n_sem + n_dep][P][P] of `image` (null_fill != 0: with the null-fill of the
+ * last depth channel).  The caller derives the target's pooled depth and labels from it, so that regions where the iterate
+ * equals the target give a difference of exactly 0 (and sign(0) = 0 in the L1 gradient), as in the reference where both go
+ * through the same resampling code. */
+int sln_refine_pool(const SlnRefineLoss* L, const float* image, int null_fill, void* workspace, float* pooled_out, void* stream);
+/* target_depth_pooled [B][n_scales*n_dep][P][P], labels [B][n_scales][P][P] int32 (-100 = ignored), inv_count [n_scales]
+ * (1 / number of non-ignored labels of the scale over the batch) */
+int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const float* target_depth_pooled, const int32_t* labels,
+                            const float* inv_count, void* workspace, float* loss_out, void* stream);
+int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, const float* grad_scale, float* grad_image, void* stream);
+
 /* =============================================================================================
  * C. SPADE generator (models/SPADE_related.py: SPADEGenerator4 :1507-1605, SPADEResnetBlock4 :1457-1505,
  *    SPADE4 :1404-1454, LayerNorm2D :128-149, SEBlock2 :70-85; driver testing/test_SPADE_shade.py:9-13,77-79)

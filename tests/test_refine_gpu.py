@@ -172,3 +172,55 @@ def test_fast_finetune_loop_matches_the_reference_shaped_loop_and_its_graph_repl
         assert_close(runs[mode][1], runs["slow"][1], mode + ": boxes", rtol=1e-3, atol=1e-4)
         assert_close(runs[mode][2], runs["slow"][2], mode + ": parameters", rtol=1e-3, atol=1e-5)
     assert len(set(runs["graph"][0].tolist())) > 1
+
+
+@pytest.mark.parametrize("image_size", [256, 96])
+def test_fused_refinement_loss_matches_the_torch_ops(image_size):
+    """csrc/refine_loss.hip (null-fill, PSP pooling, L1, cross-entropy; backward through the transposed resampling) against
+    the reference's own formulation - F.interpolate / l1_loss / cross_entropy (test_render_refine.py:192-215,328-356) -
+    evaluated on the CPU in fp64 and fp32 on the same two images."""
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    boxes, angles = _inputs("cuda")
+    bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
+    room = boxes[-1].clone()
+    v0, f0, ranges, sizes, _ = R.assemble_scene(boxes, angles, NAMES, bank, room)
+    with torch.no_grad():
+        target = DR.scene_render(v0, f0, ranges, room, image_size=image_size)
+        b2 = boxes + 0.03; b2[-1] = boxes[-1]
+        v, f, ranges, _, _ = R.assemble_scene(b2, angles + 0.7, NAMES, bank, room)
+        img = DR.scene_render(v, f, ranges, room, image_size=image_size)
+    rl = R.RefineLoss(target)
+    x = img.clone().requires_grad_(True)
+    out = rl(x)
+    (out[0] * 1.5).backward()                                     # a non-trivial incoming gradient
+    got = [float(t) for t in out.detach().cpu()]
+    g = x.grad.cpu().numpy() / 1.5
+    # labels: the product derives them from its own resampling of the target; torch's resampling must agree on them
+    lab_t = torch.cat(R.target_labels(target.cpu()), 1)
+    assert (lab_t != rl.labels.cpu().long()).float().mean() < 2e-3
+    labels = [rl.labels[:, k:k + 1].cpu().long() for k in range(rl.labels.shape[1])]
+    ref = {}
+    for dt in (torch.float64, torch.float32):
+        xi = img.cpu().to(dt).requires_grad_(True)
+        loss, dl, sl = R.refinement_loss(xi, target.cpu().to(dt), labels, torch.zeros((), dtype=dt))
+        loss.backward()
+        ref[dt] = ([float(loss.detach()), float(dl.detach()), float(sl.detach())], xi.grad.numpy())
+    r64, r32 = ref[torch.float64], ref[torch.float32]
+    for a, b, nm in zip(got, r64[0], ("total", "depth", "semantic")):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-7, (nm, a, b)
+    # gradient: the L1 part is sign(diff) * const, so pooled pixels whose |diff| is at rounding level may flip; the fp32
+    # evaluation of the reference itself shows how many do
+    scale = np.abs(r64[1]).max()
+    bad = np.abs(g - r64[1]) > 1e-4 * scale
+    bad32 = np.abs(r32[1] - r64[1]) > 1e-4 * scale
+    assert scale > 0 and (g[:, 0] == 0).all()
+    assert bad.mean() <= max(4.0 * bad32.mean(), 1e-5), (bad.mean(), bad32.mean())
+    assert np.abs(g - r64[1]).max() <= 1e-4 * scale + 4.0 * np.abs(r32[1] - r64[1]).max()
+    # identical images: the depth part vanishes exactly and its gradient is exactly zero (both go through the same kernel)
+    y = target.clone().requires_grad_(True)
+    o2 = rl(y)
+    o2[0].backward()
+    filled = y.grad[:, -1].abs().sum() + y.grad[:, 41:-1].abs().sum()
+    null = (target[:, 41:].sum(1) < 0.5)
+    assert float(y.grad[:, 41:-1].abs().max()) == 0.0
+    assert float(y.grad[:, -1][null].abs().max() if null.any() else 0.0) == 0.0 and torch.isfinite(filled)
