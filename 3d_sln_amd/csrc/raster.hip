@@ -228,6 +228,8 @@ __global__ void texture_sample_kernel(const float* __restrict__ faces, const flo
 
 // depth backward, atomic-free: one wavefront per face gathers the pixels it won inside its bounding box
 // (a per-pixel scatter serialises on the 9 atomics of large wall / floor faces: 1.45 ms per 16 rooms).
+// gridDim.y > 1 (few images: the launch lasts as long as the largest face's bounding box walk): the windows of 64 pixels
+// are dealt to gridDim.y wavefronts, which then add their parts atomically.
 __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __restrict__ faces, const int32_t* __restrict__ fi,
                                                                  const float* __restrict__ w, const float* __restrict__ depth,
                                                                  const float* __restrict__ gd, int F, int is,
@@ -258,7 +260,8 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
   const long base = (long)b * is * is;
   // the bounding box as one flat pixel range: narrow boxes keep all 64 lanes busy (a row per iteration used a third of them)
   const int bw = x1 - x0 + 1, npx = bw * (y1 - y0 + 1);
-  for (int pidx = lane; pidx < npx; pidx += 64) {
+  if (64 * (int)blockIdx.y >= npx) return;
+  for (int pidx = lane + 64 * (int)blockIdx.y; pidx < npx; pidx += 64 * (int)gridDim.y) {
     {
       const int y = y0 + pidx / bw, x = x0 + pidx % bw;
       const long q = base + (long)y * is + x;
@@ -281,9 +284,27 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     acc[k] = v;
   }
-  if (lane == 0)
+  if (lane == 0) {
+    if (gridDim.y == 1) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) gfaces[9 * i + k] += acc[k];
+      for (int k = 0; k < 9; ++k) gfaces[9 * i + k] += acc[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k)
+        if (acc[k] != 0.f) atomicAdd(gfaces + 9 * i + k, acc[k]);
+    }
+  }
+}
+
+// Few (image, face) pairs leave the chip idle while the largest faces are walked: split their walks (see the two kernels).
+inline int small_batch_split(long units, int max_split, long budget = 32768) {
+  int s = 1;
+  while (s < max_split && units * s * 2 <= budget) s *= 2;        // stay below `budget` workgroups
+  return s;
+}
+inline int pixel_map_scan_split(long faces_total, int B) {
+  if (B >= 8) return 1;                          // the image -> XCD affinity mapping of the kernel uses a 2-D grid
+  return small_batch_split(faces_total * 6, 16, 131072);
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
   float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
   // an edge longer than PMB_DC steps takes several rounds (chunks) in the same wavefront: one workgroup per chunk filled the
-  // grid with empty workgroups (three out of four), whose dispatch alone cost ~0.25 ms per batch
+  // grid with empty workgroups (three out of four), whose dispatch alone cost ~0.25 ms per batch of 16 rooms
   for (int c_from = d0_from; c_from <= d0_to; c_from += PMB_DC) {
   const int c_to = min(d0_to, c_from + PMB_DC - 1);
   __syncthreads();                              // the LDS tables of the previous round are no longer read
@@ -474,8 +495,11 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int W = s_pre[64];
 
   // ---- phase 2: the scan pixels of all steps, flattened ----
+  // Few images (gridDim.z > 1, pixel_map_scan_split): the launch lasts as long as the longest walk - a wall edge is 64 steps
+  // x up to 256 scan pixels per chunk = 256 windows of two dependent loads each, 150 us - so gridDim.z workgroups repeat
+  // phase 1 (one memory round trip) and deal the windows among themselves.
   int l0 = 0;                                    // row of the previous window's last pixel: rows only move forward
-  for (int w0 = 0; w0 < W; w0 += 64) {
+  for (int w0 = 64 * (int)blockIdx.z; w0 < W; w0 += 64 * (int)gridDim.z) {
     const int w = min(w0 + lane, W - 1);
     int l = l0;                                  // largest l with s_pre[l] <= w: a short walk instead of a 6-step bisection
     while (s_pre[l + 1] <= w) ++l;
@@ -668,8 +692,8 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 28.0 * npix, st);
   (void)npix;
   if ((long)B * F > 0)
-    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F)), dim3(64), 0, st, faces, face_index, weight, depth,
-                       grad_depth, F, image_size, grad_faces);
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), small_batch_split((long)B * F, 8)), dim3(64), 0, st, faces,
+                       face_index, weight, depth, grad_depth, F, image_size, grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -682,7 +706,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, image_size, eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, F, image_size, eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -1014,14 +1038,15 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                      num_classes, 70, grad_final, w.st);
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
-  hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
+  hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
+                     grad_faces);
   const int t32 = sln_cdiv(is, 32);
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
                      num_classes, 70, w.prec, w.precT);
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
                      num_classes, 70, w.st, w.g, w.gT);
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6), dim3(64), 0, st, faces, pix, F, is, pix_eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, F, is, pix_eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
