@@ -63,6 +63,13 @@ class SlnGraphBatch(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ids", "objs", "boxes", "triples", "angles", "attributes", "obj_to_img", "triple_to_img")]
 
 
+class SlnPlacement(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n", "n_vis", "Vm", "Vs", "F", "reserved")] + \
+               [(n, C.c_void_p) for n in ("vis", "model_v", "msize", "mcenter", "shell_v", "faces", "obj_face_ptr")] + \
+               [("ext", C.c_float * 3), ("K", C.c_float * 9), ("R", C.c_float * 9), ("t", C.c_float * 3),
+                ("orig_size", C.c_float), ("proj_eps", C.c_float), ("cull_eps", C.c_float)]
+
+
 class SlnRefineLoss(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "image_size", "pooled_size", "channels", "sem0", "n_sem", "dep0", "n_dep", "n_scales",
                                        "stage1_stride")] + \
@@ -137,6 +144,8 @@ SIGNATURES = {
                                  C.POINTER(SlnGraphBatch), C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_place_forward": (C.c_int, [C.POINTER(SlnPlacement), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_place_backward": (C.c_int, [C.POINTER(SlnPlacement), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sln_refine_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sln_refine_loss_init": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, C.c_void_p]),
     "sln_refine_pool": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),

@@ -16,7 +16,8 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
          "-I" + os.path.join(os.path.dirname(HERE), "include")]
 # raster kernels: bit-exact agreement with the CPU restatement needs contraction off (see raster.hip)
-PER_FILE = {"raster.hip": ["-ffp-contract=off"], "graph_build.hip": ["-ffp-contract=off"]}
+# placement: the torch expression it replaces rounds after every elementwise op
+PER_FILE = {"raster.hip": ["-ffp-contract=off"], "graph_build.hip": ["-ffp-contract=off"], "placement.hip": ["-ffp-contract=off"]}
 
 
 def sources():

@@ -1,0 +1,238 @@
+// Object placement of mesh_render_func (models/diff_render.py:76-159) fused with the camera projection, the near-plane cull
+// (:346-356) and fill_back, forward and backward, for ONE room whose meshes are resident on the device:
+//
+//   bmin, bmax = box[:3] * room, box[3:] * room;  centre = (bmax + bmin) / 2;  size = bmax - bmin
+//   theta = -angle * 2 pi / 24;  scale = min_j(size_j / model_size_j);  A = scale * R_y(theta)
+//   v' = A (v - model_centre) + centre                                      [evaluated as A v + (centre - A model_centre)]
+//   face corner -> camera (R v' + t) -> (x_ndc, y_ndc, z_cam) as sln_project_faces; a face with a corner closer than
+//   cull_eps is degenerated to a point (it never covers a pixel; shapes stay fixed); faces F..2F-1 are the same faces with
+//   corners (2, 1, 0);  size_loss = sum_k mean_j (size_kj - target_kj)^2 (:98-100,160-165).
+//
+// In torch this is ~50 small launches forward and ~55 backward per refinement iteration (stack / cat / matmul / index /
+// where / flip and their autograd nodes), a third of the iteration.  Here: one kernel each way.  Backward runs one workgroup
+// per object over that object's faces (the face list is grouped by object), reduces d centre (3) and d A (3x3) in
+// registers / LDS and applies the chain rule to the box row and the angle - no atomics, deterministic.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "sln_common.h"
+#include "sln_hip.h"
+
+namespace {
+
+struct ObjXform { float A[9]; float tr[3]; float scale, c, s; int jmin; float size[3]; };
+
+__device__ __forceinline__ ObjXform object_xform(const SlnPlacement& P, const float* __restrict__ boxes, const float* __restrict__ angles, int k) {
+  ObjXform x;
+  const int row = P.vis[k];
+  const float* b = boxes + 6 * row;
+  float centre[3];
+  x.scale = 0.f; x.jmin = 0;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float lo = b[j] * P.ext[j], hi = b[3 + j] * P.ext[j];
+    centre[j] = (hi + lo) / 2.f;
+    x.size[j] = hi - lo;
+    const float r = x.size[j] / P.msize[3 * k + j];
+    if (j == 0 || r < x.scale) { x.scale = r; x.jmin = j; }          // torch.min: first minimum wins
+  }
+  const float theta = -angles[row] * (float)(2.0 * 3.14159265358979323846 / 24.0);
+  x.c = cosf(theta); x.s = sinf(theta);
+  // R_y = [[c, 0, s], [0, 1, 0], [-s, 0, c]]
+  x.A[0] = x.scale * x.c; x.A[1] = 0.f;     x.A[2] = x.scale * x.s;
+  x.A[3] = 0.f;           x.A[4] = x.scale; x.A[5] = 0.f;
+  x.A[6] = -x.scale * x.s; x.A[7] = 0.f;    x.A[8] = x.scale * x.c;
+  const float* mc = P.mcenter + 3 * k;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) x.tr[j] = centre[j] - (x.A[3 * j] * mc[0] + x.A[3 * j + 1] * mc[1] + x.A[3 * j + 2] * mc[2]);
+  return x;
+}
+
+struct Corner { float u, v, z; float x, y; };      // ndc + camera-space coordinates
+
+__device__ __forceinline__ Corner project(const SlnPlacement& P, const float p[3]) {
+  Corner c;
+  c.x = p[0] * P.R[0] + p[1] * P.R[1] + p[2] * P.R[2] + P.t[0];
+  c.y = p[0] * P.R[3] + p[1] * P.R[4] + p[2] * P.R[5] + P.t[1];
+  c.z = p[0] * P.R[6] + p[1] * P.R[7] + p[2] * P.R[8] + P.t[2];
+  const float os = P.orig_size;
+  const float xh = c.x / (c.z + P.proj_eps), yh = c.y / (c.z + P.proj_eps);
+  float u = xh * P.K[0] + yh * P.K[1] + P.K[2];
+  float v = os - (xh * P.K[3] + yh * P.K[4] + P.K[5]);
+  c.u = 2.f * (u - os / 2.f) / os;
+  c.v = 2.f * (v - os / 2.f) / os;
+  return c;
+}
+
+__device__ __forceinline__ int object_of_face(const SlnPlacement& P, int f) {
+  int k = 0;                                        // n_vis is a dozen: linear search over the range table
+  while (k < P.n_vis && f >= P.obj_face_ptr[k + 1]) ++k;
+  return k;                                         // == n_vis: room shell
+}
+
+__global__ __launch_bounds__(256) void place_forward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                            const float* __restrict__ size_target, float* __restrict__ fxyz,
+                                                            float* __restrict__ sizes, float* __restrict__ size_loss) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x < 64) {        // sizes and the size loss: one wavefront
+    float l = 0.f;
+    for (int k = threadIdx.x; k < P.n_vis; k += 64) {
+      const ObjXform x = object_xform(P, boxes, angles, k);
+      float m = 0.f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        sizes[3 * k + j] = x.size[j];
+        if (size_target) { const float d = x.size[j] - size_target[3 * k + j]; m += d * d; }
+      }
+      l += m / 3.f;
+    }
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_down(l, o, 64);
+    if (threadIdx.x == 0) size_loss[0] = l;
+  }
+  if (f >= P.F) return;
+  const int k = object_of_face(P, f);
+  ObjXform x;
+  if (k < P.n_vis) x = object_xform(P, boxes, angles, k);
+  Corner c[3];
+  bool cull = false;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int vi = P.faces[3 * f + q];
+    float p[3];
+    if (k < P.n_vis) {
+      const float* m = P.model_v + 3L * vi;           // vi indexes the flattened [n_vis * Vm] model table
+#pragma unroll
+      for (int j = 0; j < 3; ++j) p[j] = x.A[3 * j] * m[0] + x.A[3 * j + 1] * m[1] + x.A[3 * j + 2] * m[2] + x.tr[j];
+    } else {
+      const float* m = P.shell_v + 3L * (vi - P.n_vis * P.Vm);
+      p[0] = m[0]; p[1] = m[1]; p[2] = m[2];
+    }
+    c[q] = project(P, p);
+    cull = cull || c[q].z < P.cull_eps;
+  }
+  float* o0 = fxyz + 9L * f;
+  float* o1 = fxyz + 9L * (P.F + f);
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const float u = cull ? 0.f : c[q].u, v = cull ? 0.f : c[q].v, z = cull ? 0.f : c[q].z;
+    o0[3 * q] = u; o0[3 * q + 1] = v; o0[3 * q + 2] = z;
+    o1[3 * (2 - q)] = u; o1[3 * (2 - q) + 1] = v; o1[3 * (2 - q) + 2] = z;
+  }
+}
+
+// one workgroup per row of `boxes`; rows without a visible object get zero gradients
+__global__ __launch_bounds__(256) void place_backward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                             const float* __restrict__ size_target, const float* __restrict__ gf,
+                                                             const float* __restrict__ g_size_loss, float* __restrict__ g_boxes,
+                                                             float* __restrict__ g_angles) {
+  const int row = blockIdx.x;
+  int k = -1;
+  for (int q = 0; q < P.n_vis; ++q) k = P.vis[q] == row ? q : k;
+  if (k < 0) {
+    if (threadIdx.x < 6) g_boxes[6 * row + threadIdx.x] = 0.f;
+    if (threadIdx.x == 6) g_angles[row] = 0.f;
+    return;
+  }
+  const ObjXform x = object_xform(P, boxes, angles, k);
+  float acc[12];                                     // d centre (3), d A (3x3, row-major)
+#pragma unroll
+  for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+  const float* mc = P.mcenter + 3 * k;
+  const float s2 = 2.f / P.orig_size;
+  for (int f = P.obj_face_ptr[k] + threadIdx.x; f < P.obj_face_ptr[k + 1]; f += 256) {
+    float p[3][3]; Corner c[3];
+    bool cull = false;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float* m = P.model_v + 3L * P.faces[3 * f + q];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) p[q][j] = x.A[3 * j] * m[0] + x.A[3 * j + 1] * m[1] + x.A[3 * j + 2] * m[2] + x.tr[j];
+      c[q] = project(P, p[q]);
+      cull = cull || c[q].z < P.cull_eps;
+    }
+    if (cull) continue;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const float* a = gf + 9L * f + 3 * q;
+      const float* b = gf + 9L * (P.F + f) + 3 * (2 - q);
+      const float gu = a[0] + b[0], gv = a[1] + b[1], gz = a[2] + b[2];
+      const float iz = 1.f / (c[q].z + P.proj_eps);
+      const float gxh = s2 * (gu * P.K[0] - gv * P.K[3]);
+      const float gyh = s2 * (gu * P.K[1] - gv * P.K[4]);
+      const float gx = gxh * iz, gy = gyh * iz;
+      const float gzc = gz - (gxh * c[q].x + gyh * c[q].y) * iz * iz;
+      float gp[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gp[j] = gx * P.R[j] + gy * P.R[3 + j] + gzc * P.R[6 + j];
+      const float* m = P.model_v + 3L * P.faces[3 * f + q];
+      const float d[3] = {m[0] - mc[0], m[1] - mc[1], m[2] - mc[2]};
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        acc[j] += gp[j];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) acc[3 + 3 * j + e] += gp[j] * d[e];
+      }
+    }
+  }
+  __shared__ float red[4][12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) {
+    float v = acc[j];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float g[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) g[j] = red[0][j] + red[1][j] + red[2][j] + red[3][j];
+  const float* dA = g + 3;
+  // A = scale * R_y:  d scale = <dA, R_y>,  d theta = scale * <dA, dR_y/dtheta>
+  const float dscale = dA[0] * x.c + dA[2] * x.s + dA[4] - dA[6] * x.s + dA[8] * x.c;
+  const float dtheta = x.scale * (-dA[0] * x.s + dA[2] * x.c - dA[6] * x.c - dA[8] * x.s);
+  g_angles[row] = -dtheta * (float)(2.0 * 3.14159265358979323846 / 24.0);
+  const float gsl = g_size_loss ? g_size_loss[0] : 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float dsize = j == x.jmin ? dscale / P.msize[3 * k + j] : 0.f;
+    if (size_target) dsize += gsl * 2.f * (x.size[j] - size_target[3 * k + j]) / 3.f;
+    g_boxes[6 * row + j] = (g[j] / 2.f - dsize) * P.ext[j];
+    g_boxes[6 * row + 3 + j] = (g[j] / 2.f + dsize) * P.ext[j];
+  }
+}
+
+int check(const SlnPlacement* P) {
+  if (!P || P->n <= 0 || P->n_vis < 0 || P->n_vis > P->n || P->F <= 0 || P->Vm <= 0 || P->Vs < 0) return SLN_E_BADARG;
+  if (!P->faces || !P->obj_face_ptr || (P->n_vis > 0 && (!P->vis || !P->model_v || !P->msize || !P->mcenter)) || (P->Vs > 0 && !P->shell_v))
+    return SLN_E_BADARG;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sln_place_forward(const SlnPlacement* P, const float* boxes, const float* angles, const float* size_target, float* faces_out,
+                      float* sizes, float* size_loss, void* stream) {
+  int r = check(P);
+  if (r) return r;
+  if (!boxes || !angles || !faces_out || !sizes || !size_loss) return SLN_E_BADARG;
+  hipLaunchKernelGGL(place_forward_kernel, dim3(sln_cdiv(P->F, 256)), dim3(256), 0, (hipStream_t)stream, *P, boxes, angles, size_target,
+                     faces_out, sizes, size_loss);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_place_backward(const SlnPlacement* P, const float* boxes, const float* angles, const float* size_target, const float* grad_faces,
+                       const float* grad_size_loss, float* grad_boxes, float* grad_angles, void* stream) {
+  int r = check(P);
+  if (r) return r;
+  if (!boxes || !angles || !grad_faces || !grad_boxes || !grad_angles) return SLN_E_BADARG;
+  hipLaunchKernelGGL(place_backward_kernel, dim3(P->n), dim3(256), 0, (hipStream_t)stream, *P, boxes, angles, size_target, grad_faces,
+                     grad_size_loss, grad_boxes, grad_angles);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -270,6 +270,34 @@ class RefineLoss:
         return _RefineLossFn.apply(image, self)
 
 
+class _PlaceFn(torch.autograd.Function):
+    """boxes [n,6], angles [n] -> (faces [2F,3,3] projected / culled / fill_back'ed, size_loss, sizes): csrc/placement.hip"""
+
+    @staticmethod
+    def forward(ctx, boxes, angles, scene, size_target):
+        boxes, angles = boxes.contiguous().float(), angles.contiguous().float()
+        dev = boxes.device
+        fxyz = torch.empty(2 * scene.desc.F, 3, 3, device=dev)
+        sizes = torch.empty(max(scene.n_vis, 1), 3, device=dev)
+        sl = torch.empty(1, device=dev)
+        tgt = size_target.contiguous().float() if size_target is not None else None
+        _lib.check(_lib.lib().sln_place_forward(scene.desc, _lib.ptr(boxes), _lib.ptr(angles), _lib.ptr(tgt), _lib.ptr(fxyz), _lib.ptr(sizes),
+                                                _lib.ptr(sl), _lib.current_stream_ptr()), "sln_place_forward")
+        ctx.scene, ctx.tgt = scene, tgt
+        ctx.save_for_backward(boxes, angles)
+        ctx.mark_non_differentiable(sizes)
+        return fxyz, sl.reshape(()), sizes[:scene.n_vis]
+
+    @staticmethod
+    def backward(ctx, g_fxyz, g_sl, _g_sizes):
+        boxes, angles = ctx.saved_tensors
+        gb, ga = torch.empty_like(boxes), torch.empty_like(angles)
+        _lib.check(_lib.lib().sln_place_backward(ctx.scene.desc, _lib.ptr(boxes), _lib.ptr(angles), _lib.ptr(ctx.tgt), _lib.ptr(g_fxyz.contiguous()),
+                                                 _lib.ptr(g_sl.reshape(1).contiguous()), _lib.ptr(gb), _lib.ptr(ga), _lib.current_stream_ptr()),
+                   "sln_place_backward")
+        return gb, ga, None, None
+
+
 class RefineScene:
     """The same placement + render as ``assemble_scene`` + ``DR.scene_render`` with every per-object python loop of
     diff_render.py:76-159 turned into ONE batched tensor expression over the visible objects, and fixed tensor shapes:
@@ -320,6 +348,20 @@ class RefineScene:
         self.chan = torch.tensor(chan, dtype=torch.int32, device=dev)
         self.dch = torch.tensor(dch, dtype=torch.int32, device=dev)
         self.K, self.R, self.t = DR.get_cam_mat(room_box, dev)
+        # descriptor of the fused placement kernels (csrc/placement.hip)
+        counts = [m["f"].shape[0] for m in models]
+        self._keep = [self.vis.to(torch.int32), self.model_v.reshape(-1, 3).contiguous(), self.msize.contiguous(), self.mcenter.contiguous(),
+                      self.shell_v.contiguous(), self.faces32[0].contiguous(),
+                      torch.tensor(np.concatenate([[0], np.cumsum(counts)]).astype(np.int32), device=dev)]
+        d = _lib.SlnPlacement()
+        d.n, d.n_vis, d.Vm, d.Vs, d.F = len(class_names), self.n_vis, Vm, int(self.shell_v.shape[0]), int(self.faces.shape[0])
+        for name, buf in zip(("vis", "model_v", "msize", "mcenter", "shell_v", "faces", "obj_face_ptr"), self._keep):
+            setattr(d, name, buf.data_ptr())
+        for name, vals in (("ext", room_box[3:]), ("K", self.K), ("R", self.R), ("t", self.t)):
+            arr = [float(x) for x in vals.detach().reshape(-1).cpu()]
+            setattr(d, name, (type(getattr(d, name)))(*arr))
+        d.orig_size, d.proj_eps, d.cull_eps = float(DR.inter_out), 1e-9, float(DR.CULL_EPS)
+        self.desc = d
 
     def place(self, boxes, angles):
         """-> vertices [1,V,3] (differentiable), object sizes [n_vis,3]"""
@@ -336,8 +378,13 @@ class RefineScene:
         v = torch.matmul(self.model_v, (rot * scale[:, None, None]).transpose(1, 2)) + trans[:, None, :]
         return torch.cat([v.reshape(-1, 3), self.shell_v])[None], size
 
-    def render(self, boxes, angles, obj_size_target=None):
-        """-> final [1,70,is,is], size_loss, sizes"""
+    def render(self, boxes, angles, obj_size_target=None, fused=True):
+        """-> final [1,70,is,is], size_loss, sizes.  ``fused``: placement, projection, cull and fill_back as ONE kernel each way
+        (csrc/placement.hip) instead of the torch expression below (~100 launches per iteration with its autograd nodes)."""
+        if fused:
+            fxyz, size_loss, size = _PlaceFn.apply(boxes, angles, self, obj_size_target if self.n_vis else None)
+            img = DR._SceneFn.apply(fxyz[None], self.cls2, self.chan, self.dch, self.image_size, 0.001)
+            return img, size_loss, size
         verts, size = self.place(boxes, angles)
         size_loss = boxes.new_zeros(())
         if obj_size_target is not None and self.n_vis:

@@ -282,11 +282,16 @@ def main():
         for _ in range(args.warmup):
             losses = step()
         barrier()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        marks[0].record()
+        for k in range(args.steps):
             losses = step()
+            marks[k + 1].record()                # per-step GPU time for the percentiles (SURVEY.md 8d protocol); ~1 us each
         barrier()
         dt = time.perf_counter() - t0
+    per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    pct = lambda q: round(per_step[min(len(per_step) - 1, int(q * len(per_step)))], 4)
     if dp:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -310,6 +315,7 @@ def main():
         "metric": "scene-graph VAE steps/sec + 256² diff-render fps, 1/2/4/8 MI355X",
         "value": round(value, 1), "unit": "graphs/s (scene-graph VAE fwd+loss+bwd+Adam)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "ms_per_step_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)],
         "steps_per_s": round(args.steps / dt, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batch=%d scene graphs x (%d objects, %d triples) per GPU, "

@@ -232,6 +232,26 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                        const float* grad_final, float* grad_faces, void* stream);
 
 
+/* Object placement of mesh_render_func for one room with device-resident meshes (models/diff_render.py:76-159), fused with
+ * the projection (as sln_project_faces), the near-plane cull (:346-356, culled faces are degenerated to a point) and
+ * fill_back: boxes [n,6] (room-normalised rows, visible object k is row vis[k]), angles [n] (bins, fractional) ->
+ * faces_out [2F,3,3] = (x_ndc, y_ndc, z_cam) (faces F..2F-1: corners (2,1,0)), sizes [n_vis,3], size_loss [1] =
+ * sum_k mean_j (size - size_target)^2 (0 when size_target is NULL).  The face list is grouped by object (obj_face_ptr
+ * [n_vis+1], the room shell's faces last); object faces index model_v [n_vis*Vm,3], shell faces n_vis*Vm + shell_v [Vs,3].
+ * backward: grad_faces [2F,3,3], grad_size_loss [1] (device, may be NULL) -> grad_boxes [n,6], grad_angles [n]. */
+typedef struct {
+  int n, n_vis, Vm, Vs, F, reserved;
+  const int32_t* vis; const float* model_v; const float* msize; const float* mcenter; const float* shell_v;
+  const int32_t* faces; const int32_t* obj_face_ptr;
+  float ext[3];                    /* room extent (boxes[-1][3:]) */
+  float K[9], R[9], t[3];          /* camera of get_cam_mat (diff_render.py:13-46) */
+  float orig_size, proj_eps, cull_eps;
+} SlnPlacement;
+int sln_place_forward(const SlnPlacement* P /* host struct */, const float* boxes, const float* angles, const float* size_target,
+                      float* faces_out, float* sizes, float* size_loss, void* stream);
+int sln_place_backward(const SlnPlacement* P, const float* boxes, const float* angles, const float* size_target, const float* grad_faces,
+                       const float* grad_size_loss, float* grad_boxes, float* grad_angles, void* stream);
+
 /* Refinement loss of the layout-refinement loop (testing/test_render_refine.py:192-215 PSP_pool_new, :332-356):
  * null-fill of the last depth channel, bilinear(align_corners=True) resampling of the 40 semantic and 29 depth channels of
  * the [B,70,S,S] scene tensor to each scale and bilinear resampling to pooled_size, L1 against the pooled target depth * 0.5,

@@ -127,23 +127,37 @@ def _pretrained_room():
     return model, objs, triples, boxes, angles, attrs
 
 
-def test_batched_scene_equals_per_object_assembly():
+@pytest.mark.parametrize("fused", [True, False])
+def test_batched_scene_equals_per_object_assembly(fused):
+    """RefineScene (fused: csrc/placement.hip - placement, projection, cull, fill_back, size loss in one kernel each way;
+    otherwise the batched torch expression) against the per-object assembly of diff_render.py:76-165."""
     R = pkg("host.refine"); DR = pkg("host.diff_render")
     boxes, angles = _inputs("cuda")
     bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
     room = boxes[-1].clone()
+    tgt = [torch.tensor([0.5, 0.4, 0.6], device="cuda") * (1 + 0.1 * k) for k in range(5)]
     b1 = boxes.clone().requires_grad_(True); a1 = (angles + 0.3).clone().requires_grad_(True)
-    v, f, ranges, sizes, _ = R.assemble_scene(b1, a1, NAMES, bank, room)
+    v, f, ranges, sizes, sl1 = R.assemble_scene(b1, a1, NAMES, bank, room, tgt)
     img1 = DR.scene_render(v, f, ranges, room, image_size=128)
     scene = R.RefineScene(NAMES, bank, room, image_size=128)
+    assert scene.n_vis == len(tgt)
     b2 = boxes.clone().requires_grad_(True); a2 = (angles + 0.3).clone().requires_grad_(True)
-    img2, _, size2 = scene.render(b2, a2)
+    img2, sl2, size2 = scene.render(b2, a2, torch.stack(tgt), fused=fused)
     assert torch.equal(torch.stack(sizes), size2.detach())
+    assert abs(float(sl1.detach()) - float(sl2.detach())) <= 1e-6 * abs(float(sl1.detach())) and float(sl1.detach()) > 0
     assert ((img1 - img2).abs() > 1e-4).float().mean() < 1e-3   # batched vs per-object matmul rounding: a few silhouette pixels
     w = torch.randn(img1.shape, generator=torch.Generator().manual_seed(0)).cuda()
-    (img1 * w).sum().backward(); (img2 * w).sum().backward()
+    ((img1 * w).sum() + 3.0 * sl1).backward(); ((img2 * w).sum() + 3.0 * sl2).backward()
     assert_close(b2.grad.cpu().numpy(), b1.grad.cpu().numpy(), "d/d boxes", rtol=2e-3, atol=2e-3 * float(b1.grad.abs().max()))
     assert_close(a2.grad.cpu().numpy(), a1.grad.cpu().numpy(), "d/d angles", rtol=2e-3, atol=2e-3 * float(a1.grad.abs().max()))
+    assert float(b1.grad[4].abs().max()) == 0.0 and float(b2.grad[4].abs().max()) == 0.0      # 'door' is not placed
+    # the size loss alone (no image term): exact chain rule, tight tolerance
+    b3 = boxes.clone().requires_grad_(True)
+    _, sl3, _ = scene.render(b3, angles + 0.3, torch.stack(tgt), fused=fused)
+    sl3.backward()
+    b4 = boxes.clone().requires_grad_(True)
+    R.assemble_scene(b4, angles + 0.3, NAMES, bank, room, tgt)[4].backward()
+    assert_close(b3.grad.cpu().numpy(), b4.grad.cpu().numpy(), "d size_loss / d boxes", rtol=1e-5)
 
 
 def test_fast_finetune_loop_matches_the_reference_shaped_loop_and_its_graph_replay():
