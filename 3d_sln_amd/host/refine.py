@@ -423,6 +423,9 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
     size_target = sizes.detach().clone()
     n = boxes_gt.shape[0]
     noise = torch.zeros(n, device=dev)
+    # the soft-argmax noise of every iteration, drawn in the reference's order (one randn(n) per iteration) but uploaded once:
+    # a per-iteration host-to-device copy would block the host and leave the GPU idle between two iterations
+    noise_all = torch.stack([torch.randn(n, generator=gen) for _ in range(iters)]).to(dev) if iters > 0 else torch.zeros(0, n, device=dev)
     losses = torch.zeros(iters, device=dev)
     flat, flat_grad = model.flat_params, model.flat_grads
     state = {}
@@ -452,7 +455,7 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
     graph = None
     for k in range(iters):
         if capture:
-            noise.copy_(torch.randn(n, generator=gen).to(dev))
+            noise.copy_(noise_all[k])
             if graph is None:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
@@ -467,7 +470,7 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
             graph.replay()
             losses[k] = state["loss"]
         else:
-            noise.copy_(torch.randn(n, generator=gen).to(dev))
+            noise.copy_(noise_all[k])
             losses[k] = iteration()
         if log:
             log("iter %d: loss %.4f" % (k, float(losses[k])))
