@@ -13,6 +13,7 @@ C ABI (include/sln_hip.h, csrc/raster.hip).  Semantics: oracle/raster_ref.cpp ("
 To drop it into the reference: ``sys.modules['neural_renderer'] = this module``.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -74,21 +75,28 @@ def project_faces(vertices, faces, K, R, t, orig_size=512, eps=1e-9):
     return _ProjectFaces.apply(vertices, faces, K, R, t, orig_size, eps)
 
 
+def _rasterize(faces, image_size, near, far):
+    """(face_index int32, weight, depth) maps of faces [B,F,3,3] (sln_raster_forward)"""
+    L = _lib.lib()
+    B, F = faces.shape[0], faces.shape[1]
+    dev = faces.device
+    fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device=dev)
+    w = torch.empty(B, image_size, image_size, 3, device=dev)
+    d = torch.empty(B, image_size, image_size, device=dev)
+    ws = _ws(L.sln_raster_workspace_bytes(B, F), dev)
+    _lib.check(L.sln_raster_forward(_lib.ptr(faces), B, F, image_size, near, far, _lib.ptr(ws), _lib.ptr(fi), _lib.ptr(w),
+                                    _lib.ptr(d), _lib.current_stream_ptr()), "sln_raster_forward")
+    return fi, w, d
+
+
 class _RasterizeDepth(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, faces, image_size, near, far):
-        L = _lib.lib()
+    def forward(ctx, faces, image_size, near, far, maps=None):
         faces = faces.contiguous()
-        B, F = faces.shape[0], faces.shape[1]
-        dev = faces.device
-        fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device=dev)
-        w = torch.empty(B, image_size, image_size, 3, device=dev)
-        d = torch.empty(B, image_size, image_size, device=dev)
-        ws = _ws(L.sln_raster_workspace_bytes(B, F), dev)
-        _lib.check(L.sln_raster_forward(_lib.ptr(faces), B, F, image_size, near, far, _lib.ptr(ws), _lib.ptr(fi), _lib.ptr(w),
-                                        _lib.ptr(d), _lib.current_stream_ptr()), "sln_raster_forward")
+        fi, w, d = maps if maps is not None else _rasterize(faces, image_size, near, far)
         ctx.save_for_backward(faces, fi, w, d)
         ctx.image_size = image_size
+        ctx.maps = (fi, w, d)
         return d.clone()
 
     @staticmethod
@@ -99,24 +107,22 @@ class _RasterizeDepth(torch.autograd.Function):
         _lib.check(_lib.lib().sln_raster_backward_depth(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(w), _lib.ptr(d),
                                                         _lib.ptr(gd.contiguous()), B, F, ctx.image_size, _lib.ptr(g),
                                                         _lib.current_stream_ptr()), "sln_raster_backward_depth")
-        return g, None, None, None
+        return g, None, None, None, None
 
 
 class _RasterizeRgb(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, faces, textures, image_size, near, far, eps):
+    def forward(ctx, faces, textures, image_size, near, far, eps, maps=None):
+        """``maps``: (face_index, weight, depth) of an earlier rasterisation of the SAME faces / near / far (Renderer's memo)."""
         L = _lib.lib()
         faces, textures = faces.contiguous(), textures.contiguous().float()
         B, F = faces.shape[0], faces.shape[1]
         dev = faces.device
-        fi = torch.empty(B, image_size, image_size, dtype=torch.int32, device=dev)
-        w = torch.empty(B, image_size, image_size, 3, device=dev)
-        d = torch.empty(B, image_size, image_size, device=dev)
         rgb = torch.empty(B, image_size, image_size, 3, device=dev)
-        ws = _ws(L.sln_raster_workspace_bytes(B, F), dev)
         st = _lib.current_stream_ptr()
-        _lib.check(L.sln_raster_forward(_lib.ptr(faces), B, F, image_size, near, far, _lib.ptr(ws), _lib.ptr(fi), _lib.ptr(w),
-                                        _lib.ptr(d), st), "sln_raster_forward")
+        if maps is None:
+            maps = _rasterize(faces, image_size, near, far)
+        fi, w, d = maps
         _lib.check(L.sln_raster_texture_sample(_lib.ptr(faces), _lib.ptr(textures), _lib.ptr(fi), _lib.ptr(w), _lib.ptr(d), B, F,
                                                image_size, textures.shape[2], eps, _lib.ptr(rgb), st), "sln_raster_texture_sample")
         ctx.save_for_backward(faces, fi, rgb)
@@ -132,11 +138,13 @@ class _RasterizeRgb(torch.autograd.Function):
         _lib.check(_lib.lib().sln_raster_backward_rgb(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(rgb), _lib.ptr(grgb.contiguous()), B,
                                                       F, ctx.image_size, 3, ctx.eps, _lib.ptr(g), _lib.current_stream_ptr()),
                    "sln_raster_backward_rgb")
-        return g, None, None, None, None, None     # textures do not require grad in the reference (diff_render.py:397)
+        return g, None, None, None, None, None, None     # textures do not require grad in the reference (diff_render.py:397)
 
 
 class Renderer:
     """Constructor / call signature of ``neural_renderer.Renderer`` restricted to what the reference passes."""
+
+    reuse_rasterisation = True      # see _projected(); False rasterises on every call
 
     def __init__(self, image_size=256, anti_aliasing=True, background_color=(0, 0, 0), fill_back=True,
                  camera_mode='projection', K=None, R=None, t=None, dist_coeffs=None, orig_size=1024, perspective=True,
@@ -163,17 +171,45 @@ class Renderer:
         orig_size = self.orig_size if orig_size is None else orig_size
         if vertices.device.type != 'cuda':
             raise _lib.SlnError("the rasterizer runs on the MI355X only (no CPU fallback)")
-        if self.fill_back:
-            faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)
-        fxyz = project_faces(vertices, faces, K, R, t, orig_size)
+        fxyz, memo = self._projected(vertices, faces, K, R, t, orig_size)
         if mode == 'depth':
             # the package's render_depth does not forward near/far: library defaults apply
-            d = _RasterizeDepth.apply(fxyz, self.image_size, 0.1, 100.0)
+            maps = self._maps(memo, fxyz, 0.1, 100.0)
+            d = _RasterizeDepth.apply(fxyz, self.image_size, 0.1, 100.0, maps)
             return torch.flip(d, dims=[1])
         if mode in ('rgb', None):
             if self.fill_back:
                 textures = torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)
             textures = textures * self.light_intensity_ambient          # ambient-only lighting, white light
-            rgb = _RasterizeRgb.apply(fxyz, textures, self.image_size, float(self.near), float(self.far), self.rasterizer_eps)
+            maps = self._maps(memo, fxyz, float(self.near), float(self.far))
+            rgb = _RasterizeRgb.apply(fxyz, textures, self.image_size, float(self.near), float(self.far), self.rasterizer_eps, maps)
             return torch.flip(rgb.permute(0, 3, 1, 2), dims=[2])
         raise NotImplementedError("mode=%r (the reference uses 'depth' and 'rgb')" % (mode,))
+
+    # mesh_render_func renders the SAME geometry 33 times in a row (1 depth pass + 32 class masks that differ only in their
+    # textures, diff_render.py:366,381-398).  The rasterisations (face index / weight / depth maps, not differentiable) of the last
+    # geometry are kept while the caller keeps passing the very same tensor objects, unmodified: a class pass is then a projection
+    # and one texture-sampling launch instead of a full rasterisation.  Every pass still gets its own projection node in the
+    # autograd graph (separate backward calls keep working).  The key holds weak references (a new tensor that merely reuses a
+    # freed address is a different object) and the tensors' version counters (in-place updates).
+    def _projected(self, vertices, faces, K, R, t, orig_size):
+        f2 = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1) if self.fill_back else faces
+        fxyz = project_faces(vertices, f2, K, R, t, orig_size)
+        key_objs = (vertices, faces, K, R, t)
+        if not self.reuse_rasterisation or not all(torch.is_tensor(o) for o in key_objs):
+            return fxyz, None
+        memo = getattr(self, "_memo", None)
+        if memo is not None and memo["orig_size"] == orig_size and \
+                all(r() is o and v == o._version for r, v, o in zip(memo["refs"], memo["versions"], key_objs)):
+            return fxyz, memo
+        memo = dict(refs=[weakref.ref(o) for o in key_objs], versions=[o._version for o in key_objs], orig_size=orig_size, maps={})
+        self._memo = memo
+        return fxyz, memo
+
+    def _maps(self, memo, fxyz, near, far):
+        if memo is None:
+            return None
+        key = (near, far, self.image_size, torch.cuda.current_stream().cuda_stream)
+        if key not in memo["maps"]:
+            memo["maps"][key] = _rasterize(fxyz.detach().contiguous(), self.image_size, near, far)
+        return memo["maps"][key]

@@ -116,6 +116,57 @@ def test_renderer_class_matches_restated_renderer():
         assert_close(v2.grad.cpu().numpy(), v1.grad.numpy(), mode + " dV", rtol=1e-4, atol=1e-4 * v1.grad.abs().max().item())
 
 
+def test_renderer_reuses_the_rasterisation_of_unchanged_geometry():
+    """mesh_render_func renders the same vertices 33 times with different textures (diff_render.py:366,381-398): the Renderer
+    rasterises once per (near, far) while the caller passes the same unmodified tensor objects, re-rasterises after an in-place
+    update or for a new tensor, and every result equals the one of a fresh Renderer."""
+    NR = pkg("host.neural_renderer")
+    V, F, ranges, box = rr.synth_room(4, n_objects=6, target_faces=400)
+    K, R, t = [x.cuda() for x in rr.get_cam_mat(torch.from_numpy(box))]
+    zc = (torch.from_numpy(V).cuda() @ R[0].T + t[0])[:, 2].cpu().numpy()
+    F = F[(zc[F] > 0.3).all(1)]
+    kw = dict(camera_mode='projection', image_size=96, K=K, R=R, t=t, anti_aliasing=False, orig_size=512, near=0.001,
+              light_intensity_ambient=1.0, light_intensity_directional=0.0)
+    f = torch.from_numpy(F)[None].cuda()
+    texs = []
+    for k in range(3):
+        tex = torch.zeros(1, F.shape[0], 2, 2, 2, 3, device="cuda"); tex[:, k::3] = 1.0
+        texs.append(tex)
+    calls = []
+    orig = NR._rasterize
+    NR._rasterize = lambda *a: (calls.append(a[2:]), orig(*a))[1]
+    try:
+        v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+        hip = NR.Renderer(**kw)
+        outs = [hip(v, f, texs[0], mode='depth')] + [hip(v, f, tex, mode='rgb') for tex in texs]
+        assert len(calls) == 2, calls                           # one depth-pass rasterisation (near 0.1), one for the class passes
+        w = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)).cuda() for i, o in enumerate(outs)]
+        sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+        n0 = len(calls)
+        v2 = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+        fresh = [NR.Renderer(**kw)(v2, f, texs[0], mode='depth')] + [NR.Renderer(**kw)(v2, f, tex, mode='rgb') for tex in texs]
+        assert len(calls) == n0 + 4
+        for a, b in zip(outs, fresh):
+            assert torch.equal(a, b)
+        sum((o * wi).sum() for o, wi in zip(fresh, w)).backward()
+        assert_close(v.grad.cpu().numpy(), v2.grad.cpu().numpy(), "dV shared vs fresh", rtol=1e-5, atol=1e-6 * float(v2.grad.abs().max()))
+        # in-place update of the vertices: the version counter changes, the maps are rebuilt
+        n1 = len(calls)
+        with torch.no_grad():
+            v[:, :, 0] += 0.05
+        moved = hip(v, f, texs[1], mode='rgb')
+        assert len(calls) == n1 + 1
+        v3 = v.detach().clone()
+        assert torch.equal(moved, NR.Renderer(**kw)(v3, f, texs[1], mode='rgb'))
+        assert not torch.equal(moved, outs[2])
+        # an equal tensor that is another object: not trusted
+        n2 = len(calls)
+        hip(v3, f, texs[1], mode='rgb')
+        assert len(calls) == n2 + 1
+    finally:
+        NR._rasterize = orig
+
+
 @pytest.mark.parametrize("image_size,target", [(96, 500), (256, 2000)])
 def test_fused_scene_matches_33_pass_restatement(image_size, target):
     DR = pkg("host.diff_render")
