@@ -235,6 +235,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
+constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples
 __global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ acc) {
   const int b = blockIdx.y;
   const float* xb = x + (size_t)b * n;
@@ -250,13 +251,14 @@ __global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __r
     if (threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rq[threadIdx.x] += rq[threadIdx.x + off]; }
     __syncthreads();
   }
-  if (threadIdx.x == 0) { atomicAdd(acc + 2 * b, rs[0]); atomicAdd(acc + 2 * b + 1, rq[0]); }
+  // one 128-byte line per sample: device atomics to the same line are serialised on the memory side
+  if (threadIdx.x == 0) { atomicAdd(acc + LN_ACC_STRIDE * b, rs[0]); atomicAdd(acc + LN_ACC_STRIDE * b + 1, rq[0]); }
 }
 __global__ void ln_finalize_kernel(const double* __restrict__ acc, long n, int B, float eps, float* __restrict__ stats) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const double mean = acc[2 * b] / (double)n;
-  double var = (acc[2 * b + 1] - (double)n * mean * mean) / (double)(n - 1);     // unbiased (torch.std default)
+  const double mean = acc[LN_ACC_STRIDE * b] / (double)n;
+  double var = (acc[LN_ACC_STRIDE * b + 1] - (double)n * mean * mean) / (double)(n - 1);     // unbiased (torch.std default)
   var = var < 0.0 ? 0.0 : var;
   stats[2 * b] = (float)mean;
   stats[2 * b + 1] = 1.0f / ((float)sqrt(var) + eps);                           // LayerNorm2D adds eps to sigma
@@ -489,9 +491,9 @@ int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const fl
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream) {
   if (!x || !scratch || !stats || B <= 0 || n < 2) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * 2 * B, st);
+  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * LN_ACC_STRIDE * B, st);
   if (e != hipSuccess) return (int)e;
-  int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 256 ? 256 : (gx < 1 ? 1 : gx);
+  int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 128 ? 128 : (gx < 1 ? 1 : gx);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch);
   hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, B, eps, stats);
   SLN_CHECK_LAUNCH();

@@ -155,7 +155,7 @@ class SPADEGenerator4(nn.Module):
     def _ln_stats(self, x):
         B = x.shape[0]
         stats = torch.empty(B, 2, device=x.device)
-        scratch = torch.empty(2 * B, dtype=torch.float64, device=x.device)
+        scratch = torch.empty(16 * B, dtype=torch.float64, device=x.device)        # one 128-byte line per sample
         _lib.check(_lib.lib().sln_layernorm_stats(_lib.ptr(x), B, x[0].numel(), 1e-5, _lib.ptr(scratch), _lib.ptr(stats), self._st()),
                    "sln_layernorm_stats")
         return stats

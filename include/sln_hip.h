@@ -305,6 +305,7 @@ int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const fl
  * computed once, then out[b] = LayerNorm2D(xin[b]) * (1 + gamma) + beta for every sample.  H*W % 4 == 0. */
 int sln_spade_apply(const float* xin, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act,
                     float slope, float* out, void* stream);
+/* stats[b] = (mean, 1 / (unbiased std + eps)) over the n elements of sample b; scratch: 16 * B doubles */
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream);
 /* F.interpolate(size=...): mode 0 nearest, 1 bilinear(align_corners=False) over BC planes */
 int sln_resize(const float* src, int BC, int Hi, int Wi, int Ho, int Wo, int mode, float* dst, void* stream);
