@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--graph-batch", type=int, default=512, help="rooms per scene-graph builder call")
     ap.add_argument("--graph-iters", type=int, default=50)
     ap.add_argument("--no-graph-build", action="store_true")
+    ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
+    ap.add_argument("--no-refine", action="store_true")
     return ap.parse_args()
 
 
@@ -168,6 +170,46 @@ def graph_build_leg(args, lib, torch):
         res["cpu_baseline"] = {"value": round(n_cpu / cdt, 1), "unit": "graphs/s", "cores": 1, "kind": "port",
                                "sample": "%d rooms through oracle/graph_build_ref.py (python loop per object pair, as the reference)" % n_cpu}
     return res
+
+
+def refine_leg(args, lib, torch):
+    """the inner loop of finetune_VAE (testing/test_render_refine.py:279-359) for ONE room of 12 objects on
+    procedural meshes: decoder -> soft-argmax -> fused placement -> fused 70-channel render -> fused PSP / L1 / CE loss ->
+    backward -> Nesterov SGD on z and the model copy, 60 iterations, eager launches, nothing synchronises inside the loop."""
+    R = importlib.import_module("3d_sln_amd.host.refine")
+    M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    names = ["bed", "chair", "table", "sofa", "desk", "cabinet", "lamp", "television", "bookshelf", "dresser", "night_stand", "shelves",
+             "__room__"]
+    n = len(names)
+    g = torch.Generator().manual_seed(0)
+    lo = torch.rand(n, 3, generator=g) * 0.45 + 0.05; lo[:, 1] = 0.0; lo[:, 2] *= 0.6
+    hi = lo + torch.rand(n, 3, generator=g) * 0.2 + 0.12
+    boxes = torch.cat([lo, hi], 1); boxes[-1] = torch.tensor([0, 0, 0, 4.0, 2.7, 5.0]); boxes = boxes.cuda()
+    angles = torch.randint(0, 24, (n,), generator=g).cuda()
+    torch.manual_seed(1)
+    model = M.Sg2ScVAEModel(vocab=syn.default_vocab(), batch_size=1, train_3d=True, decoder_cat=True, embedding_dim=64,
+                            gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
+                            layout_noise_dim=32, use_AE=False).cuda().train()
+    objs = torch.arange(1, n + 1).cuda(); objs[-1] = 0
+    triples = torch.tensor([[i, 1 + i % 10, (i + 1) % (n - 1)] for i in range(n - 1)] + [[i, 0, n - 1] for i in range(n - 1)]).cuda()
+    attrs = torch.zeros(n, dtype=torch.int64).cuda()
+    bank = R.MeshBank([x for x in names if x != "__room__"], "cuda", seed=3)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    st = torch.cuda.Stream()
+    iters = args.refine_iters
+    with torch.cuda.stream(st):
+        R.finetune_vae_fast(model, objs, triples, boxes, angles, attrs, names, iters=3, bank=bank)
+        model.load_state_dict(sd0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses, _ = R.finetune_vae_fast(model, objs, triples, boxes, angles, attrs, names, iters=iters, bank=bank)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    return {"ms_per_iteration": round(dt / iters * 1e3, 3), "iterations": iters, "finite": bool(torch.isfinite(losses).all()),
+            "includes": "per-room set-up (encoder, target render, loss tables) amortised over the iterations",
+            "workload": "one room, 12 objects + shell (%d triangles x2 fill_back), 256x256, VAE at train.py defaults" %
+                        int(R.RefineScene(names, bank, boxes[-1]).faces.shape[0])}
 
 
 def spade_leg(args, lib, torch):
@@ -332,6 +374,8 @@ def main():
         out["spade"] = spade_leg(args, lib, torch)
     if rank == 0 and solo and not args.no_graph_build:
         out["graph_build"] = graph_build_leg(args, lib, torch)
+    if rank == 0 and solo and not args.no_refine:
+        out["refine"] = refine_leg(args, lib, torch)
     if rank == 0 and args.prof_steps <= 0:
         print(json.dumps(out))
     elif rank == 0:
