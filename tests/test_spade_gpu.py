@@ -146,3 +146,25 @@ def test_colorize_pipeline_from_raw_maps():
     assert_close(imgs.cpu().numpy(), ref.numpy(), "colorize", rtol=1e-4, atol=1e-4)
     u8 = I.to_uint8(imgs)
     assert u8.shape == (4, cfg.crop_size, cfg.crop_size, 3) and u8.dtype == torch.uint8
+
+
+def test_full_size_batch_of_32_equals_per_sample_calls():
+    """BASELINE configs[3] at its real size (batch 32, 256x256, ngf 64): the batched call must give, sample by sample, what a
+    batch-1 call gives (no cross-sample leakage in the tiled convolutions, LayerNorm statistics per sample); a size-independent
+    property on top of the fixture of the full-size reference output (spade_full)."""
+    S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_full"][0])
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(spade_ref.init_state(cfg, seed=7))
+    G = G.cuda().eval()
+    seg, z = spade_ref.synth_input(cfg, 32, seed=11)
+    seg, z = seg.cuda(), z.cuda()
+    with torch.no_grad():
+        out = G(seg, z)
+        assert out.shape == (32, 3, cfg.crop_size, cfg.crop_size) and torch.isfinite(out).all()
+        assert float(out.abs().max()) <= 1.0                                        # tanh
+        for b in (0, 13, 31):
+            one = G(seg[b:b + 1].contiguous(), z[b:b + 1].contiguous())
+            assert_close(out[b:b + 1].cpu().numpy(), one.cpu().numpy(), "sample %d" % b, rtol=1e-5, atol=1e-5)
+        # different samples give different images (the batch is not broadcast from one sample)
+        assert float((out[0] - out[1]).abs().max()) > 1e-3

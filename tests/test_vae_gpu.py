@@ -437,3 +437,31 @@ def test_heatmap_from_words_runs_chunked_decodes():
     bp, _, _ = S.sample_layouts(model, objs, triples, attrs, n_samples=64, mean=mean, cov=cov, generator=torch.Generator().manual_seed(3))
     h1 = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=64, chunk=64, container_size=40, generator=torch.Generator().manual_seed(3))
     assert_close(h1.cpu().numpy(), S.layout_heatmap(bp, 40).cpu().numpy(), "single chunk", rtol=1e-6, atol=1e-7)
+
+
+def test_large_batch_equals_per_graph_evaluation():
+    """256 graphs (O = 8192, T = 16384: the 128x64 / 128x128 GEMM tiles, long CSR lists) in eval mode: graphs never share rows
+    (suncg_collate_fn offsets), so every graph of the batch must come out as it does alone - a size-independent check of the
+    batched kernels at 4x the BASELINE batch."""
+    cfg = vae_ref.VaeConfig()
+    sd = vae_ref.init_state(cfg, seed=42)
+    n_obj, n_tri, B = 32, 64, 256
+    batch = vae_ref.synth_batch(B, n_obj, n_tri, seed=3, cfg=cfg)
+    eps = torch.from_numpy(np.random.default_rng(4).standard_normal((B * n_obj, cfg.embedding_dim)).astype(np.float32))
+    model = _model(cfg, sd).eval()
+    with torch.no_grad():
+        full = [t.cpu().numpy() for t in model(*_dev(*batch[:5]), None, eps=eps.cuda())]
+        for g in (0, 101, 255):
+            o0, o1, t0, t1 = g * n_obj, (g + 1) * n_obj, g * n_tri, (g + 1) * n_tri
+            tr = batch[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+            one = model(*_dev(batch[0][o0:o1], tr, batch[2][o0:o1], batch[3][o0:o1], batch[4][o0:o1]), None, eps=eps[o0:o1].cuda())
+            for a, b, nm in zip(full, one, ("mu", "logvar", "boxes_pred", "angles_pred")):
+                assert_close(a[o0:o1], b.cpu().numpy(), "graph %d %s" % (g, nm), rtol=2e-5, atol=2e-5)
+    # and against the oracle on one of them
+    g = 101
+    o0, o1, t0, t1 = g * n_obj, (g + 1) * n_obj, g * n_tri, (g + 1) * n_tri
+    tr = batch[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+    with torch.no_grad():
+        ref = vae_ref.forward(sd, cfg, batch[0][o0:o1], tr, batch[2][o0:o1], batch[3][o0:o1], batch[4][o0:o1], eps[o0:o1], training=False)
+    for a, r, nm in zip(full, ref, ("mu", "logvar", "boxes_pred", "angles_pred")):
+        assert_close(a[o0:o1], r.numpy(), "oracle graph %d %s" % (g, nm), rtol=1e-4, atol=1e-5)
