@@ -267,13 +267,33 @@ def test_two_half_iteration_equals_the_whole_one(use_graph):
 
 
 # ----------------------------------------------------------------------------- BASELINE config c2
-def test_c2_full_size_train_step_vs_oracle():
-    """Batch=64 x (32 objects, 64 triples) at train.py defaults: O=2048, T=4096 (BASELINE.json configs[1])."""
+@pytest.mark.parametrize("n_graphs", [64, 256])
+def test_c2_full_size_train_step_vs_oracle(n_graphs):
+    """Batch=64 x (32 objects, 64 triples) at train.py defaults: O=2048, T=4096 (BASELINE.json configs[1]); 256 graphs: the
+    large-tile GEMM variants and the separate dgrad / wgrad launches the engine switches to above the batch-64 sizes."""
     cfg = vae_ref.VaeConfig()
-    sd = vae_ref.init_state(cfg, seed=42)
-    batch = vae_ref.synth_batch(64, 32, 64, seed=0, cfg=cfg)
+    # 256 graphs: with unit-scale weights the posterior heads give |logvar| ~ 16 and z = eps * exp(logvar / 2) + mu reaches
+    # 2e4 - the decoder input then amplifies the encoder's fp32 drift a hundredfold in ANY fp32 evaluation; quarter-scale
+    # weights (BatchNorm renormalises every hidden layer, only the head outputs shrink) keep the comparison meaningful
+    sd = vae_ref.init_state(cfg, seed=42, scale=1.0 if n_graphs == 64 else 0.25)
+    batch = vae_ref.synth_batch(n_graphs, 32, 64, seed=0, cfg=cfg)
     O = batch[0].shape[0]
     eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    if n_graphs > 64:
+        # d L1 / d boxes_pred = sign(boxes_pred - boxes) / numel: with 49 152 residuals one of them sits within fp32 rounding of
+        # 0 and ONE flipped sign moves box_net's bias gradient by 2 / numel = 2e-4 of its scale (seen).  Move the targets of the
+        # few residuals below 2e-3 away from the prediction (fp64 evaluation of the oracle decides) so that no sign is ambiguous.
+        sdx = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        boxes = batch[2].clone()
+        for _ in range(4):
+            with torch.no_grad():
+                bp64 = vae_ref.forward(sdx, cfg, batch[0], batch[1], boxes.double(), batch[3], batch[4], eps.double(), training=True)[2]
+            res = (bp64 - boxes.double()).abs()
+            if not (res < 2e-4).any():               # moving targets moves every prediction a little (train-mode BatchNorm): the
+                break                                # shifted band is 10x wider than the one that must end up empty
+            boxes = torch.where(res < 2e-3, boxes + 0.02, boxes)
+        assert not (res < 2e-4).any()
+        batch = (batch[0], batch[1], boxes) + tuple(batch[3:])
     model = _model(cfg, sd).train()
     dev = _dev(*batch[:5], eps)
     mu, lv, bp, ap = model(*dev[:5], None, eps=dev[5])
@@ -308,10 +328,23 @@ def test_c2_full_size_train_step_vs_oracle():
     gscale = max(float(gr.abs().max()) for gr in grads.values())
     named = dict(model2.named_parameters())
     bad = []
+    # 256 graphs: a gradient entry is a sum over 8 192 / 16 384 rows of terms gated by ReLU masks; a pre-activation within fp32
+    # rounding of 0 flips its mask in one fp32 evaluation and not in another and moves the entry by one term.  Measured on
+    # gconv_net_dc.gconvs.1.net2.1.bias (entries = sums of largely cancelling terms): 47 of 256 entries of the reference's own
+    # fp32 gradient and 78 of ours are > 1e-5 (0.4 % of the scale) from the fp64 one, the worst of ours by two flips = 8 %.
+    # The tight comparison is the 64-graph case; at 256 graphs the check is that the large-tile / separately launched kernels
+    # produce the same tensors: max error within 2 % of the tensor's scale, or relative L2 error within 10 %.
     for k, gr in grads.items():
         try:
-            assert_close_conditioned(named[k].grad.cpu().numpy(), grads64[k].numpy(), gr.numpy(), "c2:grad:" + k,
-                                     atol=5e-6 * gscale, k=4.0)
+            got, r64 = named[k].grad.cpu().numpy(), grads64[k].numpy()
+            if n_graphs == 64:
+                assert_close_conditioned(got, r64, gr.numpy(), "c2:grad:" + k, atol=5e-6 * gscale, k=4.0)
+            else:
+                try:
+                    assert_close_conditioned(got, r64, gr.numpy(), "c2:grad:" + k, rtol=2e-2, atol=5e-6 * gscale, k=4.0)
+                except AssertionError:
+                    l2 = float(np.linalg.norm(got.astype(np.float64) - r64) / max(np.linalg.norm(r64), 1e-30))
+                    assert l2 <= 0.1, "c2:grad:%s: relative L2 error %.3f" % (k, l2)
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, "\n".join(bad[:40])
