@@ -302,6 +302,7 @@ inline int small_batch_split(long units, int max_split, long budget = 32768) {
   while (s < max_split && units * s * 2 <= budget) s *= 2;        // stay below `budget` workgroups
   return s;
 }
+inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F); }
 inline int pixel_map_scan_split(long faces_total, int B) {
   if (B >= 8) return 1;                          // the image -> XCD affinity mapping of the kernel uses a 2-D grid
   return small_batch_split(faces_total * 6, 16, 131072);
@@ -400,7 +401,7 @@ constexpr int PMB_DC = 64;
 //   phase 2 - the lanes stride over the concatenated scan pixels of all steps (binary search of the prefix), every
 //             iteration is independent of the others, so their loads overlap.
 template <typename PIX>
-__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int F, int is,
+__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int B, int F, int is,
                                                                 float eps, float* __restrict__ gfaces) {
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
   __shared__ int s_ofrom[PMB_DC], s_lo[PMB_DC], s_ifrom[PMB_DC];
@@ -410,8 +411,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // Image -> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the
   // plain (face, edge) order all XCDs scan the SAME image at a time and each L2 fetches that image's maps for itself (measured:
   // 1.07 GB from memory per launch for 0.28 GB of maps).  With at least 8 images, XCD x takes the images x, x+8, ...
+  // The launcher (pixel_map_grid_x) pads the grid to a multiple of 8 images for this mapping: with B = 9 a grid of 9 F x 6
+  // workgroups gives XCD 0 only 6.75 F of the 12 F units of its two images (found by the 9-room parity test).
   const int lane = threadIdx.x;
-  const int B = (int)(gridDim.x / (unsigned)F);
   long i; int ea;
   if (B >= 8) {
     const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
@@ -706,7 +708,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3((unsigned)n, 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, F, image_size, eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -1046,7 +1048,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
                      num_classes, 70, w.st, w.g, w.gT);
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3((unsigned)n, 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, F, is, pix_eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
                      grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;

@@ -197,14 +197,17 @@ def test_fused_scene_matches_33_pass_restatement(image_size, target):
         assert_close(v3.grad.cpu().numpy(), v1.grad.numpy(), "dV passes", rtol=1e-4, atol=2e-4 * v1.grad.abs().max().item())
 
 
-def test_batched_rooms_with_padding_equal_single_room_renders():
+@pytest.mark.parametrize("n_rooms", [3, 9])
+def test_batched_rooms_with_padding_equal_single_room_renders(n_rooms):
     """Ragged rooms (different V / F) are batched by padding with degenerate faces of class -1: the padded batch must
-    reproduce each room's own render and vertex gradients."""
+    reproduce each room's own render and vertex gradients.  9 rooms: the image -> XCD mapping of the pixel-map backward
+    (batches of 8 and more, here with a remainder) against the single-room launches, which use the small-batch split."""
     DR = pkg("host.diff_render")
-    rooms = [rr.synth_room(s, n_objects=n, target_faces=t) for s, n, t in ((11, 4, 300), (12, 7, 600), (13, 3, 200))]
+    spec = ((11, 4, 300), (12, 7, 600), (13, 3, 200), (14, 5, 450), (15, 6, 500), (16, 2, 150), (17, 8, 700), (18, 4, 350), (19, 5, 250))
+    rooms = [rr.synth_room(s, n_objects=n, target_faces=t) for s, n, t in spec[:n_rooms]]
     IS = 96
     singles, grads = [], []
-    go = torch.randn(3, 70, IS, IS, generator=torch.Generator().manual_seed(2)).cuda()
+    go = torch.randn(n_rooms, 70, IS, IS, generator=torch.Generator().manual_seed(2)).cuda()
     for i, (V, F, ranges, box) in enumerate(rooms):
         v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
         out = DR.scene_render(v, torch.from_numpy(F)[None].cuda(), ranges, torch.from_numpy(box), image_size=IS)
@@ -219,7 +222,7 @@ def test_batched_rooms_with_padding_equal_single_room_renders():
         vp = torch.zeros(Vmax, 3); vp[:V.shape[0]] = torch.from_numpy(V)
         prepared.append((vp, faces, cls, K[0], R[0], t[0])); Fmax = max(Fmax, faces.shape[0])
     Vb = torch.stack([p[0] for p in prepared]).cuda().requires_grad_(True)
-    Fb = torch.zeros(3, Fmax, 3, dtype=torch.int32); Cb = torch.full((3, Fmax), -1, dtype=torch.int32)
+    Fb = torch.zeros(n_rooms, Fmax, 3, dtype=torch.int32); Cb = torch.full((n_rooms, Fmax), -1, dtype=torch.int32)
     for i, p in enumerate(prepared):
         Fb[i, :p[1].shape[0]] = p[1]; Cb[i, :p[2].shape[0]] = p[2]
     out = DR.scene_render_batch(Vb, Fb.cuda(), Cb.cuda(), torch.tensor(chan, dtype=torch.int32).cuda(),
