@@ -252,3 +252,36 @@ def test_fused_projection_and_gather_equal_the_torch_ops():
     w = torch.randn(ref.shape, generator=g).cuda()
     (ref * w).sum().backward(); (got * w).sum().backward()
     assert_close(v2.grad.cpu().numpy(), v1.grad.cpu().numpy(), "d/d vertices", rtol=1e-4, atol=1e-4 * float(v1.grad.abs().max()))
+
+
+def test_renderer_batch_of_nine_equals_single_image_calls():
+    """nr.Renderer with a batch of 9 images (depth and rgb, forward and backward): every image must come out as in a call of
+    its own - the dense pixel-map backward's image -> XCD mapping (batches of 8 and more) against its small-batch path."""
+    NR = pkg("host.neural_renderer")
+    V, F, ranges, box = rr.synth_room(4, n_objects=6, target_faces=400)
+    K, R, t = [x.cuda() for x in rr.get_cam_mat(torch.from_numpy(box))]
+    zc = (torch.from_numpy(V).cuda() @ R[0].T + t[0])[:, 2].cpu().numpy()
+    F = F[(zc[F] > 0.3).all(1)]
+    B = 9
+    rng = np.random.default_rng(0)
+    Vb = torch.from_numpy(np.stack([V + rng.normal(0, 0.03, V.shape).astype(np.float32) * (k > 0) for k in range(B)])).cuda()
+    fb = torch.from_numpy(F)[None].cuda().expand(B, -1, -1).contiguous()
+    tex = torch.zeros(B, F.shape[0], 2, 2, 2, 3, device="cuda")
+    for k in range(B):
+        tex[k, k % 3::3] = 1.0
+    kw = dict(camera_mode='projection', image_size=96, anti_aliasing=False, orig_size=512, near=0.001, light_intensity_ambient=1.0,
+              light_intensity_directional=0.0)
+    for mode in ("depth", "rgb"):
+        vb = Vb.clone().requires_grad_(True)
+        out = NR.Renderer(K=K.expand(B, -1, -1).contiguous(), R=R.expand(B, -1, -1).contiguous(), t=t.expand(B, -1, -1).contiguous(), **kw)(
+            vb, fb, tex, mode=mode)
+        go = torch.randn(out.shape, generator=torch.Generator().manual_seed(1)).cuda()
+        (out * go).sum().backward()
+        for k in (0, 3, 8):
+            v1 = Vb[k:k + 1].clone().requires_grad_(True)
+            o1 = NR.Renderer(K=K, R=R, t=t, **kw)(v1, fb[k:k + 1], tex[k:k + 1], mode=mode)
+            assert torch.equal(out[k:k + 1], o1), (mode, k)
+            (o1 * go[k:k + 1]).sum().backward()
+            assert_close(vb.grad[k].cpu().numpy(), v1.grad[0].cpu().numpy(), "%s image %d dV" % (mode, k), rtol=1e-4,
+                         atol=1e-5 * float(v1.grad.abs().max()))
+            assert float(v1.grad.abs().max()) > 0

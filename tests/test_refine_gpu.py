@@ -188,8 +188,8 @@ def test_fast_finetune_loop_matches_the_reference_shaped_loop_and_its_graph_repl
     assert len(set(runs["graph"][0].tolist())) > 1
 
 
-@pytest.mark.parametrize("image_size", [256, 96])
-def test_fused_refinement_loss_matches_the_torch_ops(image_size):
+@pytest.mark.parametrize("image_size,batch", [(256, 1), (96, 1), (96, 2)])
+def test_fused_refinement_loss_matches_the_torch_ops(image_size, batch):
     """csrc/refine_loss.hip (null-fill, PSP pooling, L1, cross-entropy; backward through the transposed resampling) against
     the reference's own formulation - F.interpolate / l1_loss / cross_entropy (test_render_refine.py:192-215,328-356) -
     evaluated on the CPU in fp64 and fp32 on the same two images."""
@@ -203,6 +203,8 @@ def test_fused_refinement_loss_matches_the_torch_ops(image_size):
         b2 = boxes + 0.03; b2[-1] = boxes[-1]
         v, f, ranges, _, _ = R.assemble_scene(b2, angles + 0.7, NAMES, bank, room)
         img = DR.scene_render(v, f, ranges, room, image_size=image_size)
+        if batch == 2:                                            # second sample: the roles swapped (cross_entropy / l1 average over the batch)
+            target, img = torch.cat([target, img]), torch.cat([img, target])
     rl = R.RefineLoss(target)
     x = img.clone().requires_grad_(True)
     out = rl(x)
@@ -238,3 +240,23 @@ def test_fused_refinement_loss_matches_the_torch_ops(image_size):
     null = (target[:, 41:].sum(1) < 0.5)
     assert float(y.grad[:, 41:-1].abs().max()) == 0.0
     assert float(y.grad[:, -1][null].abs().max() if null.any() else 0.0) == 0.0 and torch.isfinite(filled)
+
+
+def test_room_without_visible_objects():
+    """Only classes mesh_render_func skips (diff_render.py:93-97): the scene is the room shell, gradients are zero."""
+    R = pkg("host.refine")
+    names = ["door", "window", "__room__"]
+    boxes = torch.tensor([[0.1, 0, 0.1, 0.3, 0.5, 0.2], [0.5, 0.2, 0.0, 0.7, 0.6, 0.05], [0, 0, 0, 4.0, 2.7, 5.0]], device="cuda")
+    angles = torch.tensor([3.0, 7.0, 0.0], device="cuda")
+    bank = R.MeshBank([], "cuda", seed=0)
+    scene = R.RefineScene(names, bank, boxes[-1].clone(), image_size=96)
+    assert scene.n_vis == 0
+    outs = []
+    for fused in (True, False):
+        b = boxes.clone().requires_grad_(True); a = angles.clone().requires_grad_(True)
+        img, sl, size = scene.render(b, a, None, fused=fused)
+        assert size.shape[0] == 0 and float(sl.detach()) == 0.0
+        (img.sum() + sl).backward()
+        assert float(b.grad.abs().max()) == 0.0 and float(a.grad.abs().max()) == 0.0
+        outs.append(img.detach())
+    assert torch.equal(outs[0], outs[1]) and float((outs[0][:, 0] > 0).float().mean()) > 0.5       # the shell is visible
