@@ -267,32 +267,34 @@ def test_two_half_iteration_equals_the_whole_one(use_graph):
 
 
 # ----------------------------------------------------------------------------- BASELINE config c2
-@pytest.mark.parametrize("n_graphs", [64, 256])
-def test_c2_full_size_train_step_vs_oracle(n_graphs):
+@pytest.mark.parametrize("n_graphs,n_obj,n_tri", [(64, 32, 64), (256, 32, 64), (7, 23, 37)])
+def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
     """Batch=64 x (32 objects, 64 triples) at train.py defaults: O=2048, T=4096 (BASELINE.json configs[1]); 256 graphs: the
     large-tile GEMM variants and the separate dgrad / wgrad launches the engine switches to above the batch-64 sizes."""
     cfg = vae_ref.VaeConfig()
-    # 256 graphs: with unit-scale weights the posterior heads give |logvar| ~ 16 and z = eps * exp(logvar / 2) + mu reaches
+    # other than the BASELINE batch: with unit-scale weights the posterior heads give |logvar| ~ 16 and z = eps * exp(logvar / 2) + mu reaches
     # 2e4 - the decoder input then amplifies the encoder's fp32 drift a hundredfold in ANY fp32 evaluation; quarter-scale
     # weights (BatchNorm renormalises every hidden layer, only the head outputs shrink) keep the comparison meaningful
     sd = vae_ref.init_state(cfg, seed=42, scale=1.0 if n_graphs == 64 else 0.25)
-    batch = vae_ref.synth_batch(n_graphs, 32, 64, seed=0, cfg=cfg)
+    batch = vae_ref.synth_batch(n_graphs, n_obj, n_tri, seed=0, cfg=cfg)        # (7, 23, 37): O = 161, T = 259 - no dimension a multiple of 4
     O = batch[0].shape[0]
     eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
-    if n_graphs > 64:
-        # d L1 / d boxes_pred = sign(boxes_pred - boxes) / numel: with 49 152 residuals one of them sits within fp32 rounding of
-        # 0 and ONE flipped sign moves box_net's bias gradient by 2 / numel = 2e-4 of its scale (seen).  Move the targets of the
-        # few residuals below 2e-3 away from the prediction (fp64 evaluation of the oracle decides) so that no sign is ambiguous.
+    if n_graphs != 64:
+        # d L1 / d boxes_pred = sign(boxes_pred - boxes) / numel: a residual within fp32 rounding of 0 gets its sign from rounding,
+        # and ONE flipped sign moves box_net's bias gradient by 2 / numel (seen: 2e-4 of its scale at 256 graphs, 1.5 % at 7
+        # graphs) and every gradient behind it.  Move the targets of the few residuals close to 0 away from the prediction
+        # (fp64 evaluation of the oracle decides) so that no sign is ambiguous.
         sdx = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
         boxes = batch[2].clone()
         for _ in range(4):
             with torch.no_grad():
                 bp64 = vae_ref.forward(sdx, cfg, batch[0], batch[1], boxes.double(), batch[3], batch[4], eps.double(), training=True)[2]
             res = (bp64 - boxes.double()).abs()
-            if not (res < 2e-4).any():               # moving targets moves every prediction a little (train-mode BatchNorm): the
+            band = 2e-4 + 2e-5 * float(bp64.abs().max())
+            if not (res < band).any():               # moving targets moves every prediction a little (train-mode BatchNorm): the
                 break                                # shifted band is 10x wider than the one that must end up empty
-            boxes = torch.where(res < 2e-3, boxes + 0.02, boxes)
-        assert not (res < 2e-4).any()
+            boxes = torch.where(res < 10 * band, boxes + 100 * band, boxes)
+        assert not (res < band).any()
         batch = (batch[0], batch[1], boxes) + tuple(batch[3:])
     model = _model(cfg, sd).train()
     dev = _dev(*batch[:5], eps)
@@ -332,8 +334,10 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs):
     # rounding of 0 flips its mask in one fp32 evaluation and not in another and moves the entry by one term.  Measured on
     # gconv_net_dc.gconvs.1.net2.1.bias (entries = sums of largely cancelling terms): 47 of 256 entries of the reference's own
     # fp32 gradient and 78 of ours are > 1e-5 (0.4 % of the scale) from the fp64 one, the worst of ours by two flips = 8 %.
-    # The tight comparison is the 64-graph case; at 256 graphs the check is that the large-tile / separately launched kernels
-    # produce the same tensors: max error within 2 % of the tensor's scale, or relative L2 error within 10 %.
+    # With 161 rows (7 graphs) one flipped term is 0.6 % of a sum and the reference's own fp32 gradients are 1 % from fp64.
+    # The tight comparison is the 64-graph case; the other sizes check that the large-tile / separately launched kernels and the
+    # odd shapes (no dimension a multiple of 4) produce the same tensors: max error within 2 % of the tensor's scale, or relative
+    # L2 error within 10 %.
     for k, gr in grads.items():
         try:
             got, r64 = named[k].grad.cpu().numpy(), grads64[k].numpy()
