@@ -502,3 +502,35 @@ def test_large_batch_equals_per_graph_evaluation():
         ref = vae_ref.forward(sd, cfg, batch[0][o0:o1], tr, batch[2][o0:o1], batch[3][o0:o1], batch[4][o0:o1], eps[o0:o1], training=False)
     for a, r, nm in zip(full, ref, ("mu", "logvar", "boxes_pred", "angles_pred")):
         assert_close(a[o0:o1], r.numpy(), "oracle graph %d %s" % (g, nm), rtol=1e-4, atol=1e-5)
+
+
+def test_graph_is_recaptured_when_the_batch_shape_changes():
+    """Real rooms differ in size from batch to batch: a captured iteration is tied to one (O, T); alternating shapes must
+    re-capture (also the two half-iteration graphs of the overlapped data-parallel step) and give what eager launches give."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    shapes = [(8, 12, 20), (5, 9, 14), (8, 12, 20), (3, 30, 41)]
+    batches = []
+    for i, (g, o, t) in enumerate(shapes):
+        b = vae_ref.synth_batch(g, o, t, seed=20 + i, cfg=cfg)
+        e = torch.randn(b[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(i))
+        batches.append(_dev(*b[:5], e))
+    outs = {}
+    for mode in ("eager", "graph", "halves"):
+        model = _model(cfg, vae_ref.init_state(cfg, seed=1)).train()
+        s = torch.cuda.Stream()
+        losses = []
+        with torch.cuda.stream(s):
+            for d in batches:
+                if mode == "halves":
+                    l = model.train_step_begin(*d[:5], kl_weight=0.1, lr=1e-3, eps=d[5], use_graph=True)
+                    model.train_step_finish(use_graph=True)
+                    model.adam_step(lr=1e-3)
+                else:
+                    l = model.train_step(*d[:5], kl_weight=0.1, lr=1e-3, eps=d[5], use_graph=(mode == "graph"))
+                losses.append(l)
+        torch.cuda.synchronize()
+        outs[mode] = (torch.stack(losses).cpu().numpy(), model.flat_params.cpu().numpy().copy())
+    for mode in ("graph", "halves"):
+        assert_close(outs[mode][0], outs["eager"][0], mode + ": losses", rtol=1e-5)
+        d = np.abs(outs[mode][1] - outs["eager"][1])
+        assert d.max() <= 2.05 * 1e-3 * len(shapes) and np.mean(d > 1e-5) < 0.02, (mode, d.max(), np.mean(d > 1e-5))
