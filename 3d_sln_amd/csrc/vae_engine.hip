@@ -77,6 +77,7 @@ struct SlnVae {
   double* stats_base = nullptr; size_t stats_doubles = 0, enc_stats_doubles = 0;   // [enc sums | dec sums]
   double* gstats_base = nullptr;                                                   // [enc gsums | dec gsums]
   char* zero_begin = nullptr; size_t zero_bytes = 0; bool bulk_zeroed = false;     // see carve() / train_iteration()
+  int64_t* st_objs = nullptr; int64_t* st_angles = nullptr; int64_t* st_attrs = nullptr; float* st_boxes = nullptr;   // staged batch inputs
   BnTableEntry* bn_table_dev = nullptr;
   TransposeEntry* tr_table_dev = nullptr; int n_tr = 0, tr_max_tiles = 0;
   AdamScalars* scalars = nullptr; double* loss_acc = nullptr; float* losses = nullptr;
@@ -314,6 +315,8 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   g.deg = b.take<int>(Om); g.invdeg = b.take<float>(Om); g.rowptr = b.take<int>(Om + 1);
   g.cursor = b.take<int>(Om); g.ent = b.take<int>(2 * Tm);
   attrs32 = b.take<int>(Om); err_flag = b.take<int>(4);
+  // engine-owned copies of the batch inputs (see sln_vae_set_batch)
+  st_objs = b.take<int64_t>(Om); st_angles = b.take<int64_t>(Om); st_attrs = b.take<int64_t>(Om); st_boxes = b.take<float>(Om * 6);
   scalars = b.take<AdamScalars>(1); losses = b.take<float>(4);
   // BatchNorm statistics arena
   size_t nd = 0, nd_enc = 0;
@@ -852,6 +855,15 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
     RET_IF(upload_bn_table(h));
     h->drop_graphs();
   }
+  // The kernels of an iteration read the batch through h->batch.  A captured iteration (hipGraph) has those addresses baked in,
+  // and the caller's tensors are new ones for every batch (DataLoader, synthetic generator): stage the inputs in engine-owned
+  // buffers whose addresses never change, so that a replay sees the CURRENT batch (it used to read the tensors of the batch it was
+  // captured with whenever two consecutive batches had the same shape).  Four small device-to-device copies outside the graph.
+  HIP_RET(hipMemcpyAsync(h->st_objs, b->objs, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
+  HIP_RET(hipMemcpyAsync(h->st_angles, b->angles, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
+  HIP_RET(hipMemcpyAsync(h->st_attrs, b->attributes, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
+  HIP_RET(hipMemcpyAsync(h->st_boxes, b->boxes, sizeof(float) * (size_t)b->O * h->cfg.box_dim, hipMemcpyDeviceToDevice, st));
+  h->batch.objs = h->st_objs; h->batch.angles = h->st_angles; h->batch.attributes = h->st_attrs; h->batch.boxes = h->st_boxes;
   HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
   RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->cfg.num_preds, h->g, h->err_flag, st));
   RET_IF(sln_launch_validate_ids(b->objs, b->attributes, b->angles, b->O, h->cfg.num_objs, h->cfg.num_attrs, h->cfg.n_angle,

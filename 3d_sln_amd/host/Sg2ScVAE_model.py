@@ -164,6 +164,7 @@ class Sg2ScVAEModel(nn.Module):
                 views.append(gv)
         self._flat, self._gflat, self._gviews, self._params = flat, gflat, views, params
         self._adam_m = self._adam_v = None
+        self._adam_steps = 0                       # Adam's step counter lives in the engine's workspace: restored after a re-bind
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
         self._drop_engine()
 
@@ -252,6 +253,10 @@ class Sg2ScVAEModel(nn.Module):
             _lib.check(int(nbytes), "sln_vae_workspace_bytes")
         dev = self._flat.device
         self._ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=dev)
+        # sln_vae_bind writes Adam's constants into the workspace with a BLOCKING copy (legacy stream); the zero-fill above is
+        # asynchronous on the current (non-blocking) stream and, with work queued in front of it, would land AFTER that copy and
+        # wipe beta1 / beta2 / eps (seen when a larger batch re-created the engine in the middle of training: NaN two steps later)
+        torch.cuda.current_stream(dev).synchronize()
         if self._adam_m is None:
             self._adam_m = torch.zeros_like(self._flat)
             self._adam_v = torch.zeros_like(self._flat)
@@ -282,6 +287,10 @@ class Sg2ScVAEModel(nn.Module):
         t.adam_m, t.adam_v, t.n_flat = self._adam_m.data_ptr(), self._adam_v.data_ptr(), self._flat.numel()
         self._units_keepalive = arr
         _lib.check(L.sln_vae_bind(h, C.byref(t), C.c_void_p(self._ws.data_ptr()), int(nbytes), maxO, maxT), "sln_vae_bind")
+        if self._adam_steps:
+            # a larger batch re-creates the engine (bigger workspace); the moments live in this module, the bias-correction step
+            # in the workspace - without this the update after a re-bind would be scaled as if it were the first one
+            _lib.check(L.sln_vae_adam_reset(h, int(self._adam_steps), _lib.current_stream_ptr()), "sln_vae_adam_reset")
         self._maxO, self._maxT = maxO, maxT
         self._batch_key = None
 
@@ -406,6 +415,7 @@ class Sg2ScVAEModel(nn.Module):
         _lib.check(_lib.lib().sln_vae_train_step(
             self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph), int(with_adam),
             _lib.current_stream_ptr()), "sln_vae_train_step")
+        self._adam_steps += int(bool(with_adam))
         self._alias_grads()
         return losses
 
@@ -448,6 +458,7 @@ class Sg2ScVAEModel(nn.Module):
     def adam_step(self, lr=1e-4):
         """torch.optim.Adam(lr).step() over the flat parameter buffer (fused kernel)."""
         _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")
+        self._adam_steps += 1
 
     def loss(self, kl_weight=0.1, with_grads=False):
         """calculate_model_losses (utils.py:12-33) on the outputs of the last forward, on device."""

@@ -101,13 +101,16 @@ int sln_vae_create(const SlnVaeConfig* cfg, SlnVae** out);
 void sln_vae_destroy(SlnVae* h);
 /* bytes of device workspace needed for batches up to (max_objs, max_triples) */
 int64_t sln_vae_workspace_bytes(const SlnVae* h, int max_objs, int max_triples);
-/* workspace must be zero-filled once by the caller and stay alive while the engine is used */
+/* workspace must be zero-filled once by the caller - the fill must have COMPLETED: bind writes into it with blocking copies
+ * that are not ordered behind work on other streams - and stay alive while the engine is used */
 int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t workspace_bytes,
                  int max_objs, int max_triples);
 
 /* Build the per-batch graph structure (int32 ids, degrees, CSR of incident triples).  Must
  * precede encoder/decoder calls for a new batch.  Replaces the index/scatter_add bookkeeping of
- * GraphTripleConv.forward (models/graph.py:70-72,89-108), hoisted out of the 10 layers. */
+ * GraphTripleConv.forward (models/graph.py:70-72,89-108), hoisted out of the 10 layers.  All five inputs are copied
+ * (stream-ordered) into the workspace: the caller's tensors are not read after this call, and a captured iteration
+ * (sln_vae_train_step with use_graph) replays on whatever batch was bound last. */
 int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream);
 /* Synchronising check of the bound batch: SLN_E_BADARG when a triple / class / attribute / angle id is out of range
  * (the reference's embedding and index ops raise IndexError there; the kernels neutralise such rows). */

@@ -168,3 +168,7 @@ def test_full_size_batch_of_32_equals_per_sample_calls():
             assert_close(out[b:b + 1].cpu().numpy(), one.cpu().numpy(), "sample %d" % b, rtol=1e-5, atol=1e-5)
         # different samples give different images (the batch is not broadcast from one sample)
         assert float((out[0] - out[1]).abs().max()) > 1e-3
+        # one semantic map, several z (colorize_with_spade) at full size: the shared gamma/beta path against the per-sample path
+        shared = G(seg[5:6].contiguous(), z[:3].contiguous())
+        per = G(seg[5:6].expand(3, -1, -1, -1).contiguous(), z[:3].contiguous())
+        assert_close(shared.cpu().numpy(), per.cpu().numpy(), "full-size shared vs per-sample", rtol=1e-5, atol=1e-5)

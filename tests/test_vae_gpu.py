@@ -508,7 +508,9 @@ def test_graph_is_recaptured_when_the_batch_shape_changes():
     """Real rooms differ in size from batch to batch: a captured iteration is tied to one (O, T); alternating shapes must
     re-capture (also the two half-iteration graphs of the overlapped data-parallel step) and give what eager launches give."""
     cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
-    shapes = [(8, 12, 20), (5, 9, 14), (8, 12, 20), (3, 30, 41)]
+    # (16, 20, 30) outgrows the bound workspace (the engine is re-created, Adam's step counter must survive); its repetition is a
+    # NEW batch of the SAME shape: the replayed graph must read the new tensors, not the ones it was captured with
+    shapes = [(8, 12, 20), (5, 9, 14), (8, 12, 20), (3, 30, 41), (16, 20, 30), (16, 20, 30), (16, 20, 30)]
     batches = []
     for i, (g, o, t) in enumerate(shapes):
         b = vae_ref.synth_batch(g, o, t, seed=20 + i, cfg=cfg)
@@ -531,6 +533,9 @@ def test_graph_is_recaptured_when_the_batch_shape_changes():
         torch.cuda.synchronize()
         outs[mode] = (torch.stack(losses).cpu().numpy(), model.flat_params.cpu().numpy().copy())
     for mode in ("graph", "halves"):
-        assert_close(outs[mode][0], outs["eager"][0], mode + ": losses", rtol=1e-5)
+        # Adam turns the rounding noise of near-zero gradients into +-lr steps, so two runs of this sequence drift apart (seen:
+        # 1e-3 of the loss at the 7th step); reading a stale batch, restarting Adam's bias correction or losing its constants
+        # moves the later losses by 1.5 % and more (or to NaN)
+        assert_close(outs[mode][0], outs["eager"][0], mode + ": losses", rtol=3e-3)
         d = np.abs(outs[mode][1] - outs["eager"][1])
-        assert d.max() <= 2.05 * 1e-3 * len(shapes) and np.mean(d > 1e-5) < 0.02, (mode, d.max(), np.mean(d > 1e-5))
+        assert d.max() <= 2.05 * 1e-3 * len(shapes), (mode, d.max())
