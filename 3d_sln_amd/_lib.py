@@ -101,6 +101,7 @@ SIGNATURES = {
     "sln_vae_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "sln_vae_adam_reset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "sln_vae_set_training": (C.c_int, [C.c_void_p, C.c_int]),
     "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_prof_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

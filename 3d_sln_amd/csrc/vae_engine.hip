@@ -77,6 +77,7 @@ struct SlnVae {
   double* stats_base = nullptr; size_t stats_doubles = 0, enc_stats_doubles = 0;   // [enc sums | dec sums]
   double* gstats_base = nullptr;                                                   // [enc gsums | dec gsums]
   char* zero_begin = nullptr; size_t zero_bytes = 0; bool bulk_zeroed = false;     // see carve() / train_iteration()
+  bool step_training = true;     // BatchNorm mode of the fused training iteration (train.py:63-65: model.eval() keeps training)
   int64_t* st_objs = nullptr; int64_t* st_angles = nullptr; int64_t* st_attrs = nullptr; float* st_boxes = nullptr;   // staged batch inputs
   BnTableEntry* bn_table_dev = nullptr;
   TransposeEntry* tr_table_dev = nullptr; int n_tr = 0, tr_max_tiles = 0;
@@ -662,8 +663,8 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
     HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
     bulk_zeroed = true;
-    r = encoder_forward(true, st);
-    if (!r) r = decoder_forward(nullptr, eps, true, st);
+    r = encoder_forward(step_training, st);
+    if (!r) r = decoder_forward(nullptr, eps, step_training, st);
     if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
     if (!r) r = decoder_backward(st);
     if (!r) r = sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st);
@@ -1001,6 +1002,12 @@ int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream) {
   return (int)hipMemcpyAsync(&h->scalars->step, &h->host_step, sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream);
 }
 
+int sln_vae_set_training(SlnVae* h, int training) {
+  if (!h) return SLN_E_BADARG;
+  if (h->step_training != (training != 0)) { h->step_training = training != 0; h->drop_graphs(); }
+  return 0;
+}
+
 int sln_vae_params_changed(SlnVae* h) {       // parameters were modified outside the engine (load_state_dict, SGD)
   if (!h) return SLN_E_BADARG;
   h->wt_fresh = false;
@@ -1014,7 +1021,7 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
   if (mode < 0 || mode > 3) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (mode == SlnVae::TRAIN_ENCODER_BWD) {
-    if (!(h->have_dec && h->dec_training && h->z_from_latent)) return SLN_E_STATE;       // needs the first half
+    if (!(h->have_dec && h->dec_training == h->step_training && h->z_from_latent)) return SLN_E_STATE;       // needs the first half
   } else {
     if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
     RET_IF(set_kl(h, kl_weight, lr, st));
@@ -1039,7 +1046,7 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
       h->graph_O[mode] = h->O; h->graph_T[mode] = h->T;
     }
     HIP_RET(hipGraphLaunch(ge, st));
-    h->enc_training = h->dec_training = true; h->have_enc = h->have_dec = true; h->z_from_latent = true;
+    h->enc_training = h->dec_training = h->step_training; h->have_enc = h->have_dec = true; h->z_from_latent = true;
     h->wt_fresh = mode == SlnVae::TRAIN_UPTO_DECODER || mode == SlnVae::TRAIN_ENCODER_BWD;   // rebuilt by the graph, no Adam yet
   } else {
     RET_IF(h->train_iteration(h->eps_buf, mode, st));

@@ -400,7 +400,8 @@ class Sg2ScVAEModel(nn.Module):
     # ------------------------------------------------------------------ fused training iteration
     def train_step(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None,
                    use_graph=True, with_adam=True):
-        """train.py:62-84 in one call: zero_grad, forward (train-mode BN), losses, backward, Adam.
+        """train.py:62-84 in one call: zero_grad, forward (BatchNorm in the module's mode: ``model.eval()`` keeps training on the
+        running statistics, train.py:63-65), losses, backward, Adam.
 
         Returns a 4-element device tensor [bbox_pred, angle_pred, KLD_Gauss*w, total_loss] (no host sync).
         ``with_adam=False`` stops after backward (gradients in ``flat_grads``): the data-parallel
@@ -412,6 +413,7 @@ class Sg2ScVAEModel(nn.Module):
             eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
         losses = self._new(4)
         self._generation += 1
+        _lib.check(_lib.lib().sln_vae_set_training(self._eng, int(self.training)), "sln_vae_set_training")     # train.py:63-65
         _lib.check(_lib.lib().sln_vae_train_step(
             self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph), int(with_adam),
             _lib.current_stream_ptr()), "sln_vae_train_step")
@@ -444,6 +446,7 @@ class Sg2ScVAEModel(nn.Module):
             eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
         losses = self._new(4)
         self._generation += 1
+        _lib.check(_lib.lib().sln_vae_set_training(self._eng, int(self.training)), "sln_vae_set_training")
         _lib.check(_lib.lib().sln_vae_train_step(
             self._eng, _lib.ptr(eps), float(kl_weight), float(lr), _lib.ptr(losses), int(use_graph), 2,
             _lib.current_stream_ptr()), "sln_vae_train_step(begin)")

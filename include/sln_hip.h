@@ -156,6 +156,9 @@ int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream);       /* restore 
  * decoder-side parameters are final, SLN_TRAIN_ENCODER_BWD the rest; the all-reduce of the decoder half of flat_grads
  * runs on another stream in between.  `losses_out` is written by every mode except SLN_TRAIN_ENCODER_BWD. */
 enum { SLN_TRAIN_BACKWARD = 0, SLN_TRAIN_FULL = 1, SLN_TRAIN_UPTO_DECODER = 2, SLN_TRAIN_ENCODER_BWD = 3 };
+/* BatchNorm mode of sln_vae_train_step: 1 (default) = batch statistics + running-stat update, 0 = running statistics as a fixed
+ * affine map (train.py:63-65: after --eval_mode_after the reference calls model.eval() and keeps training). */
+int sln_vae_set_training(SlnVae* h, int training);
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
                        int with_adam, void* stream);
 

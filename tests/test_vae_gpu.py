@@ -539,3 +539,84 @@ def test_graph_is_recaptured_when_the_batch_shape_changes():
         assert_close(outs[mode][0], outs["eager"][0], mode + ": losses", rtol=3e-3)
         d = np.abs(outs[mode][1] - outs["eager"][1])
         assert d.max() <= 2.05 * 1e-3 * len(shapes), (mode, d.max())
+
+
+@pytest.mark.parametrize("norm", ["batch", "none"])
+def test_eval_mode_gradients_match_the_oracle(norm):
+    """train.py:63-65 switches the model to eval mode after --eval_mode_after iterations and KEEPS training: BatchNorm then is a
+    fixed affine map (running statistics), its gamma / beta still receive gradients.  Autograd path, every parameter."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization=norm)
+    sd = vae_ref.init_state(cfg, seed=9)
+    batch = vae_ref.synth_batch(6, 7, 11, seed=5, cfg=cfg)
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(2).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    keys = vae_ref.trainable_keys(cfg)
+    sdr = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_(True)
+    mu, lv, bp, ap = vae_ref.forward(sdr, cfg, batch[0], batch[1], batch[2].double(), batch[3], batch[4], eps.double(), training=False)
+    total, _ = vae_ref.losses(cfg, batch[2].double(), bp, batch[3], ap, mu, lv, 0.1)
+    total.backward()
+    model = _model(cfg, sd).eval()
+    dev = _dev(*batch[:5], eps)
+    out = model(*dev[:5], None, eps=dev[5])
+    U = pkg("host.utils")
+    import types
+    t2, _ = U.calculate_model_losses(types.SimpleNamespace(use_AE=cfg.use_AE), model, dev[2], out[2], dev[3], out[3], mu=out[0], logvar=out[1],
+                                     KL_weight=0.1)
+    model.zero_grad()
+    t2.backward()
+    assert_close(float(t2.detach()), float(total.detach()), "eval total", rtol=1e-5)
+    gscale = max(float(sdr[k].grad.abs().max()) for k in keys if sdr[k].grad is not None)
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = sdr[k].grad
+        got = named[k].grad
+        if ref is None:
+            assert got is None or float(got.abs().max()) == 0.0, k
+            continue
+        assert_close(got.cpu().numpy(), ref.numpy(), "eval grad " + k, rtol=2e-4, atol=2e-6 * gscale)
+    for k, v in model.state_dict().items():          # eval mode leaves the BatchNorm buffers alone
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v.cpu(), sd[k]), k
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_fused_step_in_eval_mode_matches_the_oracle(use_graph):
+    """The fused iteration after ``model.eval()`` (train.py:63-65): running statistics in forward and backward, buffers untouched,
+    gradients of every parameter as the oracle's eval-mode autograd gives them; back in train mode the graph is re-captured."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization="batch")
+    sd = vae_ref.init_state(cfg, seed=9)
+    batch = vae_ref.synth_batch(6, 7, 11, seed=5, cfg=cfg)
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(2).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    keys = vae_ref.trainable_keys(cfg)
+    refs = {}
+    for training in (False, True):
+        sdr = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k in keys:
+            sdr[k].requires_grad_(True)
+        mu, lv, bp, ap = vae_ref.forward(sdr, cfg, batch[0], batch[1], batch[2].double(), batch[3], batch[4], eps.double(), training=training)
+        total, _ = vae_ref.losses(cfg, batch[2].double(), bp, batch[3], ap, mu, lv, 0.1)
+        total.backward()
+        refs[training] = (float(total.detach()), {k: sdr[k].grad for k in keys})
+    model = _model(cfg, sd)
+    dev = _dev(*batch[:5], eps)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for training in (True, False, False, True):                      # mode switches in both directions, one replay in between
+            model.train(training)
+            before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+            losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=use_graph, with_adam=False)
+            torch.cuda.synchronize()
+            total, grads = refs[training]
+            assert_close(float(losses[3]), total, "total (training=%s)" % training, rtol=2e-5)
+            gscale = max(float(g.abs().max()) for g in grads.values() if g is not None)
+            named = dict(model.named_parameters())
+            for k, g in grads.items():
+                if g is not None:
+                    assert_close(named[k].grad.cpu().numpy(), g.numpy(), "grad %s (training=%s)" % (k, training), rtol=3e-4, atol=3e-6 * gscale)
+            changed = any(not torch.equal(before[k], v) for k, v in model.state_dict().items() if "running" in k)
+            assert changed == training
+            if training:                                                 # undo the running-stat update: the oracle starts from sd
+                model.load_state_dict({k: v.clone() for k, v in sd.items()})
