@@ -676,7 +676,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
   bulk_zeroed = false;
   RET_IF(r);
   if (mode == TRAIN_FULL) {
-    RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, st));
+    RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, losses + 3, st));
     wt_fresh = false;                  // transposed copies are rebuilt at the start of the next backward
   }
   return 0;
@@ -991,7 +991,8 @@ int sln_vae_adam_step(SlnVae* h, float lr, void* stream) {
   if (!h || !h->bound || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
   hipStream_t st = (hipStream_t)stream;
   RET_IF(set_kl(h, h->host_scalars_valid ? h->host_kl : 0.1f, lr, st));
-  RET_IF(sln_launch_adam(h->t.flat_params, h->t.flat_grads, h->t.adam_m, h->t.adam_v, (long)h->t.n_flat, h->scalars, st));
+  // the loss of the last iteration on THIS rank guards the update (losses[3] stays 0 until a loss was computed)
+  RET_IF(sln_launch_adam(h->t.flat_params, h->t.flat_grads, h->t.adam_m, h->t.adam_v, (long)h->t.n_flat, h->scalars, h->losses + 3, st));
   h->wt_fresh = false;
   return 0;
 }

@@ -116,6 +116,7 @@ int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, int i
 struct TransposeEntry { const float* src; float* dst; int rows; int cols; int dst_ld; int pad_; };   // dst[c*dst_ld + r] = src[r*cols + c]
 int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles, hipStream_t st);
 
-struct AdamScalars { int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; };
-int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars,
+struct AdamScalars { int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; int skip, pad_; };
+// total_loss (device, may be NULL): a non-finite value skips the update and the step count (train.py:79-81 'not backpropping')
+int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
                     hipStream_t st);

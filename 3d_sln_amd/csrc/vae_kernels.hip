@@ -598,7 +598,10 @@ __global__ __launch_bounds__(256) void transpose_table_kernel(const TransposeEnt
   }
 }
 
-__global__ void adam_tick_kernel(AdamScalars* s) {
+__global__ void adam_tick_kernel(AdamScalars* s, const float* __restrict__ total_loss) {
+  // train.py:79-81: a non-finite total loss is reported and the iteration is skipped (no backward, no optimizer step)
+  s->skip = (total_loss != nullptr && !isfinite(total_loss[0])) ? 1 : 0;
+  if (s->skip) return;
   s->step += 1;
   s->bc1 = (float)(1.0 - pow((double)s->beta1, (double)s->step));
   s->bc2 = (float)(1.0 - pow((double)s->beta2, (double)s->step));
@@ -607,6 +610,7 @@ __global__ void adam_tick_kernel(AdamScalars* s) {
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, long n, const AdamScalars* __restrict__ sc) {
   // torch.optim.Adam defaults (train.py:15): no weight decay, no amsgrad
+  if (sc->skip) return;
   const float b1 = sc->beta1, b2 = sc->beta2, eps = sc->eps;
   const float step_size = sc->lr / sc->bc1, rs2 = 1.0f / sqrtf(sc->bc2);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -870,9 +874,10 @@ int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles
   return 0;
 }
 
-int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, hipStream_t st) {
+int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
+                    hipStream_t st) {
   SlnProfScope prof(SLN_FAM_OTHER, 28.0 * n, st);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, scalars);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, scalars, total_loss);
   if (n > 0) {
     long blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;

@@ -155,7 +155,7 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
         if t % args.print_every == 0 or t == args.num_iterations:
             vals = [float(x) for x in losses.detach().cpu()]          # the only host sync, every print_every steps
             if not math.isfinite(vals[3]):
-                log('WARNING: Got loss = NaN')                       # train.py:79-81 (the fused step has already been applied)
+                log('WARNING: Got loss = NaN, not backpropping')     # train.py:79-81; the fused step skipped the update on the device
             if rank == 0:
                 log("On batch {} out of {}".format(t, args.num_iterations))
                 for name, v in zip(('bbox_pred', 'angle_pred', 'KLD_Gauss', 'total_loss'), vals):

@@ -620,3 +620,31 @@ def test_fused_step_in_eval_mode_matches_the_oracle(use_graph):
             assert changed == training
             if training:                                                 # undo the running-stat update: the oracle starts from sd
                 model.load_state_dict({k: v.clone() for k, v in sd.items()})
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_non_finite_loss_skips_the_update_like_the_reference(use_graph):
+    """train.py:79-81: 'WARNING: Got loss = NaN, not backpropping' - the iteration is skipped.  The fused step decides on the
+    device: parameters, Adam moments and the step count stay as they were, and the next good batch trains normally."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=3)
+    good = _dev(*vae_ref.synth_batch(4, 6, 9, seed=1, cfg=cfg)[:5])
+    bad = [t.clone() for t in good]
+    bad[2][3, 1] = float("nan")                                   # one box coordinate
+    eps = torch.randn(good[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+    ref = _model(cfg, sd).train()
+    model = _model(cfg, sd).train()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        l_ref = [ref.train_step(*good, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=use_graph) for _ in range(2)]
+        p0 = model.flat_params.clone()
+        l_bad = model.train_step(*bad, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=use_graph)
+        p1 = model.flat_params.clone()
+        l_good = [model.train_step(*good, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=use_graph) for _ in range(2)]
+    torch.cuda.synchronize()
+    assert not np.isfinite(float(l_bad[3]))
+    assert torch.equal(p0, p1), "a non-finite loss must not move the parameters"
+    assert torch.isfinite(model.flat_params).all()
+    # (BatchNorm's running statistics saw the NaN batch, as in the reference where the forward pass ran; train mode ignores them)
+    a, b = float(l_good[0][3]), float(l_ref[0][3])
+    assert abs(a - b) <= 1e-5 * abs(b), (a, b)                    # first good step: same parameters as an untouched model
