@@ -163,6 +163,7 @@ class Sg2ScVAEModel(nn.Module):
                 p.grad = gv
                 views.append(gv)
         self._flat, self._gflat, self._gviews, self._params = flat, gflat, views, params
+        self._offs = offs
         self._adam_m = self._adam_v = None
         self._adam_steps = 0                       # Adam's step counter lives in the engine's workspace: restored after a re-bind
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
@@ -462,6 +463,45 @@ class Sg2ScVAEModel(nn.Module):
         """torch.optim.Adam(lr).step() over the flat parameter buffer (fused kernel)."""
         _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")
         self._adam_steps += 1
+
+    # -- optimizer state in torch.optim.Adam's own format (train.py:94 saves optimizer.state_dict(), :25 restores it) ---------
+    def optim_state_dict(self, lr=1e-4):
+        """What ``torch.optim.Adam(model.parameters(), lr).state_dict()`` would hold after the same steps: per-parameter
+        ``step`` / ``exp_avg`` / ``exp_avg_sq`` in ``model.parameters()`` order - a reference checkpoint's ``optim_state`` and this
+        one are interchangeable."""
+        state = {}
+        if self._adam_m is not None and self._adam_steps > 0:
+            for i, (p, o) in enumerate(zip(self._params, self._offs)):
+                n = p.numel()
+                state[i] = {'step': torch.tensor(float(self._adam_steps)),
+                            'exp_avg': self._adam_m[o:o + n].view(p.shape).clone(), 'exp_avg_sq': self._adam_v[o:o + n].view(p.shape).clone()}
+        group = {'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-08, 'weight_decay': 0, 'amsgrad': False, 'maximize': False, 'foreach': None,
+                 'capturable': False, 'differentiable': False, 'fused': None, 'params': list(range(len(self._params)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optim_state_dict(self, sd):
+        """Restore the fused Adam from ``optim_state_dict()`` output or from a ``torch.optim.Adam`` state_dict of this model."""
+        g = sd['param_groups'][0]
+        if tuple(g.get('betas', (0.9, 0.999))) != (0.9, 0.999) or g.get('weight_decay', 0) != 0 or g.get('amsgrad', False):
+            raise NotImplementedError("the fused Adam implements the reference's configuration (train.py:15): default betas, no weight decay")
+        if self._adam_m is None:
+            self._adam_m = torch.zeros_like(self._flat)
+            self._adam_v = torch.zeros_like(self._flat)
+            self._drop_engine()                                    # the engine binds the moment buffers at creation
+        self._adam_m.zero_(); self._adam_v.zero_()
+        steps = 0
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(self._params, self._offs)):
+                st = sd['state'].get(i)
+                if st is None:
+                    continue
+                n = p.numel()
+                self._adam_m[o:o + n].copy_(st['exp_avg'].reshape(-1).to(self._flat.device, torch.float32))
+                self._adam_v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1).to(self._flat.device, torch.float32))
+                steps = max(steps, int(float(st['step'])))
+        self._adam_steps = steps
+        if self._eng is not None:
+            _lib.check(_lib.lib().sln_vae_adam_reset(self._eng, steps, _lib.current_stream_ptr()), "sln_vae_adam_reset")
 
     def loss(self, kl_weight=0.1, with_grads=False):
         """calculate_model_losses (utils.py:12-33) on the outputs of the last forward, on device."""

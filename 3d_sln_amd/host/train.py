@@ -147,6 +147,18 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
     checkpoint = {'args': dict(vars(args)), 'losses_ts': [], 'losses': defaultdict(list), 'checkpoint_ts': [],
                   'counters': {'t': None, 'epoch': None}, 'model_state': None, 'optim_state': None}
     t = 0
+    # train.py:16-31: resume from '<checkpoint_name>_with_model.pt' (model, optimizer - torch.optim.Adam's own state layout -, t)
+    restore_path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name) if getattr(args, "restore_from_checkpoint", False) else None
+    if restore_path is not None and os.path.isfile(restore_path) and hasattr(model, "load_optim_state_dict"):
+        log('Restoring from checkpoint:')
+        log(restore_path)
+        ck = torch.load(restore_path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ck['model_state'])
+        if ck.get('optim_state') is not None:
+            model.load_optim_state_dict(ck['optim_state'])
+        t = ck['counters']['t']
+        model.eval() if 0 <= args.eval_mode_after <= t else model.train()
+        checkpoint.update({k: ck[k] for k in ('losses_ts', 'losses', 'checkpoint_ts') if k in ck})
     while t < args.num_iterations:
         if t == args.eval_mode_after:
             model.eval()
@@ -164,6 +176,10 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
                 checkpoint['losses_ts'].append(t)
         if rank == 0 and t % args.checkpoint_every == 0:
             checkpoint['model_state'] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            if hasattr(model, "optim_state_dict"):
+                osd = model.optim_state_dict(args.learning_rate)                                # train.py:94
+                osd['state'] = {i: {k: v.detach().cpu() for k, v in st.items()} for i, st in osd['state'].items()}
+                checkpoint['optim_state'] = osd
             checkpoint['counters']['t'] = t
             os.makedirs(args.output_dir, exist_ok=True)
             torch.save(checkpoint, os.path.join(args.output_dir, 'latest_%s_with_model.pt' % args.checkpoint_name))

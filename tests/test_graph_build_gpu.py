@@ -162,3 +162,27 @@ def test_train_loop_reads_rooms_through_the_device_builder(tmp_path, capsys):
     totals = [float(l.split(":")[1]) for l in logs if "[total_loss]" in l]
     assert any("Training dataset has 48 scenes" in l for l in logs)
     assert len(totals) == 3 and all(np.isfinite(totals)) and totals[-1] < totals[0]
+
+
+def test_train_script_checkpoints_and_resumes(tmp_path, capsys):
+    """train.py:16-31,92-98: the checkpoint holds the model, the optimizer state (torch.optim.Adam's layout) and t; a run with
+    --restore_from_checkpoint continues from there (the reference restores '<name>_with_model.pt', it saves 'latest_<name>_…')."""
+    T = pkg("host.train")
+    common = ["--batch_size", "8", "--objs_per_graph", "6", "--triples_per_graph", "9", "--embedding_dim", "32", "--gconv_num_layers", "2",
+              "--print_every", "2", "--output_dir", str(tmp_path), "--checkpoint_name", "run"]
+    T.main(common + ["--num_iterations", "4", "--checkpoint_every", "4"])
+    saved = tmp_path / "latest_run_with_model.pt"
+    assert saved.is_file()
+    ck = torch.load(saved, map_location="cpu", weights_only=False)
+    assert ck["counters"]["t"] == 4 and float(ck["optim_state"]["state"][0]["step"]) == 4.0
+    assert set(ck["optim_state"]["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and ck["losses_ts"] == [2, 4]
+    os.rename(saved, tmp_path / "run_with_model.pt")
+    capsys.readouterr()
+    T.main(common + ["--num_iterations", "6", "--checkpoint_every", "6", "--restore_from_checkpoint", "1"])
+    logs = capsys.readouterr().out.splitlines()
+    assert any("Restoring from checkpoint" in l for l in logs)
+    assert [l for l in logs if l.startswith("On batch")] == ["On batch 6 out of 6"]        # t resumed at 4: only iterations 5 and 6 ran
+    ck2 = torch.load(tmp_path / "latest_run_with_model.pt", map_location="cpu", weights_only=False)
+    assert ck2["counters"]["t"] == 6 and float(ck2["optim_state"]["state"][0]["step"]) == 6.0 and ck2["losses_ts"] == [2, 4, 6]
+    moved = max(float((ck2["model_state"][k] - ck["model_state"][k]).abs().max()) for k in ck["model_state"] if k.endswith(".weight"))
+    assert 0 < moved < 1e-2

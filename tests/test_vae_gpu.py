@@ -648,3 +648,45 @@ def test_non_finite_loss_skips_the_update_like_the_reference(use_graph):
     # (BatchNorm's running statistics saw the NaN batch, as in the reference where the forward pass ran; train mode ignores them)
     a, b = float(l_good[0][3]), float(l_ref[0][3])
     assert abs(a - b) <= 1e-5 * abs(b), (a, b)                    # first good step: same parameters as an untouched model
+
+
+def test_optimizer_state_is_interchangeable_with_torch_adam():
+    """train.py:94 saves ``optimizer.state_dict()`` and :25 restores it.  The fused Adam exports / imports torch.optim.Adam's
+    own layout: three fused steps, then the 4th step taken (a) fused, (b) by a real torch.optim.Adam that loaded the exported
+    state, (c) fused by a fresh model that imported that torch optimizer's state - all three must agree."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=4)
+    dev = _dev(*vae_ref.synth_batch(5, 6, 9, seed=2, cfg=cfg)[:5])
+    eps = torch.randn(dev[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+    a = _model(cfg, sd).train()
+    for _ in range(3):
+        a.train_step(*dev, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    osd = a.optim_state_dict(lr=1e-3)
+    assert len(osd['state']) == len(list(a.parameters())) and float(osd['state'][0]['step']) == 3.0
+    msd = {k: v.clone() for k, v in a.state_dict().items()}
+    # (b) torch.optim.Adam on a copy of the model, gradients through the autograd path
+    b = _model(cfg, msd).train()
+    import copy
+    opt = torch.optim.Adam(b.parameters(), lr=1e-3)
+    opt.load_state_dict(copy.deepcopy(osd))        # torch keeps tensors of matching dtype / device by reference and steps them in place
+    U = pkg("host.utils")
+    import types
+    out = b(*dev, None, eps=eps)
+    total, _ = U.calculate_model_losses(types.SimpleNamespace(use_AE=cfg.use_AE), b, dev[2], out[2], dev[3], out[3], mu=out[0], logvar=out[1],
+                                        KL_weight=0.1)
+    opt.zero_grad(); total.backward(); opt.step(); b.params_changed()
+    # (c) a fresh model that imports a torch optimizer's state (the one of (b) BEFORE its step = the exported one, via torch)
+    c = _model(cfg, msd).train()
+    opt_c = torch.optim.Adam(c.parameters(), lr=1e-3)
+    opt_c.load_state_dict(copy.deepcopy(osd))
+    c.load_optim_state_dict(opt_c.state_dict())
+    c.train_step(*dev, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    a.train_step(*dev, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    pa, pb, pc = (m.flat_params.detach().cpu().numpy() for m in (a, b, c))
+    p0 = np.concatenate([np.pad(msd[k].cpu().numpy().reshape(-1), (0, (-msd[k].numel()) % 64)) for k, _ in a.named_parameters()])
+    assert np.abs(pa - p0).max() > 1e-4, "the 4th step moved nothing"
+    for other, nm in ((pb, "torch.optim.Adam with the exported state"), (pc, "fused Adam with the imported state")):
+        d = np.abs(other - pa)
+        # +-lr noise on parameters whose true gradient is 0 (biases in front of BatchNorm): bound it, require the bulk to agree
+        assert d.max() <= 2.05e-3 and np.mean(d > 2e-6) < 0.03, (nm, d.max(), np.mean(d > 2e-6))
+    assert float(c.optim_state_dict()['state'][0]['step']) == 4.0
