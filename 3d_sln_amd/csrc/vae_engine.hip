@@ -859,17 +859,16 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
   // The kernels of an iteration read the batch through h->batch.  A captured iteration (hipGraph) has those addresses baked in,
   // and the caller's tensors are new ones for every batch (DataLoader, synthetic generator): stage the inputs in engine-owned
   // buffers whose addresses never change, so that a replay sees the CURRENT batch (it used to read the tensors of the batch it was
-  // captured with whenever two consecutive batches had the same shape).  Four small device-to-device copies outside the graph.
-  HIP_RET(hipMemcpyAsync(h->st_objs, b->objs, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
-  HIP_RET(hipMemcpyAsync(h->st_angles, b->angles, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
-  HIP_RET(hipMemcpyAsync(h->st_attrs, b->attributes, sizeof(int64_t) * (size_t)b->O, hipMemcpyDeviceToDevice, st));
-  HIP_RET(hipMemcpyAsync(h->st_boxes, b->boxes, sizeof(float) * (size_t)b->O * h->cfg.box_dim, hipMemcpyDeviceToDevice, st));
-  h->batch.objs = h->st_objs; h->batch.angles = h->st_angles; h->batch.attributes = h->st_attrs; h->batch.boxes = h->st_boxes;
+  // captured with whenever two consecutive batches had the same shape).  One small kernel outside the graph (stage_batch_kernel).
   HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
-  RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->cfg.num_preds, h->g, h->err_flag, st));
-  RET_IF(sln_launch_validate_ids(b->objs, b->attributes, b->angles, b->O, h->cfg.num_objs, h->cfg.num_attrs, h->cfg.n_angle,
-                                 h->err_flag, st));
-  RET_IF(sln_launch_i64_to_i32(b->attributes, h->attrs32, b->O, st));
+  StageBatch sb; std::memset(&sb, 0, sizeof(sb));
+  sb.objs = b->objs; sb.attrs = b->attributes; sb.angles = b->angles; sb.boxes = b->boxes;
+  sb.st_objs = h->st_objs; sb.st_attrs = h->st_attrs; sb.st_angles = h->st_angles; sb.st_boxes = h->st_boxes;
+  sb.attrs32 = h->attrs32; sb.deg = h->g.deg; sb.err = h->err_flag;
+  sb.O = b->O; sb.box_dim = h->cfg.box_dim; sb.n_objs = h->cfg.num_objs; sb.n_attrs = h->cfg.num_attrs; sb.n_angle = h->cfg.n_angle;
+  RET_IF(sln_launch_stage_batch(sb, st));        // copies + id checks + int32 attributes + cleared degree counters: one launch
+  h->batch.objs = h->st_objs; h->batch.angles = h->st_angles; h->batch.attributes = h->st_attrs; h->batch.boxes = h->st_boxes;
+  RET_IF(sln_launch_graph_prep(b->triples, b->T, b->O, h->cfg.num_preds, h->g, h->err_flag, st, 0, 1));
   h->batch_set = true; h->have_enc = h->have_dec = false;
   return 0;
 }

@@ -15,10 +15,17 @@ struct GraphCsr {          // device pointers, all int32 unless noted
   int T, O;
 };
 int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st,
-                          int edges_only = 0);
+                          int edges_only = 0, int deg_is_zero = 0);
 // bn view must be aligned with column col0 of x
 int sln_launch_bn_relu_apply(const float* x, int ld, int col0, int cols, int rows, BnView bn, float* out, int ldo, hipStream_t st);
 // err_flag bits: 1 triple ids, 2 object class, 4 attribute, 8 angle bin out of range
+struct StageBatch {
+  const int64_t* objs; const int64_t* attrs; const int64_t* angles; const float* boxes;
+  int64_t* st_objs; int64_t* st_attrs; int64_t* st_angles; float* st_boxes;
+  int* attrs32; int* deg; int* err;
+  int O, box_dim, n_objs, n_attrs, n_angle;
+};
+int sln_launch_stage_batch(const StageBatch& a, hipStream_t st);
 int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int64_t* angles, int O, int n_objs, int n_attrs,
                             int n_angle, int* err_flag, hipStream_t st);
 

@@ -646,6 +646,28 @@ __global__ void validate_ids_kernel(const int64_t* __restrict__ objs, const int6
   if (angles && (angles[i] < 0 || angles[i] >= n_angle)) atomicOr(err, 8);
 }
 
+// One launch for everything sln_vae_set_batch does per object row: the engine-owned copies of the inputs, the id checks, the
+// int32 attribute ids and the cleared degree counters (six stream operations before).
+__global__ void stage_batch_kernel(StageBatch a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.O) return;
+  const int64_t ob = a.objs[i], at = a.attrs[i], an = a.angles[i];
+  a.st_objs[i] = ob; a.st_attrs[i] = at; a.st_angles[i] = an;
+  a.attrs32[i] = (int)at;
+  a.deg[i] = 0;
+  for (int k = 0; k < a.box_dim; ++k) a.st_boxes[(size_t)i * a.box_dim + k] = a.boxes[(size_t)i * a.box_dim + k];
+  if (ob < 0 || ob >= a.n_objs) atomicOr(a.err, 2);
+  if (at < 0 || at >= a.n_attrs) atomicOr(a.err, 4);
+  if (an < 0 || an >= a.n_angle) atomicOr(a.err, 8);
+}
+
+int sln_launch_stage_batch(const StageBatch& a, hipStream_t st) {
+  if (a.O <= 0) return 0;
+  hipLaunchKernelGGL(stage_batch_kernel, dim3(sln_cdiv(a.O, 256)), dim3(256), 0, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
 int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int64_t* angles, int O, int n_objs, int n_attrs,
                             int n_angle, int* err_flag, hipStream_t st) {
   if (O <= 0) return 0;
@@ -656,9 +678,11 @@ int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int
 }
 
 int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st,
-                          int edges_only) {
-  hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
-  if (e != hipSuccess) return (int)e;
+                          int edges_only, int deg_is_zero) {
+  if (!deg_is_zero) {
+    hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
+    if (e != hipSuccess) return (int)e;
+  }
   if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, num_preds, g, err_flag,
                               edges_only ? 2 : 3, edges_only ? -1 : 1, edges_only ? 1 : 2);
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, g, O);
