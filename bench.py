@@ -414,7 +414,9 @@ def main():
             import csv
             tot, cnt = 0.0, 0
             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_vae_render_kernel_stats.csv"))):
-                if r["kernel"].startswith(dom + "_kernel") and r["hbm_MB_per_launch_corrected"]:
+                # the training step's launches only: the refinement leg of the profiled run adds eval-mode <0, ...> variants on a
+                # 13-object graph, which are not what `achieved` above was measured on
+                if r["kernel"].startswith(dom + "_kernel") and r["hbm_MB_per_launch_corrected"] and (dom != "gemm_dual" or "<1," in r["kernel"]):
                     tot += float(r["hbm_MB_per_launch_corrected"]) * int(r["calls"]); cnt += int(r["calls"])
             if cnt:
                 out["roofline"]["traffic"] = round(tot / cnt * 1e6)
