@@ -690,3 +690,35 @@ def test_optimizer_state_is_interchangeable_with_torch_adam():
         # +-lr noise on parameters whose true gradient is 0 (biases in front of BatchNorm): bound it, require the bulk to agree
         assert d.max() <= 2.05e-3 and np.mean(d > 2e-6) < 0.03, (nm, d.max(), np.mean(d > 2e-6))
     assert float(c.optim_state_dict()['state'][0]['step']) == 4.0
+
+
+def test_validation_forward_between_training_steps_leaves_training_untouched():
+    """A validation pass (model.eval(); model(val_batch) on a same-shaped batch; model.train()) between two fused steps: the
+    second step's replayed graph must see its own batch and train-mode BatchNorm again, and give what an uninterrupted run gives."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=6)
+    tr = [_dev(*vae_ref.synth_batch(6, 8, 13, seed=s, cfg=cfg)[:5]) for s in (1, 2)]
+    val = _dev(*vae_ref.synth_batch(6, 8, 13, seed=9, cfg=cfg)[:5])
+    eps = torch.randn(tr[0][0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+    res = {}
+    for interrupted in (False, True):
+        m = _model(cfg, sd).train()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            l0 = m.train_step(*tr[0], kl_weight=0.1, lr=1e-3, eps=eps, use_graph=True)
+            if interrupted:
+                m.eval()
+                with torch.no_grad():
+                    v = m(*val, None, eps=eps)
+                assert all(torch.isfinite(t).all() for t in v)
+                m.train()
+            l1 = m.train_step(*tr[1], kl_weight=0.1, lr=1e-3, eps=eps, use_graph=True)
+        torch.cuda.synchronize()
+        res[interrupted] = (l0.cpu().numpy(), l1.cpu().numpy(), m.flat_params.cpu().numpy().copy(),
+                            {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k})
+    assert_close(res[True][0], res[False][0], "first step", rtol=1e-6)
+    assert_close(res[True][1], res[False][1], "second step after the validation pass", rtol=1e-5)
+    d = np.abs(res[True][2] - res[False][2])
+    assert d.max() <= 2.05e-3 * 2 and np.mean(d > 1e-5) < 0.02
+    for k in res[True][3]:
+        assert_close(res[True][3][k], res[False][3][k], k, rtol=3e-4, atol=1e-6)     # second-step statistics see the +-lr Adam noise of the first
