@@ -285,8 +285,9 @@ class _PlaceFn(torch.autograd.Function):
                                                 _lib.ptr(sl), _lib.current_stream_ptr()), "sln_place_forward")
         ctx.scene, ctx.tgt = scene, tgt
         ctx.save_for_backward(boxes, angles)
-        ctx.mark_non_differentiable(sizes)
-        return fxyz, sl.reshape(()), sizes[:scene.n_vis]
+        sizes = sizes[:scene.n_vis]
+        ctx.mark_non_differentiable(sizes)             # the reference detaches the cached sizes (diff_render.py:102)
+        return fxyz, sl.reshape(()), sizes
 
     @staticmethod
     def backward(ctx, g_fxyz, g_sl, _g_sizes):

@@ -10,7 +10,7 @@ from parity import assert_close
 
 pytestmark = pytest.mark.gpu
 
-from oracle import raster_ref as rr, vae_ref     # noqa: E402
+from oracle import raster_ref as rr, refine_ref, vae_ref     # noqa: E402
 
 NAMES = ["bed", "chair", "table", "sofa", "door", "desk", "__room__"]       # 'door' is skipped by the reference (DO_NOT_VIS)
 
@@ -213,13 +213,13 @@ def test_fused_refinement_loss_matches_the_torch_ops(image_size, batch):
     got = [float(t) for t in out.detach().cpu()]
     g = x.grad.cpu().numpy() / 1.5
     # labels: the product derives them from its own resampling of the target; torch's resampling must agree on them
-    lab_t = torch.cat(R.target_labels(target.cpu()), 1)
+    lab_t = torch.cat(refine_ref.target_labels(target.cpu()), 1)
     assert (lab_t != rl.labels.cpu().long()).float().mean() < 2e-3
     labels = [rl.labels[:, k:k + 1].cpu().long() for k in range(rl.labels.shape[1])]
     ref = {}
     for dt in (torch.float64, torch.float32):
         xi = img.cpu().to(dt).requires_grad_(True)
-        loss, dl, sl = R.refinement_loss(xi, target.cpu().to(dt), labels, torch.zeros((), dtype=dt))
+        loss, dl, sl = refine_ref.refinement_loss(xi, target.cpu().to(dt), labels, torch.zeros((), dtype=dt))     # the oracle: the reference's torch calls
         loss.backward()
         ref[dt] = ([float(loss.detach()), float(dl.detach()), float(sl.detach())], xi.grad.numpy())
     r64, r32 = ref[torch.float64], ref[torch.float32]
@@ -261,3 +261,51 @@ def test_room_without_visible_objects():
         assert float(b.grad.abs().max()) == 0.0 and float(a.grad.abs().max()) == 0.0
         outs.append(img.detach())
     assert torch.equal(outs[0], outs[1]) and float((outs[0][:, 0] > 0).float().mean()) > 0.5       # the shell is visible
+
+
+def test_fused_placement_matches_the_restated_object_loop():
+    """csrc/placement.hip against oracle/refine_ref.py::place_scene (diff_render.py:76-165 statement by statement, 4x4 transforms
+    and python min() included) in fp64 on the CPU: placed vertices through the camera, sizes, size loss and the gradients w.r.t.
+    the box rows and angle bins of a scalar function of the projected faces."""
+    R = pkg("host.refine"); DR = pkg("host.diff_render"); NRm = pkg("host.neural_renderer")
+    boxes, angles = _inputs("cuda")
+    bank = R.MeshBank([n for n in NAMES if n not in R.DO_NOT_VIS and n != "__room__"], "cuda", seed=3)
+    room = boxes[-1].clone()
+    scene = R.RefineScene(NAMES, bank, room, image_size=96)
+    tgt = torch.stack([torch.tensor([0.5, 0.4, 0.6]) * (1 + 0.1 * k) for k in range(scene.n_vis)])
+    b = boxes.clone().requires_grad_(True); a = (angles + 0.3).clone().requires_grad_(True)
+    fxyz, sl, size = R._PlaceFn.apply(b, a, scene, tgt.cuda())
+    Fn = scene.faces.shape[0]
+    w = torch.randn(Fn, 3, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    (fxyz[:Fn] * w).sum().add(3.0 * sl).backward()
+    # ---- oracle, fp64 on the CPU
+    models = {k: {kk: vv.detach().cpu().double() for kk, vv in m.items() if kk != "f"} for k, m in bank.models.items()}
+    b64 = boxes.detach().cpu().double().requires_grad_(True); a64 = (angles + 0.3).detach().cpu().double().requires_grad_(True)
+    # during the optimisation the room row is the cached constant (diff_render.py:55-57: boxes[-1] = model_ids_old["box_info"])
+    b_in = torch.cat([b64[:-1], boxes[-1:].detach().cpu().double()])
+    verts, sizes, sl64 = refine_ref.place_scene(b_in, a64, NAMES, models, [t.double() for t in tgt])
+    K, Rm, t = [x.cpu().double() for x in (scene.K, scene.R, scene.t)]
+    allv = torch.cat([verts, scene.shell_v.cpu().double()])[None]
+    # objects occupy Vm vertex slots each in the product's table: map its face list to the compact oracle numbering
+    Vm = scene.desc.Vm
+    counts = [bank.models[NAMES[i]]["v"].shape[0] for i in scene.vis.tolist()]
+    remap = torch.full((scene.n_vis * Vm + scene.shell_v.shape[0],), -1, dtype=torch.int64)
+    off = 0
+    for k, c in enumerate(counts):
+        remap[k * Vm:k * Vm + c] = torch.arange(off, off + c); off += c
+    remap[scene.n_vis * Vm:] = torch.arange(off, off + scene.shell_v.shape[0])
+    faces = remap[scene.faces.cpu()]
+    assert (faces >= 0).all()
+    ref = rr.vertices_to_faces(rr.project(allv, K, Rm, t, 512), faces[None])[0]          # [F,3,3]
+    cam_z = (torch.matmul(allv, Rm.transpose(1, 2)) + t)[0, :, 2]
+    culled = (cam_z[faces] < DR.CULL_EPS).any(1)
+    ref = torch.where(culled[:, None, None], torch.zeros_like(ref), ref)
+    ((ref * w.cpu().double()).sum() + 3.0 * sl64).backward()
+    assert_close(fxyz[:Fn].detach().cpu().numpy(), ref.detach().numpy(), "projected faces", rtol=1e-5, atol=1e-5)
+    assert_close(fxyz[Fn:].detach().cpu().numpy(), ref.detach().numpy()[:, [2, 1, 0]], "fill_back copies", rtol=1e-5, atol=1e-5)
+    assert_close(size.cpu().numpy(), torch.stack(sizes).detach().numpy(), "sizes", rtol=1e-6)
+    assert_close(float(sl.detach()), float(sl64.detach()), "size loss", rtol=1e-5)
+    assert_close(b.grad.cpu().numpy(), b64.grad.numpy(), "d/d boxes", rtol=2e-4, atol=2e-4 * float(b64.grad.abs().max()))
+    assert float(b.grad[-1].abs().max()) == 0.0
+    assert_close(a.grad.cpu().numpy(), a64.grad.numpy(), "d/d angles", rtol=2e-4, atol=2e-4 * float(a64.grad.abs().max()))
+    assert float(b64.grad.abs().max()) > 0 and float(a64.grad.abs().max()) > 0
