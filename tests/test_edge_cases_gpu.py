@@ -149,3 +149,33 @@ def test_raster_mixed_depth_face_and_batch_of_unequal_content():
     img1 = [_tri(3, 3, 4, 3, 3, 4, 1.0), _tri(3, 3, 4, 3, 3, 4, 1.0)]
     rfi = _check([img0, img1], 100, 0.001, 100.0, expect_visible=True)
     assert (rfi[1] == -1).all() and (rfi[0] == 0).any() and not (rfi[0] == 1).any()
+
+
+# ----------------------------------------------------------------------------- C ABI contract violations
+def test_c_abi_rejects_null_pointers_and_bad_sizes_without_launching():
+    """include/sln_hip.h: 'negative SLN_E_* code for a contract violation (nothing is launched in that case)'."""
+    import ctypes as C
+    Lm = pkg("_lib")
+    L = Lm.lib()
+    st = Lm.current_stream_ptr()
+    x = torch.zeros(64, device="cuda")
+    p = Lm.ptr(x)
+    assert L.sln_device_ok() == 0
+    assert L.sln_raster_forward(None, 1, 4, 64, 0.1, 100.0, p, p, p, p, st) < 0
+    assert L.sln_scene_forward(None, None, 1, 4, 64, 3, None, None, 0.1, 0.001, 100.0, 1e-3, None, None, st) < 0
+    assert L.sln_spade_conv(None, 1, 32, 8, 8, p, p, 64, 64, 3, 0, 0.0, p, st) < 0
+    assert L.sln_layernorm_stats(None, 1, 64, 1e-5, None, None, st) < 0
+    assert L.sln_refine_loss_forward(None, p, p, None, p, p, p, st) < 0
+    d = Lm.SlnRefineLoss()                                                       # all-zero descriptor
+    assert L.sln_refine_loss_forward(d, p, p, p, p, p, p, st) < 0 and L.sln_refine_loss_backward(d, p, p, p, st) < 0
+    assert L.sln_refine_loss_workspace_bytes(0, 256, 96, 4, 40, 29) < 0 and L.sln_refine_loss_workspace_bytes(1, 256, 96, 9, 40, 29) < 0
+    assert L.sln_place_forward(None, p, p, None, p, p, p, st) < 0
+    pl = Lm.SlnPlacement()
+    assert L.sln_place_forward(pl, p, p, None, p, p, p, st) < 0 and L.sln_place_backward(pl, p, p, None, p, None, p, p, st) < 0
+    assert L.sln_graph_plan(None, None, 4, None, None, st) < 0
+    assert L.sln_vae_set_batch(None, None, st) < 0 and L.sln_vae_train_step(None, None, 0.1, 1e-4, None, 0, 1, st) < 0
+    assert L.sln_vae_set_training(None, 1) < 0 and L.sln_vae_adam_reset(None, 3, st) < 0
+    cfg = Lm.SlnVaeConfig()                                                      # zeroed config: unsupported, no engine is created
+    h = C.c_void_p()
+    assert L.sln_vae_create(C.byref(cfg), C.byref(h)) < 0 and not h.value
+    torch.cuda.synchronize()                                                     # nothing faulted asynchronously
