@@ -172,3 +172,29 @@ def test_full_size_batch_of_32_equals_per_sample_calls():
         shared = G(seg[5:6].contiguous(), z[:3].contiguous())
         per = G(seg[5:6].expand(3, -1, -1, -1).contiguous(), z[:3].contiguous())
         assert_close(shared.cpu().numpy(), per.cpu().numpy(), "full-size shared vs per-sample", rtol=1e-5, atol=1e-5)
+
+
+def test_repeated_calls_with_changing_inputs_keep_no_stale_state():
+    """Weight packs are cached across calls, the gamma/beta of a shared map and the concat buffers only within one: alternating
+    semantic maps, batch sizes and the shared / per-sample paths must reproduce the first answers, and reloading the weights must
+    change them."""
+    S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(spade_ref.init_state(cfg, seed=7)); G = G.cuda().eval()
+    segA, zA = [t.cuda() for t in spade_ref.synth_input(cfg, 3, seed=1)]
+    segB, zB = [t.cuda() for t in spade_ref.synth_input(cfg, 2, seed=2)]
+    with torch.no_grad():
+        a1 = G(segA, zA); b1 = G(segB, zB)
+        sh1 = G(segA[:1].contiguous(), zA)                           # one map, three z: the shared path
+        a2 = G(segA, zA); sh2 = G(segA[:1].contiguous(), zA); b2 = G(segB, zB)
+        segA.mul_(1.0)                                               # same values, new version counter
+        a3 = G(segA, zA)
+        assert torch.equal(a1, a2) and torch.equal(b1, b2) and torch.equal(sh1, sh2) and torch.equal(a1, a3)
+        assert_close(sh1[0:1].cpu().numpy(), a1[0:1].cpu().numpy(), "shared path, first sample", rtol=1e-5, atol=1e-5)
+        assert float((a1[:2] - b1).abs().max()) > 1e-3
+        G.load_state_dict(spade_ref.init_state(cfg, seed=8))         # in-place copy: the packs must be rebuilt
+        a4 = G(segA, zA)
+        assert float((a4 - a1).abs().max()) > 1e-3
+        G.load_state_dict(spade_ref.init_state(cfg, seed=7))
+        assert torch.equal(G(segA, zA), a1)
