@@ -305,8 +305,15 @@ class Sg2ScVAEModel(nn.Module):
                 raise _lib.SlnError("inputs must live on the model's GPU")
             return x.to(dt).contiguous()
         objs, triples, attributes = prep(objs, torch.int64), prep(triples, torch.int64), prep(attributes, torch.int64)
-        boxes = prep(boxes, torch.float32) if boxes is not None else torch.zeros(O, self.box_dim, device=dev)
-        angles = prep(angles, torch.int64) if angles is not None else torch.zeros(O, dtype=torch.int64, device=dev)
+        if boxes is None or angles is None:
+            # decoder-only calls (no ground truth): ONE pair of zero tensors per size, so that repeated calls on the same graph
+            # (the refinement loop: 60 decoder calls per room) keep the same batch key and skip the re-binding
+            zc = getattr(self, "_zero_inputs", None)
+            if zc is None or zc[0] != (O, dev):
+                zc = ((O, dev), torch.zeros(O, self.box_dim, device=dev), torch.zeros(O, dtype=torch.int64, device=dev))
+                self._zero_inputs = zc
+        boxes = prep(boxes, torch.float32) if boxes is not None else zc[1]
+        angles = prep(angles, torch.int64) if angles is not None else zc[2]
         key = tuple((x.data_ptr(), tuple(x.shape), x._version) for x in (objs, triples, boxes, angles, attributes))
         if key == self._batch_key:
             return
