@@ -39,7 +39,7 @@ def replicate_graphs(objs, triples, attributes, n):
 
 
 def sample_layouts(model, objs, triples, attributes, n_samples=4, mean=None, cov=None, generator=None):
-    """-> boxes_pred [n_samples, O, box_dim], angle_bins [n_samples, O] (argmax of the log-probabilities)."""
+    """-> boxes_pred [n_samples, O, box_dim], angle_bins [n_samples, O] (argmax of the log-probabilities), z [n_samples, O, E]."""
     dev = objs.device
     E, O = model.embedding_dim, objs.shape[0]
     ro, rt, ra = replicate_graphs(objs, triples, attributes, n_samples)
