@@ -285,3 +285,15 @@ def test_renderer_batch_of_nine_equals_single_image_calls():
             assert_close(vb.grad[k].cpu().numpy(), v1.grad[0].cpu().numpy(), "%s image %d dV" % (mode, k), rtol=1e-4,
                          atol=1e-5 * float(v1.grad.abs().max()))
             assert float(v1.grad.abs().max()) > 0
+
+
+def test_many_triangles_bit_exact():
+    """20 000 triangles (40 000 after fill_back: ~160 chunks of 256 per tile) at 128 x 128: face index, weights and depth
+    bit-identical to the CPU restatement."""
+    fx, _ = _faces_of_room(21, 20000, 128)
+    assert fx.shape[1] >= 30000
+    rfi, rw, rd = rr.nmr_forward(fx.numpy(), 128, 0.001, 100.0)
+    _, fi, w, d = _hip_forward(fx, 128, 0.001, 100.0)
+    assert (fi.cpu().numpy() == rfi).all(), "face index map differs at %d pixels" % int((fi.cpu().numpy() != rfi).sum())
+    assert (w.cpu().numpy() == rw).all() and (d.cpu().numpy() == rd).all()
+    assert len(np.unique(rfi)) > 500
