@@ -38,7 +38,16 @@ assert [n for n, _ in model.named_parameters()] == [n for n, _ in ref.named_para
 model.load_state_dict(ref.state_dict())                 # a reference checkpoint loads unchanged
 import torch
 torch.optim.Adam(model.parameters(), lr=1e-4)
-print(json.dumps({"keys": len(a), "params": sum(p.numel() for p in model.parameters())}))
+# C. the generator, constructed as testing/test_SPADE_shade.py:9 does, small width to keep the test light
+import models.SPADE_related as ref_spade
+hs = _hip("SPADE_related")
+cargs = (41, 3, 16, 8, "spectralspadelayer3x3", 64, "normal")
+g_ref, g_hip = ref_spade.SPADEGenerator4(*cargs), hs.SPADEGenerator4(*cargs)
+ga = {k: tuple(v.shape) for k, v in g_hip.state_dict().items()}
+gb = {k: tuple(v.shape) for k, v in g_ref.state_dict().items()}
+assert ga == gb, sorted(set(ga.items()) ^ set(gb.items()))[:10]
+g_hip.load_state_dict(g_ref.state_dict())
+print(json.dumps({"keys": len(a), "params": sum(p.numel() for p in model.parameters()), "spade_keys": len(ga)}))
 '''
 
 
@@ -49,3 +58,4 @@ def test_reference_factory_builds_the_aliased_model():
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["params"] == 3879790 and out["keys"] > 200
+    assert out["spade_keys"] == 230                                # the 230-key checkpoint layout
