@@ -309,3 +309,33 @@ def test_fused_placement_matches_the_restated_object_loop():
     assert float(b.grad[-1].abs().max()) == 0.0
     assert_close(a.grad.cpu().numpy(), a64.grad.numpy(), "d/d angles", rtol=2e-4, atol=2e-4 * float(a64.grad.abs().max()))
     assert float(b64.grad.abs().max()) > 0 and float(a64.grad.abs().max()) > 0
+
+
+def test_refinement_loss_generic_backward_kernel_and_other_scales():
+    """The backward pass has two kernels: the separable one (column lists of at most 5 entries, pooled size <= 96) and a generic
+    CSR walk for everything else.  Both must give the same gradient; a different set of scales (and a pooled size of 80) goes
+    through the torch formulation as well."""
+    R = pkg("host.refine")
+    g = torch.Generator().manual_seed(5)
+    target = torch.rand(1, 70, 128, 128, generator=g).cuda()
+    target[:, 1:41] = (target[:, 1:41] > 0.9).float()
+    img = (target + 0.1 * torch.randn(1, 70, 128, 128, generator=g).cuda()).clamp(0, 1)
+    for sizes in ((32, 48, 64, 96), (20, 56, 80)):
+        rl = R.RefineLoss(target, sizes=sizes)
+        x = img.clone().requires_grad_(True)
+        out = rl(x); out[0].backward()
+        g_fast = x.grad.clone()
+        rl.desc.max_col_entries = 0                                  # 'unknown': forces the generic kernel
+        x2 = img.clone().requires_grad_(True)
+        out2 = rl(x2); out2[0].backward()
+        assert torch.equal(out.detach(), out2.detach())
+        assert_close(x2.grad.cpu().numpy(), g_fast.cpu().numpy(), "generic vs separable backward %s" % (sizes,), rtol=1e-5,
+                     atol=1e-6 * float(g_fast.abs().max()))
+        labels = [rl.labels[:, k:k + 1].cpu().long() for k in range(len(sizes))]
+        xi = img.cpu().double().requires_grad_(True)
+        loss, dl, sl = refine_ref.refinement_loss(xi, target.cpu().double(), labels, torch.zeros((), dtype=torch.float64), sizes=sizes)
+        loss.backward()
+        assert abs(float(out[0].detach()) - float(loss.detach())) <= 1e-4 * abs(float(loss.detach()))
+        scale = float(xi.grad.abs().max())
+        bad = (np.abs(g_fast.cpu().numpy() - xi.grad.numpy()) > 1e-4 * scale).mean()
+        assert bad < 2e-3, (sizes, bad)                               # L1 sign flips at rounding level only
