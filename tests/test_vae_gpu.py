@@ -722,3 +722,38 @@ def test_validation_forward_between_training_steps_leaves_training_untouched():
     assert d.max() <= 2.05e-3 * 2 and np.mean(d > 1e-5) < 0.02
     for k in res[True][3]:
         assert_close(res[True][3][k], res[False][3][k], k, rtol=3e-3, atol=1e-6)     # second-step statistics see the +-lr Adam noise of the first (up to 3e-4 seen)
+
+
+@pytest.mark.parametrize("env", [{"SLN_NO_GROUP": "1"}, {"SLN_NO_DUAL": "1"}, {"SLN_NO_DUAL": "1", "SLN_NO_SIDE_STREAM": "1"}])
+def test_unmerged_launch_paths_give_the_same_step(env):
+    """The merged launches (dgrad + wgrad in one grid, the twin branches grouped) fall back to separate launches - wgrads on a
+    side stream, or everything on one stream - for shapes they do not cover; the switches that force those paths for a whole
+    engine must reproduce the default step (loss, every gradient, BatchNorm buffers)."""
+    import os
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=3)
+    sd = vae_ref.init_state(cfg, seed=8)
+    dev = _dev(*vae_ref.synth_batch(12, 10, 17, seed=3, cfg=cfg)[:5])
+    eps = torch.randn(dev[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+
+    def run():
+        m = _model(cfg, sd).train()
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            l = m.train_step(*dev, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False, with_adam=False)
+        torch.cuda.synchronize()
+        return l.cpu().numpy(), m.flat_grads.cpu().numpy().copy(), {k: v.cpu().numpy() for k, v in m.state_dict().items() if "running" in k}
+    base = run()
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)                                   # read by sln_vae_create
+    try:
+        alt = run()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert_close(alt[0], base[0], "losses", rtol=1e-6)
+    assert_close(alt[1], base[1], "gradients", rtol=2e-5, atol=2e-6 * float(np.abs(base[1]).max()))
+    for k in base[2]:
+        assert_close(alt[2][k], base[2][k], k, rtol=1e-6)
