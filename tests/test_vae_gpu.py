@@ -757,3 +757,29 @@ def test_unmerged_launch_paths_give_the_same_step(env):
     assert_close(alt[1], base[1], "gradients", rtol=2e-5, atol=2e-6 * float(np.abs(base[1]).max()))
     for k in base[2]:
         assert_close(alt[2][k], base[2][k], k, rtol=1e-6)
+
+
+def test_graph_replay_sees_new_kl_weight_and_learning_rate():
+    """--KL_linear_decay changes the KL weight while training (train.py:73-76), a scheduler may change the learning rate: both
+    live in device scalars, not in captured kernel arguments, so a replayed graph must use the values of the current call."""
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=2)
+    dev = _dev(*vae_ref.synth_batch(6, 8, 12, seed=4, cfg=cfg)[:5])
+    eps = torch.randn(dev[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+    sched = [(0.1, 1e-3), (0.1, 1e-3), (1e-4, 1e-3), (1.0, 3e-4), (0.1, 1e-3)]
+    res = {}
+    for use_graph in (False, True):
+        m = _model(cfg, sd).train()
+        s = torch.cuda.Stream(); ls = []; moves = []
+        with torch.cuda.stream(s):
+            for w, lr in sched:
+                p0 = m.flat_params.clone()
+                ls.append(m.train_step(*dev, kl_weight=w, lr=lr, eps=eps, use_graph=use_graph))
+                moves.append((m.flat_params - p0).abs().median())
+        torch.cuda.synchronize()
+        res[use_graph] = (torch.stack(ls).cpu().numpy(), torch.stack(moves).cpu().numpy())
+    assert_close(res[True][0], res[False][0], "losses under a changing KL weight", rtol=2e-3)
+    kld = res[True][0][:, 2]
+    assert kld[2] < 0.01 * kld[1] and kld[3] > 5 * kld[1]            # the weighted KL term follows the weight of its own call
+    assert_close(res[True][1], res[False][1], "step sizes under a changing learning rate", rtol=5e-2)
+    assert res[True][1][3] < 0.6 * res[True][1][2]                    # lr 3e-4 after 1e-3
