@@ -25,7 +25,7 @@ class SlnError(RuntimeError):
 class SlnVaeConfig(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "embedding_dim", "gconv_num_layers", "recurrent", "batch_norm", "decoder_cat", "use_ae",
-        "box_dim", "n_angle", "num_objs", "num_preds", "num_attrs", "reserved")]
+        "box_dim", "n_angle", "num_objs", "num_preds", "num_attrs", "no_attr")]
 
 
 class SlnVaeUnit(C.Structure):
@@ -101,6 +101,10 @@ SIGNATURES = {
     "sln_vae_zero_grad": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "sln_vae_adam_reset": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p]),
+    "sln_vae_adam_get_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_void_p]),
+    "sln_vae_set_grad_guard": (C.c_int, [C.c_void_p, c_f32p]),
+    "sln_vae_seed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
+    "sln_vae_last_eps": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
     "sln_vae_set_training": (C.c_int, [C.c_void_p, C.c_int]),
     "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     "sln_prof_enable": (C.c_int, [C.c_int]),

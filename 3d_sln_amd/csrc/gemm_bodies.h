@@ -39,9 +39,13 @@ struct SegSel {   // block-uniform view of the segment that holds logical column
 // MULTI = false: the operand has a single segment, so its fields are loop invariants that hipcc keeps in SGPRs.  With
 // the select chain below it re-reads the chosen segment's fields from the kernarg segment (s_load_dword) in every K
 // tile, and each such read is followed by s_waitcnt lgkmcnt(0), which also drains the LDS queue.
-template <bool MULTI>
-__device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
+// MULTI = 2: segment boundaries that are not multiples of BK (decoder_cat off at embedding_dim 16: [16 | 16 | 16]); the
+// segment is then chosen per THREAD from the column of its float4 (`kc`; segment lengths are multiples of 4, a float4 never
+// straddles two segments) instead of per K tile.  Only built for the 64x64 tile.
+template <int MULTI>
+__device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0, int kc) {
   SegSel r;
+  if (MULTI == 2) k0 = kc;
   if (!MULTI) {
     const Seg& g = op.seg[0];
     r.x1 = g.x1; r.x2 = g.x2; r.ld1 = g.ld1; r.ld2 = g.ld2; r.c1 = g.c1; r.c2 = g.c2; r.which = g.which; r.base = 0; r.end = g.len;
@@ -65,7 +69,7 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0) {
 // NT kernel
 // ---------------------------------------------------------------------------------------------
 // // (An intra-block split-K variant, 8 waves per 64x64 tile, was measured and dropped: same time, see DESIGN.md.)
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
 __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
   constexpr int NT = 256;
   constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
@@ -116,7 +120,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   auto gload = [&](int kt, auto stage) {
     constexpr int S = decltype(stage)::value;
     const int k0 = kt * BK;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0);
+    const SegSel sg = pick_seg<MULTI>(a.A, k0, k0 + 4 * kq);
     const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -138,7 +142,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   auto lstore = [&](int kt, int buf, auto stage) {
     constexpr int S = decltype(stage)::value;
     const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0);
+    const SegSel sg = pick_seg<MULTI>(a.A, k0, col);
     const bool cv = col < sg.end;
     const bool x2v = HAS_X2 && sg.x2 != nullptr;
     float* as = As + buf * BM * LDT + 4 * kq;
@@ -536,6 +540,11 @@ inline int nt_heuristic_tile(const GemmNTArgs& a) {   // enough blocks to cover 
   const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
   const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
   return b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
+}
+
+inline bool nt_unaligned(const GemmNTArgs& a) {        // a segment boundary inside a K tile: needs the MULTI = 2 body
+  for (int s = 0; s + 1 < a.A.nseg; ++s) if (a.A.seg[s].len % BK) return true;
+  return false;
 }
 
 inline int nt_amode(const GemmNTArgs& a) {

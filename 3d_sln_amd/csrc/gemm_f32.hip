@@ -14,7 +14,7 @@
 // through registers (transform on the way), double-buffered so one barrier per K tile.
 #include "gemm_bodies.h"
 namespace {
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, bool MULTI>
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI>(a, blockIdx.x, gridDim.x, smem);
@@ -31,8 +31,12 @@ int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  if (a.A.nseg > 1) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, true>), dim3(grid), dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, false>), dim3(grid), dim3(256), smem, st, a);
+  if (a.A.nseg > 1 && nt_unaligned(a)) {
+    if constexpr (BM == 64 && BN == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, WM, WN, AMODE, EPI, 2>), dim3(grid), dim3(256), smem, st, a);
+    else return -2;   // SLN_E_UNSUPPORTED (sln_launch_gemm_nt forces tile 0 for such operands)
+  }
+  else if (a.A.nseg > 1) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 1>), dim3(grid), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 0>), dim3(grid), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -59,7 +63,7 @@ template <int AMODE, int EPI, bool XG>
 __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, const GemmTNArgs b, const int nt_blocks, const int tn_gx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if ((int)blockIdx.x < nt_blocks) {
-    gemm_nt_body<64, 64, 2, 2, AMODE, EPI, false>(a, blockIdx.x, nt_blocks, smem);
+    gemm_nt_body<64, 64, 2, 2, AMODE, EPI, 0>(a, blockIdx.x, nt_blocks, smem);
   } else {
     const int id = blockIdx.x - nt_blocks;
     gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(b, id % tn_gx, id / tn_gx, smem);
@@ -101,10 +105,13 @@ static int init_nt_tile() {
   hipError_t e = hipSuccess;
 #define SLN_SET(X2, EPI)                                                                                          \
   if (e == hipSuccess)                                                                                            \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, false>),       \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, 0>),           \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
   if (e == hipSuccess)                                                                                            \
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, true>),        \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, BN, WM, WN, X2, EPI, 1>),           \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                              \
+  if (e == hipSuccess && BM == 64 && BN == 64)                                                                    \
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<64, 64, WM, WN, X2, EPI, 2>),           \
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET(0, EPI_PLAIN) SLN_SET(0, EPI_STATS) SLN_SET(0, EPI_MASK)
   SLN_SET(1, EPI_PLAIN) SLN_SET(1, EPI_STATS) SLN_SET(1, EPI_MASK)
@@ -144,6 +151,7 @@ int sln_gemm_init() {
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
   SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
   if (tile < 0) tile = nt_heuristic_tile(a);
+  if (a.A.nseg > 1 && nt_unaligned(a)) tile = 0;        // the per-thread segment choice exists for the 64x64 tile only
   const int amode = nt_amode(a);
 #define SLN_DISPATCH(AM)                                                              \
   if (amode == AM) {                                                                  \

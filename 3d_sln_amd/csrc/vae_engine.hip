@@ -99,6 +99,9 @@ struct SlnVae {
   bool z_from_latent = false;
   bool wt_fresh = false;          // transposed weights valid for the current parameters
   float host_kl = 0.f, host_lr = 0.f; int64_t host_step = 0; bool host_scalars_valid = false;
+  float* grad_guard = nullptr;    // sln_vae_set_grad_guard: where the iteration leaves its total loss for the collective NaN guard
+  bool draw_eps = false;          // the iteration draws its own N(0,1) (no eps from the caller)
+  unsigned long long host_seed[2] = {0, 0};
 
   // wgrad GEMMs run on a side stream, concurrent with the dgrad chain (both only half-fill the chip at
   // batch 64); fork after the producer of the wgrad's gradient operand, join before that buffer is reused.
@@ -300,6 +303,18 @@ struct SlnVae {
   int run_bn_updates(int first, int count, hipStream_t st);
   enum { TRAIN_BACKWARD = 0, TRAIN_FULL = 1, TRAIN_UPTO_DECODER = 2, TRAIN_ENCODER_BWD = 3 };   // = SLN_TRAIN_* of sln_hip.h
   int train_iteration(const float* eps, int mode, hipStream_t st);
+  // input of box_net (with_attr) / angle_net: [obj_vecs | attr_vecs] resp. obj_vecs, where obj_vecs is the decoder gconv
+  // output - with decoder_cat off followed by z (Sg2ScVAE_model.py:162-171)
+  Operand head_input(bool with_attr, bool training) const {
+    const Layer& ll = layers[2 * L - 1];
+    Operand o; std::memset(&o, 0, sizeof(o));
+    int n = 0, cols = 0;
+    o.seg[n++] = seg_act(ll.A4, Ddc, 0, Ddc, ll.bn[3], 0, training); cols += Ddc;
+    if (!cfg.decoder_cat) { o.seg[n++] = seg_ident(z, E, 0, E, 0); cols += E; }
+    if (with_attr && n_attr_e > 0) { o.seg[n++] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1); cols += n_attr_e; o.idx_a = attrs32; }
+    o.nseg = n; o.rows = O; o.cols = cols;
+    return o;
+  }
   void drop_graphs() {
     for (int i = 0; i < 4; ++i)
       if (graph_exec[i]) { (void)hipGraphExecDestroy(graph_exec[i]); graph_exec[i] = nullptr; }
@@ -462,19 +477,14 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   da.objs = batch.objs; da.attrs = batch.attributes; da.obj_emb = t.obj_emb_dc; da.attr_emb = t.attr_emb_dc;
   da.mu = mu; da.logvar = logvar; da.eps = eps; da.z_in = z_ext;
   da.O = O; da.n_obj = n_obj_e; da.n_attr = n_attr_e; da.n_z = E; da.use_ae = cfg.use_ae;
-  da.z = z; da.x0 = X0d;
+  da.z = z; da.x0 = X0d; da.z_in_x0 = cfg.decoder_cat ? 1 : 0;
   RET_IF(sln_launch_dec_assemble(da, st));
   RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
   for (int l = 0; l < L; ++l) RET_IF(gconv_forward(L + l, training, st));
   // box_net([obj_vecs | attr_vecs]) and angle_net(obj_vecs)  (Sg2ScVAE_model.py:166-171)
-  const Layer& ll = layers[2 * L - 1];
-  Operand XA; std::memset(&XA, 0, sizeof(XA));
-  XA.seg[0] = seg_act(ll.A4, Ddc, 0, Ddc, ll.bn[3], 0, training);
-  XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
-  XA.nseg = 2; XA.rows = O; XA.cols = Ddc + n_attr_e; XA.idx_a = attrs32;
   begin_group();
-  RET_IF(linear_fwd(XA, unit_boxnet(0), bnA1, H, 0, O, bn_head[4], training, st));
-  RET_IF(linear_fwd(layer_output(2 * L - 1, training), unit_anglenet(0), anA1, H, 0, O, bn_head[5], training, st));
+  RET_IF(linear_fwd(head_input(true, training), unit_boxnet(0), bnA1, H, 0, O, bn_head[4], training, st));
+  RET_IF(linear_fwd(head_input(false, training), unit_anglenet(0), anA1, H, 0, O, bn_head[5], training, st));
   RET_IF(end_group(st));
   begin_group();
   RET_IF(linear_fwd(op1(seg_act(bnA1, H, 0, H, bn_head[4], 0, training), O), unit_boxnet(1), boxes_pred, cfg.box_dim, 0, O, -1,
@@ -509,7 +519,8 @@ int SlnVae::decoder_backward(hipStream_t st) {
   RET_IF(refresh_transposes(st));
   const int last = 2 * L - 1;
   const Layer& ll = layers[last];
-  const int W = Ddc, WA = Ddc + n_attr_e;
+  // W: width of the gconv vectors; Wh: width of the heads' input without the attribute columns (= W, plus z when decoder_cat is off)
+  const int W = Ddc, Wh = 2 * E, WA = Wh + n_attr_e;
   // box_net.1 and angle_net.1 (grouped), then box_net.0 and angle_net.0 (grouped)
   Operand Gb = op1(seg_ident(dbp, dbp_ld, 0, dbp_ld, 0), O); Gb.cols = dbp_ld;
   Operand Ga = op1(seg_ident(dlogits, cfg.n_angle, 0, cfg.n_angle, 0), O);
@@ -523,25 +534,24 @@ int SlnVae::decoder_backward(hipStream_t st) {
   RET_IF(linear_dgrad(Ga, unit_anglenet(1), g_an, H, O, anA1, H, bn_head[5], true, nullptr, 0, tr, st));
   RET_IF(end_group(st));
   Operand G0 = op1(seg_bwd(g_bn, H, bnA1, H, H, bn_head[4], tr), O);
-  Operand XA; std::memset(&XA, 0, sizeof(XA));
-  XA.seg[0] = seg_act(ll.A4, W, 0, W, ll.bn[3], 0, tr);
-  XA.seg[1] = seg_ident(t.attr_emb_dc, n_attr_e, 0, n_attr_e, 1);
-  XA.nseg = 2; XA.rows = O; XA.cols = WA; XA.idx_a = attrs32;
+  const Operand XA = head_input(true, tr);
   Operand Ga0 = op1(seg_bwd(g_an, H, anA1, H, H, bn_head[5], tr), O);
   begin_group();
   RET_IF(linear_wgrad(G0, XA, unit_boxnet(0), O, st));
   RET_IF(linear_dgrad(G0, unit_boxnet(0), d_bx, WA, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
-  RET_IF(linear_wgrad(Ga0, layer_output(last, tr), unit_anglenet(0), O, st));
-  RET_IF(linear_dgrad(Ga0, unit_anglenet(0), d_ax, W, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
+  RET_IF(linear_wgrad(Ga0, head_input(false, tr), unit_anglenet(0), O, st));
+  RET_IF(linear_dgrad(Ga0, unit_anglenet(0), d_ax, Wh, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
   RET_IF(end_group(st));
   RET_IF(join_side(st));      // g_bn / g_an / dbp / dlogits consumers done before g4 is produced
   // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
   {
     BnView v = view(ll.bn[3], 0, tr);
-    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, W, ll.A4, W, v, O, W, g4, W,
+    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, Wh, ll.A4, W, v, O, W, g4, W,
                                   v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
   }
-  RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, W, O, n_attr_e, cfg.num_attrs, t.d_attr_emb_dc, st));
+  // decoder_cat off: z entered behind the gconv net, its gradient is the sum of the two heads' (Sg2ScVAE_model.py:164)
+  if (!cfg.decoder_cat) RET_IF(sln_launch_add2(d_bx + W, WA, d_ax + W, Wh, O, E, dz, E, st));
+  if (n_attr_e > 0) RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, Wh, O, n_attr_e, cfg.num_attrs, t.d_attr_emb_dc, st));
   // gconv layers, last to first
   for (int l = L - 1; l >= 0; --l) {
     const int gi = L + l, slot = l & 1;
@@ -560,7 +570,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   }
   DecAssembleBwd db; std::memset(&db, 0, sizeof(db));
   db.objs = batch.objs; db.attrs = batch.attributes; db.dx0 = dX0; db.O = O; db.n_obj = n_obj_e; db.n_attr = n_attr_e; db.n_z = E;
-  db.d_obj_emb = t.d_obj_emb_dc; db.d_attr_emb = t.d_attr_emb_dc; db.dz = dz;
+  db.d_obj_emb = t.d_obj_emb_dc; db.d_attr_emb = t.d_attr_emb_dc; db.dz = dz; db.z_in_x0 = cfg.decoder_cat ? 1 : 0;
   RET_IF(sln_launch_dec_assemble_bwd(db, st));
   const int nb = (int)bns.size() - n_bn_enc;
   if (nb > 0) {
@@ -663,9 +673,14 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
     HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
     bulk_zeroed = true;
-    r = encoder_forward(step_training, st);
+    if (draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
+    if (!r) r = encoder_forward(step_training, st);
     if (!r) r = decoder_forward(nullptr, eps, step_training, st);
     if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
+    // data-parallel guard: the total loss travels with the gradients (one more element of the all-reduced bucket); a
+    // non-finite loss on ANY rank makes the reduced slot non-finite on EVERY rank, and sln_vae_adam_step skips on all of them
+    if (!r && grad_guard && mode != TRAIN_FULL)
+      r = (int)hipMemcpyAsync(grad_guard, losses + 3, sizeof(float), hipMemcpyDeviceToDevice, st);
     if (!r) r = decoder_backward(st);
     if (!r) r = sln_launch_latent_bwd(mu, logvar, eps, dz, &scalars->kl_weight, O, E, cfg.use_ae, dmu, dlv, st);
   }
@@ -701,7 +716,7 @@ int sln_device_ok(void) {
 static int cfg_check(const SlnVaeConfig* c) {
   if (!c) return SLN_E_BADARG;
   if (c->embedding_dim <= 0 || c->embedding_dim % 16 != 0) return SLN_E_UNSUPPORTED;
-  if (c->gconv_num_layers < 1 || !c->decoder_cat) return SLN_E_UNSUPPORTED;
+  if (c->gconv_num_layers < 1) return SLN_E_UNSUPPORTED;
   if (c->box_dim != 6 && c->box_dim != 4) return SLN_E_UNSUPPORTED;
   if (c->n_angle % 4 != 0 || c->n_angle <= 0) return SLN_E_UNSUPPORTED;
   return 0;
@@ -722,8 +737,9 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
   h->cfg = *c;
   const int E = c->embedding_dim;
   h->E = E; h->H = 4 * E; h->L = c->gconv_num_layers; h->nmod = c->recurrent ? 1 : h->L;
-  h->n_obj_e = E * 3 / 4; h->n_attr_e = E / 4; h->n_box_e = E * 3 / 4; h->n_angle_e = E / 4;
-  h->Dec = 2 * E; h->Ddc = 2 * E;
+  // Sg2ScVAE_model.py:21-37: without attributes the class embedding takes the whole E columns
+  h->n_obj_e = c->no_attr ? E : E * 3 / 4; h->n_attr_e = c->no_attr ? 0 : E / 4; h->n_box_e = E * 3 / 4; h->n_angle_e = E / 4;
+  h->Dec = 2 * E; h->Ddc = c->decoder_cat ? 2 * E : E;          // :79-88: the decoder's gconv net runs on E columns when z joins afterwards
   const int H = h->H, W = 2 * E, n = sln_vae_num_units(c);
   h->units.resize(n);
   auto set = [&](int i, int out_, int in_, bool bn) { h->units[i].out = out_; h->units[i].in = in_; h->units[i].bn = bn && c->batch_norm; };
@@ -731,7 +747,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
   set(4, H, W, true); set(5, W, H, true); set(6, h->n_angle_e, W, false); set(7, h->n_angle_e, W, false);
   for (int net = 0; net < 2; ++net)
     for (int m = 0; m < h->nmod; ++m) {
-      const int u = 8 + (net * h->nmod + m) * 4, D = W;
+      const int u = 8 + (net * h->nmod + m) * 4, D = net == 0 ? h->Dec : h->Ddc;
       set(u + 0, H, 3 * D, true); set(u + 1, 2 * H + D, H, true); set(u + 2, H, H, true); set(u + 3, D, H, true);
     }
   set(h->unit_boxnet(0), H, W + h->n_attr_e, true); set(h->unit_boxnet(1), c->box_dim, H, false);
@@ -741,8 +757,8 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
   for (int net = 0; net < 2; ++net) {
     for (int l = 0; l < h->L; ++l) {
       Layer& ly = h->layers[net * h->L + l];
-      ly.net = net; ly.first = l == 0; ly.last = l == h->L - 1; ly.D = W; ly.u0 = h->unit_of(net, l, 0);
-      const int Cs[4] = {H, 2 * H + W, H, W};
+      ly.net = net; ly.first = l == 0; ly.last = l == h->L - 1; ly.D = net == 0 ? h->Dec : h->Ddc; ly.u0 = h->unit_of(net, l, 0);
+      const int Cs[4] = {H, 2 * H + ly.D, H, ly.D};
       for (int k = 0; k < 4; ++k) {
         if (!h->units[ly.u0 + k].bn) continue;
         BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;   // -1: T rows, -2: O rows (set per batch)
@@ -813,6 +829,7 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
   HIP_RET(hipMemcpy(h->tr_table_dev, tr.data(), sizeof(TransposeEntry) * tr.size(), hipMemcpyHostToDevice));
   AdamScalars sc; std::memset(&sc, 0, sizeof(sc));
   sc.step = 0; sc.lr = 1e-4f; sc.beta1 = 0.9f; sc.beta2 = 0.999f; sc.eps = 1e-8f; sc.kl_weight = 0.1f; sc.bc1 = 1.f; sc.bc2 = 1.f;
+  sc.rng_seed = h->host_seed[0]; sc.rng_offset = h->host_seed[1];
   HIP_RET(hipMemcpy(h->scalars, &sc, sizeof(sc), hipMemcpyHostToDevice));
   RET_IF(sln_gemm_init());
   h->host_scalars_valid = false;
@@ -909,9 +926,9 @@ int sln_vae_decoder(SlnVae* h, const float* z, float* boxes_pred, float* angles_
 int sln_vae_forward(SlnVae* h, const float* eps, float* mu, float* logvar, float* z_out, float* boxes_pred,
                     float* angles_pred, int training, void* stream) {
   if (!h || !h->batch_set) return SLN_E_STATE;
-  if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+  else if (!h->cfg.use_ae) RET_IF(sln_launch_randn(h->eps_buf, (long)h->O * h->E, h->scalars, st));    // Sg2ScVAE_model.py:182
   RET_IF(h->encoder_forward(training != 0, st));
   RET_IF(h->decoder_forward(nullptr, h->eps_buf, training != 0, st));
   RET_IF(copy_out(mu, h->mu, (size_t)h->O * h->E, st));
@@ -990,8 +1007,10 @@ int sln_vae_adam_step(SlnVae* h, float lr, void* stream) {
   if (!h || !h->bound || !h->t.adam_m || !h->t.adam_v) return SLN_E_STATE;
   hipStream_t st = (hipStream_t)stream;
   RET_IF(set_kl(h, h->host_scalars_valid ? h->host_kl : 0.1f, lr, st));
-  // the loss of the last iteration on THIS rank guards the update (losses[3] stays 0 until a loss was computed)
-  RET_IF(sln_launch_adam(h->t.flat_params, h->t.flat_grads, h->t.adam_m, h->t.adam_v, (long)h->t.n_flat, h->scalars, h->losses + 3, st));
+  // guard of the update: the slot registered with sln_vae_set_grad_guard (after the trainer's all-reduce it holds the
+  // rank-averaged total loss: every rank skips, or none), else the loss of the last iteration on this rank
+  RET_IF(sln_launch_adam(h->t.flat_params, h->t.flat_grads, h->t.adam_m, h->t.adam_v, (long)h->t.n_flat, h->scalars,
+                         h->grad_guard ? h->grad_guard : h->losses + 3, st));
   h->wt_fresh = false;
   return 0;
 }
@@ -1000,6 +1019,31 @@ int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream) {
   if (!h || !h->bound) return SLN_E_STATE;
   h->host_step = step;
   return (int)hipMemcpyAsync(&h->scalars->step, &h->host_step, sizeof(int64_t), hipMemcpyHostToDevice, (hipStream_t)stream);
+}
+
+int sln_vae_adam_get_step(SlnVae* h, int64_t* step_out, void* stream) {
+  if (!h || !h->bound || !step_out) return SLN_E_STATE;
+  HIP_RET(hipMemcpyAsync(step_out, &h->scalars->step, sizeof(int64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIP_RET(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
+
+int sln_vae_set_grad_guard(SlnVae* h, float* slot) {
+  if (!h) return SLN_E_BADARG;
+  if (h->grad_guard != slot) { h->grad_guard = slot; h->drop_graphs(); }
+  return 0;
+}
+
+int sln_vae_seed(SlnVae* h, uint64_t seed, uint64_t offset, void* stream) {
+  if (!h || !h->bound) return SLN_E_STATE;
+  h->host_seed[0] = seed; h->host_seed[1] = offset;
+  HIP_RET(hipMemcpyAsync(&h->scalars->rng_seed, h->host_seed, 2 * sizeof(unsigned long long), hipMemcpyHostToDevice, (hipStream_t)stream));
+  return 0;
+}
+
+int sln_vae_last_eps(SlnVae* h, float* eps_out, void* stream) {
+  if (!h || !h->batch_set || !eps_out) return SLN_E_STATE;
+  return copy_out(eps_out, h->eps_buf, (size_t)h->O * h->E, (hipStream_t)stream);
 }
 
 int sln_vae_set_training(SlnVae* h, int training) {
@@ -1023,9 +1067,10 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
   if (mode == SlnVae::TRAIN_ENCODER_BWD) {
     if (!(h->have_dec && h->dec_training == h->step_training && h->z_from_latent)) return SLN_E_STATE;       // needs the first half
   } else {
-    if (!eps && !h->cfg.use_ae) return SLN_E_BADARG;
     RET_IF(set_kl(h, kl_weight, lr, st));
     if (eps) RET_IF(copy_out(h->eps_buf, eps, (size_t)h->O * h->E, st));
+    const bool draw = !eps && !h->cfg.use_ae;            // no eps from the caller: the iteration draws it on the device
+    if (draw != h->draw_eps) { HIP_RET(hipStreamSynchronize(st)); h->draw_eps = draw; h->drop_graphs(); }
   }
   if (use_graph && st != nullptr) {
     hipGraphExec_t& ge = h->graph_exec[mode];

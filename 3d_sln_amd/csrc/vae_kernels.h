@@ -44,6 +44,8 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
                           const float* xprev, int ldx, BnView bn, int masked, float* out, int ldo,
                           double* gsums, int cstride, hipStream_t st);
 
+// out[r, c] = a[r, c] + b[r, c]  (c < cols; plain strided sum, e.g. the two head gradients w.r.t. z when decoder_cat is off)
+int sln_launch_add2(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, int ldo, hipStream_t st);
 // generic junction: g = mask(d1 + d2) with column statistics
 int sln_launch_mask_gstats(const float* d1, int ld1, const float* d2, int ld2, const float* xprev, int ldx,
                            BnView bn, int rows, int cols, float* out, int ldo, double* gsums, int cstride,
@@ -70,11 +72,13 @@ struct DecAssemble {       // z = eps*exp(.5*logvar)+mu (or mu); X0 = [obj_emb[o
   const float* z_in;       // when non-null: use this z (decoder() call surface), mu/logvar/eps ignored
   int O, n_obj, n_attr, n_z, use_ae;
   float* z; float* x0;
+  int z_in_x0;             // decoder_cat: 1 = X0 = [obj | attr | z] (Sg2ScVAE_model.py:157-159), 0 = X0 = [obj | attr], z joins after the gconv net (:162-164)
 };
 int sln_launch_dec_assemble(DecAssemble a, hipStream_t st);
 struct DecAssembleBwd {    // scatter dX0 into the two embedding grads, pass dz through
   const int64_t* objs; const int64_t* attrs; const float* dx0; int O, n_obj, n_attr, n_z;
   float* d_obj_emb; float* d_attr_emb; float* dz;
+  int z_in_x0;             // 0: dx0 is [O, n_obj + n_attr] and dz is not touched
 };
 int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st);
 
@@ -123,7 +127,16 @@ int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, int i
 struct TransposeEntry { const float* src; float* dst; int rows; int cols; int dst_ld; int pad_; };   // dst[c*dst_ld + r] = src[r*cols + c]
 int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles, hipStream_t st);
 
-struct AdamScalars { int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; int skip, pad_; };
+struct AdamScalars {
+  int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; int skip, pad_;
+  // Philox stream of the reparameterisation draw (Sg2ScVAE_model.py:182): key = seed, counter = (element / 4, offset);
+  // the draw kernel itself advances `rng_offset`, so a replayed hipGraph takes a fresh draw every iteration
+  unsigned long long rng_seed, rng_offset; unsigned int rng_done, pad2_;
+};
 // total_loss (device, may be NULL): a non-finite value skips the update and the step count (train.py:79-81 'not backpropping')
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
                     hipStream_t st);
+
+// eps[i] ~ N(0, 1), i < n: Philox-4x32-10 + Box-Muller, 4 values per counter; the last block to finish advances
+// scalars->rng_offset by one (one offset per draw: streams of different iterations never overlap)
+int sln_launch_randn(float* eps, long n, AdamScalars* scalars, hipStream_t st);

@@ -378,10 +378,12 @@ __global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a)
 
 __global__ void dec_assemble_kernel(DecAssemble a) {
   const int W = a.n_obj + a.n_attr + a.n_z;
+  const int Wx = a.z_in_x0 ? W : a.n_obj + a.n_attr;      // row stride of x0
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)a.O * W) return;
   const int r = (int)(idx / W);
   int c = (int)(idx % W);
+  const int cx = c;
   float v;
   if (c < a.n_obj) v = a.obj_emb[(size_t)a.objs[r] * a.n_obj + c];
   else if ((c -= a.n_obj) < a.n_attr) v = a.attr_emb[(size_t)a.attrs[r] * a.n_attr + c];
@@ -392,12 +394,13 @@ __global__ void dec_assemble_kernel(DecAssemble a) {
     else if (a.use_ae) v = a.mu[zi];
     else v = a.eps[zi] * expf(0.5f * a.logvar[zi]) + a.mu[zi];     // Sg2ScVAE_model.py:180-183
     if (a.z) a.z[zi] = v;
+    if (!a.z_in_x0) return;
   }
-  a.x0[idx] = v;
+  a.x0[(size_t)r * Wx + cx] = v;
 }
 
 __global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
-  const int W = a.n_obj + a.n_attr + a.n_z;
+  const int W = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)a.O * W) return;
   const int r = (int)(idx / W);
@@ -622,6 +625,44 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
   }
 }
 
+// Philox-4x32-10 (Salmon et al., SC'11), the generator torch.randn uses on the device; Box-Muller on the four words.
+__device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+  const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+  const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned int)p1;
+  const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned int)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ eps, long n, AdamScalars* sc) {
+  const unsigned long long seed = sc->rng_seed, off = sc->rng_offset;
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (4 * q < n) {
+    unsigned int c[4] = {(unsigned int)q, (unsigned int)((unsigned long long)q >> 32), (unsigned int)off, (unsigned int)(off >> 32)};
+    unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float u1 = ((float)c[2 * h] + 1.0f) * 2.3283064365386963e-10f;          // (0, 1]
+      const float u2 = (float)c[2 * h + 1] * 2.3283064365386963e-10f;               // [0, 1]
+      const float rad = sqrtf(-2.0f * logf(u1));
+      float sn, cs;
+      sincosf(6.283185307179586f * u2, &sn, &cs);
+      v[2 * h] = rad * cs; v[2 * h + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (4 * q + k < n) eps[4 * q + k] = v[k];
+  }
+  // every block has read the offset before it gets here; the last one to arrive advances it
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(&sc->rng_done, 1u);
+    if (done == gridDim.x - 1) { sc->rng_done = 0; sc->rng_offset = off + 1; }
+  }
+}
+
 // out[r, c] = relu(bn(x[r, col0 + c]))  (materialise a post-activation, standalone GraphTripleConv API only)
 __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int ld, int col0, int cols, long n, BnView bn,
                                      float* __restrict__ out, int ldo) {
@@ -631,6 +672,14 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int ld, int co
   float sc, sh;
   bn_fwd_coef(bn, c, sc, sh);
   out[r * ldo + c] = fmaxf(fmaf(sc, x[r * ld + col0 + c], sh), 0.f);
+}
+
+__global__ void add2_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows, int cols,
+                            float* __restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  out[(size_t)r * ldo + c] = a[(size_t)r * lda + c] + b[(size_t)r * ldb + c];
 }
 
 inline dim3 colgrid(int cols, int rows) { return dim3(sln_cdiv(cols, CB), sln_cdiv(rows, RB)); }
@@ -657,7 +706,7 @@ __global__ void stage_batch_kernel(StageBatch a) {
   a.deg[i] = 0;
   for (int k = 0; k < a.box_dim; ++k) a.st_boxes[(size_t)i * a.box_dim + k] = a.boxes[(size_t)i * a.box_dim + k];
   if (ob < 0 || ob >= a.n_objs) atomicOr(a.err, 2);
-  if (at < 0 || at >= a.n_attrs) atomicOr(a.err, 4);
+  if (a.n_attrs > 0 && (at < 0 || at >= a.n_attrs)) atomicOr(a.err, 4);       // use_attr off: attributes are not looked at
   if (an < 0 || an >= a.n_angle) atomicOr(a.err, 8);
 }
 
@@ -782,7 +831,7 @@ int sln_launch_dec_assemble(DecAssemble a, hipStream_t st) {
 }
 
 int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st) {
-  const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_z);
+  const long n = (long)a.O * (a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0));
   if (n <= 0) return 0;
   hipLaunchKernelGGL(dec_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
   SLN_CHECK_LAUNCH();
@@ -907,6 +956,22 @@ int sln_launch_adam(float* params, const float* grads, float* m, float* v, long 
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars);
   }
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_randn(float* eps, long n, AdamScalars* scalars, hipStream_t st) {
+  if (n <= 0) return 0;
+  const long q = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, eps, n, scalars);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_add2(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, int ldo, hipStream_t st) {
+  const long n = (long)rows * cols;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, lda, b, ldb, rows, cols, out, ldo);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -27,7 +27,10 @@ class _ForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, anchor, model, eps, training):
+        model.params_changed()            # a torch optimizer may have stepped since the last backward (dgrad uses cached W^T)
         mu, lv, z, bp, ap = model._engine_forward(eps, training)
+        if eps is None and not model.use_AE:
+            eps = model.last_eps()        # drawn on the device (Sg2ScVAE_model.py:182); backward needs it
         ctx.model, ctx.gen = model, model._generation
         ctx.save_for_backward(eps, lv)
         return mu, lv, bp, ap
@@ -53,6 +56,7 @@ class _ForwardFn(torch.autograd.Function):
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, training):
+        model.params_changed()
         mu, lv = model._engine_encoder(training)
         ctx.model, ctx.gen = model, model._generation
         return mu, lv
@@ -69,6 +73,7 @@ class _EncoderFn(torch.autograd.Function):
 class _DecoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, z, model, training):
+        model.params_changed()
         bp, ap = model._engine_decoder(z, training)
         ctx.model, ctx.gen = model, model._generation
         return bp, ap
@@ -87,17 +92,15 @@ class Sg2ScVAEModel(nn.Module):
                  gconv_mode='feedforward', gconv_pooling='avg', gconv_num_layers=5, mlp_normalization='none',
                  vec_noise_dim=0, layout_noise_dim=0, use_AE=False, use_attr=True):
         super().__init__()
-        if not use_attr:
-            raise NotImplementedError("use_attr=False is never reached in the reference (build_model does not pass it)")
-        if not decoder_cat:
-            raise NotImplementedError("the HIP path implements decoder_cat=True (train.py's default, options.py:55)")
         if gconv_num_layers < 1:
             raise NotImplementedError("gconv_num_layers must be >= 1 on the HIP path")
         if embedding_dim % 16:
             raise NotImplementedError("embedding_dim must be a multiple of 16 on the HIP path")
         E = embedding_dim
         hidden = E * 4
-        box_e, angle_e, obj_e, attr_e = int(E * 3 / 4), int(E / 4), int(E * 3 / 4), int(E / 4)
+        box_e, angle_e = int(E * 3 / 4), int(E / 4)
+        obj_e, attr_e = (int(E * 3 / 4), int(E / 4)) if use_attr else (E, 0)          # Sg2ScVAE_model.py:23-24,35-37
+        dc_dim = E * 2 if decoder_cat else E                                          # :47,51-52,79-88
         self.use_attr, self.batch_size, self.train_3d, self.decoder_cat = use_attr, batch_size, train_3d, decoder_cat
         self.vocab, self.vec_noise_dim, self.layout_noise_dim, self.use_AE = vocab, vec_noise_dim, layout_noise_dim, use_AE
         self.embedding_dim, self.Nangle, self.gconv_mode = E, Nangle, gconv_mode
@@ -110,9 +113,10 @@ class Sg2ScVAEModel(nn.Module):
         self.obj_embeddings_ec = nn.Embedding(num_objs + 1, obj_e)
         self.pred_embeddings_ec = nn.Embedding(num_preds, E * 2)
         self.obj_embeddings_dc = nn.Embedding(num_objs + 1, obj_e)
-        self.pred_embeddings_dc = nn.Embedding(num_preds, E * 2)
-        self.attr_embedding_ec = nn.Embedding(num_attrs, attr_e)
-        self.attr_embedding_dc = nn.Embedding(num_attrs, attr_e)
+        self.pred_embeddings_dc = nn.Embedding(num_preds, dc_dim)
+        if use_attr:
+            self.attr_embedding_ec = nn.Embedding(num_attrs, attr_e)
+            self.attr_embedding_dc = nn.Embedding(num_attrs, attr_e)
         self.box_embeddings = nn.Linear(self.box_dim, box_e)
         self.angle_embeddings = nn.Embedding(Nangle, angle_e)
         n = mlp_normalization
@@ -125,7 +129,7 @@ class Sg2ScVAEModel(nn.Module):
         kw = dict(hidden_dim=hidden, pooling=gconv_pooling, num_layers=gconv_num_layers, mode=gconv_mode,
                   mlp_normalization=n)
         self.gconv_net_ec = GraphTripleConvNet(input_dim=E * 2, **kw)
-        self.gconv_net_dc = GraphTripleConvNet(input_dim=E * 2, **kw)
+        self.gconv_net_dc = GraphTripleConvNet(input_dim=dc_dim, **kw)
         self.box_net = make_mlp([E * 2 + attr_e, hidden, self.box_dim], batch_norm=n, norelu=True)
         self.angle_net = make_mlp([E * 2, hidden, Nangle], batch_norm=n, norelu=True)
         for m in (self.box_embeddings, self.box_mean_var, self.box_mean, self.box_var, self.angle_mean_var,
@@ -150,7 +154,9 @@ class Sg2ScVAEModel(nn.Module):
             offs.append(n)
             n += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
         flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        gflat = torch.zeros(n, dtype=torch.float32, device=dev)
+        # gradients + one guard element (data-parallel NaN guard, see grad_bucket) + padding to the alignment
+        gfull = torch.zeros(n + _ALIGN, dtype=torch.float32, device=dev)
+        gflat = gfull[:n]
         views = []
         with torch.no_grad():
             for p, o in zip(params, offs):
@@ -162,10 +168,16 @@ class Sg2ScVAEModel(nn.Module):
                     gv.copy_(p.grad)
                 p.grad = gv
                 views.append(gv)
-        self._flat, self._gflat, self._gviews, self._params = flat, gflat, views, params
+        # .cuda() / .float() re-flatten: the optimizer state moves with the parameters (it used to be dropped silently)
+        old_m, old_v = getattr(self, "_adam_m", None), getattr(self, "_adam_v", None)
+        steps = self._sync_adam_steps() if getattr(self, "_eng", None) is not None else getattr(self, "_adam_steps", 0)
+        self._flat, self._gflat, self._gfull, self._gviews, self._params = flat, gflat, gfull, views, params
         self._offs = offs
-        self._adam_m = self._adam_v = None
-        self._adam_steps = 0                       # Adam's step counter lives in the engine's workspace: restored after a re-bind
+        if old_m is not None and old_m.numel() == n:
+            self._adam_m, self._adam_v, self._adam_steps = old_m.to(dev), old_v.to(dev), steps
+        else:
+            self._adam_m = self._adam_v = None
+            self._adam_steps = 0                   # host copy of Adam's step counter (the device's lives in the engine's workspace)
         self._anchor = torch.zeros(1, dtype=torch.float32, device=dev, requires_grad=True)
         self._drop_engine()
 
@@ -188,6 +200,33 @@ class Sg2ScVAEModel(nn.Module):
     def flat_grads(self):
         return self._gflat
 
+    @property
+    def grad_bucket(self):
+        """What the data-parallel trainer all-reduces: ``flat_grads`` plus ONE trailing guard element.  ``train_step(with_adam=
+        False)`` / ``train_step_begin`` leave the rank's total loss there; after the all-reduce it is the rank average, and
+        ``adam_step`` skips the update on EVERY rank when it is not finite (train.py:79-81 on a single GPU)."""
+        return self._gfull[:self._gflat.numel() + 1]
+
+    def _sync_adam_steps(self):
+        """The device's step counter (it does not advance on an iteration skipped for a non-finite loss)."""
+        if self._eng is not None:
+            out = C.c_int64(0)
+            _lib.check(_lib.lib().sln_vae_adam_get_step(self._eng, C.byref(out), _lib.current_stream_ptr()), "sln_vae_adam_get_step")
+            self._adam_steps = int(out.value)
+        return self._adam_steps
+
+    def manual_seed(self, seed):
+        """Seed of the on-device N(0,1) draws taken when no ``eps`` is passed (default: torch.initial_seed())."""
+        self._rng_seed, self._rng_epoch = int(seed) & (2 ** 64 - 1), 0
+        if self._eng is not None:
+            _lib.check(_lib.lib().sln_vae_seed(self._eng, self._rng_seed, 0, _lib.current_stream_ptr()), "sln_vae_seed")
+
+    def last_eps(self):
+        """eps of the last forward / train_step (injected or drawn on the device)."""
+        out = self._new(self._O, self.embedding_dim)
+        _lib.check(_lib.lib().sln_vae_last_eps(self._eng, _lib.ptr(out), _lib.current_stream_ptr()), "sln_vae_last_eps")
+        return out
+
     def params_changed(self):
         """Call after modifying parameters outside the engine (e.g. a torch optimizer step)."""
         if self._eng is not None:
@@ -204,6 +243,10 @@ class Sg2ScVAEModel(nn.Module):
     # ------------------------------------------------------------------ engine plumbing
     def _drop_engine(self):
         if getattr(self, "_eng", None) is not None:
+            try:
+                self._sync_adam_steps()            # the counter lives in the workspace that goes away with the engine
+            except Exception:
+                pass
             _lib.lib().sln_vae_destroy(self._eng)
         self._eng = None
         self._maxO = self._maxT = 0
@@ -220,10 +263,11 @@ class Sg2ScVAEModel(nn.Module):
         c.embedding_dim, c.gconv_num_layers = self.embedding_dim, self.gconv_num_layers
         c.recurrent = int(self.gconv_mode == 'recurrent')
         c.batch_norm = int(self.mlp_normalization == 'batch')
-        c.decoder_cat, c.use_ae, c.box_dim, c.n_angle = 1, int(self.use_AE), self.box_dim, self.Nangle
+        c.decoder_cat, c.use_ae, c.box_dim, c.n_angle = int(self.decoder_cat), int(self.use_AE), self.box_dim, self.Nangle
         c.num_objs = self.obj_embeddings_ec.num_embeddings
         c.num_preds = self.pred_embeddings_ec.num_embeddings
-        c.num_attrs = self.attr_embedding_ec.num_embeddings
+        c.num_attrs = self.attr_embedding_ec.num_embeddings if self.use_attr else 0
+        c.no_attr = int(not self.use_attr)
         return c
 
     def _unit_modules(self):
@@ -277,9 +321,10 @@ class Sg2ScVAEModel(nn.Module):
         t = _lib.SlnVaeTensors()
         embs = dict(obj_emb_ec=self.obj_embeddings_ec.weight, pred_emb_ec=self.pred_embeddings_ec.weight,
                     obj_emb_dc=self.obj_embeddings_dc.weight, pred_emb_dc=self.pred_embeddings_dc.weight,
-                    attr_emb_ec=self.attr_embedding_ec.weight, attr_emb_dc=self.attr_embedding_dc.weight,
                     box_emb_w=self.box_embeddings.weight, box_emb_b=self.box_embeddings.bias,
                     angle_emb=self.angle_embeddings.weight)
+        if self.use_attr:
+            embs.update(attr_emb_ec=self.attr_embedding_ec.weight, attr_emb_dc=self.attr_embedding_dc.weight)
         for k, p in embs.items():
             setattr(t, k, p.data_ptr())
             setattr(t, "d_" + k, gptr[id(p)])
@@ -292,6 +337,12 @@ class Sg2ScVAEModel(nn.Module):
             # a larger batch re-creates the engine (bigger workspace); the moments live in this module, the bias-correction step
             # in the workspace - without this the update after a re-bind would be scaled as if it were the first one
             _lib.check(L.sln_vae_adam_reset(h, int(self._adam_steps), _lib.current_stream_ptr()), "sln_vae_adam_reset")
+        _lib.check(L.sln_vae_set_grad_guard(h, C.c_void_p(self._gfull.data_ptr() + 4 * self._gflat.numel())), "sln_vae_set_grad_guard")
+        if getattr(self, "_rng_seed", None) is None:
+            self._rng_seed, self._rng_epoch = int(torch.initial_seed()) & (2 ** 64 - 1), 0
+        # a re-created engine (larger batch) continues on a disjoint range of Philox offsets
+        _lib.check(L.sln_vae_seed(h, self._rng_seed, self._rng_epoch << 40, _lib.current_stream_ptr()), "sln_vae_seed")
+        self._rng_epoch += 1
         self._maxO, self._maxT = maxO, maxT
         self._batch_key = None
 
@@ -396,10 +447,8 @@ class Sg2ScVAEModel(nn.Module):
         """Returns (mu, logvar, boxes_pred, angles_pred).  ``eps`` (optional, [O, embedding_dim]) pins the
         N(0,1) draw that the reference takes with torch.randn_like (Sg2ScVAE_model.py:182)."""
         self._set_batch(objs, triples, boxes_gt, angles_gt, attributes)
-        if eps is None and not self.use_AE:
-            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
         if eps is not None:
-            eps = eps.to(torch.float32).contiguous()
+            eps = eps.to(torch.float32).contiguous()       # None: drawn on the device inside sln_vae_forward
         if torch.is_grad_enabled():
             return _ForwardFn.apply(self._anchor, self, eps, self.training)
         mu, lv, z, bp, ap = self._engine_forward(eps, self.training)
@@ -417,8 +466,8 @@ class Sg2ScVAEModel(nn.Module):
         current stream.
         """
         self._set_batch(objs, triples, boxes, angles, attributes)
-        if eps is None and not self.use_AE:
-            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
+        if eps is not None:
+            eps = eps.to(torch.float32).contiguous()       # None: the iteration draws N(0,1) on the device (also under graph replay)
         losses = self._new(4)
         self._generation += 1
         _lib.check(_lib.lib().sln_vae_set_training(self._eng, int(self.training)), "sln_vae_set_training")     # train.py:63-65
@@ -450,8 +499,8 @@ class Sg2ScVAEModel(nn.Module):
     def train_step_begin(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None, use_graph=True):
         """zero_grad, forward, losses and the decoder's half of backward (SLN_TRAIN_UPTO_DECODER); returns the losses."""
         self._set_batch(objs, triples, boxes, angles, attributes)
-        if eps is None and not self.use_AE:
-            eps = torch.randn(self._O, self.embedding_dim, dtype=torch.float32, device=self._flat.device)
+        if eps is not None:
+            eps = eps.to(torch.float32).contiguous()
         losses = self._new(4)
         self._generation += 1
         _lib.check(_lib.lib().sln_vae_set_training(self._eng, int(self.training)), "sln_vae_set_training")
@@ -477,7 +526,7 @@ class Sg2ScVAEModel(nn.Module):
         ``step`` / ``exp_avg`` / ``exp_avg_sq`` in ``model.parameters()`` order - a reference checkpoint's ``optim_state`` and this
         one are interchangeable."""
         state = {}
-        if self._adam_m is not None and self._adam_steps > 0:
+        if self._adam_m is not None and self._sync_adam_steps() > 0:
             for i, (p, o) in enumerate(zip(self._params, self._offs)):
                 n = p.numel()
                 state[i] = {'step': torch.tensor(float(self._adam_steps)),
@@ -520,6 +569,8 @@ class Sg2ScVAEModel(nn.Module):
     def tap(self, layer, what):
         """Debug: copy of an internal pre-activation (see sln_vae_tap)."""
         H, D = self.embedding_dim * 4, self.embedding_dim * 2
+        if layer >= self.gconv_num_layers and not self.decoder_cat:
+            D = self.embedding_dim
         shape = {0: (self._T, H), 1: (self._T, 2 * H + D), 2: (self._O, H), 3: (self._O, H), 4: (self._O, D)}[what]
         out = self._new(*shape)
         n = _lib.lib().sln_vae_tap(self._eng, layer, what, _lib.ptr(out), _lib.current_stream_ptr())

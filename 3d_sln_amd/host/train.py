@@ -98,6 +98,11 @@ class DataParallelStep:
             overlap = os.environ.get("SLN_DP_OVERLAP", "0") == "1"
         self.split = int(getattr(model, "decoder_grad_offset", 0)) if hasattr(model, "train_step_begin") else 0
         self.overlap = bool(overlap) and self.dp and 0 < self.split < model.flat_grads.numel()
+        # Collective non-finite guard (the reference's 'not backpropping', train.py:79-81, is single-GPU): a model with a
+        # ``grad_bucket`` leaves its total loss in the element behind the gradients; the all-reduce averages it with them, and
+        # ``adam_step`` skips on EVERY rank when that average is not finite - one NaN rank can neither poison the other replicas
+        # through the averaged gradients nor let their step counters drift apart.
+        self.guarded = hasattr(model, "grad_bucket")
         # RCCL divides inside the collective; gloo (CPU tests) has no AVG
         self.avg_in_collective = self.dp and dist.get_backend() == "nccl"
 
@@ -106,7 +111,8 @@ class DataParallelStep:
         return dist.all_reduce(buf, op=op, async_op=async_op)
 
     def __call__(self, b, kl_weight, lr, use_graph=True, eps=None):
-        m, g = self.model, self.model.flat_grads
+        m = self.model
+        g = m.grad_bucket if self.guarded else m.flat_grads       # [gradients | total loss of this rank]
         kw = dict(kl_weight=kl_weight, lr=lr, use_graph=use_graph)
         if eps is not None:
             kw["eps"] = eps
@@ -126,6 +132,27 @@ class DataParallelStep:
             g.mul_(1.0 / self.world)
         m.adam_step(lr=lr)
         return losses
+
+
+class EpochSampler:
+    """DataLoader(shuffle=True, drop_last=False) of build_dataset_model.py:28-34 as a pure function of the step: every
+    epoch is one seeded permutation of the rooms (no replacement), cut into batches; the last batch of an epoch may be
+    short.  The permutation depends on (seed, epoch) only, so every rank computes the same one and takes its own block."""
+
+    def __init__(self, n_items, batch_size, seed):
+        self.n, self.bs, self.seed = int(n_items), int(batch_size), int(seed)
+        self.per_epoch = max(1, (self.n + self.bs - 1) // self.bs)
+        self._cache = (None, None)
+
+    def epoch(self, t):
+        """1-based epoch of training step t (t counts from 1, as train.py:56-66)."""
+        return (t - 1) // self.per_epoch + 1
+
+    def batch(self, t):
+        e, k = (t - 1) // self.per_epoch, (t - 1) % self.per_epoch
+        if self._cache[0] != e:
+            self._cache = (e, torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + 1000003 * e)))
+        return self._cache[1][k * self.bs:(k + 1) * self.bs]
 
 
 def kl_weight_at(args, t):
@@ -148,7 +175,14 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
                   'counters': {'t': None, 'epoch': None}, 'model_state': None, 'optim_state': None}
     t = 0
     # train.py:16-31: resume from '<checkpoint_name>_with_model.pt' (model, optimizer - torch.optim.Adam's own state layout -, t)
-    restore_path = os.path.join(args.output_dir, '%s_with_model.pt' % args.checkpoint_name) if getattr(args, "restore_from_checkpoint", False) else None
+    # (the reference restores '<name>_with_model.pt' but writes 'latest_<name>_with_model.pt', :18 vs :103 - only its default
+    # name hides the mismatch; here the file this loop wrote is found under either spelling)
+    restore_path = None
+    if getattr(args, "restore_from_checkpoint", False):
+        for cand in ('%s_with_model.pt', 'latest_%s_with_model.pt'):
+            restore_path = os.path.join(args.output_dir, cand % args.checkpoint_name)
+            if os.path.isfile(restore_path):
+                break
     if restore_path is not None and os.path.isfile(restore_path) and hasattr(model, "load_optim_state_dict"):
         log('Restoring from checkpoint:')
         log(restore_path)
@@ -157,6 +191,7 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
         if ck.get('optim_state') is not None:
             model.load_optim_state_dict(ck['optim_state'])
         t = ck['counters']['t']
+        checkpoint['counters']['epoch'] = ck['counters'].get('epoch')
         model.eval() if 0 <= args.eval_mode_after <= t else model.train()
         checkpoint.update({k: ck[k] for k in ('losses_ts', 'losses', 'checkpoint_ts') if k in ck})
     while t < args.num_iterations:
@@ -181,6 +216,7 @@ def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
                 osd['state'] = {i: {k: v.detach().cpu() for k, v in st.items()} for i, st in osd['state'].items()}
                 checkpoint['optim_state'] = osd
             checkpoint['counters']['t'] = t
+            checkpoint['counters']['epoch'] = getattr(batch_fn, "epoch", lambda _t: None)(t)
             os.makedirs(args.output_dir, exist_ok=True)
             torch.save(checkpoint, os.path.join(args.output_dir, 'latest_%s_with_model.pt' % args.checkpoint_name))
     return checkpoint
@@ -211,14 +247,18 @@ def main(argv=None):
                             vec_noise_dim=args.vec_noise_dim, layout_noise_dim=args.layout_noise_dim,
                             use_AE=args.use_AE).cuda().train()
 
+    sampler = EpochSampler(len(dataset), args.batch_size, args.manual_seed) if dataset is not None else None
+
     def batch_fn(t, lo, hi):
-        if dataset is not None:                                  # shuffled rooms, built on the device (DataLoader + collate of train.py:17-22)
-            g = torch.Generator().manual_seed(args.manual_seed + t)
-            idx = torch.randint(0, len(dataset), (args.batch_size,), generator=g)[lo:hi]        # the same draw on every rank
-            _, objs, boxes, triples, angles, attrs, _, _ = dataset.build_batch(idx)
+        if dataset is not None:                                  # DataLoader(shuffle=True) + collate (build_dataset_model.py:28-34), on the device
+            idx = sampler.batch(t)
+            lo2, hi2 = shard_range(len(idx), rank, world)        # the epoch's last batch may be short (drop_last=False)
+            _, objs, boxes, triples, angles, attrs, _, _ = dataset.build_batch(idx[lo2:hi2])
             return dict(objs=objs, triples=triples, boxes=boxes, angles=angles, attributes=attrs)
         return synthetic.scene_graph_batch(hi - lo, args.objs_per_graph, args.triples_per_graph, seed=t * 100003 + lo,
                                            box_dim=6 if args.train_3d else 4, device="cuda")
+    if sampler is not None:
+        batch_fn.epoch = sampler.epoch
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         # real rooms differ in size from batch to batch: eager launches (a hipGraph is tied to one (O, T) pair)

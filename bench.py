@@ -271,11 +271,27 @@ def main():
     import torch
     import torch.distributed as dist
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # launched plainly (`python bench.py --gpus N`): become the launcher - one rank per GPU under torch.distributed.run,
+        # exactly the command line the driver uses; the ranks' output (rank 0 prints the JSON line) passes through
+        import socket
+        import subprocess
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible; refusing to report a smaller job as n_gpus=%d"
+                             % (args.gpus, have, args.gpus))
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU)" % (args.gpus, world))
+    if torch.cuda.device_count() <= local:
+        raise SystemExit("bench.py: rank %d has no GPU (LOCAL_RANK=%d, %d visible)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     # SLN_BENCH_FORCE_DP=1 exercises the data-parallel code path (graph without Adam + RCCL all-reduce + fused Adam)
     # on a single GPU; used to test that path on a 1-GPU box
@@ -352,7 +368,7 @@ def main():
             for i in range(25):
                 if i == 5:
                     e0.record()
-                dp_step._reduce(model.flat_grads, False)
+                dp_step._reduce(model.grad_bucket, False)
             e1.record()
         torch.cuda.synchronize()
         coll_us = round(e0.elapsed_time(e1) / 20 * 1e3, 1)

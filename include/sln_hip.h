@@ -44,14 +44,16 @@ typedef struct SlnVaeConfig {
   int gconv_num_layers;  /* >= 1                                                                   */
   int recurrent;         /* gconv_mode == 'recurrent' (weights shared by all layers)               */
   int batch_norm;        /* mlp_normalization == 'batch' (1) or 'none' (0)                         */
-  int decoder_cat;       /* must be 1 on this path (train.py default, options/options.py:55)       */
+  int decoder_cat;       /* 1: z is concatenated in front of the decoder's gconv net (train.py default,
+                          * options/options.py:55); 0: behind it (the class default, Sg2ScVAE_model.py:9,157-164) */
   int use_ae;            /* use_AE: z = mu, no KL term                                             */
   int box_dim;           /* 6 (train_3d) or 4                                                      */
   int n_angle;           /* Nangle = 24                                                            */
   int num_objs;          /* rows of obj_embeddings_* (len(object_idx_to_name) + 1)                 */
   int num_preds;         /* rows of pred_embeddings_*                                              */
-  int num_attrs;         /* rows of attr_embedding_*                                               */
-  int reserved;
+  int num_attrs;         /* rows of attr_embedding_* (0 with no_attr)                              */
+  int no_attr;           /* 1 = use_attr=False (Sg2ScVAE_model.py:17,35-37,48-50,97-98): no attribute
+                          * embeddings, the class embedding is E wide, box_net reads 2E columns     */
 } SlnVaeConfig;
 
 /* Number of Linear(+BatchNorm) units and their canonical order:
@@ -147,6 +149,21 @@ int sln_vae_zero_grad(SlnVae* h, void* stream);                       /* optimiz
 /* torch.optim.Adam(lr).step(), train.py:15,84 (betas .9/.999, eps 1e-8, no weight decay) */
 int sln_vae_adam_step(SlnVae* h, float lr, void* stream);
 int sln_vae_adam_reset(SlnVae* h, int64_t step, void* stream);       /* restore the step counter (checkpoint resume) */
+/* The device's own step counter (synchronises): after an iteration skipped for a non-finite loss it is one behind
+ * the number of sln_vae_adam_step calls (train.py:79-81 skips the optimizer step too). */
+int sln_vae_adam_get_step(SlnVae* h, int64_t* step_out, void* stream);
+/* Data-parallel NaN guard (the reference is single-GPU: build_dataset_model.py:54-55 asserts).  `slot` = one device float
+ * that the trainer all-reduces together with flat_grads (in practice flat_grads[n_flat]): SLN_TRAIN_BACKWARD /
+ * SLN_TRAIN_UPTO_DECODER store the rank's total loss there, sln_vae_adam_step skips the update when the slot - by then
+ * the average over the ranks - is not finite, so all replicas skip or step together.  NULL restores the per-rank guard.
+ * Call while the engine is idle (captured iterations are dropped). */
+int sln_vae_set_grad_guard(SlnVae* h, float* slot);
+/* The reparameterisation draw, Sg2ScVAE_model.py:180-183 (eps = randn_like(std)).  sln_vae_forward / sln_vae_train_step
+ * called with eps == NULL draw eps on the device: Philox-4x32-10 keyed by `seed`, one `offset` per draw (advanced by
+ * the draw kernel itself, so a replayed hipGraph sees a new draw every iteration).  sln_vae_last_eps copies the eps of
+ * the last forward / iteration (the injected one or the drawn one) to eps_out[O, embedding_dim]. */
+int sln_vae_seed(SlnVae* h, uint64_t seed, uint64_t offset, void* stream);
+int sln_vae_last_eps(SlnVae* h, float* eps_out, void* stream);
 
 /* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward and
  * (with_adam == SLN_TRAIN_FULL) the Adam update.  `use_graph`: replay a captured hipGraph while shapes are unchanged

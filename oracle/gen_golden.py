@@ -47,6 +47,11 @@ VAE_CASES = {
     "vae_small_none": (dict(embedding_dim=16, gconv_num_layers=2, mlp_normalization="none"), 16, 6, 9),
     "vae_small_recurrent": (dict(embedding_dim=16, gconv_num_layers=3, gconv_mode="recurrent"), 16, 5, 8),
     "vae_small_nocat": (dict(embedding_dim=16, gconv_num_layers=2, decoder_cat=False), 16, 5, 8),
+    # use_attr=False (Sg2ScVAE_model.py:17,35-37,48-50,97-98), with z in front of / behind the decoder's gconv net
+    "vae_small_noattr": (dict(embedding_dim=16, gconv_num_layers=2, use_attr=False), 16, 5, 8),
+    "vae_small_nocat_noattr": (dict(embedding_dim=16, gconv_num_layers=2, decoder_cat=False, use_attr=False), 16, 5, 8),
+    # decoder_cat=False at a width whose segments are multiples of the GEMM's K tile (the aligned operand loader)
+    "vae_e32_nocat": (dict(embedding_dim=32, gconv_num_layers=1, decoder_cat=False), 8, 5, 8),
     "vae_small_ae": (dict(embedding_dim=16, gconv_num_layers=2, use_AE=True), 16, 5, 8),
     "vae_small_2d": (dict(embedding_dim=16, gconv_num_layers=2, train_3d=False), 16, 5, 8),
     # ragged: graphs of different sizes concatenated like suncg_collate_fn does
@@ -68,10 +73,12 @@ def _ragged_batch(cfg, seed):
     return tuple(torch.cat(x) for x in (objs, trip, boxes, angles, attrs, o2i))
 
 
-def gen_vae():
+def gen_vae(only=None):
     from oracle import vae_ref
     ref_graph, ref_vae, ref_utils = _import_reference()
     for name, (over, B, n, tt) in VAE_CASES.items():
+        if only and name not in only:
+            continue
         cfg = vae_ref.VaeConfig(**over)
         sd0 = vae_ref.init_state(cfg, seed=42)
         batch = _ragged_batch(cfg, 7) if B < 0 else vae_ref.synth_batch(B, n, tt, seed=0, cfg=cfg)
@@ -133,7 +140,7 @@ if __name__ == "__main__":
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(1)
     if what in ("vae", "all"):
-        gen_vae()
+        gen_vae(set(sys.argv[2].split(",")) if len(sys.argv) > 2 else None)        # optional: only these cases
     if what in ("spade", "all"):
         from oracle import gen_golden_spade
         gen_golden_spade.gen_spade()

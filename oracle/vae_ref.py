@@ -52,6 +52,7 @@ class VaeConfig:
     mlp_normalization: str = "batch"         # or "none"
     decoder_cat: bool = True
     use_AE: bool = False
+    use_attr: bool = True                    # the class default; build_model never passes it (Sg2ScVAE_model.py:17)
     train_3d: bool = True
     Nangle: int = 24
     num_objs: int = 32                       # len(vocab['object_idx_to_name'])
@@ -68,9 +69,9 @@ class VaeConfig:
     @property
     def angle_emb(self): return int(self.embedding_dim / 4)
     @property
-    def obj_emb(self): return int(self.embedding_dim * 3 / 4)
+    def obj_emb(self): return int(self.embedding_dim * 3 / 4) if self.use_attr else self.embedding_dim      # :24,35-37
     @property
-    def attr_emb(self): return int(self.embedding_dim / 4)
+    def attr_emb(self): return int(self.embedding_dim / 4) if self.use_attr else 0
     @property
     def box_dim(self): return 6 if self.train_3d else 4
     @property
@@ -89,11 +90,14 @@ class VaeConfig:
 
     def model_kwargs(self) -> dict:
         """kwargs for the reference ctor, as build_dataset_model.py:40-52 passes them."""
-        return dict(vocab=self.vocab(), batch_size=128, train_3d=self.train_3d,
-                    decoder_cat=self.decoder_cat, embedding_dim=self.embedding_dim,
-                    gconv_mode=self.gconv_mode, gconv_num_layers=self.gconv_num_layers,
-                    mlp_normalization=self.mlp_normalization, vec_noise_dim=0,
-                    layout_noise_dim=32, use_AE=self.use_AE)
+        kw = dict(vocab=self.vocab(), batch_size=128, train_3d=self.train_3d,
+                  decoder_cat=self.decoder_cat, embedding_dim=self.embedding_dim,
+                  gconv_mode=self.gconv_mode, gconv_num_layers=self.gconv_num_layers,
+                  mlp_normalization=self.mlp_normalization, vec_noise_dim=0,
+                  layout_noise_dim=32, use_AE=self.use_AE)
+        if not self.use_attr:
+            kw["use_attr"] = False
+        return kw
 
 
 # --------------------------------------------------------------------------
@@ -126,8 +130,9 @@ def state_layout(cfg: VaeConfig) -> List[Tuple[str, tuple, str]]:
     L.append(("pred_embeddings_ec.weight", (cfg.num_preds, 2 * E), "emb"))
     L.append(("obj_embeddings_dc.weight", (cfg.num_objs + 1, cfg.obj_emb), "emb"))
     L.append(("pred_embeddings_dc.weight", (cfg.num_preds, cfg.d_dc), "emb"))
-    L.append(("attr_embedding_ec.weight", (cfg.num_attrs, cfg.attr_emb), "emb"))
-    L.append(("attr_embedding_dc.weight", (cfg.num_attrs, cfg.attr_emb), "emb"))
+    if cfg.use_attr:                                                            # :48-50
+        L.append(("attr_embedding_ec.weight", (cfg.num_attrs, cfg.attr_emb), "emb"))
+        L.append(("attr_embedding_dc.weight", (cfg.num_attrs, cfg.attr_emb), "emb"))
     L.append(("box_embeddings.weight", (cfg.box_emb, cfg.box_dim), "w"))
     L.append(("box_embeddings.bias", (cfg.box_emb,), "b"))
     L.append(("angle_embeddings.weight", (cfg.Nangle, cfg.angle_emb), "emb"))
@@ -237,10 +242,11 @@ def encoder(sd: State, cfg: VaeConfig, objs, triples, boxes, angles, attrs, trai
     """models/Sg2ScVAE_model.py:115-143 -> (mu, logvar) each [O, embedding_dim]."""
     s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
     edges = torch.stack([s, o], dim=1)
-    x = torch.cat([sd["obj_embeddings_ec.weight"][objs],
-                   sd["attr_embedding_ec.weight"][attrs],
-                   F.linear(boxes, sd["box_embeddings.weight"], sd["box_embeddings.bias"]),
-                   sd["angle_embeddings.weight"][angles]], dim=1)
+    parts = [sd["obj_embeddings_ec.weight"][objs]]
+    if cfg.use_attr:
+        parts.append(sd["attr_embedding_ec.weight"][attrs])
+    x = torch.cat(parts + [F.linear(boxes, sd["box_embeddings.weight"], sd["box_embeddings.bias"]),
+                           sd["angle_embeddings.weight"][angles]], dim=1)
     pv = sd["pred_embeddings_ec.weight"][p]
     if cfg.gconv_num_layers > 0:
         x, pv = gconv_net_apply(sd, cfg, "ec", x, pv, edges, training)
@@ -258,8 +264,10 @@ def decoder(sd: State, cfg: VaeConfig, z, objs, triples, attrs, training: bool):
     """models/Sg2ScVAE_model.py:145-172 -> (boxes_pred [O,6], angles_pred [O,24] log-probs)."""
     s, p, o = triples[:, 0], triples[:, 1], triples[:, 2]
     edges = torch.stack([s, o], dim=1)
-    attr_v = sd["attr_embedding_dc.weight"][attrs]
-    x = torch.cat([sd["obj_embeddings_dc.weight"][objs], attr_v], dim=1)
+    x = sd["obj_embeddings_dc.weight"][objs]
+    if cfg.use_attr:
+        attr_v = sd["attr_embedding_dc.weight"][attrs]
+        x = torch.cat([x, attr_v], dim=1)
     pv = sd["pred_embeddings_dc.weight"][p]
     if cfg.decoder_cat:
         x = torch.cat([x, z], dim=1)
@@ -268,7 +276,7 @@ def decoder(sd: State, cfg: VaeConfig, z, objs, triples, attrs, training: bool):
         x, pv = gconv_net_apply(sd, cfg, "dc", x, pv, edges, training)
         x = torch.cat([x, z], dim=1)
     n = cfg.mlp_normalization
-    boxes_pred = mlp_apply(sd, "box_net", 2, torch.cat([x, attr_v], 1), n, training, norelu=True)
+    boxes_pred = mlp_apply(sd, "box_net", 2, torch.cat([x, attr_v], 1) if cfg.use_attr else x, n, training, norelu=True)
     angles_pred = F.log_softmax(mlp_apply(sd, "angle_net", 2, x, n, training, norelu=True), dim=1)
     return boxes_pred, angles_pred
 

@@ -30,7 +30,9 @@ class CpuStandInPlain:
         self.keys = vae_ref.trainable_keys(cfg)
         self.sizes = [self.sd[k].numel() for k in self.keys]
         self.flat_params = torch.cat([self.sd[k].reshape(-1) for k in self.keys]).clone()
-        self.flat_grads = torch.zeros_like(self.flat_params)
+        # [gradients | guard element]: the trainer all-reduces the bucket, adam_step looks at the (then averaged) guard
+        self.grad_bucket = torch.zeros(self.flat_params.numel() + 1)
+        self.flat_grads = self.grad_bucket[:-1]
         self.m = torch.zeros_like(self.flat_params); self.v = torch.zeros_like(self.flat_params); self.t = 0
         self._views()
 
@@ -58,11 +60,14 @@ class CpuStandInPlain:
         for k in self.keys:
             self.sd[k].requires_grad_(False)
         self.flat_grads.copy_(torch.cat([(g if g is not None else torch.zeros(n)).reshape(-1) for g, n in zip(grads, self.sizes)]))
+        self.grad_bucket[-1] = total.detach()
         if with_adam:
             self.adam_step(lr)
         return torch.stack([parts["bbox_pred"], parts["angle_pred"], parts.get("KLD_Gauss", torch.zeros(())), total]).detach()
 
     def adam_step(self, lr=1e-4):
+        if not torch.isfinite(self.grad_bucket[-1]):        # collective guard: the averaged total loss (train.py:79-81)
+            return
         self.t += 1
         g = self.flat_grads
         self.m.mul_(0.9).add_(g, alpha=0.1); self.v.mul_(0.999).addcmul_(g, g, value=0.001)
@@ -87,18 +92,55 @@ class CpuStandIn(CpuStandInPlain):
     def train_step_begin(self, objs, triples, boxes, angles, attributes, kl_weight=0.1, lr=1e-4, eps=None, use_graph=True):
         """everything is computed here, but only the decoder half of the gradients is handed out (as on the GPU, where
         the encoder half does not exist yet); a trainer that reduces the lower half too early averages zeros"""
-        keep = self.flat_grads
-        self.flat_grads = torch.zeros_like(keep)
         losses = self.train_step(objs, triples, boxes, angles, attributes, kl_weight=kl_weight, lr=lr, with_adam=False)
-        self._late, self.flat_grads = self.flat_grads, keep
+        self._late = self.flat_grads.clone()
         s = self.decoder_grad_offset
         self.flat_grads[:s] = 0.0
-        self.flat_grads[s:] = self._late[s:]
         return losses
 
     def train_step_finish(self, use_graph=True):
         s = self.decoder_grad_offset
         self.flat_grads[:s] = self._late[:s]
+
+
+def _worker_nan(rank, world, port, out_dir, two_halves):
+    """Two iterations; on the first one rank 1's batch produces a NaN loss.  Every rank must skip that update (same step
+    count, parameters untouched by NaN gradients), and the second iteration must leave identical finite replicas."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    model = (CpuStandIn if two_halves else CpuStandInPlain)(cfg, seed=5)
+    os.environ["SLN_DP_OVERLAP"] = "1" if two_halves else "0"
+    args = T.build_parser().parse_args(["--batch_size", "24", "--num_iterations", "2", "--print_every", "1000"])
+    full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
+    p_start = model.flat_params.clone()
+    seen = []
+
+    def batch_fn(t, lo, hi):
+        o0, o1, t0, t1 = lo * 5, hi * 5, lo * 8, hi * 8
+        tr = full[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+        boxes = full[2][o0:o1].clone()
+        if t == 1 and rank == 1:
+            boxes[0, 0] = float("nan")
+        if t == 2:
+            seen.append((model.t, bool((model.flat_params == p_start).all())))     # state after the guarded first iteration
+        return dict(objs=full[0][o0:o1], triples=tr, boxes=boxes, angles=full[3][o0:o1], attributes=full[4][o0:o1])
+    T.train(args, model, batch_fn, rank, world, log=lambda *_: None)
+    assert seen == [(0, True)], seen                  # iteration 1 skipped on THIS rank too (also on the rank whose loss was finite)
+    assert model.t == 1 and bool(torch.isfinite(model.flat_params).all())
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), model.flat_params.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("two_halves", [True, False])
+def test_rank_local_nan_skips_the_update_on_every_rank(tmp_path, two_halves):
+    port = _free_port()
+    mp.spawn(_worker_nan, args=(2, port, str(tmp_path), two_halves), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert (p0 == p1).all() and np.isfinite(p0).all()
 
 
 def _worker(rank, world, port, out_dir, two_halves):

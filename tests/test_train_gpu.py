@@ -1,0 +1,197 @@
+"""GPU tests of the training-loop plumbing around the fused iteration: the data-parallel step over RCCL (world of one on the
+1-GPU box: the collective path, the guard element, the two-half overlap), the on-device N(0,1) draw, the optimizer-state
+bookkeeping and the reference-shaped loop with an unmodified torch optimizer (run with -m gpu on an MI355X)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from conftest import pkg
+from parity import assert_close
+
+pytestmark = pytest.mark.gpu
+
+from oracle import vae_ref                                   # noqa: E402
+
+
+def _model(cfg, sd):
+    M = pkg("host.Sg2ScVAE_model")
+    m = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m.cuda()
+
+
+def _dev(*ts):
+    return [t.cuda() for t in ts]
+
+
+@pytest.fixture(scope="module")
+def rccl_world_of_one():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_data_parallel_step_over_rccl_equals_the_plain_step(rccl_world_of_one, overlap, use_graph):
+    """DataParallelStep(force=True): backward, all-reduce(AVG) of [gradients | guard] through RCCL, fused Adam - with a world of
+    one the result must be the plain fused step's (the collective is an identity), in both the one-bucket and the two-half
+    (decoder half reduced under the encoder's backward) forms, eager and replayed."""
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=7)
+    batches = [_dev(*vae_ref.synth_batch(8, 12, 20, seed=s, cfg=cfg)[:5]) for s in (3, 4, 5)]
+    eps = torch.randn(batches[0][0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0)).cuda()
+    res = []
+    for dp in (False, True):
+        model = _model(cfg, sd).train()
+        step = T.DataParallelStep(model, 1, overlap=overlap, force=dp)
+        assert step.dp == dp and step.overlap == (overlap and dp) and step.guarded
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for b in batches:
+                losses = step(dict(objs=b[0], triples=b[1], boxes=b[2], angles=b[3], attributes=b[4]), 0.1, 1e-3, use_graph=use_graph, eps=eps)
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), model.flat_params.cpu().numpy().copy(), model._sync_adam_steps(),
+                    float(model.grad_bucket[-1].cpu())))
+    assert res[0][2] == res[1][2] == 3
+    assert_close(res[1][0], res[0][0], "losses dp vs plain", rtol=1e-5)
+    assert_close(res[1][3], res[1][0][3], "guard element = the rank's total loss", rtol=1e-6)
+    d = np.abs(res[1][1] - res[0][1])
+    # +-lr noise on parameters whose true gradient is 0 (atomic order differs between runs): bounded; the bulk agrees
+    assert d.max() <= 2.05e-3 * 3 and np.mean(d > 1e-5) < 0.02, (d.max(), np.mean(d > 1e-5))
+
+
+def test_non_finite_loss_skips_the_update_and_the_step_count(rccl_world_of_one):
+    """train.py:79-81 ('not backpropping'): a NaN batch leaves parameters, moments and the step counter alone - on the fused
+    step and on the data-parallel one (guard element), and the optimizer state exported afterwards carries the device's count."""
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=1)
+    sd = vae_ref.init_state(cfg, seed=1)
+    good = _dev(*vae_ref.synth_batch(4, 6, 9, seed=2, cfg=cfg)[:5])
+    bad = [t.clone() for t in good]; bad[2][0, 0] = float("nan")
+    eps = torch.zeros(good[0].shape[0], cfg.embedding_dim, device="cuda")
+    for dp in (False, True):
+        model = _model(cfg, sd).train()
+        step = T.DataParallelStep(model, 1, force=dp)
+        mk = lambda b: dict(objs=b[0], triples=b[1], boxes=b[2], angles=b[3], attributes=b[4])
+        step(mk(good), 0.1, 1e-3, use_graph=False, eps=eps)
+        p1 = model.flat_params.clone()
+        l = step(mk(bad), 0.1, 1e-3, use_graph=False, eps=eps)
+        assert not np.isfinite(l.cpu().numpy()[3])
+        assert bool((model.flat_params == p1).all()), "a non-finite iteration moved the parameters"
+        step(mk(good), 0.1, 1e-3, use_graph=False, eps=eps)
+        assert bool(torch.isfinite(model.flat_params).all()) and not bool((model.flat_params == p1).all())
+        assert model._sync_adam_steps() == 2
+        assert float(model.optim_state_dict(1e-3)['state'][0]['step']) == 2.0
+
+
+def test_device_side_normal_draw():
+    """train_step / forward without eps draw N(0,1) on the device (Sg2ScVAE_model.py:182): moments and tail of the draw, a new
+    draw per iteration also under hipGraph replay, reproducible from the seed, and the iteration computed with the drawn eps is
+    the one an injected copy of that eps gives."""
+    cfg = vae_ref.VaeConfig(embedding_dim=64, gconv_num_layers=1)
+    sd = vae_ref.init_state(cfg, seed=3)
+    b = _dev(*vae_ref.synth_batch(64, 16, 24, seed=1, cfg=cfg)[:5])            # O = 1024 -> 65 536 normals per draw
+    draws = {}
+    for use_graph in (False, True):
+        model = _model(cfg, sd).train()
+        model.manual_seed(1234)
+        st = torch.cuda.Stream()
+        seq = []
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                model.train_step(*b, kl_weight=0.1, lr=1e-4, use_graph=use_graph)
+                seq.append(model.last_eps().cpu().numpy().copy())
+        torch.cuda.synchronize()
+        draws[use_graph] = seq
+    for k in range(3):
+        assert (draws[False][k] == draws[True][k]).all(), "graph replay and eager launches draw different streams"
+    e0, e1 = draws[True][0].ravel(), draws[True][1].ravel()
+    assert not (e0 == e1).any() or np.mean(e0 == e1) < 1e-4, "the replayed graph re-used its first draw"
+    allv = np.concatenate([d.ravel() for d in draws[True]]).astype(np.float64)
+    n = allv.size
+    assert abs(allv.mean()) < 5 / np.sqrt(n) and abs(allv.var() - 1) < 5 * np.sqrt(2.0 / n)
+    assert abs(np.mean(allv ** 3)) < 5 * np.sqrt(15.0 / n) and abs(np.mean(allv ** 4) - 3) < 5 * np.sqrt(96.0 / n)
+    assert abs(np.corrcoef(allv[:-1], allv[1:])[0, 1]) < 5 / np.sqrt(n)
+    from scipy import stats
+    assert stats.kstest(allv[:50000], "norm").pvalue > 1e-4
+    assert np.abs(allv).max() > 3.5 and np.isfinite(allv).all()
+    # the step computed from the drawn eps == the step with that eps injected
+    a = _model(cfg, sd).train(); a.manual_seed(99)
+    la = a.train_step(*b, kl_weight=0.1, lr=1e-4, use_graph=False).cpu().numpy()
+    eps = a.last_eps()
+    c = _model(cfg, sd).train()
+    lc = c.train_step(*b, kl_weight=0.1, lr=1e-4, eps=eps, use_graph=False).cpu().numpy()
+    assert_close(la, lc, "losses drawn vs injected", rtol=1e-6)
+    # autograd path: forward() without eps keeps the drawn eps for backward
+    d = _model(cfg, sd).train(); d.manual_seed(99)
+    mu, lv, bp, ap = d(*b, None)
+    (bp.sum() + ap.sum() + mu.sum()).backward()
+    e = _model(cfg, sd).train()
+    mu2, lv2, bp2, ap2 = e(*b, None, eps=eps)
+    (bp2.sum() + ap2.sum() + mu2.sum()).backward()
+    assert_close(bp.detach().cpu().numpy(), bp2.detach().cpu().numpy(), "boxes drawn vs injected", rtol=1e-6)
+    gs = float(e.flat_grads.abs().max())
+    assert_close(d.flat_grads.cpu().numpy(), e.flat_grads.cpu().numpy(), "grads drawn vs injected", rtol=1e-5, atol=1e-6 * gs)
+
+
+def test_reference_loop_with_an_unmodified_torch_optimizer():
+    """train.py:70-84 as written: model(...) -> calculate_model_losses -> zero_grad -> backward -> torch.optim.Adam.step(), with
+    NO call into the engine between the steps: the dgrad GEMMs must not run on the previous step's transposed weights
+    (two steps against the oracle doing the same with CPU autograd; a stale W^T shows up in the second step's gradients)."""
+    import types
+    U = pkg("host.utils")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    sd = vae_ref.init_state(cfg, seed=11)
+    batch = vae_ref.synth_batch(6, 9, 14, seed=2, cfg=cfg)
+    eps = torch.randn(batch[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(5))
+    model = _model(cfg, sd).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)           # a big step: stale weights would be far off
+    dev = _dev(*batch[:5], eps)
+    ref = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    keys = vae_ref.trainable_keys(cfg)
+    ropt = torch.optim.Adam([ref[k] for k in keys], lr=1e-2)
+    for it in range(2):
+        out = model(*dev[:5], None, eps=dev[5])
+        total, _ = U.calculate_model_losses(types.SimpleNamespace(use_AE=False), model, dev[2], out[2], dev[3], out[3], mu=out[0],
+                                            logvar=out[1], KL_weight=0.1)
+        opt.zero_grad(); total.backward()
+        mu, lv, bp, ap = vae_ref.forward(ref, cfg, *batch[:5], eps, True)
+        rt, _ = vae_ref.losses(cfg, batch[2], bp, batch[3], ap, mu, lv, 0.1)
+        ropt.zero_grad(); rt.backward()
+        assert_close(total.item(), rt.item(), "loss step %d" % it, rtol=2e-4)
+        named = dict(model.named_parameters())
+        gscale = max(float(ref[k].grad.abs().max()) for k in keys if ref[k].grad is not None)
+        for k in keys:
+            if ref[k].grad is not None:
+                assert_close(named[k].grad.cpu().numpy(), ref[k].grad.numpy(), "step %d grad %s" % (it, k), rtol=2e-3, atol=2e-4 * gscale)
+        opt.step(); ropt.step()
+
+
+def test_optimizer_state_survives_a_device_or_dtype_re_flatten():
+    """model.float() / .cuda() re-flatten the parameters: the Adam moments and the step count move along (they used to be
+    dropped silently: load_optim_state_dict followed by .cuda() lost the state)."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=1)
+    sd = vae_ref.init_state(cfg, seed=1)
+    b = _dev(*vae_ref.synth_batch(4, 6, 9, seed=2, cfg=cfg)[:5])
+    eps = torch.zeros(b[0].shape[0], cfg.embedding_dim, device="cuda")
+    a = _model(cfg, sd).train()
+    for _ in range(2):
+        a.train_step(*b, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    m_before = a._adam_m.clone()
+    a = a.float().cuda()
+    assert a._sync_adam_steps() == 2 and bool((a._adam_m == m_before).all())
+    a.train_step(*b, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    c = _model(cfg, sd).train()
+    for _ in range(3):
+        c.train_step(*b, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=False)
+    d = np.abs(a.flat_params.cpu().numpy() - c.flat_params.cpu().numpy())
+    assert d.max() <= 2.05e-3 * 3 and np.mean(d > 1e-5) < 0.02, (d.max(), np.mean(d > 1e-5))
+    assert a._sync_adam_steps() == 3

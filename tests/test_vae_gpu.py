@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 from oracle import vae_ref                                   # noqa: E402
 from oracle.gen_golden import KL_WEIGHT, VAE_CASES           # noqa: E402
 
-HIP_CASES = [n for n, (over, *_rest) in VAE_CASES.items() if over.get("decoder_cat", True)]
+HIP_CASES = list(VAE_CASES)          # every reference-generated fixture, decoder_cat / use_attr off included
 
 
 def _lib():
@@ -150,33 +150,54 @@ def test_golden_eval_and_train(name):
     import types
     total, parts = U.calculate_model_losses(types.SimpleNamespace(use_AE=cfg.use_AE), model, boxes, bp, angles, ap,
                                             mu=mu, logvar=lv, KL_weight=KL_WEIGHT)
-    if not ill:
+    # losses of the fp64 oracle (BASELINE config c1 - BatchNorm over 8 rows - is held to them within the reference's own fp32
+    # distance, like its forward outputs; the well-conditioned fixtures to the reference's numbers directly)
+    t64, p64 = vae_ref.losses(cfg, b64[2], r64[2], b64[3], r64[3], r64[0], r64[1], KL_WEIGHT)
+    if ill:
+        assert_close_conditioned(total.item(), float(t64), g["total_loss"], name + ":total")
+        for k, v in parts.items():
+            assert_close_conditioned(v, float(p64[k]), g["loss_" + k], name + ":loss_" + k)
+    else:
         assert_close(total.item(), g["total_loss"], name + ":total")
         for k, v in parts.items():
             assert_close(v, g["loss_" + k], name + ":loss_" + k)
     model.zero_grad()
     total.backward()
     torch.cuda.synchronize()
-    if not ill:
-        gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad:"))
-        g64 = _fp64_grads(cfg, sd64, b64, ins["eps"].double())
-        bad = []
-        for k in g.files:
-            if k.startswith("grad:"):
-                p = dict(model.named_parameters())[k[5:]]
-                try:
-                    # the reference's own fp32 gradient can be 1e-2 off in a fixture with a near-constant BatchNorm
-                    # column (vae_small_2d): hold HIP to the fp64 result within the reference's own distance from it
-                    assert_close_conditioned(p.grad.cpu().numpy(), g64[k[5:]], g[k], name + ":" + k, atol=5e-6 * gscale, k=4.0)
-                except AssertionError as e:
-                    bad.append(str(e))
-        assert not bad, "\n".join(bad[:40]) + "\n" + report
-        for k in g.files:
-            if k.startswith("buf:"):
+    # gradients of EVERY parameter against the fp64 oracle, with the reference's own fp32 distance from it as slack (the
+    # reference's fp32 gradient can be 1e-2 off in a fixture with a near-constant BatchNorm column, vae_small_2d).  The
+    # full-width fixture stores the reference's gradients only for tensors <= 4096 elements (+ checksums of all of them):
+    # for the others the fp32 oracle - proven equal to the reference on every fixture by tests/test_oracle_vae.py - stands in.
+    g64 = _fp64_grads(cfg, sd64, b64, ins["eps"].double())
+    g32 = _fp64_grads(cfg, {k: v.clone() for k, v in sd0.items()}, batch_cpu, ins["eps"])
+    gscale = max(float(np.abs(v).max()) for v in g64.values())
+    named = dict(model.named_parameters())
+    bad = []
+    for k, r64g in g64.items():
+        ref32 = g["grad:" + k] if ("grad:" + k) in g.files else g32[k]
+        try:
+            assert_close_conditioned(named[k].grad.cpu().numpy(), r64g, ref32, name + ":grad:" + k, atol=5e-6 * gscale, k=4.0)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad[:40]) + "\n" + report
+    for k in g.files:
+        if k.startswith("gsum:"):                      # the reference's own checksums of every gradient tensor (full-width fixture)
+            gg = named[k[5:]].grad.double().cpu()
+            got = np.array([float(gg.sum()), float(gg.abs().sum()), float((gg * gg).sum())])
+            r64g = torch.from_numpy(g64[k[5:]])
+            ref64 = np.array([float(r64g.sum()), float(r64g.abs().sum()), float((r64g * r64g).sum())])
+            # sum |g| and sum g^2 are well-conditioned summaries; the plain sum cancels and is bounded on the |g| scale
+            assert_close_conditioned(got[1:], ref64[1:], g[k][1:], name + ":" + k, rtol=1e-3, k=4.0)
+            assert abs(got[0] - ref64[0]) <= 1e-3 * ref64[1] + 4.0 * abs(g[k][0] - ref64[0]), name + ":" + k + " (sum)"
+    for k in g.files:
+        if k.startswith("buf:"):
+            if ill:
+                assert_close_conditioned(model.state_dict()[k[4:]].double().cpu().numpy(), sd64t[k[4:]].numpy(), g[k], name + ":" + k)
+            else:
                 assert_close(model.state_dict()[k[4:]].cpu().numpy(), g[k], name + ":" + k)
 
 
-@pytest.mark.parametrize("name", [n for n in HIP_CASES if n != "vae_c1_full"])
+@pytest.mark.parametrize("name", HIP_CASES)
 def test_golden_fused_train_step(name):
     """sln_vae_train_step (zero_grad + fwd + loss + bwd + Adam in one call) against the reference's
     losses, BatchNorm buffers and Adam-updated parameters."""
@@ -189,19 +210,31 @@ def test_golden_fused_train_step(name):
     for use_graph in (False,):
         losses = model.train_step(objs, triples, boxes, angles, attrs, kl_weight=KL_WEIGHT, lr=1e-4, eps=eps,
                                   use_graph=use_graph).cpu().numpy()
-    assert_close(losses[3], g["total_loss"], name + ":total")
-    assert_close(losses[0], g["loss_bbox_pred"], name + ":bbox")
-    assert_close(losses[1], g["loss_angle_pred"], name + ":angle")
-    if not cfg.use_AE:
-        assert_close(losses[2], g["loss_KLD_Gauss"], name + ":kld")
+    ill = name == "vae_c1_full"       # BatchNorm over 8 rows: conditioned comparison against the fp64 oracle (tests/parity.py)
     sd = model.state_dict()
     gscale = max(float(np.abs(g[k]).max()) for k in g.files if k.startswith("grad:"))
     sd0 = vae_ref.init_state(cfg, seed=42)
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
-    g64 = _fp64_grads(cfg, sd64, (ins["objs"], ins["triples"], ins["boxes"].double(), ins["angles"], ins["attrs"]), ins["eps"].double())
+    b64 = (ins["objs"], ins["triples"], ins["boxes"].double(), ins["angles"], ins["attrs"])
+    g64 = _fp64_grads(cfg, sd64, b64, ins["eps"].double())
+    sd64t = {k: v.clone() for k, v in sd64.items()}
+    r64 = vae_ref.forward(sd64t, cfg, *b64, ins["eps"].double(), training=True)       # also leaves the fp64 BatchNorm buffers in sd64t
+    t64, p64 = vae_ref.losses(cfg, b64[2], r64[2], b64[3], r64[3], r64[0], r64[1], KL_WEIGHT)
+    refs = [("total", losses[3], float(t64), g["total_loss"]), ("bbox", losses[0], float(p64["bbox_pred"]), g["loss_bbox_pred"]),
+            ("angle", losses[1], float(p64["angle_pred"]), g["loss_angle_pred"])]
+    if not cfg.use_AE:
+        refs.append(("kld", losses[2], float(p64["KLD_Gauss"]), g["loss_KLD_Gauss"]))
+    for nm, got, r6, r32 in refs:
+        if ill:
+            assert_close_conditioned(got, r6, r32, name + ":" + nm)
+        else:
+            assert_close(got, r32, name + ":" + nm)
     for k in g.files:
         if k.startswith("buf:"):
-            assert_close(sd[k[4:]].cpu().numpy(), g[k], name + ":" + k)
+            if ill:
+                assert_close_conditioned(sd[k[4:]].double().cpu().numpy(), sd64t[k[4:]].numpy(), g[k], name + ":" + k)
+            else:
+                assert_close(sd[k[4:]].cpu().numpy(), g[k], name + ":" + k)
         elif k.startswith("adam:") and ("grad:" + k[5:]) in g.files:
             gnoise = float(np.abs(g["grad:" + k[5:]] - g64[k[5:]]).max())
             assert_adam_close(sd[k[5:]].cpu().numpy(), g[k], g["grad:" + k[5:]], name + ":" + k, gscale=gscale, gnoise=gnoise)
