@@ -85,7 +85,8 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
   float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
-  float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2]
+  float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2] floats (EPI_MASK) or doubles (EPI_STATS)
+  double* redd = reinterpret_cast<double*>(ecoef + BN);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (a.N + BN - 1) / BN;
@@ -263,6 +264,10 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
     if (EPI == EPI_MASK) ec = ecoef[cl];
     float s1 = 0.f, s2 = 0.f;
+    // forward BatchNorm statistics in fp64 (y * y is exact there): var = E[y^2] - mean^2 cancels, and with fp32 partial sums a
+    // column whose rows nearly agree (mean >> sigma: 8-row batches, BASELINE config c1) lost 1e-7 (mean / sigma)^2 of its
+    // variance - torch's two-pass batch_norm does not.  Two fp64 ops per output element next to 2K MFMA flops.
+    double d1 = 0.0, d2 = 0.0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -271,7 +276,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
         if (cvalid && row < a.M) {
           float y = acc[i][j][r] + bias;
           if (a.addend) y += a.addend[(size_t)row * a.ldadd + a.addcol0 + col];
-          if (EPI == EPI_STATS) { s1 += y; s2 = fmaf(y, y, s2); }
+          if (EPI == EPI_STATS) { d1 += (double)y; d2 = fma((double)y, (double)y, d2); }
           if (EPI == EPI_MASK) {
             const float xp = a.xprev[(size_t)row * a.ldx + a.xcol0 + col];
             y = fmaf(ec.x, xp, ec.y) > 0.f ? y : 0.f;
@@ -281,7 +286,10 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
         }
       }
     }
-    if (EPI != EPI_PLAIN) {
+    if (EPI == EPI_STATS) {
+      d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+      if (lk == 0) { redd[((wave / WN) * BN + cl) * 2 + 0] = d1; redd[((wave / WN) * BN + cl) * 2 + 1] = d2; }
+    } else if (EPI != EPI_PLAIN) {
       s1 = wave_sum_halves(s1); s2 = wave_sum_halves(s2);
       if (lk == 0) { red[((wave / WN) * BN + cl) * 2 + 0] = s1; red[((wave / WN) * BN + cl) * 2 + 1] = s2; }
     }
@@ -292,11 +300,14 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     if (out != nullptr) {
       for (int c = tid; c < BN; c += NT) {
         if (n0 + c < a.N) {
-          float s1 = 0.f, s2 = 0.f;
+          double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-          for (int w = 0; w < WM; ++w) { s1 += red[(w * BN + c) * 2]; s2 += red[(w * BN + c) * 2 + 1]; }
-          atomicAdd(out + n0 + c, (double)s1);
-          atomicAdd(out + a.ocstride + n0 + c, (double)s2);
+          for (int w = 0; w < WM; ++w) {
+            if (EPI == EPI_STATS) { s1 += redd[(w * BN + c) * 2]; s2 += redd[(w * BN + c) * 2 + 1]; }
+            else { s1 += (double)red[(w * BN + c) * 2]; s2 += (double)red[(w * BN + c) * 2 + 1]; }
+          }
+          atomicAdd(out + n0 + c, s1);
+          atomicAdd(out + a.ocstride + n0 + c, s2);
         }
       }
     }
@@ -531,7 +542,7 @@ inline bool tn_supported(const GemmTNArgs& a) {     // the gradient operand is a
 
 inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
+  return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 16;
 }
 
 inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + TN_PAD + BN + TN_PAD) * 4; }

@@ -27,7 +27,7 @@ namespace {
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int kpad = (a.K + 31) & ~31;
-  const size_t smem = (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 8;
+  const size_t smem = nt_smem_bytes(a.K, BM, BN, WM);
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }

@@ -25,14 +25,16 @@ struct BnView {
   const float* rvar;
   int cstride;           // distance between the two rows of sums / gsums
   int mode;
-  float inv_n;           // 1 / rows
+  float n_rows;          // rows the sums run over (exact in fp32 below 2^24); the reciprocal is taken in fp64: 1.0f / 12 is 6e-8
+                         // off, and var = E[x^2] - mean^2 amplifies that by (mean / sigma)^2
   float eps;
 };
 
 __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean, float& istd) {
   if (b.mode == SLN_BN_TRAIN) {
-    double m = b.sums[c] * (double)b.inv_n;
-    double v = b.sums[b.cstride + c] * (double)b.inv_n - m * m;
+    const double rn = 1.0 / (double)b.n_rows;
+    double m = b.sums[c] * rn;
+    double v = b.sums[b.cstride + c] * rn - m * m;
     v = v < 0.0 ? 0.0 : v;
     mean = (float)m;
     istd = (float)(1.0 / sqrt(v + (double)b.eps));
@@ -61,8 +63,9 @@ __device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, f
   float scale = b.gamma[c] * istd;
   p0 = scale;
   if (b.mode == SLN_BN_TRAIN) {
-    float c1 = (float)(b.gsums[c] * (double)b.inv_n);
-    float c2 = (float)(b.gsums[b.cstride + c] * (double)b.inv_n);
+    const double rn = 1.0 / (double)b.n_rows;
+    float c1 = (float)(b.gsums[c] * rn);
+    float c2 = (float)(b.gsums[b.cstride + c] * rn);
     p1 = -scale * istd * c2;
     p2 = -scale * c1 - p1 * mean;
   } else {

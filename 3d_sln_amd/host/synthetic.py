@@ -125,3 +125,29 @@ def scene_rooms(n_rooms, objs_per_room=31, seed=0, n_classes=31):
     size_data_30 = {nm: dict(height_7=float(rng.uniform(0.25, 0.5)), height_3=float(rng.uniform(0.0, 0.25)),
                              volume_7=float(rng.uniform(0.01, 0.03)), volume_3=float(rng.uniform(0.0005, 0.01))) for nm in names[1::2]}
     return rooms, names, size_data, size_data_30
+
+
+def pack_rooms(rooms, device="cuda"):
+    """Pad a list of ``synthetic_room`` tuples (different V / F) into one render batch for ``diff_render.scene_render_batch``:
+    near-plane cull + class lookup per room (diff_render.py:346-356,372-376), fill_back duplicates, faces padded with
+    degenerate triangles of class -1.  -> dict(V [B,Vmax,3], F [B,Fmax,3] i32, C [B,Fmax] i32, chan, dch, K, R, t, tris)."""
+    import importlib
+    import torch
+    DR = importlib.import_module("3d_sln_amd.host.diff_render")
+    Vmax = max(r[0].shape[0] for r in rooms)
+    prepared, Fmax, tris = [], 0, 0
+    for V, F, ranges, box in rooms:
+        K, R, t = DR.get_cam_mat(torch.from_numpy(box), "cpu")
+        faces, cls, classes, chan, dch = DR.cull_and_classify(torch.from_numpy(V)[None], torch.from_numpy(F)[None], ranges, R, t)
+        tris += faces.shape[1]
+        faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), 1)[0]; cls = torch.cat((cls, cls))
+        vp = torch.zeros(Vmax, 3); vp[:V.shape[0]] = torch.from_numpy(V)
+        prepared.append((vp, faces, cls, K[0], R[0], t[0])); Fmax = max(Fmax, faces.shape[0])
+    B = len(rooms)
+    Fb = torch.zeros(B, Fmax, 3, dtype=torch.int32); Cb = torch.full((B, Fmax), -1, dtype=torch.int32)
+    for i, p in enumerate(prepared):
+        Fb[i, :p[1].shape[0]] = p[1]; Cb[i, :p[2].shape[0]] = p[2]
+    return dict(V=torch.stack([p[0] for p in prepared]).to(device), F=Fb.to(device), C=Cb.to(device),
+                chan=torch.tensor(chan, dtype=torch.int32, device=device), dch=torch.tensor(dch, dtype=torch.int32, device=device),
+                K=torch.stack([p[3] for p in prepared]).to(device), R=torch.stack([p[4] for p in prepared]).to(device),
+                t=torch.stack([p[5] for p in prepared]).to(device), tris=tris)

@@ -1,21 +1,24 @@
 #!/usr/bin/env python
 """bench.py - headline benchmark of the 3D_SLN hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: re-launches itself, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]; per GPU, weak scaling = configs[4] at N=8):
-  one "step" = one full training iteration of the scene-graph VAE (train.py:62-84: zero_grad,
-  forward with train-mode BatchNorm, the three losses, backward, Adam) on a synthetic batch of
-  64 scene graphs x (32 objects, 64 triples) => O=2048 object rows, T=4096 triples, at train.py's
-  default widths (embedding_dim=64: GraphTripleConv 128/256/128, 5+5 layers).  Inputs are resident
-  in HBM before the timed region.  For N>1 every rank trains its own 64 graphs and the flat
-  15.5 MB fp32 gradient buffer is all-reduced (RCCL) between backward and Adam.
+  one "step" = one full training iteration of the scene-graph VAE (train.py:62-84: zero_grad, forward with train-mode
+  BatchNorm incl. the N(0,1) draw of the reparameterisation, the three losses, backward, Adam) on a synthetic batch of 64 scene
+  graphs x (32 objects, 64 triples) => O=2048 object rows, T=4096 triples, at train.py's default widths (embedding_dim=64:
+  GraphTripleConv 128/256/128, 5+5 layers).  Inputs are resident in HBM before the timed region.  For N>1 every rank trains its
+  own 64 graphs and the flat 15.5 MB fp32 gradient buffer (+ the guard element) is all-reduced (RCCL) between backward and Adam.
 
-Prints ONE JSON line (rank 0).  `value` = graphs/s over all GPUs.  `roofline` describes the
-dominant kernel family (fused fp32-MFMA GEMMs), timed live with HIP events on the launch stream in
-a separate eager pass of the same step; `cpu_baseline` is the CPU oracle (a PyTorch-CPU port proven
-equal to the reference on the golden fixtures) timed on this box's host cores on the same batch.
+Prints ONE JSON line (rank 0).  `value` = graphs/s over all GPUs.  `roofline` describes the dominant kernel family of that step,
+timed live with HIP events on the launch stream in a separate eager pass; `cpu_baseline` is the CPU oracle (a PyTorch-CPU port
+proven equal to the reference on the golden fixtures) timed on this box's host cores on the same batch.  At N=1 the line also
+carries the other BASELINE configs as sub-objects, each with its own `roofline` and `cpu_baseline`: `c1` (configs[0]),
+`render` (configs[2]), `spade` (configs[3]), plus `vae_large_batch`, `graph_build`, `refine`.
+
+Every leg first checks the HIP path against the oracle on the leg's own inputs (`parity` keys); a failed check aborts the run
+before anything is printed.  The oracle is only ever the checker and the timed CPU baseline, never part of a GPU number.
 """
 import argparse
 import ctypes as C
@@ -29,8 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+VALU_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak (2 flop x 64 lanes x 4 SIMD x 256 CU x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "gemm_dual"]
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")      # rocprofv3 summary of this very command (profiles/README.md)
 
 
 def parse():
@@ -43,22 +48,42 @@ def parse():
     ap.add_argument("--triples", type=int, default=64)
     ap.add_argument("--batch-ring", type=int, default=4, help="distinct pre-generated batches cycled through by the timed loop (1 = one reused batch)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--inject-eps", action="store_true", help="feed one constant eps instead of drawing N(0,1) inside the step")
+    ap.add_argument("--no-cpu", action="store_true", help="skip every CPU baseline leg")
+    ap.add_argument("--no-check", action="store_true", help="skip the in-run parity checks against the oracle")
     ap.add_argument("--cpu-steps", type=int, default=20)
     ap.add_argument("--prof-steps", type=int, default=5)
     ap.add_argument("--rooms", type=int, default=16, help="rooms per render batch (BASELINE configs[2])")
     ap.add_argument("--tris", type=int, default=2000)
-    ap.add_argument("--render-iters", type=int, default=50)
+    ap.add_argument("--render-iters", type=int, default=100)
+    ap.add_argument("--render-warmup", type=int, default=20)
     ap.add_argument("--no-render", action="store_true")
     ap.add_argument("--spade-batch", type=int, default=32, help="images per SPADE call (BASELINE configs[3])")
-    ap.add_argument("--spade-iters", type=int, default=3)
+    ap.add_argument("--spade-iters", type=int, default=20)
+    ap.add_argument("--spade-warmup", type=int, default=5)
     ap.add_argument("--no-spade", action="store_true")
     ap.add_argument("--graph-batch", type=int, default=512, help="rooms per scene-graph builder call")
-    ap.add_argument("--graph-iters", type=int, default=50)
+    ap.add_argument("--graph-iters", type=int, default=100)
     ap.add_argument("--no-graph-build", action="store_true")
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
+    ap.add_argument("--large-batches", type=str, default="256,1024,4096", help="extra VAE points (graphs per step), '' = none")
     return ap.parse_args()
+
+
+class ParityError(SystemExit):
+    pass
+
+
+def rel_err(got, ref):
+    import numpy as np
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    return float(np.abs(got - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def require(ok, what):
+    if not ok:
+        raise ParityError("bench.py: parity check failed, nothing reported: " + what)
 
 
 def prof_read(lib):
@@ -68,6 +93,198 @@ def prof_read(lib):
     return {FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n) if cnt[i]}
 
 
+def profile_rows(prefixes):
+    """Rows of the committed rocprofv3 summary (kernel-trace stats joined with the PMC traffic passes) whose kernel name starts
+    with one of `prefixes`: -> (launch-weighted HBM bytes per launch or None, launch-weighted avg us or None)."""
+    try:
+        import csv
+        tot_b, tot_us, n_b, n_us = 0.0, 0.0, 0, 0
+        for r in csv.DictReader(open(PROFILE_CSV)):
+            if not r["kernel"].startswith(tuple(prefixes)):
+                continue
+            calls = int(r["calls"])
+            tot_us += float(r["avg_us"]) * calls; n_us += calls
+            if r.get("hbm_MB_per_launch_corrected"):
+                tot_b += float(r["hbm_MB_per_launch_corrected"]) * 1e6 * calls; n_b += calls
+        return (round(tot_b / n_b) if n_b else None), (round(tot_us / n_us, 2) if n_us else None)
+    except Exception:
+        return None, None
+
+
+def cpu_threads(torch=None):
+    """Host cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota (a container that
+    sees 256 CPUs but owns 16 of them makes a 256-thread OpenMP team spin against itself)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries the one JSON line)"""
+    sys.stderr.write("[bench %7.1fs] %s\n" % (time.perf_counter() - _T0, msg))
+    sys.stderr.flush()
+
+
+# ------------------------------------------------------------------------------------------------------------- checks
+def check_vae(lib, torch, M, model, batch):
+    """Smoke-style check of the fused step on a small configuration (1e-4 on the loss and on a gradient tensor) and a gross-error
+    guard on the bench's own model and batch (forward + loss of the 64-graph batch against the oracle)."""
+    import numpy as np
+    from oracle import vae_ref
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=3)
+    b = vae_ref.synth_batch(16, 8, 12, seed=5, cfg=cfg)
+    eps = torch.from_numpy(np.random.default_rng(2).standard_normal((b[0].shape[0], cfg.embedding_dim)).astype(np.float32))
+    small = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    small.load_state_dict({k: v.clone() for k, v in sd.items()})
+    small = small.cuda().train()
+    losses = small.train_step(*[t.cuda() for t in b[:5]], kl_weight=0.1, lr=1e-4, eps=eps.cuda(), use_graph=False, with_adam=False)
+    keys = vae_ref.trainable_keys(cfg)
+    m = {k: torch.zeros_like(sd[k]) for k in keys}; v = {k: torch.zeros_like(sd[k]) for k in keys}
+    total, _, grads = vae_ref.train_step({k: t.clone() for k, t in sd.items()}, cfg, b[:5], eps, 0.1, m, v, step=1)
+    e_loss = rel_err(losses[3].cpu().numpy(), float(total))
+    k = "gconv_net_dc.gconvs.0.net1.0.weight"
+    e_grad = rel_err(dict(small.named_parameters())[k].grad.cpu().numpy(), grads[k].numpy())
+    require(e_loss <= 1e-4 and e_grad <= 1e-4, "VAE small step: loss %.2e, grad %.2e" % (e_loss, e_grad))
+    # the bench model on the bench batch: same parameters through the oracle (state_dict keys are the reference's)
+    sdb = {k: t.detach().cpu().clone() for k, t in model.state_dict().items()}
+    cfgb = vae_ref.VaeConfig()
+    cb = [t.cpu() for t in batch]
+    epsb = torch.randn(cb[0].shape[0], cfgb.embedding_dim, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        model.train()
+        mu, lv, bp, ap = model(*batch, None, eps=epsb.cuda())
+        lg = model.loss(kl_weight=0.1).cpu().numpy()
+        rmu, rlv, rbp, rap = vae_ref.forward({k: t.clone() for k, t in sdb.items()}, cfgb, *cb, epsb, True)
+        rt, _ = vae_ref.losses(cfgb, cb[2], rbp, cb[3], rap, rmu, rlv, 0.1)
+    model.load_state_dict(sdb)                       # the forward above moved the BatchNorm running statistics: restore
+    e_full = rel_err(lg[3], float(rt))
+    require(e_full <= 1e-3, "VAE bench batch: total loss %.6f vs oracle %.6f" % (lg[3], float(rt)))
+    return {"small_step_loss_rel_err": e_loss, "small_step_grad_rel_err": e_grad, "bench_batch_loss_rel_err": e_full}
+
+
+def check_render(torch, pk, rooms_idx):
+    """face-index / weight / depth maps of some rooms of the bench batch: bit-identical to the CPU restatement on identical faces"""
+    from oracle import raster_ref as rr
+    NR = importlib.import_module("3d_sln_amd.host.neural_renderer")
+    with torch.no_grad():
+        fxyz = NR.project_faces(pk["V"], pk["F"], pk["K"], pk["R"], pk["t"], 512)[rooms_idx].contiguous()
+        fi, w, d = NR._rasterize(fxyz, 256, 0.001, 100.0)
+    rfi, rw, rd = rr.nmr_forward(fxyz.cpu().numpy(), 256, 0.001, 100.0)
+    diff = int((fi.cpu().numpy() != rfi).sum())
+    same = bool((w.cpu().numpy() == rw).all() and (d.cpu().numpy() == rd).all())
+    require(diff == 0 and same, "render: face index map differs at %d pixels, weights/depth identical: %s" % (diff, same))
+    return {"rooms_checked": list(rooms_idx), "face_index_pixels_differing": diff, "weights_depth_bit_identical": same}
+
+
+def check_spade(torch, S):
+    """the reduced generator (ngf 8, 64 x 64) against the oracle: 1e-4 on the image"""
+    from oracle import spade_ref
+    cfg = spade_ref.SpadeConfig(nz=16, ngf=8, crop_size=64)
+    sd = spade_ref.init_state(cfg, seed=7)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, z = spade_ref.synth_input(cfg, 2, seed=3)
+    with torch.no_grad():
+        out = G(seg.cuda(), z.cuda()).cpu().numpy()
+        ref = spade_ref.generator(sd, cfg, seg, z).numpy()
+    e = rel_err(out, ref)
+    require(e <= 1e-4, "SPADE small generator: image rel err %.2e" % e)
+    return {"small_generator_image_rel_err": e}
+
+
+# --------------------------------------------------------------------------------------------------------------- legs
+def c1_leg(args, torch, M):
+    """BASELINE configs[0]: Sg2ScVAE forward + loss on ONE synthetic 8-object / 12-triple scene graph, CPU, 1 iteration after 3
+    warm-ups, all cores.  The same graph through the HIP path is timed next to it."""
+    from oracle import vae_ref
+    cfg = vae_ref.VaeConfig()
+    sd = vae_ref.init_state(cfg, seed=42)
+    b = vae_ref.synth_batch(1, 8, 12, seed=0, cfg=cfg)
+    eps = torch.randn(8, cfg.embedding_dim, generator=torch.Generator().manual_seed(0))
+    n = cpu_threads(torch)
+    torch.set_num_threads(n)
+
+    def cpu_iter():
+        with torch.no_grad():
+            mu, lv, bp, ap = vae_ref.forward({k: v.clone() for k, v in sd.items()}, cfg, *b[:5], eps, True)
+            return vae_ref.losses(cfg, b[2], bp, b[3], ap, mu, lv, 0.1)[0]
+    for _ in range(3):
+        cpu_iter()
+    t0 = time.perf_counter(); tot = cpu_iter(); cdt = time.perf_counter() - t0
+    res = {"workload": "BASELINE configs[0]: 1 graph, 8 objects / 12 triples, forward + loss, train-mode BatchNorm, train.py defaults",
+           "cpu_ms_per_iter": round(cdt * 1e3, 3), "cpu_graphs_per_s": round(1.0 / cdt, 2), "cores": n, "kind": "port",
+           "sample": "1 iteration after 3 warm-ups (SURVEY.md 8d protocol), oracle/vae_ref.py, torch CPU fp32", "cpu_total_loss": round(float(tot), 6)}
+    model = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    model.load_state_dict({k: v.clone() for k, v in sd.items()})
+    model = model.cuda().train()
+    dev = [t.cuda() for t in b[:5]]; epsd = eps.cuda()
+    sd_dev = {k: v.clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        model(*dev, None, eps=epsd); l0 = model.loss(kl_weight=0.1)      # first call: same BatchNorm buffers as the CPU iteration
+        res["hip_total_loss"] = round(float(l0[3].item()), 6)
+        for _ in range(3):
+            model(*dev, None, eps=epsd); l = model.loss(kl_weight=0.1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            model(*dev, None, eps=epsd); l = model.loss(kl_weight=0.1)
+        torch.cuda.synchronize()
+        gdt = (time.perf_counter() - t0) / 20
+    del sd_dev
+    res["hip_ms_per_iter"] = round(gdt * 1e3, 3)
+    res["note"] = "8-row train-mode BatchNorm: any two fp32 evaluations differ by ~1e-3 (tests/parity.py); latency-bound on the GPU (one graph)"
+    return res
+
+
+def large_batch_leg(args, torch, M, syn, sizes):
+    """The same fused step at larger per-GPU batches, where kernels fill the chip ('report larger-B points')."""
+    out = {}
+    for B in sizes:
+        torch.manual_seed(42)
+        model = M.Sg2ScVAEModel(vocab=syn.default_vocab(), batch_size=B, train_3d=True, decoder_cat=True, embedding_dim=64,
+                                gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
+                                layout_noise_dim=32, use_AE=False).cuda().train()
+        model.validate_inputs = False
+        b = syn.scene_graph_batch(B, args.objs, args.triples, seed=77, device="cuda")
+        batch = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
+        st = torch.cuda.Stream()
+        n_w, n_t = 3, (20 if B <= 1024 else 8)
+        with torch.cuda.stream(st):
+            for _ in range(n_w):
+                l = model.train_step(*batch, kl_weight=0.1, lr=1e-4, use_graph=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_t):
+                l = model.train_step(*batch, kl_weight=0.1, lr=1e-4, use_graph=True)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n_t
+        flop = 1.24e9 * B                              # SURVEY.md 8d: 1.24 GFLOP per graph (fwd + bwd)
+        out[str(B)] = {"graphs_per_s": round(B / dt, 1), "ms_per_step": round(dt * 1e3, 3), "tflops_whole_step": round(flop / dt / 1e12, 2),
+                       "frac_mfma_whole_step": round(flop / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4), "finite": bool(torch.isfinite(l).all().item())}
+        del model
+        torch.cuda.empty_cache()
+    return out
+
+
 def render_leg(args, lib, torch, rank):
     """BASELINE configs[2]: differentiable render of `rooms` synthetic rooms x ~`tris` triangles at 256x256,
     forward (70-channel scene tensor of mesh_render_func) + backward to the vertices, fused HIP pass."""
@@ -75,23 +292,12 @@ def render_leg(args, lib, torch, rank):
     syn = importlib.import_module("3d_sln_amd.host.synthetic")
     dev = "cuda"
     rooms = [syn.synthetic_room(100 + rank * 64 + i, n_objects=12, target_faces=args.tris) for i in range(args.rooms)]
-    Vmax = max(r[0].shape[0] for r in rooms)
-    prepared, Fmax, tri_count = [], 0, 0
-    for V, F, ranges, box in rooms:
-        v = torch.zeros(1, Vmax, 3); v[0, :V.shape[0]] = torch.from_numpy(V)
-        K, R, t = DR.get_cam_mat(torch.from_numpy(box), "cpu")
-        faces, cls, classes, chan, dch = DR.cull_and_classify(torch.from_numpy(V)[None], torch.from_numpy(F)[None], ranges, R, t)
-        tri_count += faces.shape[1]
-        faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), 1)[0]; cls = torch.cat((cls, cls))
-        prepared.append((v[0], faces, cls, K[0], R[0], t[0])); Fmax = max(Fmax, faces.shape[0])
-    Vb = torch.stack([p[0] for p in prepared]).to(dev).requires_grad_(True)
-    Fb = torch.zeros(args.rooms, Fmax, 3, dtype=torch.int32); Cb = torch.full((args.rooms, Fmax), -1, dtype=torch.int32)
-    for i, p in enumerate(prepared):
-        Fb[i, :p[1].shape[0]] = p[1]; Cb[i, :p[2].shape[0]] = p[2]
-    Fb, Cb = Fb.to(dev), Cb.to(dev)
-    Kb = torch.stack([p[3] for p in prepared]).to(dev); Rb = torch.stack([p[4] for p in prepared]).to(dev)
-    tb = torch.stack([p[5] for p in prepared]).to(dev)
-    chan_t = torch.tensor(chan, dtype=torch.int32, device=dev); dch_t = torch.tensor(dch, dtype=torch.int32, device=dev)
+    pk = syn.pack_rooms(rooms, dev)
+    res = {}
+    if not args.no_check:
+        res["parity"] = check_render(torch, pk, sorted({0, args.rooms - 1}))
+    Vb = pk["V"].requires_grad_(True)
+    Fb, Cb, Kb, Rb, tb, chan_t, dch_t, tri_count = pk["F"], pk["C"], pk["K"], pk["R"], pk["t"], pk["chan"], pk["dch"], pk["tris"]
     gout = torch.randn(args.rooms, 70, 256, 256, device=dev)
 
     def it():
@@ -99,14 +305,18 @@ def render_leg(args, lib, torch, rank):
         out = DR.scene_render_batch(Vb, Fb, Cb, chan_t, dch_t, Kb, Rb, tb, 256, 0.001)
         out.backward(gout)
         return out
-    for _ in range(5):
+    for _ in range(args.render_warmup):
         out = it()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.render_iters + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.render_iters):
+    marks[0].record()
+    for k in range(args.render_iters):
         it()
+        marks[k + 1].record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.render_iters))
     lib.check(lib.lib().sln_prof_enable(1), "prof")
     for _ in range(5):
         it()
@@ -114,19 +324,70 @@ def render_leg(args, lib, torch, rank):
     fam = prof_read(lib)
     lib.check(lib.lib().sln_prof_enable(0), "prof")
     per_render = dt / args.render_iters / args.rooms
-    res = {"renders_per_s": round(1.0 / per_render, 1), "ms_per_room_fwd_bwd": round(per_render * 1e3, 4),
-           "nmr_equivalent_raster_passes_per_s": round(33.0 / per_render, 1),
-           "workload": "BASELINE configs[2]: %d rooms x %d triangles (%.0f after near-plane cull, x2 fill_back), 256x256, "
-                       "70-channel scene tensor fwd + bwd to vertices" % (args.rooms, args.tris, tri_count / args.rooms),
-           "covered_pixels": round(float((out[:, 0] > 0).float().mean().item()), 3)}
-    bytes_per_render = 2 * 70 * 256 * 256 * 4 + 2 * (tri_count / args.rooms) * 36 * 2     # out + grad + faces
+    tris = tri_count / args.rooms
+    res.update({"renders_per_s": round(1.0 / per_render, 1), "ms_per_room_fwd_bwd": round(per_render * 1e3, 4),
+                "ms_per_batch_p10_p50_p90": [round(per[int(q * (len(per) - 1))], 4) for q in (0.1, 0.5, 0.9)],
+                "warmup": args.render_warmup, "iters": args.render_iters,
+                "nmr_equivalent_raster_passes_per_s": round(33.0 / per_render, 1),
+                "workload": "BASELINE configs[2]: %d rooms x %d triangles (%.0f after near-plane cull, x2 fill_back), 256x256, "
+                            "70-channel scene tensor fwd + bwd to vertices" % (args.rooms, args.tris, tris),
+                "covered_pixels": round(float((out[:, 0] > 0).float().mean().item()), 3), "finite": bool(torch.isfinite(Vb.grad).all().item())})
+    bytes_per_render = 2 * 70 * 256 * 256 * 4 + 2 * tris * 36 * 2     # out + grad + faces
+    algo = (70 * 256 * 256 * 4 + tris * 72) * args.rooms
     for k, name in (("raster_fwd", "scene_forward"), ("raster_bwd", "scene_backward")):
         if k in fam:
             ms = fam[k]["ms"] / fam[k]["launches"]
-            algo = (70 * 256 * 256 * 4 + (tri_count / args.rooms) * 72) * args.rooms
             res[name] = {"avg_ms_per_batch": round(ms, 4), "gbs_algorithmic": round(algo / (ms * 1e-3) / 1e9, 1),
                          "frac_hbm": round(algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
     res["algorithmic_bytes_per_render"] = int(bytes_per_render)
+    # rooflines of the leg.  (i) SURVEY.md 8d's definition: the 70-channel output, its gradient and the faces over HBM.
+    # (ii) the kernels that actually carry the time, named as in profiles/: the forward tile kernel is bound by per-pixel edge
+    # tests on the vector ALUs (3 edge functions x 2 fma + sign tests per (pixel, face) pair: counted from the brute-force
+    # 256^2 x 2F tests the package performs = the work replaced, and priced at the fp32 vector peak).
+    whole_ms = dt / args.render_iters * 1e3
+    res["roofline"] = {"kernel": "scene_forward + scene_backward (all launches of one batch)", "bound": "hbm",
+                       "achieved": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       "traffic": None, "algorithmic_bytes_per_launch": int(bytes_per_render * args.rooms)}
+    tr_pm, us_pm = profile_rows(["pixel_map_backward", "class_scan_backward"])
+    tr_rt, us_rt = profile_rows(["raster_tile_kernel"])
+    brute_tests = 256.0 * 256.0 * 2.0 * tris * args.rooms          # (pixel, face) pairs of ONE brute-force pass over the batch
+    flop_per_test = 3 * 2 * 2 + 3                                    # three edge functions (2 fma each) + sign tests
+    res["roofline_kernels"] = {
+        "raster_tile_kernel": {"bound": "valu", "unit": "TFLOP/s", "peak": VALU_F32_PEAK_TFLOPS, "avg_launch_us": us_rt,
+                               "brute_force_equivalent_tests_per_launch": brute_tests,
+                               "achieved": round(brute_tests * flop_per_test / (us_rt * 1e-6) / 1e12, 2) if us_rt else None,
+                               "frac": round(brute_tests * flop_per_test / (us_rt * 1e-6) / 1e12 / VALU_F32_PEAK_TFLOPS, 4) if us_rt else None,
+                               "traffic": tr_rt, "note": "binning + tile-corner rejection skip most of these tests; the figure is work replaced / time"},
+        "pixel_map_backward_kernel": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "avg_launch_us": us_pm, "traffic": tr_pm,
+                                      "achieved": round(tr_pm / (us_pm * 1e-6) / 1e9, 1) if (tr_pm and us_pm) else None,
+                                      "frac": round(tr_pm / (us_pm * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (tr_pm and us_pm) else None,
+                                      "note": "achieved = measured HBM traffic / duration (L2-resident scans: the kernel is latency / occupancy bound)"}}
+    if not args.no_cpu:
+        # CPU baseline: the 33-pass restatement (oracle/raster_ref.py + the OpenMP C++ rasterizer) forward + backward on rooms of
+        # the same batch, all cores; bounded sample
+        from oracle import raster_ref as rr
+        n = cpu_threads(torch)
+        torch.set_num_threads(n)
+        try:                                   # the C++ restatement's own OpenMP team (same libgomp as torch's where both link it)
+            C.CDLL("libgomp.so.1").omp_set_num_threads(n)
+        except OSError:
+            pass
+        log('render CPU baseline on %d threads' % n)
+        n_cpu, t_cpu = 0, 0.0
+        gcpu = gout[:2].cpu()
+        for V, F, ranges, box in rooms[:2]:
+            v1 = torch.from_numpy(V)[None].requires_grad_(True)
+            t0 = time.perf_counter()
+            ref = rr.scene_render(v1, torch.from_numpy(F)[None], ranges, torch.from_numpy(box), image_size=256)
+            (ref * gcpu[n_cpu:n_cpu + 1]).sum().backward()
+            t_cpu += time.perf_counter() - t0
+            n_cpu += 1
+            if t_cpu > 20.0:
+                break
+        res["cpu_baseline"] = {"value": round(n_cpu / t_cpu, 3), "unit": "renders/s", "cores": n, "kind": "port",
+                               "sample": "%d room(s) of the same batch, forward + backward through oracle/raster_ref.py (33 brute-force "
+                                         "passes per render, OpenMP C++ rasterizer), %.2f s per render" % (n_cpu, t_cpu / n_cpu)}
     return res
 
 
@@ -141,7 +402,7 @@ def graph_build_leg(args, lib, torch):
     B = args.graph_batch
     gen = torch.Generator(device="cuda").manual_seed(0)
     idx = torch.randint(0, len(rooms), (B,), generator=torch.Generator().manual_seed(0)).cuda()
-    for _ in range(5):
+    for _ in range(20):
         out = ds.build_batch(idx, generator=gen)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -217,8 +478,12 @@ def spade_leg(args, lib, torch):
     """BASELINE configs[3]: SPADEGenerator4(41,3,256,64,'spectralspadelayer3x3',256,'normal') forward, batch 32,
     256x256 semantic+depth -> RGB, seeded random weights (the authors' checkpoint is not distributable), eval."""
     S = importlib.import_module("3d_sln_amd.host.SPADE_related")
+    res = {}
+    if not args.no_check:
+        res["parity"] = check_spade(torch, S)
     torch.manual_seed(0)
-    G = S.SPADEGenerator4(41, 3, 256, 64, 'spectralspadelayer3x3', 256, 'normal').cuda().eval()
+    G = S.SPADEGenerator4(41, 3, 256, 64, 'spectralspadelayer3x3', 256, 'normal')        # torch's default init, as the reference's constructor
+    G = G.cuda().eval()
     B = args.spade_batch
     g = torch.Generator(device="cuda").manual_seed(0)
     low = torch.rand(B, 1, 16, 16, device="cuda", generator=g) * 2 - 1
@@ -227,28 +492,39 @@ def spade_leg(args, lib, torch):
                                           align_corners=False).argmax(1)
     seg = torch.cat([depth, torch.nn.functional.one_hot(lab, 40).permute(0, 3, 1, 2).float()], 1).contiguous()
     z = torch.randn(B, 256, device="cuda", generator=g)
-    out = G(seg, z)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.spade_iters):
+    for _ in range(args.spade_warmup):
         out = G(seg, z)
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.spade_iters + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for k in range(args.spade_iters):
+        out = G(seg, z)
+        marks[k + 1].record()
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.spade_iters
+    per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.spade_iters))
     lib.check(lib.lib().sln_prof_enable(1), "prof")
     G(seg, z)
     torch.cuda.synchronize()
     fam = prof_read(lib)
     lib.check(lib.lib().sln_prof_enable(0), "prof")
     flop_img = 2 * 152.61e9                                       # 152.6 GMAC per 256x256 image
-    res = {"images_per_s": round(B / dt, 2), "ms_per_batch": round(dt * 1e3, 2), "batch": B,
-           "tflops_end_to_end": round(flop_img * B / dt / 1e12, 2), "frac_mfma_end_to_end": round(flop_img * B / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-           "workload": "BASELINE configs[3]: SPADEGenerator4 256x256 semantic+depth -> RGB, batch %d, fp32, seeded random weights" % B,
-           "finite": bool(torch.isfinite(out).all().item())}
+    res.update({"images_per_s": round(B / dt, 2), "ms_per_batch": round(dt * 1e3, 2), "batch": B, "warmup": args.spade_warmup, "iters": args.spade_iters,
+                "ms_per_batch_p10_p50_p90": [round(per[int(q * (len(per) - 1))], 2) for q in (0.1, 0.5, 0.9)],
+                "tflops_end_to_end": round(flop_img * B / dt / 1e12, 2), "frac_mfma_end_to_end": round(flop_img * B / dt / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                "workload": "BASELINE configs[3]: SPADEGenerator4 256x256 semantic+depth -> RGB, batch %d, fp32, seeded random weights" % B,
+                "finite": bool(torch.isfinite(out).all().item())})
     if "conv" in fam:
         c = fam["conv"]
         tf = c["work"] / (c["ms"] * 1e-3) / 1e12
         res["conv_kernels"] = {"launches": c["launches"], "ms": round(c["ms"], 2), "tflops": round(tf, 2),
                                "frac_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
+        tr, us = profile_rows(["conv_mfma_kernel"])
+        res["roofline"] = {"kernel": "conv_mfma_kernel (3x3 reflect-padded implicit GEMM, %d launches per batch)" % c["launches"], "bound": "mfma",
+                           "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                           "traffic": tr, "flop_per_launch": round(c["work"] / c["launches"], 1), "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),
+                           "rocprof_avg_launch_us": us}
     # colorize_with_spade's own shape (testing/test_SPADE_shade.py:30-79): ONE semantic map, 50 z vectors.  gamma/beta depend
     # on the map only, so they are computed once (sln_spade_apply does the per-sample part).
     nz = 50
@@ -256,13 +532,44 @@ def spade_leg(args, lib, torch):
     G(seg[:1], z50)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(2):
+    for _ in range(5):
         o50 = G(seg[:1], z50)
     torch.cuda.synchronize()
-    dt50 = (time.perf_counter() - t0) / 2
+    dt50 = (time.perf_counter() - t0) / 5
     res["colorize_one_map_50z"] = {"images_per_s": round(nz / dt50, 1), "ms_per_room": round(dt50 * 1e3, 2),
                                    "speedup_vs_per_sample_path": round((nz / dt50) / (B / dt), 2),
                                    "finite": bool(torch.isfinite(o50).all().item())}
+    if not args.no_cpu:
+        # CPU baseline: the oracle (PyTorch-CPU restatement = what the reference module computes) on images of the same batch, all cores
+        from oracle import spade_ref
+        n = cpu_threads(torch)
+        torch.set_num_threads(n)
+        log('spade CPU baseline on %d threads' % n)
+        cfg = spade_ref.SpadeConfig()
+        sd = {k: v.detach().cpu() for k, v in G.state_dict().items()}
+        bc = 2
+        segc, zc = seg[:bc].cpu(), z[:bc].cpu()
+        with torch.no_grad():
+            ref = spade_ref.generator(sd, cfg, segc, zc)                       # warm-up; doubles as a full-size parity check
+            t0 = time.perf_counter()
+            n_it = 0
+            while n_it < 3 and time.perf_counter() - t0 < 20.0:
+                spade_ref.generator(sd, cfg, segc, zc); n_it += 1
+            cdt = (time.perf_counter() - t0) / n_it
+        if not args.no_check:
+            # full-size parity, conditioned: the image is a 1600-term sum of cancelling products (tanh of a small number), where
+            # any two fp32 evaluations differ by a few 1e-4 of its scale; hold |hip - fp64 oracle| to 1e-4 plus a small multiple of
+            # the fp32 oracle's own distance from the fp64 one (tests/parity.py: assert_close_conditioned)
+            log('spade full-size parity: fp64 oracle, 1 image')
+            with torch.no_grad():
+                ref64 = spade_ref.generator({k: v.double() for k, v in sd.items()}, cfg, segc[:1].double(), zc[:1].double())
+            e_hip, e_cpu = rel_err(out[:1].cpu().numpy(), ref64.numpy()), rel_err(ref[:1].numpy(), ref64.numpy())
+            require(e_hip <= 1e-4 + 4.0 * e_cpu, "SPADE full-size generator (110 M parameters, 256x256): image rel err vs fp64 oracle %.2e "
+                                                 "(fp32 oracle: %.2e)" % (e_hip, e_cpu))
+            res["parity"].update({"full_size_image_rel_err_vs_fp64_oracle": e_hip, "fp32_oracle_rel_err_vs_fp64_oracle": e_cpu})
+        res["cpu_baseline"] = {"value": round(bc / cdt, 3), "unit": "images/s", "cores": n, "kind": "port",
+                               "sample": "%d x batch of %d images of the same input through oracle/spade_ref.py (torch CPU fp32), %.2f s per image"
+                                         % (n_it, bc, cdt / bc)}
     return res
 
 
@@ -323,7 +630,16 @@ def main():
     b = ring[0]
     batch = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
     O = b["objs"].shape[0]
-    eps = torch.randn(O, 64, device="cuda")
+    solo = world == 1          # the side legs, the checks and the CPU baselines are single-GPU measurements (rank 0 at N = 1 only)
+    parity = None
+    if rank == 0 and solo and not args.no_check:
+        log('parity check: VAE')
+        parity = check_vae(lib, torch, M, model, batch)
+    if rank == 0:
+        log('timed VAE loop')
+    # eps: by default the step draws its own N(0,1) on the device (Philox, inside the captured iteration), as the reference's
+    # forward does with randn_like every call (Sg2ScVAE_model.py:182); --inject-eps feeds one constant tensor instead
+    eps = torch.randn(O, 64, device="cuda") if args.inject_eps else None
     stream = torch.cuda.Stream()
     use_graph = not args.no_graph
     T = importlib.import_module("3d_sln_amd.host.train")
@@ -332,6 +648,7 @@ def main():
     dp_step = T.DataParallelStep(model, world, force=force_dp)
     bdicts = [dict(objs=r["objs"], triples=r["triples"], boxes=r["boxes"], angles=r["angles"], attributes=r["attributes"]) for r in ring]
     counter = [0]
+    model.validate_inputs = False               # synthetic ids, checked above: no host sync per new batch (as host/train.py does)
 
     def step():
         counter[0] += 1
@@ -387,21 +704,20 @@ def main():
                                "Sg2ScVAE train step at train.py defaults (embedding_dim=64, 5+5 GraphTripleConv, BatchNorm)"
                                % (args.graphs, args.objs, args.triples),
                    "O": int(O), "T": int(b["triples"].shape[0]), "hipgraph": bool(use_graph), "distinct_batches_cycled": len(ring),
-                   "parallelism": "dp%d" % world, "collective": ("all-reduce(avg) of %d fp32 grads/step%s" % (model.flat_grads.numel(), " in 2 buckets, decoder half overlapped with the encoder backward" if dp_step.overlap else "")) if dp else None, "allreduce_us_standalone": coll_us, "final_total_loss": round(final_loss, 5)},
+                   "eps": "constant tensor" if args.inject_eps else "N(0,1) drawn on the device inside the step",
+                   "parallelism": "dp%d" % world,
+                   "collective": ("all-reduce(avg) of %d fp32 grads + 1 guard element per step%s"
+                                  % (model.flat_grads.numel(), " in 2 buckets, decoder half overlapped with the encoder backward" if dp_step.overlap else "")) if dp else None,
+                   "allreduce_us_standalone": coll_us, "final_total_loss": round(final_loss, 5)},
     }
+    if not (final_loss == final_loss and abs(final_loss) < 1e30):
+        raise SystemExit("bench.py: the training loss is not finite (%r): nothing reported" % final_loss)
+    if parity is not None:
+        out["parity"] = parity
 
-    solo = world == 1          # the side legs and the CPU baseline are single-GPU measurements (rank 0 at N = 1 only)
-    if rank == 0 and solo and not args.no_render:
-        out["render"] = render_leg(args, lib, torch, rank)
-    if rank == 0 and solo and not args.no_spade:
-        out["spade"] = spade_leg(args, lib, torch)
-    if rank == 0 and solo and not args.no_graph_build:
-        out["graph_build"] = graph_build_leg(args, lib, torch)
-    if rank == 0 and solo and not args.no_refine:
-        out["refine"] = refine_leg(args, lib, torch)
-    if rank == 0 and args.prof_steps <= 0:
-        print(json.dumps(out))
-    elif rank == 0:
+    if rank == 0:
+        log('VAE loop done: %.3f ms/step' % ms_per_step)
+    if rank == 0 and args.prof_steps > 0:
         # ---- per-kernel-family timing, eager launches + HIP events on the launch stream -----------
         with torch.cuda.stream(stream):
             lib.check(lib.lib().sln_prof_enable(1), "prof")
@@ -420,53 +736,73 @@ def main():
         out["kernels"] = kern
         dom = max((k for k in fam if k.startswith("gemm")), key=lambda k: fam[k]["ms"])
         ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12
+        # HBM traffic of that kernel family from the committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in
+        # separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); launch-weighted mean over its variants;
+        # the training step's launches only: the refinement leg adds eval-mode <0, ...> variants on a 13-object graph
+        traffic, prof_us = profile_rows([dom + "_kernel<1,", dom + "_kernel<2,"] if dom == "gemm_dual" else [dom + "_kernel"])
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+                           "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
-                           "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2)}
-        # HBM traffic of that kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-        # separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); launch-weighted mean over its variants
-        try:
-            import csv
-            tot, cnt = 0.0, 0
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_vae_render_kernel_stats.csv"))):
-                # the training step's launches only: the refinement leg of the profiled run adds eval-mode <0, ...> variants on a
-                # 13-object graph, which are not what `achieved` above was measured on
-                if r["kernel"].startswith(dom + "_kernel") and r["hbm_MB_per_launch_corrected"] and (dom != "gemm_dual" or "<1," in r["kernel"]):
-                    tot += float(r["hbm_MB_per_launch_corrected"]) * int(r["calls"]); cnt += int(r["calls"])
-            if cnt:
-                out["roofline"]["traffic"] = round(tot / cnt * 1e6)
-                out["roofline"]["traffic_source"] = "profiles/r01_vae_render_kernel_stats.csv (bytes per launch)"
-                out["roofline"]["algorithmic_bytes_per_launch"] = ("dgrad+wgrad pair of one Linear: G (two sources under BatchNorm), X, W^T, "
-                                                                   "xprev, dX: 4-56 MB (shape dependent)")
-        except Exception:
-            pass
+                           "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2), "rocprof_avg_launch_us": prof_us,
+                           "traffic_source": (os.path.relpath(PROFILE_CSV, ROOT) + " (bytes per launch)") if traffic else None,
+                           "algorithmic_bytes_per_launch": "dgrad+wgrad pair of one Linear: G (two sources under BatchNorm), X, W^T, "
+                                                           "xprev, dX: 4-56 MB (shape dependent)"}
+        gemm_flop = sum(v["work"] for k, v in fam.items() if k.startswith("gemm")) / args.prof_steps
+        out["roofline_step"] = {"kernel": "whole training step (all launches)", "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
+                                "achieved": round(gemm_flop / (ms_per_step * 1e-3) / 1e12, 2),
+                                "frac": round(gemm_flop / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                "gemm_flop_per_step": round(gemm_flop, 1)}
         if "edge" in fam:
             e = fam["edge"]
             gbs = e["work"] / (e["ms"] * 1e-3) / 1e9
             out["roofline_edge"] = {"kernel": "edge scatter/gather", "bound": "hbm", "achieved": round(gbs, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
 
-        # ---- CPU baseline: the oracle (PyTorch-CPU port of the reference path) on the same batch ----
-        if solo and not args.no_cpu:
-            from oracle import vae_ref
-            cfg = vae_ref.VaeConfig()
-            sd = vae_ref.init_state(cfg, seed=42)
-            cb = tuple(t.cpu() for t in batch)
-            ceps = eps.cpu()
-            keys = vae_ref.trainable_keys(cfg)
-            m = {k: torch.zeros_like(sd[k]) for k in keys}; v = {k: torch.zeros_like(sd[k]) for k in keys}
-            ncores = min(16, os.cpu_count() or 1)      # beyond ~16 threads the small CPU GEMMs of this step slow down
-            torch.set_num_threads(ncores)
+    if rank == 0 and solo and not args.no_cpu:
+        # ---- CPU baseline: the oracle (PyTorch-CPU port of the reference path) on the same batch, all host cores ----
+        from oracle import vae_ref
+        cfg = vae_ref.VaeConfig()
+        sd = vae_ref.init_state(cfg, seed=42)
+        cb = tuple(t.cpu() for t in batch)
+        ceps = torch.randn(O, 64, generator=torch.Generator().manual_seed(1))
+        keys = vae_ref.trainable_keys(cfg)
+
+        def cpu_rate(nthreads, steps):
+            torch.set_num_threads(nthreads)
+            s = {k: v.clone() for k, v in sd.items()}
+            m = {k: torch.zeros_like(s[k]) for k in keys}; v = {k: torch.zeros_like(s[k]) for k in keys}
             for i in range(2):
-                vae_ref.train_step(sd, cfg, cb, ceps, 0.1, m, v, step=i + 1)
+                vae_ref.train_step(s, cfg, cb, ceps, 0.1, m, v, step=i + 1)
             t0 = time.perf_counter()
-            for i in range(args.cpu_steps):
-                vae_ref.train_step(sd, cfg, cb, ceps, 0.1, m, v, step=i + 3)
-            cdt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": round(args.graphs * args.cpu_steps / cdt, 1), "unit": "graphs/s", "cores": ncores,
-                                   "kind": "port", "sample": "%d train steps of the same batch (%d graphs), oracle/vae_ref.py, "
-                                   "torch CPU fp32, %.1f ms/step" % (args.cpu_steps, args.graphs, cdt / args.cpu_steps * 1e3)}
+            for i in range(steps):
+                vae_ref.train_step(s, cfg, cb, ceps, 0.1, m, v, step=i + 3)
+            return (time.perf_counter() - t0) / steps
+        ncores = cpu_threads(torch)
+        log('CPU baseline: VAE step on %d threads (os.cpu_count() = %s)' % (ncores, os.cpu_count()))
+        cdt = cpu_rate(ncores, args.cpu_steps)
+        out["cpu_baseline"] = {"value": round(args.graphs / cdt, 1), "unit": "graphs/s", "cores": ncores,
+                               "kind": "port", "sample": "%d train steps of the same batch (%d graphs), oracle/vae_ref.py, "
+                               "torch CPU fp32, %.1f ms/step" % (args.cpu_steps, args.graphs, cdt * 1e3)}
+        if ncores > 16:                            # the small GEMMs of this step stop scaling beyond ~16 threads: report that point too
+            cdt16 = cpu_rate(16, max(5, args.cpu_steps // 2))
+            out["cpu_baseline"]["value_at_16_threads"] = round(args.graphs / cdt16, 1)
+
+    if rank == 0 and solo:
+        if not args.no_cpu:
+            log('c1 leg'); out["c1"] = c1_leg(args, torch, M)
+        sizes = [int(x) for x in args.large_batches.split(",") if x.strip()]
+        if sizes:
+            log('large-batch leg'); out["vae_large_batch"] = large_batch_leg(args, torch, M, syn, sizes)
+        if not args.no_render:
+            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
+        if not args.no_spade:
+            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
+        if not args.no_graph_build:
+            log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
+        if not args.no_refine:
+            log('refine leg'); out["refine"] = refine_leg(args, lib, torch)
+        log('done')
+    if rank == 0:
         print(json.dumps(out))
     if dp:
         dist.barrier()

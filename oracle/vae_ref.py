@@ -319,14 +319,15 @@ def adam_step(sd: State, grads: Dict[str, torch.Tensor], m: State, v: State, ste
 
 
 def train_step(sd: State, cfg: VaeConfig, batch, eps, kl_weight: float, m: State, v: State,
-               step: int, lr: float = 1e-4):
-    """One iteration of train.py:62-84 on the CPU (forward, loss, backward, Adam)."""
+               step: int, lr: float = 1e-4, training: bool = True):
+    """One iteration of train.py:62-84 on the CPU (forward, loss, backward, Adam).  ``training=False``: BatchNorm on its
+    running statistics, as after ``--eval_mode_after`` (train.py:63-65 calls model.eval() and keeps optimising)."""
     keys = trainable_keys(cfg)
     for k in keys:
         sd[k].requires_grad_(True)
         sd[k].grad = None
     objs, triples, boxes, angles, attrs = batch
-    mu, logvar, bp, ap = forward(sd, cfg, objs, triples, boxes, angles, attrs, eps, True)
+    mu, logvar, bp, ap = forward(sd, cfg, objs, triples, boxes, angles, attrs, eps, training)
     total, parts = losses(cfg, boxes, bp, angles, ap, mu, logvar, kl_weight)
     total.backward()
     grads = {k: sd[k].grad for k in keys if sd[k].grad is not None}

@@ -297,3 +297,37 @@ def test_many_triangles_bit_exact():
     assert (fi.cpu().numpy() == rfi).all(), "face index map differs at %d pixels" % int((fi.cpu().numpy() != rfi).sum())
     assert (w.cpu().numpy() == rw).all() and (d.cpu().numpy() == rd).all()
     assert len(np.unique(rfi)) > 500
+
+
+def test_c3_sixteen_rooms_at_size():
+    """BASELINE configs[2] at its own size - 16 rooms x 2000 triangles (x2 fill_back), 256 x 256, the bench's rooms: (a) face
+    index / barycentric / depth maps of ALL 16 images bit-identical to the CPU restatement on identical projected faces,
+    (b) the fused 70-channel scene tensor and d/d vertices of three of the 16 rooms (first, middle, last: every XCD slot of the
+    image -> XCD mapping that batches of >= 8 use) against the 33-pass restatement."""
+    DR = pkg("host.diff_render"); NR = pkg("host.neural_renderer"); syn = pkg("host.synthetic")
+    rooms = [syn.synthetic_room(100 + i, n_objects=12, target_faces=2000) for i in range(16)]
+    b = syn.pack_rooms(rooms)
+    assert b["tris"] / 16 > 1800
+    with torch.no_grad():
+        fxyz = NR.project_faces(b["V"], b["F"], b["K"], b["R"], b["t"], 512).contiguous()
+    rfi, rw, rd = rr.nmr_forward(fxyz.cpu().numpy(), 256, 0.001, 100.0)
+    _, fi, w, d = _hip_forward(fxyz, 256, 0.001, 100.0)
+    assert (fi.cpu().numpy() == rfi).all(), "face index map differs at %d pixels" % int((fi.cpu().numpy() != rfi).sum())
+    assert (w.cpu().numpy() == rw).all() and (d.cpu().numpy() == rd).all()
+    assert min(float((rfi[k] >= 0).mean()) for k in range(16)) > 0.9
+    Vb = b["V"].clone().requires_grad_(True)
+    out = DR.scene_render_batch(Vb, b["F"], b["C"], b["chan"], b["dch"], b["K"], b["R"], b["t"], 256, 0.001)
+    go = torch.randn(16, 70, 256, 256, generator=torch.Generator().manual_seed(3))
+    (out * go.cuda()).sum().backward()
+    assert out.shape == (16, 70, 256, 256) and torch.isfinite(Vb.grad).all()
+    for k in (0, 7, 15):
+        V, F, ranges, box = rooms[k]
+        v1 = torch.from_numpy(V)[None].requires_grad_(True)
+        ref = rr.scene_render(v1, torch.from_numpy(F)[None], ranges, torch.from_numpy(box), image_size=256)
+        (ref * go[k:k + 1]).sum().backward()
+        o, r = out[k].detach().cpu().numpy(), ref[0].detach().numpy()
+        # projection on the GPU vs on the CPU: last-bit differences of a vertex may flip a handful of silhouette pixels
+        assert (np.abs(o[1:41] - r[1:41]) > 1e-6).sum() <= 8, "room %d: class images differ" % k
+        assert_close(o, r, "room %d final" % k, rtol=1e-4, atol=1e-5)
+        assert_close(Vb.grad[k, :V.shape[0]].cpu().numpy(), v1.grad[0].numpy(), "room %d dV" % k, rtol=1e-4,
+                     atol=2e-4 * v1.grad.abs().max().item())

@@ -66,8 +66,15 @@ def test_linear_wgrad(R, N, K):
 
 
 # ----------------------------------------------------------------------------- golden fixtures
-def _fp64_grads(cfg, sd64, b64, eps64):
+def _fp64_grads(cfg, sd64, b64, eps64, perturb_seed=None):
+    """Gradients of one oracle iteration.  ``perturb_seed``: every floating parameter is first moved by a relative 2^-23
+    (one fp32 rounding) in a random direction - the spread of the exact gradient under such perturbations is the
+    conditioning of the problem itself (train-mode BatchNorm over 8 rows: ReLU masks and L1 signs flip)."""
     s = {k: v.clone() for k, v in sd64.items()}
+    if perturb_seed is not None:
+        gen = torch.Generator().manual_seed(perturb_seed)
+        for k in vae_ref.trainable_keys(cfg):
+            s[k] = s[k] * (1.0 + (torch.rand(s[k].shape, generator=gen, dtype=s[k].dtype) * 2 - 1) * 2.0 ** -23)
     m = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
     v = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
     _, _, grads = vae_ref.train_step(s, cfg, b64, eps64, KL_WEIGHT, m, v, 1)
@@ -173,10 +180,33 @@ def test_golden_eval_and_train(name):
     gscale = max(float(np.abs(v).max()) for v in g64.values())
     named = dict(model.named_parameters())
     bad = []
+    # c1 (BatchNorm over 8 rows): any fp32 evaluation of the forward is 1e-3..1e-2 away from the exact one (the reference's own
+    # boxes_pred moves by 1e-2 between 1 and 8 CPU threads), ReLU masks and L1 signs flip, and the gradient moves by O(1) of its
+    # scale.  The yardstick is the reference path's own fp32 scatter: its stored gradient, the fp32 oracle on 1 thread and on all
+    # of them, and the fp32 oracle with every parameter moved by one ulp (five rounding trajectories), all measured against the
+    # fp64 gradient.  The TIGHT check of the backward kernels at this shape is test_tight_gradients_when_no_threshold_is_near.
+    spread = {}
+    if ill:
+        sd32 = {k: v.clone() for k, v in sd0.items()}
+        samples = [_fp64_grads(cfg, sd32, batch_cpu, ins["eps"], perturb_seed=ps) for ps in (1, 2, 3, 4, 5)]
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        samples.append(_fp64_grads(cfg, sd32, batch_cpu, ins["eps"]))
+        torch.set_num_threads(nthr)
+        for gp in samples + [g32]:
+            for k in g64:
+                spread[k] = max(spread.get(k, 0.0), float(np.abs(gp[k] - g64[k]).max()))
     for k, r64g in g64.items():
         ref32 = g["grad:" + k] if ("grad:" + k) in g.files else g32[k]
         try:
-            assert_close_conditioned(named[k].grad.cpu().numpy(), r64g, ref32, name + ":grad:" + k, atol=5e-6 * gscale, k=4.0)
+            got = named[k].grad.cpu().numpy()
+            if ill:
+                err, scale = max_err(got, r64g)
+                noise = max(max_err(ref32, r64g)[0], spread[k])
+                assert np.isfinite(err) and err <= 5e-6 * gscale + 1e-4 * scale + 4.0 * noise, \
+                    "%s:grad:%s: err %.3e, scale %.3e, conditioning spread %.3e" % (name, k, err, scale, noise)
+            else:
+                assert_close_conditioned(got, r64g, ref32, name + ":grad:" + k, atol=5e-6 * gscale, k=4.0)
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, "\n".join(bad[:40]) + "\n" + report
@@ -186,9 +216,9 @@ def test_golden_eval_and_train(name):
             got = np.array([float(gg.sum()), float(gg.abs().sum()), float((gg * gg).sum())])
             r64g = torch.from_numpy(g64[k[5:]])
             ref64 = np.array([float(r64g.sum()), float(r64g.abs().sum()), float((r64g * r64g).sum())])
-            # sum |g| and sum g^2 are well-conditioned summaries; the plain sum cancels and is bounded on the |g| scale
-            assert_close_conditioned(got[1:], ref64[1:], g[k][1:], name + ":" + k, rtol=1e-3, k=4.0)
-            assert abs(got[0] - ref64[0]) <= 1e-3 * ref64[1] + 4.0 * abs(g[k][0] - ref64[0]), name + ":" + k + " (sum)"
+            # the reference's own checksums: sum |g| of ours within the reference's distance from fp64 plus the spread above
+            slack = 4.0 * (abs(g[k][1] - ref64[1]) + spread.get(k[5:], 0.0) * gg.numel())
+            assert abs(got[1] - ref64[1]) <= 1e-3 * ref64[1] + slack, "%s:%s sum|g| %.4e vs %.4e" % (name, k, got[1], ref64[1])
     for k in g.files:
         if k.startswith("buf:"):
             if ill:
@@ -388,6 +418,58 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
     for k in sdg:
         if "running" in k:
             assert_close(model2.state_dict()[k].cpu().numpy(), sdg[k].numpy(), "c2:" + k)
+
+
+def _threshold_free_state(cfg, seed):
+    """A state in which no ReLU pre-activation and no L1 residual sits near its threshold: weights at a tenth of their initial
+    scale, every Linear bias in front of a ReLU at +8 (|W x| stays below ~1.5), posterior-head biases 0.  The network is then
+    a smooth function of its parameters and fp32 evaluations agree with fp64 to ~1e-6 - unlike the random-init state, where
+    ~1e2 of the ~4e8 pre-activations of a 256-graph step lie within fp32 rounding of 0 and every flipped mask moves the
+    gradients by 1e-3 of their scale in ANY fp32 evaluation (the reference's included)."""
+    sd = vae_ref.init_state(cfg, seed=seed, scale=0.1)
+    relu_free = ("box_mean.", "box_var.", "angle_mean.", "angle_var.", "box_net.%d." % (3 if cfg.mlp_normalization == "batch" else 2),
+                 "angle_net.%d." % (3 if cfg.mlp_normalization == "batch" else 2))
+    for k, v in sd.items():
+        if k.endswith(".bias") and v.dim() == 1 and not k.startswith(relu_free) and "embeddings" not in k:
+            if cfg.mlp_normalization == "batch" and k.rsplit(".", 2)[-2] in ("1", "4"):
+                continue                                   # BatchNorm beta stays 0: the Linear bias in front of it carries the +8
+            v.fill_(8.0)
+    return sd
+
+
+@pytest.mark.parametrize("norm,training", [("none", True), ("batch", False)])
+@pytest.mark.parametrize("n_graphs", [256, 1])
+def test_tight_gradients_when_no_threshold_is_near(norm, training, n_graphs):
+    """1e-4 on EVERY gradient of a full-width step, (a) at 256 graphs (O = 8192, T = 16384): the >= 128-row tiles and the
+    separately launched dgrad / wgrad kernels the engine switches to above the batch-64 sizes, (b) at BASELINE config c1's shape
+    (1 graph, 8 objects, 12 triples), without BatchNorm and with eval-mode BatchNorm (train.py:63-65 keeps training after
+    model.eval()).  Train-mode BatchNorm cannot be made threshold-free (it removes the bias), see the conditioned tests."""
+    cfg = vae_ref.VaeConfig(mlp_normalization=norm)
+    sd = _threshold_free_state(cfg, seed=3)
+    batch = list(vae_ref.synth_batch(n_graphs, 32 if n_graphs > 1 else 8, 64 if n_graphs > 1 else 12, seed=0, cfg=cfg)[:5])
+    batch[2] = batch[2] - 100.0                             # every L1 residual positive, far from 0
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    b64 = (batch[0], batch[1], batch[2].double(), batch[3], batch[4])
+    keys = vae_ref.trainable_keys(cfg)
+    m64 = {k: torch.zeros_like(sd64[k]) for k in keys}; v64 = {k: torch.zeros_like(sd64[k]) for k in keys}
+    total64, parts64, g64 = vae_ref.train_step(sd64, cfg, b64, eps.double(), 0.1, m64, v64, step=1, training=training)
+    model = _model(cfg, sd).train(training)
+    dev = _dev(*batch, eps)
+    losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=False, with_adam=False).cpu().numpy()
+    assert_close(losses[3], float(total64), "total")
+    assert_close(losses[0], parts64["bbox_pred"], "bbox"); assert_close(losses[1], parts64["angle_pred"], "angle")
+    assert_close(losses[2], parts64["KLD_Gauss"], "kld")
+    named = dict(model.named_parameters())
+    bad = []
+    for k in keys:
+        ref = g64[k].numpy() if k in g64 else np.zeros(tuple(sd[k].shape))
+        try:
+            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=1e-7 * max(float(np.abs(ref).max()), 1e-30) + 1e-9)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad[:40])
 
 
 def test_out_of_range_ids_raise_like_the_reference():
