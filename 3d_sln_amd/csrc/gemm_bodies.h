@@ -11,6 +11,11 @@
 namespace {
 
 
+// phase stamps for tools/gemm_lab.hip (a no-op in the product build)
+#ifndef SLN_TRACE
+#define SLN_TRACE(i)
+#endif
+
 constexpr int BK = 32;
 constexpr int TN_PAD = 32;     // LDS row padding of the TN (wgrad) tiles, see gemm_tn_body
 
@@ -78,7 +83,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   constexpr int LDT = BK + 4;                 // k-contiguous LDS rows, +4 floats: ds_read_b128 conflict-free
   constexpr int RP = 32;                       // rows staged per pass
   constexpr int PA = BM / RP, PB = BN / RP;
-  constexpr int NST = 3;                      // register stages: tiles kt+1..kt+3 in flight while kt computes
+  constexpr int NST = 2;                      // register stages: tiles kt+1, kt+2 (and kt+3 once kt+1 is in LDS) in flight while kt computes
   static_assert(WM * WN == 4, "4 waves per block");
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);
@@ -89,6 +94,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   double* redd = reinterpret_cast<double*>(ecoef + BN);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SLN_TRACE(0);
   const int tiles_n = (a.N + BN - 1) / BN;
   const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
@@ -112,6 +118,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   }
   float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
   const int ntiles = kpad / BK;
+  const int last = ntiles - 1;
   const float* Wp = a.W; const int ldw = a.ldw, Mr = a.M, Nr = a.N, Kr = a.K;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -140,11 +147,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       gb[S][p] = ld4(Wp + (size_t)n * ldw + cw);
     }
   };
-  auto lstore = [&](int kt, int buf, auto stage) {
+  auto lstore = [&](int kt_raw, int buf, auto stage) {
     constexpr int S = decltype(stage)::value;
+    const int kt = min(kt_raw, last);
     const int k0 = kt * BK, col = k0 + 4 * kq;
     const SegSel sg = pick_seg<MULTI>(a.A, k0, col);
-    const bool cv = col < sg.end;
+    const bool cv = col < sg.end && kt_raw <= last;          // surplus tiles (loop padded to a multiple of 3) are stored as zeros
     const bool x2v = HAS_X2 && sg.x2 != nullptr;
     float* as = As + buf * BM * LDT + 4 * kq;
     float* bs = Bs + buf * BN * LDT + 4 * kq;
@@ -157,7 +165,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(as + rl * LDT) = t;
     }
-    const bool kv = col < Kr;
+    const bool kv = col < Kr && kt_raw <= last;
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const bool v = kv && (n0 + r0 + RP * p) < Nr;
@@ -168,11 +176,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   };
 
   // issue the first tiles' loads before the (dependent, sqrt-heavy) coefficient set-up
-  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
-  const int last = ntiles - 1;
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
   gload(0, S0{});
   gload(min(1, last), S1{});
-  gload(min(2, last), S2{});
 
   if (!IDENT) {
     sln_fill_coefs(a.A, coef, tid, NT);
@@ -198,9 +204,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   __syncthreads();            // coef tables visible
+  SLN_TRACE(1);
   lstore(0, 0, S0{});
-  gload(min(3, last), S0{});
+  gload(min(2, last), S0{});
   __syncthreads();
+  SLN_TRACE(2);
   const int lrow = lane & 31, lk = lane >> 5;
 
   // Fragments ping-pong between two register sets; on entry to body(kt) set 0 already holds the first 8-wide k chunk of
@@ -231,30 +239,35 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   };
   rd(0, 0, S0{});
 
-  // tile j lives in register stage j % 3; body(kt) computes tile kt from LDS, stores tile kt+1 from its stage
-  // and refills that stage with tile kt+4.  Every body issues the SAME loads unconditionally (tile
-  // indices clamped; the surplus tiles are never consumed) so that hipcc's s_waitcnt accounting is exact
-  // and the wait in lstore() leaves the two younger stages in flight (vmcnt(8), not vmcnt(0)).
+  // Tile j lives in register stage j % 2.  body(kt) stages tile kt+1 from its register stage into LDS, refills that stage
+  // with tile kt+3, and computes tile kt from LDS.  Every body issues the SAME loads unconditionally (tile indices clamped;
+  // surplus tiles are stored as zeros) so that the loop is one straight block.
+  // The next tile is staged (and its register stage refilled) FIRST, under the MFMAs the previous body issued last: hipcc
+  // waits for ALL loads in flight at an lstore (vmcnt(0), never a partial count - seen in the ISA of every formulation tried),
+  // so the youngest load must be a whole tile old by then: with the refill issued right behind the lstore it is.
   auto body = [&](int kt, auto stage_next) {
     const int buf = kt & 1;
+    lstore(kt + 1, buf ^ 1, stage_next);
+    gload(min(kt + 3, last), stage_next);
+    __builtin_amdgcn_sched_barrier(0);      // hipcc otherwise sinks these loads to the end of the body, half a tile before their wait
     rd(buf, 8, S1{});
     mma(S0{});
-    lstore(min(kt + 1, last), buf ^ 1, stage_next);
     rd(buf, 16, S0{});
     mma(S1{});
     rd(buf, 24, S1{});
     mma(S0{});
-    gload(min(kt + 4, last), stage_next);
     __syncthreads();
     rd(buf ^ 1, 0, S0{});
     mma(S1{});
   };
-  int kt = 0;
-  for (; kt + 3 <= ntiles; kt += 3) { body(kt, S1{}); body(kt + 1, S2{}); body(kt + 2, S0{}); }
-  if (ntiles - kt == 1) { body(kt, S1{}); }
-  else if (ntiles - kt == 2) { body(kt, S1{}); body(kt + 1, S2{}); }
+  // ONE straight loop over pairs of tiles; an odd tile count (K % 64 == 32: only box_net's 2E + E/4 columns) runs one
+  // surplus tile of zeros.  With three stages and separate remainder bodies behind the loop (round 1) hipcc could not keep the
+  // register stages in place: it copied all of them (and the accumulators) at the top of every iteration, and a copy of a
+  // register with a load in flight is an s_waitcnt vmcnt(0) - 16 v_mov_b64 + 16 v_accvgpr_mov behind a vmcnt(0) per 3 tiles.
+  for (int kt = 0; kt < ntiles; kt += 2) { body(kt, S1{}); body(kt + 1, S0{}); }
 
   // ------------------------------- epilogue -------------------------------
+  SLN_TRACE(3);
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
@@ -268,22 +281,37 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     // column whose rows nearly agree (mean >> sigma: 8-row batches, BASELINE config c1) lost 1e-7 (mean / sigma)^2 of its
     // variance - torch's two-pass batch_norm does not.  Two fp64 ops per output element next to 2K MFMA flops.
     double d1 = 0.0, d2 = 0.0;
+    // Loads first (addend, xprev: unconditional, clamped rows), then arithmetic, then the stores: written element by element
+    // (load, wait, store, wait for the store before the next conditional load) the 16 values of a lane cost 5 000 cycles.
+    const int ccl = cvalid ? col : 0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      float yv[16], xpv[16];
+      const bool has_add = a.addend != nullptr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, a.M - 1);
+        yv[r] = acc[i][j][r] + bias;
+        xpv[r] = 0.f;
+        if (EPI == EPI_MASK) xpv[r] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
+      }
+      if (has_add) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = min(m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, a.M - 1);
+          yv[r] += a.addend[(size_t)row * a.ldadd + a.addcol0 + ccl];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (cvalid && row < a.M) {
-          float y = acc[i][j][r] + bias;
-          if (a.addend) y += a.addend[(size_t)row * a.ldadd + a.addcol0 + col];
-          if (EPI == EPI_STATS) { d1 += (double)y; d2 = fma((double)y, (double)y, d2); }
-          if (EPI == EPI_MASK) {
-            const float xp = a.xprev[(size_t)row * a.ldx + a.xcol0 + col];
-            y = fmaf(ec.x, xp, ec.y) > 0.f ? y : 0.f;
-            s1 += y; s2 = fmaf(y, (xp - ec.z) * ec.w, s2);
-          }
-          a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
-        }
+        const bool ok = cvalid && row < a.M;
+        float y = yv[r];
+        if (EPI == EPI_MASK) y = fmaf(ec.x, xpv[r], ec.y) > 0.f ? y : 0.f;
+        y = ok ? y : 0.f;
+        if (EPI == EPI_STATS) { d1 += (double)y; d2 = fma((double)y, (double)y, d2); }
+        if (EPI == EPI_MASK) { s1 += y; s2 = fmaf(y, (xpv[r] - ec.z) * ec.w, s2); }
+        if (ok) a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
       }
     }
     if (EPI == EPI_STATS) {
@@ -312,6 +340,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       }
     }
   }
+  SLN_TRACE(4);
 }
 
 
@@ -383,7 +412,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   const ColSel gs = pick_col(a.G, n0 + ca);
   const ColSel xs = pick_col(a.X, k0 + cb);
 
-  constexpr int NST = 3;
+  constexpr int NST = 2;      // register stages, see gemm_nt_body
   float4 g1[NST][PA], g2[NST][PA], x1[NST][PB];
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // unconditional, clamped loads (see the note in gemm_nt_body); masking happens in lstore()
@@ -414,7 +443,9 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     if (XG) iload(rt_idx, stage);          // indices of the tile this stage will load next
   };
   float4 dbacc = z4;
-  auto lstore = [&](int rt, int buf, auto stage, bool real) {
+  // rt is NOT clamped here: the rows of a surplus tile (rt > last, the loop runs whole pairs of tiles) lie behind rend and are
+  // stored as zeros
+  auto lstore = [&](int rt, int buf, auto stage) {
     constexpr int S = decltype(stage)::value;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -422,7 +453,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
       const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
       float4 t = xform(g1[S][p], (G_X2 && gs.x2) ? g2[S][p] : z4, coefG + ca);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      if (real) { dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w; }   // surplus (clamped) tiles do not count
+      dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
       *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
     }
 #pragma unroll
@@ -444,15 +475,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int ntiles = (rend - rbeg + BK - 1) / BK;
-  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
   const int last = ntiles - 1;          // ntiles >= 1: every launched block owns at least one row
-  if (XG) { iload(0, S0{}); iload(min(1, last), S1{}); iload(min(2, last), S2{}); }
-  gload(0, min(3, last), S0{});
-  gload(min(1, last), min(4, last), S1{});
-  gload(min(2, last), min(5, last), S2{});
+  if (XG) { iload(0, S0{}); iload(min(1, last), S1{}); }
+  gload(0, min(2, last), S0{});
+  gload(min(1, last), min(3, last), S1{});
   __syncthreads();            // coefficient tables visible
-  lstore(0, 0, S0{}, true);
-  gload(min(3, last), min(6, last), S0{});
+  lstore(0, 0, S0{});
+  gload(min(2, last), min(4, last), S0{});
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
   // fragments of 4 k-steps (8 rows of the tile) ping-pong between two register sets; set 0 is refilled with the next
@@ -480,24 +510,23 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q][i], fb[F][q][j], acc[i][j], 0, 0, 0);
   };
   rd(0, 0, S0{});
+  // same schedule as gemm_nt_body: stage the next tile and refill its register stage first, one straight loop over pairs
   auto body = [&](int rt, auto stage_next) {
     const int buf = rt & 1;
+    lstore(rt + 1, buf ^ 1, stage_next);
+    gload(min(rt + 3, last), min(rt + 5, last), stage_next);
+    __builtin_amdgcn_sched_barrier(0);
     rd(buf, 8, S1{});
     mma(S0{});
-    lstore(min(rt + 1, last), buf ^ 1, stage_next, rt + 1 <= last);
     rd(buf, 16, S0{});
     mma(S1{});
     rd(buf, 24, S1{});
     mma(S0{});
-    gload(min(rt + 4, last), min(rt + 7, last), stage_next);
     __syncthreads();
     rd(buf ^ 1, 0, S0{});
     mma(S1{});
   };
-  int rt = 0;
-  for (; rt + 3 <= ntiles; rt += 3) { body(rt, S1{}); body(rt + 1, S2{}); body(rt + 2, S0{}); }
-  if (ntiles - rt == 1) { body(rt, S1{}); }
-  else if (ntiles - rt == 2) { body(rt, S1{}); body(rt + 1, S2{}); }
+  for (int rt = 0; rt < ntiles; rt += 2) { body(rt, S1{}); body(rt + 1, S0{}); }
 
 #pragma unroll
   for (int i = 0; i < TM; ++i)

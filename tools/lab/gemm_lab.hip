@@ -1,0 +1,64 @@
+// Stand-alone GEMM laboratory (GPU box only): phase stamps of the product's NT body on the VAE's shapes.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -I include -I 3d_sln_amd/csrc tools/lab/gemm_lab.hip -o /tmp/gemm_lab && /tmp/gemm_lab
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+__device__ long long* g_trace;
+#define SLN_TRACE(i) do { if (threadIdx.x == 0) g_trace[(size_t)bid * 8 + (i)] = clock64(); } while (0)
+#include "gemm_bodies.h"
+#include "../../3d_sln_amd/csrc/prof.hip"
+
+template <int BM, int BN, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void lab_nt(const GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  gemm_nt_body<BM, BN, 2, 2, AMODE, EPI, 0>(a, bid, gridDim.x, smem);
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main() {
+  const int shapes[][3] = {{4096, 256, 384}, {4096, 640, 256}, {2048, 256, 256}, {2048, 128, 256}, {2048, 256, 128}, {32768, 640, 256}};
+  long long* trace; CK(hipMalloc(&trace, sizeof(long long) * 8 * 65536));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &trace, sizeof(trace)));
+  for (auto& sh : shapes) {
+    const int M = sh[0], N = sh[1], K = sh[2];
+    float *x, *W, *b, *y; double* sums;
+    CK(hipMalloc(&x, sizeof(float) * M * K)); CK(hipMalloc(&W, sizeof(float) * N * K)); CK(hipMalloc(&b, sizeof(float) * N));
+    CK(hipMalloc(&y, sizeof(float) * M * N)); CK(hipMalloc(&sums, sizeof(double) * 2 * N));
+    CK(hipMemset(x, 0, sizeof(float) * M * K)); CK(hipMemset(W, 0, sizeof(float) * N * K)); CK(hipMemset(b, 0, sizeof(float) * N));
+    CK(hipMemset(sums, 0, sizeof(double) * 2 * N));
+    GemmNTArgs a; memset(&a, 0, sizeof(a));
+    Seg s; memset(&s, 0, sizeof(s)); s.x1 = x; s.ld1 = K; s.len = K; s.coef = SLN_COEF_IDENT;
+    a.A.seg[0] = s; a.A.nseg = 1; a.A.rows = M; a.A.cols = K;
+    a.W = W; a.bias = b; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.ldw = K; a.osums = sums; a.ocstride = N;
+    const size_t smem = nt_smem_bytes(K, 64, 64, 2);
+    const int grid = ((M + 63) / 64) * ((N + 63) / 64);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_nt<64, 64, 2, EPI_STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, 0, a);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, 0, a);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<long long> t(8 * grid);
+    CK(hipMemcpy(t.data(), trace, sizeof(long long) * 8 * grid, hipMemcpyDeviceToHost));
+    long long tmin = t[0], tmax = 0;
+    std::vector<long long> ph[4];
+    for (int b2 = 0; b2 < grid; ++b2) {
+      tmin = std::min(tmin, t[8 * b2]); tmax = std::max(tmax, t[8 * b2 + 4]);
+      for (int p = 0; p < 4; ++p) ph[p].push_back(t[8 * b2 + p + 1] - t[8 * b2 + p]);
+    }
+    for (auto& v : ph) std::sort(v.begin(), v.end());
+    auto med = [&](std::vector<long long>& v) { return v[v.size() / 2]; };
+    std::vector<long long> starts; for (int b2 = 0; b2 < grid; ++b2) starts.push_back(t[8 * b2] - tmin);
+    std::sort(starts.begin(), starts.end());
+    printf("M=%5d N=%4d K=%4d grid %4d: %6.2f us/launch (%.1f TF) | span %lld ticks; median ticks: coef/prologue %lld, first tile %lld, main loop %lld (%d k-tiles), epilogue %lld; block start p50 %lld p100 %lld\n",
+           M, N, K, grid, ms / 50 * 1e3, 2.0 * M * N * K / (ms / 50 * 1e-3) / 1e12, tmax - tmin, med(ph[0]), med(ph[1]), med(ph[2]), (K + 31) / 32, med(ph[3]),
+           starts[starts.size() / 2], starts.back());
+    hipFree(x); hipFree(W); hipFree(b); hipFree(y); hipFree(sums);
+  }
+  return 0;
+}

@@ -9,8 +9,8 @@ set -u
 TAG=${1:-r02}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
-P=gpurun_out/prof_$TAG
-rm -rf "$P"; mkdir -p "$P" profiles
+P=/tmp/prof_$TAG          # raw rocprofv3 output stays on the box (tens of MB); only the summaries travel back
+rm -rf "$P"; mkdir -p "$P" profiles gpurun_out
 SHORT="--steps 20 --warmup 5 --no-cpu --no-check --spade-iters 1 --spade-warmup 1 --render-iters 5 --render-warmup 2 --graph-iters 5 --large-batches= $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -o vae -- python bench.py "$@" > "$P/bench_traced.json" 2> "$P/trace.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/fetch" -o vae -- python bench.py $SHORT > /dev/null 2> "$P/fetch.err"
@@ -21,5 +21,5 @@ for d in trace fetch write sq; do f=$(find "$P/$d" -name '*.csv' | head -1); [ -
 cp "$P/trace/vae_kernel_stats.csv" "profiles/${TAG}_rocprofv3_kernel_stats_raw.csv"
 python tools/summarize_profile.py "$P" "profiles/${TAG}"
 python tools/summarize_sq.py "$P/sq/sq_counter_collection.csv" "profiles/${TAG}"
-mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* "$P/bench_traced.json" gpurun_out/profiles_$TAG/
 tail -c 600 "$P/bench_traced.json"
