@@ -35,7 +35,7 @@ Seg ident(const float* x, int ld, int col0, int len, int which) {
 }
 BnView bnview(const SlnVaeUnit& u, double* sums, int C, int rows, int col0, int mode) {
   BnView v; std::memset(&v, 0, sizeof(v));
-  v.mode = mode; v.eps = 1e-5f; v.n_rows = (float)(rows > 0 ? rows : 1);
+  v.mode = mode; v.eps = 1e-5f; v.n_rows = (float)(rows > 0 ? rows : 1); v.rn = 1.0 / (double)(rows > 0 ? rows : 1);
   if (mode == SLN_BN_NONE) return v;
   v.sums = sums + col0; v.gsums = nullptr; v.cstride = C;
   v.gamma = u.bn_weight + col0; v.beta = u.bn_bias + col0; v.rmean = u.bn_running_mean + col0; v.rvar = u.bn_running_var + col0;

@@ -601,10 +601,10 @@ inline bool tn_prepare(GemmTNArgs& a) {   // fills rows_per_block; returns wheth
   if (a.rows_per_block <= 0) {
     // measured on MI355X (tools/gemm_bench.py): ~768 blocks in flight, but never fewer than 256 rows per block -
     // below that the per-block prologue and the dW atomics (64x64 per block) dominate; chunks a multiple of BK rows
-    const int target = 768;
+    static const int target = std::getenv("SLN_TN_TARGET") ? std::atoi(std::getenv("SLN_TN_TARGET")) : 768;
+    static const int minrows = std::getenv("SLN_TN_MINROWS") ? std::atoi(std::getenv("SLN_TN_MINROWS")) : 256;
     const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64);
     int chunks = sln_cdiv(target, tiles);
-    const int minrows = 256;
     int rpb = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
     a.rows_per_block = rpb < minrows ? minrows : rpb;
   }

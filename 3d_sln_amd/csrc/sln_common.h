@@ -28,19 +28,24 @@ struct BnView {
   float n_rows;          // rows the sums run over (exact in fp32 below 2^24); the reciprocal is taken in fp64: 1.0f / 12 is 6e-8
                          // off, and var = E[x^2] - mean^2 amplifies that by (mean / sigma)^2
   float eps;
+  double rn;             // 1 / n_rows in fp64, taken on the host
 };
 
+// The coefficient set-up sits in the prologue of EVERY GEMM block, in front of its first MFMA: independent loads are issued
+// together (they used to alternate with the arithmetic that consumed them: 3-4 serialized memory round trips), the row-count
+// reciprocal comes from the host, and 1/sqrt is v_rsq_f32 on the fp32 variance (the variance itself - E[x^2] - mean^2, which
+// cancels - stays in fp64; round 1 used three fp64 divisions per column here).
 __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean, float& istd) {
   if (b.mode == SLN_BN_TRAIN) {
-    const double rn = 1.0 / (double)b.n_rows;
-    double m = b.sums[c] * rn;
-    double v = b.sums[b.cstride + c] * rn - m * m;
+    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    const double m = s1 * b.rn;
+    double v = fma(-m, m, s2 * b.rn);
     v = v < 0.0 ? 0.0 : v;
     mean = (float)m;
-    istd = (float)(1.0 / sqrt(v + (double)b.eps));
+    istd = __builtin_amdgcn_rsqf((float)v + b.eps);
   } else if (b.mode == SLN_BN_EVAL) {
     mean = b.rmean[c];
-    istd = 1.0f / sqrtf(b.rvar[c] + b.eps);
+    istd = __builtin_amdgcn_rsqf(b.rvar[c] + b.eps);
   } else {
     mean = 0.f;
     istd = 1.f;
@@ -49,23 +54,26 @@ __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean
 // forward coefficients: h = max(scale*x + shift, 0)
 __device__ __forceinline__ void bn_fwd_coef(const BnView& b, int c, float& scale, float& shift) {
   if (b.mode == SLN_BN_NONE) { scale = 1.f; shift = 0.f; return; }
+  const float gamma = b.gamma[c], beta = b.beta[c];
   float mean, istd;
   bn_mean_istd(b, c, mean, istd);
-  scale = b.gamma[c] * istd;
-  shift = b.beta[c] - mean * scale;
+  scale = gamma * istd;
+  shift = beta - mean * scale;
 }
 // backward coefficients: dX = p0*g + p1*x + p2  (g = relu-masked incoming gradient)
 //   train: dX = scale*(g - mean(g) - xhat*mean(g*xhat)), xhat = (x-mean)*istd
 __device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, float& p1, float& p2) {
   if (b.mode == SLN_BN_NONE) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
+  const float gamma = b.gamma[c];
+  double g1 = 0.0, g2 = 0.0;
+  if (b.mode == SLN_BN_TRAIN) { g1 = b.gsums[c]; g2 = b.gsums[b.cstride + c]; }
   float mean, istd;
   bn_mean_istd(b, c, mean, istd);
-  float scale = b.gamma[c] * istd;
+  float scale = gamma * istd;
   p0 = scale;
   if (b.mode == SLN_BN_TRAIN) {
-    const double rn = 1.0 / (double)b.n_rows;
-    float c1 = (float)(b.gsums[c] * rn);
-    float c2 = (float)(b.gsums[b.cstride + c] * rn);
+    float c1 = (float)(g1 * b.rn);
+    float c2 = (float)(g2 * b.rn);
     p1 = -scale * istd * c2;
     p2 = -scale * c1 - p1 * mean;
   } else {

@@ -152,7 +152,7 @@ struct SlnVae {
   }
   BnView view(int inst, int col0, bool training) const {
     BnView v; std::memset(&v, 0, sizeof(v));
-    v.eps = kBnEps; v.n_rows = 1.f; v.mode = SLN_BN_NONE;
+    v.eps = kBnEps; v.n_rows = 1.f; v.rn = 1.0; v.mode = SLN_BN_NONE;
     if (inst < 0) return v;
     const BnInst& b = bns[inst];
     const Unit& u = units[b.unit];
@@ -161,7 +161,7 @@ struct SlnVae {
     v.sums = b.sums + col0; v.gsums = b.gsums + col0; v.cstride = b.C;
     v.gamma = u.p.bn_weight + col0; v.beta = u.p.bn_bias + col0;
     v.rmean = u.p.bn_running_mean + col0; v.rvar = u.p.bn_running_var + col0;
-    v.n_rows = (float)(b.rows > 0 ? b.rows : 1);
+    v.n_rows = (float)(b.rows > 0 ? b.rows : 1); v.rn = 1.0 / (double)(b.rows > 0 ? b.rows : 1);
     return v;
   }
   static Seg seg_ident(const float* x, int ld, int col0, int len, int which) {

@@ -66,7 +66,7 @@ def test_linear_wgrad(R, N, K):
 
 
 # ----------------------------------------------------------------------------- golden fixtures
-def _fp64_grads(cfg, sd64, b64, eps64, perturb_seed=None):
+def _fp64_grads(cfg, sd64, b64, eps64, perturb_seed=None, kl_weight=KL_WEIGHT):
     """Gradients of one oracle iteration.  ``perturb_seed``: every floating parameter is first moved by a relative 2^-23
     (one fp32 rounding) in a random direction - the spread of the exact gradient under such perturbations is the
     conditioning of the problem itself (train-mode BatchNorm over 8 rows: ReLU masks and L1 signs flip)."""
@@ -77,7 +77,7 @@ def _fp64_grads(cfg, sd64, b64, eps64, perturb_seed=None):
             s[k] = s[k] * (1.0 + (torch.rand(s[k].shape, generator=gen, dtype=s[k].dtype) * 2 - 1) * 2.0 ** -23)
     m = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
     v = {k: torch.zeros_like(s[k]) for k in vae_ref.trainable_keys(cfg)}
-    _, _, grads = vae_ref.train_step(s, cfg, b64, eps64, KL_WEIGHT, m, v, 1)
+    _, _, grads = vae_ref.train_step(s, cfg, b64, eps64, kl_weight, m, v, 1)
     return {k: (grads[k].numpy() if k in grads else np.zeros(tuple(s[k].shape))) for k in vae_ref.trainable_keys(cfg)}
 
 
@@ -403,11 +403,25 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
     # The tight comparison is the 64-graph case; the other sizes check that the large-tile / separately launched kernels and the
     # odd shapes (no dimension a multiple of 4) produce the same tensors: max error within 2 % of the tensor's scale, or relative
     # L2 error within 10 %.
+    # the yardstick at 64 graphs: the fp32 scatter of the reference path itself - its gradient and the fp32 oracle with every
+    # parameter moved by one ulp (three rounding trajectories) - measured against the fp64 gradient; ONE fp32 sample
+    # under-estimates the spread of a tensor by chance (the problem is chaotic at the 1e-2 level, see above)
+    spread = {}
+    if n_graphs == 64:
+        samples = [{k: g.numpy() for k, g in grads.items()}]
+        for ps in (1, 2, 3):
+            samples.append(_fp64_grads(cfg, {k: v.clone() for k, v in sd.items()}, batch[:5], eps, perturb_seed=ps))
+        for smp in samples:
+            for k in grads64:
+                if k in smp:
+                    spread[k] = max(spread.get(k, 0.0), float(np.abs(smp[k] - grads64[k].numpy()).max()))
     for k, gr in grads.items():
         try:
             got, r64 = named[k].grad.cpu().numpy(), grads64[k].numpy()
             if n_graphs == 64:
-                assert_close_conditioned(got, r64, gr.numpy(), "c2:grad:" + k, atol=5e-6 * gscale, k=4.0)
+                err, scale = max_err(got, r64)
+                assert np.isfinite(err) and err <= 5e-6 * gscale + 1e-4 * scale + 4.0 * spread[k], \
+                    "c2:grad:%s: err %.3e, scale %.3e, fp32-reference spread %.3e" % (k, err, scale, spread[k])
             else:
                 try:
                     assert_close_conditioned(got, r64, gr.numpy(), "c2:grad:" + k, rtol=2e-2, atol=5e-6 * gscale, k=4.0)
