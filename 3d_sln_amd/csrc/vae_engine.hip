@@ -142,7 +142,8 @@ struct SlnVae {
   hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_O[4] = {-1, -1, -1, -1}, graph_T[4] = {-1, -1, -1, -1};
 
   // ------------------------------------------------------------------------------------------
-  int unit_of(int net, int l, int k) const { return 8 + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
+  bool gconv_only = false;        // a bare GraphTripleConvNet (sln_gconv_net_*): units = the modules' four Linears, one net, no heads
+  int unit_of(int net, int l, int k) const { return (gconv_only ? 0 : 8) + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
   int unit_boxnet(int k) const { return 8 + 2 * nmod * 4 + k; }
   int unit_anglenet(int k) const { return 8 + 2 * nmod * 4 + 2 + k; }
 
@@ -365,7 +366,7 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   dbp = b.take<float>(Om * dbp_ld); dlogits = b.take<float>(Om * cfg.n_angle);
   g_bn = b.take<float>(Om * H); g_an = b.take<float>(Om * H);
   d_bx = b.take<float>(Om * (W + n_attr_e)); d_ax = b.take<float>(Om * W);
-  const size_t Dm = W;
+  const size_t Dm = (size_t)(Dec > Ddc ? Dec : Ddc);      // = 2E for the VAE
   g4 = b.take<float>(Om * Dm); g3 = b.take<float>(Om * H); dM = b.take<float>(Om * H);
   g2 = b.take<float>(Tm * (2 * H + Dm)); g1 = b.take<float>(Tm * H);
   dG[0] = b.take<float>(Tm * 3 * Dm); dG[1] = b.take<float>(Tm * 3 * Dm);
@@ -1098,6 +1099,131 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
   }
   if (mode == SlnVae::TRAIN_ENCODER_BWD) return 0;       // the losses were handed out by the first half
   RET_IF(copy_out(losses_out, h->losses, 4, st));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A bare GraphTripleConvNet with autograd (models/graph.py:57-143 used on its own): the engine's layer kernels without the
+// VAE around them.  Same handle type; destroy / workspace_bytes / bind are the sln_vae_* ones (SlnVaeTensors carries only
+// units_host: 4 units per module - net1.0, net1.1, net2.0, net2.1 - with weights AND gradient pointers).
+// ---------------------------------------------------------------------------------------------
+int sln_gconv_net_create(int D, int H, int num_layers, int recurrent, int batch_norm, SlnVae** out) {
+  if (!out || D <= 0 || H <= 0 || num_layers < 1 || D % 4 || H % 4) return SLN_E_UNSUPPORTED;
+  SlnVae* h = new (std::nothrow) SlnVae();
+  if (!h) return SLN_E_BADARG;
+  std::memset(&h->cfg, 0, sizeof(h->cfg));
+  h->cfg.gconv_num_layers = num_layers; h->cfg.recurrent = recurrent; h->cfg.batch_norm = batch_norm; h->cfg.decoder_cat = 1;
+  h->cfg.box_dim = 4; h->cfg.n_angle = 4; h->cfg.num_preds = 1 << 30;
+  h->gconv_only = true;
+  h->E = 0; h->H = H; h->L = num_layers; h->nmod = recurrent ? 1 : num_layers;
+  h->n_obj_e = h->n_attr_e = h->n_box_e = h->n_angle_e = 0;
+  h->Dec = D; h->Ddc = D;
+  h->units.resize((size_t)h->nmod * 4);
+  for (int m = 0; m < h->nmod; ++m) {
+    Unit* u = &h->units[(size_t)m * 4];
+    u[0].out = H; u[0].in = 3 * D; u[1].out = 2 * H + D; u[1].in = H; u[2].out = H; u[2].in = H; u[3].out = D; u[3].in = H;
+    for (int k = 0; k < 4; ++k) u[k].bn = batch_norm != 0;
+  }
+  h->layers.resize(num_layers);
+  for (int l = 0; l < num_layers; ++l) {
+    Layer& ly = h->layers[l];
+    ly.net = 0; ly.first = l == 0; ly.last = l == num_layers - 1; ly.D = D; ly.u0 = h->unit_of(0, l, 0);
+    const int Cs[4] = {H, 2 * H + D, H, D};
+    for (int k = 0; k < 4; ++k) {
+      if (!h->units[ly.u0 + k].bn) continue;
+      BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;
+      ly.bn[k] = (int)h->bns.size(); h->bns.push_back(b);
+    }
+  }
+  h->n_bn_enc = (int)h->bns.size();
+  h->use_dual = true; h->use_group = false; h->use_side = false;
+  *out = h;
+  return 0;
+}
+
+// edges [T,2] int64 (s, o) of the graph the next forward / backward run on
+int sln_gconv_net_set_edges(SlnVae* h, const int64_t* edges, int O, int T, void* stream) {
+  if (!h || !h->bound || !h->gconv_only) return SLN_E_STATE;
+  if (O <= 0 || T < 0 || O > h->maxO || T > h->maxT || (T > 0 && !edges)) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const bool shape_changed = O != h->O || T != h->T || !h->batch_set;
+  h->O = O; h->T = T; h->g.T = T; h->g.O = O;
+  if (shape_changed) {
+    for (auto& ly : h->layers)
+      for (int k = 0; k < 4; ++k)
+        if (ly.bn[k] >= 0) h->bns[ly.bn[k]].rows = k < 2 ? T : O;
+    HIP_RET(hipStreamSynchronize(st));
+    RET_IF(upload_bn_table(h));
+  }
+  HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
+  RET_IF(sln_launch_graph_prep(edges, T, O, 1 << 30, h->g, h->err_flag, st, 1, 0));
+  h->batch_set = true; h->have_enc = false;
+  return 0;
+}
+
+// (new_obj [O,D], new_pred [T,D]) = GraphTripleConvNet(obj_vecs [O,D], pred_vecs [T,D], edges); pre-activations stay in the
+// workspace for sln_gconv_net_backward.  training: batch statistics + running-statistics update.
+int sln_gconv_net_forward(SlnVae* h, const float* obj_vecs, const float* pred_vecs, float* new_obj, float* new_pred, int training,
+                          void* stream) {
+  if (!h || !h->gconv_only || !h->batch_set) return SLN_E_STATE;
+  if (!obj_vecs || !pred_vecs || !new_obj || !new_pred) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = h->Dec, H = h->H, L = h->L;
+  const bool tr = training != 0;
+  if (tr && h->stats_doubles) HIP_RET(hipMemsetAsync(h->stats_base, 0, h->stats_doubles * sizeof(double), st));
+  RET_IF(copy_out(h->X0e, obj_vecs, (size_t)h->O * D, st));
+  RET_IF(copy_out(h->P0e, pred_vecs, (size_t)h->T * D, st));
+  for (int l = 0; l < L; ++l) RET_IF(h->gconv_forward(l, tr, st));
+  const Layer& ll = h->layers[L - 1];
+  RET_IF(sln_launch_bn_relu_apply(ll.A4, D, 0, D, h->O, h->view(ll.bn[3], 0, tr), new_obj, D, st));
+  RET_IF(sln_launch_bn_relu_apply(ll.A2, 2 * H + D, H, D, h->T, h->view(ll.bn[1], H, tr), new_pred, D, st));
+  if (tr) RET_IF(h->run_bn_updates(0, (int)h->bns.size(), st));
+  h->enc_training = tr; h->have_enc = true;
+  return 0;
+}
+
+// Backward of the last sln_gconv_net_forward: d_obj_vecs [O,D], d_pred_vecs [T,D] (either may be NULL), parameter gradients
+// accumulated (+=) into the d_* pointers of the bound units.
+int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new_pred, float* d_obj_vecs, float* d_pred_vecs,
+                           void* stream) {
+  if (!h || !h->gconv_only || !h->have_enc) return SLN_E_STATE;
+  if (!d_new_obj || !d_new_pred) return SLN_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = h->Dec, L = h->L;
+  const bool tr = h->enc_training;
+  h->ev_next = 0;
+  if (h->stats_doubles) HIP_RET(hipMemsetAsync(h->gstats_base, 0, h->stats_doubles * sizeof(double), st));
+  h->wt_fresh = false;                      // the caller's optimizer owns the parameters: rebuild W^T every backward
+  RET_IF(h->refresh_transposes(st));
+  {
+    const Layer& ll = h->layers[L - 1];
+    BnView v = h->view(ll.bn[3], 0, tr);
+    RET_IF(sln_launch_mask_gstats(d_new_obj, D, nullptr, 0, ll.A4, D, v, h->O, D, h->g4, D,
+                                  v.mode != SLN_BN_NONE ? h->bns[ll.bn[3]].gsums : nullptr, D, st));
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const int slot = l & 1;
+    const float* dP = (l == L - 1) ? d_new_pred : h->dG[slot ^ 1];
+    RET_IF(h->gconv_backward(l, dP, l == L - 1 ? D : 3 * D, l == L - 1 ? 0 : D, slot, tr, st));
+    if (l > 0) {
+      const Layer& pv = h->layers[l - 1];
+      BnView v = h->view(pv.bn[3], 0, tr);
+      RET_IF(sln_launch_gather_bwd(h->dG[slot], 3 * D, D, h->g, h->O, nullptr, 0, pv.A4, D, v, 1, h->g4, D,
+                                   v.mode != SLN_BN_NONE ? h->bns[pv.bn[3]].gsums : nullptr, D, st));
+    } else {
+      BnView none = h->view(-1, 0, tr);
+      RET_IF(sln_launch_gather_bwd(h->dG[slot], 3 * D, D, h->g, h->O, nullptr, 0, nullptr, 0, none, 0, h->dX0, D, nullptr, 0, st));
+      if (d_obj_vecs) RET_IF(copy_out(d_obj_vecs, h->dX0, (size_t)h->O * D, st));
+      if (d_pred_vecs && h->T > 0)
+        HIP_RET(hipMemcpy2DAsync(d_pred_vecs, sizeof(float) * D, h->dG[slot] + D, sizeof(float) * 3 * D, sizeof(float) * D, (size_t)h->T,
+                                 hipMemcpyDeviceToDevice, st));
+    }
+  }
+  if (!h->bns.empty()) {
+    int maxc = 0;
+    for (auto& b : h->bns) maxc = b.C > maxc ? b.C : maxc;
+    RET_IF(sln_launch_bn_param_grads(h->bn_table_dev, (int)h->bns.size(), maxc, h->cfg.recurrent ? 0 : 1, st));
+  }
   return 0;
 }
 

@@ -5,7 +5,7 @@ Mirrors models/graph.py of the reference: ``make_mlp`` (:10-27), ``_init_weights
 parameters (so ``state_dict`` keys are the reference's: ``gconvs.{i}.net1.{0,1,3,4}.*``);
 the arithmetic runs in the HIP engine (csrc/vae_engine.hip), which the owning
 ``Sg2ScVAEModel`` drives.  A GraphTripleConv(Net) used on its own also runs on the
-engine's kernels through ``forward`` below.
+engine's kernels through ``forward`` below, with autograd to both inputs and every parameter.
 """
 import ctypes as C
 
@@ -65,8 +65,8 @@ class GraphTripleConv(nn.Module):
         self.net2.apply(_init_weights)
 
     def forward(self, obj_vecs, pred_vecs, edges):
-        """(new_obj_vecs [O, Dout], new_pred_vecs [T, Dout]) - inference only (see _gconv_forward)."""
-        return _gconv_forward([self], 1, obj_vecs, pred_vecs, edges, self.training)
+        """(new_obj_vecs [O, Dout], new_pred_vecs [T, Dout]); differentiable when output_dim == input_dim (see _gconv_forward)."""
+        return _gconv_forward([self], 1, obj_vecs, pred_vecs, edges, self.training, owner=self)
 
 
 class GraphTripleConvNet(nn.Module):
@@ -82,18 +82,124 @@ class GraphTripleConvNet(nn.Module):
                             mlp_normalization=mlp_normalization) for _ in range(n_mod)])
 
     def forward(self, obj_vecs, pred_vecs, edges):
-        return _gconv_forward(list(self.gconvs), self.num_layers, obj_vecs, pred_vecs, edges, self.training)
+        return _gconv_forward(list(self.gconvs), self.num_layers, obj_vecs, pred_vecs, edges, self.training, owner=self)
 
 
-def _gconv_forward(modules, num_layers, obj_vecs, pred_vecs, edges, training):
-    """Standalone GraphTripleConv(Net).forward on the HIP kernels (sln_gconv_forward).  No autograd: training runs
-    through Sg2ScVAEModel (fused forward/backward in csrc/vae_engine.hip)."""
-    if torch.is_grad_enabled() and (obj_vecs.requires_grad or pred_vecs.requires_grad or
-                                    any(p.requires_grad for m in modules for p in m.parameters())):
-        raise NotImplementedError("standalone GraphTripleConv(Net).forward is inference-only on the HIP path "
-                                  "(wrap the call in torch.no_grad(); train through Sg2ScVAEModel)")
+class _GconvEngine:
+    """Engine handle for a bare GraphTripleConv(Net) with autograd (sln_gconv_net_*): weights bound by pointer, parameter
+    gradients accumulated by the kernels into buffers owned here (handed to ``p.grad`` after every backward)."""
+
+    def __init__(self, modules, num_layers, device):
+        m0 = modules[0]
+        self.D, self.H, self.L, self.modules = m0.input_dim, m0.hidden_dim, num_layers, modules
+        self.recurrent = len(modules) == 1 and num_layers > 1
+        pairs = [pr for m in modules for pr in (mlp_linears(m.net1) + mlp_linears(m.net2))]
+        self.bn = any(bn is not None for _, bn in pairs)
+        self.params = [p for m in modules for p in m.parameters()]
+        self.key = tuple((p.data_ptr(), p._version) for p in self.params)
+        self.gbuf = {id(p): torch.zeros_like(p) for p in self.params}
+        L = _lib.lib()
+        h = C.c_void_p()
+        _lib.check(L.sln_gconv_net_create(self.D, self.H, num_layers, int(self.recurrent), int(self.bn), C.byref(h)), "sln_gconv_net_create")
+        self.h = h
+        self.units = (_lib.SlnVaeUnit * len(pairs))()
+        for u, (lin, bn) in zip(self.units, pairs):
+            u.weight, u.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
+            u.d_weight, u.d_bias = self.gbuf[id(lin.weight)].data_ptr(), self.gbuf[id(lin.bias)].data_ptr()
+            if bn is not None:
+                u.bn_weight, u.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
+                u.bn_running_mean, u.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                u.bn_num_batches_tracked = bn.num_batches_tracked.data_ptr()
+                u.d_bn_weight, u.d_bn_bias = self.gbuf[id(bn.weight)].data_ptr(), self.gbuf[id(bn.bias)].data_ptr()
+        self.maxO = self.maxT = 0
+        self.device = device
+
+    def ensure(self, O, T):
+        if O <= self.maxO and T <= self.maxT:
+            return
+        L = _lib.lib()
+        maxO, maxT = max(O, 64, self.maxO), max(T, 64, self.maxT)
+        nbytes = L.sln_vae_workspace_bytes(self.h, maxO, maxT)
+        if nbytes < 0:
+            _lib.check(int(nbytes), "sln_vae_workspace_bytes")
+        self.ws = torch.zeros(int(nbytes), dtype=torch.uint8, device=self.device)
+        torch.cuda.current_stream(self.device).synchronize()          # bind writes with blocking copies (see sln_vae_bind)
+        t = _lib.SlnVaeTensors()
+        t.units_host = self.units
+        _lib.check(L.sln_vae_bind(self.h, C.byref(t), C.c_void_p(self.ws.data_ptr()), int(nbytes), maxO, maxT), "sln_vae_bind")
+        self.maxO, self.maxT = maxO, maxT
+
+    def __del__(self):
+        try:
+            _lib.lib().sln_vae_destroy(self.h)
+        except Exception:
+            pass
+
+
+class _GconvNetFn(torch.autograd.Function):
+    """(new_obj, new_pred) = net(obj_vecs, pred_vecs, edges) with gradients w.r.t. both inputs and every parameter."""
+
+    @staticmethod
+    def forward(ctx, anchor, obj_vecs, pred_vecs, edges, eng, training):
+        L = _lib.lib()
+        x = obj_vecs.detach().float().contiguous(); p = pred_vecs.detach().float().contiguous()
+        e = edges.to(torch.int64).contiguous()
+        O, T = x.shape[0], p.shape[0]
+        eng.ensure(O, T)
+        st = _lib.current_stream_ptr()
+        _lib.check(L.sln_gconv_net_set_edges(eng.h, _lib.ptr(e), O, T, st), "sln_gconv_net_set_edges")
+        new_obj = torch.empty(O, eng.D, device=x.device); new_pred = torch.empty(T, eng.D, device=x.device)
+        _lib.check(L.sln_gconv_net_forward(eng.h, _lib.ptr(x), _lib.ptr(p), _lib.ptr(new_obj), _lib.ptr(new_pred), int(training), st),
+                   "sln_gconv_net_forward")
+        eng.generation = getattr(eng, "generation", 0) + 1
+        ctx.eng, ctx.gen, ctx.shapes = eng, eng.generation, (O, T)
+        return new_obj, new_pred
+
+    @staticmethod
+    def backward(ctx, d_obj, d_pred):
+        eng = ctx.eng
+        if ctx.gen != eng.generation:
+            raise _lib.SlnError("backward() through a stale forward: another forward ran on this GraphTripleConv(Net) in between")
+        O, T = ctx.shapes
+        dev = eng.device
+        d_obj = torch.zeros(O, eng.D, device=dev) if d_obj is None else d_obj.float().contiguous()
+        d_pred = torch.zeros(T, eng.D, device=dev) if d_pred is None else d_pred.float().contiguous()
+        dx = torch.empty(O, eng.D, device=dev); dp = torch.empty(T, eng.D, device=dev)
+        for buf in eng.gbuf.values():
+            buf.zero_()
+        _lib.check(_lib.lib().sln_gconv_net_backward(eng.h, _lib.ptr(d_obj), _lib.ptr(d_pred), _lib.ptr(dx), _lib.ptr(dp),
+                                                     _lib.current_stream_ptr()), "sln_gconv_net_backward")
+        for prm in eng.params:
+            if prm.requires_grad:
+                g = eng.gbuf[id(prm)]
+                prm.grad = g.clone() if prm.grad is None else prm.grad + g
+        return None, dx, dp, None, None, None
+
+
+def _gconv_autograd(owner, modules, num_layers, obj_vecs, pred_vecs, edges, training):
+    m0 = modules[0]
+    if m0.input_dim != m0.output_dim or m0.input_dim % 4 or m0.hidden_dim % 4:
+        raise NotImplementedError("autograd through a standalone GraphTripleConv needs output_dim == input_dim (what "
+                                  "GraphTripleConvNet builds) and dimensions that are multiples of 4; train other shapes through Sg2ScVAEModel")
+    eng = getattr(owner, "_sln_engine", None)
+    key = tuple(p.data_ptr() for m in modules for p in m.parameters())
+    if eng is None or eng.key_ptrs != key or eng.device != obj_vecs.device:
+        eng = _GconvEngine(modules, num_layers, obj_vecs.device)
+        eng.key_ptrs = key
+        object.__setattr__(owner, "_sln_engine", eng)
+        object.__setattr__(owner, "_sln_anchor", torch.zeros(1, device=obj_vecs.device, requires_grad=True))
+    return _GconvNetFn.apply(owner._sln_anchor, obj_vecs, pred_vecs, edges, eng, training)
+
+
+def _gconv_forward(modules, num_layers, obj_vecs, pred_vecs, edges, training, owner=None):
+    """Standalone GraphTripleConv(Net).forward on the HIP kernels.  With gradients enabled it runs on an engine handle that
+    keeps the pre-activations for backward (sln_gconv_net_*: models/graph.py:57-111,136-143 are differentiable in the
+    reference); under torch.no_grad() on the workspace-per-call inference entry point (sln_gconv_forward)."""
     if obj_vecs.device.type != 'cuda':
         raise _lib.SlnError("GraphTripleConv runs on the MI355X only (no CPU fallback)")
+    if torch.is_grad_enabled() and (obj_vecs.requires_grad or pred_vecs.requires_grad or
+                                    any(p.requires_grad for m in modules for p in m.parameters())):
+        return _gconv_autograd(owner if owner is not None else modules[0], modules, num_layers, obj_vecs, pred_vecs, edges, training)
     m0 = modules[0]
     D, H, Do = m0.input_dim, m0.hidden_dim, m0.output_dim
     units = (_lib.SlnVaeUnit * (4 * len(modules)))()

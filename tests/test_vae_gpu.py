@@ -556,8 +556,44 @@ def test_standalone_graph_triple_conv_net(norm, mode, layers):
                 if "running" in k or "num_batches" in k:
                     assert_close(v.cpu().numpy(), sdr["gconv_net_ec." + k].numpy(), k)
             sd = sdr                       # carry the updated running statistics into the eval comparison
+    # autograd (models/graph.py:57-111,136-143 are differentiable): gradients w.r.t. both inputs and every parameter against
+    # CPU autograd through the oracle, train-mode and eval-mode BatchNorm; a second backward accumulates into .grad
+    keys = [k for k in sd if k.startswith("gconv_net_ec.") and sd[k].is_floating_point() and "running" not in k]
+    wo = torch.randn(O, 32, generator=g); wp = torch.randn(T, 32, generator=g)
+    for training in (True, False):
+        net.train(training)
+        net.zero_grad(set_to_none=True)
+        sdr = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k in keys:
+            sdr[k].requires_grad_(True)
+        x1 = x.double().requires_grad_(True); p1 = p.double().requires_grad_(True)
+        ro, rp = vae_ref.gconv_net_apply(sdr, cfg, "ec", x1, p1, edges, training)
+        ((ro * wo.double()).sum() + (rp * wp.double()).sum()).backward()
+        before = {k: v.clone() for k, v in net.state_dict().items()}
+        x2 = x.cuda().requires_grad_(True); p2 = p.cuda().requires_grad_(True)
+        ho, hp = net(x2, p2, edges.cuda())
+        ((ho * wo.cuda()).sum() + (hp * wp.cuda()).sum()).backward()
+        assert_close(ho.detach().cpu().numpy(), ro.detach().numpy(), "autograd forward obj training=%s" % training)
+        gs = max(float(sdr[k].grad.abs().max()) for k in keys if sdr[k].grad is not None)
+        assert_close(x2.grad.cpu().numpy(), x1.grad.numpy(), "d obj_vecs training=%s" % training, rtol=2e-4, atol=1e-5 * float(x1.grad.abs().max()))
+        assert_close(p2.grad.cpu().numpy(), p1.grad.numpy(), "d pred_vecs training=%s" % training, rtol=2e-4, atol=1e-5 * float(p1.grad.abs().max()))
+        named = dict(net.named_parameters())
+        for k in keys:
+            ref = sdr[k].grad
+            if ref is None:
+                continue
+            got = named[k[len("gconv_net_ec."):]].grad
+            assert_close(got.cpu().numpy(), ref.numpy(), "d %s training=%s" % (k, training), rtol=2e-4, atol=2e-6 * gs)
+        if training:
+            net.load_state_dict(before)           # the autograd forward moved the running statistics once more
+    g1 = {k: v.grad.clone() for k, v in net.named_parameters()}
+    ho, hp = net(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
+    ((ho * wo.cuda()).sum() + (hp * wp.cuda()).sum()).backward()
+    for k, v in net.named_parameters():
+        assert_close(v.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), "accumulated " + k, rtol=1e-4, atol=1e-6 * float(g1[k].abs().max()) + 1e-9)
+    odd = G.GraphTripleConv(32, output_dim=48, hidden_dim=64).cuda()
     with pytest.raises(NotImplementedError):
-        net(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
+        odd(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
 
 
 def test_high_degree_room_node_beyond_the_lds_entry_cache():
