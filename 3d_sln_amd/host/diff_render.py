@@ -53,7 +53,16 @@ def class_tables(class_names):
             dch.append(-1)
         else:
             dch.append(k); k += 1
+    # the fused pass writes the reference's 70 channels: depth + 40 NYU one-hot + (len(classes) - 3) depth-hot planes, 29 with
+    # the shipped valid_types.json (diff_render.py:377-379); a longer class list would not fit the output tensor
+    if k > N_DEPTH_HOT:
+        raise ValueError("%d object classes besides wall / floor / ceiling: the fused scene pass holds %d depth-hot channels "
+                         "(the reference's valid_types.json has 29)" % (k, N_DEPTH_HOT))
     return classes, chan, dch
+
+
+N_DEPTH_HOT = 29
+N_SCENE_CHANNELS = 41 + N_DEPTH_HOT
 
 
 class _SceneFn(torch.autograd.Function):
@@ -66,7 +75,7 @@ class _SceneFn(torch.autograd.Function):
         B, F = faces.shape[0], faces.shape[1]
         dev = faces.device
         ws = torch.empty(int(L.sln_scene_workspace_bytes(B, F, image_size)), dtype=torch.uint8, device=dev)
-        out = torch.empty(B, 70, image_size, image_size, device=dev)
+        out = torch.empty(B, N_SCENE_CHANNELS, image_size, image_size, device=dev)
         nc = chan.numel()
         _lib.check(L.sln_scene_forward(_lib.ptr(faces), _lib.ptr(face_class), B, F, image_size, nc, _lib.ptr(chan), _lib.ptr(dch),
                                        0.1, float(near_rgb), 100.0, 1e-3, _lib.ptr(ws), _lib.ptr(out), _lib.current_stream_ptr()),
@@ -109,15 +118,27 @@ def scene_render(vertices_buf, face_buf, class_ranges, room_box, image_size=fina
     faces, cls, classes, chan, dch = cull_and_classify(vertices_buf, face_buf, class_ranges, R, t)
     faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)                 # fill_back
     cls = torch.cat((cls, cls))[None].contiguous()
+    faces, cls = _never_empty(faces, cls)
     fxyz = nr.project_faces(vertices_buf, faces, K, R, t, inter_out)
     chan_t = torch.tensor(chan, dtype=torch.int32, device=dev)
     dch_t = torch.tensor(dch, dtype=torch.int32, device=dev)
     return _SceneFn.apply(fxyz, cls, chan_t, dch_t, image_size, near)
 
 
+def _never_empty(faces, face_class):
+    """Every face culled (the reference then renders an empty image): keep one degenerate triangle of no class so that the
+    kernels have a face list to walk; it covers no pixel."""
+    if faces.shape[1] > 0:
+        return faces, face_class
+    B = faces.shape[0]
+    return (torch.zeros(B, 1, 3, dtype=faces.dtype, device=faces.device),
+            torch.full((B, 1), -1, dtype=torch.int32, device=faces.device))
+
+
 def scene_render_batch(vertices, faces, face_class, chan, dch, K, R, t, image_size=final_out, near=0.001):
     """Batched fused pass for B rooms with equal (padded) V and F: vertices [B,V,3], faces [B,F,3] int32 (already
     culled, fill_back applied by the caller or not at all), face_class [B,F] int32, K/R/t [B,...]."""
+    faces, face_class = _never_empty(faces, face_class)
     fxyz = nr.project_faces(vertices, faces, K, R, t, inter_out)
     return _SceneFn.apply(fxyz, face_class.contiguous(), chan, dch, image_size, near)
 

@@ -331,3 +331,26 @@ def test_c3_sixteen_rooms_at_size():
         assert_close(o, r, "room %d final" % k, rtol=1e-4, atol=1e-5)
         assert_close(Vb.grad[k, :V.shape[0]].cpu().numpy(), v1.grad[0].numpy(), "room %d dV" % k, rtol=1e-4,
                      atol=2e-4 * v1.grad.abs().max().item())
+
+
+def test_scene_with_every_face_culled_renders_the_empty_image():
+    """All faces behind the near plane (diff_render.py:346-356 drops them): the reference renders an empty image - background
+    depth, no class pixels - and no gradient reaches the vertices; the fused pass must not refuse the empty face list."""
+    DR = pkg("host.diff_render")
+    V, F, ranges, box = rr.synth_room(4, n_objects=3, target_faces=120)
+    Vb = torch.from_numpy(V)[None].cuda()
+    Vb = (Vb + torch.tensor([0.0, 0.0, 50.0], device="cuda")).requires_grad_(True)      # the whole room far behind the camera
+    out = DR.scene_render(Vb, torch.from_numpy(F)[None].cuda(), ranges, torch.from_numpy(box), image_size=64)
+    assert out.shape == (1, 70, 64, 64) and torch.isfinite(out).all()
+    assert float(out[0, 1:41].abs().max()) == 0.0
+    out.sum().backward()
+    assert float(Vb.grad.abs().max()) == 0.0
+
+
+def test_class_list_longer_than_the_depth_hot_planes_is_refused():
+    DR = pkg("host.diff_render")
+    names = ["wall", "floor", "ceiling"] + ["bed"] * 1
+    DR.class_tables(names)
+    with pytest.raises(ValueError):
+        others = [c.replace(" ", "_") for c in DR.nyu_class if c not in ("wall", "floor", "ceiling")]
+        DR.class_tables(["wall", "floor", "ceiling"] + others[:30])
