@@ -83,17 +83,34 @@ __global__ void csr_fill_kernel(GraphCsr g, int T) {
   g.ent[pos] = e;
 }
 
-__global__ void csr_sort_kernel(GraphCsr g, int O) {
-  // ascending entry id inside each row == reference scatter_add order (all subject rows in triple
-  // order, then all object rows, models/graph.py:97-98); rows are short (<= ~2x objects per room).
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ascending entry id inside each row == reference scatter_add order (all subject rows in triple order, then all object rows,
+// models/graph.py:97-98).  One wavefront per row, rank by counting: a lane's entry goes to position #(smaller entries).  (One
+// THREAD per row with an insertion sort took 23 us per batch - the room node of every graph has 31+ entries - on the critical
+// path of every training step, outside the captured iteration.)
+constexpr int SORT_MAXDEG = 1024;      // entries of a row held in LDS; longer rows fall back to the serial sort of one lane
+__global__ __launch_bounds__(64) void csr_sort_kernel(GraphCsr g, int O) {
+  __shared__ int keys[SORT_MAXDEG];
+  const int i = blockIdx.x;
   if (i >= O) return;
-  const int b = g.rowptr[i], e = g.rowptr[i + 1];
-  for (int a = b + 1; a < e; ++a) {
-    const int key = g.ent[a];
-    int j = a - 1;
-    while (j >= b && g.ent[j] > key) { g.ent[j + 1] = g.ent[j]; --j; }
-    g.ent[j + 1] = key;
+  const int b = g.rowptr[i], e = g.rowptr[i + 1], deg = e - b;
+  if (deg <= 1) return;
+  if (deg > SORT_MAXDEG) {
+    if (threadIdx.x == 0)
+      for (int a = b + 1; a < e; ++a) {
+        const int key = g.ent[a];
+        int j = a - 1;
+        while (j >= b && g.ent[j] > key) { g.ent[j + 1] = g.ent[j]; --j; }
+        g.ent[j + 1] = key;
+      }
+    return;
+  }
+  for (int k = threadIdx.x; k < deg; k += 64) keys[k] = g.ent[b + k];
+  __syncthreads();
+  for (int k = threadIdx.x; k < deg; k += 64) {
+    const int key = keys[k];
+    int rank = 0;
+    for (int j = 0; j < deg; ++j) rank += keys[j] < key ? 1 : 0;       // entry ids of a row are distinct
+    g.ent[b + rank] = key;
   }
 }
 
@@ -736,7 +753,7 @@ int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, G
                               edges_only ? 2 : 3, edges_only ? -1 : 1, edges_only ? 1 : 2);
   hipLaunchKernelGGL(csr_scan_kernel, dim3(1), dim3(1024), 0, st, g, O);
   if (T > 0) hipLaunchKernelGGL(csr_fill_kernel, dim3(sln_cdiv(2 * T, 256)), dim3(256), 0, st, g, T);
-  hipLaunchKernelGGL(csr_sort_kernel, dim3(sln_cdiv(O, 64)), dim3(64), 0, st, g, O);
+  hipLaunchKernelGGL(csr_sort_kernel, dim3(O), dim3(64), 0, st, g, O);
   SLN_CHECK_LAUNCH();
   return 0;
 }

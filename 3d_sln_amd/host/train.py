@@ -246,6 +246,7 @@ def main(argv=None):
                             gconv_num_layers=args.gconv_num_layers, mlp_normalization=args.mlp_normalization,
                             vec_noise_dim=args.vec_noise_dim, layout_noise_dim=args.layout_noise_dim,
                             use_AE=args.use_AE).cuda().train()
+    model.manual_seed(args.manual_seed + 7919 * rank)        # the on-device N(0,1) draws differ between the replicas (same parameters)
 
     sampler = EpochSampler(len(dataset), args.batch_size, args.manual_seed) if dataset is not None else None
 

@@ -618,6 +618,7 @@ def main():
                   gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
                   layout_noise_dim=32, use_AE=False)      # build_dataset_model.py:40-52 at options.py defaults
     model = M.Sg2ScVAEModel(**kwargs).cuda().train()
+    model.manual_seed(42 + 7919 * rank)         # every replica draws its own eps
     dp = world > 1 or force_dp
     if dp:
         dist.broadcast(model.flat_params, 0)

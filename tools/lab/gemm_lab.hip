@@ -43,6 +43,23 @@ int main() {
     for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, 0, a);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    {   // two independent launches of the same problem side by side (two streams): does co-residency hide the per-block latencies?
+      hipStream_t s1, s2; CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+      float* y2; CK(hipMalloc(&y2, sizeof(float) * M * N)); double* sums2; CK(hipMalloc(&sums2, sizeof(double) * 2 * N));
+      CK(hipMemset(sums2, 0, sizeof(double) * 2 * N));
+      GemmNTArgs a2 = a; a2.Y = y2; a2.osums = sums2;
+      CK(hipDeviceSynchronize());
+      hipEvent_t f0, f1, f2; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1)); CK(hipEventCreate(&f2));
+      CK(hipEventRecord(f0, s1)); CK(hipStreamWaitEvent(s2, f0, 0));
+      for (int i = 0; i < 50; ++i) {
+        hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, s1, a);
+        hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, s2, a2);
+      }
+      CK(hipEventRecord(f1, s1)); CK(hipEventRecord(f2, s2)); CK(hipDeviceSynchronize());
+      float m1, m2; CK(hipEventElapsedTime(&m1, f0, f1)); CK(hipEventElapsedTime(&m2, f0, f2));
+      printf("   two streams side by side: %.2f us per PAIR of launches\n", (m1 > m2 ? m1 : m2) / 50 * 1e3);
+      (void)hipFree(y2); (void)hipFree(sums2);
+    }
     std::vector<long long> t(8 * grid);
     CK(hipMemcpy(t.data(), trace, sizeof(long long) * 8 * grid, hipMemcpyDeviceToHost));
     long long tmin = t[0], tmax = 0;
