@@ -606,7 +606,9 @@ def main():
     if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            del os.environ["NCCL_DEBUG"]               # RCCL's version banner goes to STDOUT, which carries the one JSON line
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     lib = importlib.import_module("3d_sln_amd._lib")
     lib.check(lib.lib().sln_device_ok(), "sln_device_ok")
