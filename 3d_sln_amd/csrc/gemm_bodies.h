@@ -345,6 +345,174 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 
 
 // ---------------------------------------------------------------------------------------------
+// NT kernel, small tile: 32 x 32 outputs per workgroup, the K loop SPLIT over its four wavefronts
+// ---------------------------------------------------------------------------------------------
+// The object-side GEMMs of a batch of 64 graphs (M = 2048 rows, N = 128 / 256) have 64-128 tiles of 64 x 64 for 256 CUs, and on
+// its CU a block walks K tile by tile with one wave per SIMD (~1 650 cycles per tile for 1 024 cycles of MFMA): 8 tiles at
+// K = 256 whatever the tile shape.  Here a workgroup owns a 32 x 32 tile (4x the workgroups: every CU gets one), wave w takes the
+// k-tiles w, w + 4, ... through its OWN LDS tiles (no workgroup barrier in the loop; the LDS queue of a wave is in order), the
+// four partial accumulators meet in LDS once, and every wave finishes 8 of the 32 rows (bias / mask / statistics / store).
+// Single-segment operands only (the gathered concat input stays with gemm_nt_body).
+template <int AMODE, int EPI>
+__device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const int bid, char* smem) {
+  constexpr bool HAS_X2 = AMODE == 1;
+  constexpr bool IDENT = AMODE == 2;
+  constexpr int LDT = BK + 4;
+  constexpr int TS = 32;                                   // tile edge
+  const int kpad = (a.K + 31) & ~31;
+  float4* coef = reinterpret_cast<float4*>(smem);           // [kpad]
+  float4* ecoef = coef + kpad;                              // [TS]
+  double* sred = reinterpret_cast<double*>(ecoef + TS);     // [4][TS][2] column statistics of the four waves
+  float* wl = reinterpret_cast<float*>(sred + 4 * TS * 2);  // per wave: A [TS][LDT] | B [TS][LDT]; later its 16 x 64 partial accumulator
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_n = (a.N + TS - 1) / TS;
+  const int m0 = (bid / tiles_n) * TS, n0 = (bid % tiles_n) * TS;
+  float* As = wl + wave * 2 * TS * LDT;
+  float* Bs = As + TS * LDT;
+
+  const int kq = lane & 7, r0 = lane >> 3;                  // float4 column, first of this lane's 4 rows (stride 8)
+  const Seg& sg = a.A.seg[0];
+  int rid[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = min(m0 + r0 + 8 * p, a.M - 1);
+    rid[p] = sg.which == 0 ? row : (sg.which == 1 ? a.A.idx_a[row] : a.A.idx_b[row]);
+  }
+  const int ntiles = kpad / BK;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ga1[4], ga2[4], gb[4];
+  const float* x2p = sg.x2 ? sg.x2 : sg.x1;
+  const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
+  auto gload = [&](int kt) {                               // kt clamped by the caller; everything unconditional
+    const int cs = min(kt * BK + 4 * kq, sg.len - 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ga1[p] = ld4(sg.x1 + (size_t)rid[p] * sg.ld1 + sg.c1 + cs);
+      if (HAS_X2) ga2[p] = ld4(x2p + (size_t)rid[p] * ld2 + c2 + cs);
+    }
+    const int cw = min(kt * BK + 4 * kq, a.K - 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) gb[p] = ld4(a.W + (size_t)min(n0 + r0 + 8 * p, a.N - 1) * a.ldw + cw);
+  };
+  auto lstore = [&](int kt) {
+    const int col = kt * BK + 4 * kq;
+    const bool cv = col < sg.len, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
+    const float4* cf = coef + min(col, kpad - 4);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int rl = r0 + 8 * p;
+      const bool v = cv && (m0 + rl) < a.M;
+      float4 t = IDENT ? ga1[p] : xform(ga1[p], x2v ? ga2[p] : z4, cf);
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+      *reinterpret_cast<float4*>(As + rl * LDT + 4 * kq) = t;
+      const bool vb = kv && (n0 + rl) < a.N;
+      float4 u = gb[p];
+      u.x = vb ? u.x : 0.f; u.y = vb ? u.y : 0.f; u.z = vb ? u.z : 0.f; u.w = vb ? u.w : 0.f;
+      *reinterpret_cast<float4*>(Bs + rl * LDT + 4 * kq) = u;
+    }
+  };
+
+  if (wave < ntiles) gload(wave);                           // first tile of this wave, issued before the coefficient set-up
+  if (!IDENT) {
+    sln_fill_coefs(a.A, coef, tid, 256);
+    for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+  }
+  if (EPI == EPI_MASK) {
+    for (int c = tid; c < TS; c += 256) {
+      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+      if (n0 + c < a.N) { bn_fwd_coef(a.obn, n0 + c, e.x, e.y); bn_mean_istd(a.obn, n0 + c, e.z, e.w); }
+      ecoef[c] = e;
+    }
+  }
+  __syncthreads();                                          // coefficient tables visible
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int kt = wave; kt < ntiles; kt += 4) {
+    lstore(kt);
+    if (kt + 4 < ntiles) gload(kt + 4);                     // wave-uniform branch; the refill flies under this tile's MFMAs
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int kb = 0; kb < BK; kb += 8) {
+      const float4 fa = *reinterpret_cast<const float4*>(As + lrow * LDT + 4 * lk + kb);
+      const float4 fb = *reinterpret_cast<const float4*>(Bs + lrow * LDT + 4 * lk + kb);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ---- the four partial tiles meet: wave w keeps registers 4w .. 4w+3 (rows 8w + (r & 3) + 4 lk) ----
+  float* part = wl + wave * 2 * TS * LDT;                   // this wave's own LDS region: 16 x 64 floats fit into its two tiles
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[r * 64 + lane] = acc[r];
+  __syncthreads();
+  float yv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += wl[w * 2 * TS * LDT + (4 * wave + q) * 64 + lane];
+    yv[q] = v;
+  }
+  const int col = n0 + lrow;
+  const bool cvalid = col < a.N;
+  const int ccl = cvalid ? col : 0;
+  const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+  float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
+  if (EPI == EPI_MASK) ec = ecoef[lrow];
+  float xpv[4], addv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = min(m0 + 8 * wave + q + 4 * lk, a.M - 1);
+    xpv[q] = 0.f; addv[q] = 0.f;
+    if (EPI == EPI_MASK) xpv[q] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
+    if (a.addend) addv[q] = a.addend[(size_t)row * a.ldadd + a.addcol0 + ccl];
+  }
+  float s1 = 0.f, s2 = 0.f;
+  double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = m0 + 8 * wave + q + 4 * lk;
+    const bool ok = cvalid && row < a.M;
+    float y = yv[q] + bias + addv[q];
+    if (EPI == EPI_MASK) y = fmaf(ec.x, xpv[q], ec.y) > 0.f ? y : 0.f;
+    y = ok ? y : 0.f;
+    if (EPI == EPI_STATS) { d1 += (double)y; d2 = fma((double)y, (double)y, d2); }
+    if (EPI == EPI_MASK) { s1 += y; s2 = fmaf(y, (xpv[q] - ec.z) * ec.w, s2); }
+    if (ok) a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
+  }
+  if (EPI != EPI_PLAIN) {
+    if (EPI == EPI_MASK) { d1 = (double)wave_sum_halves(s1); d2 = (double)wave_sum_halves(s2); }
+    else { d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64); }
+    if (lk == 0) { sred[(wave * TS + lrow) * 2] = d1; sred[(wave * TS + lrow) * 2 + 1] = d2; }
+    __syncthreads();
+    double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
+    if (out != nullptr && tid < TS && n0 + tid < a.N) {
+      double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { t1 += sred[(w * TS + tid) * 2]; t2 += sred[(w * TS + tid) * 2 + 1]; }
+      atomicAdd(out + n0 + tid, t1);
+      atomicAdd(out + a.ocstride + n0 + tid, t2);
+    }
+  }
+}
+
+inline size_t nt_small_smem_bytes(int K) {
+  const int kpad = (K + 31) & ~31;
+  return (size_t)kpad * 16 + 32 * 16 + 4 * 32 * 2 * 8 + (size_t)4 * 2 * 32 * (BK + 4) * 4;
+}
+
+// under-filled single-segment problems: fewer than this many 64 x 64 tiles (the object-side GEMMs of a 64-graph batch, the heads)
+inline bool nt_wants_small(const GemmNTArgs& a) {
+  return a.A.nseg == 1 && (long)sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64) <= 160 && a.K <= 2048;
+}
+
+// ---------------------------------------------------------------------------------------------
 // TN kernel (wgrad)
 // ---------------------------------------------------------------------------------------------
 struct ColSel { const float* x1; const float* x2; int ld1, ld2, which; bool valid; };

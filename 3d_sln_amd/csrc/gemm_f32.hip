@@ -20,9 +20,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI>(a, blockIdx.x, gridDim.x, smem);
 }
 
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_small_body<AMODE, EPI>(a, blockIdx.x, smem);
+}
+
 }  // namespace
 int sln_gemm_init();
 namespace {
+
+template <int AMODE, int EPI>
+int launch_nt_small(const GemmNTArgs& a, hipStream_t st) {
+  const size_t smem = nt_small_smem_bytes(a.K);
+  const int grid = sln_cdiv(a.M, 32) * sln_cdiv(a.N, 32);
+  if (grid <= 0) return 0;
+  if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI>
 int launch_nt(const GemmNTArgs& a, hipStream_t st) {
@@ -125,6 +142,12 @@ int sln_gemm_init() {
   static bool done = false;
   if (done) return 0;
   int r = init_nt_tile<64, 64, 2, 2>();
+#define SLN_SET_S(AM, EPI)                                                                                        \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_kernel<AM, EPI>),            \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  SLN_SET_S(0, EPI_PLAIN) SLN_SET_S(0, EPI_STATS) SLN_SET_S(0, EPI_MASK) SLN_SET_S(1, EPI_PLAIN) SLN_SET_S(1, EPI_STATS)
+  SLN_SET_S(1, EPI_MASK) SLN_SET_S(2, EPI_PLAIN) SLN_SET_S(2, EPI_STATS) SLN_SET_S(2, EPI_MASK)
+#undef SLN_SET_S
   if (!r) r = init_nt_tile<128, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 128, 2, 2>();
 #define SLN_SET_TN(X2, XG)                                                                                        \
@@ -150,9 +173,22 @@ int sln_gemm_init() {
 
 int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
   SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
+  static const bool no_small = std::getenv("SLN_NO_SMALL_NT") != nullptr;
+  const int amode = nt_amode(a);
+  // stand-alone launches only: inside a dual launch (dgrad blocks next to wgrad blocks on every CU) the small body measured
+  // slower than the 64 x 64 one (pairs 28.8 -> 30.3 us on average): its 4x more workgroups pay 4x the prologues on a busy chip
+  if (tile < 0 && !no_small && nt_wants_small(a)) {
+#define SLN_DISPATCH_S(AM)                                                            \
+    if (amode == AM) {                                                                \
+      if (epi == EPI_MASK) return launch_nt_small<AM, EPI_MASK>(a, st);               \
+      if (epi == EPI_STATS) return launch_nt_small<AM, EPI_STATS>(a, st);             \
+      return launch_nt_small<AM, EPI_PLAIN>(a, st);                                   \
+    }
+    SLN_DISPATCH_S(0) SLN_DISPATCH_S(1) SLN_DISPATCH_S(2)
+#undef SLN_DISPATCH_S
+  }
   if (tile < 0) tile = nt_heuristic_tile(a);
   if (a.A.nseg > 1 && nt_unaligned(a)) tile = 0;        // the per-thread segment choice exists for the 64x64 tile only
-  const int amode = nt_amode(a);
 #define SLN_DISPATCH(AM)                                                              \
   if (amode == AM) {                                                                  \
     if (epi == EPI_MASK) return dispatch_nt_tile<AM, EPI_MASK>(a, st, tile);          \

@@ -54,15 +54,19 @@ def test_data_parallel_step_over_rccl_equals_the_plain_step(rccl_world_of_one, o
         step = T.DataParallelStep(model, 1, overlap=overlap, force=dp)
         assert step.dp == dp and step.overlap == (overlap and dp) and step.guarded
         st = torch.cuda.Stream()
+        ls = []
         with torch.cuda.stream(st):
             for b in batches:
-                losses = step(dict(objs=b[0], triples=b[1], boxes=b[2], angles=b[3], attributes=b[4]), 0.1, 1e-3, use_graph=use_graph, eps=eps)
+                ls.append(step(dict(objs=b[0], triples=b[1], boxes=b[2], angles=b[3], attributes=b[4]), 0.1, 1e-3, use_graph=use_graph, eps=eps).clone())
         torch.cuda.synchronize()
-        res.append((losses.cpu().numpy(), model.flat_params.cpu().numpy().copy(), model._sync_adam_steps(),
+        res.append((np.stack([l.cpu().numpy() for l in ls]), model.flat_params.cpu().numpy().copy(), model._sync_adam_steps(),
                     float(model.grad_bucket[-1].cpu())))
     assert res[0][2] == res[1][2] == 3
-    assert_close(res[1][0], res[0][0], "losses dp vs plain", rtol=1e-5)
-    assert_close(res[1][3], res[1][0][3], "guard element = the rank's total loss", rtol=1e-6)
+    # steps 1-2 tightly; the third loss follows the random signs Adam's first steps give to parameters whose gradient is
+    # rounding noise (tools/replay_stress.py: 3e-4 apart between two runs of the SAME path)
+    assert_close(res[1][0][:2], res[0][0][:2], "losses of steps 1-2, dp vs plain", rtol=2e-6)
+    assert_close(res[1][0][2], res[0][0][2], "losses of step 3, dp vs plain", rtol=5e-4)
+    assert_close(res[1][3], res[1][0][2][3], "guard element = the rank's total loss", rtol=1e-6)
     d = np.abs(res[1][1] - res[0][1])
     # +-lr noise on parameters whose true gradient is 0 (atomic order differs between runs): bounded; the bulk agrees
     assert d.max() <= 2.05e-3 * 3 and np.mean(d > 1e-5) < 0.02, (d.max(), np.mean(d > 1e-5))
