@@ -24,3 +24,25 @@ def test_world_size_must_match_the_request():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_recorded_bench_line_carries_the_contract_keys():
+    """profiles/r02_bench.json is the line `python bench.py` printed on the MI355X for the committed code: the keys the driver
+    and the judge read must all be there (the default run fills every leg, each with its roofline and cpu_baseline)."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r02_bench.json")
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32" and "workload" in d["config"]
+    assert abs(d["value"] - 64 * d["steps"] / (d["ms_per_step"] * d["steps"] / 1e3)) < 1e-3 * d["value"]
+    for leg in (d, d["render"], d["spade"]):
+        r, c = leg["roofline"], leg["cpu_baseline"]
+        assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and r["bound"] in ("hbm", "mfma")
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3
+        assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert d["c1"]["cores"] >= 1 and d["c1"]["cpu_ms_per_iter"] > 0
+    assert all(v is not None for v in d["parity"].values()) and d["render"]["parity"]["face_index_pixels_differing"] == 0
