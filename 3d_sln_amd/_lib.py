@@ -146,6 +146,13 @@ SIGNATURES = {
     "sln_resize": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_spade_depth_concat": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     "sln_se_scale_add": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_spade_conv_sums": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_float, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sln_spade_modulate_up": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, C.c_int,
+                                        c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "sln_layernorm_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "sln_block_tail": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, c_f32p, c_f32p, c_f32p,
+                                 C.c_int, c_f32p, C.c_void_p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
     "sln_upsample2x": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_conv_img_tanh": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "sln_graph_plan": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -42,7 +42,12 @@ struct ConvArgs {
   const float* xin;      // tensor being normalised [B, C, H, W]
   const float* stats;    // [B, 2] = (mean, 1/(std+eps))
   int C;
+  int xin_up;            // MODULATE: xin is [B, C, H/2, W/2] and is read through nn.Upsample(x2, nearest) (never materialised)
+  // BIAS_ACT, optional reductions of what the epilogue writes (fp64 atomics, zeroed by the caller)
+  double* ln_acc;        // [B][LN_ACC_STRIDE]: sum y, sum y^2 of sample b (LayerNorm2D statistics of the NEXT SPADE layer)
+  double* gap_acc;       // [B, rows]: sum over pixels (SEBlock2's global average pool)
 };
+constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples (one 128-byte line each)
 
 __device__ __forceinline__ int reflect_idx(int i, int n) {      // ReflectionPad2d(1) (pad < n)
   i = i < 0 ? -i : i;
@@ -200,8 +205,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
           float v = acc[i][j][r] + bias[i][r];
           if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (a.act == ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
-          if (pv && row < a.rows) a.y[((size_t)b * a.rows + row) * plane + pix] = v;
+          const bool ok = pv && row < a.rows;
+          if (ok) a.y[((size_t)b * a.rows + row) * plane + pix] = v;
+          acc[i][j][r] = ok ? v : 0.f;               // what was written, for the reductions below
         }
+    }
+    if (a.ln_acc) {
+      // LayerNorm2D sums of the written values in fp64 (as the stand-alone statistics kernel); 2 atomics per block
+      double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) { const double v = acc[i][j][r]; d1 += v; d2 = fma(v, v, d2); }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+      double* red = reinterpret_cast<double*>(lds);      // the slabs are free: the K loop ended with a barrier
+      if (lane == 0) { red[2 * wave] = d1; red[2 * wave + 1] = d2; }
+      __syncthreads();
+      if (tid == 0) {
+        atomicAdd(a.ln_acc + LN_ACC_STRIDE * b, red[0] + red[2] + red[4] + red[6]);
+        atomicAdd(a.ln_acc + LN_ACC_STRIDE * b + 1, red[1] + red[3] + red[5] + red[7]);
+      }
+      __syncthreads();
+    }
+    if (a.gap_acc) {
+      // per-row sums over the block's pixels: the lane's pixel tiles in registers, the 32 pixel lanes through a padded LDS
+      // transpose (row-major, 33 floats per row), then one fp64 atomic per (wave, row)
+      float* tr = lds + wave * (64 * 33);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) v += acc[i][j][r];
+          tr[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk) * 33 + li] = v;
+        }
+      __syncthreads();
+      double rs = 0.0;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) rs += (double)tr[lane * 33 + q];
+      const int row = r0 + wr + lane;
+      if (row < a.rows) atomicAdd(a.gap_acc + (size_t)b * a.rows + row, rs);
     }
   } else {
     // rows of this wave: [32 gamma | 32 beta] of channels cbase .. cbase+31
@@ -220,12 +267,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       const int py = y0 + m / TW, px = x0 + m % TW;
       const bool pv = py < a.H && px < a.W;
       const size_t pix = (size_t)py * a.W + px;
-      const size_t pixc = (size_t)min(py, a.H - 1) * a.W + min(px, a.W - 1);
+      const int pyc = min(py, a.H - 1), pxc = min(px, a.W - 1);
+      const size_t pixc = a.xin_up ? (size_t)(pyc >> 1) * (a.W >> 1) + (pxc >> 1) : (size_t)pyc * a.W + pxc;
+      const size_t xplane = a.xin_up ? plane >> 2 : plane;
       float xin[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lk, a.C - 1);
-        xin[r] = a.xin[((size_t)b * a.C + c) * plane + pixc];
+        xin[r] = a.xin[((size_t)b * a.C + c) * xplane + pixc];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -245,7 +294,8 @@ template <int BMC, int KS, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? HALO : TH * TW;
-  const size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
+  size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
+  if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
   static bool raised = false;
   if (!raised && smem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BMC, KS, EPI>),
@@ -262,7 +312,6 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples
 __global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ acc) {
   const int b = blockIdx.y;
   const float* xb = x + (size_t)b * n;
@@ -281,11 +330,14 @@ __global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __r
   // one 128-byte line per sample: device atomics to the same line are serialised on the memory side
   if (threadIdx.x == 0) { atomicAdd(acc + LN_ACC_STRIDE * b, rs[0]); atomicAdd(acc + LN_ACC_STRIDE * b + 1, rq[0]); }
 }
-__global__ void ln_finalize_kernel(const double* __restrict__ acc, long n, int B, float eps, float* __restrict__ stats) {
+// rep: every accumulated value stands for `rep` elements of the normalised tensor (4 when the tensor is the nearest x2
+// upsampling of what was summed: same mean, n -> 4 n in the unbiased variance)
+__global__ void ln_finalize_kernel(const double* __restrict__ acc, long n_acc, int rep, int B, float eps, float* __restrict__ stats) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  const double mean = acc[LN_ACC_STRIDE * b] / (double)n;
-  double var = (acc[LN_ACC_STRIDE * b + 1] - (double)n * mean * mean) / (double)(n - 1);     // unbiased (torch.std default)
+  const double n = (double)n_acc * rep;
+  const double mean = acc[LN_ACC_STRIDE * b] / (double)n_acc;
+  double var = ((double)rep * acc[LN_ACC_STRIDE * b + 1] - n * mean * mean) / (n - 1.0);     // unbiased (torch.std default)
   var = var < 0.0 ? 0.0 : var;
   stats[2 * b] = (float)mean;
   stats[2 * b + 1] = 1.0f / ((float)sqrt(var) + eps);                           // LayerNorm2D adds eps to sigma
@@ -350,12 +402,13 @@ __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restri
   if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (float)hw;
 }
 // scale[b, :] = sigmoid(W2 relu(W0 gap[b, :]))   (SEBlock2, :70-85; reduction 8)
-__global__ void se_fc_kernel(const float* __restrict__ gap, const float* __restrict__ w0, const float* __restrict__ w2, int C,
-                             int Cr, float* __restrict__ scale) {
+// gap: the averages, or (gsum != nullptr) the fp64 pixel sums a conv epilogue accumulated, divided here by hw
+__global__ void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw, const float* __restrict__ w0,
+                             const float* __restrict__ w2, int C, int Cr, float* __restrict__ scale) {
   extern __shared__ float sm[];
   float* g = sm; float* hdn = sm + C;
   const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gap[(size_t)b * C + c];
+  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? (float)(gsum[(size_t)b * C + c] / hw) : gap[(size_t)b * C + c];
   __syncthreads();
   for (int r = threadIdx.x; r < Cr; r += blockDim.x) {
     float s = 0.f;
@@ -390,6 +443,83 @@ __global__ void upsample2x_kernel(const float* __restrict__ x, int H, int W, int
   const float ly = fy - ya, lx = fx - xa;
   y[i] = (1.f - ly) * ((1.f - lx) * s[(long)ya * W + xa] + lx * s[(long)ya * W + xb]) +
          ly * ((1.f - lx) * s[(long)yb * W + xa] + lx * s[(long)yb * W + xb]);
+}
+
+// Tail of a SPADEResnetBlock4 (:1492-1493) and the nn.Upsample that follows it (:1585-1600) in one pass:
+//   v = xs + dx * scale[b, c];   out = v | nearest x2 (v) | bilinear x2 (v);   acc[b] += (sum out, sum out^2)
+// The residual sum is written once, at the resolution the next block reads, together with the LayerNorm2D sums of the next
+// block (separately: scale-add R2 W1, upsample R1 W4, statistics R4 units of HBM traffic; here R2 W4 - or R2 W1 when the
+// consumers read the result through the nearest upsampling themselves and only the sums are needed at the higher resolution).
+// UP: 0 none, 1 nearest, 2 bilinear (align_corners=False).  xs_up: xs is [B,C,H/2,W/2], read through nearest x2 (the identity
+// shortcut of a block whose input was never materialised).  Four consecutive outputs of a row per thread.
+template <int UP>
+__global__ __launch_bounds__(256) void block_tail_kernel(const float* __restrict__ xs, const float* __restrict__ dx,
+                                                         const float* __restrict__ scale, int C, int H, int W, int xs_up,
+                                                         float* __restrict__ out, double* __restrict__ acc) {
+  const int b = blockIdx.y;
+  const int Ho = UP ? 2 * H : H, Wo = UP ? 2 * W : W;
+  const long plane = (long)H * W, oplane = (long)Ho * Wo;
+  const long n4 = (long)C * oplane / 4;
+  const float* dxb = dx + (size_t)b * C * plane;
+  const float* xsb = xs + (size_t)b * C * (xs_up ? plane / 4 : plane);
+  float* ob = out + (size_t)b * C * oplane;
+  const int w4 = Wo / 4;
+  double s = 0.0, q = 0.0;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n4; g += (long)gridDim.x * 256) {
+    const int xo = (int)(g % w4) * 4;
+    const long t = g / w4;
+    const int yo = (int)(t % Ho), c = (int)(t / Ho);
+    const float sc = scale[(size_t)b * C + c];
+    const float* dp = dxb + (size_t)c * plane;
+    const float* xp = xsb + (size_t)c * (xs_up ? plane / 4 : plane);
+    auto val = [&](int y, int x) -> float {           // v at source pixel (y, x)
+      const float xv = xs_up ? xp[(long)(y >> 1) * (W >> 1) + (x >> 1)] : xp[(long)y * W + x];
+      return xv + dp[(long)y * W + x] * sc;
+    };
+    float4 v;
+    if (UP == 0) {
+      if (!xs_up) {
+        const float4 xv = *reinterpret_cast<const float4*>(xp + (long)yo * W + xo);
+        const float4 dv = *reinterpret_cast<const float4*>(dp + (long)yo * W + xo);
+        v.x = xv.x + dv.x * sc; v.y = xv.y + dv.y * sc; v.z = xv.z + dv.z * sc; v.w = xv.w + dv.w * sc;
+      } else {
+        v.x = val(yo, xo); v.y = val(yo, xo + 1); v.z = val(yo, xo + 2); v.w = val(yo, xo + 3);
+      }
+    } else if (UP == 1) {
+      const float a0 = val(yo >> 1, xo >> 1), a1 = val(yo >> 1, (xo >> 1) + 1);
+      v.x = a0; v.y = a0; v.z = a1; v.w = a1;
+    } else {
+      float fy = (yo + 0.5f) * 0.5f - 0.5f;
+      fy = fy < 0.f ? 0.f : fy;
+      const int ya = min((int)fy, H - 1), yb = min(ya + 1, H - 1);
+      const float ly = fy - ya;
+      const int k2 = xo >> 1;                                       // source columns k2-1 .. k2+2 (clamped)
+      const int cx[4] = {max(k2 - 1, 0), k2, k2 + 1, min(k2 + 2, W - 1)};
+      float ra[4], rb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ra[i] = val(ya, cx[i]); rb[i] = val(yb, cx[i]); }
+      // output xo + t: fx = k2 - 0.25 + 0.5 t  ->  (xa, lx) = (k2-1, .75), (k2, .25), (k2, .75), (k2+1, .25); fx < 0 clamps to 0
+      const float lx0 = k2 == 0 ? 0.f : 0.75f;
+      const int i0 = k2 == 0 ? 1 : 0;                                // xa = 0, xb = 1 at the left border
+      v.x = (1.f - ly) * ((1.f - lx0) * ra[i0] + lx0 * ra[i0 + 1]) + ly * ((1.f - lx0) * rb[i0] + lx0 * rb[i0 + 1]);
+      v.y = (1.f - ly) * (0.75f * ra[1] + 0.25f * ra[2]) + ly * (0.75f * rb[1] + 0.25f * rb[2]);
+      v.z = (1.f - ly) * (0.25f * ra[1] + 0.75f * ra[2]) + ly * (0.25f * rb[1] + 0.75f * rb[2]);
+      v.w = (1.f - ly) * (0.75f * ra[2] + 0.25f * ra[3]) + ly * (0.75f * rb[2] + 0.25f * rb[3]);
+    }
+    *reinterpret_cast<float4*>(ob + (size_t)c * oplane + (long)yo * Wo + xo) = v;
+    s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+    q += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (!acc) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); q += __shfl_xor(q, off); }
+  __shared__ double red[8];
+  if ((threadIdx.x & 63) == 0) { red[2 * (threadIdx.x >> 6)] = s; red[2 * (threadIdx.x >> 6) + 1] = q; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + LN_ACC_STRIDE * b, red[0] + red[2] + red[4] + red[6]);
+    atomicAdd(acc + LN_ACC_STRIDE * b + 1, red[1] + red[3] + red[5] + red[7]);
+  }
 }
 
 // tanh(conv5x5_zero_pad(leaky_0.2(x)))  (:1602-1603).  Cout is tiny (3): VALU FMAs.  A workgroup owns a 16x16 output
@@ -487,31 +617,85 @@ int sln_spade_apply(const float* x, const float* gb, int B, int C, int H, int W,
 }
 
 // conv KSxKS (KS = 3 reflect pad 1, KS = 1) with packed weights wp[KS*KS][Cin][rows_pad]; rows_pad % 64 == 0.
-int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
-                   int ksize, int act, float slope, float* y, void* stream) {
+int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
+                        int ksize, int act, float slope, float* y, double* ln_acc, double* gap_acc, void* stream) {
   if (!x || !wp || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || rows <= 0 || rows_pad % 64 != 0 || rows > rows_pad) return SLN_E_BADARG;
   if (ksize != 1 && ksize != 3) return SLN_E_UNSUPPORTED;
   if (ksize == 3 && (H < 2 || W < 2)) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a; a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = rows; a.rows_pad = rows_pad;
-  a.act = act; a.slope = slope; a.xin = nullptr; a.stats = nullptr; a.C = 0;
+  a.act = act; a.slope = slope; a.xin = nullptr; a.stats = nullptr; a.C = 0; a.xin_up = 0; a.ln_acc = ln_acc; a.gap_acc = gap_acc;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * ksize * ksize * rows, st);
   const bool big = rows_pad % 128 == 0;
   if (ksize == 3) return big ? launch_conv<128, 3, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 3, CEPI_BIAS_ACT>(a, st);
   return big ? launch_conv<128, 1, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 1, CEPI_BIAS_ACT>(a, st);
 }
+int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
+                   int ksize, int act, float slope, float* y, void* stream) {
+  return sln_spade_conv_sums(x, B, Cin, H, W, wp, bias, rows, rows_pad, ksize, act, slope, y, nullptr, nullptr, stream);
+}
 
 // out = LN(xin) * (1 + gamma) + beta [-> LeakyReLU(slope) when act == 2], gamma/beta = conv3x3_reflect(actv) with
 // weights packed [32 gamma | 32 beta] per 64 rows (rows_pad = 64 * ceil(C / 32)).
-int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
-                       const float* xin, const float* stats, int act, float slope, float* out, void* stream) {
+int sln_spade_modulate_up(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
+                          const float* xin, int xin_up, const float* stats, int act, float slope, float* out, void* stream) {
+  if (xin_up && ((H | W) & 1)) return SLN_E_BADARG;
   if (!actv || !wp || !bias || !xin || !stats || !out || B <= 0 || C <= 0 || rows_pad % 64 != 0 || rows_pad < 64 * ((C + 31) / 32))
     return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a; a.x = actv; a.wp = wp; a.bias = bias; a.y = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = 2 * C; a.rows_pad = rows_pad;
-  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C;
+  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C; a.xin_up = xin_up; a.ln_acc = nullptr; a.gap_acc = nullptr;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * 9 * 2 * C, st);
   return rows_pad % 128 == 0 ? launch_conv<128, 3, CEPI_MODULATE>(a, st) : launch_conv<64, 3, CEPI_MODULATE>(a, st);
+}
+int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
+                       const float* xin, const float* stats, int act, float slope, float* out, void* stream) {
+  return sln_spade_modulate_up(actv, B, Cin, H, W, wp, bias, C, rows_pad, xin, 0, stats, act, slope, out, stream);
+}
+
+// stats[b] from sums a conv epilogue / block tail accumulated (acc [B][16] doubles: sum, sum of squares over n_acc values,
+// each standing for `rep` elements of the normalised tensor)
+int sln_layernorm_finalize(const double* acc, int B, int64_t n_acc, int rep, float eps, float* stats, void* stream) {
+  if (!acc || !stats || B <= 0 || n_acc < 1 || rep < 1 || n_acc * rep < 2) return SLN_E_BADARG;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, acc, (long)n_acc, rep, B, eps, stats);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// out = up(xs + dx * sigmoid(W2 relu(W0 GAP(dx)))) and the LayerNorm2D statistics of the next block's input in one pass.
+//   xs [B,C,H,W] (xs_up = 1: [B,C,H/2,W/2] read through nearest x2), dx [B,C,H,W];
+//   gap_sums: fp64 pixel sums of dx from sln_spade_conv_sums, or NULL (a reduction kernel computes the averages);
+//   up_mode: -1 out [B,C,H,W]; 0 nearest / 1 bilinear: out [B,C,2H,2W];
+//   stats_rep: 1, or 4 = the consumers read `out` through nearest x2 (statistics of that tensor);  stats may be NULL.
+//   scratch: 2*B*C floats;  acc: 16*B doubles (zeroed here).
+int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, int H, int W, const double* gap_sums, const float* w0,
+                   const float* w2, float* scratch, int up_mode, float* out, double* acc, int stats_rep, float eps, float* stats,
+                   void* stream) {
+  if (!xs || !dx || !w0 || !w2 || !scratch || !out || B <= 0 || C <= 0 || C % 8 != 0 || up_mode < -1 || up_mode > 1) return SLN_E_BADARG;
+  if (stats && !acc) return SLN_E_BADARG;
+  if ((up_mode < 0 && W % 4 != 0) || (W % 2 != 0) || (xs_up && (H % 2 != 0))) return SLN_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long hw = (long)H * W;
+  float* gap = scratch; float* scale = scratch + (size_t)B * C;
+  if (!gap_sums) hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, hw, gap);
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale);
+  if (stats) {
+    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * LN_ACC_STRIDE * B, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const long n_out = (long)C * hw * (up_mode >= 0 ? 4 : 1);
+  SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * (2.0 * C * hw + n_out), st);
+  long gx = (n_out / 4 + 255) / 256;
+  const long cap = 4096 / B > 16 ? 4096 / B : 16;
+  gx = gx > cap ? cap : gx;
+  const dim3 grid((unsigned)gx, B);
+  double* ac = stats ? acc : nullptr;
+  if (up_mode < 0) hipLaunchKernelGGL(block_tail_kernel<0>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
+  else if (up_mode == 0) hipLaunchKernelGGL(block_tail_kernel<1>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
+  else hipLaunchKernelGGL(block_tail_kernel<2>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
+  if (stats) hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, acc, n_out, stats_rep, B, eps, stats);
+  SLN_CHECK_LAUNCH();
+  return 0;
 }
 
 // stats[b] = (mean, 1/(std_unbiased + eps)) over the n = C*H*W elements of sample b; scratch: 2*B doubles
@@ -522,7 +706,7 @@ int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scr
   if (e != hipSuccess) return (int)e;
   int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 128 ? 128 : (gx < 1 ? 1 : gx);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch);
-  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, B, eps, stats);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, 1, B, eps, stats);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -554,7 +738,8 @@ int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw,
   hipStream_t st = (hipStream_t)stream;
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, (long)hw, gap);
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, w0, w2, C, C / 8, scale);
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, (const double*)nullptr, (double)hw, w0, w2,
+                     C, C / 8, scale);
   const long n = (long)B * C * hw;
   hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xs, dx, scale, (long)hw, n, out);
   SLN_CHECK_LAUNCH();

@@ -111,6 +111,7 @@ class SPADEGenerator4(nn.Module):
         self.conv_img = nn.Conv2d(nf, target_nc, 5, padding=2)
         self._packed = None
         self._packed_key = None
+        self.unfused = False          # True: one launch per module (the round-1 schedule; kept for A/B runs and odd sizes)
 
     # ------------------------------------------------------------------ weight packing
     def _pack_all(self):
@@ -160,12 +161,15 @@ class SPADEGenerator4(nn.Module):
                    "sln_layernorm_stats")
         return stats
 
-    def _spade(self, e, x, stats, seg, leaky):
-        """SPADE4.forward (:1438-1454) + the following actvn (:1503-1505) fused into the modulation conv."""
+    def _spade(self, e, x, stats, seg, leaky, x_up=False):
+        """SPADE4.forward (:1438-1454) + the following actvn (:1503-1505) fused into the modulation conv.
+        x_up: x is stored at half the resolution of seg and stands for its nearest x2 upsampling (never materialised)."""
         L = _lib.lib()
-        B, C, H, W = x.shape
+        B, C = x.shape[:2]
+        H, W = seg.shape[2:]
         nd = NHIDDEN // 8
         if seg.shape[0] == 1 and B > 1 and (H * W) % 4 == 0:
+            assert not x_up
             return self._spade_shared(e, x, stats, seg, leaky)
         if seg.shape[0] != B:
             seg = seg.expand(B, -1, -1, -1).contiguous()
@@ -175,10 +179,10 @@ class SPADEGenerator4(nn.Module):
         actv = torch.empty(B, NHIDDEN, H, W, device=x.device)
         _lib.check(L.sln_spade_conv(_lib.ptr(cat), B, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
                                     1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
-        out = torch.empty_like(x)
-        _lib.check(L.sln_spade_modulate(_lib.ptr(actv), B, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), C, e["rpg"],
-                                        _lib.ptr(x), _lib.ptr(stats), 2 if leaky else 0, 0.2, _lib.ptr(out), self._st()),
-                   "sln_spade_modulate")
+        out = torch.empty(B, C, H, W, device=x.device)
+        _lib.check(L.sln_spade_modulate_up(_lib.ptr(actv), B, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), C, e["rpg"],
+                                           _lib.ptr(x), 1 if x_up else 0, _lib.ptr(stats), 2 if leaky else 0, 0.2, _lib.ptr(out),
+                                           self._st()), "sln_spade_modulate_up")
         return out
 
     def _cat_buffer(self, seg, nd):
@@ -216,16 +220,55 @@ class SPADEGenerator4(nn.Module):
                                      _lib.ptr(out), self._st()), "sln_spade_apply")
         return out
 
-    def _conv(self, x, wbr, cout, ks):
+    def _conv(self, x, wbr, cout, ks, ln_acc=None, gap_acc=None):
         w, b, rp = wbr
         B, _, H, W = x.shape
         y = torch.empty(B, cout, H, W, device=x.device)
-        _lib.check(_lib.lib().sln_spade_conv(_lib.ptr(x), B, x.shape[1], H, W, _lib.ptr(w), _lib.ptr(b), cout, rp, ks, 0, 0.0,
-                                             _lib.ptr(y), self._st()), "sln_spade_conv")
+        _lib.check(_lib.lib().sln_spade_conv_sums(_lib.ptr(x), B, x.shape[1], H, W, _lib.ptr(w), _lib.ptr(b), cout, rp, ks, 0, 0.0,
+                                                  _lib.ptr(y), _lib.ptr(ln_acc) if ln_acc is not None else None,
+                                                  _lib.ptr(gap_acc) if gap_acc is not None else None, self._st()), "sln_spade_conv_sums")
         return y
 
-    def _block(self, name, x, seg):
-        """SPADEResnetBlock4.forward (:1487-1502)."""
+    def _block(self, name, x, x_up, stats_x, seg, tail, want_stats=True, tap=None):
+        """SPADEResnetBlock4.forward (:1487-1502) and the nn.Upsample behind it (:1585-1600), the HBM-bound passes folded into
+        their neighbours: LayerNorm2D sums of conv_0's output and SEBlock2's average pool come out of the conv epilogues, the
+        residual sum is written once by `sln_block_tail` together with the statistics of the NEXT block's input.
+        x_up: x stands for its nearest x2 upsampling.  tail: None (no upsampling follows), 'nearest' (the result stays at this
+        resolution, its consumers read it through the upsampling), 'bilinear' (written upsampled).
+        Returns (out, out_up, stats_out)."""
+        blk, e = getattr(self, name), self._packed[name]
+        L = _lib.lib()
+        B = x.shape[0]
+        H, W = seg.shape[2:]
+        accs = torch.zeros(32 * B + B * blk.fout, dtype=torch.float64, device=x.device)
+        ln_dx, ln_out, gap = accs[:16 * B], accs[16 * B:32 * B], accs[32 * B:]
+        if blk.learned_shortcut:
+            x_s, xs_up = self._conv(self._spade(e["norm_s"], x, stats_x, seg, False, x_up), e["conv_s"], blk.fout, 1), 0
+        else:
+            x_s, xs_up = x, 1 if x_up else 0
+        dx = self._conv(self._spade(e["norm_0"], x, stats_x, seg, True, x_up), e["conv_0"], blk.fmiddle, 3, ln_acc=ln_dx)
+        stats_dx = torch.empty(B, 2, device=x.device)
+        _lib.check(L.sln_layernorm_finalize(_lib.ptr(ln_dx), B, blk.fmiddle * H * W, 1, 1e-5, _lib.ptr(stats_dx), self._st()),
+                   "sln_layernorm_finalize")
+        dx = self._conv(self._spade(e["norm_1"], dx, stats_dx, seg, True), e["conv_1"], blk.fout, 3, gap_acc=gap)
+        up_mode = 1 if tail == 'bilinear' else -1
+        k = 2 if tail == 'bilinear' else 1
+        out = torch.empty(B, blk.fout, k * H, k * W, device=x.device)
+        stats = torch.empty(B, 2, device=x.device) if want_stats else None
+        scratch = torch.empty(2 * B * blk.fout, device=x.device)
+        if tap is not None:                       # the block's own output, when the caller asked for it and `out` is upsampled
+            tap[name] = torch.empty(B, blk.fout, H, W, device=x.device)
+            _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, _lib.ptr(gap), _lib.ptr(e["se0"]),
+                                        _lib.ptr(e["se2"]), _lib.ptr(scratch), -1, _lib.ptr(tap[name]), None, 1, 1e-5, None, self._st()),
+                       "sln_block_tail(tap)")
+        _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, _lib.ptr(gap), _lib.ptr(e["se0"]),
+                                    _lib.ptr(e["se2"]), _lib.ptr(scratch), up_mode, _lib.ptr(out), _lib.ptr(ln_out),
+                                    4 if tail == 'nearest' else 1, 1e-5, _lib.ptr(stats) if want_stats else None, self._st()),
+                   "sln_block_tail")
+        return out, tail == 'nearest', stats
+
+    def _block_unfused(self, name, x, seg):
+        """SPADEResnetBlock4.forward (:1487-1502), one launch per module (one map for many z, sizes the fused tail does not take)."""
         blk, e = getattr(self, name), self._packed[name]
         stats_x = self._ln_stats(x)                                  # norm_0 and norm_s normalise the same tensor
         if blk.learned_shortcut:
@@ -283,18 +326,26 @@ class SPADEGenerator4(nn.Module):
                 pyr[r] = self._resize(seg, r, 1)                      # SPADE4's bilinear resize of the full-size map (:1444)
             seg_1 = self._resize(seg, self.sw, 0)                     # nearest (:1579); SPADE4's bilinear to the same size is identity
 
-            def run(name, t, s):
-                t = self._block(name, t, s)
-                if taps is not None:
-                    taps[name] = t
-                return t
-            x = run("head_0", x.contiguous(), seg_1)
-            x = run("G_middle_0", self._up(x, 0), pyr[self.sw * 2])
-            x = run("G_middle_1", x, pyr[self.sw * 2])
-            x = run("up_0", self._up(x, 0), pyr[self.sw * 4])
-            x = run("up_1", self._up(x, 0), pyr[self.sw * 8])
-            x = run("up_2", self._up(x, 0), pyr[self.sw * 16])
-            x = run("up_3", self._up(x, 1), pyr[S])
+            chain = (("head_0", seg_1, 'nearest'), ("G_middle_0", pyr[self.sw * 2], None), ("G_middle_1", pyr[self.sw * 2], 'nearest'),
+                     ("up_0", pyr[self.sw * 4], 'nearest'), ("up_1", pyr[self.sw * 8], 'nearest'), ("up_2", pyr[self.sw * 16], 'bilinear'),
+                     ("up_3", pyr[S], None))
+            fused = self.sw % 4 == 0 and self.sh % 4 == 0 and not (seg.shape[0] == 1 and B > 1) and not self.unfused
+            if fused:
+                x, x_up, stats = x.contiguous(), False, None
+                stats = self._ln_stats(x)
+                for name, s, tail in chain:
+                    x, x_up, stats = self._block(name, x, x_up, stats, s, tail, want_stats=name != "up_3",
+                                                 tap=taps if taps is not None and tail == 'bilinear' else None)
+                    if taps is not None and tail != 'bilinear':        # the block's output as the reference module returns it
+                        taps[name] = x
+            else:
+                x = x.contiguous()
+                for name, s, tail in chain:
+                    x = self._block_unfused(name, x, s)
+                    if taps is not None:
+                        taps[name] = x
+                    if tail is not None:
+                        x = self._up(x, 1 if tail == 'bilinear' else 0)
             out = torch.empty(B, self.target_nc, S, S, device=seg.device)
             _lib.check(L.sln_conv_img_tanh(_lib.ptr(x), B, self.nf, S, S, _lib.ptr(P["img_w"]), _lib.ptr(P["img_b"]), self.target_nc,
                                            _lib.ptr(out), self._st()), "sln_conv_img_tanh")

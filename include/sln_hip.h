@@ -335,6 +335,27 @@ int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp
  * [gamma | beta] = conv3x3_reflect(actv); stats[b] = (mean, 1 / (std + eps)) from sln_layernorm_stats */
 int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
                        const float* xin, const float* stats, int act, float slope, float* out, void* stream);
+/* sln_spade_conv that also accumulates, from the values its epilogue writes, the sums the next layers need (fp64 atomics into
+ * buffers the caller zeroed; either may be NULL): ln_acc [B][16] doubles = (sum y, sum y^2) of sample b -> LayerNorm2D
+ * statistics of the following SPADE layer (:128-149) through sln_layernorm_finalize; gap_acc [B, rows] doubles = sum over
+ * pixels -> SEBlock2's average pool (:70-85) through sln_block_tail. */
+int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
+                        int ksize, int act, float slope, float* y, double* ln_acc, double* gap_acc, void* stream);
+/* sln_spade_modulate with xin_up = 1: xin is [B, C, H/2, W/2] and stands for nn.Upsample(scale_factor=2) (nearest) of itself
+ * (SPADEGenerator4.forward :1585-1597) - the upsampled tensor is never written; stats must be those of the upsampled tensor. */
+int sln_spade_modulate_up(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
+                          const float* xin, int xin_up, const float* stats, int act, float slope, float* out, void* stream);
+/* stats[b] = (mean, 1 / (unbiased std + eps)) from accumulated sums: acc [B][16] doubles (sum, sum of squares of n_acc values),
+ * every value standing for `rep` elements of the normalised tensor (4 = its nearest x2 upsampling) */
+int sln_layernorm_finalize(const double* acc, int B, int64_t n_acc, int rep, float eps, float* stats, void* stream);
+/* Tail of SPADEResnetBlock4.forward (:1492-1493) and the nn.Upsample after it (:1585-1600) in one pass:
+ *   out = up(xs + dx * sigmoid(W2 relu(W0 GAP(dx)))),  stats = LayerNorm2D statistics of the next block's input.
+ * xs [B,C,H,W] (xs_up = 1: [B,C,H/2,W/2] read through nearest x2); gap_sums = the gap_acc of sln_spade_conv_sums or NULL;
+ * up_mode -1: out [B,C,H,W], 0 nearest / 1 bilinear: out [B,C,2H,2W]; stats_rep 4 when the consumers read `out` through
+ * nearest x2 themselves; stats may be NULL; scratch 2*B*C floats; acc 16*B doubles. */
+int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, int H, int W, const double* gap_sums, const float* w0,
+                   const float* w2, float* scratch, int up_mode, float* out, double* acc, int stats_rep, float eps, float* stats,
+                   void* stream);
 /* The same modulation when ONE semantic map drives the whole batch (colorize_with_spade, testing/test_SPADE_shade.py:30-79:
  * 50 z vectors per room): gb [rows_pad, H, W] = sln_spade_conv(actv of that map, the packed gamma|beta weights, act 0) is
  * computed once, then out[b] = LayerNorm2D(xin[b]) * (1 + gamma) + beta for every sample.  H*W % 4 == 0. */

@@ -171,7 +171,10 @@ def test_full_size_batch_of_32_equals_per_sample_calls():
         # one semantic map, several z (colorize_with_spade) at full size: the shared gamma/beta path against the per-sample path
         shared = G(seg[5:6].contiguous(), z[:3].contiguous())
         per = G(seg[5:6].expand(3, -1, -1, -1).contiguous(), z[:3].contiguous())
-        assert_close(shared.cpu().numpy(), per.cpu().numpy(), "full-size shared vs per-sample", rtol=1e-5, atol=1e-5)
+        # the two schedules sum SEBlock2's average pool in a different order (fp32 tree / fp64 epilogue sums): 1e-7 on a scale, which
+        # the 110 M-parameter stack and the final 5x5 conv over 1 600 cancelling products carry to some 1e-5 of the image (the CPU
+        # fp32 oracle sits 1e-4 from the fp64 one on the same weights, bench.py check_spade)
+        assert_close(shared.cpu().numpy(), per.cpu().numpy(), "full-size shared vs per-sample", rtol=1e-5, atol=2e-4)
 
 
 def test_repeated_calls_with_changing_inputs_keep_no_stale_state():
@@ -198,3 +201,90 @@ def test_repeated_calls_with_changing_inputs_keep_no_stale_state():
         assert float((a4 - a1).abs().max()) > 1e-3
         G.load_state_dict(spade_ref.init_state(cfg, seed=7))
         assert torch.equal(G(segA, zA), a1)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(3, 24, 128, 16, 16, 3), (2, 40, 72, 12, 20, 3), (2, 32, 64, 8, 8, 1), (1, 16, 200, 9, 17, 3)])
+def test_conv_epilogue_sums(B, Cin, Cout, H, W, ks):
+    """sln_spade_conv_sums: the LayerNorm2D sums and SEBlock2's pixel sums of what the epilogue wrote (models/SPADE_related.py:70-85,
+    128-149) against torch on the conv's own output."""
+    L = pkg("_lib"); S = pkg("host.SPADE_related")
+    g = torch.Generator().manual_seed(Cin + 7 * Cout)
+    x = (torch.randn(B, Cin, H, W, generator=g) + 0.3).cuda()
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5).cuda()
+    wp, rp = S._pack(w)
+    bp = torch.zeros(rp, device="cuda"); bp[:Cout] = torch.randn(Cout, generator=g).cuda()
+    for act in (0, 2):
+        y = torch.empty(B, Cout, H, W, device="cuda")
+        ln = torch.zeros(16 * B, dtype=torch.float64, device="cuda"); gap = torch.zeros(B, Cout, dtype=torch.float64, device="cuda")
+        L.check(L.lib().sln_spade_conv_sums(L.ptr(x), B, Cin, H, W, L.ptr(wp), L.ptr(bp), Cout, rp, ks, act, 0.2, L.ptr(y), L.ptr(ln), L.ptr(gap),
+                                            L.current_stream_ptr()), "conv_sums")
+        y2 = torch.empty_like(y)
+        L.check(L.lib().sln_spade_conv(L.ptr(x), B, Cin, H, W, L.ptr(wp), L.ptr(bp), Cout, rp, ks, act, 0.2, L.ptr(y2), L.current_stream_ptr()), "conv")
+        assert torch.equal(y, y2)
+        yd = y.double()
+        ln = ln.view(B, 16)
+        assert_close(ln[:, 0].cpu().numpy(), yd.sum((1, 2, 3)).cpu().numpy(), "sum", rtol=1e-6, atol=1e-4)
+        assert_close(ln[:, 1].cpu().numpy(), (yd * yd).sum((1, 2, 3)).cpu().numpy(), "sumsq", rtol=1e-6)
+        assert_close(gap.cpu().numpy(), yd.sum((2, 3)).cpu().numpy(), "pixel sums", rtol=1e-5, atol=1e-4)
+        stats = torch.empty(B, 2, device="cuda")
+        L.check(L.lib().sln_layernorm_finalize(L.ptr(ln), B, Cout * H * W, 1, 1e-5, L.ptr(stats), L.current_stream_ptr()), "finalize")
+        flat = y.reshape(B, -1)
+        assert_close(stats[:, 0].cpu().numpy(), flat.mean(1).cpu().numpy(), "mean", rtol=1e-5, atol=1e-6)
+        assert_close(stats[:, 1].cpu().numpy(), (1.0 / (flat.std(1) + 1e-5)).cpu().numpy(), "inv", rtol=1e-5)
+
+
+@pytest.mark.parametrize("up_mode,xs_up,with_sums", [(-1, 0, True), (-1, 1, False), (0, 0, True), (1, 0, False), (1, 1, True), (0, 1, False)])
+def test_block_tail_against_torch(up_mode, xs_up, with_sums):
+    """x_s + SEBlock2(dx) (:70-85, :1492-1493), nn.Upsample (:1585-1600) and the next LayerNorm2D's statistics in one launch."""
+    L = pkg("_lib")
+    g = torch.Generator().manual_seed(5 + up_mode)
+    B, C, H, W = 3, 24, 12, 8
+    dx = torch.randn(B, C, H, W, generator=g).cuda() + 0.2
+    xs_small = torch.randn(B, C, H // 2, W // 2, generator=g).cuda()
+    xs = F.interpolate(xs_small, scale_factor=2, mode="nearest") if xs_up else torch.randn(B, C, H, W, generator=g).cuda()
+    w0 = torch.randn(C // 8, C, generator=g).cuda(); w2 = torch.randn(C, C // 8, generator=g).cuda()
+    scale = torch.sigmoid(F.relu(dx.mean((2, 3)) @ w0.t()) @ w2.t())
+    v = xs + dx * scale[:, :, None, None]
+    ref = v if up_mode < 0 else F.interpolate(v, scale_factor=2, mode="nearest" if up_mode == 0 else "bilinear",
+                                              **({} if up_mode == 0 else {"align_corners": False}))
+    k = 1 if up_mode < 0 else 2
+    out = torch.empty(B, C, k * H, k * W, device="cuda")
+    acc = torch.full((16 * B,), 7.0, dtype=torch.float64, device="cuda")       # zeroed by the call
+    stats = torch.empty(B, 2, device="cuda")
+    scratch = torch.empty(2 * B * C, device="cuda")
+    sums = dx.double().sum((2, 3)).contiguous() if with_sums else None
+    for rep in (1, 4):
+        L.check(L.lib().sln_block_tail(L.ptr(xs_small if xs_up else xs), xs_up, L.ptr(dx), B, C, H, W, L.ptr(sums) if with_sums else None,
+                                       L.ptr(w0), L.ptr(w2), L.ptr(scratch), up_mode, L.ptr(out), L.ptr(acc), rep, 1e-5, L.ptr(stats),
+                                       L.current_stream_ptr()), "tail")
+        assert_close(out.cpu().numpy(), ref.cpu().numpy(), "tail output", rtol=1e-5, atol=1e-5)
+        normed = ref if rep == 1 else F.interpolate(ref, scale_factor=2, mode="nearest")
+        flat = normed.reshape(B, -1)
+        assert_close(stats[:, 0].cpu().numpy(), flat.mean(1).cpu().numpy(), "mean", rtol=1e-5, atol=1e-6)
+        assert_close(stats[:, 1].cpu().numpy(), (1.0 / (flat.std(1) + 1e-5)).cpu().numpy(), "inv", rtol=1e-5)
+    assert L.lib().sln_block_tail(L.ptr(xs), 0, L.ptr(dx), B, C, H, 6, None, L.ptr(w0), L.ptr(w2), L.ptr(scratch), -1, L.ptr(out), None, 1, 1e-5,
+                                  None, L.current_stream_ptr()) < 0                # a row must be a whole number of float4
+
+
+@pytest.mark.parametrize("crop,B", [(128, 3), (256, 2)])
+def test_fused_schedule_against_oracle_and_unfused(crop, B):
+    """The fused schedule (conv epilogue sums, block tail, nearest upsampling read through by its consumers) against the oracle
+    and against the one-launch-per-module schedule on the same weights: every block output and the image."""
+    S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(ngf=8, nz=16, crop_size=crop)
+    sd = spade_ref.init_state(cfg, seed=11)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, z = spade_ref.synth_input(cfg, B, seed=4)
+    taps_ref, taps, taps_u = {}, {}, {}
+    ref = spade_ref.generator(sd, cfg, seg, z, taps_ref)
+    out = G(seg.cuda(), z.cuda(), taps=taps)
+    G.unfused = True
+    out_u = G(seg.cuda(), z.cuda(), taps=taps_u)
+    assert set(taps) == set(taps_ref) == set(taps_u)
+    for n in taps_ref:
+        scale = float(taps_ref[n].abs().max())
+        assert_close(taps[n].cpu().numpy(), taps_ref[n].numpy(), "fused:" + n, rtol=1e-4, atol=1e-4 * scale)
+        assert_close(taps[n].cpu().numpy(), taps_u[n].cpu().numpy(), "fused vs unfused:" + n, rtol=1e-5, atol=2e-5 * scale)
+    assert_close(out.cpu().numpy(), ref.numpy(), "fused:image", rtol=1e-4, atol=1e-4)
+    assert_close(out.cpu().numpy(), out_u.cpu().numpy(), "fused vs unfused:image", rtol=1e-5, atol=2e-4)      # see the full-size test
