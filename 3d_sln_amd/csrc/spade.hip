@@ -49,6 +49,15 @@ struct ConvArgs {
 };
 constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples (one 128-byte line each)
 
+// Read one accumulator element where it is used.  Left to itself the register allocator copies all 64 accumulator registers of
+// a wave out of the AGPRs in one place after the K loop, and that copy - not the loop - sets the kernel's VGPR count (182 -> 2
+// waves per SIMD); pinned to the use, the epilogue works through 16 values at a time and three workgroups fit a CU.
+__device__ __forceinline__ float acc_read(const float& v) {
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(v));
+  return r;
+}
+
 __device__ __forceinline__ int reflect_idx(int i, int n) {      // ReflectionPad2d(1) (pad < n)
   i = i < 0 ? -i : i;
   return i >= n ? 2 * n - 2 - i : i;
@@ -133,6 +142,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
   };
 
+  const int wr = (wave / WN) * 64;                 // wave's first row inside the block
+  const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
+  const int li = lane & 31, lk = lane >> 5;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -140,10 +152,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int wr = (wave / WN) * 64;                 // wave's first row inside the block
-  const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
-  const int li = lane & 31, lk = lane >> 5;
   // pixel of this lane for pixel-tile j: m = wp0 + 32 j + li -> (py, px)
   int pbase[TN];
 #pragma unroll
@@ -157,21 +165,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     if (ch + 1 < nchunks) gload(ch + 1);
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
+    // 36 (tap, channel pair) steps of 4 MFMAs; the operands of step s + 1 are read from LDS before the MFMAs of step s issue
+    // (hipcc on its own sinks each step's ds_reads to right in front of its first MFMA: the scheduler is fenced)
+    constexpr int NS = TAPS * (CK / 2);
+    auto ld = [&](int st, float (&av)[TM], float (&bv)[TN]) {
+      const int tap = st / (CK / 2), kk = (st % (CK / 2)) * 2;
       const int toff = KS == 3 ? (tap / 3) * (TW + 2) + (tap % 3) : 0;
 #pragma unroll
-      for (int kk = 0; kk < CK; kk += 2) {
-        float av[TM], bv[TN];
+      for (int i = 0; i < TM; ++i) av[i] = wl[(tap * CK + kk + lk) * BMC + wr + 32 * i + li];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = wl[(tap * CK + kk + lk) * BMC + wr + 32 * i + li];
+      for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
+    };
+    auto mma = [&](const float (&av)[TM], const float (&bv)[TN]) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    float av0[TM], bv0[TN], av1[TM], bv1[TN];
+    ld(0, av0, bv0);
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-      }
+    for (int st = 0; st < NS; st += 2) {
+      ld(st + 1, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 2 < NS) ld(st + 2, av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                     // everyone done reading the LDS slab
     if (ch + 1 < nchunks) { lstore(ch + 1); __syncthreads(); }
@@ -183,32 +205,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   // (and the previous element's store) before issuing the next ones - 32 serialized memory round trips per lane, ~10 us per
   // 128 x 128 tile of the modulation convolutions.
   if (EPI == CEPI_BIAS_ACT) {
-    float bias[TM][16];
+    // one 32 x 32 tile at a time, the scheduler fenced between tiles: with everything hoisted the epilogue, not the K loop, set
+    // the kernel's register count and cost a third of the occupancy
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      float bias[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = min(r0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, a.rows - 1);
-        bias[i][r] = a.bias ? a.bias[row] : 0.f;
+        bias[r] = a.bias ? a.bias[row] : 0.f;
       }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int m = wp0 + 32 * j + li;
-      const int py = y0 + m / TW, px = x0 + m % TW;
-      const bool pv = py < a.H && px < a.W;
-      const size_t pix = (size_t)py * a.W + px;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) {
+        const int m = wp0 + 32 * j + li;
+        const int py = y0 + m / TW, px = x0 + m % TW;
+        const bool pv = py < a.H && px < a.W;
+        const size_t pix = (size_t)py * a.W + px;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = r0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-          float v = acc[i][j][r] + bias[i][r];
+          float v = acc_read(acc[i][j][r]) + bias[r];
           if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
           else if (a.act == ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
           const bool ok = pv && row < a.rows;
           if (ok) a.y[((size_t)b * a.rows + row) * plane + pix] = v;
           acc[i][j][r] = ok ? v : 0.f;               // what was written, for the reductions below
         }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (a.ln_acc) {
       // LayerNorm2D sums of the written values in fp64 (as the stand-alone statistics kernel); 2 atomics per block
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) { const double v = acc[i][j][r]; d1 += v; d2 = fma(v, v, d2); }
+          for (int r = 0; r < 16; ++r) { const double v = acc_read(acc[i][j][r]); d1 += v; d2 = fma(v, v, d2); }
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
       double* red = reinterpret_cast<double*>(lds);      // the slabs are free: the K loop ended with a barrier
@@ -240,7 +264,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int r = 0; r < 16; ++r) {
           float v = 0.f;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) v += acc[i][j][r];
+          for (int j = 0; j < TN; ++j) v += acc_read(acc[i][j][r]);
           tr[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk) * 33 + li] = v;
         }
       __syncthreads();
@@ -254,38 +278,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     // rows of this wave: [32 gamma | 32 beta] of channels cbase .. cbase+31
     const int cbase = (r0 + wr) / 2;
     const float mean = a.stats[2 * b], inv = a.stats[2 * b + 1];
-    float gb[16], bb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      gb[r] = a.bias[r0 + wr + cl];
-      bb[r] = a.bias[r0 + wr + 32 + cl];
-    }
+    // uniform per-sample bases + 32-bit lane offsets (one VGPR per address instead of two; C * plane < 2^31, checked by the caller)
+    const unsigned xplane = a.xin_up ? (unsigned)(plane >> 2) : (unsigned)plane;
+    const float* __restrict__ xinb = a.xin + (size_t)b * a.C * xplane;
+    float* __restrict__ yb = a.y + (size_t)b * a.C * plane;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int m = wp0 + 32 * j + li;
       const int py = y0 + m / TW, px = x0 + m % TW;
       const bool pv = py < a.H && px < a.W;
-      const size_t pix = (size_t)py * a.W + px;
+      const unsigned pix = (unsigned)py * a.W + px;
       const int pyc = min(py, a.H - 1), pxc = min(px, a.W - 1);
-      const size_t pixc = a.xin_up ? (size_t)(pyc >> 1) * (a.W >> 1) + (pxc >> 1) : (size_t)pyc * a.W + pxc;
-      const size_t xplane = a.xin_up ? plane >> 2 : plane;
-      float xin[16];
+      const unsigned pixc = a.xin_up ? (unsigned)(pyc >> 1) * (a.W >> 1) + (pxc >> 1) : (unsigned)pyc * a.W + pxc;
+      float xin[16], gb[16], bb[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int c = min(cbase + (r & 3) + 8 * (r >> 2) + 4 * lk, a.C - 1);
-        xin[r] = a.xin[((size_t)b * a.C + c) * xplane + pixc];
+        const int cl = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        const unsigned c = min(cbase + cl, a.C - 1);
+        xin[r] = xinb[c * xplane + pixc];
+        gb[r] = a.bias[r0 + wr + cl];
+        bb[r] = a.bias[r0 + wr + 32 + cl];
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int c = cbase + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        const float gamma = acc[0][j][r] + gb[r];
-        const float beta = acc[1][j][r] + bb[r];
+        const float gamma = acc_read(acc[0][j][r]) + gb[r];
+        const float beta = acc_read(acc[1][j][r]) + bb[r];
         float v = (xin[r] - mean) * inv;
         v = v * (1.f + gamma) + beta;
         if (a.act == ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
-        if (pv && c < a.C) a.y[((size_t)b * a.C + c) * plane + pix] = v;
+        if (pv && c < a.C) yb[(unsigned)c * (unsigned)plane + pix] = v;
       }
+      __builtin_amdgcn_sched_barrier(0);             // one pixel tile's 16 loads in flight at a time (register count, see above)
     }
   }
 }
@@ -640,6 +664,7 @@ int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp
 int sln_spade_modulate_up(const float* actv, int B, int Cin, int H, int W, const float* wp, const float* bias, int C, int rows_pad,
                           const float* xin, int xin_up, const float* stats, int act, float slope, float* out, void* stream) {
   if (xin_up && ((H | W) & 1)) return SLN_E_BADARG;
+  if ((int64_t)C * H * W >= (int64_t)1 << 31) return SLN_E_UNSUPPORTED;      // 32-bit offsets inside a sample
   if (!actv || !wp || !bias || !xin || !stats || !out || B <= 0 || C <= 0 || rows_pad % 64 != 0 || rows_pad < 64 * ((C + 31) / 32))
     return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
