@@ -17,6 +17,7 @@
 //     registers and gamma/beta never touch HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sln_hip.h"
 #include "sln_common.h"
@@ -63,142 +64,15 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {      // ReflectionPad
   return i >= n ? 2 * n - 2 - i : i;
 }
 
-// BMC: channels (rows) per block (64 or 128); KS: 1 or 3.  4 waves: WM x WN over (rows, pixels).
-template <int BMC, int KS, int EPI>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int TAPS = KS * KS;
-  constexpr int WM = BMC / 64;                 // waves along rows (each wave: 64 rows = 2 tiles)
-  constexpr int WN = 4 / WM;                   // waves along pixels
-  constexpr int TN = 128 / WN / 32;            // pixel tiles per wave (128 pixels per block)
-  constexpr int TM = 2;
-  constexpr int HS = KS == 3 ? HALO : TH * TW; // floats per channel in the LDS patch
-  constexpr int WSLAB = TAPS * CK * BMC;
-  constexpr int NW4 = (WSLAB / 4 + 255) / 256; // float4 weight loads per thread per chunk (tail slots clamped)
-  constexpr int NH = (CK * HS + 255) / 256;    // scalar patch loads per thread per chunk
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* wl = lds;                             // [TAPS][CK][BMC]
-  float* xl = lds + WSLAB;                     // [CK][HS]
-
+// Epilogue shared by the conv kernels.  4 waves: WM x WN over (rows, pixels); acc[i][j] = 32 rows x 32 pixels.
+template <int BMC, int EPI>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][(BMC / 64) * 128 / 4 / 32], float* lds, int b, int r0,
+                                              int x0, int y0) {
+  constexpr int WM = BMC / 64, WN = 4 / WM, TN = 128 / WN / 32, TM = 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-  int bid = blockIdx.x;
-  const int tx = bid % tiles_x; bid /= tiles_x;
-  const int ty = bid % tiles_y; bid /= tiles_y;
-  const int b = bid;
-  const int r0 = blockIdx.y * BMC;             // first packed row of this block
-  const int x0 = tx * TW, y0 = ty * TH;
-  const size_t plane = (size_t)a.H * a.W;
-  const float* xb = a.x + (size_t)b * a.Cin * plane;
-
-  // per-thread patch positions (constant over chunks): element e -> (channel-in-chunk, pos) -> global offset
-  int h_off[NH], h_lds[NH];
-#pragma unroll
-  for (int j = 0; j < NH; ++j) {
-    const int e = tid + 256 * j;
-    const int c = e / HS, p = e % HS;
-    int gy, gx;
-    if (KS == 3) { gy = reflect_idx(y0 + p / (TW + 2) - 1, a.H); gx = reflect_idx(x0 + p % (TW + 2) - 1, a.W); }
-    else { gy = min(y0 + p / TW, a.H - 1); gx = min(x0 + p % TW, a.W - 1); }
-    gy = min(max(gy, 0), a.H - 1); gx = min(max(gx, 0), a.W - 1);
-    h_off[j] = e < CK * HS ? (int)(c * plane + (size_t)gy * a.W + gx) : 0;     // tail slots load a valid address, never stored
-    h_lds[j] = e;
-  }
-  float hreg[NH];
-  float4 wreg[NW4];
-  const int nchunks = (a.Cin + CK - 1) / CK;
-
-  auto gload = [&](int ch) {
-    const int ci0 = ch * CK;
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const int c = min((tid + 256 * j) / HS, CK - 1);
-      // unconditional load (clamped channel); surplus channels / tail slots are dropped at the LDS store
-      const int cc = min(ci0 + c, a.Cin - 1) - c;
-      hreg[j] = xb[(ptrdiff_t)cc * (ptrdiff_t)plane + h_off[j]];
-    }
-#pragma unroll
-    for (int j = 0; j < NW4; ++j) {
-      const int e4 = min(tid + 256 * j, WSLAB / 4 - 1);     // float4 index inside the slab [TAPS][CK][BMC/4]
-      const int col4 = e4 % (BMC / 4), rr = e4 / (BMC / 4); // rr = tap*CK + c
-      const int tap = rr / CK, c = rr % CK;
-      const int ci = min(ci0 + c, a.Cin - 1);
-      wreg[j] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Cin + ci) * a.rows_pad + r0 + 4 * col4);
-    }
-  };
-  auto lstore = [&](int ch) {
-    const int ci0 = ch * CK;
-#pragma unroll
-    for (int j = 0; j < NH; ++j) {
-      const int e = h_lds[j];
-      if (e < CK * HS) xl[e] = (ci0 + e / HS) < a.Cin ? hreg[j] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < NW4; ++j) {
-      const int e4 = tid + 256 * j;
-      const int c = (e4 / (BMC / 4)) % CK;
-      float4 v = wreg[j];
-      if (ci0 + c >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e4 < WSLAB / 4) *reinterpret_cast<float4*>(wl + 4 * e4) = v;
-    }
-  };
-
-  const int wr = (wave / WN) * 64;                 // wave's first row inside the block
-  const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
+  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (128 / WN);
   const int li = lane & 31, lk = lane >> 5;
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // pixel of this lane for pixel-tile j: m = wp0 + 32 j + li -> (py, px)
-  int pbase[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int m = wp0 + 32 * j + li;
-    pbase[j] = KS == 3 ? (m / TW) * (TW + 2) + (m % TW) : m;
-  }
-
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) gload(ch + 1);
-    // 36 (tap, channel pair) steps of 4 MFMAs; the operands of step s + 1 are read from LDS before the MFMAs of step s issue
-    // (hipcc on its own sinks each step's ds_reads to right in front of its first MFMA: the scheduler is fenced)
-    constexpr int NS = TAPS * (CK / 2);
-    auto ld = [&](int st, float (&av)[TM], float (&bv)[TN]) {
-      const int tap = st / (CK / 2), kk = (st % (CK / 2)) * 2;
-      const int toff = KS == 3 ? (tap / 3) * (TW + 2) + (tap % 3) : 0;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = wl[(tap * CK + kk + lk) * BMC + wr + 32 * i + li];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
-    };
-    auto mma = [&](const float (&av)[TM], const float (&bv)[TN]) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-    };
-    float av0[TM], bv0[TN], av1[TM], bv1[TN];
-    ld(0, av0, bv0);
-#pragma unroll
-    for (int st = 0; st < NS; st += 2) {
-      ld(st + 1, av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(av0, bv0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (st + 2 < NS) ld(st + 2, av0, bv0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(av1, bv1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    __syncthreads();                     // everyone done reading the LDS slab
-    if (ch + 1 < nchunks) { lstore(ch + 1); __syncthreads(); }
-  }
-
+  const size_t plane = (size_t)a.H * a.W;
   // ---- epilogue: lane = pixel (li), register r = row (r&3) + 8 (r>>2) + 4 lk inside the 32-row tile.
   // All loads first (bias per row once, x per output element; unconditional, clamped addresses), then the arithmetic, then the
   // stores: written as "if (valid) { load, load, load, compute, store }" per element, hipcc waited for every element's loads
@@ -314,21 +188,293 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
+// BMC: channels (rows) per block (64 or 128); KS: 1 or 3.  4 waves: WM x WN over (rows, pixels).
+template <int BMC, int KS, int EPI>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int TAPS = KS * KS;
+  constexpr int WM = BMC / 64;                 // waves along rows (each wave: 64 rows = 2 tiles)
+  constexpr int WN = 4 / WM;                   // waves along pixels
+  constexpr int TN = 128 / WN / 32;            // pixel tiles per wave (128 pixels per block)
+  constexpr int TM = 2;
+  constexpr int HS = KS == 3 ? HALO : TH * TW; // floats per channel in the LDS patch
+  constexpr int WSLAB = TAPS * CK * BMC;
+  constexpr int NW4 = (WSLAB / 4 + 255) / 256; // float4 weight loads per thread per chunk (tail slots clamped)
+  constexpr int NH = (CK * HS + 255) / 256;    // scalar patch loads per thread per chunk
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* wl = lds;                             // [TAPS][CK][BMC]
+  float* xl = lds + WSLAB;                     // [CK][HS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int r0 = blockIdx.y * BMC;             // first packed row of this block
+  const int x0 = tx * TW, y0 = ty * TH;
+  const size_t plane = (size_t)a.H * a.W;
+  const float* xb = a.x + (size_t)b * a.Cin * plane;
+
+  // per-thread patch positions (constant over chunks): element e -> (channel-in-chunk, pos) -> global offset
+  int h_off[NH], h_lds[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int e = tid + 256 * j;
+    const int c = e / HS, p = e % HS;
+    int gy, gx;
+    if (KS == 3) { gy = reflect_idx(y0 + p / (TW + 2) - 1, a.H); gx = reflect_idx(x0 + p % (TW + 2) - 1, a.W); }
+    else { gy = min(y0 + p / TW, a.H - 1); gx = min(x0 + p % TW, a.W - 1); }
+    gy = min(max(gy, 0), a.H - 1); gx = min(max(gx, 0), a.W - 1);
+    h_off[j] = e < CK * HS ? (int)(c * plane + (size_t)gy * a.W + gx) : 0;     // tail slots load a valid address, never stored
+    h_lds[j] = e;
+  }
+  float hreg[NH];
+  float4 wreg[NW4];
+  const int nchunks = (a.Cin + CK - 1) / CK;
+
+  auto gload = [&](int ch) {
+    const int ci0 = ch * CK;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int c = min((tid + 256 * j) / HS, CK - 1);
+      // unconditional load (clamped channel); surplus channels / tail slots are dropped at the LDS store
+      const int cc = min(ci0 + c, a.Cin - 1) - c;
+      hreg[j] = xb[(ptrdiff_t)cc * (ptrdiff_t)plane + h_off[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e4 = min(tid + 256 * j, WSLAB / 4 - 1);     // float4 index inside the slab [TAPS][CK][BMC/4]
+      const int col4 = e4 % (BMC / 4), rr = e4 / (BMC / 4); // rr = tap*CK + c
+      const int tap = rr / CK, c = rr % CK;
+      const int ci = min(ci0 + c, a.Cin - 1);
+      wreg[j] = *reinterpret_cast<const float4*>(a.wp + ((size_t)tap * a.Cin + ci) * a.rows_pad + r0 + 4 * col4);
+    }
+  };
+  auto lstore = [&](int ch) {
+    const int ci0 = ch * CK;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int e = h_lds[j];
+      if (e < CK * HS) xl[e] = (ci0 + e / HS) < a.Cin ? hreg[j] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NW4; ++j) {
+      const int e4 = tid + 256 * j;
+      const int c = (e4 / (BMC / 4)) % CK;
+      float4 v = wreg[j];
+      if (ci0 + c >= a.Cin) v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e4 < WSLAB / 4) *reinterpret_cast<float4*>(wl + 4 * e4) = v;
+    }
+  };
+
+  const int wr = (wave / WN) * 64;                 // wave's first row inside the block
+  const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
+  const int li = lane & 31, lk = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // pixel of this lane for pixel-tile j: m = wp0 + 32 j + li -> (py, px)
+  int pbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int m = wp0 + 32 * j + li;
+    pbase[j] = KS == 3 ? (m / TW) * (TW + 2) + (m % TW) : m;
+  }
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) gload(ch + 1);
+    // 36 (tap, channel pair) steps of 4 MFMAs; the operands of step s + 1 are read from LDS before the MFMAs of step s issue
+    // (hipcc on its own sinks each step's ds_reads to right in front of its first MFMA: the scheduler is fenced)
+    // 36 (tap, channel pair) steps of 4 MFMAs; the operands of step s + 1 are read from LDS before the MFMAs of step s issue
+    // (hipcc on its own sinks each step's ds_reads to right in front of its first MFMA: the scheduler is fenced).  All 36 steps
+    // unrolled: rolled per tap, the 25 scalar / address instructions at the loop end outlast the tap's last MFMA and the K loop
+    // alone drops from 154 to 139 TFLOP/s (tools/lab/mfma_peak modes 6 / 4); the two-way bank conflict of the two-row pixel tile
+    // costs nothing once unrolled (modes 6 / 7), a conflict-free 48-float row stride measured 0.7 % slower (larger LDS image).
+    constexpr int NS = TAPS * (CK / 2);
+    auto ld = [&](int st, float (&av)[TM], float (&bv)[TN]) {
+      const int tap = st / (CK / 2), kk = (st % (CK / 2)) * 2;
+      const int toff = KS == 3 ? (tap / 3) * (TW + 2) + (tap % 3) : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = wl[(tap * CK + kk + lk) * BMC + wr + 32 * i + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
+    };
+    auto mma = [&](const float (&av)[TM], const float (&bv)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    float av0[TM], bv0[TN], av1[TM], bv1[TN];
+    ld(0, av0, bv0);
+#pragma unroll
+    for (int st = 0; st < NS; st += 2) {
+      ld(st + 1, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (st + 2 < NS) ld(st + 2, av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                     // everyone done reading the LDS slab
+    if (ch + 1 < nchunks) { lstore(ch + 1); __syncthreads(); }
+  }
+
+  conv_epilogue<BMC, EPI>(a, acc, lds, b, r0, x0, y0);
+}
+
+// The same convolution with its operands DMA'd straight into LDS (global_load_lds, Cin % 4 == 0): no staging registers and no
+// ds_write pass between two barriers per chunk.  Two LDS buffers of GK = 4 input channels each ([9][4][rows] weights + the
+// 4-channel halo, 21.5 KB per buffer at 128 rows): the loads of chunk c + 1 are issued right after the single barrier that
+// opens chunk c and have the whole chunk (72 MFMAs per wave) to land.  ~75 VGPRs + 64 accumulators and 43 KB of LDS: three
+// workgroups per CU (the register-staged kernel above: two).  Measured on the modulation convs of up_3 (B 32, 128 -> 2 x 128
+// channels at 256 x 256): MFMA phase 8.9 ms of 10.3 ms in the staged kernel - the rest was its load/store/barrier phases.
+constexpr int GK = 4;
+template <int BMC, int KS, int EPI>
+__global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
+  constexpr int TAPS = KS * KS;
+  constexpr int WM = BMC / 64, WN = 4 / WM, TN = 128 / WN / 32, TM = 2;
+  constexpr int HS = KS == 3 ? HALO : TH * TW;
+  constexpr int WSLAB = TAPS * GK * BMC;            // floats; WSLAB / 4 float4 is a multiple of 64: whole waves per round
+  constexpr int NWR = (WSLAB / 4 + 255) / 256;      // rounds of 256 x 16 B
+  constexpr int NHR = (GK * HS + 255) / 256;        // rounds of 256 x 4 B (the last one runs past the patch into padding)
+  constexpr int BUF = WSLAB + NHR * 256;
+  static_assert((WSLAB / 4) % 64 == 0, "weight slab is a whole number of wave-wide 16-byte loads");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y; bid /= tiles_y;
+  const int b = bid;
+  const int r0 = blockIdx.y * BMC;
+  const int x0 = tx * TW, y0 = ty * TH;
+  const size_t plane = (size_t)a.H * a.W;
+  const float* xb = a.x + (size_t)b * a.Cin * plane;
+
+  // per-lane source offsets inside a chunk (constant over chunks)
+  unsigned h_off[NHR], w_off[NWR];
+#pragma unroll
+  for (int j = 0; j < NHR; ++j) {
+    const int e = tid + 256 * j;
+    const int c = e / HS, p = e % HS;
+    int gy, gx;
+    if (KS == 3) { gy = reflect_idx(y0 + p / (TW + 2) - 1, a.H); gx = reflect_idx(x0 + p % (TW + 2) - 1, a.W); }
+    else { gy = y0 + p / TW; gx = x0 + p % TW; }
+    gy = min(max(gy, 0), a.H - 1); gx = min(max(gx, 0), a.W - 1);
+    h_off[j] = e < GK * HS ? (unsigned)(c * plane + (size_t)gy * a.W + gx) : 0u;     // padding lanes fetch a valid word
+  }
+#pragma unroll
+  for (int j = 0; j < NWR; ++j) {
+    const int e4 = min(tid + 256 * j, WSLAB / 4 - 1);
+    const int col4 = e4 % (BMC / 4), rr = e4 / (BMC / 4);   // rr = tap * GK + c
+    w_off[j] = (unsigned)(((rr / GK) * a.Cin + rr % GK) * a.rows_pad + 4 * col4);
+  }
+  auto issue = [&](int ch, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the DMA builtin exists in the device pass only (the host pass must still emit the launch stub)
+    float* wb = lds + buf * BUF;
+    const float* ws = a.wp + (size_t)ch * GK * a.rows_pad + r0;
+    const float* xs = xb + (size_t)ch * GK * plane;
+#pragma unroll
+    for (int j = 0; j < NWR; ++j)
+      if (256 * (j + 1) <= WSLAB / 4 || 256 * j + 64 * wave < WSLAB / 4)
+        __builtin_amdgcn_global_load_lds(ws + w_off[j], (lds_ptr)(wb + 4 * (256 * j + 64 * wave)), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NHR; ++j)
+      __builtin_amdgcn_global_load_lds(xs + h_off[j], (lds_ptr)(wb + WSLAB + 256 * j + 64 * wave), 4, 0, 0);
+#endif
+  };
+
+  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (128 / WN);
+  const int li = lane & 31, lk = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  int pbase[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int m = wp0 + 32 * j + li;
+    pbase[j] = KS == 3 ? (m / TW) * (TW + 2) + (m % TW) : m;
+  }
+
+  const int nchunks = a.Cin / GK;
+  issue(0, 0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();                 // chunk ch has landed (the barrier drains the DMA queue); nobody reads the other buffer any more
+    if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
+    const float* wl = lds + (ch & 1) * BUF;
+    const float* xl = wl + WSLAB;
+    auto ld = [&](int tap, int kk, float (&av)[TM], float (&bv)[TN]) {
+      const int toff = KS == 3 ? (tap / 3) * (TW + 2) + (tap % 3) : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = wl[(tap * GK + kk + lk) * BMC + wr + 32 * i + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = xl[(kk + lk) * HS + pbase[j] + toff];
+    };
+    auto mma = [&](const float (&av)[TM], const float (&bv)[TN]) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    float av0[TM], bv0[TN], av1[TM], bv1[TN];
+    ld(0, 0, av0, bv0);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {           // operands of the next step read before the MFMAs of this one (fenced, see above)
+      ld(tap, 2, av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      ld(tap + 1 < TAPS ? tap + 1 : tap, 0, av0, bv0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(av1, bv1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();                   // the epilogue's reductions reuse the buffers
+  conv_epilogue<BMC, EPI>(a, acc, lds, b, r0, x0, y0);
+}
+
 template <int BMC, int KS, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? HALO : TH * TW;
-  size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
+  static const bool staged_only = getenv("SLN_CONV_STAGED") != nullptr;      // A/B runs
+  // measured per shape (tools/lab/conv_lab.py, same box): the DMA kernel wins 2 % on the modulation convs (128 input channels, 16
+  // chunks of 8), loses 2-6 % on the bias/activation convs (64-row blocks, 1 024 input channels: twice the barriers)
+  static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
+  const bool dma = a.Cin % GK == 0 && !staged_only && (EPI == CEPI_MODULATE || dma_all);
+  size_t smem = dma ? sizeof(float) * 2 * (size_t)(TAPS * GK * BMC + ((GK * HS + 255) / 256) * 256)
+                    : sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
   static bool raised = false;
-  if (!raised && smem > 48 * 1024) {
+  if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BMC, KS, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B;
-  hipLaunchKernelGGL((conv_mfma_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  if (dma) hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL((conv_mfma_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
