@@ -65,12 +65,12 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {      // ReflectionPad
 }
 
 // Epilogue shared by the conv kernels.  4 waves: WM x WN over (rows, pixels); acc[i][j] = 32 rows x 32 pixels.
-template <int BMC, int EPI>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][(BMC / 64) * 128 / 4 / 32], float* lds, int b, int r0,
+template <int BMC, int EPI, int THT = TH>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2][(BMC / 64) * THT * TW / 4 / 32], float* lds, int b, int r0,
                                               int x0, int y0) {
-  constexpr int WM = BMC / 64, WN = 4 / WM, TN = 128 / WN / 32, TM = 2;
+  constexpr int WM = BMC / 64, WN = 4 / WM, TN = THT * TW / WN / 32, TM = 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (128 / WN);
+  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (THT * TW / WN);
   const int li = lane & 31, lk = lane >> 5;
   const size_t plane = (size_t)a.H * a.W;
   // ---- epilogue: lane = pixel (li), register r = row (r&3) + 8 (r>>2) + 4 lk inside the 32-row tile.
@@ -339,11 +339,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // workgroups per CU (the register-staged kernel above: two).  Measured on the modulation convs of up_3 (B 32, 128 -> 2 x 128
 // channels at 256 x 256): MFMA phase 8.9 ms of 10.3 ms in the staged kernel - the rest was its load/store/barrier phases.
 constexpr int GK = 4;
-template <int BMC, int KS, int EPI>
+template <int BMC, int KS, int EPI, int THT>
 __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
   constexpr int TAPS = KS * KS;
-  constexpr int WM = BMC / 64, WN = 4 / WM, TN = 128 / WN / 32, TM = 2;
-  constexpr int HS = KS == 3 ? HALO : TH * TW;
+  constexpr int WM = BMC / 64, WN = 4 / WM, TN = THT * TW / WN / 32, TM = 2;   // THT x 16 pixels per workgroup (THT = 8 or 16)
+  constexpr int HS = KS == 3 ? (THT + 2) * (TW + 2) : THT * TW;
   constexpr int WSLAB = TAPS * GK * BMC;            // floats; WSLAB / 4 float4 is a multiple of 64: whole waves per round
   constexpr int NWR = (WSLAB / 4 + 255) / 256;      // rounds of 256 x 16 B
   constexpr int NHR = (GK * HS + 255) / 256;        // rounds of 256 x 4 B (the last one runs past the patch into padding)
@@ -353,13 +353,13 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + THT - 1) / THT;
   int bid = blockIdx.x;
   const int tx = bid % tiles_x; bid /= tiles_x;
   const int ty = bid % tiles_y; bid /= tiles_y;
   const int b = bid;
   const int r0 = blockIdx.y * BMC;
-  const int x0 = tx * TW, y0 = ty * TH;
+  const int x0 = tx * TW, y0 = ty * THT;
   const size_t plane = (size_t)a.H * a.W;
   const float* xb = a.x + (size_t)b * a.Cin * plane;
 
@@ -396,7 +396,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
 #endif
   };
 
-  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (128 / WN);
+  const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (THT * TW / WN);
   const int li = lane & 31, lk = lane >> 5;
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -447,34 +447,53 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();                   // the epilogue's reductions reuse the buffers
-  conv_epilogue<BMC, EPI>(a, acc, lds, b, r0, x0, y0);
+  conv_epilogue<BMC, EPI, THT>(a, acc, lds, b, r0, x0, y0);
+}
+
+template <int BMC, int KS, int EPI, int THT>
+int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+  constexpr int TAPS = KS * KS;
+  constexpr int HS = KS == 3 ? (THT + 2) * (TW + 2) : THT * TW;
+  size_t smem = sizeof(float) * 2 * (size_t)(TAPS * GK * BMC + ((GK * HS + 255) / 256) * 256);
+  if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI, THT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, THT) * a.B;
+  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
 }
 
 template <int BMC, int KS, int EPI>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? HALO : TH * TW;
-  static const bool staged_only = getenv("SLN_CONV_STAGED") != nullptr;      // A/B runs
-  // measured per shape (tools/lab/conv_lab.py, same box): the DMA kernel wins 2 % on the modulation convs (128 input channels, 16
-  // chunks of 8), loses 2-6 % on the bias/activation convs (64-row blocks, 1 024 input channels: twice the barriers)
+  static const bool staged_only = getenv("SLN_CONV_STAGED") != nullptr;      // A/B runs and tests
+  // measured per shape (tools/lab/conv_lab.py, same box): the DMA kernel wins on the modulation convs (128 input channels), loses
+  // 2-6 % on the bias/activation convs (64-row blocks, 1 024 input channels: twice the barriers of the staged kernel)
   static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
-  const bool dma = a.Cin % GK == 0 && !staged_only && (EPI == CEPI_MODULATE || dma_all);
-  size_t smem = dma ? sizeof(float) * 2 * (size_t)(TAPS * GK * BMC + ((GK * HS + 255) / 256) * 256)
-                    : sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
+  static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
+  if (a.Cin % GK == 0 && !staged_only && (EPI == CEPI_MODULATE || dma_all)) {
+    // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, 144 MFMAs per wave and barrier)
+    if (BMC == 128 && KS == 3 && tall && a.H >= 16) return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH)>(a, st);
+    return launch_conv_dma<BMC, KS, EPI, TH>(a, st);
+  }
+  size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
   static bool raised = false;
   if (!raised) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BMC, KS, EPI>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B;
-  if (dma) hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((conv_mfma_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<BMC, KS, EPI>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
