@@ -474,14 +474,16 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? HALO : TH * TW;
   static const bool staged_only = getenv("SLN_CONV_STAGED") != nullptr;      // A/B runs and tests
-  // measured per shape (tools/lab/conv_lab.py, same box): the DMA kernel wins on the modulation convs (128 input channels), loses
-  // 2-6 % on the bias/activation convs (64-row blocks, 1 024 input channels: twice the barriers of the staged kernel)
+  // measured per shape (tools/lab/conv_lab.py, same box): with 8 x 16 pixels per workgroup the DMA kernel wins 2 % on the modulation
+  // convs and loses 2-6 % on the bias/activation convs (twice the barriers of the staged kernel); with 16 x 16 pixels it wins on
+  // every 128-row conv (modulation 9.8 -> 9.15 ms, 1 024 -> 512 channels at 32 x 32 2.34 -> 2.26 ms)
   static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
   static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
-  if (a.Cin % GK == 0 && !staged_only && (EPI == CEPI_MODULATE || dma_all)) {
-    // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, 144 MFMAs per wave and barrier)
+  if (a.Cin % GK == 0 && !staged_only) {
+    // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, twice the MFMAs per barrier)
+    // (64-row blocks: 2 % slower that way, they stay on the staged kernel)
     if (BMC == 128 && KS == 3 && tall && a.H >= 16) return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH)>(a, st);
-    return launch_conv_dma<BMC, KS, EPI, TH>(a, st);
+    if (EPI == CEPI_MODULATE || dma_all) return launch_conv_dma<BMC, KS, EPI, TH>(a, st);
   }
   size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
