@@ -143,6 +143,8 @@ SIGNATURES = {
                                      C.c_int, C.c_float, c_f32p, C.c_void_p]),
     "sln_layernorm_stats": (C.c_int, [c_f32p, C.c_int, C.c_int64, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),
     "sln_spade_apply": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_float, c_f32p, C.c_void_p]),
+    "sln_spade_apply_up": (C.c_int, [c_f32p, C.c_int, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_int, C.c_float, c_f32p,
+                                     C.c_void_p]),
     "sln_resize": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_spade_depth_concat": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_int, C.c_void_p]),
     "sln_se_scale_add": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int, C.c_int64, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -481,8 +481,11 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
   if (a.Cin % GK == 0 && !staged_only) {
     // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, twice the MFMAs per barrier)
-    // (64-row blocks: 2 % slower that way, they stay on the staged kernel)
-    if (BMC == 128 && KS == 3 && tall && a.H >= 16) return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH)>(a, st);
+    // (not for 64-row blocks - 2 % slower that way, they stay on the staged kernel -
+    // and launches too small to give every CU two of the tall workgroups: batch-1 convs of the one-map-many-z path)
+    const long tall_blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, 16) * a.B * (a.rows_pad / BMC);
+    if (BMC == 128 && KS == 3 && tall && a.H >= 16 && tall_blocks >= 512)
+      return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH)>(a, st);
     if (EPI == CEPI_MODULATE || dma_all) return launch_conv_dma<BMC, KS, EPI, TH>(a, st);
   }
   size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
@@ -764,8 +767,10 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
 // SPADE modulation with gamma/beta shared by the whole batch (one semantic map, many z): gb [rows_pad, plane] is the
 // output of the packed [32 gamma | 32 beta] conv for that map; out[b,c,p] = ((x - mu_b) * inv_b) * (1 + gamma) + beta.
 // HBM-bound: x read once, out written once, gb stays in L2/MALL across the batch (blockIdx.y = sample is the slow index).
+// x_up: x is [B, C, H/2, W/2] read through nearest x2 (W given; 4 consecutive outputs of a row = 2 source pixels).
 __global__ __launch_bounds__(256) void spade_apply_kernel(const float* __restrict__ x, const float* __restrict__ gb, int C, long plane,
-                                                          const float* __restrict__ stats, int act, float slope, float* __restrict__ out) {
+                                                          const float* __restrict__ stats, int act, float slope, float* __restrict__ out,
+                                                          int x_up, int W) {
   const long i4 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
   const long n = (long)C * plane;
   if (i4 >= n) return;
@@ -774,7 +779,15 @@ __global__ __launch_bounds__(256) void spade_apply_kernel(const float* __restric
   const long pix = i4 - (long)c * plane;
   const float mean = stats[2 * b], inv = stats[2 * b + 1];
   const long grow = (long)(c / 32) * 64 + (c % 32);
-  const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * n + i4);
+  float4 xv;
+  if (x_up) {
+    const int yo = (int)(pix / W), xo = (int)(pix % W);
+    const float* xs = x + ((size_t)b * C + c) * (plane >> 2) + (size_t)(yo >> 1) * (W >> 1) + (xo >> 1);
+    const float a0 = xs[0], a1 = xs[1];
+    xv = make_float4(a0, a0, a1, a1);
+  } else {
+    xv = *reinterpret_cast<const float4*>(x + (size_t)b * n + i4);
+  }
   const float4 g = *reinterpret_cast<const float4*>(gb + grow * plane + pix);
   const float4 be = *reinterpret_cast<const float4*>(gb + (grow + 32) * plane + pix);
   float4 v;
@@ -794,17 +807,21 @@ __global__ __launch_bounds__(256) void spade_apply_kernel(const float* __restric
 extern "C" {
 
 // Batch-shared modulation (see spade_apply_kernel): gb = sln_spade_conv(actv of the ONE map, packed gamma|beta weights).
-int sln_spade_apply(const float* x, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act, float slope,
-                    float* out, void* stream) {
+int sln_spade_apply_up(const float* x, int x_up, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act,
+                       float slope, float* out, void* stream) {
   if (!x || !gb || !stats || !out || B <= 0 || C <= 0 || rows_pad < 64 * ((C + 31) / 32)) return SLN_E_BADARG;
   const long plane = (long)H * W;
-  if (plane % 4 != 0) return SLN_E_UNSUPPORTED;
+  if (plane % 4 != 0 || (x_up && (W % 4 != 0 || H % 2 != 0))) return SLN_E_UNSUPPORTED;
   const long n4 = (long)C * plane / 4;
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * (2.0 * B * C * plane + 2.0 * C * plane), (hipStream_t)stream);
   hipLaunchKernelGGL(spade_apply_kernel, dim3((unsigned)((n4 + 255) / 256), B), dim3(256), 0, (hipStream_t)stream, x, gb, C, plane, stats, act,
-                     slope, out);
+                     slope, out, x_up, W);
   SLN_CHECK_LAUNCH();
   return 0;
+}
+int sln_spade_apply(const float* x, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act, float slope,
+                    float* out, void* stream) {
+  return sln_spade_apply_up(x, 0, gb, B, C, H, W, rows_pad, stats, act, slope, out, stream);
 }
 
 // conv KSxKS (KS = 3 reflect pad 1, KS = 1) with packed weights wp[KS*KS][Cin][rows_pad]; rows_pad % 64 == 0.

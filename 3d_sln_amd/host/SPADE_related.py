@@ -169,8 +169,7 @@ class SPADEGenerator4(nn.Module):
         H, W = seg.shape[2:]
         nd = NHIDDEN // 8
         if seg.shape[0] == 1 and B > 1 and (H * W) % 4 == 0:
-            assert not x_up
-            return self._spade_shared(e, x, stats, seg, leaky)
+            return self._spade_shared(e, x, stats, seg, leaky, x_up)
         if seg.shape[0] != B:
             seg = seg.expand(B, -1, -1, -1).contiguous()
         cat = self._cat_buffer(seg, nd)
@@ -199,12 +198,13 @@ class SPADEGenerator4(nn.Module):
                 cache[key] = buf
         return buf
 
-    def _spade_shared(self, e, x, stats, seg, leaky):
+    def _spade_shared(self, e, x, stats, seg, leaky, x_up=False):
         """One semantic map for the whole batch (the reference broadcasts gamma/beta [1,C,H,W] in that case, and
         colorize_with_spade is exactly that use: 50 z per room).  gamma/beta - 72 % of the generator's MACs - are computed
         once per map instead of once per sample; the per-sample part is an HBM-bound elementwise pass."""
         L = _lib.lib()
-        B, C, H, W = x.shape
+        B, C = x.shape[:2]
+        H, W = seg.shape[2:]
         nd = NHIDDEN // 8
         cat = self._cat_buffer(seg, nd)
         _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), 1, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
@@ -215,9 +215,9 @@ class SPADEGenerator4(nn.Module):
         gb = torch.empty(1, e["rpg"], H, W, device=x.device)
         _lib.check(L.sln_spade_conv(_lib.ptr(actv), 1, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), e["rpg"], e["rpg"], 3,
                                     0, 0.0, _lib.ptr(gb), self._st()), "sln_spade_conv(gamma|beta)")
-        out = torch.empty_like(x)
-        _lib.check(L.sln_spade_apply(_lib.ptr(x), _lib.ptr(gb), B, C, H, W, e["rpg"], _lib.ptr(stats), 2 if leaky else 0, 0.2,
-                                     _lib.ptr(out), self._st()), "sln_spade_apply")
+        out = torch.empty(B, C, H, W, device=x.device)
+        _lib.check(L.sln_spade_apply_up(_lib.ptr(x), 1 if x_up else 0, _lib.ptr(gb), B, C, H, W, e["rpg"], _lib.ptr(stats),
+                                        2 if leaky else 0, 0.2, _lib.ptr(out), self._st()), "sln_spade_apply_up")
         return out
 
     def _conv(self, x, wbr, cout, ks, ln_acc=None, gap_acc=None):
@@ -329,7 +329,7 @@ class SPADEGenerator4(nn.Module):
             chain = (("head_0", seg_1, 'nearest'), ("G_middle_0", pyr[self.sw * 2], None), ("G_middle_1", pyr[self.sw * 2], 'nearest'),
                      ("up_0", pyr[self.sw * 4], 'nearest'), ("up_1", pyr[self.sw * 8], 'nearest'), ("up_2", pyr[self.sw * 16], 'bilinear'),
                      ("up_3", pyr[S], None))
-            fused = self.sw % 4 == 0 and self.sh % 4 == 0 and not (seg.shape[0] == 1 and B > 1) and not self.unfused
+            fused = self.sw % 4 == 0 and self.sh % 4 == 0 and not self.unfused
             if fused:
                 x, x_up, stats = x.contiguous(), False, None
                 stats = self._ln_stats(x)

@@ -537,8 +537,9 @@ def spade_leg(args, lib, torch):
         tf = c["work"] / (c["ms"] * 1e-3) / 1e12
         res["conv_kernels"] = {"launches": c["launches"], "ms": round(c["ms"], 2), "tflops": round(tf, 2),
                                "frac_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
-        tr, us = profile_rows(["conv_mfma_kernel"])
-        res["roofline"] = {"kernel": "conv_mfma_kernel (3x3 reflect-padded implicit GEMM, %d launches per batch)" % c["launches"], "bound": "mfma",
+        tr, us = profile_rows(["conv_glds_kernel", "conv_mfma_kernel"])
+        res["roofline"] = {"kernel": "conv_glds_kernel + conv_mfma_kernel (reflect-padded implicit GEMM: direct-to-LDS and register-staged "
+                                     "variants, %d launches per batch)" % c["launches"], "bound": "mfma",
                            "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                            "traffic": tr, "flop_per_launch": round(c["work"] / c["launches"], 1), "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),
                            "rocprof_avg_launch_us": us}

@@ -361,6 +361,9 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
  * computed once, then out[b] = LayerNorm2D(xin[b]) * (1 + gamma) + beta for every sample.  H*W % 4 == 0. */
 int sln_spade_apply(const float* xin, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats, int act,
                     float slope, float* out, void* stream);
+/* sln_spade_apply with xin_up = 1: xin is [B, C, H/2, W/2] and stands for its nearest x2 upsampling (W % 4 == 0, H % 2 == 0) */
+int sln_spade_apply_up(const float* xin, int xin_up, const float* gb, int B, int C, int H, int W, int rows_pad, const float* stats,
+                       int act, float slope, float* out, void* stream);
 /* stats[b] = (mean, 1 / (unbiased std + eps)) over the n elements of sample b; scratch: 16 * B doubles */
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream);
 /* F.interpolate(size=...): mode 0 nearest, 1 bilinear(align_corners=False) over BC planes */

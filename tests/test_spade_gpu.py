@@ -105,7 +105,7 @@ def test_generator_against_reference_fixture(name):
 
 def test_one_semantic_map_many_z_equals_the_broadcast_of_the_reference():
     """colorize_with_spade (testing/test_SPADE_shade.py:30-79) draws many z for ONE map; the reference module
-    broadcasts gamma/beta [1,C,H,W] over the batch.  The shared path (gamma/beta computed once, sln_spade_apply per sample)
+    broadcasts gamma/beta [1,C,H,W] over the batch.  The shared path (gamma/beta computed once, sln_spade_apply_up per sample)
     must equal the oracle's broadcast and the per-sample path on the expanded map."""
     S = pkg("host.SPADE_related")
     cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
@@ -290,6 +290,11 @@ def test_fused_schedule_against_oracle_and_unfused(crop, B):
         assert_close(taps[n].cpu().numpy(), taps_u[n].cpu().numpy(), "fused vs unfused:" + n, rtol=1e-5, atol=2e-5 * scale)
     assert_close(out.cpu().numpy(), ref.numpy(), "fused:image", rtol=1e-4, atol=1e-4)
     assert_close(out.cpu().numpy(), out_u.cpu().numpy(), "fused vs unfused:image", rtol=1e-5, atol=2e-4)      # see the full-size test
+    # one map, many z (colorize_with_spade): gamma/beta once per map (sln_spade_apply_up) inside the fused schedule
+    G.unfused = False
+    shared = G(seg[:1].contiguous().cuda(), z.cuda())
+    ref1 = spade_ref.generator(sd, cfg, seg[:1].contiguous(), z)
+    assert_close(shared.cpu().numpy(), ref1.numpy(), "fused shared:image", rtol=1e-4, atol=1e-4)
 
 
 @pytest.mark.parametrize("env", ["SLN_CONV_DMA", "SLN_CONV_STAGED"])
