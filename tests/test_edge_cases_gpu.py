@@ -165,6 +165,15 @@ def test_c_abi_rejects_null_pointers_and_bad_sizes_without_launching():
     assert L.sln_scene_forward(None, None, 1, 4, 64, 3, None, None, 0.1, 0.001, 100.0, 1e-3, None, None, st) < 0
     assert L.sln_spade_conv(None, 1, 32, 8, 8, p, p, 64, 64, 3, 0, 0.0, p, st) < 0
     assert L.sln_layernorm_stats(None, 1, 64, 1e-5, None, None, st) < 0
+    # round-2 SPADE entry points: null operands, an odd image under a read-through upsampling, a row that is no whole float4
+    assert L.sln_spade_conv_sums(None, 1, 32, 8, 8, p, p, 64, 64, 3, 0, 0.0, p, None, None, st) < 0
+    assert L.sln_spade_modulate_up(p, 1, 32, 7, 8, p, p, 32, 64, p, 1, p, 0, 0.2, p, st) < 0
+    assert L.sln_spade_modulate_up(p, 1, 32, 8, 8, p, None, 32, 64, p, 0, p, 0, 0.2, p, st) < 0
+    assert L.sln_layernorm_finalize(None, 1, 64, 1, 1e-5, p, st) < 0 and L.sln_layernorm_finalize(p, 1, 1, 1, 1e-5, p, st) < 0
+    assert L.sln_block_tail(p, 0, p, 1, 8, 4, 6, None, p, p, p, -1, p, None, 1, 1e-5, None, st) < 0          # W % 4
+    assert L.sln_block_tail(p, 0, p, 1, 12, 4, 4, None, p, p, p, -1, p, None, 1, 1e-5, None, st) < 0         # C % 8
+    assert L.sln_block_tail(p, 0, p, 1, 8, 4, 4, None, p, p, p, 0, p, None, 1, 1e-5, p, st) < 0              # stats without accumulators
+    assert L.sln_spade_apply_up(p, 1, p, 1, 32, 3, 4, 64, p, 0, 0.2, p, st) < 0
     assert L.sln_refine_loss_forward(None, p, p, None, p, p, p, st) < 0
     d = Lm.SlnRefineLoss()                                                       # all-zero descriptor
     assert L.sln_refine_loss_forward(d, p, p, p, p, p, p, st) < 0 and L.sln_refine_loss_backward(d, p, p, p, st) < 0
