@@ -332,14 +332,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   conv_epilogue<BMC, EPI>(a, acc, lds, b, r0, x0, y0);
 }
 
-// The same convolution with its operands DMA'd straight into LDS (global_load_lds, Cin % 4 == 0): no staging registers and no
-// ds_write pass between two barriers per chunk.  Two LDS buffers of GK = 4 input channels each ([9][4][rows] weights + the
-// 4-channel halo, 21.5 KB per buffer at 128 rows): the loads of chunk c + 1 are issued right after the single barrier that
-// opens chunk c and have the whole chunk (72 MFMAs per wave) to land.  ~75 VGPRs + 64 accumulators and 43 KB of LDS: three
-// workgroups per CU (the register-staged kernel above: two).  Measured on the modulation convs of up_3 (B 32, 128 -> 2 x 128
-// channels at 256 x 256): MFMA phase 8.9 ms of 10.3 ms in the staged kernel - the rest was its load/store/barrier phases.
-constexpr int GK = 4;
-template <int BMC, int KS, int EPI, int THT>
+// The same convolution with its operands DMA'd straight into LDS (global_load_lds; Cin % GK == 0): no staging registers and no
+// ds_write pass between two barriers per chunk.  Two LDS buffers of GK input channels each ([9][GK][rows] weights + the
+// GK-channel halo): the loads of chunk c + 1 are issued right after the single barrier that opens chunk c and have the whole
+// chunk to land.  THT x 16 pixels per workgroup: 8 x 16 (64 accumulator registers per lane, 72 MFMAs per wave and chunk at
+// GK = 4) or 16 x 16 (128 accumulators, 144 MFMAs per wave and chunk, half the weight DMA per MFMA; 116 VGPRs + 128 AGPRs and
+// 49 KB of LDS: two workgroups per CU).  Ablation of the staged kernel on the modulation convs of up_3 (B 32, 128 -> 2 x 128
+// channels at 256 x 256, 9.8 ms): 8.84 ms without its per-chunk load / ds_write / second barrier; this kernel: 9.06 ms.
+template <int BMC, int KS, int EPI, int THT, int GK>      // GK input channels per LDS buffer (4 or 8)
 __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
   constexpr int TAPS = KS * KS;
   constexpr int WM = BMC / 64, WN = 4 / WM, TN = THT * TW / WN / 32, TM = 2;   // THT x 16 pixels per workgroup (THT = 8 or 16)
@@ -432,15 +432,17 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     };
+    constexpr int SPT = GK / 2, NS = TAPS * SPT;       // channel-pair steps per tap, steps per chunk (even)
+    static_assert(NS % 2 == 0, "steps are issued in pairs");
     float av0[TM], bv0[TN], av1[TM], bv1[TN];
     ld(0, 0, av0, bv0);
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {           // operands of the next step read before the MFMAs of this one (fenced, see above)
-      ld(tap, 2, av1, bv1);
+    for (int st = 0; st < NS; st += 2) {             // operands of the next step read before the MFMAs of this one (fenced, see above)
+      ld((st + 1) / SPT, ((st + 1) % SPT) * 2, av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
       mma(av0, bv0);
       __builtin_amdgcn_sched_barrier(0);
-      ld(tap + 1 < TAPS ? tap + 1 : tap, 0, av0, bv0);
+      if (st + 2 < NS) ld((st + 2) / SPT, ((st + 2) % SPT) * 2, av0, bv0);
       __builtin_amdgcn_sched_barrier(0);
       mma(av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
   conv_epilogue<BMC, EPI, THT>(a, acc, lds, b, r0, x0, y0);
 }
 
-template <int BMC, int KS, int EPI, int THT>
+template <int BMC, int KS, int EPI, int THT, int GK>
 int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? (THT + 2) * (TW + 2) : THT * TW;
@@ -458,13 +460,13 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
   static bool raised = false;
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI, THT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI, THT, GK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, THT) * a.B;
-  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT, GK>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -479,14 +481,17 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   // every 128-row conv (modulation 9.8 -> 9.15 ms, 1 024 -> 512 channels at 32 x 32 2.34 -> 2.26 ms)
   static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
   static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
-  if (a.Cin % GK == 0 && !staged_only) {
+  if (a.Cin % 8 == 0 && !staged_only) {
     // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, twice the MFMAs per barrier)
-    // (not for 64-row blocks - 2 % slower that way, they stay on the staged kernel -
-    // and launches too small to give every CU two of the tall workgroups: batch-1 convs of the one-map-many-z path)
+    // (not for launches too small to give every CU two of the tall workgroups: batch-1 convs of the one-map-many-z path)
     const long tall_blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, 16) * a.B * (a.rows_pad / BMC);
     if (BMC == 128 && KS == 3 && tall && a.H >= 16 && tall_blocks >= 512)
-      return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH)>(a, st);
-    if (EPI == CEPI_MODULATE || dma_all) return launch_conv_dma<BMC, KS, EPI, TH>(a, st);
+      return launch_conv_dma<BMC, KS, EPI, (BMC == 128 && KS == 3 ? 16 : TH), 4>(a, st);
+    // 64-row blocks: buffers of 8 channels (the same 144 MFMAs per wave and barrier; 2 % over the staged kernel at 256 x 256).
+    // 8-channel buffers for the 128-row blocks leave room for one workgroup per CU only: 10.1 ms against 9.06 ms.
+    if (BMC == 64 && KS == 3 && tall && a.H >= 16 && tall_blocks >= 512)
+      return launch_conv_dma<BMC, KS, EPI, (BMC == 64 && KS == 3 ? 16 : TH), 8>(a, st);
+    if (EPI == CEPI_MODULATE || dma_all) return launch_conv_dma<BMC, KS, EPI, TH, 4>(a, st);
   }
   size_t smem = sizeof(float) * (size_t)(TAPS * CK * BMC + CK * HS);
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
