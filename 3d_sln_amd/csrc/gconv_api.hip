@@ -80,8 +80,8 @@ int sln_gconv_forward(int D, int H, int Dout, int num_layers, int n_modules, int
   const int mode = batch_norm ? (training ? SLN_BN_TRAIN : SLN_BN_EVAL) : SLN_BN_NONE;
   const int C2 = 2 * H + Dout;
   const size_t per_layer = 2 * (size_t)(3 * H + 2 * H + 2 * Dout);       // doubles: [bn1 2H | bn2 2C2 | bn3 2H | bn4 2Do]
-  hipError_t e = hipMemsetAsync(w.err, 0, sizeof(int), st);
-  if (e == hipSuccess && mode == SLN_BN_TRAIN) e = hipMemsetAsync(w.sums, 0, sizeof(double) * per_layer * num_layers, st);
+  int e = sln_zero_async(w.err, sizeof(int), st);                  // caller-owned workspace: kernel fills (sln_common.h)
+  if (e == 0 && mode == SLN_BN_TRAIN) e = sln_zero_async(w.sums, sizeof(double) * per_layer * num_layers, st);
   if (e != hipSuccess) return (int)e;
   RET_IF(sln_launch_graph_prep(edges, T, O, 1 << 30, w.g, w.err, st, 1));
   const float* X = obj_vecs; const float* P = pred_vecs;

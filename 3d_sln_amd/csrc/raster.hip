@@ -22,6 +22,8 @@
 
 namespace {
 
+
+
 constexpr int TS = 16;          // tile side
 constexpr int CHUNK = 256;      // faces tested per round
 
@@ -647,8 +649,8 @@ int sln_project_faces_backward(const float* vertices, const int32_t* faces, cons
                                int F, float orig_size, float eps, const float* grad_faces_xyz, float* grad_vertices, void* stream) {
   if (!vertices || !faces || !K || !R || !t || !grad_faces_xyz || !grad_vertices || B <= 0 || V <= 0 || F < 0) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_vertices, 0, sizeof(float) * 3 * (size_t)B * V, st);
-  if (e != hipSuccess) return (int)e;
+  const int e = sln_zero_async(grad_vertices, sizeof(float) * 3 * (size_t)B * V, st);
+  if (e != 0) return e;
   const long n = (long)B * F * 3;
   if (n == 0) return 0;
   hipLaunchKernelGGL(project_faces_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vertices, faces, K, R, t, V, F, n, orig_size,
@@ -1031,7 +1033,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
   SceneWs w = carve_scene(workspace, B, F, is);
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
-  hipError_t e = hipMemsetAsync(grad_faces, 0, sizeof(float) * 9 * n, st);
+  const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, st, w.st, B);
   hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, st, class_depth_channel, is, num_classes, 70, grad_final,

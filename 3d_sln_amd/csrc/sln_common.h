@@ -144,6 +144,23 @@ __device__ __forceinline__ float wave_sum_halves(float v) {   // lanes l and l^3
 
 static inline int sln_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Zero-fill as a kernel, for buffers a caller may have just re-allocated inside a stream capture.  A captured hipMemsetAsync on
+// a block the caching allocator handed out again (the gradient tensor of a backward pass taking the place of a just-freed
+// workspace) replayed BEFORE the kernels that still wrote the old tenant: the first / last floats of the gradient came back as
+// garbage in two replays out of three (tools/lab/dbg_graph.py; a captured memset on its own is fine, tools/lab/dbg_memset.py).
+// bytes % 4 == 0.
+template <int UNUSED = 0>
+__global__ void sln_zero_kernel(uint32_t* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline int sln_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(sln_zero_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  return (int)hipGetLastError();
+}
+
 #define SLN_CHECK_LAUNCH()                                                  \
   do {                                                                      \
     hipError_t e__ = hipGetLastError();                                     \

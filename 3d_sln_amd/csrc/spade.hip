@@ -894,8 +894,8 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   if (!gap_sums) hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, hw, gap);
   hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale);
   if (stats) {
-    hipError_t e = hipMemsetAsync(acc, 0, sizeof(double) * LN_ACC_STRIDE * B, st);
-    if (e != hipSuccess) return (int)e;
+    const int e = sln_zero_async(acc, sizeof(double) * LN_ACC_STRIDE * B, st);
+    if (e != 0) return e;
   }
   const long n_out = (long)C * hw * (up_mode >= 0 ? 4 : 1);
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * (2.0 * C * hw + n_out), st);
@@ -916,8 +916,8 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
 int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scratch, float* stats, void* stream) {
   if (!x || !scratch || !stats || B <= 0 || n < 2) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(double) * LN_ACC_STRIDE * B, st);
-  if (e != hipSuccess) return (int)e;
+  const int e = sln_zero_async(scratch, sizeof(double) * LN_ACC_STRIDE * B, st);
+  if (e != 0) return e;
   int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 128 ? 128 : (gx < 1 ? 1 : gx);
   hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch);
   hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, 1, B, eps, stats);

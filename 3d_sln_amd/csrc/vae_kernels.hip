@@ -746,8 +746,8 @@ int sln_launch_validate_ids(const int64_t* objs, const int64_t* attrs, const int
 int sln_launch_graph_prep(const int64_t* triples, int T, int O, int num_preds, GraphCsr g, int* err_flag, hipStream_t st,
                           int edges_only, int deg_is_zero) {
   if (!deg_is_zero) {
-    hipError_t e = hipMemsetAsync(g.deg, 0, sizeof(int) * (size_t)O, st);
-    if (e != hipSuccess) return (int)e;
+    const int e = sln_zero_async(g.deg, sizeof(int) * (size_t)O, st);
+    if (e != 0) return e;
   }
   if (T > 0) hipLaunchKernelGGL(prep_split_kernel, dim3(sln_cdiv(T, 256)), dim3(256), 0, st, triples, T, O, num_preds, g, err_flag,
                               edges_only ? 2 : 3, edges_only ? -1 : 1, edges_only ? 1 : 2);
@@ -921,8 +921,8 @@ int sln_launch_log_softmax(const float* logits, float* out, int O, int n, hipStr
 
 int sln_launch_loss(LossArgs a, hipStream_t st) {
   if (!a.acc_prezeroed) {
-    hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(double) * 4, st);
-    if (e != hipSuccess) return (int)e;
+    const int e = sln_zero_async(a.acc, sizeof(double) * 4, st);
+    if (e != 0) return e;
   }
   if (a.O > 0) hipLaunchKernelGGL(loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, a);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, a);

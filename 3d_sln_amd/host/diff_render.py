@@ -143,6 +143,45 @@ def scene_render_batch(vertices, faces, face_class, chan, dch, K, R, t, image_si
     return _SceneFn.apply(fxyz, face_class.contiguous(), chan, dch, image_size, near)
 
 
+class SceneRenderGraph:
+    """``scene_render_batch`` forward + backward to the vertices as ONE hipGraph for fixed shapes.  A refinement loop renders the
+    same topology every iteration (testing/test_render_refine.py:279-359: only boxes / angles move); replaying the ~19 launches
+    of one fused pass takes the host out of the loop.  (On the bench box the eager pass is already GPU-bound: 0.85 ms per 16
+    rooms either way - what a graph cannot remove is the ~5 us boundary between dependent launches.)
+    ``g = SceneRenderGraph(V, F, C, chan, dch, K, R, t); image, dV = g(V_new, grad_out)`` - the returned tensors are the graph's
+    static buffers (overwritten by the next call); ``grad_out=None`` reuses the gradient already in ``g.grad_out``."""
+
+    def __init__(self, vertices, faces, face_class, chan, dch, K, R, t, image_size=final_out, near=0.001):
+        if vertices.device.type != 'cuda':
+            raise _lib.SlnError("SceneRenderGraph runs on the MI355X only (no CPU fallback)")
+        self.vertices = vertices.detach().clone().requires_grad_(True)
+        args = (faces, face_class, chan, dch, K, R, t, image_size, near)
+
+        def run():
+            out = scene_render_batch(self.vertices, *args)
+            return out, torch.autograd.grad(out, self.vertices, self.grad_out)[0]
+        with torch.no_grad():
+            probe = scene_render_batch(self.vertices.detach(), *args)
+        self.grad_out = torch.zeros_like(probe)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                              # warm-up outside the capture (allocator, lazy init)
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.image, self.grad_vertices = run()
+
+    def __call__(self, vertices=None, grad_out=None):
+        with torch.no_grad():
+            if vertices is not None:
+                self.vertices.copy_(vertices)
+            if grad_out is not None:
+                self.grad_out.copy_(grad_out)
+        self.graph.replay()
+        return self.image, self.grad_vertices
+
+
 def scene_render_passes(vertices_buf, face_buf, class_ranges, room_box, image_size=final_out):
     """Same result through the reference's own pass structure (1 depth + one rgb pass per class) on top of the
     HIP ``Renderer`` - 33 rasterisations; kept as a cross-check of the fused path."""

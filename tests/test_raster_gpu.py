@@ -354,3 +354,26 @@ def test_class_list_longer_than_the_depth_hot_planes_is_refused():
     with pytest.raises(ValueError):
         others = [c.replace(" ", "_") for c in DR.nyu_class if c not in ("wall", "floor", "ceiling")]
         DR.class_tables(["wall", "floor", "ceiling"] + others[:30])
+
+
+def test_captured_scene_pass_replays_with_new_vertices_and_gradients():
+    """SceneRenderGraph: forward + backward of the fused pass as one hipGraph for a fixed topology (the refinement loop of
+    testing/test_render_refine.py:279-359 moves vertices only): every replay must equal the eager pass on the same inputs."""
+    DR = pkg("host.diff_render"); syn = pkg("host.synthetic")
+    rooms = [syn.synthetic_room(300 + i, n_objects=6, target_faces=400) for i in range(3)]
+    pk = syn.pack_rooms(rooms, "cuda")
+    IS = 128
+    args = (pk["F"], pk["C"], pk["chan"], pk["dch"], pk["K"], pk["R"], pk["t"], IS, 0.001)
+    g = DR.SceneRenderGraph(pk["V"], *args)
+    gen = torch.Generator().manual_seed(4)
+    for trial in range(3):
+        V = (pk["V"] + 0.01 * trial * torch.randn(pk["V"].shape, generator=gen).cuda()).detach()
+        go = torch.randn(3, 70, IS, IS, generator=gen).cuda()
+        image, dV = g(V, go)
+        Ve = V.clone().requires_grad_(True)
+        ref = DR.scene_render_batch(Ve, *args)
+        ref.backward(go)
+        assert_close(image.detach().cpu().numpy(), ref.detach().cpu().numpy(), "captured image %d" % trial, rtol=1e-6, atol=1e-6)
+        assert_close(dV.detach().cpu().numpy(), Ve.grad.cpu().numpy(), "captured dV %d" % trial, rtol=1e-4, atol=1e-4 * float(Ve.grad.abs().max()))      # float atomics of the face backward: order differs between runs
+    image2, dV2 = g()                                             # nothing new: the last inputs again
+    assert torch.equal(image2, image) and torch.isfinite(dV2).all()
