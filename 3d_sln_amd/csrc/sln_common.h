@@ -149,15 +149,20 @@ static inline int sln_cdiv(int a, int b) { return (a + b - 1) / b; }
 // workspace) replayed BEFORE the kernels that still wrote the old tenant: the first / last floats of the gradient came back as
 // garbage in two replays out of three (tools/lab/dbg_graph.py; a captured memset on its own is fine, tools/lab/dbg_memset.py).
 // bytes % 4 == 0.
-template <int UNUSED = 0>
-__global__ void sln_zero_kernel(uint32_t* p, size_t n) {
+template <typename T>
+__global__ void sln_zero_kernel(T* p, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0u;
+  if (i < n) p[i] = T{};
 }
 static inline int sln_zero_async(void* p, size_t bytes, hipStream_t st) {
-  const size_t n = bytes / 4;
-  if (n == 0) return 0;
-  hipLaunchKernelGGL(sln_zero_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  if (bytes < 4) return 0;
+  if (reinterpret_cast<uintptr_t>(p) % 16 == 0 && bytes % 16 == 0) {
+    const size_t n = bytes / 16;
+    hipLaunchKernelGGL(sln_zero_kernel<uint4>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint4*>(p), n);
+  } else {
+    const size_t n = bytes / 4;
+    hipLaunchKernelGGL(sln_zero_kernel<uint32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  }
   return (int)hipGetLastError();
 }
 

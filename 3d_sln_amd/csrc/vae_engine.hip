@@ -437,7 +437,7 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
 }
 
 int SlnVae::encoder_forward(bool training, hipStream_t st) {
-  if (training && enc_stats_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(stats_base, 0, enc_stats_doubles * sizeof(double), st));
+  if (training && enc_stats_doubles && !bulk_zeroed) RET_IF(sln_zero_async(stats_base, enc_stats_doubles * sizeof(double), st));
   EncAssemble ea; std::memset(&ea, 0, sizeof(ea));
   ea.objs = batch.objs; ea.attrs = batch.attributes; ea.angles = batch.angles; ea.boxes = batch.boxes;
   ea.obj_emb = t.obj_emb_ec; ea.attr_emb = t.attr_emb_ec; ea.angle_emb = t.angle_emb; ea.wb = t.box_emb_w; ea.bb = t.box_emb_b;
@@ -473,7 +473,7 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
 
 int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training, hipStream_t st) {
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
-  if (training && dec_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(stats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  if (training && dec_doubles && !bulk_zeroed) RET_IF(sln_zero_async(stats_base + enc_stats_doubles, dec_doubles * sizeof(double), st));
   DecAssemble da; std::memset(&da, 0, sizeof(da));
   da.objs = batch.objs; da.attrs = batch.attributes; da.obj_emb = t.obj_emb_dc; da.attr_emb = t.attr_emb_dc;
   da.mu = mu; da.logvar = logvar; da.eps = eps; da.z_in = z_ext;
@@ -516,7 +516,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   const bool tr = dec_training;
   ev_next = 0;
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
-  if (dec_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(gstats_base + enc_stats_doubles, 0, dec_doubles * sizeof(double), st));
+  if (dec_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base + enc_stats_doubles, dec_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = 2 * L - 1;
   const Layer& ll = layers[last];
@@ -586,7 +586,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
 int SlnVae::encoder_backward(hipStream_t st) {
   const bool tr = enc_training;
   if (ev_next > 4096) ev_next = 0;
-  if (enc_stats_doubles && !bulk_zeroed) HIP_RET(hipMemsetAsync(gstats_base, 0, enc_stats_doubles * sizeof(double), st));
+  if (enc_stats_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base, enc_stats_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = L - 1, W = 2 * E;
   const Layer& ll = layers[last];
@@ -878,7 +878,7 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
   // and the caller's tensors are new ones for every batch (DataLoader, synthetic generator): stage the inputs in engine-owned
   // buffers whose addresses never change, so that a replay sees the CURRENT batch (it used to read the tensors of the batch it was
   // captured with whenever two consecutive batches had the same shape).  One small kernel outside the graph (stage_batch_kernel).
-  HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
+  RET_IF(sln_zero_async(h->err_flag, sizeof(int), st));
   StageBatch sb; std::memset(&sb, 0, sizeof(sb));
   sb.objs = b->objs; sb.attrs = b->attributes; sb.angles = b->angles; sb.boxes = b->boxes;
   sb.st_objs = h->st_objs; sb.st_attrs = h->st_attrs; sb.st_angles = h->st_angles; sb.st_boxes = h->st_boxes;
@@ -971,9 +971,9 @@ int sln_vae_decoder_backward(SlnVae* h, const float* d_boxes_pred, const float* 
   if (d_boxes_pred)
     HIP_RET(hipMemcpy2DAsync(h->dbp, sizeof(float) * h->dbp_ld, d_boxes_pred, sizeof(float) * h->cfg.box_dim,
                              sizeof(float) * h->cfg.box_dim, (size_t)h->O, hipMemcpyDeviceToDevice, st));
-  else HIP_RET(hipMemsetAsync(h->dbp, 0, sizeof(float) * (size_t)h->O * h->dbp_ld, st));
+  else RET_IF(sln_zero_async(h->dbp, sizeof(float) * (size_t)h->O * h->dbp_ld, st));
   if (d_angles_pred) RET_IF(sln_launch_log_softmax_bwd(h->angles_pred, d_angles_pred, h->dlogits, h->O, h->cfg.n_angle, st));
-  else HIP_RET(hipMemsetAsync(h->dlogits, 0, sizeof(float) * (size_t)h->O * h->cfg.n_angle, st));
+  else RET_IF(sln_zero_async(h->dlogits, sizeof(float) * (size_t)h->O * h->cfg.n_angle, st));
   RET_IF(h->decoder_backward(st));
   RET_IF(copy_out(dz, h->dz, (size_t)h->O * h->E, st));
   return 0;
@@ -983,8 +983,8 @@ int sln_vae_encoder_backward(SlnVae* h, const float* d_mu, const float* d_logvar
   if (!h || !h->have_enc) return SLN_E_STATE;
   hipStream_t st = (hipStream_t)stream;
   const size_t n = (size_t)h->O * h->E;
-  if (d_mu) RET_IF(copy_out(h->dmu, d_mu, n, st)); else HIP_RET(hipMemsetAsync(h->dmu, 0, n * sizeof(float), st));
-  if (d_logvar) RET_IF(copy_out(h->dlv, d_logvar, n, st)); else HIP_RET(hipMemsetAsync(h->dlv, 0, n * sizeof(float), st));
+  if (d_mu) RET_IF(copy_out(h->dmu, d_mu, n, st)); else RET_IF(sln_zero_async(h->dmu, n * sizeof(float), st));
+  if (d_logvar) RET_IF(copy_out(h->dlv, d_logvar, n, st)); else RET_IF(sln_zero_async(h->dlv, n * sizeof(float), st));
   RET_IF(h->encoder_backward(st));
   return 0;
 }
@@ -1001,7 +1001,7 @@ int sln_vae_backward(SlnVae* h, void* stream) {
 
 int sln_vae_zero_grad(SlnVae* h, void* stream) {
   if (!h || !h->bound) return SLN_E_STATE;
-  return (int)hipMemsetAsync(h->t.flat_grads, 0, sizeof(float) * (size_t)h->t.n_flat, (hipStream_t)stream);
+  return sln_zero_async(h->t.flat_grads, sizeof(float) * (size_t)h->t.n_flat, (hipStream_t)stream);
 }
 
 int sln_vae_adam_step(SlnVae* h, float lr, void* stream) {
@@ -1155,7 +1155,7 @@ int sln_gconv_net_set_edges(SlnVae* h, const int64_t* edges, int O, int T, void*
     HIP_RET(hipStreamSynchronize(st));
     RET_IF(upload_bn_table(h));
   }
-  HIP_RET(hipMemsetAsync(h->err_flag, 0, sizeof(int), st));
+  RET_IF(sln_zero_async(h->err_flag, sizeof(int), st));
   RET_IF(sln_launch_graph_prep(edges, T, O, 1 << 30, h->g, h->err_flag, st, 1, 0));
   h->batch_set = true; h->have_enc = false;
   return 0;
@@ -1170,7 +1170,7 @@ int sln_gconv_net_forward(SlnVae* h, const float* obj_vecs, const float* pred_ve
   hipStream_t st = (hipStream_t)stream;
   const int D = h->Dec, H = h->H, L = h->L;
   const bool tr = training != 0;
-  if (tr && h->stats_doubles) HIP_RET(hipMemsetAsync(h->stats_base, 0, h->stats_doubles * sizeof(double), st));
+  if (tr && h->stats_doubles) RET_IF(sln_zero_async(h->stats_base, h->stats_doubles * sizeof(double), st));
   RET_IF(copy_out(h->X0e, obj_vecs, (size_t)h->O * D, st));
   RET_IF(copy_out(h->P0e, pred_vecs, (size_t)h->T * D, st));
   for (int l = 0; l < L; ++l) RET_IF(h->gconv_forward(l, tr, st));
@@ -1192,7 +1192,7 @@ int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new
   const int D = h->Dec, L = h->L;
   const bool tr = h->enc_training;
   h->ev_next = 0;
-  if (h->stats_doubles) HIP_RET(hipMemsetAsync(h->gstats_base, 0, h->stats_doubles * sizeof(double), st));
+  if (h->stats_doubles) RET_IF(sln_zero_async(h->gstats_base, h->stats_doubles * sizeof(double), st));
   h->wt_fresh = false;                      // the caller's optimizer owns the parameters: rebuild W^T every backward
   RET_IF(h->refresh_transposes(st));
   {

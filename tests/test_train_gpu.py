@@ -175,7 +175,9 @@ def test_reference_loop_with_an_unmodified_torch_optimizer():
         gscale = max(float(ref[k].grad.abs().max()) for k in keys if ref[k].grad is not None)
         for k in keys:
             if ref[k].grad is not None:
-                assert_close(named[k].grad.cpu().numpy(), ref[k].grad.numpy(), "step %d grad %s" % (it, k), rtol=2e-3, atol=2e-4 * gscale)
+                # atol: one ReLU input within an atomics-order rounding of zero flips in ~1 run out of 10 and moves a layer's gradient
+                # by 5e-4 of the largest one (the same discrete 1.503e-3 every time); stale transposed weights are 10-20 % off
+                assert_close(named[k].grad.cpu().numpy(), ref[k].grad.numpy(), "step %d grad %s" % (it, k), rtol=2e-3, atol=2e-3 * gscale)
         opt.step(); ropt.step()
 
 
