@@ -27,6 +27,45 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters, int random_da
   for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// mode 9: TWO accumulators alternating (dependency distance 2); mode 10: the 16x16x4 shape on one accumulator; mode 11: 16x16x4, four
+template <int NACC>
+__global__ __launch_bounds__(256) void spin_chain_n(float* out, int iters) {
+  f32x16 a[NACC] = {};
+  float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a[u % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a[u % NACC], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int k = 0; k < NACC; ++k) for (int r = 0; r < 16; ++r) s += a[k][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void spin_16(float* out, int iters) {        // v_mfma_f32_16x16x4_f32: 2048 flop per instruction
+  f32x4 a[NACC] = {};
+  float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 64; ++u) a[u % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(x, y, a[u % NACC], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int k = 0; k < NACC; ++k) for (int r = 0; r < 4; ++r) s += a[k][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// mode 8: ONE accumulator per wave - a dependent MFMA chain (the 32 x 32 wave tile of the 64 x 64 GEMM blocks).  Measured: 154.8
+// TFLOP/s like every other variant here (2 / 3 accumulators, 16x16x4 on 1 / 2 / 4): a dependent chain costs nothing on gfx950.
+__global__ __launch_bounds__(256) void spin_chain(float* out, int iters) {
+  f32x16 a0 = {0};
+  float x = threadIdx.x * 1e-3f, y = blockIdx.x * 1e-3f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int r = 0; r < 16; ++r) s += a0[r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 // The conv kernel's K step: 4 ds_read_b32 ahead, 4 MFMAs (mode 2); mode 3 adds a global load per step (L2 hits).
 __global__ __launch_bounds__(256) void spin_lds(float* out, int iters, const float* g) {
   __shared__ float sm[8192];
@@ -110,9 +149,9 @@ int main(int argc, char** argv) {
   float* gbuf; hipMalloc(&gbuf, 4096); hipMemset(gbuf, 0, 4096);
   spin<<<blocks, 256>>>(out, 100, rnd); hipDeviceSynchronize();
   for (int r = 0; r < reps; ++r) {
-    hipEventRecord(e0); if (rnd == 4) spin_conv<1, 1><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 5) spin_conv<0, 1><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 6) spin_conv<1, 9><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 7) spin_conv<0, 9><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd >= 2) spin_lds<<<blocks, 256>>>(out, iters, rnd == 3 ? gbuf : nullptr); else spin<<<blocks, 256>>>(out, iters, rnd); hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventRecord(e0); if (rnd == 8) spin_chain<<<blocks, 256>>>(out, iters); else if (rnd == 9) spin_chain_n<2><<<blocks, 256>>>(out, iters); else if (rnd == 12) spin_chain_n<3><<<blocks, 256>>>(out, iters); else if (rnd == 10) spin_16<1><<<blocks, 256>>>(out, iters); else if (rnd == 11) spin_16<4><<<blocks, 256>>>(out, iters); else if (rnd == 13) spin_16<2><<<blocks, 256>>>(out, iters); else if (rnd == 4) spin_conv<1, 1><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 5) spin_conv<0, 1><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 6) spin_conv<1, 9><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd == 7) spin_conv<0, 9><<<blocks, 256, 43008>>>(out, iters / 18); else if (rnd >= 2) spin_lds<<<blocks, 256>>>(out, iters, rnd == 3 ? gbuf : nullptr); else spin<<<blocks, 256>>>(out, iters, rnd); hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flop = (double)blocks * 4 * (rnd >= 4 ? (iters / 18) * 144.0 / 32 : (double)iters) * 32 * 2.0 * 32 * 32 * 2;
+    const double flop = (double)blocks * 4 * (rnd >= 4 && rnd <= 7 ? (iters / 18) * 144.0 / 32 : (double)iters) * 32 * 2.0 * 32 * 32 * 2;
     printf("rep %2d: %.2f ms  %.1f TFLOP/s  (implied clock %.0f MHz at 256 flop/clk/CU)\n", r, ms, flop / ms / 1e9, flop / ms / 1e9 * 1e6 / (256.0 * 256.0) );
   }
   return 0;
