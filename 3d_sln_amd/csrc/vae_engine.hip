@@ -572,6 +572,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   DecAssembleBwd db; std::memset(&db, 0, sizeof(db));
   db.objs = batch.objs; db.attrs = batch.attributes; db.dx0 = dX0; db.O = O; db.n_obj = n_obj_e; db.n_attr = n_attr_e; db.n_z = E;
   db.d_obj_emb = t.d_obj_emb_dc; db.d_attr_emb = t.d_attr_emb_dc; db.dz = dz; db.z_in_x0 = cfg.decoder_cat ? 1 : 0;
+  db.rows_obj = cfg.num_objs; db.rows_attr = cfg.num_attrs;
   RET_IF(sln_launch_dec_assemble_bwd(db, st));
   const int nb = (int)bns.size() - n_bn_enc;
   if (nb > 0) {
@@ -656,6 +657,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
   eb.O = O; eb.n_obj = n_obj_e; eb.n_attr = n_attr_e; eb.n_box = n_box_e; eb.n_angle = n_angle_e; eb.box_dim = cfg.box_dim;
   eb.d_obj_emb = t.d_obj_emb_ec; eb.d_attr_emb = t.d_attr_emb_ec; eb.d_angle_emb = t.d_angle_emb;
   eb.d_wb = t.d_box_emb_w; eb.d_bb = t.d_box_emb_b;
+  eb.rows_obj = cfg.num_objs; eb.rows_attr = cfg.num_attrs; eb.rows_angle = cfg.n_angle;
   RET_IF(sln_launch_enc_assemble_bwd(eb, st));
   if (n_bn_enc > 0) {
     int maxc = 0;

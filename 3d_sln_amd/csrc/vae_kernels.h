@@ -63,6 +63,7 @@ struct EncAssembleBwd {
   const int64_t* objs; const int64_t* attrs; const int64_t* angles; const float* boxes;
   const float* dx0; int O, n_obj, n_attr, n_box, n_angle, box_dim;
   float* d_obj_emb; float* d_attr_emb; float* d_angle_emb; float* d_wb; float* d_bb;
+  int rows_obj, rows_attr, rows_angle;      // table rows (> 0: the tables are accumulated in LDS per block of rows first)
 };
 int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st);
 
@@ -79,6 +80,7 @@ struct DecAssembleBwd {    // scatter dX0 into the two embedding grads, pass dz 
   const int64_t* objs; const int64_t* attrs; const float* dx0; int O, n_obj, n_attr, n_z;
   float* d_obj_emb; float* d_attr_emb; float* dz;
   int z_in_x0;             // 0: dx0 is [O, n_obj + n_attr] and dz is not touched
+  int rows_obj, rows_attr; // table rows (> 0: LDS accumulation, see EncAssembleBwd)
 };
 int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st);
 

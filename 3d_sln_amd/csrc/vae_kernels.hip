@@ -3,6 +3,7 @@
 //
 // These are HBM/L2-bound streaming kernels: coalesced 64-column row segments per wave, per-column
 // statistics reduced in registers -> LDS -> one fp64 atomic per column per block.
+#include <cstring>
 #include "vae_kernels.h"
 #include "sln_prof.h"
 
@@ -830,9 +831,79 @@ int sln_launch_enc_assemble(EncAssemble a, hipStream_t st) {
   return 0;
 }
 
+// Embedding gradients of the assembled encoder / decoder input: d_emb[idx[r], :] += dx0[r, col0 : col0 + n] for up to three
+// tables.  2 048 rows draw from 5-35 table rows, so element-wise global atomics pile 60-400 adds on every table element (51 and
+// 42 us per step for 1 MB of gradient); a workgroup accumulates ITS rows into LDS copies of the tables first and adds the
+// touched elements once.
+struct EmbSeg { const int64_t* idx; float* d_emb; int n, rows, col0, lds0; };
+struct AssembleBwdLds {
+  EmbSeg seg[3]; int nseg;
+  const float* dx0; int ld, O, rows_per_block, lds_floats;
+  float* dz; int z_col0, n_z;               // decoder: dz[r, :] = dx0[r, z_col0 : z_col0 + n_z]  (dz may be null)
+};
+__global__ __launch_bounds__(256) void assemble_bwd_lds_kernel(AssembleBwdLds a) {
+  extern __shared__ float tab[];
+  for (int i = threadIdx.x; i < a.lds_floats; i += 256) tab[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * a.rows_per_block, r1 = min(a.O, r0 + a.rows_per_block);
+  for (int s = 0; s < a.nseg; ++s) {
+    const EmbSeg sg = a.seg[s];
+    const long iend = (long)r1 * sg.n;
+    for (long i = (long)r0 * sg.n + threadIdx.x; i < iend; i += 256 * 4) {     // independent loads first, then the LDS atomics
+      float v[4]; int slot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long q = min(i + 256L * u, iend - 1);
+        const int r = (int)(q / sg.n), c = (int)(q % sg.n);
+        slot[u] = sg.lds0 + (int)sg.idx[r] * sg.n + c;
+        v[u] = a.dx0[(size_t)r * a.ld + sg.col0 + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i + 256L * u < iend) atomicAdd(&tab[slot[u]], v[u]);
+    }
+  }
+  if (a.dz) {
+    const long iend = (long)r1 * a.n_z;
+    for (long i = (long)r0 * a.n_z + threadIdx.x; i < iend; i += 256) {
+      const int r = (int)(i / a.n_z), c = (int)(i % a.n_z);
+      a.dz[i] = a.dx0[(size_t)r * a.ld + a.z_col0 + c];
+    }
+  }
+  __syncthreads();
+  for (int s = 0; s < a.nseg; ++s) {
+    const EmbSeg sg = a.seg[s];
+    for (int i = threadIdx.x; i < sg.rows * sg.n; i += 256) {
+      const float v = tab[sg.lds0 + i];
+      if (v != 0.f) atomicAdd(sg.d_emb + i, v);
+    }
+  }
+}
+static int launch_assemble_bwd_lds(AssembleBwdLds a, hipStream_t st) {
+  int off = 0;
+  for (int s = 0; s < a.nseg; ++s) { a.seg[s].lds0 = off; off += a.seg[s].rows * a.seg[s].n; }
+  a.lds_floats = off;
+  a.rows_per_block = a.O <= 8192 ? 16 : 64;
+  hipLaunchKernelGGL(assemble_bwd_lds_kernel, dim3(sln_cdiv(a.O, a.rows_per_block)), dim3(256), sizeof(float) * off, st, a);
+  return (int)hipGetLastError();
+}
+constexpr int ASSEMBLE_LDS_MAX_FLOATS = 10240;      // 40 KB of tables per workgroup; larger vocabularies keep the global atomics
+
 int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st) {
   const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_box + a.n_angle);
   if (n <= 0) return 0;
+  const long tabs = (long)a.rows_obj * a.n_obj + (long)a.rows_attr * a.n_attr + (long)a.rows_angle * a.n_angle;
+  if (a.rows_obj > 0 && a.rows_angle > 0 && (a.n_attr == 0 || a.rows_attr > 0) && tabs <= ASSEMBLE_LDS_MAX_FLOATS) {
+    AssembleBwdLds l; std::memset(&l, 0, sizeof(l));
+    l.dx0 = a.dx0; l.ld = a.n_obj + a.n_attr + a.n_box + a.n_angle; l.O = a.O;
+    int k = 0;
+    l.seg[k++] = EmbSeg{a.objs, a.d_obj_emb, a.n_obj, a.rows_obj, 0, 0};
+    if (a.n_attr > 0) l.seg[k++] = EmbSeg{a.attrs, a.d_attr_emb, a.n_attr, a.rows_attr, a.n_obj, 0};
+    l.seg[k++] = EmbSeg{a.angles, a.d_angle_emb, a.n_angle, a.rows_angle, a.n_obj + a.n_attr + a.n_box, 0};
+    l.nseg = k;
+    const int e = launch_assemble_bwd_lds(l, st);
+    if (e) return e;
+  } else
   hipLaunchKernelGGL(enc_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, 64)), dim3(CB, RL), 0, st, a);
   SLN_CHECK_LAUNCH();
@@ -850,6 +921,17 @@ int sln_launch_dec_assemble(DecAssemble a, hipStream_t st) {
 int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st) {
   const long n = (long)a.O * (a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0));
   if (n <= 0) return 0;
+  const long tabs = (long)a.rows_obj * a.n_obj + (long)a.rows_attr * a.n_attr;
+  if (a.rows_obj > 0 && (a.n_attr == 0 || a.rows_attr > 0) && tabs <= ASSEMBLE_LDS_MAX_FLOATS) {
+    AssembleBwdLds l; std::memset(&l, 0, sizeof(l));
+    l.dx0 = a.dx0; l.ld = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0); l.O = a.O;
+    int k = 0;
+    l.seg[k++] = EmbSeg{a.objs, a.d_obj_emb, a.n_obj, a.rows_obj, 0, 0};
+    if (a.n_attr > 0) l.seg[k++] = EmbSeg{a.attrs, a.d_attr_emb, a.n_attr, a.rows_attr, a.n_obj, 0};
+    l.nseg = k;
+    if (a.z_in_x0 && a.dz) { l.dz = a.dz; l.z_col0 = a.n_obj + a.n_attr; l.n_z = a.n_z; }
+    return launch_assemble_bwd_lds(l, st);
+  }
   hipLaunchKernelGGL(dec_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
