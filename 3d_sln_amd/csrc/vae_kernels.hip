@@ -11,6 +11,7 @@ namespace {
 
 constexpr int CB = 64;   // columns per block
 constexpr int RL = 4;    // row lanes per block
+constexpr int BOX_ROWS = 64;   // rows per block of box_embed_bwd_kernel
 constexpr int RB = 32;   // rows per block (dense row kernels)
 
 __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid, double* out, int cstride, int col) {
@@ -373,12 +374,27 @@ __global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a)
   const int j = blockIdx.x * CB + threadIdx.x;
   const bool jv = j < a.n_box;
   float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int r1 = min(a.O, (int)(blockIdx.y + 1) * 64);
+  // BOX_ROWS rows per block in batches of 16 (4 per thread, their loads issued together: one memory round trip per batch).  Every
+  // block ends in 7 atomics per column on the same 7 x n_box addresses, which the L2 serialises - measured at 2 048 rows: 64 rows
+  // walked one at a time 20.6 us; batches, 16 rows x 128 blocks 21.6 us, 256 x 8 15.9 us, 64 x 32 9.8 us
+  const int rb0 = (int)blockIdx.y * BOX_ROWS, r1 = min(a.O, rb0 + BOX_ROWS);
   if (jv) {
-    for (int r = blockIdx.y * 64 + threadIdx.y; r < r1; r += RL) {
-      const float d = a.dx0[(size_t)r * W + off + j];
-      acc[6] += d;
-      for (int k = 0; k < a.box_dim; ++k) acc[k] = fmaf(d, a.boxes[(size_t)r * a.box_dim + k], acc[k]);
+    for (int rb = rb0; rb < r1; rb += 4 * RL) {
+      float d[4], bx[4][6];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = min(rb + (int)threadIdx.y + RL * u, a.O - 1);
+        d[u] = a.dx0[(size_t)r * W + off + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bx[u][k] = a.boxes[(size_t)r * a.box_dim + min(k, a.box_dim - 1)];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (rb + (int)threadIdx.y + RL * u >= r1) continue;
+        acc[6] += d[u];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < a.box_dim) acc[k] = fmaf(d[u], bx[u][k], acc[k]);
+      }
     }
   }
   __shared__ float red[7][RL][CB];
@@ -905,7 +921,7 @@ int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st) {
     if (e) return e;
   } else
   hipLaunchKernelGGL(enc_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, 64)), dim3(CB, RL), 0, st, a);
+  hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, BOX_ROWS)), dim3(CB, RL), 0, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
