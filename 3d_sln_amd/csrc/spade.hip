@@ -7,10 +7,11 @@
 //     out[co, pixel] = sum_{ci, tap} Wp[tap][ci][co] * x[ci, reflect(pixel + tap)]
 //   * M = output channels (A operand = packed weights), N = pixels (B operand = activations): the MFMA
 //     result then has lanes = 32 consecutive pixels, i.e. coalesced NCHW stores and epilogue loads;
-//   * a workgroup owns an (8 x 16)-pixel patch x 128 (or 64) channels; per chunk of 8 input channels it stages
-//     the (8+2)x(16+2) halo once in LDS and reuses it for all 9 taps (9x fewer global loads than im2col)
-//     together with the [9][8][channels] weight slab; next chunk is prefetched into registers during the
-//     144 MFMAs of the current one;
+//   * a workgroup owns a (16 x 16)- or (8 x 16)-pixel patch x 128 (or 64) channels; per chunk of 4 or 8 input channels the
+//     reflect-padded halo is staged once in LDS and reused for all 9 taps (9x fewer global loads than im2col) together with
+//     the [9][chunk][channels] weight slab.  Two kernels share the K loop and the epilogue: conv_glds_kernel DMAs the next
+//     chunk straight into a second LDS buffer (global_load_lds) while the MFMAs of the current one run; conv_mfma_kernel
+//     (64-row blocks on small grids, 1x1 convs, tiny images, Cin % 8 != 0) prefetches it into registers;
 //   * epilogues: bias + {none, ReLU, LeakyReLU(s)}; or the SPADE modulation - the gamma and beta channels
 //     of one feature land in the same lane/register of two accumulators (weights are packed [32 gamma | 32
 //     beta] per 64 rows), so out = (x - mu_b) * inv_b * (1 + gamma) + beta [-> LeakyReLU(0.2)] is computed in
