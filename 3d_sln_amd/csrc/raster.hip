@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
+#include <mutex>
+
 #include "../../include/sln_hip.h"
 #include "sln_common.h"
 #include "sln_prof.h"
@@ -729,6 +732,28 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
 // ====================================================================================================
 namespace {
 
+// Side stream of the scene backward (one per device, created on first use, kept for the life of the process).  SLN_SCENE_NO_SIDE=1
+// keeps every launch on the caller's stream.
+struct SceneSide { hipStream_t stream; hipEvent_t fork, join; };
+SceneSide* scene_side() {
+  static const bool off = [] { const char* v = std::getenv("SLN_SCENE_NO_SIDE"); return v && v[0] == '1'; }();
+  if (off) return nullptr;
+  static std::mutex mu;
+  static SceneSide* per_dev[64] = {};
+  static bool failed[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (per_dev[dev] == nullptr && !failed[dev]) {
+    SceneSide* s = new SceneSide{nullptr, nullptr, nullptr};
+    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) { failed[dev] = true; delete s; return nullptr; }
+    per_dev[dev] = s;
+  }
+  return per_dev[dev];
+}
+
 struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int pad_[2]; };
 
 // order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
@@ -1035,14 +1060,24 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
   const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, st, w.st, B);
-  hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, st, class_depth_channel, is, num_classes, 70, grad_final,
+  // Two independent chains add into grad_faces: the depth channel's (gradient sums -> depth-map gradient -> per-face walk,
+  // five launches, ~0.12 ms per 16 rooms) and the class planes' (packed records, gradient planes, edge scans: ~0.35 ms, bound by
+  // latency and by the number of WORKING wavefronts, not by a pipe).  The depth chain runs on a side stream next to the class
+  // chain; in a stream capture the event edges become graph dependencies (fork / join inside this call).
+  SceneSide* sd = scene_side();
+  hipStream_t sd_st = st;
+  if (sd != nullptr) {
+    if (hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
+    else sd = nullptr;
+  }
+  hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, sd_st, w.st, B);
+  hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
                      w.st);
-  hipLaunchKernelGGL(scene_bwd_masked_sums_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_depth_channel, F, is,
+  hipLaunchKernelGGL(scene_bwd_masked_sums_kernel, dim3(64, B), dim3(256), 0, sd_st, w.fiB, w.val, face_class, class_depth_channel, F, is,
                      num_classes, 70, grad_final, w.st);
-  hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
+  hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, sd_st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
-  hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
+  hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
                      grad_faces);
   const int t32 = sln_cdiv(is, 32);
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
@@ -1052,6 +1087,11 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
                      grad_faces);
+  if (sd != nullptr) {            // join: whatever follows on `st` sees both chains
+    hipError_t r = hipEventRecord(sd->join, sd->stream);
+    if (r == hipSuccess) r = hipStreamWaitEvent(st, sd->join, 0);
+    if (r != hipSuccess) return (int)r;
+  }
   SLN_CHECK_LAUNCH();
   return 0;
 }

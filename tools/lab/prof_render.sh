@@ -6,6 +6,6 @@ import csv
 rows=list(csv.DictReader(open("/tmp/prof_r/e_kernel_stats.csv")))
 for r in rows:
     c=int(r["Calls"])
-    if c>=200 and c<=800:
+    if c>=100 and c<=800:
         print("%-100s %6s %9.2f ms %8.1f us"%(r["Name"][:100], r["Calls"], float(r["TotalDurationNs"])/1e6, float(r["AverageNs"])/1e3))
 PY
