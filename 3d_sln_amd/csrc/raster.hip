@@ -317,24 +317,33 @@ inline int pixel_map_scan_split(long faces_total, int B) {
 // pixel-map backward.  One wavefront per (face, edge, axis): see pixel_map_backward_kernel for the two-phase walk.
 // PIX is a policy giving diff(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
 // ----------------------------------------------------------------------------------------------------
-// A policy exposes, per scan axis, a view with: fi (face index map addressed by the view's own linear index),
-// idx(base, d0, d1) and contrib(q, ref) = sum_c (I_c(q) - I_c(ref)) * dI_c(q) with the package's positive-part test.
+// A policy exposes, per (scan axis, image), a view with pixel offsets LOCAL to the image (32-bit: the base pointers of the image
+// are wavefront-uniform, so a load is "uniform base + 32-bit lane offset" - the 64-bit per-lane address arithmetic of the first
+// version was a dozen of the ~130 instructions a scan window costs, and the kernel is bound by instruction issue, see below):
+// idx(d0, d1), ref_at(p), load(p, ref) and eval(loaded, ref) = sum_c (I_c(p) - I_c(ref)) * dI_c(p) with the package's
+// positive-part test.
 struct PixDenseView {
-  const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;
-  __device__ __forceinline__ long idx(long base, int d0, int d1) const { return axis == 0 ? base + (long)d1 * is + d0 : base + (long)d0 * is + d1; }
+  const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;      // pointers at the image's first pixel
+  __device__ __forceinline__ int idx(int d0, int d1) const { return axis == 0 ? d1 * is + d0 : d0 * is + d1; }
   // Ref: what a scan needs to know about its reference pixel, fetched once per edge step (phase 1)
-  struct Ref { long q; int fi; };
-  __device__ __forceinline__ Ref ref_at(long q) const { Ref r; r.q = q; r.fi = fi[q]; return r; }
-  __device__ __forceinline__ float contrib(long q, const Ref& ref, int, int& fq) const {
-    fq = fi[q];
+  struct __align__(16) Ref { int p; int fi; int pad_[2]; };
+  __device__ __forceinline__ Ref ref_at(int p) const { Ref r; r.p = p; r.fi = fi[p]; r.pad_[0] = r.pad_[1] = 0; return r; }
+  struct Loaded { int fq; float diff; };
+  __device__ __forceinline__ Loaded load(int p, const Ref& ref) const {
+    Loaded r; r.fq = fi[p];
     float diff = 0.f;
-    for (int k = 0; k < C; ++k) diff += (rgb[q * C + k] - rgb[ref.q * C + k]) * grad[q * C + k];
-    return diff > 0.f ? diff : 0.f;
+    for (int k = 0; k < C; ++k) diff += (rgb[(long)p * C + k] - rgb[(long)ref.p * C + k]) * grad[(long)p * C + k];
+    r.diff = diff;
+    return r;
   }
+  __device__ __forceinline__ float eval(const Loaded& L, const Ref&, int& fq) const { fq = L.fq; return L.diff > 0.f ? L.diff : 0.f; }
 };
 struct PixDense {            // C-channel image: one positive-part test over the channel sum (package's rgb mode, C=3)
   const int32_t* fi; const float* rgb; const float* grad; int C, is;
-  __device__ __forceinline__ PixDenseView view(int axis) const { return PixDenseView{fi, rgb, grad, C, is, axis}; }
+  __device__ __forceinline__ PixDenseView view(int axis, int b) const {
+    const long plane = (long)is * is;
+    return PixDenseView{fi + b * plane, rgb + b * plane * C, grad + b * plane * C, C, is, axis};
+  }
 };
 
 // The reference's 32 class passes fused (models/diff_render.py:381-398): pass c renders value(pixel) where the
@@ -347,21 +356,32 @@ struct PixDense {            // C-channel image: one positive-part test over the
 // 4-byte streams before); only when the reference pixel's class differs is the gradient plane of that class read as well.
 struct PixRec { int fi; int cp; float v; float gown; };
 struct PixClassView {
-  const PixRec* rec; const float* g; int is, NC; long plane;
-  __device__ __forceinline__ long idx(long base, int d0, int d1) const { return base + (long)d0 * is + d1; }
+  const char* rec; const char* g; int is; unsigned plane4;        // byte pointers at the image's records / first class plane
+  __device__ __forceinline__ int idx(int d0, int d1) const { return d0 * is + d1; }
   // Ref: class and value of the reference pixel of an edge step (phase 1).  Knowing the class up front makes the address of
   // the second gradient plane independent of the scanned pixel's record, so both loads of a scan pixel go out together.
-  struct Ref { int fi, cp; float v; };
-  __device__ __forceinline__ Ref ref_at(long q) const {
-    const int4 ir = *reinterpret_cast<const int4*>(rec + q);
-    Ref r; r.fi = ir.x; r.cp = ir.y; r.v = __int_as_float(ir.z);
+  struct __align__(16) Ref { int fi, cp; float v; int pad_; };
+  __device__ __forceinline__ Ref ref_at(int p) const {
+    int4 ir = *reinterpret_cast<const int4*>(rec + (unsigned)p * 16u);
+    asm volatile("" : "+v"(ir.x), "+v"(ir.y), "+v"(ir.z), "+v"(ir.w));          // one 16-byte load, see load()
+    Ref r; r.fi = ir.x; r.cp = ir.y; r.v = __int_as_float(ir.z); r.pad_ = 0;
     return r;
   }
-  __device__ __forceinline__ float contrib(long q, const Ref& ref, int b, int& fq) const {
-    const long pq = q - (long)b * plane;
+  struct Loaded { int4 iq; float g_cr; };
+  __device__ __forceinline__ Loaded load(int p, const Ref& ref) const {
+    Loaded r;
+    r.iq = *reinterpret_cast<const int4*>(rec + (unsigned)p * 16u);               // one 16-byte load ...
+    // ... and it has to stay one: value and own-plane gradient (z, w) are only used when the class (y) is >= 0, so hipcc split
+    // the load into two 8-byte halves and sank the second one behind the class test - a second, dependent round trip per
+    // scan window (global_load_dwordx2, s_waitcnt vmcnt(1), branch, global_load_dwordx2 offset:8, s_waitcnt vmcnt(0) in the ISA)
+    asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w));
+    r.g_cr = *reinterpret_cast<const float*>(g + ((unsigned)max(ref.cp, 0) * plane4 + (unsigned)p * 4u));   // unconditional, independent of iq
+    return r;
+  }
+  __device__ __forceinline__ float eval(const Loaded& L, const Ref& ref, int& fq) const {
     const int cr = ref.cp;
-    const int4 iq = *reinterpret_cast<const int4*>(rec + q);                       // one 16-byte load
-    const float g_cr = g[((long)b * NC + max(cr, 0)) * plane + pq];                // unconditional, independent of iq
+    const int4 iq = L.iq;
+    const float g_cr = L.g_cr;
     fq = iq.x;
     const int cq = iq.y;
     const float vq = cq >= 0 ? __int_as_float(iq.z) : 0.f, vr = cr >= 0 ? ref.v : 0.f;
@@ -382,8 +402,10 @@ struct PixClassView {
 };
 struct PixClass {
   const PixRec *rec, *recT; const float *g, *gT; int is, NC;
-  __device__ __forceinline__ PixClassView view(int axis) const {
-    return axis == 0 ? PixClassView{recT, gT, is, NC, (long)is * is} : PixClassView{rec, g, is, NC, (long)is * is};
+  __device__ __forceinline__ PixClassView view(int axis, int b) const {
+    const long plane = (long)is * is;
+    return PixClassView{reinterpret_cast<const char*>((axis == 0 ? recT : rec) + b * plane),
+                        reinterpret_cast<const char*>((axis == 0 ? gT : g) + (long)b * NC * plane), is, (unsigned)(plane * 4)};
   }
 };
 
@@ -397,22 +419,35 @@ __device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2)
 // small faces had finished - the kernel ran as long as its largest face.  Units outside the edge's d0 range exit at
 // once; each unit adds its two partial sums to the face gradient with two atomics.
 constexpr int PMB_DC = 64;
+#ifdef PMB_FAST_DIV
+#define PMB_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#else
+#define PMB_DIV(a, b) ((a) / (b))
+#endif
 
 // Inside a unit the serial form of the edge walk (for each d0: load the face index under the edge, then scan) is a
 // chain of three dependent memory round trips per edge step.  Here the walk is flattened:
 //   phase 1 - lane l owns edge step d0 = c_from + l: crossing, reference pixels, the face index under the edge and
 //             the two scan ranges, all 64 steps in ONE round trip; parameters + an exclusive prefix of the scan
 //             lengths go to LDS;
-//   phase 2 - the lanes stride over the concatenated scan pixels of all steps (binary search of the prefix), every
+//   phase 2 - the lanes stride over the concatenated scan pixels of all steps (a short walk along the prefix), every
 //             iteration is independent of the others, so their loads overlap.
+// What bounds phase 2 (round 2, measured): NOT the memory round trip of a window - two or four windows per lane with all loads
+// in flight together were 1-5 % SLOWER (more registers, fewer wavefronts), and removing a second dependent round trip per
+// window that hipcc had created (see PixClassView::load) gained 0.6 % - but the ~130 instructions a wavefront issues per window
+// of 64 scan pixels: 1.3 M windows x 130 x 4 cycles over 1 024 SIMDs = 0.28 ms.  Hence the packed 16-byte step records in LDS
+// (one ds_read_b128 instead of four ds_read_b32), the 16-byte reference records (one read, selected by address), the ratios of
+// a step read only by contributing pixels, and image-local 32-bit pixel offsets.
+struct __align__(16) PmbStep { int lo, ofrom, ifrom; float cross; };
 template <typename PIX>
 __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int B, int F, int is,
                                                                 float eps, float* __restrict__ gfaces) {
+  typedef decltype(pix.view(0, 0)) View;
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
-  __shared__ int s_ofrom[PMB_DC], s_lo[PMB_DC], s_ifrom[PMB_DC];
-  __shared__ float s_cross[PMB_DC], s_r0[PMB_DC], s_r1[PMB_DC];
-  typedef decltype(pix.view(0)) View;
-  __shared__ typename View::Ref s_rin[PMB_DC], s_rout[PMB_DC];     // reference pixel of the outward / inward scan of a step
+  __shared__ PmbStep s_step[PMB_DC];
+  __shared__ float2 s_ratio[PMB_DC];
+  __shared__ typename View::Ref s_ref[PMB_DC][2];     // [0]: reference pixel of the outward scan of a step, [1]: of the inward scan
+  static_assert(sizeof(typename View::Ref) == 16, "one ds_read_b128 per reference record");
   // Image -> XCD affinity.  Workgroups are dealt to the 8 XCDs round-robin by linear id and every XCD has its own L2: with the
   // plain (face, edge) order all XCDs scan the SAME image at a time and each L2 fetches that image's maps for itself (measured:
   // 1.07 GB from memory per launch for 0.28 GB of maps).  With at least 8 images, XCD x takes the images x, x+8, ...
@@ -438,7 +473,6 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 #pragma unroll
   for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
   if (backfacing(face)) return;
-  const long base = (long)b * is * is;
   const bool pow2 = (is & (is - 1)) == 0;
   const float s2 = 2.0f / (float)is;
   int pi[3]; float pp[3][2];
@@ -448,7 +482,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   for (int n = 0; n < 3; ++n)
 #pragma unroll
     for (int d = 0; d < 2; ++d) pp[n][d] = 0.5f * (face[3 * pi[n] + d] * is + is - 1);
-  const auto V = pix.view(axis);
+  const View V = pix.view(axis, b);
   float p[3][2];
 #pragma unroll
   for (int n = 0; n < 3; ++n)
@@ -466,38 +500,40 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 
   // ---- phase 1: one edge step per lane ----
   const int d0 = c_from + lane;
-  int lo = 0, li = 0, ofrom = 0, ifrom = 0;
-  float d1_cross = 0.f, r0 = 0.f, r1 = 0.f;
+  PmbStep sp; sp.lo = 0; sp.ofrom = 0; sp.ifrom = 0; sp.cross = 0.f;
+  int li = 0;
+  float r0 = 0.f, r1 = 0.f;
   if (d0 <= c_to) {
-    d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+    const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
+    sp.cross = d1_cross;
     const int d1_in = dir > 0 ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
     const int d1_out = d1_in + dir;
     if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
       const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
       r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;         // 0 marks "slot not used" (a used ratio is never 0)
       r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-      const typename View::Ref rin = V.ref_at(V.idx(base, d0, d1_in));
-      s_rin[lane] = rin; s_rout[lane] = V.ref_at(V.idx(base, d0, d1_out));
+      const typename View::Ref rin = V.ref_at(V.idx(d0, d1_in));
+      s_ref[lane][0] = rin; s_ref[lane][1] = V.ref_at(V.idx(d0, d1_out));
       if (rin.fi == fn) {                                              // outward scan to the image border
         const int lim = dir > 0 ? is - 1 : 0;
         const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
-        ofrom = from; lo = max(to - from + 1, 0);
+        sp.ofrom = from; sp.lo = max(to - from + 1, 0);
       }
       float cross2;                                                    // inward scan to the opposite edge
       if ((d0 - p[0][0]) * (d0 - p[2][0]) < 0) cross2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
       else cross2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * (d0 - p[2][0]) + p[2][1];
       const int lim = dir > 0 ? (int)ceilf(cross2) : (int)floorf(cross2);
       const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
-      ifrom = from; li = max(to - from + 1, 0);
+      sp.ifrom = from; li = max(to - from + 1, 0);
     }
   }
-  int incl = lo + li;
+  int incl = sp.lo + li;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
   s_pre[lane + 1] = incl;
   if (lane == 0) s_pre[0] = 0;
-  s_ofrom[lane] = ofrom; s_lo[lane] = lo; s_ifrom[lane] = ifrom;
-  s_cross[lane] = d1_cross; s_r0[lane] = r0; s_r1[lane] = r1;
+  s_step[lane] = sp;
+  s_ratio[lane] = make_float2(r0, r1);
   __syncthreads();
   const int W = s_pre[64];
 
@@ -509,29 +545,30 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   for (int w0 = 64 * (int)blockIdx.z; w0 < W; w0 += 64 * (int)gridDim.z) {
     const int w = min(w0 + lane, W - 1);
     int l = l0;                                  // largest l with s_pre[l] <= w: a short walk instead of a 6-step bisection
-    while (s_pre[l + 1] <= w) ++l;
+    int pre = s_pre[l];
+    for (int nx = s_pre[l + 1]; nx <= w; nx = s_pre[l + 1]) { ++l; pre = nx; }
     l0 = __shfl(l, 63, 64);
     if (w0 + lane >= W) continue;
-    const int t = w - s_pre[l];
-    const int step_d0 = c_from + l;
-    const float cr = s_cross[l];
-    const bool outward = t < s_lo[l];
-    const int d1 = outward ? s_ofrom[l] + t : s_ifrom[l] + (t - s_lo[l]);
-    const long q = V.idx(base, step_d0, d1);
+    const int t = w - pre;
+    const PmbStep st = s_step[l];
+    const bool outward = t < st.lo;
+    const int d1 = outward ? st.ofrom + t : st.ifrom + (t - st.lo);
+    const typename View::Ref ref = s_ref[l][outward ? 0 : 1];
     int fq;
-    const float diff = V.contrib(q, outward ? s_rin[l] : s_rout[l], b, fq);
+    const float diff = V.eval(V.load(V.idx(c_from + l, d1), ref), ref, fq);
     if (!outward && fq != fn) continue;          // inward: this face's pixels only
     if (diff > 0.f) {
-      const float q0 = s_r0[l], q1 = s_r1[l];
-      if (q0 != 0.f) {
-        float dist = pix_scale(q0 * (d1 - cr), is, pow2, s2);
+      const float2 rq = s_ratio[l];
+      const float dc = d1 - st.cross;
+      if (rq.x != 0.f) {
+        float dist = pix_scale(rq.x * dc, is, pow2, s2);
         dist = 0 < dist ? dist + eps : dist - eps;
-        acc0 -= diff / dist;
+        acc0 -= PMB_DIV(diff, dist);
       }
-      if (q1 != 0.f) {
-        float dist = pix_scale(q1 * (d1 - cr), is, pow2, s2);
+      if (rq.y != 0.f) {
+        float dist = pix_scale(rq.y * dc, is, pow2, s2);
         dist = 0 < dist ? dist + eps : dist - eps;
-        acc1 -= diff / dist;
+        acc1 -= PMB_DIV(diff, dist);
       }
     }
   }
@@ -708,6 +745,7 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
 int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const float* rgb, const float* grad_rgb, int B,
                             int F, int image_size, int channels, float eps, float* grad_faces, void* stream) {
   if (!faces || !face_index || !rgb || !grad_rgb || !grad_faces || channels <= 0) return SLN_E_BADARG;
+  if ((long)image_size * image_size >= (1L << 31)) return SLN_E_UNSUPPORTED;      // 32-bit pixel offsets inside an image
   const long n = (long)B * F;
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1053,6 +1091,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                        const float* grad_final, float* grad_faces, void* stream) {
   if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !grad_final || !grad_faces) return SLN_E_BADARG;
   if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
+  if ((long)num_classes * image_size * image_size >= (1L << 30)) return SLN_E_UNSUPPORTED;   // 32-bit byte offsets inside an image's class planes (pixel_map_backward_kernel)
   hipStream_t st = (hipStream_t)stream;
   const int is = image_size;
   const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
