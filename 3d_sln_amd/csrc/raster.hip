@@ -290,14 +290,11 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
     acc[k] = v;
   }
   if (lane == 0) {
-    if (gridDim.y == 1) {
+    // always atomic: in the fused scene pass this kernel runs on a side stream NEXT TO pixel_map_backward_kernel, which adds into
+    // the same nine floats of the face (a plain read-modify-write here could swallow one of its atomic adds)
 #pragma unroll
-      for (int k = 0; k < 9; ++k) gfaces[9 * i + k] += acc[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 9; ++k)
-        if (acc[k] != 0.f) atomicAdd(gfaces + 9 * i + k, acc[k]);
-    }
+    for (int k = 0; k < 9; ++k)
+      if (acc[k] != 0.f) atomicAdd(gfaces + 9 * i + k, acc[k]);
   }
 }
 
@@ -320,14 +317,17 @@ inline int pixel_map_scan_split(long faces_total, int B) {
 // A policy exposes, per (scan axis, image), a view with pixel offsets LOCAL to the image (32-bit: the base pointers of the image
 // are wavefront-uniform, so a load is "uniform base + 32-bit lane offset" - the 64-bit per-lane address arithmetic of the first
 // version was a dozen of the ~130 instructions a scan window costs, and the kernel is bound by instruction issue, see below):
-// idx(d0, d1), ref_at(p), load(p, ref) and eval(loaded, ref) = sum_c (I_c(p) - I_c(ref)) * dI_c(p) with the package's
+// idx(d0, d1), ref_pair(p, p', ..), load(p, ref) and eval(loaded, ref) = sum_c (I_c(p) - I_c(ref)) * dI_c(p) with the package's
 // positive-part test.
 struct PixDenseView {
   const int32_t* fi; const float* rgb; const float* grad; int C, is, axis;      // pointers at the image's first pixel
   __device__ __forceinline__ int idx(int d0, int d1) const { return axis == 0 ? d1 * is + d0 : d0 * is + d1; }
   // Ref: what a scan needs to know about its reference pixel, fetched once per edge step (phase 1)
   struct __align__(16) Ref { int p; int fi; int pad_[2]; };
-  __device__ __forceinline__ Ref ref_at(int p) const { Ref r; r.p = p; r.fi = fi[p]; r.pad_[0] = r.pad_[1] = 0; return r; }
+  __device__ __forceinline__ void ref_pair(int pa, int pb, Ref& ra, Ref& rb) const {
+    ra.p = pa; ra.fi = fi[pa]; ra.pad_[0] = ra.pad_[1] = 0;
+    rb.p = pb; rb.fi = fi[pb]; rb.pad_[0] = rb.pad_[1] = 0;
+  }
   struct Loaded { int fq; float diff; };
   __device__ __forceinline__ Loaded load(int p, const Ref& ref) const {
     Loaded r; r.fq = fi[p];
@@ -361,11 +361,12 @@ struct PixClassView {
   // Ref: class and value of the reference pixel of an edge step (phase 1).  Knowing the class up front makes the address of
   // the second gradient plane independent of the scanned pixel's record, so both loads of a scan pixel go out together.
   struct __align__(16) Ref { int fi, cp; float v; int pad_; };
-  __device__ __forceinline__ Ref ref_at(int p) const {
-    int4 ir = *reinterpret_cast<const int4*>(rec + (unsigned)p * 16u);
-    asm volatile("" : "+v"(ir.x), "+v"(ir.y), "+v"(ir.z), "+v"(ir.w));          // one 16-byte load, see load()
-    Ref r; r.fi = ir.x; r.cp = ir.y; r.v = __int_as_float(ir.z); r.pad_ = 0;
-    return r;
+  __device__ __forceinline__ void ref_pair(int pa, int pb, Ref& ra, Ref& rb) const {      // both loads, then both pins (see load())
+    int4 ia = *reinterpret_cast<const int4*>(rec + (unsigned)pa * 16u);
+    int4 ib = *reinterpret_cast<const int4*>(rec + (unsigned)pb * 16u);
+    asm volatile("" : "+v"(ia.x), "+v"(ia.y), "+v"(ia.z), "+v"(ia.w), "+v"(ib.x), "+v"(ib.y), "+v"(ib.z), "+v"(ib.w));
+    ra.fi = ia.x; ra.cp = ia.y; ra.v = __int_as_float(ia.z); ra.pad_ = 0;
+    rb.fi = ib.x; rb.cp = ib.y; rb.v = __int_as_float(ib.z); rb.pad_ = 0;
   }
   struct Loaded { int4 iq; float g_cr; };
   __device__ __forceinline__ Loaded load(int p, const Ref& ref) const {
@@ -374,8 +375,11 @@ struct PixClassView {
     // ... and it has to stay one: value and own-plane gradient (z, w) are only used when the class (y) is >= 0, so hipcc split
     // the load into two 8-byte halves and sank the second one behind the class test - a second, dependent round trip per
     // scan window (global_load_dwordx2, s_waitcnt vmcnt(1), branch, global_load_dwordx2 offset:8, s_waitcnt vmcnt(0) in the ISA)
-    asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w));
-    r.g_cr = *reinterpret_cast<const float*>(g + ((unsigned)max(ref.cp, 0) * plane4 + (unsigned)p * 4u));   // unconditional, independent of iq
+    // The pin below makes the four words live at that point, i.e. it is also where the wavefront waits for them: the load of
+    // the reference class's gradient plane (unconditional, independent of the record) is an operand too, so that it is issued
+    // BEFORE the wait and both loads share one round trip.
+    r.g_cr = *reinterpret_cast<const float*>(g + ((unsigned)max(ref.cp, 0) * plane4 + (unsigned)p * 4u));
+    asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w), "+v"(r.g_cr));
     return r;
   }
   __device__ __forceinline__ float eval(const Loaded& L, const Ref& ref, int& fq) const {
@@ -419,10 +423,15 @@ __device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2)
 // small faces had finished - the kernel ran as long as its largest face.  Units outside the edge's d0 range exit at
 // once; each unit adds its two partial sums to the face gradient with two atomics.
 constexpr int PMB_DC = 64;
-#ifdef PMB_FAST_DIV
-#define PMB_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
-#else
+// diff / dist of a contributing scan pixel: v_rcp_f32 (1 ulp) and a multiplication instead of the ~12-instruction IEEE division
+// sequence, twice per contributing pixel in a kernel bound by instruction issue (0.774 -> 0.750 ms per 16 rooms forward + backward).
+// The face gradient is a sum of thousands of such terms whose order already differs from the restatement's (lane partial sums,
+// atomics): the relative change is ~1e-7, three orders below the 1e-4 tolerance of the parity tests (which pass in both builds).
+// -DPMB_EXACT_DIV restores the division.
+#ifdef PMB_EXACT_DIV
 #define PMB_DIV(a, b) ((a) / (b))
+#else
+#define PMB_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
 #endif
 
 // Inside a unit the serial form of the edge walk (for each d0: load the face index under the edge, then scan) is a
@@ -492,6 +501,8 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
   const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
   float acc0 = 0.f, acc1 = 0.f;                 // gradient slots pi[0] / pi[1], component (1 - axis)
+  // hoisted by hand: hipcc re-read gridDim.z from the dispatch packet in every window (s_load_dword + s_waitcnt lgkmcnt(0))
+  const int wfirst = 64 * (int)blockIdx.z, wstep = 64 * (int)gridDim.z;
   // an edge longer than PMB_DC steps takes several rounds (chunks) in the same wavefront: one workgroup per chunk filled the
   // grid with empty workgroups (three out of four), whose dispatch alone cost ~0.25 ms per batch of 16 rooms
   for (int c_from = d0_from; c_from <= d0_to; c_from += PMB_DC) {
@@ -512,8 +523,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       const bool use0 = p[1][0] != d0, use1 = p[0][0] != d0;
       r0 = use0 ? (p[1][0] - p[0][0]) / (p[1][0] - d0) : 0.f;         // 0 marks "slot not used" (a used ratio is never 0)
       r1 = use1 ? (p[1][0] - p[0][0]) / (d0 - p[0][0]) : 0.f;
-      const typename View::Ref rin = V.ref_at(V.idx(d0, d1_in));
-      s_ref[lane][0] = rin; s_ref[lane][1] = V.ref_at(V.idx(d0, d1_out));
+      typename View::Ref rin, rout;
+      V.ref_pair(V.idx(d0, d1_in), V.idx(d0, d1_out), rin, rout);
+      s_ref[lane][0] = rin; s_ref[lane][1] = rout;
       if (rin.fi == fn) {                                              // outward scan to the image border
         const int lim = dir > 0 ? is - 1 : 0;
         const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
@@ -542,7 +554,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // x up to 256 scan pixels per chunk = 256 windows of two dependent loads each, 150 us - so gridDim.z workgroups repeat
   // phase 1 (one memory round trip) and deal the windows among themselves.
   int l0 = 0;                                    // row of the previous window's last pixel: rows only move forward
-  for (int w0 = 64 * (int)blockIdx.z; w0 < W; w0 += 64 * (int)gridDim.z) {
+  for (int w0 = wfirst; w0 < W; w0 += wstep) {
     const int w = min(w0 + lane, W - 1);
     int l = l0;                                  // largest l with s_pre[l] <= w: a short walk instead of a 6-step bisection
     int pre = s_pre[l];
@@ -550,9 +562,10 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
     l0 = __shfl(l, 63, 64);
     if (w0 + lane >= W) continue;
     const int t = w - pre;
-    const PmbStep st = s_step[l];
+    PmbStep st = s_step[l];
+    asm volatile("" : "+v"(st.lo), "+v"(st.ofrom), "+v"(st.ifrom), "+v"(st.cross));      // one ds_read_b128 (hipcc read two words and fetched the others in two branches)
     const bool outward = t < st.lo;
-    const int d1 = outward ? st.ofrom + t : st.ifrom + (t - st.lo);
+    const int d1 = t + (outward ? st.ofrom : st.ifrom - st.lo);
     const typename View::Ref ref = s_ref[l][outward ? 0 : 1];
     int fq;
     const float diff = V.eval(V.load(V.idx(c_from + l, d1), ref), ref, fq);
