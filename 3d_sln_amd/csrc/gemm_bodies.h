@@ -188,8 +188,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     for (int c = tid; c < BN; c += NT) {
       float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
       if (n0 + c < a.N) {
-        bn_fwd_coef(a.obn, n0 + c, e.x, e.y);
-        bn_mean_istd(a.obn, n0 + c, e.z, e.w);
+        e = bn_fwd_coef4(a.obn, n0 + c);
       }
       ecoef[c] = e;
     }
@@ -420,7 +419,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   if (EPI == EPI_MASK) {
     for (int c = tid; c < TS; c += 256) {
       float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-      if (n0 + c < a.N) { bn_fwd_coef(a.obn, n0 + c, e.x, e.y); bn_mean_istd(a.obn, n0 + c, e.z, e.w); }
+      if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
       ecoef[c] = e;
     }
   }

@@ -35,50 +35,94 @@ struct BnView {
 // together (they used to alternate with the arithmetic that consumed them: 3-4 serialized memory round trips), the row-count
 // reciprocal comes from the host, and 1/sqrt is v_rsq_f32 on the fp32 variance (the variance itself - E[x^2] - mean^2, which
 // cancels - stays in fp64; round 1 used three fp64 divisions per column here).
+// (Round 2, from the ISA of the edge kernels: with the mode tests BETWEEN the loads - gamma / beta, branch, sums, and a second
+// call for (mean, 1/std) that loaded the sums again - hipcc put an s_waitcnt vmcnt(0) in front of every group: three dependent
+// round trips per coefficient table, six in front of a scatter / gather kernel's first row.  Every mode is now one straight
+// block: all loads, then the arithmetic; bn_fwd_coef4 returns the four forward values from ONE set of loads.)
+__device__ __forceinline__ void bn_train_mean_istd(const BnView& b, double s1, double s2, float& mean, float& istd) {
+  const double m = s1 * b.rn;
+  double v = fma(-m, m, s2 * b.rn);
+  v = v < 0.0 ? 0.0 : v;
+  mean = (float)m;
+  istd = __builtin_amdgcn_rsqf((float)v + b.eps);
+}
 __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean, float& istd) {
   if (b.mode == SLN_BN_TRAIN) {
     const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
-    const double m = s1 * b.rn;
-    double v = fma(-m, m, s2 * b.rn);
-    v = v < 0.0 ? 0.0 : v;
-    mean = (float)m;
-    istd = __builtin_amdgcn_rsqf((float)v + b.eps);
+    bn_train_mean_istd(b, s1, s2, mean, istd);
   } else if (b.mode == SLN_BN_EVAL) {
-    mean = b.rmean[c];
-    istd = __builtin_amdgcn_rsqf(b.rvar[c] + b.eps);
+    const float rm = b.rmean[c], rv = b.rvar[c];
+    mean = rm;
+    istd = __builtin_amdgcn_rsqf(rv + b.eps);
   } else {
     mean = 0.f;
     istd = 1.f;
   }
 }
-// forward coefficients: h = max(scale*x + shift, 0)
-__device__ __forceinline__ void bn_fwd_coef(const BnView& b, int c, float& scale, float& shift) {
-  if (b.mode == SLN_BN_NONE) { scale = 1.f; shift = 0.f; return; }
-  const float gamma = b.gamma[c], beta = b.beta[c];
+// forward coefficients (scale, shift, mean, istd): h = max(scale*x + shift, 0)
+__device__ __forceinline__ float4 bn_fwd_coef4(const BnView& b, int c) {
   float mean, istd;
-  bn_mean_istd(b, c, mean, istd);
-  scale = gamma * istd;
-  shift = beta - mean * scale;
+  if (b.mode == SLN_BN_TRAIN) {
+    const float gamma = b.gamma[c], beta = b.beta[c];
+    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    bn_train_mean_istd(b, s1, s2, mean, istd);
+    const float scale = gamma * istd;
+    return make_float4(scale, beta - mean * scale, mean, istd);
+  }
+  if (b.mode == SLN_BN_EVAL) {
+    const float gamma = b.gamma[c], beta = b.beta[c], rm = b.rmean[c], rv = b.rvar[c];
+    mean = rm;
+    istd = __builtin_amdgcn_rsqf(rv + b.eps);
+    const float scale = gamma * istd;
+    return make_float4(scale, beta - mean * scale, mean, istd);
+  }
+  return make_float4(1.f, 0.f, 0.f, 1.f);
+}
+// two columns of the same BatchNorm at once (the subject / object halves of GraphTripleConv's second Linear): one round trip
+__device__ __forceinline__ void bn_fwd_coef4x2(const BnView& b, int ca, int cb, float4& va, float4& vb) {
+  if (b.mode == SLN_BN_TRAIN) {
+    const float ga = b.gamma[ca], ba = b.beta[ca], gb = b.gamma[cb], bb = b.beta[cb];
+    const double a1 = b.sums[ca], a2 = b.sums[b.cstride + ca], b1 = b.sums[cb], b2 = b.sums[b.cstride + cb];
+    float mean, istd;
+    bn_train_mean_istd(b, a1, a2, mean, istd);
+    float scale = ga * istd;
+    va = make_float4(scale, ba - mean * scale, mean, istd);
+    bn_train_mean_istd(b, b1, b2, mean, istd);
+    scale = gb * istd;
+    vb = make_float4(scale, bb - mean * scale, mean, istd);
+    return;
+  }
+  va = bn_fwd_coef4(b, ca);
+  vb = bn_fwd_coef4(b, cb);
+}
+__device__ __forceinline__ void bn_fwd_coef(const BnView& b, int c, float& scale, float& shift) {
+  const float4 v = bn_fwd_coef4(b, c);
+  scale = v.x; shift = v.y;
 }
 // backward coefficients: dX = p0*g + p1*x + p2  (g = relu-masked incoming gradient)
 //   train: dX = scale*(g - mean(g) - xhat*mean(g*xhat)), xhat = (x-mean)*istd
 __device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, float& p1, float& p2) {
-  if (b.mode == SLN_BN_NONE) { p0 = 1.f; p1 = 0.f; p2 = 0.f; return; }
-  const float gamma = b.gamma[c];
-  double g1 = 0.0, g2 = 0.0;
-  if (b.mode == SLN_BN_TRAIN) { g1 = b.gsums[c]; g2 = b.gsums[b.cstride + c]; }
-  float mean, istd;
-  bn_mean_istd(b, c, mean, istd);
-  float scale = gamma * istd;
-  p0 = scale;
   if (b.mode == SLN_BN_TRAIN) {
-    float c1 = (float)(g1 * b.rn);
-    float c2 = (float)(g2 * b.rn);
+    const float gamma = b.gamma[c];
+    const double g1 = b.gsums[c], g2 = b.gsums[b.cstride + c];
+    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    float mean, istd;
+    bn_train_mean_istd(b, s1, s2, mean, istd);
+    const float scale = gamma * istd;
+    const float c1 = (float)(g1 * b.rn);
+    const float c2 = (float)(g2 * b.rn);
+    p0 = scale;
     p1 = -scale * istd * c2;
     p2 = -scale * c1 - p1 * mean;
-  } else {
-    p1 = 0.f; p2 = 0.f;
+    return;
   }
+  if (b.mode == SLN_BN_EVAL) {
+    const float gamma = b.gamma[c], rv = b.rvar[c];
+    p0 = gamma * __builtin_amdgcn_rsqf(rv + b.eps);
+    p1 = 0.f; p2 = 0.f;
+    return;
+  }
+  p0 = 1.f; p1 = 0.f; p2 = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------

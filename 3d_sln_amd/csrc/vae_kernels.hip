@@ -136,7 +136,7 @@ __device__ __forceinline__ void fill_coef_table(float4* tab, const BnView& bn, i
   const int tid = threadIdx.y * XT + threadIdx.x;
   for (int j = tid; j < 4 * XT; j += XT * YT) {
     float4 v = make_float4(1.f, 0.f, 0.f, 1.f);
-    if (c0 + j < ncols) { bn_fwd_coef(bn, coloff + c0 + j, v.x, v.y); bn_mean_istd(bn, coloff + c0 + j, v.z, v.w); }
+    if (c0 + j < ncols) v = bn_fwd_coef4(bn, coloff + c0 + j);
     tab[j] = v;
   }
 }
@@ -168,12 +168,28 @@ __device__ __forceinline__ void commit_col_stats4(const float4& s1, const float4
 constexpr int ECACHE = 64;
 constexpr int EB = 8;                      // row loads in flight per thread
 
+// The prologue of an edge kernel is a chain of memory round trips in front of the first row: the CSR bounds of the row are loaded
+// FIRST (row_bounds), the coefficient tables' loads go out next to them, the entry list follows (cache_entries): two round trips
+// (the first version took eight: gamma / beta, sums, sums again per table, two tables, row pointers, entries).
+__device__ __forceinline__ void row_bounds(const GraphCsr& g, int row, int nrows, int& b, int& e) {
+  const int r = min(row, nrows - 1);               // unconditional, clamped
+  b = g.rowptr[r]; e = g.rowptr[r + 1];
+  if (row >= nrows) { b = 0; e = 0; }
+}
 template <int XT, int YT>
-__device__ __forceinline__ void cache_entries(int (*ents)[ECACHE], const GraphCsr& g, int row, int nrows, int& b, int& e) {
-  b = 0; e = 0;
-  if (row < nrows) { b = g.rowptr[row]; e = g.rowptr[row + 1]; }
+__device__ __forceinline__ void cache_entries(int (*ents)[ECACHE], const GraphCsr& g, int b, int e) {
   for (int k = threadIdx.x; k < min(e - b, ECACHE); k += XT) ents[threadIdx.y][k] = g.ent[b + k];
   __syncthreads();
+}
+// the two coefficient tables of the forward scatter (columns c0.. of the subject half and of the object half)
+template <int XT, int YT>
+__device__ __forceinline__ void fill_coef_table2(float4* ta, float4* tb, const BnView& bn, int c0, int ncols, int coloff_b) {
+  const int tid = threadIdx.y * XT + threadIdx.x;
+  for (int j = tid; j < 4 * XT; j += XT * YT) {
+    float4 va = make_float4(1.f, 0.f, 0.f, 1.f), vb = va;
+    if (c0 + j < ncols) bn_fwd_coef4x2(bn, c0 + j, coloff_b + c0 + j, va, vb);
+    ta[j] = va; tb[j] = vb;
+  }
 }
 
 template <int XT, int YT>
@@ -184,9 +200,9 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
   int b, e;
-  fill_coef_table<XT, YT>(cs, bn, c0, H, 0);
-  fill_coef_table<XT, YT>(co, bn, c0, H, H + D);
-  cache_entries<XT, YT>(ents, g, i, O, b, e);
+  row_bounds(g, i, O, b, e);
+  fill_coef_table2<XT, YT>(cs, co, bn, c0, H, H + D);
+  cache_entries<XT, YT>(ents, g, b, e);
   const int c = c0 + 4 * threadIdx.x;
   if (c >= H || i >= O) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -271,8 +287,9 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
   int b, e;
+  row_bounds(g, i, O, b, e);
   if (masked) fill_coef_table<XT, YT>(cf, bn, c0, D, 0);
-  cache_entries<XT, YT>(ents, g, i, O, b, e);
+  cache_entries<XT, YT>(ents, g, b, e);
   const int c = c0 + 4 * threadIdx.x;
   const bool cv = c < D && i < O;
   const float4* kk = cf + 4 * threadIdx.x;
@@ -319,7 +336,7 @@ __global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __rest
   const int c = blockIdx.x * CB + threadIdx.x;
   const bool cv = c < cols;
   float sc = 1.f, sh = 0.f, mean = 0.f, istd = 1.f;
-  if (cv) { bn_fwd_coef(bn, c, sc, sh); bn_mean_istd(bn, c, mean, istd); }
+  if (cv) { const float4 k4 = bn_fwd_coef4(bn, c); sc = k4.x; sh = k4.y; mean = k4.z; istd = k4.w; }
   float s1 = 0.f, s2 = 0.f;
   const int r1 = min(rows, (int)(blockIdx.y + 1) * RB);
   if (cv) {
