@@ -121,8 +121,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     const int fn = c0 + tid;
     bool hit = false;
     if (fn < F) {
-      const BBox8 q = bb[fn];
-      const int bx0 = q.x0, bx1 = q.x1, by0 = q.y0, by1 = q.y1;
+      // one 8-byte load, pinned: hipcc loaded x0 alone (global_load_ushort), waited, and fetched the other three fields behind the
+      // first comparison of the short-circuit test below - two dependent round trips per chunk of 256 faces for one
+      uint2 q = *reinterpret_cast<const uint2*>(bb + fn);
+      asm volatile("" : "+v"(q.x), "+v"(q.y));
+      const int bx0 = (int)(q.x & 0xffffu), bx1 = (int)(q.x >> 16), by0 = (int)(q.y & 0xffffu), by1 = (int)(q.y >> 16);
       hit = bx0 <= tx1 && bx1 >= tx0 && by0 <= ty1 && by1 >= ty0;
       if (hit) {
         // the bounding box of a triangle is twice its area: drop the face when the whole tile lies outside one of its
