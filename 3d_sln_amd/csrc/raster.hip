@@ -831,26 +831,35 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   const int b = blockIdx.y;
   const long plane = (long)is * is;
   __shared__ float ssum[64]; __shared__ int scnt[64];
+  __shared__ int s_wkey, s_wany;        // the block's wall maximum: ONE pair of device atomics per block (every wall pixel - a third
+                                        // of a room image - used to issue its own pair on the same two words)
   if (threadIdx.x < 64) { ssum[threadIdx.x] = 0.f; scnt[threadIdx.x] = 0; }
+  if (threadIdx.x == 0) { s_wkey = (int)0x80000000; s_wany = 0; }
   __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
     const long q = b * plane + p;
-    const int f = fi_b[q];
+    // the three streams of a pixel in one round trip (pinned: hipcc sinks each load behind the test that precedes its use)
+    int f = fi_b[q]; float v = val[3 * q]; float d = d_a[q];
+    asm volatile("" : "+v"(f), "+v"(v), "+v"(d));
     if (f < 0) continue;
     const int c = cls[(long)b * F + f];
     if (c < 0 || c >= NC) continue;
-    if (!(class_image_value(val[3 * q]) > 0.1f)) continue;
-    const float dd = depth_value(d_a[q]);
+    if (!(class_image_value(v) > 0.1f)) continue;
+    const float dd = depth_value(d);
     atomicAdd(&ssum[c], dd); atomicAdd(&scnt[c], 1);
     if (c == 0) {                       // wall_max = max depth over the wall mask (models/diff_render.py:408-411)
-      atomicMax(&st[b].wall_any, 1);
-      atomicMax(&st[b].wall_key, fkey(dd));
+      s_wany = 1;
+      atomicMax(&s_wkey, fkey(dd));
     }
   }
   __syncthreads();
   if (threadIdx.x < NC && scnt[threadIdx.x] > 0) {
     atomicAdd(&st[b].sum[threadIdx.x], (double)ssum[threadIdx.x]);
     atomicAdd(&st[b].cnt[threadIdx.x], (double)scnt[threadIdx.x]);
+  }
+  if (threadIdx.x == 0 && s_wany) {
+    atomicMax(&st[b].wall_any, 1);
+    atomicMax(&st[b].wall_key, s_wkey);
   }
 }
 
@@ -862,22 +871,32 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
                                                             float* __restrict__ out) {
   __shared__ int s_chan[64];          // image channel (0-based among the 40) of class c
+  __shared__ int s_dch[64];           // depth channel of class c
   __shared__ int s_owner[32];         // class owning depth channel k, -1 if none
-  __shared__ float s_fill[32];        // mean_c / wall_max of that class
+  __shared__ float s_fill[32];        // mean_c / wall_max of that class (the quotient: it is the same for every pixel)
   __shared__ float s_wall;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
-  if (threadIdx.x < 64) s_chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;
+  // The class tables go to LDS in one round trip; the owner search then walks LDS.  (It walked dch[] in global memory with a
+  // break - up to 32 dependent loads in front of every workgroup's first pixel - and every pixel divided each of its 29
+  // depth-hot values by wall_max: 0.048 ms per 16 rooms for a kernel that writes 73 MB.)
+  if (threadIdx.x < 64) {
+    s_chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;
+    s_dch[threadIdx.x] = threadIdx.x < NC ? dch[threadIdx.x] : -1;
+  }
+  __syncthreads();
   if (threadIdx.x < 32) {
     const int k = threadIdx.x;
     int owner = -1;
     if (k < ndch)
-      for (int c = 0; c < NC; ++c) if (dch[c] == k) { owner = c; break; }
+      for (int c = 0; c < NC; ++c) if (s_dch[c] == k) { owner = c; break; }
     s_owner[k] = owner;
     const float wall_max = wall_max_of(st[b]);
+    const int oc = max(owner, 0);
+    const double cnt = st[b].cnt[oc], sum = st[b].sum[oc];          // unconditional: one round trip together with the wall statistics
     float fill = 0.f;
-    if (owner >= 0) fill = (st[b].cnt[owner] > 0.0 ? (float)(st[b].sum[owner] / st[b].cnt[owner]) : wall_max);
-    s_fill[k] = fill;
+    if (owner >= 0) fill = (cnt > 0.0 ? (float)(sum / cnt) : wall_max);
+    s_fill[k] = fill / wall_max;
     if (k == 0) s_wall = wall_max;
   }
   __syncthreads();
@@ -896,10 +915,12 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   o[0] = dd;
   const int mych = cvalid ? s_chan[c] : -1;
   for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
+  const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
+  const bool own_ok = img > 0.1f;
   for (int k = 0; k < ndch; ++k) {
     const int owner = s_owner[k];
     float v = 0.f;
-    if (owner >= 0) v = ((c == owner && img > 0.1f) ? dd : s_fill[k]) / wall_max;
+    if (owner >= 0) v = (c == owner && own_ok) ? ddq : s_fill[k];
     o[(long)(41 + k) * plane] = v;
   }
 }
@@ -916,16 +937,27 @@ __global__ void scene_zero_gsum_kernel(SceneStats* st, int B) {      // backward
 __global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t* __restrict__ dch, int is, int NC, int nch,
                                                                    const float* __restrict__ gout, SceneStats* __restrict__ st) {
   const int b = blockIdx.z, k = blockIdx.y;                       // depth-hot channel k
-  int owner = -1;
-  for (int c = 0; c < NC; ++c) if (dch[c] == k) { owner = c; break; }
+  __shared__ int s_owner;
+  if (threadIdx.x == 0) s_owner = -1;
+  __syncthreads();
+  // owner = the lowest class whose depth channel is k: one load per lane and an LDS minimum (the scalar walk with its break was up
+  // to 32 dependent loads in front of the stream)
+  if (threadIdx.x < 64 && threadIdx.x < NC && dch[threadIdx.x] == k) atomicMin(reinterpret_cast<unsigned*>(&s_owner), (unsigned)threadIdx.x);
+  __syncthreads();
+  const int owner = s_owner;
   if (owner < 0) return;
   const long plane = (long)is * is;
   const float4* src = reinterpret_cast<const float4*>(gout + ((long)b * nch + 41 + k) * plane);
   const long n4 = plane / 4;
   float acc = 0.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = src[i];
-    acc += (v.x + v.y) + (v.z + v.w);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 8 * stride) {
+    float4 v[8];                                                   // eight loads in flight, summed in the order of the plain loop
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = src[min(i0 + u * stride, n4 - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * stride < n4) acc += (v[u].x + v[u].y) + (v[u].z + v[u].w);
   }
   if (blockIdx.x == 0)                                             // tail when the plane size is not a multiple of 4
     for (long i = n4 * 4 + threadIdx.x; i < plane; i += blockDim.x) acc += gout[((long)b * nch + 41 + k) * plane + i];
