@@ -863,6 +863,34 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   }
 }
 
+struct ComposeTabs { int chan[64]; int dch[64]; int owner[32]; float fill[32]; float wall; };
+// The class tables go to LDS in one round trip; the owner search then walks LDS.  (It walked dch[] in global memory with a
+// break - up to 32 dependent loads in front of every workgroup's first pixel - and every pixel divided each of its 29
+// depth-hot values by wall_max.)
+__device__ __forceinline__ void compose_tables(ComposeTabs& t, const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int NC,
+                                               int ndch, const SceneStats& sb) {
+  if (threadIdx.x < 64) {
+    t.chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;      // image channel (0-based among the 40) of class c
+    t.dch[threadIdx.x] = threadIdx.x < NC ? dch[threadIdx.x] : -1;        // depth channel of class c
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int k = threadIdx.x;
+    int owner = -1;                                                         // class owning depth channel k, -1 if none
+    if (k < ndch)
+      for (int c = 0; c < NC; ++c) if (t.dch[c] == k) { owner = c; break; }
+    t.owner[k] = owner;
+    const float wall_max = wall_max_of(sb);
+    const int oc = max(owner, 0);
+    const double cnt = sb.cnt[oc], sum = sb.sum[oc];                      // unconditional: one round trip together with the wall statistics
+    float fill = 0.f;
+    if (owner >= 0) fill = (cnt > 0.0 ? (float)(sum / cnt) : wall_max);
+    t.fill[k] = fill / wall_max;                                            // mean_c / wall_max: the same quotient for every pixel
+    if (k == 0) t.wall = wall_max;
+  }
+  __syncthreads();
+}
+
 // One thread per pixel writes all nch channels: the per-pixel inputs are read once (a thread per (pixel, channel) re-read
 // them 70 times), every store instruction of a wavefront covers 64 consecutive pixels of one channel plane.
 __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
@@ -870,42 +898,16 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
                                                             float* __restrict__ out) {
-  __shared__ int s_chan[64];          // image channel (0-based among the 40) of class c
-  __shared__ int s_dch[64];           // depth channel of class c
-  __shared__ int s_owner[32];         // class owning depth channel k, -1 if none
-  __shared__ float s_fill[32];        // mean_c / wall_max of that class (the quotient: it is the same for every pixel)
-  __shared__ float s_wall;
+  __shared__ ComposeTabs t;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
-  // The class tables go to LDS in one round trip; the owner search then walks LDS.  (It walked dch[] in global memory with a
-  // break - up to 32 dependent loads in front of every workgroup's first pixel - and every pixel divided each of its 29
-  // depth-hot values by wall_max: 0.048 ms per 16 rooms for a kernel that writes 73 MB.)
-  if (threadIdx.x < 64) {
-    s_chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;
-    s_dch[threadIdx.x] = threadIdx.x < NC ? dch[threadIdx.x] : -1;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {
-    const int k = threadIdx.x;
-    int owner = -1;
-    if (k < ndch)
-      for (int c = 0; c < NC; ++c) if (s_dch[c] == k) { owner = c; break; }
-    s_owner[k] = owner;
-    const float wall_max = wall_max_of(st[b]);
-    const int oc = max(owner, 0);
-    const double cnt = st[b].cnt[oc], sum = st[b].sum[oc];          // unconditional: one round trip together with the wall statistics
-    float fill = 0.f;
-    if (owner >= 0) fill = (cnt > 0.0 ? (float)(sum / cnt) : wall_max);
-    s_fill[k] = fill / wall_max;
-    if (k == 0) s_wall = wall_max;
-  }
-  __syncthreads();
+  compose_tables(t, chan, dch, NC, ndch, st[b]);
   const long plane = (long)is * is;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int y = (int)(p / is), x = (int)(p % is);
   const long q = b * plane + p;
-  const float wall_max = s_wall;
+  const float wall_max = t.wall;
   const int f = fi_b[q];
   const int c = f >= 0 ? cls[(long)b * F + f] : -1;
   const bool cvalid = c >= 0 && c < NC;
@@ -913,14 +915,14 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   const float dd = depth_value(d_a[q]);
   float* o = out + ((long)b * nch * is + (is - 1 - y)) * is + x;       // channel stride = plane
   o[0] = dd;
-  const int mych = cvalid ? s_chan[c] : -1;
+  const int mych = cvalid ? t.chan[c] : -1;
   for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
   const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
   const bool own_ok = img > 0.1f;
   for (int k = 0; k < ndch; ++k) {
-    const int owner = s_owner[k];
+    const int owner = t.owner[k];
     float v = 0.f;
-    if (owner >= 0) v = (c == owner && own_ok) ? ddq : s_fill[k];
+    if (owner >= 0) v = (c == owner && own_ok) ? ddq : t.fill[k];
     o[(long)(41 + k) * plane] = v;
   }
 }

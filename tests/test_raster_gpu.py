@@ -167,7 +167,7 @@ def test_renderer_reuses_the_rasterisation_of_unchanged_geometry():
         NR._rasterize = orig
 
 
-@pytest.mark.parametrize("image_size,target", [(96, 500), (256, 2000)])
+@pytest.mark.parametrize("image_size,target", [(96, 500), (256, 2000), (50, 200)])
 def test_fused_scene_matches_33_pass_restatement(image_size, target):
     DR = pkg("host.diff_render")
     V, F, ranges, box = rr.synth_room(7, n_objects=12 if target > 1000 else 5, target_faces=target)
