@@ -788,7 +788,7 @@ namespace {
 
 // Side stream of the scene backward (one per device, created on first use, kept for the life of the process).  SLN_SCENE_NO_SIDE=1
 // keeps every launch on the caller's stream.
-struct SceneSide { hipStream_t stream; hipEvent_t fork, join; };
+struct SceneSide { hipStream_t stream; hipEvent_t fork, mid, join; };
 SceneSide* scene_side() {
   static const bool off = [] { const char* v = std::getenv("SLN_SCENE_NO_SIDE"); return v && v[0] == '1'; }();
   if (off) return nullptr;
@@ -799,9 +799,10 @@ SceneSide* scene_side() {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
   if (per_dev[dev] == nullptr && !failed[dev]) {
-    SceneSide* s = new SceneSide{nullptr, nullptr, nullptr};
+    SceneSide* s = new SceneSide{nullptr, nullptr, nullptr, nullptr};
     if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s->mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) { failed[dev] = true; delete s; return nullptr; }
     per_dev[dev] = s;
   }
@@ -1147,18 +1148,25 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
   SceneWs w = carve_scene(workspace, B, F, is);
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 70.0 * 4.0 * npix + 36.0 * n, st);
-  const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
-  if (e != hipSuccess) return (int)e;
   // Two independent chains add into grad_faces: the depth channel's (gradient sums -> depth-map gradient -> per-face walk,
-  // five launches, ~0.12 ms per 16 rooms) and the class planes' (packed records, gradient planes, edge scans: ~0.35 ms, bound by
-  // latency and by the number of WORKING wavefronts, not by a pipe).  The depth chain runs on a side stream next to the class
-  // chain; in a stream capture the event edges become graph dependencies (fork / join inside this call).
+  // five launches, ~0.12 ms per 16 rooms) and the class planes' (packed records, gradient planes, edge scans: ~0.25 ms, bound by
+  // instruction issue and by the number of WORKING wavefronts).  The depth chain runs on a side stream next to the class
+  // chain; in a stream capture the event edges become graph dependencies (fork / join inside this call).  The side stream
+  // also takes the two launches the edge scans need but the record pass does not - the zero-fill of the face gradient and the
+  // gradient planes - in front of the depth chain: the caller's stream runs the record pass meanwhile and waits (`mid`) before
+  // the scans.
   SceneSide* sd = scene_side();
   hipStream_t sd_st = st;
   if (sd != nullptr) {
     if (hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
     else sd = nullptr;
   }
+  const int t32 = sln_cdiv(is, 32);
+  const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, sd_st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, sd_st, grad_final, class_channel, is,
+                     num_classes, 70, w.st, w.g, w.gT);
+  if (sd != nullptr && hipEventRecord(sd->mid, sd->stream) != hipSuccess) return SLN_E_STATE;
   hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, sd_st, w.st, B);
   hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
                      w.st);
@@ -1168,11 +1176,9 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
                      grad_faces);
-  const int t32 = sln_cdiv(is, 32);
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
                      num_classes, 70, w.prec, w.precT);
-  hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, st, grad_final, class_channel, is,
-                     num_classes, 70, w.st, w.g, w.gT);
+  if (sd != nullptr && hipStreamWaitEvent(st, sd->mid, 0) != hipSuccess) return SLN_E_STATE;
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
                      grad_faces);
