@@ -1155,7 +1155,9 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // also takes the two launches the edge scans need but the record pass does not - the zero-fill of the face gradient and the
   // gradient planes - in front of the depth chain: the caller's stream runs the record pass meanwhile and waits (`mid`) before
   // the scans.
-  SceneSide* sd = scene_side();
+  // Batches only: with one room (the refinement loop, a captured iteration of ~240 small launches) the three event edges cost
+  // more than the overlap returns - 1.37 ms per iteration with the side stream, 1.22 ms without (same-box A/B).
+  SceneSide* sd = n >= 16384 ? scene_side() : nullptr;
   hipStream_t sd_st = st;
   if (sd != nullptr) {
     if (hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
