@@ -242,8 +242,9 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
                                                                  const float* __restrict__ w, const float* __restrict__ depth,
                                                                  const float* __restrict__ gd, int F, int is,
                                                                  float* __restrict__ gfaces) {
-  const long i = blockIdx.x;
-  const int b = (int)(i / F), fn = (int)(i % F), lane = threadIdx.x;
+  const size_t i = blockIdx.x;
+  const int b = (int)(blockIdx.x / (unsigned)F), fn = (int)(blockIdx.x - (unsigned)b * (unsigned)F), lane = threadIdx.x;      // 32-bit division
+
   float fl[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) fl[k] = faces[9 * i + k];
@@ -308,6 +309,7 @@ inline int small_batch_split(long units, int max_split, long budget = 32768) {
   return s;
 }
 inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F); }
+inline bool pixel_map_grid_ok(int B, int F) { return (long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F * 6 < (1L << 31); }   // 32-bit workgroup ids in the kernel
 inline int pixel_map_scan_split(long faces_total, int B) {
   if (B >= 8) return 1;                          // the image -> XCD affinity mapping of the kernel uses a 2-D grid
   return small_batch_split(faces_total * 6, 16, 131072);
@@ -465,21 +467,25 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // 1.07 GB from memory per launch for 0.28 GB of maps).  With at least 8 images, XCD x takes the images x, x+8, ...
   // The launcher (pixel_map_grid_x) pads the grid to a multiple of 8 images for this mapping: with B = 9 a grid of 9 F x 6
   // workgroups gives XCD 0 only 6.75 F of the 12 F units of its two images (found by the 9-room parity test).
+  // (32-bit arithmetic: the first version did this mapping with 64-bit integers - four software divisions, ~600 scalar
+  // instructions in front of every one of the 370 k workgroups of a 16-room batch, as many as all their scan windows issue)
   const int lane = threadIdx.x;
-  long i; int ea;
+  unsigned bu, fnu; int ea;
   if (B >= 8) {
-    const long lin = (long)blockIdx.y * gridDim.x + blockIdx.x;
-    const int xcd = (int)(lin & 7); const long j = lin >> 3;
-    const long per_img = (long)F * 6;
-    const long img_local = j / per_img, rem = j % per_img;
-    const long img = xcd + 8 * img_local;
-    if (img >= B) return;
-    ea = (int)(rem / F);
-    i = img * F + rem % F;
+    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;       // < 6 * 8 * ceil(B / 8) * F: the launcher refuses grids beyond 2^32
+    const unsigned xcd = lin & 7u, j = lin >> 3;
+    const unsigned per_img = (unsigned)F * 6u;
+    const unsigned img_local = j / per_img, rem = j - img_local * per_img;
+    bu = xcd + 8u * img_local;
+    if (bu >= (unsigned)B) return;
+    const unsigned q = rem / (unsigned)F;
+    ea = (int)q;
+    fnu = rem - q * (unsigned)F;
   } else {
-    i = blockIdx.x; ea = blockIdx.y;
+    bu = blockIdx.x / (unsigned)F; fnu = blockIdx.x - bu * (unsigned)F; ea = blockIdx.y;
   }
-  const int b = (int)(i / F), fn = (int)(i % F);
+  const int b = (int)bu, fn = (int)fnu;
+  const size_t i = (size_t)bu * F + fnu;
   const int e = ea >> 1, axis = ea & 1;
   float face[9];
 #pragma unroll
@@ -762,6 +768,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
                             int F, int image_size, int channels, float eps, float* grad_faces, void* stream) {
   if (!faces || !face_index || !rgb || !grad_rgb || !grad_faces || channels <= 0) return SLN_E_BADARG;
   if ((long)image_size * image_size >= (1L << 31)) return SLN_E_UNSUPPORTED;      // 32-bit pixel offsets inside an image
+  if (!pixel_map_grid_ok(B, F)) return SLN_E_UNSUPPORTED;
   const long n = (long)B * F;
   if (n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -906,7 +913,7 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   const long plane = (long)is * is;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
-  const int y = (int)(p / is), x = (int)(p % is);
+  const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);      // p < is^2 < 2^31: 32-bit division
   const long q = b * plane + p;
   const float wall_max = t.wall;
   const int f = fi_b[q];
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(256) void scene_bwd_masked_sums_kernel(const int32_
     const int c = cls[(long)b * F + f];
     if (c < 0 || c >= NC || dch[c] < 0) continue;
     if (!(class_image_value(val[3 * q]) > 0.1f)) continue;
-    const int y = (int)(p / is), x = (int)(p % is);
+    const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);      // p < is^2 < 2^31: 32-bit division
     atomicAdd(&ssum[c], gout[(((long)b * nch + 41 + dch[c]) * is + (is - 1 - y)) * is + x]);
   }
   __syncthreads();
@@ -1062,7 +1069,7 @@ __global__ void scene_bwd_depthgrad_kernel(const int32_t* __restrict__ fi_b, con
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const long q = b * plane + p;
-  const int y = (int)(p / is), x = (int)(p % is);
+  const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);      // p < is^2 < 2^31: 32-bit division
   float g = 0.f;
   if (!(d_a[q] > 15.f)) {
     const float wall_max = wall_max_of(st[b]);
@@ -1143,6 +1150,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !grad_final || !grad_faces) return SLN_E_BADARG;
   if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
   if ((long)num_classes * image_size * image_size >= (1L << 30)) return SLN_E_UNSUPPORTED;   // 32-bit byte offsets inside an image's class planes (pixel_map_backward_kernel)
+  if (!pixel_map_grid_ok(B, F)) return SLN_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int is = image_size;
   const long plane = (long)is * is, npix = (long)B * plane, n = (long)B * F;
