@@ -356,19 +356,23 @@ def test_class_list_longer_than_the_depth_hot_planes_is_refused():
         DR.class_tables(["wall", "floor", "ceiling"] + others[:30])
 
 
-def test_captured_scene_pass_replays_with_new_vertices_and_gradients():
+@pytest.mark.parametrize("n_rooms,target_faces,IS", [(3, 400, 128), (9, 1200, 96)])
+def test_captured_scene_pass_replays_with_new_vertices_and_gradients(n_rooms, target_faces, IS):
     """SceneRenderGraph: forward + backward of the fused pass as one hipGraph for a fixed topology (the refinement loop of
-    testing/test_render_refine.py:279-359 moves vertices only): every replay must equal the eager pass on the same inputs."""
+    testing/test_render_refine.py:279-359 moves vertices only): every replay must equal the eager pass on the same inputs.
+    The second case is a batch of more than 16 k (image, face) pairs: its backward forks the depth chain onto the library's side
+    stream INSIDE the capture (event edges as graph dependencies)."""
     DR = pkg("host.diff_render"); syn = pkg("host.synthetic")
-    rooms = [syn.synthetic_room(300 + i, n_objects=6, target_faces=400) for i in range(3)]
+    rooms = [syn.synthetic_room(300 + i, n_objects=6, target_faces=target_faces) for i in range(n_rooms)]
     pk = syn.pack_rooms(rooms, "cuda")
-    IS = 128
+    if n_rooms > 3:
+        assert n_rooms * pk["F"].shape[1] * 2 >= 16384, "batch too small to take the side stream (fill_back doubles the faces)"
     args = (pk["F"], pk["C"], pk["chan"], pk["dch"], pk["K"], pk["R"], pk["t"], IS, 0.001)
     g = DR.SceneRenderGraph(pk["V"], *args)
     gen = torch.Generator().manual_seed(4)
     for trial in range(3):
         V = (pk["V"] + 0.01 * trial * torch.randn(pk["V"].shape, generator=gen).cuda()).detach()
-        go = torch.randn(3, 70, IS, IS, generator=gen).cuda()
+        go = torch.randn(n_rooms, 70, IS, IS, generator=gen).cuda()
         image, dV = g(V, go)
         Ve = V.clone().requires_grad_(True)
         ref = DR.scene_render_batch(Ve, *args)
