@@ -493,19 +493,18 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   if (backfacing(face)) return;
   const bool pow2 = (is & (is - 1)) == 0;
   const float s2 = 2.0f / (float)is;
-  int pi[3]; float pp[3][2];
+  // the edge's vertices (rotated by e) with the scan axis first: read straight from memory at computed offsets (the face sits
+  // in scalar registers, and picking six of its nine words by the run-time (e, axis) was a chain of ~90 scalar selects per workgroup)
+  int pi[3];
 #pragma unroll
-  for (int n = 0; n < 3; ++n) pi[n] = (e + n) % 3;
-#pragma unroll
-  for (int n = 0; n < 3; ++n)
-#pragma unroll
-    for (int d = 0; d < 2; ++d) pp[n][d] = 0.5f * (face[3 * pi[n] + d] * is + is - 1);
+  for (int n = 0; n < 3; ++n) pi[n] = e + n >= 3 ? e + n - 3 : e + n;
   const View V = pix.view(axis, b);
+  const float* fp = faces + 9 * i;
   float p[3][2];
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int d = 0; d < 2; ++d) p[n][d] = pp[n][(d + axis) % 2];
+    for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (fp[3 * pi[n] + ((d + axis) & 1)] * is + is - 1);
   const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
   const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
   const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
