@@ -83,6 +83,13 @@ __global__ void raster_prep_kernel(const float* __restrict__ faces, long n, int 
     for (int k = 0; k < 9; ++k) r.inv[k] = 0.f;
     r.x0 = 1; r.x1 = 0; r.y0 = 1; r.y1 = 0;
   }
+  // a lower bound of every depth the face can produce (zp is a weighted harmonic mean of the three vertex depths when they are
+  // all positive; the margin covers its rounding): the tile kernel skips the barycentric / depth arithmetic of a covered pixel
+  // that already holds something nearer.  -inf (never skips) for faces that reach behind the camera.
+  {
+    const float zmin = fminf(r.f[2], fminf(r.f[5], r.f[8]));
+    r.pad_[0] = __float_as_int(draw && zmin > 0.f ? zmin * (1.0f - 1e-5f) : -__builtin_huge_valf());
+  }
   rec[i] = r;
   BBox8 bb; bb.x0 = (unsigned short)r.x0; bb.x1 = (unsigned short)r.x1; bb.y0 = (unsigned short)r.y0; bb.y1 = (unsigned short)r.y1;
   bbox[i] = bb;
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
                                                           float* __restrict__ w_a, float* __restrict__ d_a,
                                                           int32_t* __restrict__ fi_b, float* __restrict__ w_b,
                                                           float* __restrict__ d_b) {
-  __shared__ float sf[CHUNK][18];
+  __shared__ float sf[CHUNK][19];          // 9 vertex words, 9 inverse words, the face's depth lower bound
   __shared__ int sid[CHUNK];
   __shared__ int wave_cnt[4];
   const int tiles_x = (is + TS - 1) / TS;
@@ -151,11 +158,11 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     for (int wv = 0; wv < 4; ++wv) { if (wv < wave) off += wave_cnt[wv]; total += wave_cnt[wv]; }
     if (hit) sid[off + before] = fn;
     __syncthreads();
-    // stage the kept faces (18 coefficients each), coalesced over (face, field)
-    for (int e = tid; e < total * 18; e += 256) {
-      const int k = e / 18, q = e % 18;
+    // stage the kept faces (18 coefficients + the depth bound each), coalesced over (face, field)
+    for (int e = tid; e < total * 19; e += 256) {
+      const int k = e / 19, q = e % 19;
       const FaceRec& r = rb[sid[k]];
-      sf[k][q] = q < 9 ? r.f[q] : r.inv[q - 9];
+      sf[k][q] = q < 9 ? r.f[q] : (q < 18 ? r.inv[q - 9] : __int_as_float(r.pad_[0]));
     }
     __syncthreads();
     if (inimg) {
@@ -164,6 +171,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
         if (((yp - f[1]) * (f[3] - f[0]) < (xp - f[0]) * (f[4] - f[1])) ||
             ((yp - f[4]) * (f[6] - f[3]) < (xp - f[3]) * (f[7] - f[4])) ||
             ((yp - f[7]) * (f[0] - f[6]) < (xp - f[6]) * (f[1] - f[7]))) continue;
+        if (f[18] >= (DUAL ? fmaxf(A.z, Bz.z) : A.z)) continue;      // cannot beat what the pixel holds (strict < decides below)
         float w0 = f[9] * fxi + f[10] * fyi + f[11];
         float w1 = f[12] * fxi + f[13] * fyi + f[14];
         float w2 = f[15] * fxi + f[16] * fyi + f[17];
