@@ -168,10 +168,10 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     if (inimg) {
       for (int k = 0; k < total; ++k) {
         const float* f = sf[k];
+        if (f[18] >= (DUAL ? fmaxf(A.z, Bz.z) : A.z)) continue;      // cannot beat what the pixel holds (strict < decides below)
         if (((yp - f[1]) * (f[3] - f[0]) < (xp - f[0]) * (f[4] - f[1])) ||
             ((yp - f[4]) * (f[6] - f[3]) < (xp - f[3]) * (f[7] - f[4])) ||
             ((yp - f[7]) * (f[0] - f[6]) < (xp - f[6]) * (f[1] - f[7]))) continue;
-        if (f[18] >= (DUAL ? fmaxf(A.z, Bz.z) : A.z)) continue;      // cannot beat what the pixel holds (strict < decides below)
         float w0 = f[9] * fxi + f[10] * fyi + f[11];
         float w1 = f[12] * fxi + f[13] * fyi + f[14];
         float w2 = f[15] * fxi + f[16] * fyi + f[17];
