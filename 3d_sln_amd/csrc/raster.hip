@@ -10,8 +10,8 @@
 // set-up records in chunks of 256 (coalesced: one record field per lane), keeps the faces whose pixel
 // bounding box touches the tile by an ORDER-PRESERVING ballot/prefix compaction into LDS (ascending
 // face index == the package's tie rule "lowest index wins"), stages their 18 coefficients in LDS and
-// lets every lane run the edge tests against broadcast LDS reads.  z-min / index / barycentrics live
-// in registers.  The package's 33 passes per scene (1 depth + 32 class masks over the same geometry)
+// lets every lane run the edge tests against broadcast LDS reads (a pixel that already holds something nearer than the
+// face's depth lower bound skips the face).  z-min / index / barycentrics live in registers.  The package's 33 passes per scene (1 depth + 32 class masks over the same geometry)
 // collapse into ONE pass that tracks two z-buffers (depth pass near=0.1, class passes near=ctor value).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
