@@ -463,7 +463,7 @@ constexpr int PMB_DC = 64;
 struct __align__(16) PmbStep { int lo, ofrom, ifrom; float cross; };
 template <typename PIX>
 __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int B, int F, int is,
-                                                                float eps, float* __restrict__ gfaces) {
+                                                                float eps, float* __restrict__ gfaces, const FaceRec* __restrict__ vis) {
   typedef decltype(pix.view(0, 0)) View;
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
   __shared__ PmbStep s_step[PMB_DC];
@@ -494,6 +494,11 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   }
   const int b = (int)bu, fn = (int)fnu;
   const size_t i = (size_t)bu * F + fnu;
+  // A face that owns no pixel of the map contributes nothing: outward scans start from a pixel of the face under the edge, inward
+  // scans count the face's own pixels only.  The fused scene pass marks the owners in its forward (FaceRec::pad_[1]); their
+  // complement - every back-facing face, and the front-facing ones that are hidden or fall between pixel centres - leaves here on
+  // one scalar load instead of loading the face, walking its edge and scanning its interior for nothing.
+  if (vis != nullptr && vis[i].pad_[1] == 0) return;
   const int e = ea >> 1, axis = ea & 1;
   float face[9];
 #pragma unroll
@@ -782,7 +787,7 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
-                     grad_faces);
+                     grad_faces, (const FaceRec*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -842,7 +847,8 @@ __device__ __forceinline__ float class_image_value(float v) { float s = 0.f; s +
 __device__ __forceinline__ float depth_value(float d) { return d > 15.f ? -1.f : d; }
 
 __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val, const float* __restrict__ d_a,
-                                   const int32_t* __restrict__ cls, int F, int is, int NC, SceneStats* __restrict__ st) {
+                                   const int32_t* __restrict__ cls, int F, int is, int NC, SceneStats* __restrict__ st,
+                                   FaceRec* __restrict__ rec) {
   const int b = blockIdx.y;
   const long plane = (long)is * is;
   __shared__ float ssum[64]; __shared__ int scnt[64];
@@ -857,6 +863,7 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
     int f = fi_b[q]; float v = val[3 * q]; float d = d_a[q];
     asm volatile("" : "+v"(f), "+v"(v), "+v"(d));
     if (f < 0) continue;
+    rec[(long)b * F + f].pad_[1] = 1;       // the face owns a pixel of the class pass (raster_prep_kernel cleared the flag): see pixel_map_backward_kernel
     const int c = cls[(long)b * F + f];
     if (c < 0 || c >= NC) continue;
     if (!(class_image_value(v) > 0.1f)) continue;
@@ -1144,7 +1151,7 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
   hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
                      w.dB, F, is, 2, tex_eps, npix, w.val);
   // wall_max starts at -inf surrogate
-  hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st);
+  hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
   hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
   SLN_CHECK_LAUNCH();
@@ -1198,7 +1205,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   if (sd != nullptr && hipStreamWaitEvent(st, sd->mid, 0) != hipSuccess) return SLN_E_STATE;
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
-                     grad_faces);
+                     grad_faces, (const FaceRec*)w.rec);
   if (sd != nullptr) {            // join: whatever follows on `st` sees both chains
     hipError_t r = hipEventRecord(sd->join, sd->stream);
     if (r == hipSuccess) r = hipStreamWaitEvent(st, sd->join, 0);
