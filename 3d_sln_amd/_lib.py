@@ -113,7 +113,7 @@ SIGNATURES = {
     "sln_gconv_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sln_gconv_forward": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(SlnVaeUnit), c_f32p, c_f32p,
                                     C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, c_f32p, c_f32p, C.c_void_p]),
-    "sln_gconv_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "sln_gconv_net_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "sln_gconv_net_set_edges": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "sln_gconv_net_forward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int, C.c_void_p]),
     "sln_gconv_net_backward": (C.c_int, [C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

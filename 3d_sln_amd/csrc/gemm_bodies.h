@@ -31,6 +31,16 @@ __device__ __forceinline__ float4 xform(float4 x1, float4 x2, const float4* cf) 
   return r;
 }
 
+// single-source operands: fmaf(c.y, 0, c.z) == c.z, so this is xform(x1, 0, cf) bit for bit without keeping c.y alive
+__device__ __forceinline__ float4 xform1(float4 x1, const float4* cf) {
+  float4 r;
+  r.x = fmaxf(fmaf(cf[0].x, x1.x, cf[0].z), cf[0].w);
+  r.y = fmaxf(fmaf(cf[1].x, x1.y, cf[1].z), cf[1].w);
+  r.z = fmaxf(fmaf(cf[2].x, x1.z, cf[2].z), cf[2].w);
+  r.w = fmaxf(fmaf(cf[3].x, x1.w, cf[3].z), cf[3].w);
+  return r;
+}
+
 // XCD-aware bijective remap of a linear block id: consecutive logical ids share an XCD (and its L2).
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -514,6 +524,12 @@ inline bool nt_wants_small(const GemmNTArgs& a) {
 // ---------------------------------------------------------------------------------------------
 // TN kernel (wgrad)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float tn_acc_read(const float& v) {   // see the epilogue of gemm_tn_body
+  float r;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r) : "a"(v));
+  return r;
+}
+
 struct ColSel { const float* x1; const float* x2; int ld1, ld2, which; bool valid; };
 
 __device__ __forceinline__ ColSel pick_col(const Operand& op, int col) {
@@ -549,11 +565,23 @@ __device__ __forceinline__ float4 coef_for_col(const Operand& op, int col) {
 // XG: the X operand has row-gathered segments (GraphTripleConv input).  Its row indices then run through their own
 // three-stage register pipeline, one tile ahead of the data loads that use them, so that no load waits on another.
 // G (a gradient) is never gathered.
+//
+// Round 3 layout of the compute half.  The tiles stay ROW-major in LDS, as the rows arrive ([BK rows][64 columns + pad]: one
+// ds_write_b128 per staged float4, no transposing store).  The four wavefronts of a block no longer own a 32 x 32 quarter of the
+// 64 x 64 output tile each (every operand value fetched with its own ds_read_b32: 32 per wave and tile).  Wave (wr, wc) takes
+// the row half wr of a tile (16 rows = 8 MFMA k-steps) and the column half wc of X, and accumulates a 64 x 32 piece of dW in two
+// 32 x 32 accumulators: a lane reads two ADJACENT G columns with one ds_read_b64 - they become output rows 2i and 2i+1, any fixed
+// permutation of dW's rows is as good as another - and one X value (columns stay lane-contiguous for the atomics); hipcc pairs
+// the reads of two k-steps (ds_read2_b64 / ds_read2_b32): 8 LDS instructions per wave and tile instead of 32.  The two row
+// halves meet in LDS once, behind the loop (each wave hands over one accumulator and finishes the other: 16 KB through the tile
+// buffers), so a block issues the same 64 x 64 atomics as before.  (Four accumulators per wave - the whole 64 x 64 tile, rows
+// split four ways - need 6 LDS instructions per tile but 64 AGPRs: 181-196 registers, two workgroups per CU instead of three.)
+// The per-column coefficients of the two operands are loop invariants of a thread (its four columns never change): they sit in
+// registers instead of being read from LDS for every staged float4 (16 ds_read_b128 per tile and thread).
 template <int BM, int BN, int WM, int WN, bool G_X2, bool XG>
 __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, const int by, char* smem) {
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  // row stride = 32 (mod 64) floats: the two k rows a wavefront reads per ds_read (lanes 0-31 / 32-63) then fall into
-  // disjoint bank halves; with +4 they overlapped on 28 banks (2-way conflict on every fragment read)
+  static_assert(BM == 64 && BN == 64 && WM * WN == 4, "64 x 64 tile, 4 waves");
+  // row stride = 32 (mod 64) floats: the two rows a wavefront reads per fragment (lanes 0-31 / 32-63) fall into disjoint bank halves
   constexpr int SA = BM + TN_PAD, SB = BN + TN_PAD;
   constexpr int TPRA = BM / 4, TPRB = BN / 4;         // threads per row
   constexpr int RPA = 256 / TPRA, RPB = 256 / TPRB;   // rows per pass
@@ -568,7 +596,6 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   const int n0 = (bx / tiles_k) * BM, k0 = (bx % tiles_k) * BN;
   const int rbeg = by * a.rows_per_block;
   const int rend = min(a.R, rbeg + a.rows_per_block);
-  const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
   // per-column coefficient tables for this block's column ranges
   for (int c = tid; c < BM; c += 256) coefG[c] = coef_for_col(a.G, n0 + c);
@@ -610,6 +637,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     if (XG) iload(rt_idx, stage);          // indices of the tile this stage will load next
   };
   float4 dbacc = z4;
+  float4 cG[4], cX[4];                     // this thread's coefficients (filled behind the table barrier)
   // rt is NOT clamped here: the rows of a surplus tile (rt > last, the loop runs whole pairs of tiles) lie behind rend and are
   // stored as zeros
   auto lstore = [&](int rt, int buf, auto stage) {
@@ -618,7 +646,9 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     for (int p = 0; p < PA; ++p) {
       const int rl = ra0 + RPA * p;
       const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = xform(g1[S][p], (G_X2 && gs.x2) ? g2[S][p] : z4, coefG + ca);
+      // two-source gradients (BatchNorm backward) keep their coefficients in LDS: with them in registers the dgrad + wgrad kernels
+      // need 172-180 registers and lose the third workgroup per CU
+      float4 t = G_X2 ? xform(g1[S][p], gs.x2 ? g2[S][p] : z4, coefG + ca) : xform1(g1[S][p], cG);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
       *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
@@ -627,19 +657,17 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     for (int p = 0; p < PB; ++p) {
       const int rl = rb0 + RPB * p;
       const bool v = xs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = xform(x1[S][p], z4, coefX + cb);
+      float4 t = xform1(x1[S][p], cX);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = t;
     }
   };
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[2];                           // [ja]: output rows n0 + 2 i + ja, columns k0 + 32 wc + lane % 32
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const int ntiles = (rend - rbeg + BK - 1) / BK;
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
@@ -648,33 +676,33 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   gload(0, min(2, last), S0{});
   gload(min(1, last), min(3, last), S1{});
   __syncthreads();            // coefficient tables visible
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { if (!G_X2) cG[j] = coefG[ca + j]; cX[j] = coefX[cb + j]; }
   lstore(0, 0, S0{});
   gload(min(2, last), min(4, last), S0{});
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
-  // fragments of 4 k-steps (8 rows of the tile) ping-pong between two register sets; set 0 is refilled with the next
-  // tile's first chunk right after the barrier, under the MFMAs of the current tile's last chunk (as in gemm_nt_body)
-  float fa[2][4][TM], fb[2][4][TN];
-  auto rd = [&](int buf, int kk0, auto set) {
+  // fragments of two k-steps (4 rows of the tile) ping-pong between two register sets; set 0 is refilled with the next tile's
+  // first quarter right after the barrier, under the MFMAs of the current tile's last quarter (as in gemm_nt_body)
+  const int wr = wave >> 1, wc = wave & 1;
+  float2 fa[2][2]; float fb[2][2];
+  auto rd = [&](int buf, int quarter, auto set) {
     constexpr int F = decltype(set)::value;
-    const float* as = As + buf * BK * SA + wm0 + lrow + (kk0 + lk) * SA;
-    const float* bs = Bs + buf * BK * SB + wn0 + lrow + (kk0 + lk) * SB;
+    const float* as = As + buf * BK * SA + (16 * wr + 4 * quarter + lk) * SA + 2 * lrow;
+    const float* bs = Bs + buf * BK * SB + (16 * wr + 4 * quarter + lk) * SB + 32 * wc + lrow;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[F][q][i] = as[2 * q * SA + 32 * i];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[F][q][j] = bs[2 * q * SB + 32 * j];
+    for (int q = 0; q < 2; ++q) {
+      fa[F][q] = *reinterpret_cast<const float2*>(as + 2 * q * SA);
+      fb[F][q] = bs[2 * q * SB];
     }
   };
   auto mma = [&](auto set) {
     constexpr int F = decltype(set)::value;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q][i], fb[F][q][j], acc[i][j], 0, 0, 0);
+    for (int q = 0; q < 2; ++q) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q].x, fb[F][q], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][q].y, fb[F][q], acc[1], 0, 0, 0);
+    }
   };
   rd(0, 0, S0{});
   // same schedule as gemm_nt_body: stage the next tile and refill its register stage first, one straight loop over pairs
@@ -683,11 +711,11 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     lstore(rt + 1, buf ^ 1, stage_next);
     gload(min(rt + 3, last), min(rt + 5, last), stage_next);
     __builtin_amdgcn_sched_barrier(0);
-    rd(buf, 8, S1{});
+    rd(buf, 1, S1{});
     mma(S0{});
-    rd(buf, 16, S0{});
+    rd(buf, 2, S0{});
     mma(S1{});
-    rd(buf, 24, S1{});
+    rd(buf, 3, S1{});
     mma(S0{});
     __syncthreads();
     rd(buf ^ 1, 0, S0{});
@@ -695,17 +723,44 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   };
   for (int rt = 0; rt < ntiles; rt += 2) { body(rt, S1{}); body(rt + 1, S0{}); }
 
+  // ---- the two row halves meet: wave (wr, wc) finishes accumulator ja = wr of column half wc ----
+  // Accumulators are read out of the AGPRs at their use (v_accvgpr_read through an "a" constraint): left alone hipcc copies all
+  // of them to VGPRs in front of the epilogue and that copy sets the kernel's register count.
+  __syncthreads();                          // every wave is done with the tile buffers
+  float* red = As;                          // [wave 4][16][64] floats = 16 KB of the tile buffers
+  {
+    float* dst = red + (wave * 16) * 64 + lane;
+    if (wr == 0) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+      for (int r = 0; r < 16; ++r) dst[r * 64] = tn_acc_read(acc[1][r]);
+    } else {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int k = k0 + wn0 + 32 * j + lrow;
+      for (int r = 0; r < 16; ++r) dst[r * 64] = tn_acc_read(acc[0][r]);
+    }
+  }
+  __syncthreads();
+  {
+    const float* src = red + ((wave ^ 2) * 16) * 64 + lane;      // the partner's copy of the accumulator this wave keeps
+    const int k = k0 + 32 * wc + lrow;
+    float* dcol = a.dW + min(k, a.Kin - 1);
+    const bool kv = k < a.Kin;
+    // sum order (row half 0) + (row half 1) whichever wave finishes
+    if (wr == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (n < a.Nout && k < a.Kin) atomicAdd(a.dW + (size_t)n * a.lddw + k, acc[i][j][r]);
+        const float v = tn_acc_read(acc[0][r]) + src[r * 64];
+        const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk);
+        if (kv && n < a.Nout) atomicAdd(dcol + (size_t)n * a.lddw, v);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = src[r * 64] + tn_acc_read(acc[1][r]);
+        const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk) + 1;
+        if (kv && n < a.Nout) atomicAdd(dcol + (size_t)n * a.lddw, v);
       }
     }
+  }
 
   if (a.db != nullptr && (bx % tiles_k) == 0) {
     // threads with equal (tid % TPRA) hold partial sums of the same 4 columns

@@ -87,6 +87,20 @@ __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, cons
   }
 }
 
+// Every wgrad of a backward pass in one grid: block b belongs to problem p with block_begin[p] <= b < block_begin[p + 1]
+// (one vector load + a ballot: the table has at most 64 entries), then runs the TN body on that problem's description in
+// device memory (uniform address: scalar loads).
+template <bool G_X2, bool XG>
+__global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const GemmTNArgs* __restrict__ probs, const TnMultiMeta* __restrict__ meta) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int b = blockIdx.x, lane = threadIdx.x & 63;
+  const int n = meta->nprob;
+  const int beg = lane < n ? meta->block_begin[lane] : 0x7fffffff;
+  const int p = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(b >= beg)) - 1);
+  const int id = b - meta->block_begin[p], gx = meta->gx[p];
+  gemm_tn_body<64, 64, 2, 2, G_X2, XG>(probs[p], id % gx, id / gx, smem);
+}
+
 
 template <int AMODE, int EPI>
 int launch_dual(const GemmNTArgs& a, const GemmTNArgs& b, hipStream_t st) {
@@ -155,6 +169,11 @@ int sln_gemm_init() {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET_TN(true, true) SLN_SET_TN(true, false) SLN_SET_TN(false, true) SLN_SET_TN(false, false)
 #undef SLN_SET_TN
+#define SLN_SET_TNM(X2, XG)                                                                                       \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_multi_kernel<X2, XG>),             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  SLN_SET_TNM(true, true) SLN_SET_TNM(true, false) SLN_SET_TNM(false, true) SLN_SET_TNM(false, false)
+#undef SLN_SET_TNM
 #define SLN_SET_DUAL(AM, EPI)                                                                                     \
   if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dual_kernel<AM, EPI, false>),         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
@@ -224,4 +243,59 @@ int sln_launch_gemm_dual(const GemmNTArgs& a, int epi, const GemmTNArgs& b0, hip
   SLN_DISPATCH(0) SLN_DISPATCH(1) SLN_DISPATCH(2)
 #undef SLN_DISPATCH
   return -1;
+}
+
+int sln_tn_multi_plan(GemmTNArgs* probs, int n, TnMultiMeta* meta, int* blocks, bool* x2, bool* xg, double* flops) {
+  if (n < 1 || n > SLN_TN_MULTI_MAX) return -1;
+  // rows per block: long chunks (tools/gemm_bench.py: a 256-row block spends as long in its prologue, its first-tile latency and
+  // its 64 x 64 atomics as in its 8 tiles - 46 TF at R = 4096 against 79 TF with 1.6 k-row chunks)
+  static const int target = std::getenv("SLN_TN_MULTI_ROWS") ? std::atoi(std::getenv("SLN_TN_MULTI_ROWS")) : 1024;
+  bool any_x2 = false, any_xg = false;
+  double work = 0.0;
+  for (int i = 0; i < n; ++i) {
+    GemmTNArgs& a = probs[i];
+    if (a.R <= 0 || a.Nout <= 0 || a.Kin <= 0 || !tn_supported(a)) return -1;
+    for (int s = 0; s < a.G.nseg; ++s) any_x2 |= a.G.seg[s].x2 != nullptr;
+    any_xg |= tn_gathers(a);
+    const int chunks = sln_cdiv(a.R, target);
+    a.rows_per_block = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
+    work += 2.0 * a.R * a.Nout * a.Kin;
+  }
+  // longest blocks first (stable): the tail of the launch is made of the short ones
+  for (int i = 1; i < n; ++i) {
+    GemmTNArgs t = probs[i];
+    int j = i;
+    while (j > 0 && probs[j - 1].rows_per_block < t.rows_per_block) { probs[j] = probs[j - 1]; --j; }
+    probs[j] = t;
+  }
+  if (any_xg) {        // the index pipeline of the gathering body loads indices unconditionally: every X needs a valid array
+    const int* any = nullptr;
+    for (int i = 0; i < n; ++i) { if (probs[i].X.idx_a) any = probs[i].X.idx_a; else if (probs[i].X.idx_b) any = probs[i].X.idx_b; }
+    for (int i = 0; i < n; ++i) if (!probs[i].X.idx_a && !probs[i].X.idx_b) probs[i].X.idx_a = any;
+  }
+  std::memset(meta, 0, sizeof(*meta));
+  meta->nprob = n;
+  int b = 0;
+  for (int i = 0; i < n; ++i) {
+    meta->block_begin[i] = b;
+    meta->gx[i] = sln_cdiv(probs[i].Nout, 64) * sln_cdiv(probs[i].Kin, 64);
+    b += meta->gx[i] * sln_cdiv(probs[i].R, probs[i].rows_per_block);
+  }
+  for (int i = n; i <= SLN_TN_MULTI_MAX; ++i) meta->block_begin[i] = b;
+  *blocks = b; *x2 = any_x2; *xg = any_xg; *flops = work;
+  return 0;
+}
+
+int sln_launch_gemm_tn_multi(const GemmTNArgs* dev_probs, const TnMultiMeta* dev_meta, int blocks, bool x2, bool xg, double flops,
+                             hipStream_t st) {
+  if (blocks <= 0) return 0;
+  SlnProfScope prof(SLN_FAM_GEMM_TN, flops, st);
+  const size_t smem = tn_smem_bytes(64, 64);
+  if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  if (x2 && xg) hipLaunchKernelGGL((gemm_tn_multi_kernel<true, true>), dim3(blocks), dim3(256), smem, st, dev_probs, dev_meta);
+  else if (x2) hipLaunchKernelGGL((gemm_tn_multi_kernel<true, false>), dim3(blocks), dim3(256), smem, st, dev_probs, dev_meta);
+  else if (xg) hipLaunchKernelGGL((gemm_tn_multi_kernel<false, true>), dim3(blocks), dim3(256), smem, st, dev_probs, dev_meta);
+  else hipLaunchKernelGGL((gemm_tn_multi_kernel<false, false>), dim3(blocks), dim3(256), smem, st, dev_probs, dev_meta);
+  SLN_CHECK_LAUNCH();
+  return 0;
 }

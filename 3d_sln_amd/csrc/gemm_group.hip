@@ -60,6 +60,8 @@ int sln_gemm_group_init() {
 #define SLN_G_FWD(AM, EP) if (!r) r = raise_lds_limit<AM, EP, false, false, false>(); if (!r) r = raise_lds_limit<AM, EP, true, false, false>();
 #define SLN_G_BWD(AM, EP, XGV) if (!r) r = raise_lds_limit<AM, EP, false, XGV, true>();
   SLN_G_FWD(0, EPI_PLAIN) SLN_G_FWD(0, EPI_STATS) SLN_G_FWD(2, EPI_PLAIN) SLN_G_FWD(2, EPI_STATS)
+  // dgrad-only groups (round 3: the wgrads of a pass run in their own launch, sln_launch_gemm_tn_multi)
+  SLN_G_FWD(0, EPI_MASK) SLN_G_FWD(1, EPI_PLAIN) SLN_G_FWD(1, EPI_MASK) SLN_G_FWD(2, EPI_MASK)
   SLN_G_BWD(0, EPI_PLAIN, false) SLN_G_BWD(0, EPI_MASK, false) SLN_G_BWD(1, EPI_PLAIN, false) SLN_G_BWD(1, EPI_MASK, false)
   SLN_G_BWD(2, EPI_PLAIN, false) SLN_G_BWD(2, EPI_MASK, false) SLN_G_BWD(1, EPI_PLAIN, true)
 #undef SLN_G_FWD
@@ -118,6 +120,7 @@ int sln_launch_gemm_group(const GemmNTArgs* nt, const int* epi, int n_nt, const 
   if (amode == AM && e0 == EP && xg == XGV && !multi) return launch_group<AM, EP, false, XGV, true>(g, smem, blocks, st);
   if (n_tn == 0) {
     SLN_GROUP_FWD(0, EPI_PLAIN) SLN_GROUP_FWD(0, EPI_STATS) SLN_GROUP_FWD(2, EPI_PLAIN) SLN_GROUP_FWD(2, EPI_STATS)
+    SLN_GROUP_FWD(0, EPI_MASK) SLN_GROUP_FWD(1, EPI_PLAIN) SLN_GROUP_FWD(1, EPI_MASK) SLN_GROUP_FWD(2, EPI_MASK)
   } else {
     SLN_GROUP_BWD(0, EPI_PLAIN, false) SLN_GROUP_BWD(0, EPI_MASK, false) SLN_GROUP_BWD(1, EPI_PLAIN, false) SLN_GROUP_BWD(1, EPI_MASK, false)
     SLN_GROUP_BWD(2, EPI_PLAIN, false) SLN_GROUP_BWD(2, EPI_MASK, false) SLN_GROUP_BWD(1, EPI_PLAIN, true)

@@ -43,4 +43,16 @@ int sln_launch_gemm_dual(const GemmNTArgs& nt, int epi, const GemmTNArgs& tn, hi
 // up to two independent NT problems + up to two independent TN problems in one launch (gemm_group.hip); returns 1 without
 // launching anything when the problems cannot share a kernel - the caller launches them separately then
 int sln_launch_gemm_group(const GemmNTArgs* nt, const int* epi, int n_nt, const GemmTNArgs* tn, int n_tn, hipStream_t st);
+// ---- every wgrad of a backward pass as ONE launch (round 3) --------------------------------------------------------------
+// A wgrad has no consumer before the optimizer, so the engine no longer pairs it with the next dgrad: it records the problems
+// and launches them together when the pass is over.  The problem table lives in device memory (a hipGraph replays the launch
+// with the same pointers); each block finds its problem from the prefix of block counts.
+enum { SLN_TN_MULTI_MAX = 64 };
+struct TnMultiMeta { int nprob, pad_; int block_begin[SLN_TN_MULTI_MAX + 1]; int gx[SLN_TN_MULTI_MAX]; };
+// host side: fills rows_per_block of every problem (long chunks: the per-block prologue / 64x64 atomics are paid once per
+// ~1 k rows instead of once per 256), orders them longest first and builds the block prefix.  Returns 0, or SLN_E_* when a
+// problem cannot run on the TN body.  `probs` is permuted in place.
+int sln_tn_multi_plan(GemmTNArgs* probs, int n, TnMultiMeta* meta, int* blocks, bool* x2, bool* xg, double* flops);
+int sln_launch_gemm_tn_multi(const GemmTNArgs* dev_probs, const TnMultiMeta* dev_meta, int blocks, bool x2, bool xg, double flops,
+                             hipStream_t st);
 int sln_gemm_init();   // raises dynamic-LDS limits; call once outside any stream capture

@@ -36,9 +36,13 @@ struct BnInst {
 
 struct Layer {              // one GraphTripleConv application
   float *A1 = nullptr, *A2 = nullptr, *M = nullptr, *A3 = nullptr, *A4 = nullptr;
+  // relu-masked gradients w.r.t. the four Linear outputs.  One set PER LAYER since round 3: the wgrads that read them run at the
+  // end of the backward pass (flush_deferred), not next to the dgrad that produced them.
+  float *g1 = nullptr, *g2 = nullptr, *g3 = nullptr, *g4 = nullptr;
   int bn[4] = {-1, -1, -1, -1};
   int u0 = 0;               // unit index of net1.0
-  int D = 0;
+  int D = 0;                // input width of the object / predicate vectors
+  int Do = 0;               // output width (models/graph.py:36-56: output_dim; = D everywhere except a bare GraphTripleConv)
   bool first = false, last = false;
   int net = 0;              // 0 encoder, 1 decoder
 };
@@ -88,7 +92,7 @@ struct SlnVae {
   float *bnA1 = nullptr, *anA1 = nullptr, *boxes_pred = nullptr, *logits = nullptr, *angles_pred = nullptr;
   // backward temporaries
   float *dbp = nullptr, *dlogits = nullptr, *g_bn = nullptr, *g_an = nullptr, *d_bx = nullptr, *d_ax = nullptr;
-  float *g4 = nullptr, *g3 = nullptr, *dM = nullptr, *g2 = nullptr, *g1 = nullptr, *dG[2] = {nullptr, nullptr};
+  float *dM = nullptr, *dG[2] = {nullptr, nullptr};
   float *dX0 = nullptr, *dz = nullptr, *dmu = nullptr, *dlv = nullptr;
   float *g_h2 = nullptr, *g_h1 = nullptr, *d_xb = nullptr, *d_xa = nullptr, *tmp_d = nullptr;
   float *g_h2b = nullptr, *g_h1b = nullptr, *tmp_db = nullptr;     // the angle branch's copies (both branches run grouped)
@@ -125,6 +129,100 @@ struct SlnVae {
   int flush_pending(hipStream_t st) {
     for (const GemmTNArgs& t : pending) { int r = sln_launch_gemm_tn(t, -1, st); if (r) { pending.clear(); return r; } }
     pending.clear();
+    return 0;
+  }
+  // Round 3: deferral.  A wgrad has no consumer before the optimizer, so nothing forces it to run next to the dgrad of the same
+  // Linear.  The problems of a backward pass are recorded and run as ONE launch per pass (two when some gather their X rows)
+  // through sln_launch_gemm_tn_multi: chunks of ~1 k rows instead of 256 (the prologue, the first-tile latency and the 64 x 64
+  // atomics of a block are paid a quarter as often), no launch boundary per wgrad, and the dgrad chain - now alone in its
+  // launches - gets the chip to itself.  SLN_NO_DEFER=1 restores the pairing.
+  // The problem tables live in device memory.  Set 0 belongs to the captured iterations (filled after the capture ends, before
+  // the graph is launched: a capture records, nothing runs), set 1 to eager calls; [which] 0 = decoder pass, 1 = encoder pass;
+  // [k] 0 = plain rows, 1 = gathered X rows.
+  struct TnGroup {
+    GemmTNArgs probs[SLN_TN_MULTI_MAX]; TnMultiMeta meta; int n = 0, blocks = 0; bool x2 = false, xg = false; double flops = 0.0;
+    bool dirty = true; GemmTNArgs* dev_probs = nullptr; TnMultiMeta* dev_meta = nullptr;
+  };
+  enum { TN_SLOTS = 64 };                        // launches per iteration: slots [0, 32) decoder pass, [32, 64) encoder pass
+  bool defer = true, capturing = false, tn_upload_pending = false;
+  bool tn_per_layer = false;                     // flush after every GraphTripleConv instead of once per pass
+  bool tn_side = false, tn_side_busy = false;    // run the wgrad launches on the side stream, next to the dgrad chain
+  int tn_slot_next[2] = {0, 0};
+  std::vector<GemmTNArgs> deferred;
+  TnGroup* tn_groups_store = nullptr;            // [2 sets][TN_SLOTS][2], heap (a TnGroup is 50 KB)
+  TnGroup& tn_group(int set, int slot, int k) { return tn_groups_store[((size_t)set * TN_SLOTS + slot) * 2 + k]; }
+  int upload_group(TnGroup& g) {
+    hipError_t e = hipMemcpy(g.dev_probs, g.probs, sizeof(GemmTNArgs) * (size_t)g.n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(g.dev_meta, &g.meta, sizeof(TnMultiMeta), hipMemcpyHostToDevice);
+    g.dirty = e != hipSuccess;
+    return (int)e;
+  }
+  int upload_pending_tables() {                   // after a capture: everything the captured launches will read
+    for (int w = 0; w < TN_SLOTS; ++w)
+      for (int k = 0; k < 2; ++k) {
+        TnGroup& g = tn_group(0, w, k);
+        if (g.n > 0 && g.dirty) { int r = upload_group(g); if (r) return r; }
+      }
+    tn_upload_pending = false;
+    return 0;
+  }
+  // the wgrad launches may run on the side stream: fork behind the producer of their operands, join before anything reads the
+  // parameter gradients (end of an iteration / of an eager backward call)
+  int join_tn_side(hipStream_t st) {
+    if (!tn_side_busy) return 0;
+    hipEvent_t e = next_event();
+    hipError_t r = hipEventRecord(e, side);
+    if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
+    tn_side_busy = false;
+    return (int)r;
+  }
+  int flush_deferred(int which, hipStream_t st) {
+    if (deferred.empty()) return 0;
+    const int set = capturing ? 0 : 1;
+    if (tn_slot_next[which] >= TN_SLOTS / 2) { deferred.clear(); return SLN_E_UNSUPPORTED; }
+    const int slot = which * (TN_SLOTS / 2) + tn_slot_next[which]++;
+    hipStream_t lst = st;
+    if (tn_side && side) {
+      hipEvent_t e = next_event();
+      hipError_t r = hipEventRecord(e, st);
+      if (r == hipSuccess) r = hipStreamWaitEvent(side, e, 0);
+      if (r != hipSuccess) { deferred.clear(); return (int)r; }
+      lst = side; tn_side_busy = true;
+    }
+    static thread_local TnGroup tmp;
+    for (int k = 0; k < 2; ++k) {
+      tmp.n = 0;
+      for (const GemmTNArgs& t : deferred) {
+        bool gathers = false;
+        for (int s2 = 0; s2 < t.X.nseg; ++s2) gathers |= t.X.seg[s2].which != 0;
+        if ((int)gathers != k) continue;
+        if (tmp.n == SLN_TN_MULTI_MAX) { deferred.clear(); return SLN_E_UNSUPPORTED; }
+        tmp.probs[tmp.n++] = t;
+      }
+      if (tmp.n == 0) continue;
+      int r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
+      if (r) { deferred.clear(); return r; }
+      TnGroup& g = tn_group(set, slot, k);
+      if (g.n != tmp.n || std::memcmp(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n) != 0 ||
+          std::memcmp(&g.meta, &tmp.meta, sizeof(TnMultiMeta)) != 0) {
+        std::memcpy(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n);
+        g.meta = tmp.meta; g.n = tmp.n; g.blocks = tmp.blocks; g.x2 = tmp.x2; g.xg = tmp.xg; g.flops = tmp.flops;
+        g.dirty = true;
+      }
+      if (g.dirty) {
+        if (capturing) tn_upload_pending = true;
+        else {       // eager call with a new problem set (first call, new shape, other BatchNorm mode): rare, blocking
+          hipError_t e = hipStreamSynchronize(st);          // an earlier launch may still read the old table
+          if (e == hipSuccess && side) e = hipStreamSynchronize(side);
+          if (e != hipSuccess) { deferred.clear(); return (int)e; }
+          r = upload_group(g);
+          if (r) { deferred.clear(); return r; }
+        }
+      }
+      r = sln_launch_gemm_tn_multi(g.dev_probs, g.dev_meta, g.blocks, g.x2, g.xg, g.flops, lst);
+      if (r) { deferred.clear(); return r; }
+    }
+    deferred.clear();
     return 0;
   }
   int join_side(hipStream_t st) {
@@ -210,7 +308,7 @@ struct SlnVae {
   }
   Operand layer_output(int gi, bool training) const {
     const Layer& ly = layers[gi];
-    return op1(seg_act(ly.A4, ly.D, 0, ly.D, ly.bn[3], 0, training), O);
+    return op1(seg_act(ly.A4, ly.Do, 0, ly.Do, ly.bn[3], 0, training), O);
   }
 
   // Group mode: between begin_group() and end_group() the Linear launches are recorded instead of issued; end_group()
@@ -283,6 +381,7 @@ struct SlnVae {
     GemmTNArgs a; std::memset(&a, 0, sizeof(a));
     a.G = G; a.X = X; a.dW = u.p.d_weight; a.db = u.p.d_bias; a.lddw = u.in;
     a.R = R; a.Nout = u.out; a.Kin = u.in; a.rows_per_block = 0;
+    if (defer) { deferred.push_back(a); return 0; }
     if (use_dual) { pending.push_back(a); return 0; }
     if (use_side && side) {
       int r = fork_side(st);
@@ -353,7 +452,7 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   X0e = b.take<float>(Om * Dec); P0e = b.take<float>(Tm * Dec);
   X0d = b.take<float>(Om * Ddc); P0d = b.take<float>(Tm * Ddc);
   for (auto& ly : layers) {
-    const size_t D = ly.D;
+    const size_t D = ly.Do;
     ly.A1 = b.take<float>(Tm * H); ly.A2 = b.take<float>(Tm * (2 * H + D)); ly.M = b.take<float>(Om * H);
     ly.A3 = b.take<float>(Om * H); ly.A4 = b.take<float>(Om * D);
   }
@@ -367,8 +466,22 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
   g_bn = b.take<float>(Om * H); g_an = b.take<float>(Om * H);
   d_bx = b.take<float>(Om * (W + n_attr_e)); d_ax = b.take<float>(Om * W);
   const size_t Dm = (size_t)(Dec > Ddc ? Dec : Ddc);      // = 2E for the VAE
-  g4 = b.take<float>(Om * Dm); g3 = b.take<float>(Om * H); dM = b.take<float>(Om * H);
-  g2 = b.take<float>(Tm * (2 * H + Dm)); g1 = b.take<float>(Tm * H);
+  dM = b.take<float>(Om * H);
+  for (auto& ly : layers) {
+    const size_t D = ly.Do;
+    ly.g4 = b.take<float>(Om * D); ly.g3 = b.take<float>(Om * H); ly.g2 = b.take<float>(Tm * (2 * H + D)); ly.g1 = b.take<float>(Tm * H);
+  }
+  for (int set = 0; set < 2; ++set)
+    for (int w = 0; w < TN_SLOTS; ++w)
+      for (int k = 0; k < 2; ++k) {
+        // a per-layer slot holds 4 problems, a per-pass slot all of a pass
+        GemmTNArgs* dp = b.take<GemmTNArgs>(SLN_TN_MULTI_MAX);
+        TnMultiMeta* dm = b.take<TnMultiMeta>(1);
+        if (!b.dry && tn_groups_store) {  // (a dry run works on a COPY of the handle that shares the tables: leave them alone)
+          TnGroup& tg = tn_group(set, w, k);
+          tg.dev_probs = dp; tg.dev_meta = dm; tg.dirty = true; tg.n = 0;
+        }
+      }
   dG[0] = b.take<float>(Tm * 3 * Dm); dG[1] = b.take<float>(Tm * 3 * Dm);
   dX0 = b.take<float>(Om * Dm); dz = b.take<float>(Om * E); dmu = b.take<float>(Om * E); dlv = b.take<float>(Om * E);
   g_h2 = b.take<float>(Om * W); g_h1 = b.take<float>(Om * H); d_xb = b.take<float>(Om * W); d_xa = b.take<float>(Om * W);
@@ -394,13 +507,13 @@ int SlnVae::run_bn_updates(int first, int count, hipStream_t st) {
 // One GraphTripleConv forward (models/graph.py:57-111) as 5 launches.
 int SlnVae::gconv_forward(int gi, bool training, hipStream_t st) {
   Layer& ly = layers[gi];
-  const int D = ly.D;
+  const int Do = ly.Do;
   RET_IF(linear_fwd(layer_input(gi, training), ly.u0 + 0, ly.A1, H, 0, T, ly.bn[0], training, st));
-  RET_IF(linear_fwd(op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, training), T), ly.u0 + 1, ly.A2, 2 * H + D, 0, T, ly.bn[1],
+  RET_IF(linear_fwd(op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, training), T), ly.u0 + 1, ly.A2, 2 * H + Do, 0, T, ly.bn[1],
                     training, st));
-  RET_IF(sln_launch_scatter_avg_fwd(ly.A2, 2 * H + D, H, D, view(ly.bn[1], 0, training), g, O, ly.M, st));
+  RET_IF(sln_launch_scatter_avg_fwd(ly.A2, 2 * H + Do, H, Do, view(ly.bn[1], 0, training), g, O, ly.M, st));
   RET_IF(linear_fwd(op1(seg_ident(ly.M, H, 0, H, 0), O), ly.u0 + 2, ly.A3, H, 0, O, ly.bn[2], training, st));
-  RET_IF(linear_fwd(op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, training), O), ly.u0 + 3, ly.A4, D, 0, O, ly.bn[3], training,
+  RET_IF(linear_fwd(op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, training), O), ly.u0 + 3, ly.A4, Do, 0, O, ly.bn[3], training,
                     st));
   return 0;
 }
@@ -411,9 +524,10 @@ int SlnVae::gconv_forward(int gi, bool training, hipStream_t st) {
 // gathered [obj[s] | pred | obj[o]] input.
 int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int slot, bool tr, hipStream_t st) {
   Layer& ly = layers[gi];
-  const int D = ly.D, C2 = 2 * H + D;
+  const int D = ly.D, Do = ly.Do, C2 = 2 * H + Do;
   // net2.1 : h3 -> A4
-  Operand G4 = op1(seg_bwd(g4, D, ly.A4, D, D, ly.bn[3], tr), O);
+  float *g1 = ly.g1, *g2 = ly.g2, *g3 = ly.g3, *g4 = ly.g4;
+  Operand G4 = op1(seg_bwd(g4, Do, ly.A4, Do, Do, ly.bn[3], tr), O);
   RET_IF(linear_wgrad(G4, op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, tr), O), ly.u0 + 3, O, st));
   RET_IF(linear_dgrad(G4, ly.u0 + 3, g3, H, O, ly.A3, H, ly.bn[2], true, nullptr, 0, tr, st));
   // net2.0 : pooled -> A3
@@ -422,7 +536,7 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   RET_IF(linear_dgrad(G3, ly.u0 + 2, dM, H, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
   // avg-pool backward (a gather) + relu/BN mask of A2
   BnView v2 = view(ly.bn[1], 0, tr);
-  RET_IF(sln_launch_scatter_avg_bwd(dM, dP, lddp, dpcol0, ly.A2, C2, H, D, v2, g, T, g2,
+  RET_IF(sln_launch_scatter_avg_bwd(dM, dP, lddp, dpcol0, ly.A2, C2, H, Do, v2, g, T, g2,
                                     v2.mode != SLN_BN_NONE ? bns[ly.bn[1]].gsums : nullptr, C2, st));
   // net1.1 : h1 -> A2
   Operand G2 = op1(seg_bwd(g2, C2, ly.A2, C2, C2, ly.bn[1], tr), T);
@@ -432,7 +546,8 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   Operand G1 = op1(seg_bwd(g1, H, ly.A1, H, H, ly.bn[0], tr), T);
   RET_IF(linear_wgrad(G1, layer_input(gi, tr), ly.u0 + 0, T, st));
   RET_IF(linear_dgrad(G1, ly.u0 + 0, dG[slot], 3 * D, T, nullptr, 0, -1, false, nullptr, 0, tr, st));
-  RET_IF(join_side(st));      // g4/g3/g2/g1 are rewritten by the next (earlier) layer
+  RET_IF(join_side(st));      // (pairing / side-stream modes: their wgrads are launched before the next layer starts)
+  if (tn_per_layer) RET_IF(flush_deferred(ly.net == 0 ? 1 : 0, st));
   return 0;
 }
 
@@ -515,6 +630,7 @@ int SlnVae::loss(const float* bp, const float* ap, const float* mu_, const float
 int SlnVae::decoder_backward(hipStream_t st) {
   const bool tr = dec_training;
   ev_next = 0;
+  tn_slot_next[0] = 0;
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
   if (dec_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base + enc_stats_doubles, dec_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
@@ -547,7 +663,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
   {
     BnView v = view(ll.bn[3], 0, tr);
-    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, Wh, ll.A4, W, v, O, W, g4, W,
+    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, Wh, ll.A4, W, v, O, W, ll.g4, W,
                                   v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
   }
   // decoder_cat off: z entered behind the gconv net, its gradient is the sum of the two heads' (Sg2ScVAE_model.py:164)
@@ -561,7 +677,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
     if (l > 0) {
       const Layer& pv = layers[gi - 1];
       BnView v = view(pv.bn[3], 0, tr);
-      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, g4, W,
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, pv.g4, W,
                                    v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
     } else {
       BnView none = view(-1, 0, tr);
@@ -580,6 +696,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
     for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, cfg.recurrent ? 0 : 1, st));
   }
+  RET_IF(flush_deferred(0, st));       // every decoder-side wgrad: after this launch the upper half of the flat gradient is final
   return 0;
 }
 
@@ -587,6 +704,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
 int SlnVae::encoder_backward(hipStream_t st) {
   const bool tr = enc_training;
   if (ev_next > 4096) ev_next = 0;
+  tn_slot_next[1] = 0;
   if (enc_stats_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base, enc_stats_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = L - 1, W = 2 * E;
@@ -634,7 +752,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
   RET_IF(join_side(st));
   {
     BnView v = view(ll.bn[3], 0, tr);
-    RET_IF(sln_launch_mask_gstats(d_xb, W, d_xa, W, ll.A4, W, v, O, W, g4, W,
+    RET_IF(sln_launch_mask_gstats(d_xb, W, d_xa, W, ll.A4, W, v, O, W, ll.g4, W,
                                   v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
   }
   for (int l = L - 1; l >= 0; --l) {
@@ -644,7 +762,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
     if (l > 0) {
       const Layer& pv = layers[gi - 1];
       BnView v = view(pv.bn[3], 0, tr);
-      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, g4, W,
+      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, pv.g4, W,
                                    v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
     } else {
       BnView none = view(-1, 0, tr);
@@ -664,6 +782,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
     for (int i = 0; i < n_bn_enc; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, cfg.recurrent ? 0 : 1, st));
   }
+  RET_IF(flush_deferred(1, st));
   return 0;
 }
 
@@ -693,6 +812,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
   }
   bulk_zeroed = false;
   RET_IF(r);
+  RET_IF(join_tn_side(st));            // the parameter gradients are complete behind this point (all-reduce, optimizer)
   if (mode == TRAIN_FULL) {
     RET_IF(sln_launch_adam(t.flat_params, t.flat_grads, t.adam_m, t.adam_v, (long)t.n_flat, scalars, losses + 3, st));
     wt_fresh = false;                  // transposed copies are rebuilt at the start of the next backward
@@ -760,7 +880,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
   for (int net = 0; net < 2; ++net) {
     for (int l = 0; l < h->L; ++l) {
       Layer& ly = h->layers[net * h->L + l];
-      ly.net = net; ly.first = l == 0; ly.last = l == h->L - 1; ly.D = net == 0 ? h->Dec : h->Ddc; ly.u0 = h->unit_of(net, l, 0);
+      ly.net = net; ly.first = l == 0; ly.last = l == h->L - 1; ly.D = net == 0 ? h->Dec : h->Ddc; ly.Do = ly.D; ly.u0 = h->unit_of(net, l, 0);
       const int Cs[4] = {H, 2 * H + ly.D, H, ly.D};
       for (int k = 0; k < 4; ++k) {
         if (!h->units[ly.u0 + k].bn) continue;
@@ -781,6 +901,13 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     const char* ns = std::getenv("SLN_NO_SIDE_STREAM");
     const char* nd = std::getenv("SLN_NO_DUAL");
     h->use_dual = !(nd && nd[0] == '1');
+    const char* nf = std::getenv("SLN_NO_DEFER");
+    h->defer = !(nf && nf[0] == '1');
+    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
+    if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
+    { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
+    { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }
+    if (h->tn_side && !h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
     const char* ng = std::getenv("SLN_NO_GROUP");
     h->use_group = h->use_dual && !(ng && ng[0] == '1');
     h->use_side = !h->use_dual && !(ns && ns[0] == '1');
@@ -795,6 +922,7 @@ void sln_vae_destroy(SlnVae* h) {
   h->drop_graphs();
   for (auto e : h->events) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
+  delete[] h->tn_groups_store;
   delete h;
 }
 
@@ -963,6 +1091,10 @@ int sln_vae_loss(SlnVae* h, const float* boxes_pred, const float* angles_pred, c
   RET_IF(set_kl(h, kl_weight, -1.f, st));
   RET_IF(h->loss(boxes_pred ? boxes_pred : h->boxes_pred, angles_pred ? angles_pred : h->angles_pred,
                  mu ? mu : h->mu, logvar ? logvar : h->logvar, with_grads != 0, st));
+  // the guard slot of the optimizer step (sln_vae_set_grad_guard) follows the loss of THIS path too: only train_iteration wrote
+  // it, so a forward() / loss / backward() / adam_step() sequence kept whatever an earlier data-parallel iteration had left
+  // there - a stale NaN skipped every later update
+  if (with_grads && h->grad_guard) HIP_RET(hipMemcpyAsync(h->grad_guard, h->losses + 3, sizeof(float), hipMemcpyDeviceToDevice, st));
   RET_IF(copy_out(losses_out, h->losses, 4, st));
   return 0;
 }
@@ -970,6 +1102,9 @@ int sln_vae_loss(SlnVae* h, const float* boxes_pred, const float* angles_pred, c
 int sln_vae_decoder_backward(SlnVae* h, const float* d_boxes_pred, const float* d_angles_pred, float* dz, void* stream) {
   if (!h || !h->have_dec) return SLN_E_STATE;
   hipStream_t st = (hipStream_t)stream;
+  // gradients from the caller's own loss (torch autograd): the engine has no loss value to guard the update with - the caller
+  // checks it, as train.py:79-81 does - so the slot must not keep an older iteration's value
+  if ((d_boxes_pred || d_angles_pred) && h->grad_guard) RET_IF(sln_zero_async(h->grad_guard, sizeof(float), st));
   if (d_boxes_pred)
     HIP_RET(hipMemcpy2DAsync(h->dbp, sizeof(float) * h->dbp_ld, d_boxes_pred, sizeof(float) * h->cfg.box_dim,
                              sizeof(float) * h->cfg.box_dim, (size_t)h->O, hipMemcpyDeviceToDevice, st));
@@ -977,6 +1112,7 @@ int sln_vae_decoder_backward(SlnVae* h, const float* d_boxes_pred, const float* 
   if (d_angles_pred) RET_IF(sln_launch_log_softmax_bwd(h->angles_pred, d_angles_pred, h->dlogits, h->O, h->cfg.n_angle, st));
   else RET_IF(sln_zero_async(h->dlogits, sizeof(float) * (size_t)h->O * h->cfg.n_angle, st));
   RET_IF(h->decoder_backward(st));
+  RET_IF(h->join_tn_side(st));
   RET_IF(copy_out(dz, h->dz, (size_t)h->O * h->E, st));
   return 0;
 }
@@ -988,6 +1124,7 @@ int sln_vae_encoder_backward(SlnVae* h, const float* d_mu, const float* d_logvar
   if (d_mu) RET_IF(copy_out(h->dmu, d_mu, n, st)); else RET_IF(sln_zero_async(h->dmu, n * sizeof(float), st));
   if (d_logvar) RET_IF(copy_out(h->dlv, d_logvar, n, st)); else RET_IF(sln_zero_async(h->dlv, n * sizeof(float), st));
   RET_IF(h->encoder_backward(st));
+  RET_IF(h->join_tn_side(st));
   return 0;
 }
 
@@ -998,6 +1135,7 @@ int sln_vae_backward(SlnVae* h, void* stream) {
   RET_IF(sln_launch_latent_bwd(h->mu, h->logvar, h->eps_buf, h->dz, &h->scalars->kl_weight, h->O, h->E, h->cfg.use_ae,
                                h->dmu, h->dlv, st));
   RET_IF(h->encoder_backward(st));
+  RET_IF(h->join_tn_side(st));
   return 0;
 }
 
@@ -1084,10 +1222,13 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
       if (mode != SlnVae::TRAIN_ENCODER_BWD) h->wt_fresh = false;
       hipGraph_t graph = nullptr;
       HIP_RET(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      h->capturing = true;
       const int r = h->train_iteration(h->eps_buf, mode, st);
+      h->capturing = false;
       hipError_t e = hipStreamEndCapture(st, &graph);
       if (r != 0) { if (graph) (void)hipGraphDestroy(graph); return r; }
       if (e != hipSuccess) return (int)e;
+      if (h->tn_upload_pending) RET_IF(h->upload_pending_tables());     // the wgrad problem tables the captured launches read
       e = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0);
       (void)hipGraphDestroy(graph);
       if (e != hipSuccess) { ge = nullptr; return (int)e; }
@@ -1109,8 +1250,9 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
 // VAE around them.  Same handle type; destroy / workspace_bytes / bind are the sln_vae_* ones (SlnVaeTensors carries only
 // units_host: 4 units per module - net1.0, net1.1, net2.0, net2.1 - with weights AND gradient pointers).
 // ---------------------------------------------------------------------------------------------
-int sln_gconv_net_create(int D, int H, int num_layers, int recurrent, int batch_norm, SlnVae** out) {
-  if (!out || D <= 0 || H <= 0 || num_layers < 1 || D % 4 || H % 4) return SLN_E_UNSUPPORTED;
+int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, int batch_norm, SlnVae** out) {
+  if (!out || D <= 0 || H <= 0 || Dout <= 0 || num_layers < 1 || D % 4 || H % 4 || Dout % 4) return SLN_E_UNSUPPORTED;
+  if (Dout != D && num_layers != 1) return SLN_E_UNSUPPORTED;       // a stack feeds its output back in (models/graph.py:121-131)
   SlnVae* h = new (std::nothrow) SlnVae();
   if (!h) return SLN_E_BADARG;
   std::memset(&h->cfg, 0, sizeof(h->cfg));
@@ -1123,14 +1265,14 @@ int sln_gconv_net_create(int D, int H, int num_layers, int recurrent, int batch_
   h->units.resize((size_t)h->nmod * 4);
   for (int m = 0; m < h->nmod; ++m) {
     Unit* u = &h->units[(size_t)m * 4];
-    u[0].out = H; u[0].in = 3 * D; u[1].out = 2 * H + D; u[1].in = H; u[2].out = H; u[2].in = H; u[3].out = D; u[3].in = H;
+    u[0].out = H; u[0].in = 3 * D; u[1].out = 2 * H + Dout; u[1].in = H; u[2].out = H; u[2].in = H; u[3].out = Dout; u[3].in = H;
     for (int k = 0; k < 4; ++k) u[k].bn = batch_norm != 0;
   }
   h->layers.resize(num_layers);
   for (int l = 0; l < num_layers; ++l) {
     Layer& ly = h->layers[l];
-    ly.net = 0; ly.first = l == 0; ly.last = l == num_layers - 1; ly.D = D; ly.u0 = h->unit_of(0, l, 0);
-    const int Cs[4] = {H, 2 * H + D, H, D};
+    ly.net = 0; ly.first = l == 0; ly.last = l == num_layers - 1; ly.D = D; ly.Do = Dout; ly.u0 = h->unit_of(0, l, 0);
+    const int Cs[4] = {H, 2 * H + Dout, H, Dout};
     for (int k = 0; k < 4; ++k) {
       if (!h->units[ly.u0 + k].bn) continue;
       BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;
@@ -1139,6 +1281,15 @@ int sln_gconv_net_create(int D, int H, int num_layers, int recurrent, int batch_
   }
   h->n_bn_enc = (int)h->bns.size();
   h->use_dual = true; h->use_group = false; h->use_side = false;
+  {
+    const char* nf = std::getenv("SLN_NO_DEFER");
+    h->defer = !(nf && nf[0] == '1');
+    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
+    if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
+    { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
+    { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }
+    if (h->tn_side && !h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
+  }
   *out = h;
   return 0;
 }
@@ -1163,7 +1314,7 @@ int sln_gconv_net_set_edges(SlnVae* h, const int64_t* edges, int O, int T, void*
   return 0;
 }
 
-// (new_obj [O,D], new_pred [T,D]) = GraphTripleConvNet(obj_vecs [O,D], pred_vecs [T,D], edges); pre-activations stay in the
+// (new_obj [O,Dout], new_pred [T,Dout]) = GraphTripleConvNet(obj_vecs [O,D], pred_vecs [T,D], edges); pre-activations stay in the
 // workspace for sln_gconv_net_backward.  training: batch statistics + running-statistics update.
 int sln_gconv_net_forward(SlnVae* h, const float* obj_vecs, const float* pred_vecs, float* new_obj, float* new_pred, int training,
                           void* stream) {
@@ -1177,14 +1328,16 @@ int sln_gconv_net_forward(SlnVae* h, const float* obj_vecs, const float* pred_ve
   RET_IF(copy_out(h->P0e, pred_vecs, (size_t)h->T * D, st));
   for (int l = 0; l < L; ++l) RET_IF(h->gconv_forward(l, tr, st));
   const Layer& ll = h->layers[L - 1];
-  RET_IF(sln_launch_bn_relu_apply(ll.A4, D, 0, D, h->O, h->view(ll.bn[3], 0, tr), new_obj, D, st));
-  RET_IF(sln_launch_bn_relu_apply(ll.A2, 2 * H + D, H, D, h->T, h->view(ll.bn[1], H, tr), new_pred, D, st));
+  const int Do = ll.Do;
+  RET_IF(sln_launch_bn_relu_apply(ll.A4, Do, 0, Do, h->O, h->view(ll.bn[3], 0, tr), new_obj, Do, st));
+  RET_IF(sln_launch_bn_relu_apply(ll.A2, 2 * H + Do, H, Do, h->T, h->view(ll.bn[1], H, tr), new_pred, Do, st));
   if (tr) RET_IF(h->run_bn_updates(0, (int)h->bns.size(), st));
   h->enc_training = tr; h->have_enc = true;
   return 0;
 }
 
-// Backward of the last sln_gconv_net_forward: d_obj_vecs [O,D], d_pred_vecs [T,D] (either may be NULL), parameter gradients
+// Backward of the last sln_gconv_net_forward (d_new_obj [O,Dout], d_new_pred [T,Dout]): d_obj_vecs [O,D], d_pred_vecs [T,D]
+// (either may be NULL), parameter gradients
 // accumulated (+=) into the d_* pointers of the bound units.
 int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new_pred, float* d_obj_vecs, float* d_pred_vecs,
                            void* stream) {
@@ -1194,23 +1347,25 @@ int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new
   const int D = h->Dec, L = h->L;
   const bool tr = h->enc_training;
   h->ev_next = 0;
+  h->tn_slot_next[0] = h->tn_slot_next[1] = 0;
   if (h->stats_doubles) RET_IF(sln_zero_async(h->gstats_base, h->stats_doubles * sizeof(double), st));
   h->wt_fresh = false;                      // the caller's optimizer owns the parameters: rebuild W^T every backward
   RET_IF(h->refresh_transposes(st));
   {
     const Layer& ll = h->layers[L - 1];
     BnView v = h->view(ll.bn[3], 0, tr);
-    RET_IF(sln_launch_mask_gstats(d_new_obj, D, nullptr, 0, ll.A4, D, v, h->O, D, h->g4, D,
-                                  v.mode != SLN_BN_NONE ? h->bns[ll.bn[3]].gsums : nullptr, D, st));
+    const int Do = ll.Do;
+    RET_IF(sln_launch_mask_gstats(d_new_obj, Do, nullptr, 0, ll.A4, Do, v, h->O, Do, ll.g4, Do,
+                                  v.mode != SLN_BN_NONE ? h->bns[ll.bn[3]].gsums : nullptr, Do, st));
   }
   for (int l = L - 1; l >= 0; --l) {
     const int slot = l & 1;
     const float* dP = (l == L - 1) ? d_new_pred : h->dG[slot ^ 1];
-    RET_IF(h->gconv_backward(l, dP, l == L - 1 ? D : 3 * D, l == L - 1 ? 0 : D, slot, tr, st));
+    RET_IF(h->gconv_backward(l, dP, l == L - 1 ? h->layers[l].Do : 3 * D, l == L - 1 ? 0 : D, slot, tr, st));
     if (l > 0) {
       const Layer& pv = h->layers[l - 1];
       BnView v = h->view(pv.bn[3], 0, tr);
-      RET_IF(sln_launch_gather_bwd(h->dG[slot], 3 * D, D, h->g, h->O, nullptr, 0, pv.A4, D, v, 1, h->g4, D,
+      RET_IF(sln_launch_gather_bwd(h->dG[slot], 3 * D, D, h->g, h->O, nullptr, 0, pv.A4, D, v, 1, pv.g4, D,
                                    v.mode != SLN_BN_NONE ? h->bns[pv.bn[3]].gsums : nullptr, D, st));
     } else {
       BnView none = h->view(-1, 0, tr);
@@ -1226,13 +1381,15 @@ int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new
     for (auto& b : h->bns) maxc = b.C > maxc ? b.C : maxc;
     RET_IF(sln_launch_bn_param_grads(h->bn_table_dev, (int)h->bns.size(), maxc, h->cfg.recurrent ? 0 : 1, st));
   }
+  RET_IF(h->flush_deferred(1, st));
+  RET_IF(h->join_tn_side(st));
   return 0;
 }
 
 int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream) {
   if (!h || layer < 0 || layer >= (int)h->layers.size() || !dst) return SLN_E_BADARG;
   const Layer& ly = h->layers[layer];
-  const int H = h->H, D = ly.D;
+  const int H = h->H, D = ly.Do;
   const float* src; size_t n;
   switch (what) {
     case 0: src = ly.A1; n = (size_t)h->T * H; break;

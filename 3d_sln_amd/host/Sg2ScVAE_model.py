@@ -220,6 +220,9 @@ class Sg2ScVAEModel(nn.Module):
         self._rng_seed, self._rng_epoch = int(seed) & (2 ** 64 - 1), 0
         if self._eng is not None:
             _lib.check(_lib.lib().sln_vae_seed(self._eng, self._rng_seed, 0, _lib.current_stream_ptr()), "sln_vae_seed")
+            # the live engine now consumes the offsets of epoch 0: an engine re-created later (a larger batch arrives) must start
+            # on the NEXT disjoint range, not replay them
+            self._rng_epoch = 1
 
     def last_eps(self):
         """eps of the last forward / train_step (injected or drawn on the device)."""

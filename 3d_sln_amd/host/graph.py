@@ -65,7 +65,7 @@ class GraphTripleConv(nn.Module):
         self.net2.apply(_init_weights)
 
     def forward(self, obj_vecs, pred_vecs, edges):
-        """(new_obj_vecs [O, Dout], new_pred_vecs [T, Dout]); differentiable when output_dim == input_dim (see _gconv_forward)."""
+        """(new_obj_vecs [O, Dout], new_pred_vecs [T, Dout]); differentiable (see _gconv_forward)."""
         return _gconv_forward([self], 1, obj_vecs, pred_vecs, edges, self.training, owner=self)
 
 
@@ -92,6 +92,7 @@ class _GconvEngine:
     def __init__(self, modules, num_layers, device):
         m0 = modules[0]
         self.D, self.H, self.L, self.modules = m0.input_dim, m0.hidden_dim, num_layers, modules
+        self.Dout = m0.output_dim
         self.recurrent = len(modules) == 1 and num_layers > 1
         pairs = [pr for m in modules for pr in (mlp_linears(m.net1) + mlp_linears(m.net2))]
         self.bn = any(bn is not None for _, bn in pairs)
@@ -100,7 +101,7 @@ class _GconvEngine:
         self.gbuf = {id(p): torch.zeros_like(p) for p in self.params}
         L = _lib.lib()
         h = C.c_void_p()
-        _lib.check(L.sln_gconv_net_create(self.D, self.H, num_layers, int(self.recurrent), int(self.bn), C.byref(h)), "sln_gconv_net_create")
+        _lib.check(L.sln_gconv_net_create(self.D, self.H, self.Dout, num_layers, int(self.recurrent), int(self.bn), C.byref(h)), "sln_gconv_net_create")
         self.h = h
         self.units = (_lib.SlnVaeUnit * len(pairs))()
         for u, (lin, bn) in zip(self.units, pairs):
@@ -137,10 +138,16 @@ class _GconvEngine:
 
 
 class _GconvNetFn(torch.autograd.Function):
-    """(new_obj, new_pred) = net(obj_vecs, pred_vecs, edges) with gradients w.r.t. both inputs and every parameter."""
+    """(new_obj, new_pred) = net(obj_vecs, pred_vecs, edges) with gradients w.r.t. both inputs and every parameter.
+
+    The parameters are INPUTS of the function (``*params``): autograd accumulates their gradients itself, so
+    ``torch.autograd.grad(loss, net.parameters())``, gradient hooks (DDP) and a second backward through a retained graph behave
+    as for any other module.  (Round 2 assigned ``p.grad`` inside backward: ``autograd.grad`` then failed with 'not used in
+    the graph' and asking for the input gradients alone still wrote ``.grad``.)  Double backward is not supported
+    (``once_differentiable``)."""
 
     @staticmethod
-    def forward(ctx, anchor, obj_vecs, pred_vecs, edges, eng, training):
+    def forward(ctx, obj_vecs, pred_vecs, edges, eng, training, *params):
         L = _lib.lib()
         x = obj_vecs.detach().float().contiguous(); p = pred_vecs.detach().float().contiguous()
         e = edges.to(torch.int64).contiguous()
@@ -148,7 +155,7 @@ class _GconvNetFn(torch.autograd.Function):
         eng.ensure(O, T)
         st = _lib.current_stream_ptr()
         _lib.check(L.sln_gconv_net_set_edges(eng.h, _lib.ptr(e), O, T, st), "sln_gconv_net_set_edges")
-        new_obj = torch.empty(O, eng.D, device=x.device); new_pred = torch.empty(T, eng.D, device=x.device)
+        new_obj = torch.empty(O, eng.Dout, device=x.device); new_pred = torch.empty(T, eng.Dout, device=x.device)
         _lib.check(L.sln_gconv_net_forward(eng.h, _lib.ptr(x), _lib.ptr(p), _lib.ptr(new_obj), _lib.ptr(new_pred), int(training), st),
                    "sln_gconv_net_forward")
         eng.generation = getattr(eng, "generation", 0) + 1
@@ -156,39 +163,40 @@ class _GconvNetFn(torch.autograd.Function):
         return new_obj, new_pred
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, d_obj, d_pred):
         eng = ctx.eng
         if ctx.gen != eng.generation:
             raise _lib.SlnError("backward() through a stale forward: another forward ran on this GraphTripleConv(Net) in between")
         O, T = ctx.shapes
         dev = eng.device
-        d_obj = torch.zeros(O, eng.D, device=dev) if d_obj is None else d_obj.float().contiguous()
-        d_pred = torch.zeros(T, eng.D, device=dev) if d_pred is None else d_pred.float().contiguous()
+        d_obj = torch.zeros(O, eng.Dout, device=dev) if d_obj is None else d_obj.float().contiguous()
+        d_pred = torch.zeros(T, eng.Dout, device=dev) if d_pred is None else d_pred.float().contiguous()
         dx = torch.empty(O, eng.D, device=dev); dp = torch.empty(T, eng.D, device=dev)
-        for buf in eng.gbuf.values():
+        for buf in eng.gbuf.values():           # the kernels accumulate (+=) into the engine's own buffers ...
             buf.zero_()
         _lib.check(_lib.lib().sln_gconv_net_backward(eng.h, _lib.ptr(d_obj), _lib.ptr(d_pred), _lib.ptr(dx), _lib.ptr(dp),
                                                      _lib.current_stream_ptr()), "sln_gconv_net_backward")
-        for prm in eng.params:
-            if prm.requires_grad:
-                g = eng.gbuf[id(prm)]
-                prm.grad = g.clone() if prm.grad is None else prm.grad + g
-        return None, dx, dp, None, None, None
+        # ... and autograd receives copies: a retained graph may run this backward again while the first result is still in use
+        need = ctx.needs_input_grad
+        pg = tuple(eng.gbuf[id(prm)].clone() if need[5 + i] else None for i, prm in enumerate(eng.params))
+        return (dx if need[0] else None, dp if need[1] else None, None, None, None) + pg
 
 
 def _gconv_autograd(owner, modules, num_layers, obj_vecs, pred_vecs, edges, training):
     m0 = modules[0]
-    if m0.input_dim != m0.output_dim or m0.input_dim % 4 or m0.hidden_dim % 4:
-        raise NotImplementedError("autograd through a standalone GraphTripleConv needs output_dim == input_dim (what "
-                                  "GraphTripleConvNet builds) and dimensions that are multiples of 4; train other shapes through Sg2ScVAEModel")
+    if m0.input_dim % 4 or m0.hidden_dim % 4 or m0.output_dim % 4:
+        raise NotImplementedError("autograd through a standalone GraphTripleConv needs dimensions that are multiples of 4; "
+                                  "train other shapes through Sg2ScVAEModel")
+    if num_layers > 1 and m0.input_dim != m0.output_dim:
+        raise ValueError("a stack of GraphTripleConv layers needs output_dim == input_dim (models/graph.py:121-131)")
     eng = getattr(owner, "_sln_engine", None)
     key = tuple(p.data_ptr() for m in modules for p in m.parameters())
     if eng is None or eng.key_ptrs != key or eng.device != obj_vecs.device:
         eng = _GconvEngine(modules, num_layers, obj_vecs.device)
         eng.key_ptrs = key
         object.__setattr__(owner, "_sln_engine", eng)
-        object.__setattr__(owner, "_sln_anchor", torch.zeros(1, device=obj_vecs.device, requires_grad=True))
-    return _GconvNetFn.apply(owner._sln_anchor, obj_vecs, pred_vecs, edges, eng, training)
+    return _GconvNetFn.apply(obj_vecs, pred_vecs, edges, eng, training, *eng.params)
 
 
 def _gconv_forward(modules, num_layers, obj_vecs, pred_vecs, edges, training, owner=None):

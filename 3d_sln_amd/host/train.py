@@ -91,20 +91,28 @@ class DataParallelStep:
     (second graph launch, second collective, RCCL's kernel sharing the CUs with the encoder's GEMMs), about what hiding
     half of a 15.5 MB all-reduce can win back - it has to be measured on an 8-GPU node before it becomes the default."""
 
-    def __init__(self, model, world, overlap=None, force=False):
+    def __init__(self, model, world, overlap=None, force=False, weighted=False):
         self.model, self.world = model, world
         self.dp = world > 1 or force                # force: the collective path with a world of one (single-GPU test of it)
         if overlap is None:
             overlap = os.environ.get("SLN_DP_OVERLAP", "0") == "1"
+        # ``weighted``: shards of unequal size (real rooms; the short last batch of an epoch, which may leave ranks WITHOUT any
+        # graph).  The reference's three loss terms are means over the object rows of the whole batch (utils.py:16-27), so the
+        # gradient of the global batch is sum_r O_r g_r / sum_r O_r: every rank scales its bucket by its own row count O_r, the
+        # all-reduce sums, one more one-element all-reduce sums the O_r, and the bucket is divided on the device.  A rank with
+        # an empty shard skips the compute and contributes zeros with weight 0 - it still joins both collectives, so nobody
+        # waits for it forever.  Equal shards (the synthetic generator, the bench) keep the plain average: no extra passes.
+        self.weighted = bool(weighted) and self.dp
         self.split = int(getattr(model, "decoder_grad_offset", 0)) if hasattr(model, "train_step_begin") else 0
-        self.overlap = bool(overlap) and self.dp and 0 < self.split < model.flat_grads.numel()
+        self.overlap = bool(overlap) and self.dp and not self.weighted and 0 < self.split < model.flat_grads.numel()
         # Collective non-finite guard (the reference's 'not backpropping', train.py:79-81, is single-GPU): a model with a
         # ``grad_bucket`` leaves its total loss in the element behind the gradients; the all-reduce averages it with them, and
         # ``adam_step`` skips on EVERY rank when that average is not finite - one NaN rank can neither poison the other replicas
         # through the averaged gradients nor let their step counters drift apart.
         self.guarded = hasattr(model, "grad_bucket")
         # RCCL divides inside the collective; gloo (CPU tests) has no AVG
-        self.avg_in_collective = self.dp and dist.get_backend() == "nccl"
+        self.avg_in_collective = self.dp and dist.get_backend() == "nccl" and not self.weighted
+        self._w = None
 
     def _reduce(self, buf, async_op):
         op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
@@ -116,9 +124,27 @@ class DataParallelStep:
         kw = dict(kl_weight=kl_weight, lr=lr, use_graph=use_graph)
         if eps is not None:
             kw["eps"] = eps
-        args = (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
+        rows = 0 if b is None else int(b["objs"].shape[0])
+        if rows == 0 and not self.weighted:
+            raise ValueError("empty shard: build DataParallelStep(weighted=True) for batches that may leave a rank without graphs")
+        args = None if rows == 0 else (b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"])
         if not self.dp:
             return m.train_step(*args, with_adam=True, **kw)
+        if self.weighted:
+            if self._w is None:
+                self._w = torch.zeros(1, dtype=g.dtype, device=g.device)
+            if rows:
+                losses = m.train_step(*args, with_adam=False, **kw)
+                g.mul_(float(rows))
+            else:
+                losses = torch.zeros(4, dtype=g.dtype, device=g.device)
+                g.zero_()
+            self._w.fill_(float(rows))
+            self._reduce(g, False)
+            self._reduce(self._w, False)
+            g.div_(self._w)                                     # on the device: no host read-back of the total
+            m.adam_step(lr=lr)
+            return losses
         if self.overlap:
             losses = m.train_step_begin(*args, **kw)
             w_dec = self._reduce(g[self.split:], True)          # waits for the first half, runs beside the second
@@ -162,12 +188,13 @@ def kl_weight_at(args, t):
 def train(args, model, batch_fn, rank=0, world=1, log=print, use_graph=True):
     """train.py:56-114.  ``model`` exposes train_step(..., with_adam=False) / adam_step / flat_params / flat_grads and,
     optionally, train_step_begin / train_step_finish / decoder_grad_offset (Sg2ScVAEModel on the GPU; tests plug a CPU
-    stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs."""
+    stand-in).  ``batch_fn(t, lo, hi)`` returns the rank's graphs; a ``batch_fn.ragged = True`` attribute says that shards may
+    differ in size or be empty (it then returns None for an empty shard) and switches the step to the row-weighted average."""
     if world > 1:
         dist.broadcast(model.flat_params, 0)                      # identical replicas
         if hasattr(model, "params_changed"):
             model.params_changed()
-    step = DataParallelStep(model, world)
+    step = DataParallelStep(model, world, weighted=bool(getattr(batch_fn, "ragged", False)))
     if hasattr(model, "validate_inputs"):
         model.validate_inputs = False             # no per-batch host sync inside the loop
     lo, hi = shard_range(args.batch_size, rank, world)
@@ -253,13 +280,16 @@ def main(argv=None):
     def batch_fn(t, lo, hi):
         if dataset is not None:                                  # DataLoader(shuffle=True) + collate (build_dataset_model.py:28-34), on the device
             idx = sampler.batch(t)
-            lo2, hi2 = shard_range(len(idx), rank, world)        # the epoch's last batch may be short (drop_last=False)
+            lo2, hi2 = shard_range(len(idx), rank, world)        # the epoch's last batch may be short (drop_last=False) ...
+            if hi2 == lo2:
+                return None                                      # ... and leave this rank without a room: it contributes weight 0
             _, objs, boxes, triples, angles, attrs, _, _ = dataset.build_batch(idx[lo2:hi2])
             return dict(objs=objs, triples=triples, boxes=boxes, angles=angles, attributes=attrs)
         return synthetic.scene_graph_batch(hi - lo, args.objs_per_graph, args.triples_per_graph, seed=t * 100003 + lo,
                                            box_dim=6 if args.train_3d else 4, device="cuda")
     if sampler is not None:
         batch_fn.epoch = sampler.epoch
+        batch_fn.ragged = True                                   # rooms differ in size: row-weighted gradient average
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         # real rooms differ in size from batch to batch: eager launches (a hipGraph is tied to one (O, T) pair)

@@ -200,11 +200,12 @@ int sln_gconv_forward(int D, int H, int Dout, int num_layers, int n_modules, int
                       int64_t workspace_bytes, float* new_obj, float* new_pred, void* stream);
 
 /* GraphTripleConvNet on its own WITH autograd (models/graph.py:57-143 is differentiable): an engine handle whose units are
- * the modules' four Linears (net1.0, net1.1, net2.0, net2.1 per module; `recurrent` = one shared module), Dout == D.
+ * the modules' four Linears (net1.0, net1.1, net2.0, net2.1 per module; `recurrent` = one shared module).  Dout != D (a bare
+ * GraphTripleConv(input_dim, output_dim), models/graph.py:36-56) needs num_layers == 1.
  * Life cycle: sln_gconv_net_create -> sln_vae_workspace_bytes / sln_vae_bind (SlnVaeTensors: only units_host, with the
  * gradient pointers filled) -> per graph sln_gconv_net_set_edges -> sln_gconv_net_forward -> sln_gconv_net_backward (parameter
  * gradients are accumulated into the units' d_* pointers; input gradients written) -> sln_vae_destroy. */
-int sln_gconv_net_create(int D, int H, int num_layers, int recurrent, int batch_norm, SlnVae** out);
+int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, int batch_norm, SlnVae** out);
 int sln_gconv_net_set_edges(SlnVae* h, const int64_t* edges, int O, int T, void* stream);
 int sln_gconv_net_forward(SlnVae* h, const float* obj_vecs, const float* pred_vecs, float* new_obj, float* new_pred, int training,
                           void* stream);

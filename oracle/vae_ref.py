@@ -216,7 +216,8 @@ def gconv_apply(sd: State, prefix: str, obj: torch.Tensor, pred: torch.Tensor,
     s_idx, o_idx = edges[:, 0], edges[:, 1]
     t_in = torch.cat([obj[s_idx], pred, obj[o_idx]], dim=1)
     t_out = mlp_apply(sd, prefix + ".net1", 2, t_in, norm, training)
-    new_s, new_p, new_o = t_out[:, :H], t_out[:, H:H + D], t_out[:, H + D:2 * H + D]
+    Do = t_out.shape[1] - 2 * H                      # output_dim (graph.py:84-86); = D inside a GraphTripleConvNet
+    new_s, new_p, new_o = t_out[:, :H], t_out[:, H:H + Do], t_out[:, H + Do:2 * H + Do]
     pooled = torch.zeros(O, H, dtype=obj.dtype)
     pooled = pooled.index_add(0, s_idx, new_s)       # scatter_add along rows, s first
     pooled = pooled.index_add(0, o_idx, new_o)       # then o (graph.py:97-98)

@@ -203,3 +203,68 @@ def test_shard_ranges_cover_batch():
     for n, w in ((512, 8), (10, 3), (7, 8), (64, 1)):
         r = [T.shard_range(n, k, w) for k in range(w)]
         assert r[0][0] == 0 and r[-1][1] == n and all(r[i][1] == r[i + 1][0] for i in range(w - 1))
+
+
+def _slice_graphs(full, lo, hi, n_obj=5, n_tri=8):
+    o0, o1, t0, t1 = lo * n_obj, hi * n_obj, lo * n_tri, hi * n_tri
+    tr = full[1][t0:t1].clone(); tr[:, 0] -= o0; tr[:, 2] -= o0
+    return dict(objs=full[0][o0:o1], triples=tr, boxes=full[2][o0:o1], angles=full[3][o0:o1], attributes=full[4][o0:o1])
+
+
+def _worker_ragged(rank, world, port, out_dir):
+    """The short last batch of an epoch (build_dataset_model.py:28-34: drop_last=False): iteration 1 has 3 graphs for 2 ranks
+    (shards of 2 and 1: unequal weights), iteration 2 has ONE graph (rank 1 gets nothing).  No rank may hang or raise, the
+    replicas stay identical, and the averaged gradient is the gradient of the WHOLE batch (row-weighted, not mean of means)."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization="none")
+    model = CpuStandIn(cfg, seed=5)
+    os.environ["SLN_DP_OVERLAP"] = "1"                     # asked for, but the weighted step must not take the two-half route
+    args = T.build_parser().parse_args(["--batch_size", "3", "--num_iterations", "2", "--print_every", "1000"])
+    full = vae_ref.synth_batch(4, 5, 8, seed=11, cfg=cfg)
+    sizes = {1: 3, 2: 1}
+    grads = {}
+
+    def batch_fn(t, lo, hi):
+        if t == 2:
+            grads[1] = model.flat_grads.clone()
+        base = 0 if t == 1 else 3
+        lo2, hi2 = T.shard_range(sizes[t], rank, world)
+        return None if hi2 == lo2 else _slice_graphs(full, base + lo2, base + hi2)
+    batch_fn.ragged = True
+    T.train(args, model, batch_fn, rank, world, log=lambda *_: None)
+    assert model.t == 2
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), model.flat_params.numpy())
+    np.save(os.path.join(out_dir, "g1_%d.npy" % rank), grads[1].numpy())
+    np.save(os.path.join(out_dir, "g2_%d.npy" % rank), model.flat_grads.numpy())
+    dist.destroy_process_group()
+
+
+def test_ragged_last_batch_empty_shard_and_row_weighted_average(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_ragged, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    p0, p1 = np.load(tmp_path / "p0.npy"), np.load(tmp_path / "p1.npy")
+    assert (p0 == p1).all() and np.isfinite(p0).all(), "replicas diverged"
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization="none")
+    full = vae_ref.synth_batch(4, 5, 8, seed=11, cfg=cfg)
+    ref = CpuStandIn(cfg, seed=5)
+    # iteration 1: without BatchNorm the graphs are independent, so the gradient of the 3-graph batch IS the row-weighted mean
+    ref.train_step(**_slice_graphs(full, 0, 3), with_adam=False)
+    whole = ref.flat_grads.numpy().copy()
+    g1 = np.load(tmp_path / "g1_0.npy")
+    assert (g1 == np.load(tmp_path / "g1_1.npy")).all()
+    assert np.abs(g1 - whole).max() <= 1e-5 * np.abs(whole).max() + 1e-8
+    # ... and an unweighted mean of the two shard means would have been visibly different
+    a = CpuStandIn(cfg, seed=5); a.train_step(**_slice_graphs(full, 0, 2), with_adam=False)
+    b = CpuStandIn(cfg, seed=5); b.train_step(**_slice_graphs(full, 2, 3), with_adam=False)
+    naive = 0.5 * (a.flat_grads + b.flat_grads).numpy()
+    assert np.abs(naive - whole).max() > 1e-3 * np.abs(whole).max()
+    # iteration 2: one graph, rank 1 empty - the reduced gradient is rank 0's
+    ref.adam_step(1e-4)
+    ref.train_step(**_slice_graphs(full, 3, 4), with_adam=False)
+    g2 = np.load(tmp_path / "g2_0.npy")
+    assert (g2 == np.load(tmp_path / "g2_1.npy")).all()
+    assert np.abs(g2 - ref.flat_grads.numpy()).max() <= 1e-4 * np.abs(g2).max() + 1e-7

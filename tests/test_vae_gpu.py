@@ -607,9 +607,47 @@ def test_standalone_graph_triple_conv_net(norm, mode, layers):
     ((ho * wo.cuda()).sum() + (hp * wp.cuda()).sum()).backward()
     for k, v in net.named_parameters():
         assert_close(v.grad.cpu().numpy(), 2 * g1[k].cpu().numpy(), "accumulated " + k, rtol=1e-4, atol=1e-6 * float(g1[k].abs().max()) + 1e-9)
-    odd = G.GraphTripleConv(32, output_dim=48, hidden_dim=64).cuda()
-    with pytest.raises(NotImplementedError):
-        odd(x.cuda().requires_grad_(True), p.cuda(), edges.cuda())
+
+
+@pytest.mark.parametrize("norm", ["batch", "none"])
+def test_bare_graph_triple_conv_with_other_output_dim(norm):
+    """models/graph.py:36-56 allows GraphTripleConv(input_dim, output_dim != input_dim) (net1 -> 2H + Dout, net2 -> Dout).
+    Forward and autograd - through torch.autograd.grad with the parameters as targets, which needs them to be inputs of the
+    autograd node - against fp64 CPU autograd through the oracle's gconv_apply."""
+    G = pkg("host.graph")
+    torch.manual_seed(4)
+    conv = G.GraphTripleConv(32, output_dim=48, hidden_dim=64, mlp_normalization=norm)
+    sd = {"g." + k: v.clone() for k, v in conv.state_dict().items()}
+    conv = conv.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    O, T = 90, 170
+    x = torch.randn(O, 32, generator=g); p = torch.randn(T, 32, generator=g)
+    edges = torch.randint(0, O, (T, 2), generator=g)
+    wo = torch.randn(O, 48, generator=g); wp = torch.randn(T, 48, generator=g)
+    keys = [k for k in sd if sd[k].is_floating_point() and "running" not in k]
+    sdr = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_(True)
+    x1 = x.double().requires_grad_(True); p1 = p.double().requires_grad_(True)
+    ro, rp = vae_ref.gconv_apply(sdr, "g", x1, p1, edges, 64, norm, True)
+    assert ro.shape == (O, 48) and rp.shape == (T, 48)
+    ref = torch.autograd.grad((ro * wo.double()).sum() + (rp * wp.double()).sum(), [x1, p1] + [sdr[k] for k in keys])
+    x2 = x.cuda().requires_grad_(True); p2 = p.cuda().requires_grad_(True)
+    ho, hp = conv(x2, p2, edges.cuda())
+    assert_close(ho.detach().cpu().numpy(), ro.detach().numpy(), "new_obj")
+    assert_close(hp.detach().cpu().numpy(), rp.detach().numpy(), "new_pred")
+    named = dict(conv.named_parameters())
+    prm = [named[k[2:]] for k in keys]
+    got = torch.autograd.grad((ho * wo.cuda()).sum() + (hp * wp.cuda()).sum(), [x2, p2] + prm)
+    assert all(q.grad is None for q in prm), "autograd.grad must not write .grad"
+    gs = max(float(r.abs().max()) for r in ref[2:])
+    for name, a, b in zip(["d obj_vecs", "d pred_vecs"] + keys, got, ref):
+        scale = float(b.abs().max()) if name.startswith("d ") else gs
+        assert_close(a.cpu().numpy(), b.numpy(), name, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    with pytest.raises(ValueError):
+        bad = G.GraphTripleConvNet(32, num_layers=2, hidden_dim=64)
+        bad.gconvs[0].output_dim = 48
+        G._gconv_autograd(bad, list(bad.gconvs), 2, x2, p2, edges.cuda(), True)
 
 
 def test_high_degree_room_node_beyond_the_lds_entry_cache():
