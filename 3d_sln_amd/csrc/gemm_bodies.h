@@ -518,7 +518,8 @@ inline size_t nt_small_smem_bytes(int K) {
 
 // under-filled single-segment problems: fewer than this many 64 x 64 tiles (the object-side GEMMs of a 64-graph batch, the heads)
 inline bool nt_wants_small(const GemmNTArgs& a) {
-  return a.A.nseg == 1 && (long)sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64) <= 160 && a.K <= 2048;
+  static const int max_tiles = std::getenv("SLN_NT_SMALL_TILES") ? std::atoi(std::getenv("SLN_NT_SMALL_TILES")) : 160;
+  return a.A.nseg == 1 && (long)sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64) <= max_tiles && a.K <= 2048;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -915,17 +915,21 @@ __device__ __forceinline__ void compose_tables(ComposeTabs& t, const int32_t* __
 
 // One thread per pixel writes all nch channels: the per-pixel inputs are read once (a thread per (pixel, channel) re-read
 // them 70 times), every store instruction of a wavefront covers 64 consecutive pixels of one channel plane.
+// VARIANT (lab switch SLN_COMPOSE_VARIANT, see sln_scene_forward): 0 plain stores; 1 nontemporal stores; 2 the channels dealt to
+// gridDim.z groups of workgroups (each re-reads the per-pixel inputs, 12 bytes against 280 written).
+template <int VARIANT>
 __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
                                                             const float* __restrict__ d_a, const int32_t* __restrict__ cls,
                                                             const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, int chunks) {
   __shared__ ComposeTabs t;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
   compose_tables(t, chan, dch, NC, ndch, st[b]);
   const long plane = (long)is * is;
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int rr = 0; rr < chunks; ++rr) {          // `chunks` consecutive 256-pixel pieces per workgroup (lab: 4 KB per plane and block)
+  const long p = ((long)blockIdx.x * chunks + rr) * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);      // p < is^2 < 2^31: 32-bit division
   const long q = b * plane + p;
@@ -936,16 +940,23 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   const float img = cvalid ? class_image_value(val[3 * q]) : 0.f;
   const float dd = depth_value(d_a[q]);
   float* o = out + ((long)b * nch * is + (is - 1 - y)) * is + x;       // channel stride = plane
-  o[0] = dd;
+  auto put = [&](long off, float v) {
+    if (VARIANT == 1) __builtin_nontemporal_store(v, o + off); else o[off] = v;
+  };
+  // channel range of this workgroup (VARIANT 2: gridDim.z groups; otherwise everything)
+  const int ch0 = VARIANT == 2 ? (int)(((long)nch * blockIdx.z) / gridDim.z) : 0;
+  const int ch1 = VARIANT == 2 ? (int)(((long)nch * (blockIdx.z + 1)) / gridDim.z) : nch;
+  if (ch0 == 0) put(0, dd);
   const int mych = cvalid ? t.chan[c] : -1;
-  for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
+  for (int ch = max(1, ch0); ch <= 40 && ch < min(nch, ch1); ++ch) put((long)ch * plane, (mych == ch - 1) ? img : 0.f);
   const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
   const bool own_ok = img > 0.1f;
-  for (int k = 0; k < ndch; ++k) {
+  for (int k = max(0, ch0 - 41); k < ndch && 41 + k < ch1; ++k) {
     const int owner = t.owner[k];
     float v = 0.f;
     if (owner >= 0) v = (c == owner && own_ok) ? ddq : t.fill[k];
-    o[(long)(41 + k) * plane] = v;
+    put((long)(41 + k) * plane, v);
+  }
   }
 }
 
@@ -1152,8 +1163,20 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
                      w.dB, F, is, 2, tex_eps, npix, w.val);
   // wall_max starts at -inf surrogate
   hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
-  hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
-                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
+  {
+    static const int variant = std::getenv("SLN_COMPOSE_VARIANT") ? std::atoi(std::getenv("SLN_COMPOSE_VARIANT")) : 0;
+    static const int chunks = std::getenv("SLN_COMPOSE_CHUNKS") ? std::atoi(std::getenv("SLN_COMPOSE_CHUNKS")) : 1;
+    const dim3 grid((unsigned)((plane + 256L * chunks - 1) / (256L * chunks)), B, variant >= 2 ? (unsigned)variant : 1u);     // variant >= 2: that many channel groups
+    if (variant == 1)
+      hipLaunchKernelGGL((scene_compose_kernel<1>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
+                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
+    else if (variant >= 2)
+      hipLaunchKernelGGL((scene_compose_kernel<2>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
+                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
+    else
+      hipLaunchKernelGGL((scene_compose_kernel<0>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
+                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
+  }
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -240,6 +240,11 @@ struct SlnVae {
   hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr}; int graph_O[4] = {-1, -1, -1, -1}, graph_T[4] = {-1, -1, -1, -1};
 
   // ------------------------------------------------------------------------------------------
+  // Round 3: bookkeeping launches of the fused iteration merged (train_iteration sets these around its calls; the stand-alone
+  // entry points - sln_vae_encoder / _decoder / _loss / *_backward - keep their own launches):
+  bool it_prologue = false;       // enc_assemble + both predicate gathers (+ the N(0,1) draw) already issued as ONE launch
+  bool it_fused_loss = false;     // log_softmax is taken inside the loss kernel
+  bool it_merge_bn = false;       // ONE running-statistics launch per iteration (after the decoder) and ONE parameter-gradient launch
   bool gconv_only = false;        // a bare GraphTripleConvNet (sln_gconv_net_*): units = the modules' four Linears, one net, no heads
   int unit_of(int net, int l, int k) const { return (gconv_only ? 0 : 8) + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
   int unit_boxnet(int k) const { return 8 + 2 * nmod * 4 + k; }
@@ -558,8 +563,17 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
   ea.obj_emb = t.obj_emb_ec; ea.attr_emb = t.attr_emb_ec; ea.angle_emb = t.angle_emb; ea.wb = t.box_emb_w; ea.bb = t.box_emb_b;
   ea.O = O; ea.n_obj = n_obj_e; ea.n_attr = n_attr_e; ea.n_box = n_box_e; ea.n_angle = n_angle_e; ea.box_dim = cfg.box_dim;
   ea.x0 = X0e;
-  RET_IF(sln_launch_enc_assemble(ea, st));
-  RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_ec, T, Dec, P0e, st));
+  if (it_prologue) {
+    StepPrologue sp; std::memset(&sp, 0, sizeof(sp));
+    sp.eps = draw_eps ? eps_buf : nullptr; sp.n_eps = (long)O * E; sp.scalars = scalars;        // Sg2ScVAE_model.py:182
+    sp.enc = ea; sp.pidx = g.p; sp.T = T;
+    sp.pemb_ec = t.pred_emb_ec; sp.n_ec = Dec; sp.p0e = P0e;
+    sp.pemb_dc = t.pred_emb_dc; sp.n_dc = Ddc; sp.p0d = P0d;
+    RET_IF(sln_launch_step_prologue(sp, st));
+  } else {
+    RET_IF(sln_launch_enc_assemble(ea, st));
+    RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_ec, T, Dec, P0e, st));
+  }
   for (int l = 0; l < L; ++l) RET_IF(gconv_forward(l, training, st));
   const Operand XL = layer_output(L - 1, training);
   const int W = 2 * E;
@@ -581,7 +595,7 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
   RET_IF(linear_fwd(HB, 3, logvar, E, 0, O, -1, training, st));
   RET_IF(linear_fwd(HA, 7, logvar, E, n_box_e, O, -1, training, st));
   RET_IF(end_group(st));
-  if (training) RET_IF(run_bn_updates(0, n_bn_enc, st));
+  if (training && !it_merge_bn) RET_IF(run_bn_updates(0, n_bn_enc, st));
   enc_training = training; have_enc = true;
   return 0;
 }
@@ -595,7 +609,7 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   da.O = O; da.n_obj = n_obj_e; da.n_attr = n_attr_e; da.n_z = E; da.use_ae = cfg.use_ae;
   da.z = z; da.x0 = X0d; da.z_in_x0 = cfg.decoder_cat ? 1 : 0;
   RET_IF(sln_launch_dec_assemble(da, st));
-  RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
+  if (!it_prologue) RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
   for (int l = 0; l < L; ++l) RET_IF(gconv_forward(L + l, training, st));
   // box_net([obj_vecs | attr_vecs]) and angle_net(obj_vecs)  (Sg2ScVAE_model.py:166-171)
   begin_group();
@@ -608,8 +622,11 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   RET_IF(linear_fwd(op1(seg_act(anA1, H, 0, H, bn_head[5], 0, training), O), unit_anglenet(1), logits, cfg.n_angle, 0, O, -1,
                     training, st));
   RET_IF(end_group(st));
-  RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));
-  if (training) RET_IF(run_bn_updates(n_bn_enc, (int)bns.size() - n_bn_enc, st));
+  if (!it_fused_loss) RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));
+  if (training) {
+    if (it_merge_bn) RET_IF(run_bn_updates(0, (int)bns.size(), st));      // encoder's and decoder's tables: one launch, application order
+    else RET_IF(run_bn_updates(n_bn_enc, (int)bns.size() - n_bn_enc, st));
+  }
   dec_training = training; have_dec = true; z_from_latent = (z_ext == nullptr);
   return 0;
 }
@@ -621,6 +638,7 @@ int SlnVae::loss(const float* bp, const float* ap, const float* mu_, const float
   a.mu = mu_; a.logvar = lv_; a.n_z = E; a.use_ae = cfg.use_ae; a.kl_weight = &scalars->kl_weight;
   a.O = O; a.acc = loss_acc; a.losses = losses; a.acc_prezeroed = bulk_zeroed ? 1 : 0;
   a.d_boxes_pred = with_grads ? dbp : nullptr; a.d_logits = with_grads ? dlogits : nullptr; a.ld_dbp = dbp_ld;
+  a.from_logits = (it_fused_loss && ap == angles_pred) ? 1 : 0;
   RET_IF(sln_launch_loss(a, st));
   have_loss_grads = with_grads;
   return 0;
@@ -691,7 +709,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
   db.rows_obj = cfg.num_objs; db.rows_attr = cfg.num_attrs;
   RET_IF(sln_launch_dec_assemble_bwd(db, st));
   const int nb = (int)bns.size() - n_bn_enc;
-  if (nb > 0) {
+  if (nb > 0 && !it_merge_bn) {
     int maxc = 0;
     for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, cfg.recurrent ? 0 : 1, st));
@@ -777,7 +795,11 @@ int SlnVae::encoder_backward(hipStream_t st) {
   eb.d_wb = t.d_box_emb_w; eb.d_bb = t.d_box_emb_b;
   eb.rows_obj = cfg.num_objs; eb.rows_attr = cfg.num_attrs; eb.rows_angle = cfg.n_angle;
   RET_IF(sln_launch_enc_assemble_bwd(eb, st));
-  if (n_bn_enc > 0) {
+  if (it_merge_bn && !bns.empty()) {            // both passes' BatchNorm parameter gradients: one launch
+    int maxc = 0;
+    for (auto& bi : bns) maxc = bi.C > maxc ? bi.C : maxc;
+    RET_IF(sln_launch_bn_param_grads(bn_table_dev, (int)bns.size(), maxc, cfg.recurrent ? 0 : 1, st));
+  } else if (n_bn_enc > 0) {
     int maxc = 0;
     for (int i = 0; i < n_bn_enc; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, cfg.recurrent ? 0 : 1, st));
@@ -795,7 +817,10 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
     HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
     bulk_zeroed = true;
-    if (draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
+    static const bool no_merge = std::getenv("SLN_NO_MERGE") != nullptr;          // A/B switch: the round-2 launch sequence
+    it_prologue = it_fused_loss = !no_merge;
+    it_merge_bn = !no_merge && (mode == TRAIN_BACKWARD || mode == TRAIN_FULL);    // the two-half form hands the decoder's gradients out early
+    if (!it_prologue && draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
     if (!r) r = encoder_forward(step_training, st);
     if (!r) r = decoder_forward(nullptr, eps, step_training, st);
     if (!r) r = loss(boxes_pred, angles_pred, mu, logvar, true, st);
@@ -811,6 +836,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     if (!r) r = encoder_backward(st);
   }
   bulk_zeroed = false;
+  it_prologue = it_fused_loss = it_merge_bn = false;
   RET_IF(r);
   RET_IF(join_tn_side(st));            // the parameter gradients are complete behind this point (all-reduce, optimizer)
   if (mode == TRAIN_FULL) {

@@ -104,6 +104,7 @@ struct LossArgs {
   float* d_boxes_pred; float* d_logits;   // may be nullptr (forward only)
   int ld_dbp;              // row stride of d_boxes_pred (padded to a multiple of 4)
   int acc_prezeroed;       // the caller already cleared acc (one bulk memset per training iteration)
+  int from_logits;         // angles_pred = log_softmax(logits) is computed HERE (the fused iteration: no log_softmax launch)
 };
 // d_logits = d_logprob - softmax * rowsum(d_logprob)   (backward of log_softmax given grad of its output)
 int sln_launch_log_softmax_bwd(const float* logprob, const float* d_logprob, float* d_logits, int O, int n, hipStream_t st);
@@ -133,7 +134,7 @@ struct AdamScalars {
   int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; int skip, pad_;
   // Philox stream of the reparameterisation draw (Sg2ScVAE_model.py:182): key = seed, counter = (element / 4, offset);
   // the draw kernel itself advances `rng_offset`, so a replayed hipGraph takes a fresh draw every iteration
-  unsigned long long rng_seed, rng_offset; unsigned int rng_done, pad2_;
+  unsigned long long rng_seed, rng_offset; unsigned int rng_done, adam_done;      // arrival tickets of the draw / the update
 };
 // total_loss (device, may be NULL): a non-finite value skips the update and the step count (train.py:79-81 'not backpropping')
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
@@ -142,3 +143,14 @@ int sln_launch_adam(float* params, const float* grads, float* m, float* v, long 
 // eps[i] ~ N(0, 1), i < n: Philox-4x32-10 + Box-Muller, 4 values per counter; the last block to finish advances
 // scalars->rng_offset by one (one offset per draw: streams of different iterations never overlap)
 int sln_launch_randn(float* eps, long n, AdamScalars* scalars, hipStream_t st);
+
+// The head of a fused training iteration as ONE launch (round 3; it was four): the N(0,1) draw (eps == NULL: skipped), the
+// encoder's input assembly and BOTH predicate-embedding gathers (the decoder's does not depend on the encoder).
+struct StepPrologue {
+  float* eps; long n_eps; AdamScalars* scalars;
+  EncAssemble enc;
+  const int* pidx; int T;
+  const float* pemb_ec; int n_ec; float* p0e;
+  const float* pemb_dc; int n_dc; float* p0d;
+};
+int sln_launch_step_prologue(const StepPrologue& a, hipStream_t st);

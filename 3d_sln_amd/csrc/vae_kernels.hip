@@ -355,9 +355,9 @@ __global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __rest
 // ----------------------------------------------------------------------------------------------
 // embeddings
 // ----------------------------------------------------------------------------------------------
-__global__ void enc_assemble_kernel(EncAssemble a) {
+__device__ __forceinline__ void enc_assemble_body(const EncAssemble& a, long bid) {
   const int W = a.n_obj + a.n_attr + a.n_box + a.n_angle;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = bid * blockDim.x + threadIdx.x;
   if (idx >= (long)a.O * W) return;
   const int r = (int)(idx / W);
   int c = (int)(idx % W);
@@ -370,6 +370,7 @@ __global__ void enc_assemble_kernel(EncAssemble a) {
   } else { c -= a.n_box; v = a.angle_emb[(size_t)a.angles[r] * a.n_angle + c]; }
   a.x0[idx] = v;
 }
+__global__ void enc_assemble_kernel(EncAssemble a) { enc_assemble_body(a, blockIdx.x); }
 
 __global__ void enc_assemble_bwd_kernel(EncAssembleBwd a) {
   // embedding parts: atomics straight into the (small) tables
@@ -503,12 +504,16 @@ __global__ void embed_bwd_kernel(const IdxT* __restrict__ idx, const float* __re
   atomicAdd(d_emb + (size_t)idx[r] * n + c, d[(size_t)r * ld + col0 + c]);
 }
 
-__global__ void embed_gather_kernel(const int* __restrict__ idx, const float* __restrict__ emb, int rows, int n,
-                                    float* __restrict__ out) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void embed_gather_body(const int* __restrict__ idx, const float* __restrict__ emb, int rows, int n,
+                                                  float* __restrict__ out, long bid) {
+  const long i = bid * blockDim.x + threadIdx.x;
   if (i >= (long)rows * n) return;
   const int r = (int)(i / n), c = (int)(i % n);
   out[i] = emb[(size_t)idx[r] * n + c];
+}
+__global__ void embed_gather_kernel(const int* __restrict__ idx, const float* __restrict__ emb, int rows, int n,
+                                    float* __restrict__ out) {
+  embed_gather_body(idx, emb, rows, n, out, blockIdx.x);
 }
 
 __global__ void i64_to_i32_kernel(const int64_t* __restrict__ src, int* __restrict__ dst, int n) {
@@ -543,6 +548,9 @@ __global__ void log_softmax_kernel(const float* __restrict__ x, float* __restric
 // element-parallel (coalesced) over the three parts of the loss; LOSS_BLOCKS blocks stride over the elements so that the
 // three fp64 accumulators see few same-address atomics
 constexpr int LOSS_BLOCKS = 64;
+// Round 3: ONE launch.  (i) With `from_logits` the row-wise log_softmax (Sg2ScVAE_model.py:171) is taken here, one thread per
+// object row, instead of by a launch of its own in front; (ii) the last block to arrive (ticket in the unused fourth accumulator,
+// cleared with the others) turns the three sums into the four loss values - the single-thread finalize launch is gone.
 __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
   const long stride = (long)gridDim.x * 256;
   const long i0 = (long)blockIdx.x * 256 + threadIdx.x;
@@ -554,12 +562,30 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     l1 += fabsf(diff);
     if (a.d_boxes_pred) a.d_boxes_pred[(size_t)r * a.ld_dbp + k] = diff > 0.f ? gb : (diff < 0.f ? -gb : 0.f);
   }
-  for (long i = i0; i < (long)a.O * a.n_angle; i += stride) {
-    const int r = (int)(i / a.n_angle), k = (int)(i % a.n_angle);
-    const int tgt = (int)a.angles[r];
-    const float lp = a.angles_pred[i];
-    if (k == tgt) nll -= (double)lp;
-    if (a.d_logits) a.d_logits[i] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+  if (a.from_logits) {
+    for (long r = i0; r < a.O; r += stride) {            // same expressions as log_softmax_kernel
+      const float* xr = a.logits + (size_t)r * a.n_angle;
+      float m = xr[0];
+      for (int k = 1; k < a.n_angle; ++k) m = fmaxf(m, xr[k]);
+      float s = 0.f;
+      for (int k = 0; k < a.n_angle; ++k) s += expf(xr[k] - m);
+      const float ls = logf(s) + m;
+      const int tgt = (int)a.angles[r];
+      for (int k = 0; k < a.n_angle; ++k) {
+        const float lp = xr[k] - ls;
+        a.angles_pred[(size_t)r * a.n_angle + k] = lp;
+        if (k == tgt) nll -= (double)lp;
+        if (a.d_logits) a.d_logits[(size_t)r * a.n_angle + k] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+      }
+    }
+  } else {
+    for (long i = i0; i < (long)a.O * a.n_angle; i += stride) {
+      const int r = (int)(i / a.n_angle), k = (int)(i % a.n_angle);
+      const int tgt = (int)a.angles[r];
+      const float lp = a.angles_pred[i];
+      if (k == tgt) nll -= (double)lp;
+      if (a.d_logits) a.d_logits[i] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+    }
   }
   if (!a.use_ae) {
     float s = 0.f;
@@ -578,15 +604,21 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     __syncthreads();
   }
   if (threadIdx.x < 3) atomicAdd(a.acc + threadIdx.x, red[threadIdx.x][0]);
-}
-
-__global__ void loss_finalize_kernel(LossArgs a) {
-  const double O = (double)a.O;
-  const float lb = (float)(a.acc[0] / (O * a.box_dim));
-  const float la = (float)(a.acc[1] / O);
-  float lk = 0.f;
-  if (!a.use_ae) lk = (float)(-0.5 * a.acc[2] / O) * a.kl_weight[0];
-  a.losses[0] = lb; a.losses[1] = la; a.losses[2] = lk; a.losses[3] = lb + la + lk;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int t = atomicAdd(reinterpret_cast<unsigned int*>(a.acc + 3), 1u);
+    if (t == gridDim.x - 1) {                            // every other block's sums are in (their fence precedes their ticket)
+      __threadfence();
+      const double s0 = atomicAdd(a.acc + 0, 0.0), s1 = atomicAdd(a.acc + 1, 0.0), s2 = atomicAdd(a.acc + 2, 0.0);
+      const double O = (double)a.O;
+      const float lb = (float)(s0 / (O * a.box_dim));
+      const float la = (float)(s1 / O);
+      float lk = 0.f;
+      if (!a.use_ae) lk = (float)(-0.5 * s2 / O) * a.kl_weight[0];
+      a.losses[0] = lb; a.losses[1] = la; a.losses[2] = lk; a.losses[3] = lb + la + lk;
+    }
+  }
 }
 
 __global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __restrict__ lv,
@@ -652,27 +684,32 @@ __global__ __launch_bounds__(256) void transpose_table_kernel(const TransposeEnt
   }
 }
 
-__global__ void adam_tick_kernel(AdamScalars* s, const float* __restrict__ total_loss) {
-  // train.py:79-81: a non-finite total loss is reported and the iteration is skipped (no backward, no optimizer step)
-  s->skip = (total_loss != nullptr && !isfinite(total_loss[0])) ? 1 : 0;
-  if (s->skip) return;
-  s->step += 1;
-  s->bc1 = (float)(1.0 - pow((double)s->beta1, (double)s->step));
-  s->bc2 = (float)(1.0 - pow((double)s->beta2, (double)s->step));
-}
-
+// torch.optim.Adam defaults (train.py:15): no weight decay, no amsgrad.  train.py:79-81: a non-finite total loss is reported and
+// the iteration is skipped (no optimizer step, the step count stays).  Round 3: the scalar bookkeeping (step + 1, the two bias
+// corrections, the skip decision) is taken by every block from the OLD scalars instead of by a one-thread launch in front; the last
+// block to finish commits the new step (every other block has read the old one by then: it arrived before).
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, const AdamScalars* __restrict__ sc) {
-  // torch.optim.Adam defaults (train.py:15): no weight decay, no amsgrad
-  if (sc->skip) return;
+                            float* __restrict__ v, long n, AdamScalars* __restrict__ sc, const float* __restrict__ total_loss) {
+  const bool skip = total_loss != nullptr && !isfinite(total_loss[0]);
+  const int64_t step = sc->step + 1;
   const float b1 = sc->beta1, b2 = sc->beta2, eps = sc->eps;
-  const float step_size = sc->lr / sc->bc1, rs2 = 1.0f / sqrtf(sc->bc2);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-    m[i] = mi; v[i] = vi;
-    p[i] -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
+  const float step_size = sc->lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  if (!skip)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const float gi = g[i];
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(&sc->adam_done, 1u);
+    if (done == gridDim.x - 1) {
+      sc->adam_done = 0; sc->skip = skip ? 1 : 0;
+      if (!skip) { sc->step = step; sc->bc1 = bc1; sc->bc2 = bc2; }
+    }
   }
 }
 
@@ -684,9 +721,9 @@ __device__ __forceinline__ void philox_round(unsigned int (&c)[4], unsigned int 
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ eps, long n, AdamScalars* sc) {
+__device__ __forceinline__ void randn_body(float* __restrict__ eps, long n, AdamScalars* sc, long bid, unsigned int nblocks) {
   const unsigned long long seed = sc->rng_seed, off = sc->rng_offset;
-  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  const long q = bid * 256 + threadIdx.x;
   if (4 * q < n) {
     unsigned int c[4] = {(unsigned int)q, (unsigned int)((unsigned long long)q >> 32), (unsigned int)off, (unsigned int)(off >> 32)};
     unsigned int k0 = (unsigned int)seed, k1 = (unsigned int)(seed >> 32);
@@ -710,8 +747,20 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ eps, lon
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int done = atomicAdd(&sc->rng_done, 1u);
-    if (done == gridDim.x - 1) { sc->rng_done = 0; sc->rng_offset = off + 1; }
+    if (done == nblocks - 1) { sc->rng_done = 0; sc->rng_offset = off + 1; }
   }
+}
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ eps, long n, AdamScalars* sc) {
+  randn_body(eps, n, sc, blockIdx.x, gridDim.x);
+}
+
+// blocks [0, b0) draw eps, [b0, b1) assemble the encoder input, [b1, b2) / [b2, ..) gather the two predicate embeddings
+__global__ __launch_bounds__(256) void step_prologue_kernel(StepPrologue a, unsigned int b0, unsigned int b1, unsigned int b2) {
+  const unsigned int b = blockIdx.x;
+  if (b < b0) randn_body(a.eps, a.n_eps, a.scalars, b, b0);
+  else if (b < b1) enc_assemble_body(a.enc, b - b0);
+  else if (b < b2) embed_gather_body(a.pidx, a.pemb_ec, a.T, a.n_ec, a.p0e, b - b1);
+  else embed_gather_body(a.pidx, a.pemb_dc, a.T, a.n_dc, a.p0d, b - b2);
 }
 
 // out[r, c] = relu(bn(x[r, col0 + c]))  (materialise a post-activation, standalone GraphTripleConv API only)
@@ -1039,8 +1088,7 @@ int sln_launch_loss(LossArgs a, hipStream_t st) {
     const int e = sln_zero_async(a.acc, sizeof(double) * 4, st);
     if (e != 0) return e;
   }
-  if (a.O > 0) hipLaunchKernelGGL(loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(1), 0, st, a);
+  hipLaunchKernelGGL(loss_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, a);      // O == 0: every loop is empty, the sums are 0
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1082,12 +1130,10 @@ int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
                     hipStream_t st) {
   SlnProfScope prof(SLN_FAM_OTHER, 28.0 * n, st);
-  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, scalars, total_loss);
-  if (n > 0) {
-    long blocks = (n + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars);
-  }
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars, total_loss);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1096,6 +1142,18 @@ int sln_launch_randn(float* eps, long n, AdamScalars* scalars, hipStream_t st) {
   if (n <= 0) return 0;
   const long q = (n + 3) / 4;
   hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, eps, n, scalars);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_step_prologue(const StepPrologue& a, hipStream_t st) {
+  auto blocks = [](long n) { return (unsigned int)((n + 255) / 256); };
+  const unsigned int nr = a.eps ? blocks((a.n_eps + 3) / 4) : 0;
+  const unsigned int ne = blocks((long)a.enc.O * (a.enc.n_obj + a.enc.n_attr + a.enc.n_box + a.enc.n_angle));
+  const unsigned int n1 = blocks((long)a.T * a.n_ec), n2 = blocks((long)a.T * a.n_dc);
+  const unsigned int tot = nr + ne + n1 + n2;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(tot), dim3(256), 0, st, a, nr, nr + ne, nr + ne + n1);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -523,6 +523,14 @@ class Sg2ScVAEModel(nn.Module):
         _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")
         self._adam_steps += 1
 
+    def fused_adam(self, lr=1e-4):
+        """The one-line swap for train.py:15 - ``optimizer = model.fused_adam(lr=args.learning_rate)`` instead of
+        ``torch.optim.Adam(model.parameters(), lr=...)``: same update rule (default betas / eps, no weight decay), same
+        ``zero_grad()`` / ``step()`` / ``state_dict()`` / ``load_state_dict()`` surface, but ``step()`` is ONE kernel over the flat
+        parameter buffer instead of torch's multi-tensor passes over 230 tensors, and ``zero_grad()`` one fill of the flat gradient
+        buffer (the parameters' ``.grad`` stay views of it)."""
+        return FusedAdam(self, lr)
+
     # -- optimizer state in torch.optim.Adam's own format (train.py:94 saves optimizer.state_dict(), :25 restores it) ---------
     def optim_state_dict(self, lr=1e-4):
         """What ``torch.optim.Adam(model.parameters(), lr).state_dict()`` would hold after the same steps: per-parameter
@@ -580,3 +588,36 @@ class Sg2ScVAEModel(nn.Module):
         if n < 0:
             _lib.check(int(n), "sln_vae_tap")
         return out
+
+
+class FusedAdam:
+    """``torch.optim.Adam(model.parameters(), lr)`` for a ``Sg2ScVAEModel``, on the engine's fused kernel (see ``fused_adam``)."""
+
+    def __init__(self, model, lr=1e-4):
+        self.model = model
+        self.param_groups = [{'params': list(model.parameters()), 'lr': lr, 'betas': (0.9, 0.999), 'eps': 1e-08, 'weight_decay': 0,
+                              'amsgrad': False}]
+
+    def zero_grad(self, set_to_none=False):
+        m = self.model
+        m._alias_grads()                                   # .grad of every parameter is (again) its view of the flat buffer
+        m._gfull.zero_()                                   # gradients + the guard slot: one fill
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        m = self.model
+        if m._eng is None:
+            raise _lib.SlnError("FusedAdam.step() before the first forward / backward of the model")
+        m.adam_step(lr=float(self.param_groups[0]['lr']))
+        return loss
+
+    def state_dict(self):
+        return self.model.optim_state_dict(self.param_groups[0]['lr'])
+
+    def load_state_dict(self, sd):
+        self.model.load_optim_state_dict(sd)
+        self.param_groups[0]['lr'] = sd['param_groups'][0].get('lr', self.param_groups[0]['lr'])

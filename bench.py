@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
     ap.add_argument("--large-batches", type=str, default="256,1024,4096", help="extra VAE points (graphs per step), '' = none")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-call-sequence legs (vae_dropin, render_33pass, spade_50x1)")
+    ap.add_argument("--dropin-steps", type=int, default=40)
     return ap.parse_args()
 
 
@@ -209,6 +211,112 @@ def check_spade(torch, S):
     e = rel_err(out, ref)
     require(e <= 1e-4, "SPADE small generator: image rel err %.2e" % e)
     return {"small_generator_image_rel_err": e}
+
+
+def vae_dropin_leg(args, torch, M, syn, fused_ms):
+    """The literal train.py:70-84 iteration on the aliased classes - what a user gets WITHOUT touching train.py:
+    model(...) -> utils.calculate_model_losses (three .item() syncs, utils.py:139-146) -> losses['total_loss'] = total_loss.item()
+    -> isfinite test -> optimizer.zero_grad() -> total_loss.backward() -> optimizer.step(), eager launches, a new batch per step.
+    Three optimizers: torch.optim.Adam as train.py:15 builds it; the documented one-line swap `optimizer = model.fused_adam(lr)`
+    (same update, one kernel over the flat parameter buffer); and, as the reference point, the fused step of the headline."""
+    import math
+    U = importlib.import_module("3d_sln_amd.host.utils")
+
+    class A:                                            # what calculate_model_losses reads from `args`
+        use_AE = False
+    ring = [syn.scene_graph_batch(args.graphs, args.objs, args.triples, seed=5000 + 7919 * k, device="cuda") for k in range(4)]
+    res = {"workload": "train.py:70-84 unchanged on the aliased model: %d graphs x (%d objects, %d triples), eager, a new batch every step"
+                       % (args.graphs, args.objs, args.triples), "fused_step_ms": round(fused_ms, 4)}
+    for name in ("torch_adam", "fused_adam"):
+        torch.manual_seed(42)
+        model = M.Sg2ScVAEModel(vocab=syn.default_vocab(), batch_size=args.graphs, train_3d=True, decoder_cat=True, embedding_dim=64,
+                                gconv_mode='feedforward', gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0,
+                                layout_noise_dim=32, use_AE=False).cuda().train()
+        model.validate_inputs = False
+        optimizer = torch.optim.Adam(model.parameters(), lr=1e-4) if name == "torch_adam" else model.fused_adam(lr=1e-4)
+        st = torch.cuda.Stream()
+        skipped = 0
+
+        def one(t):
+            b = ring[t % len(ring)]
+            mu, logvar, boxes_pred, angles_pred = model(b["objs"], b["triples"], b["boxes"], b["angles"], b["attributes"], None)
+            total_loss, losses = U.calculate_model_losses(A, model, b["boxes"], boxes_pred, b["angles"], angles_pred, mu=mu, logvar=logvar,
+                                                          KL_weight=0.1)
+            losses['total_loss'] = total_loss.item()
+            if not math.isfinite(losses['total_loss']):
+                return None
+            optimizer.zero_grad()
+            total_loss.backward()
+            optimizer.step()
+            return losses
+        with torch.cuda.stream(st):
+            for t in range(5):
+                one(t)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in range(args.dropin_steps):
+                l = one(t)
+                skipped += l is None
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.dropin_steps
+        res[name] = {"ms_per_step": round(dt * 1e3, 4), "graphs_per_s": round(args.graphs / dt, 1), "ratio_to_fused_step": round(dt * 1e3 / fused_ms, 2),
+                     "steps": args.dropin_steps, "skipped_non_finite": int(skipped), "final_total_loss": None if l is None else round(l['total_loss'], 5)}
+        del model, optimizer
+        torch.cuda.empty_cache()
+    return res
+
+
+def render_33pass_leg(args, torch, fused_ms_per_room):
+    """mesh_render_func's own call pattern (diff_render.py:366,381-398): ONE room, 1 depth pass + 32 class passes through the
+    aliased nr.Renderer, forward + backward - what an unchanged diff_render.py gets.  The Renderer keeps the maps of identical
+    geometry between the passes (host/neural_renderer.py); `rasterising_each_pass` switches that off."""
+    DR = importlib.import_module("3d_sln_amd.host.diff_render")
+    NR = importlib.import_module("3d_sln_amd.host.neural_renderer")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    V, F, ranges, box = syn.synthetic_room(1, n_objects=12, target_faces=args.tris)
+    f = torch.from_numpy(F)[None].cuda(); room = torch.from_numpy(box).cuda()
+    res = {"workload": "one room, %d triangles, 256x256: 1 depth + 32 class passes through nr.Renderer, forward + backward" % int(F.shape[0]),
+           "fused_scene_pass_ms_per_room_in_batch_of_%d" % args.rooms: round(fused_ms_per_room, 4)}
+    keep = NR.Renderer.reuse_rasterisation
+    for key, fn, reuse in (("maps_reused", DR.scene_render_passes, True), ("rasterising_each_pass", DR.scene_render_passes, False),
+                           ("fused_one_room", DR.scene_render, True)):
+        NR.Renderer.reuse_rasterisation = reuse
+
+        def run():
+            v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+            out = fn(v, f, ranges, room)
+            out.sum().backward()
+            return out
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            run()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        res[key] = {"ms_per_render": round(ms, 3), "renders_per_s": round(1e3 / ms, 1)}
+    NR.Renderer.reuse_rasterisation = keep
+    res["ratio_33pass_to_fused_one_room"] = round(res["maps_reused"]["ms_per_render"] / res["fused_one_room"]["ms_per_render"], 1)
+    return res
+
+
+def spade_50x1_leg(args, torch, G, seg, batched_img_per_s):
+    """testing/test_SPADE_shade.py:77-79 unchanged: for each of 50 z vectors, colorization_model(total, z) at batch 1."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    zs = [torch.randn(1, 256, device="cuda", generator=g) for _ in range(50)]
+    total = seg[:1]
+    with torch.no_grad():
+        for z in zs[:3]:
+            G(total, z)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for z in zs:
+            img = G(total, z)
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "50 x colorization_model(total[1,41,256,256], z[1,256]), one call per z", "ms_per_room_of_50": round(dt * 1e3, 2),
+            "images_per_s": round(50 / dt, 1), "ratio_to_batch_path": round((50 / dt) / batched_img_per_s, 3),
+            "finite": bool(torch.isfinite(img).all().item())}
 
 
 # --------------------------------------------------------------------------------------------------------------- legs
@@ -380,6 +488,8 @@ def render_leg(args, lib, torch, rank):
                                       "achieved": round(tr_pm / (us_pm * 1e-6) / 1e9, 1) if (tr_pm and us_pm) else None,
                                       "frac": round(tr_pm / (us_pm * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (tr_pm and us_pm) else None,
                                       "note": "achieved = measured HBM traffic / duration (L2-resident scans: the kernel is latency / occupancy bound)"}}
+    if not args.no_dropin:
+        res["render_33pass"] = render_33pass_leg(args, torch, per_render * 1e3)
     if not args.no_cpu:
         # CPU baseline: the 33-pass restatement (oracle/raster_ref.py + the OpenMP C++ rasterizer) forward + backward on rooms of
         # the same batch, all cores; bounded sample
@@ -557,6 +667,8 @@ def spade_leg(args, lib, torch):
     res["colorize_one_map_50z"] = {"images_per_s": round(nz / dt50, 1), "ms_per_room": round(dt50 * 1e3, 2),
                                    "speedup_vs_per_sample_path": round((nz / dt50) / (B / dt), 2),
                                    "finite": bool(torch.isfinite(o50).all().item())}
+    if not args.no_dropin:
+        res["spade_50x1"] = spade_50x1_leg(args, torch, G, seg, B / dt)
     if not args.no_cpu:
         # CPU baseline: the oracle (PyTorch-CPU restatement = what the reference module computes) on images of the same batch, all cores
         from oracle import spade_ref
@@ -779,8 +891,9 @@ def main():
             out["roofline_edge"] = {"kernel": "edge scatter/gather", "bound": "hbm", "achieved": round(gbs, 1),
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "traffic": None}
 
-    if rank == 0 and solo and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
         # ---- CPU baseline: the oracle (PyTorch-CPU port of the reference path) on the same batch, all host cores ----
+        # (at N > 1 too, with a shorter sample: a SCALE line then carries its own baseline; the other ranks wait at the barrier)
         from oracle import vae_ref
         cfg = vae_ref.VaeConfig()
         sd = vae_ref.init_state(cfg, seed=42)
@@ -800,17 +913,20 @@ def main():
             return (time.perf_counter() - t0) / steps
         ncores = cpu_threads(torch)
         log('CPU baseline: VAE step on %d threads (os.cpu_count() = %s)' % (ncores, os.cpu_count()))
-        cdt = cpu_rate(ncores, args.cpu_steps)
+        cpu_steps = args.cpu_steps if solo else max(3, args.cpu_steps // 4)
+        cdt = cpu_rate(ncores, cpu_steps)
         out["cpu_baseline"] = {"value": round(args.graphs / cdt, 1), "unit": "graphs/s", "cores": ncores,
                                "kind": "port", "sample": "%d train steps of the same batch (%d graphs), oracle/vae_ref.py, "
-                               "torch CPU fp32, %.1f ms/step" % (args.cpu_steps, args.graphs, cdt * 1e3)}
-        if ncores > 16:                            # the small GEMMs of this step stop scaling beyond ~16 threads: report that point too
+                               "torch CPU fp32, %.1f ms/step" % (cpu_steps, args.graphs, cdt * 1e3)}
+        if ncores > 16 and solo:                            # the small GEMMs of this step stop scaling beyond ~16 threads: report that point too
             cdt16 = cpu_rate(16, max(5, args.cpu_steps // 2))
             out["cpu_baseline"]["value_at_16_threads"] = round(args.graphs / cdt16, 1)
 
     if rank == 0 and solo:
         if not args.no_cpu:
             log('c1 leg'); out["c1"] = c1_leg(args, torch, M)
+        if not args.no_dropin:
+            log('drop-in VAE leg'); out["vae_dropin"] = vae_dropin_leg(args, torch, M, syn, ms_per_step)
         sizes = [int(x) for x in args.large_batches.split(",") if x.strip()]
         if sizes:
             log('large-batch leg'); out["vae_large_batch"] = large_batch_leg(args, torch, M, syn, sizes)

@@ -46,3 +46,28 @@ def test_recorded_bench_line_carries_the_contract_keys():
         assert set(("value", "unit", "cores", "kind", "sample")) <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1
     assert d["c1"]["cores"] >= 1 and d["c1"]["cpu_ms_per_iter"] > 0
     assert all(v is not None for v in d["parity"].values()) and d["render"]["parity"]["face_index_pixels_differing"] == 0
+
+
+import pytest       # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_data_parallel_path_end_to_end_on_one_gpu():
+    """bench.py's own launcher -> RCCL -> JSON line, end to end, on the one GPU a test box has: SLN_BENCH_FORCE_DP=1 takes the
+    data-parallel route (graph without Adam, all-reduce of [gradients | guard] over RCCL with a world of one, fused Adam) that
+    the 8-GPU run takes - the only part of that run this box cannot exercise is a second rank."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(SLN_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu",
+                        "--no-render", "--no-spade", "--no-graph-build", "--no-refine", "--no-dropin", "--large-batches=", "--prof-steps", "1"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["config"]["parallelism"] == "dp1"
+    assert d["config"]["collective"] and "all-reduce" in d["config"]["collective"]
+    assert d["config"]["allreduce_us_standalone"] is not None and d["config"]["allreduce_us_standalone"] > 0
+    import math
+    assert math.isfinite(d["config"]["final_total_loss"]) and d["value"] > 0 and "roofline" in d

@@ -181,6 +181,48 @@ def test_reference_loop_with_an_unmodified_torch_optimizer():
         opt.step(); ropt.step()
 
 
+def test_fused_adam_is_torch_adam_in_the_reference_loop():
+    """`optimizer = model.fused_adam(lr)` (the one-line swap for train.py:15) against torch.optim.Adam in the literal train.py:70-84
+    loop: three iterations from the same state and inputs; parameters agree to fp32 rounding, the Adam state round-trips through
+    torch's own state_dict layout, and a stale guard value (left by a data-parallel iteration) does not block the update."""
+    import types
+    U = pkg("host.utils")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    sd = vae_ref.init_state(cfg, seed=11)
+    batch = vae_ref.synth_batch(6, 9, 14, seed=2, cfg=cfg)
+    eps = torch.randn(batch[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(5))
+    dev = _dev(*batch[:5], eps)
+    outs = {}
+    for name in ("torch", "fused"):
+        model = _model(cfg, sd).train()
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3) if name == "torch" else model.fused_adam(lr=1e-3)
+        if name == "fused":
+            model(*dev[:5], None, eps=dev[5])                    # engine exists; poison the guard slot as a NaN rank would
+            model.grad_bucket[-1] = float("nan")
+        for it in range(3):
+            out = model(*dev[:5], None, eps=dev[5])
+            total, _ = U.calculate_model_losses(types.SimpleNamespace(use_AE=False), model, dev[2], out[2], dev[3], out[3], mu=out[0],
+                                                logvar=out[1], KL_weight=0.1)
+            opt.zero_grad(); total.backward(); opt.step()
+        outs[name] = (model.flat_params.clone(), opt.state_dict())
+    pt, pf = outs["torch"][0].cpu().numpy(), outs["fused"][0].cpu().numpy()
+    moved = np.abs(pt - vae_ref_flat(cfg, sd, _model(cfg, sd))).max()
+    assert moved > 1e-3, "the loop did not train"
+    # Adam turns the rounding noise of near-zero gradients into +-lr steps of either sign: bound those, require the bulk to agree
+    d = np.abs(pt - pf)
+    assert d.max() <= 3 * 2.05e-3 and np.mean(d > 1e-5) < 0.05, (d.max(), np.mean(d > 1e-5))
+    st, sf = outs["torch"][1], outs["fused"][1]
+    assert sorted(st["state"].keys()) == sorted(sf["state"].keys())
+    for i in st["state"]:
+        a, b2 = st["state"][i]["exp_avg"].cpu().numpy(), sf["state"][i]["exp_avg"].cpu().numpy()
+        assert_close(b2, a, "exp_avg %d" % i, rtol=1e-3, atol=1e-5 * max(float(np.abs(a).max()), 1e-30) + 1e-9)
+        assert int(float(sf["state"][i]["step"])) == 3
+
+
+def vae_ref_flat(cfg, sd, model):
+    return model.flat_params.detach().cpu().numpy()
+
+
 def test_optimizer_state_survives_a_device_or_dtype_re_flatten():
     """model.float() / .cuda() re-flatten the parameters: the Adam moments and the step count move along (they used to be
     dropped silently: load_optim_state_dict followed by .cuda() lost the state)."""

@@ -3,14 +3,14 @@
 #   tools/step_timeline.sh [out.txt]
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_t; mkdir -p /tmp/prof_t
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o e -- python bench.py --steps 12 --warmup 4 --no-spade --no-render --no-graph-build --no-refine --no-cpu --no-check --large-batches= > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o e -- python bench.py --steps 12 --warmup 4 --no-spade --no-render --no-graph-build --no-refine --no-cpu --no-check --no-dropin --large-batches= > /dev/null 2>&1
 python - "${1:-/dev/stdout}" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/prof_t/**/e_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the N(0,1) draw / first kernel after the adam kernel: split on the Adam kernel
 names = [r["Kernel_Name"] for r in rows]
-ends = [i for i, n in enumerate(names) if "randn_kernel(" in n]   # the N(0,1) draw is the first kernel of an iteration's graph
+XX
 out = open(sys.argv[1], "w")
 if len(ends) < 3:
     print("no step boundary found", file=out); sys.exit(0)
