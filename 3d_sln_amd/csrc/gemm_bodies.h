@@ -343,8 +343,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
             if (EPI == EPI_STATS) { s1 += redd[(w * BN + c) * 2]; s2 += redd[(w * BN + c) * 2 + 1]; }
             else { s1 += (double)red[(w * BN + c) * 2]; s2 += (double)red[(w * BN + c) * 2 + 1]; }
           }
-          atomicAdd(out + n0 + c, s1);
-          atomicAdd(out + a.ocstride + n0 + c, s2);
+          const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;      // order-independent sums (sln_common.h)
+          atomicAdd(out + n0 + c, sln_qd(s1, qs));
+          atomicAdd(out + a.ocstride + n0 + c, sln_qd(s2, qs));
         }
       }
     }
@@ -363,7 +364,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 // four partial accumulators meet in LDS once, and every wave finishes 8 of the 32 rows (bias / mask / statistics / store).
 // Single-segment operands only (the gathered concat input stays with gemm_nt_body).
 template <int AMODE, int EPI>
-__device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const int bid, char* smem) {
+__device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const int bid, char* smem, const bool small_xcd = true) {
   constexpr bool HAS_X2 = AMODE == 1;
   constexpr bool IDENT = AMODE == 2;
   constexpr int LDT = BK + 4;
@@ -375,7 +376,10 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   float* wl = reinterpret_cast<float*>(sred + 4 * TS * 2);  // per wave: A [TS][LDT] | B [TS][LDT]; later its 16 x 64 partial accumulator
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_n = (a.N + TS - 1) / TS;
-  const int m0 = (bid / tiles_n) * TS, n0 = (bid % tiles_n) * TS;
+  // workgroups that share A rows (same m tile, all n tiles) share an XCD and its L2: in plain order the eight XCDs each fetched
+  // every A row (profiles/r03: 34 MB per launch for 7 MB of operands)
+  const int lb = small_xcd ? xcd_remap(bid, (int)gridDim.x) : bid;
+  const int m0 = (lb / tiles_n) * TS, n0 = (lb % tiles_n) * TS;
   float* As = wl + wave * 2 * TS * LDT;
   float* Bs = As + TS * LDT;
 
@@ -505,8 +509,9 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
       double t1 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { t1 += sred[(w * TS + tid) * 2]; t2 += sred[(w * TS + tid) * 2 + 1]; }
-      atomicAdd(out + n0 + tid, t1);
-      atomicAdd(out + a.ocstride + n0 + tid, t2);
+      const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;
+      atomicAdd(out + n0 + tid, sln_qd(t1, qs));
+      atomicAdd(out + a.ocstride + n0 + tid, sln_qd(t2, qs));
     }
   }
 }
@@ -770,12 +775,19 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
       dbacc.x += __shfl_xor(dbacc.x, off, 64); dbacc.y += __shfl_xor(dbacc.y, off, 64);
       dbacc.z += __shfl_xor(dbacc.z, off, 64); dbacc.w += __shfl_xor(dbacc.w, off, 64);
     }
-    if (lane < TPRA && lane == (tid % TPRA)) {
-      const int n = n0 + ca;
-      if (n + 0 < a.Nout) atomicAdd(a.db + n + 0, dbacc.x);
-      if (n + 1 < a.Nout) atomicAdd(a.db + n + 1, dbacc.y);
-      if (n + 2 < a.Nout) atomicAdd(a.db + n + 2, dbacc.z);
-      if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, dbacc.w);
+    // the four wavefronts' sums meet in LDS in a fixed order: ONE add per element and block (four atomics - one per wavefront, in
+    // arrival order - made the bias gradient the last order-dependent sum of a single-chunk wgrad)
+    __syncthreads();                          // the accumulator hand-over above is done with `red`
+    float4* dbs = reinterpret_cast<float4*>(red);            // [4 waves][TPRA]
+    if (lane < TPRA) dbs[wave * TPRA + lane] = dbacc;
+    __syncthreads();
+    if (tid < TPRA) {
+      const float4 p0 = dbs[tid], p1 = dbs[TPRA + tid], p2 = dbs[2 * TPRA + tid], p3 = dbs[3 * TPRA + tid];
+      const int n = n0 + 4 * tid;
+      if (n + 0 < a.Nout) atomicAdd(a.db + n + 0, ((p0.x + p1.x) + p2.x) + p3.x);
+      if (n + 1 < a.Nout) atomicAdd(a.db + n + 1, ((p0.y + p1.y) + p2.y) + p3.y);
+      if (n + 2 < a.Nout) atomicAdd(a.db + n + 2, ((p0.z + p1.z) + p2.z) + p3.z);
+      if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, ((p0.w + p1.w) + p2.w) + p3.w);
     }
   }
 }

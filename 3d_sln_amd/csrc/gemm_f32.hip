@@ -12,6 +12,8 @@
 // LDS tiles are k-major ([BK][rows+pad]); each lane feeds the MFMA with one ds_read_b32 per
 // operand (conflict-free: consecutive lanes -> consecutive rows).  Global->LDS staging goes
 // through registers (transform on the way), double-buffered so one barrier per K tile.
+#include <algorithm>
+#include <vector>
 #include "gemm_bodies.h"
 namespace {
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
@@ -21,9 +23,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
 }
 
 template <int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmNTArgs a) {
+__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_small_body<AMODE, EPI>(a, blockIdx.x, smem);
+  gemm_nt_small_body<AMODE, EPI>(a, blockIdx.x, smem, xcd != 0);
 }
 
 }  // namespace
@@ -36,7 +38,8 @@ int launch_nt_small(const GemmNTArgs& a, hipStream_t st) {
   const int grid = sln_cdiv(a.M, 32) * sln_cdiv(a.N, 32);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
+  static const int xcd = std::getenv("SLN_NT_SMALL_NO_XCD") ? 0 : 1;      // lab switch: plain workgroup order
+  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(256), smem, st, a, xcd);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -87,18 +90,14 @@ __global__ __launch_bounds__(256) void gemm_dual_kernel(const GemmNTArgs a, cons
   }
 }
 
-// Every wgrad of a backward pass in one grid: block b belongs to problem p with block_begin[p] <= b < block_begin[p + 1]
-// (one vector load + a ballot: the table has at most 64 entries), then runs the TN body on that problem's description in
-// device memory (uniform address: scalar loads).
+// Every wgrad of a backward pass in one grid: workgroup b runs entry b of the item table (problem, output tile, row chunk; see
+// TnMultiMeta for the XCD-aware layout) on that problem's description in device memory (uniform address: scalar loads).
 template <bool G_X2, bool XG>
 __global__ __launch_bounds__(256) void gemm_tn_multi_kernel(const GemmTNArgs* __restrict__ probs, const TnMultiMeta* __restrict__ meta) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int b = blockIdx.x, lane = threadIdx.x & 63;
-  const int n = meta->nprob;
-  const int beg = lane < n ? meta->block_begin[lane] : 0x7fffffff;
-  const int p = __builtin_amdgcn_readfirstlane((int)__popcll(__ballot(b >= beg)) - 1);
-  const int id = b - meta->block_begin[p], gx = meta->gx[p];
-  gemm_tn_body<64, 64, 2, 2, G_X2, XG>(probs[p], id % gx, id / gx, smem);
+  const TnMultiItem it = meta->item[blockIdx.x];
+  if (it.prob < 0) return;
+  gemm_tn_body<64, 64, 2, 2, G_X2, XG>(probs[it.prob], it.tile, it.chunk, smem);
 }
 
 
@@ -249,40 +248,71 @@ int sln_tn_multi_plan(GemmTNArgs* probs, int n, TnMultiMeta* meta, int* blocks, 
   if (n < 1 || n > SLN_TN_MULTI_MAX) return -1;
   // rows per block: long chunks (tools/gemm_bench.py: a 256-row block spends as long in its prologue, its first-tile latency and
   // its 64 x 64 atomics as in its 8 tiles - 46 TF at R = 4096 against 79 TF with 1.6 k-row chunks)
-  static const int target = std::getenv("SLN_TN_MULTI_ROWS") ? std::atoi(std::getenv("SLN_TN_MULTI_ROWS")) : 1024;
+  static const int target0 = std::getenv("SLN_TN_MULTI_ROWS") ? std::atoi(std::getenv("SLN_TN_MULTI_ROWS")) : 768;
+  static const bool no_xcd = std::getenv("SLN_TN_NO_XCD") != nullptr;           // lab: plain order, no XCD grouping
   bool any_x2 = false, any_xg = false;
   double work = 0.0;
   for (int i = 0; i < n; ++i) {
-    GemmTNArgs& a = probs[i];
+    const GemmTNArgs& a = probs[i];
     if (a.R <= 0 || a.Nout <= 0 || a.Kin <= 0 || !tn_supported(a)) return -1;
     for (int s = 0; s < a.G.nseg; ++s) any_x2 |= a.G.seg[s].x2 != nullptr;
     any_xg |= tn_gathers(a);
-    const int chunks = sln_cdiv(a.R, target);
-    a.rows_per_block = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
     work += 2.0 * a.R * a.Nout * a.Kin;
   }
-  // longest blocks first (stable): the tail of the launch is made of the short ones
-  for (int i = 1; i < n; ++i) {
-    GemmTNArgs t = probs[i];
-    int j = i;
-    while (j > 0 && probs[j - 1].rows_per_block < t.rows_per_block) { probs[j] = probs[j - 1]; --j; }
-    probs[j] = t;
+  // chunking; the launch must fit the item table (8 XCDs x the longest XCD list): longer chunks for big batches
+  struct Group { int prob, chunk, tiles; long cost; };
+  std::vector<Group> groups;
+  int per_xcd[8];
+  std::vector<int> owner;
+  // deterministic mode: ONE chunk per problem - every dW / db element then receives exactly one add per launch (onto the zeroed
+  // gradient, or onto the previous launch's result in stream order): no sum depends on the arrival order of workgroups
+  for (long target = g_sln_deterministic ? (1L << 30) : (target0 > 0 ? target0 : 1024);; target *= 2) {
+    groups.clear();
+    for (int i = 0; i < n; ++i) {
+      GemmTNArgs& a = probs[i];
+      const int chunks = sln_cdiv(a.R, (int)(target > a.R ? a.R : target));
+      a.rows_per_block = sln_cdiv(sln_cdiv(a.R, chunks), BK) * BK;
+      const int tiles = sln_cdiv(a.Nout, 64) * sln_cdiv(a.Kin, 64), nch = sln_cdiv(a.R, a.rows_per_block);
+      for (int c = 0; c < nch; ++c) {
+        const int rows = (c + 1) * a.rows_per_block <= a.R ? a.rows_per_block : a.R - c * a.rows_per_block;
+        groups.push_back(Group{i, c, tiles, (long)tiles * rows});
+      }
+    }
+    // longest processing time first: sort the groups by cost (stable), give each to the XCD with the least work so far
+    std::stable_sort(groups.begin(), groups.end(), [](const Group& x, const Group& y) { return x.cost > y.cost; });
+    long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int x = 0; x < 8; ++x) per_xcd[x] = 0;
+    owner.assign(groups.size(), 0);
+    for (size_t g = 0; g < groups.size(); ++g) {
+      int best = 0;
+      if (no_xcd) best = (int)(g % 8);
+      else for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      owner[g] = best; load[best] += groups[g].cost; per_xcd[best] += groups[g].tiles;
+    }
+    int mx = 0;
+    for (int x = 0; x < 8; ++x) mx = per_xcd[x] > mx ? per_xcd[x] : mx;
+    if (8 * mx <= SLN_TN_MULTI_ITEMS) break;
+    if (target > (1L << 30)) return -1;
   }
   if (any_xg) {        // the index pipeline of the gathering body loads indices unconditionally: every X needs a valid array
     const int* any = nullptr;
     for (int i = 0; i < n; ++i) { if (probs[i].X.idx_a) any = probs[i].X.idx_a; else if (probs[i].X.idx_b) any = probs[i].X.idx_b; }
     for (int i = 0; i < n; ++i) if (!probs[i].X.idx_a && !probs[i].X.idx_b) probs[i].X.idx_a = any;
   }
+  int mx = 0;
+  for (int x = 0; x < 8; ++x) mx = per_xcd[x] > mx ? per_xcd[x] : mx;
   std::memset(meta, 0, sizeof(*meta));
-  meta->nprob = n;
-  int b = 0;
-  for (int i = 0; i < n; ++i) {
-    meta->block_begin[i] = b;
-    meta->gx[i] = sln_cdiv(probs[i].Nout, 64) * sln_cdiv(probs[i].Kin, 64);
-    b += meta->gx[i] * sln_cdiv(probs[i].R, probs[i].rows_per_block);
+  meta->nprob = n; meta->nblocks = 8 * mx;
+  for (int b = 0; b < 8 * mx; ++b) meta->item[b].prob = -1;
+  int fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (size_t g = 0; g < groups.size(); ++g) {          // cost order: an XCD starts with its longest groups
+    const int x = owner[g];
+    for (int t = 0; t < groups[g].tiles; ++t) {
+      TnMultiItem& it = meta->item[8 * (fill[x]++) + x];  // the j-th workgroup of XCD x is workgroup 8 j + x of the grid
+      it.prob = groups[g].prob; it.tile = t; it.chunk = groups[g].chunk;
+    }
   }
-  for (int i = n; i <= SLN_TN_MULTI_MAX; ++i) meta->block_begin[i] = b;
-  *blocks = b; *x2 = any_x2; *xg = any_xg; *flops = work;
+  *blocks = 8 * mx; *x2 = any_x2; *xg = any_xg; *flops = work;
   return 0;
 }
 

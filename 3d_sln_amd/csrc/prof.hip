@@ -1,9 +1,11 @@
 // HIP-event profiler behind sln_prof_enable / sln_prof_read (include/sln_hip.h).
+#include <cstdlib>
 #include <vector>
 #include "../../include/sln_hip.h"
 #include "sln_prof.h"
 
 bool g_sln_prof_on = false;
+int g_sln_deterministic = [] { const char* v = std::getenv("SLN_DETERMINISTIC"); return (v && v[0] == '1') ? 1 : 0; }();
 
 namespace {
 struct Rec { int family; double work; hipEvent_t a, b; };
@@ -26,6 +28,8 @@ void sln_prof_end(hipStream_t st) {
   if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().b, st);
 }
 
+extern "C" int sln_set_deterministic(int on) { g_sln_deterministic = on != 0; return 0; }
+extern "C" int sln_get_deterministic(void) { return g_sln_deterministic; }
 extern "C" int sln_prof_enable(int enable) {
   g_sln_prof_on = enable != 0;
   return 0;

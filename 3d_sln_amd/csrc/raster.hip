@@ -680,6 +680,38 @@ __global__ void project_faces_bwd_kernel(const float* __restrict__ verts, const 
   atomicAdd(g + 2, gx * c.R[2] + gy * c.R[5] + gzc * c.R[8]);
 }
 
+// Deterministic form (SLN_DETERMINISTIC): one thread per vertex walks every face corner of its image in order and adds the
+// contributions of the corners that reference it - the scatter above adds them with float atomics in arrival order.  O(V F) loads
+// (served by L2: the corner list of an image is a few hundred KB) instead of O(F) atomics.
+__global__ void project_faces_bwd_det_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, const float* __restrict__ K,
+                                             const float* __restrict__ R, const float* __restrict__ t, int V, int F, float os, float eps,
+                                             const float* __restrict__ gout, float* __restrict__ gverts) {
+  const int b = blockIdx.y, vi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vi >= V) return;
+  const float* p = verts + ((long)b * V + vi) * 3;
+  const Cam c = load_cam(K, R, t, b);
+  const float x = p[0] * c.R[0] + p[1] * c.R[1] + p[2] * c.R[2] + c.t[0];
+  const float y = p[0] * c.R[3] + p[1] * c.R[4] + p[2] * c.R[5] + c.t[1];
+  const float z = p[0] * c.R[6] + p[1] * c.R[7] + p[2] * c.R[8] + c.t[2];
+  const float iz = 1.f / (z + eps), s = 2.f / os;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  const long base = (long)b * F * 3;
+  for (long j = 0; j < 3L * F; ++j) {
+    if (faces[base + j] != vi) continue;
+    const float gu = gout[3 * (base + j)], gv = gout[3 * (base + j) + 1], gz = gout[3 * (base + j) + 2];
+    if (gu == 0.f && gv == 0.f && gz == 0.f) continue;
+    const float gxh = s * (gu * c.K[0] - gv * c.K[3]);
+    const float gyh = s * (gu * c.K[1] - gv * c.K[4]);
+    const float gx = gxh * iz, gy = gyh * iz;
+    const float gzc = gz - (gxh * x + gyh * y) * iz * iz;
+    a0 += gx * c.R[0] + gy * c.R[3] + gzc * c.R[6];
+    a1 += gx * c.R[1] + gy * c.R[4] + gzc * c.R[7];
+    a2 += gx * c.R[2] + gy * c.R[5] + gzc * c.R[8];
+  }
+  float* g = gverts + ((long)b * V + vi) * 3;
+  g[0] = a0; g[1] = a1; g[2] = a2;
+}
+
 }  // namespace
 
 // ====================================================================================================
@@ -727,6 +759,10 @@ int sln_project_faces_backward(const float* vertices, const int32_t* faces, cons
   if (e != 0) return e;
   const long n = (long)B * F * 3;
   if (n == 0) return 0;
+  if (g_sln_deterministic)
+    hipLaunchKernelGGL(project_faces_bwd_det_kernel, dim3(sln_cdiv(V, 64), B), dim3(64), 0, st, vertices, faces, K, R, t, V, F, orig_size, eps,
+                       grad_faces_xyz, grad_vertices);
+  else
   hipLaunchKernelGGL(project_faces_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vertices, faces, K, R, t, V, F, n, orig_size,
                      eps, grad_faces_xyz, grad_vertices);
   SLN_CHECK_LAUNCH();
@@ -770,7 +806,8 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 28.0 * npix, st);
   (void)npix;
   if ((long)B * F > 0)
-    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), small_batch_split((long)B * F, 8)), dim3(64), 0, st, faces,
+    // (deterministic mode: one wavefront per face - a single add per value onto the caller's zeros)
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), g_sln_deterministic ? 1 : small_batch_split((long)B * F, 8)), dim3(64), 0, st, faces,
                        face_index, weight, depth, grad_depth, F, image_size, grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -786,7 +823,9 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_RASTER_BWD, 8.0 * channels * B * image_size * image_size + 72.0 * n, st);
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
+  // (deterministic mode: no scan split - every gradient value then receives exactly two adds, one per incident edge, and a + b
+  // is b + a)
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
                      grad_faces, (const FaceRec*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -851,10 +890,14 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
                                    FaceRec* __restrict__ rec) {
   const int b = blockIdx.y;
   const long plane = (long)is * is;
-  __shared__ float ssum[64]; __shared__ int scnt[64];
+  // Per-class depth sums in 64-bit FIXED POINT (2^-32): depths are fp32 values below 16, i.e. multiples of 2^-30 down to 2^-7 - the
+  // integer sum is exact and does not depend on the order the lanes arrive in (the LDS float atomics of rounds 1-2 did, at ulp level,
+  // and carried the rounding of a 65 536-term fp32 sum); as a double it is a multiple of 2^-32 below 2^21: the cross-block fp64
+  // atomics are exact too.  The statistics of the forward pass are order-independent in every mode.
+  __shared__ unsigned long long ssum[64]; __shared__ int scnt[64];
   __shared__ int s_wkey, s_wany;        // the block's wall maximum: ONE pair of device atomics per block (every wall pixel - a third
                                         // of a room image - used to issue its own pair on the same two words)
-  if (threadIdx.x < 64) { ssum[threadIdx.x] = 0.f; scnt[threadIdx.x] = 0; }
+  if (threadIdx.x < 64) { ssum[threadIdx.x] = 0ull; scnt[threadIdx.x] = 0; }
   if (threadIdx.x == 0) { s_wkey = (int)0x80000000; s_wany = 0; }
   __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
@@ -868,7 +911,7 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
     if (c < 0 || c >= NC) continue;
     if (!(class_image_value(v) > 0.1f)) continue;
     const float dd = depth_value(d);
-    atomicAdd(&ssum[c], dd); atomicAdd(&scnt[c], 1);
+    atomicAdd(&ssum[c], (unsigned long long)(long long)rint((double)dd * 4294967296.0)); atomicAdd(&scnt[c], 1);
     if (c == 0) {                       // wall_max = max depth over the wall mask (models/diff_render.py:408-411)
       s_wany = 1;
       atomicMax(&s_wkey, fkey(dd));
@@ -876,7 +919,7 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   }
   __syncthreads();
   if (threadIdx.x < NC && scnt[threadIdx.x] > 0) {
-    atomicAdd(&st[b].sum[threadIdx.x], (double)ssum[threadIdx.x]);
+    atomicAdd(&st[b].sum[threadIdx.x], (double)(long long)ssum[threadIdx.x] * (1.0 / 4294967296.0));
     atomicAdd(&st[b].cnt[threadIdx.x], (double)scnt[threadIdx.x]);
   }
   if (threadIdx.x == 0 && s_wany) {
@@ -915,21 +958,17 @@ __device__ __forceinline__ void compose_tables(ComposeTabs& t, const int32_t* __
 
 // One thread per pixel writes all nch channels: the per-pixel inputs are read once (a thread per (pixel, channel) re-read
 // them 70 times), every store instruction of a wavefront covers 64 consecutive pixels of one channel plane.
-// VARIANT (lab switch SLN_COMPOSE_VARIANT, see sln_scene_forward): 0 plain stores; 1 nontemporal stores; 2 the channels dealt to
-// gridDim.z groups of workgroups (each re-reads the per-pixel inputs, 12 bytes against 280 written).
-template <int VARIANT>
 __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
                                                             const float* __restrict__ d_a, const int32_t* __restrict__ cls,
                                                             const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
-                                                            float* __restrict__ out, int chunks) {
+                                                            float* __restrict__ out) {
   __shared__ ComposeTabs t;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
   compose_tables(t, chan, dch, NC, ndch, st[b]);
   const long plane = (long)is * is;
-  for (int rr = 0; rr < chunks; ++rr) {          // `chunks` consecutive 256-pixel pieces per workgroup (lab: 4 KB per plane and block)
-  const long p = ((long)blockIdx.x * chunks + rr) * blockDim.x + threadIdx.x;
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
   const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);      // p < is^2 < 2^31: 32-bit division
   const long q = b * plane + p;
@@ -940,23 +979,16 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   const float img = cvalid ? class_image_value(val[3 * q]) : 0.f;
   const float dd = depth_value(d_a[q]);
   float* o = out + ((long)b * nch * is + (is - 1 - y)) * is + x;       // channel stride = plane
-  auto put = [&](long off, float v) {
-    if (VARIANT == 1) __builtin_nontemporal_store(v, o + off); else o[off] = v;
-  };
-  // channel range of this workgroup (VARIANT 2: gridDim.z groups; otherwise everything)
-  const int ch0 = VARIANT == 2 ? (int)(((long)nch * blockIdx.z) / gridDim.z) : 0;
-  const int ch1 = VARIANT == 2 ? (int)(((long)nch * (blockIdx.z + 1)) / gridDim.z) : nch;
-  if (ch0 == 0) put(0, dd);
+  o[0] = dd;
   const int mych = cvalid ? t.chan[c] : -1;
-  for (int ch = max(1, ch0); ch <= 40 && ch < min(nch, ch1); ++ch) put((long)ch * plane, (mych == ch - 1) ? img : 0.f);
+  for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
   const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
   const bool own_ok = img > 0.1f;
-  for (int k = max(0, ch0 - 41); k < ndch && 41 + k < ch1; ++k) {
+  for (int k = 0; k < ndch; ++k) {
     const int owner = t.owner[k];
     float v = 0.f;
     if (owner >= 0) v = (c == owner && own_ok) ? ddq : t.fill[k];
-    put((long)(41 + k) * plane, v);
-  }
+    o[(long)(41 + k) * plane] = v;
   }
 }
 
@@ -1002,6 +1034,35 @@ __global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(&st[b].gsum[owner], (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// Deterministic form of the masked sums (SLN_DETERMINISTIC; one workgroup per image): every thread keeps its own accumulator per
+// class in LDS (priv[c][thread]: no atomics, a thread adds its pixels in order), then thread c sums the 256 columns of class c in
+// thread order and adds the result to gsum[c] - the only other add into that value is the plane sum's, and a + b is b + a.
+__global__ __launch_bounds__(256) void scene_bwd_masked_sums_det_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                                        const int32_t* __restrict__ cls, const int32_t* __restrict__ dch,
+                                                                        int F, int is, int NC, int nch, const float* __restrict__ gout,
+                                                                        SceneStats* __restrict__ st) {
+  extern __shared__ float priv[];            // [NC][256]
+  const int b = blockIdx.y;
+  const long plane = (long)is * is;
+  for (int c = 0; c < NC; ++c) priv[c * 256 + threadIdx.x] = 0.f;
+  for (long p = threadIdx.x; p < plane; p += 256) {
+    const long q = b * plane + p;
+    const int f = fi_b[q];
+    if (f < 0) continue;
+    const int c = cls[(long)b * F + f];
+    if (c < 0 || c >= NC || dch[c] < 0) continue;
+    if (!(class_image_value(val[3 * q]) > 0.1f)) continue;
+    const int y = (int)((unsigned)p / (unsigned)is), x = (int)((unsigned)p - (unsigned)y * (unsigned)is);
+    priv[c * 256 + threadIdx.x] += gout[(((long)b * nch + 41 + dch[c]) * is + (is - 1 - y)) * is + x];
+  }
+  __syncthreads();
+  if (threadIdx.x < NC) {
+    float s = 0.f;
+    for (int t = 0; t < 256; ++t) s += priv[threadIdx.x * 256 + t];
+    if (s != 0.f) atomicAdd(&st[b].gsum[threadIdx.x], -(double)s);
+  }
 }
 
 __global__ __launch_bounds__(256) void scene_bwd_masked_sums_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
@@ -1163,20 +1224,8 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
                      w.dB, F, is, 2, tex_eps, npix, w.val);
   // wall_max starts at -inf surrogate
   hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
-  {
-    static const int variant = std::getenv("SLN_COMPOSE_VARIANT") ? std::atoi(std::getenv("SLN_COMPOSE_VARIANT")) : 0;
-    static const int chunks = std::getenv("SLN_COMPOSE_CHUNKS") ? std::atoi(std::getenv("SLN_COMPOSE_CHUNKS")) : 1;
-    const dim3 grid((unsigned)((plane + 256L * chunks - 1) / (256L * chunks)), B, variant >= 2 ? (unsigned)variant : 1u);     // variant >= 2: that many channel groups
-    if (variant == 1)
-      hipLaunchKernelGGL((scene_compose_kernel<1>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
-                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
-    else if (variant >= 2)
-      hipLaunchKernelGGL((scene_compose_kernel<2>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
-                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
-    else
-      hipLaunchKernelGGL((scene_compose_kernel<0>), grid, dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, class_channel,
-                         class_depth_channel, F, is, num_classes, 70, w.st, final_out, chunks);
-  }
+  hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
+                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1202,12 +1251,33 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // the scans.
   // Batches only: with one room (the refinement loop, a captured iteration of ~240 small launches) the three event edges cost
   // more than the overlap returns - 1.37 ms per iteration with the side stream, 1.22 ms without (same-box A/B).
-  SceneSide* sd = n >= 16384 ? scene_side() : nullptr;
+  // Deterministic mode (SLN_DETERMINISTIC): ONE stream, no split units, the depth walk BEHIND the edge scans - every face-gradient
+  // value then receives two adds from the scans (one per incident edge: a + b is b + a) onto the zero fill and one more from the
+  // depth walk, in stream order; the gradient sums take their fixed-order forms (one workgroup per plane / per image).
+  const bool det = g_sln_deterministic != 0;
+  SceneSide* sd = (!det && n >= 16384) ? scene_side() : nullptr;
+  // One stream and three events per device serve every caller: two host threads (or a capturing and an eager caller) enqueuing
+  // their fork / mid / join records at the same time would cross their dependencies, so the fork..join section is exclusive
+  // (host-side enqueue only: microseconds).  The guard below also JOINS on every way out: an error return between fork and join
+  // used to leave the side stream un-joined - work on grad_faces still in flight, and an active stream capture invalidated.
+  static std::mutex side_mu;
+  std::unique_lock<std::mutex> side_lock(side_mu, std::defer_lock);
   hipStream_t sd_st = st;
   if (sd != nullptr) {
+    side_lock.lock();
     if (hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
-    else sd = nullptr;
+    else { sd = nullptr; side_lock.unlock(); }
   }
+  struct Join {
+    SceneSide* sd; hipStream_t st; hipError_t err;
+    void run() {
+      if (sd == nullptr) return;
+      err = hipEventRecord(sd->join, sd->stream);
+      if (err == hipSuccess) err = hipStreamWaitEvent(st, sd->join, 0);
+      sd = nullptr;
+    }
+    ~Join() { run(); }
+  } join{sd, st, hipSuccess};
   const int t32 = sln_cdiv(is, 32);
   const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, sd_st);
   if (e != hipSuccess) return (int)e;
@@ -1215,25 +1285,29 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                      num_classes, 70, w.st, w.g, w.gT);
   if (sd != nullptr && hipEventRecord(sd->mid, sd->stream) != hipSuccess) return SLN_E_STATE;
   hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, sd_st, w.st, B);
-  hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
+  hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(det ? 1 : 8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
                      w.st);
+  if (det)
+    hipLaunchKernelGGL(scene_bwd_masked_sums_det_kernel, dim3(1, B), dim3(256), sizeof(float) * 256 * (size_t)num_classes, sd_st, w.fiB, w.val,
+                       face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st);
+  else
   hipLaunchKernelGGL(scene_bwd_masked_sums_kernel, dim3(64, B), dim3(256), 0, sd_st, w.fiB, w.val, face_class, class_depth_channel, F, is,
                      num_classes, 70, grad_final, w.st);
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, sd_st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
-  hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
-                     grad_faces);
+  if (!det)
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
+                       grad_faces);
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
                      num_classes, 70, w.prec, w.precT);
   if (sd != nullptr && hipStreamWaitEvent(st, sd->mid, 0) != hipSuccess) return SLN_E_STATE;
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, det ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
                      grad_faces, (const FaceRec*)w.rec);
-  if (sd != nullptr) {            // join: whatever follows on `st` sees both chains
-    hipError_t r = hipEventRecord(sd->join, sd->stream);
-    if (r == hipSuccess) r = hipStreamWaitEvent(st, sd->join, 0);
-    if (r != hipSuccess) return (int)r;
-  }
+  if (det)
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, 1), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
+  join.run();                     // whatever follows on `st` sees both chains
+  if (join.err != hipSuccess) return (int)join.err;
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -182,6 +182,20 @@ __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, 
   }
 }
 
+// Order-independent fp64 accumulation (round 3).  The column statistics and the loss terms are sums of per-block partials added
+// with fp64 atomics, in whatever order the blocks arrive.  A partial rounded to a multiple of 2^-k is added EXACTLY as long as
+// the running sum stays below 2^(53-k) - and exact additions commute: the total no longer depends on the arrival order (two
+// runs give bit-identical BatchNorm statistics and losses).  The rounding itself moves a partial by at most 2^-(k+1):
+//   forward sums (sum y, sum y^2)        k = 20: 5e-7 absolute per block on sums of magnitude >= 1, exact below 8.6e9
+//   backward sums (sum g, sum g*xhat)    k = 44: 3e-14 absolute on sums of magnitude 1e-6 .. 1, exact below 512
+//   loss terms                           k = 24: exact below 5e8
+// Beyond those ranges rint() is the identity or the additions round as before: values stay correct, only the order
+// independence is lost.
+#define SLN_Q_FWD 1048576.0                   /* 2^20 */
+#define SLN_Q_BWD 17592186044416.0            /* 2^44 */
+#define SLN_Q_LOSS 16777216.0                 /* 2^24 */
+__device__ __forceinline__ double sln_qd(double v, double scale) { return rint(v * scale) * (1.0 / scale); }
+
 __device__ __forceinline__ float wave_sum_halves(float v) {   // lanes l and l^32 -> both hold the sum
   return v + __shfl_xor(v, 32, 64);
 }

@@ -47,11 +47,17 @@ int sln_launch_gemm_group(const GemmNTArgs* nt, const int* epi, int n_nt, const 
 // A wgrad has no consumer before the optimizer, so the engine no longer pairs it with the next dgrad: it records the problems
 // and launches them together when the pass is over.  The problem table lives in device memory (a hipGraph replays the launch
 // with the same pointers); each block finds its problem from the prefix of block counts.
-enum { SLN_TN_MULTI_MAX = 64 };
-struct TnMultiMeta { int nprob, pad_; int block_begin[SLN_TN_MULTI_MAX + 1]; int gx[SLN_TN_MULTI_MAX]; };
+enum { SLN_TN_MULTI_MAX = 64, SLN_TN_MULTI_ITEMS = 4096 };
+// One entry per workgroup of the launch: problem, output tile, row chunk.  The table is laid out for the hardware's round-robin
+// placement (workgroup b runs on XCD b % 8): all tiles of one (problem, row chunk) share an XCD - they read the same G / X rows,
+// which then come out of THAT XCD's L2 once instead of from the fabric once per XCD (profiles/r03: 645 MB fetched per launch for
+// 100 MB of operands before) - and the (problem, chunk) groups are dealt to the eight XCDs longest first, so that every XCD gets
+// the same amount of work.  XCDs with fewer items are padded with empty entries (prob < 0).
+struct TnMultiItem { int prob, tile, chunk, pad_; };
+struct TnMultiMeta { int nprob, nblocks; TnMultiItem item[SLN_TN_MULTI_ITEMS]; };
 // host side: fills rows_per_block of every problem (long chunks: the per-block prologue / 64x64 atomics are paid once per
-// ~1 k rows instead of once per 256), orders them longest first and builds the block prefix.  Returns 0, or SLN_E_* when a
-// problem cannot run on the TN body.  `probs` is permuted in place.
+// ~1 k rows instead of once per 256; longer still when the launch would not fit the table) and builds the item table.
+// Returns 0, or a negative value when a problem cannot run on the TN body.
 int sln_tn_multi_plan(GemmTNArgs* probs, int n, TnMultiMeta* meta, int* blocks, bool* x2, bool* xg, double* flops);
 int sln_launch_gemm_tn_multi(const GemmTNArgs* dev_probs, const TnMultiMeta* dev_meta, int blocks, bool x2, bool xg, double flops,
                              hipStream_t st);

@@ -7,6 +7,8 @@ enum { SLN_FAM_GEMM_NT = 0, SLN_FAM_GEMM_TN = 1, SLN_FAM_EDGE = 2, SLN_FAM_OTHER
        SLN_FAM_RASTER_BWD = 5, SLN_FAM_CONV = 6, SLN_FAM_GEMM_DUAL = 7, SLN_FAM_COUNT = 8 };
 
 extern bool g_sln_prof_on;
+// SLN_DETERMINISTIC=1 / sln_set_deterministic(1): launchers pick the order-independent variants (see DESIGN.md "Deterministic mode")
+extern int g_sln_deterministic;
 void sln_prof_begin(int family, double work, hipStream_t st);
 void sln_prof_end(hipStream_t st);
 

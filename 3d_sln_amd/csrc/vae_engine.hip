@@ -11,6 +11,7 @@
 #include "../../include/sln_hip.h"
 #include "sln_gemm.h"
 #include "vae_kernels.h"
+#include "sln_prof.h"
 
 namespace {
 
@@ -143,8 +144,9 @@ struct SlnVae {
     GemmTNArgs probs[SLN_TN_MULTI_MAX]; TnMultiMeta meta; int n = 0, blocks = 0; bool x2 = false, xg = false; double flops = 0.0;
     bool dirty = true; GemmTNArgs* dev_probs = nullptr; TnMultiMeta* dev_meta = nullptr;
   };
-  enum { TN_SLOTS = 64 };                        // launches per iteration: slots [0, 32) decoder pass, [32, 64) encoder pass
+  enum { TN_SLOTS = 32 };                        // launches per iteration: slots [0, 16) decoder pass, [16, 32) encoder pass
   bool defer = true, capturing = false, tn_upload_pending = false;
+  int det_seen = 0;                              // g_sln_deterministic the captured iterations were recorded with
   bool tn_per_layer = false;                     // flush after every GraphTripleConv instead of once per pass
   bool tn_side = false, tn_side_busy = false;    // run the wgrad launches on the side stream, next to the dgrad chain
   int tn_slot_next[2] = {0, 0};
@@ -552,7 +554,9 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   RET_IF(linear_wgrad(G1, layer_input(gi, tr), ly.u0 + 0, T, st));
   RET_IF(linear_dgrad(G1, ly.u0 + 0, dG[slot], 3 * D, T, nullptr, 0, -1, false, nullptr, 0, tr, st));
   RET_IF(join_side(st));      // (pairing / side-stream modes: their wgrads are launched before the next layer starts)
-  if (tn_per_layer) RET_IF(flush_deferred(ly.net == 0 ? 1 : 0, st));
+  // deterministic mode with shared (recurrent) weights: the layers' wgrads add into the SAME dW, so they run as separate
+  // launches in stream order instead of side by side in one
+  if (tn_per_layer || (g_sln_deterministic && cfg.recurrent)) RET_IF(flush_deferred(ly.net == 0 ? 1 : 0, st));
   return 0;
 }
 
@@ -1239,6 +1243,7 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
     const bool draw = !eps && !h->cfg.use_ae;            // no eps from the caller: the iteration draws it on the device
     if (draw != h->draw_eps) { HIP_RET(hipStreamSynchronize(st)); h->draw_eps = draw; h->drop_graphs(); }
   }
+  if (h->det_seen != g_sln_deterministic) { h->det_seen = g_sln_deterministic; h->drop_graphs(); }   // other launch sequence: re-capture
   if (use_graph && st != nullptr) {
     hipGraphExec_t& ge = h->graph_exec[mode];
     if (!ge || h->graph_O[mode] != h->O || h->graph_T[mode] != h->T) {

@@ -23,8 +23,8 @@ __device__ __forceinline__ void commit_col_stats(float s1, float s2, bool valid,
     float a = 0.f, b = 0.f;
 #pragma unroll
     for (int i = 0; i < RL; ++i) { a += red[0][i][threadIdx.x]; b += red[1][i][threadIdx.x]; }
-    atomicAdd(out + col, (double)a);
-    atomicAdd(out + cstride + col, (double)b);
+    atomicAdd(out + col, sln_qd((double)a, SLN_Q_BWD));
+    atomicAdd(out + cstride + col, sln_qd((double)b, SLN_Q_BWD));
   }
 }
 
@@ -158,7 +158,7 @@ __device__ __forceinline__ void commit_col_stats4(const float4& s1, const float4
       float a = 0.f;
 #pragma unroll
       for (int i = 0; i < YT; ++i) a += red[which][i][cj];
-      atomicAdd(out + which * cstride + col0 + cj, (double)a);
+      atomicAdd(out + which * cstride + col0 + cj, sln_qd((double)a, SLN_Q_BWD));
     }
   }
 }
@@ -386,7 +386,7 @@ __global__ void enc_assemble_bwd_kernel(EncAssembleBwd a) {
   else { c -= a.n_box; atomicAdd(a.d_angle_emb + (size_t)a.angles[r] * a.n_angle + c, d); }
 }
 
-__global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a) {
+__global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a, const int box_rows) {
   // d_bb[j] += sum_r d[r,j];  d_wb[j,k] += sum_r d[r,j]*boxes[r,k]   (box_dim <= 6)
   const int W = a.n_obj + a.n_attr + a.n_box + a.n_angle, off = a.n_obj + a.n_attr;
   const int j = blockIdx.x * CB + threadIdx.x;
@@ -395,7 +395,8 @@ __global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a)
   // BOX_ROWS rows per block in batches of 16 (4 per thread, their loads issued together: one memory round trip per batch).  Every
   // block ends in 7 atomics per column on the same 7 x n_box addresses, which the L2 serialises - measured at 2 048 rows: 64 rows
   // walked one at a time 20.6 us; batches, 16 rows x 128 blocks 21.6 us, 256 x 8 15.9 us, 64 x 32 9.8 us
-  const int rb0 = (int)blockIdx.y * BOX_ROWS, r1 = min(a.O, rb0 + BOX_ROWS);
+  // (deterministic mode: box_rows = O, one workgroup per column group walks every row - one add per element)
+  const int rb0 = (int)blockIdx.y * box_rows, r1 = min(a.O, rb0 + box_rows);
   if (jv) {
     for (int rb = rb0; rb < r1; rb += 4 * RL) {
       float d[4], bx[4][6];
@@ -492,6 +493,40 @@ __global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restri
   for (int i = threadIdx.x; i < tsz; i += 256) {
     const float v = tab[i];
     if (v != 0.f) atomicAdd(d_emb + i, v);
+  }
+}
+
+// Deterministic form (SLN_DETERMINISTIC): one workgroup per (table row e, 64 columns).  Its four row lanes walk the source rows
+// in order and keep those with idx[r] == e; the four partial sums meet in a fixed order; the result is added to the table with a
+// plain read-modify-write (one writer per element and launch).  No atomics, no arrival order.
+template <typename IdxT>
+__global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0,
+                                                             int rows, int n, float* __restrict__ d_emb) {
+  // 16 row lanes x 64 columns; a row lane takes rows lane_r, lane_r + 16, ... eight at a time (their indices in one round trip,
+  // then the matching rows' values: the walk is latency-bound), always in ascending order
+  const int e = blockIdx.x, x = threadIdx.x & 63, c = blockIdx.y * 64 + x, lane_r = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < n)
+    for (int r0 = lane_r; r0 < rows; r0 += 16 * 8) {
+      int id[8]; float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) id[u] = (int)idx[min(r0 + 16 * u, rows - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int r = r0 + 16 * u;
+        v[u] = (r < rows && id[u] == e) ? d[(size_t)r * ld + col0 + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];          // adding 0.f for the other rows changes nothing
+    }
+  __shared__ float red[16][64];
+  red[lane_r][x] = acc;
+  __syncthreads();
+  if (lane_r == 0 && c < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][x];
+    d_emb[(size_t)e * n + c] += s;
   }
 }
 
@@ -603,7 +638,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x < 3) atomicAdd(a.acc + threadIdx.x, red[threadIdx.x][0]);
+  if (threadIdx.x < 3) atomicAdd(a.acc + threadIdx.x, sln_qd(red[threadIdx.x][0], SLN_Q_LOSS));
   __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -975,6 +1010,16 @@ int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st) {
   const long n = (long)a.O * (a.n_obj + a.n_attr + a.n_box + a.n_angle);
   if (n <= 0) return 0;
   const long tabs = (long)a.rows_obj * a.n_obj + (long)a.rows_attr * a.n_attr + (long)a.rows_angle * a.n_angle;
+  if (g_sln_deterministic && a.rows_obj > 0 && a.rows_angle > 0 && (a.n_attr == 0 || a.rows_attr > 0)) {
+    const int ld = a.n_obj + a.n_attr + a.n_box + a.n_angle;
+    int r = sln_launch_embed_bwd_i64(a.objs, a.dx0, ld, 0, a.O, a.n_obj, a.rows_obj, a.d_obj_emb, st);
+    if (!r && a.n_attr > 0) r = sln_launch_embed_bwd_i64(a.attrs, a.dx0, ld, a.n_obj, a.O, a.n_attr, a.rows_attr, a.d_attr_emb, st);
+    if (!r) r = sln_launch_embed_bwd_i64(a.angles, a.dx0, ld, a.n_obj + a.n_attr + a.n_box, a.O, a.n_angle, a.rows_angle, a.d_angle_emb, st);
+    if (r) return r;
+    hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), 1), dim3(CB, RL), 0, st, a, a.O);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   if (a.rows_obj > 0 && a.rows_angle > 0 && (a.n_attr == 0 || a.rows_attr > 0) && tabs <= ASSEMBLE_LDS_MAX_FLOATS) {
     AssembleBwdLds l; std::memset(&l, 0, sizeof(l));
     l.dx0 = a.dx0; l.ld = a.n_obj + a.n_attr + a.n_box + a.n_angle; l.O = a.O;
@@ -987,7 +1032,7 @@ int sln_launch_enc_assemble_bwd(EncAssembleBwd a, hipStream_t st) {
     if (e) return e;
   } else
   hipLaunchKernelGGL(enc_assemble_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, BOX_ROWS)), dim3(CB, RL), 0, st, a);
+  hipLaunchKernelGGL(box_embed_bwd_kernel, dim3(sln_cdiv(a.n_box, CB), sln_cdiv(a.O, BOX_ROWS)), dim3(CB, RL), 0, st, a, (int)BOX_ROWS);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1004,6 +1049,16 @@ int sln_launch_dec_assemble_bwd(DecAssembleBwd a, hipStream_t st) {
   const long n = (long)a.O * (a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0));
   if (n <= 0) return 0;
   const long tabs = (long)a.rows_obj * a.n_obj + (long)a.rows_attr * a.n_attr;
+  if (g_sln_deterministic && a.rows_obj > 0 && (a.n_attr == 0 || a.rows_attr > 0)) {
+    const int ld = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0);
+    int r = sln_launch_embed_bwd_i64(a.objs, a.dx0, ld, 0, a.O, a.n_obj, a.rows_obj, a.d_obj_emb, st);
+    if (!r && a.n_attr > 0) r = sln_launch_embed_bwd_i64(a.attrs, a.dx0, ld, a.n_obj, a.O, a.n_attr, a.rows_attr, a.d_attr_emb, st);
+    if (r) return r;
+    if (a.z_in_x0 && a.dz)
+      return (int)hipMemcpy2DAsync(a.dz, sizeof(float) * a.n_z, a.dx0 + a.n_obj + a.n_attr, sizeof(float) * ld, sizeof(float) * a.n_z,
+                                   (size_t)a.O, hipMemcpyDeviceToDevice, st);
+    return 0;
+  }
   if (a.rows_obj > 0 && (a.n_attr == 0 || a.rows_attr > 0) && tabs <= ASSEMBLE_LDS_MAX_FLOATS) {
     AssembleBwdLds l; std::memset(&l, 0, sizeof(l));
     l.dx0 = a.dx0; l.ld = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0); l.O = a.O;
@@ -1023,6 +1078,11 @@ int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, i
                              float* d_emb, hipStream_t st) {
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
+  if (g_sln_deterministic && table_rows > 0) {
+    hipLaunchKernelGGL(embed_bwd_det_kernel<int>, dim3(table_rows, sln_cdiv(n, 64)), dim3(1024), 0, st, idx, d, ld, col0, rows, n, d_emb);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
     const int rpb = 64;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st, idx,
@@ -1040,6 +1100,11 @@ int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col
                              float* d_emb, hipStream_t st) {
   const long tot = (long)rows * n;
   if (tot <= 0) return 0;
+  if (g_sln_deterministic && table_rows > 0) {
+    hipLaunchKernelGGL(embed_bwd_det_kernel<int64_t>, dim3(table_rows, sln_cdiv(n, 64)), dim3(1024), 0, st, idx, d, ld, col0, rows, n, d_emb);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
     const int rpb = 64;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int64_t>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st,

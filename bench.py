@@ -35,7 +35,13 @@ MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 VALU_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak (2 flop x 64 lanes x 4 SIMD x 256 CU x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "gemm_dual"]
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_kernel_stats.csv")      # rocprofv3 summary of this very command (profiles/README.md)
+# rocprofv3 summaries, ONE PER LEG (tools/profile_round.sh r03): kernel-trace statistics of a run that executes that leg's
+# workload only, joined with the HBM traffic of two PMC passes of the same command (profiles/README.md)
+PROFILE_TAG = "r03"
+
+
+def profile_csv(leg):
+    return os.path.join(ROOT, "profiles", "%s_%s_kernel_stats.csv" % (PROFILE_TAG, leg))
 
 
 def parse():
@@ -68,6 +74,7 @@ def parse():
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
     ap.add_argument("--large-batches", type=str, default="256,1024,4096", help="extra VAE points (graphs per step), '' = none")
+    ap.add_argument("--no-colorize", action="store_true", help="skip the one-map / 50-z SPADE leg (per-leg profiles: batch-32 launches only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-call-sequence legs (vae_dropin, render_33pass, spade_50x1)")
     ap.add_argument("--dropin-steps", type=int, default=40)
     return ap.parse_args()
@@ -95,13 +102,14 @@ def prof_read(lib):
     return {FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n) if cnt[i]}
 
 
-def profile_rows(prefixes):
-    """Rows of the committed rocprofv3 summary (kernel-trace stats joined with the PMC traffic passes) whose kernel name starts
-    with one of `prefixes`: -> (launch-weighted HBM bytes per launch or None, launch-weighted avg us or None)."""
+def profile_rows(prefixes, leg):
+    """Rows of the committed rocprofv3 summary of `leg` ("vae" / "render" / "spade": kernel-trace stats joined with the PMC traffic
+    passes) whose kernel name starts with one of `prefixes`: -> (launch-weighted HBM bytes per launch or None, launch-weighted
+    avg us or None)."""
     try:
         import csv
         tot_b, tot_us, n_b, n_us = 0.0, 0.0, 0, 0
-        for r in csv.DictReader(open(PROFILE_CSV)):
+        for r in csv.DictReader(open(profile_csv(leg))):
             if not r["kernel"].startswith(tuple(prefixes)):
                 continue
             calls = int(r["calls"])
@@ -457,8 +465,8 @@ def render_leg(args, lib, torch, rank):
                        "achieved": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic": None, "algorithmic_bytes_per_launch": int(bytes_per_render * args.rooms)}
-    tr_pm, us_pm = profile_rows(["pixel_map_backward", "class_scan_backward"])
-    tr_rt, us_rt = profile_rows(["raster_tile_kernel"])
+    tr_pm, us_pm = profile_rows(["pixel_map_backward", "class_scan_backward"], "render")
+    tr_rt, us_rt = profile_rows(["raster_tile_kernel"], "render")
     brute_tests = 256.0 * 256.0 * 2.0 * tris * args.rooms          # (pixel, face) pairs of ONE brute-force pass over the batch
     flop_per_test = 3 * 2 * 2 + 3                                    # three edge functions (2 fma each) + sign tests
     # edge tests the tile kernel can at most execute: (front-facing face, 16x16 tile its pixel bounding box touches) pairs x 256
@@ -647,7 +655,7 @@ def spade_leg(args, lib, torch):
         tf = c["work"] / (c["ms"] * 1e-3) / 1e12
         res["conv_kernels"] = {"launches": c["launches"], "ms": round(c["ms"], 2), "tflops": round(tf, 2),
                                "frac_mfma": round(tf / MFMA_F32_PEAK_TFLOPS, 4)}
-        tr, us = profile_rows(["conv_glds_kernel", "conv_mfma_kernel"])
+        tr, us = profile_rows(["conv_glds_kernel", "conv_mfma_kernel"], "spade")
         res["roofline"] = {"kernel": "conv_glds_kernel + conv_mfma_kernel (reflect-padded implicit GEMM: direct-to-LDS and register-staged "
                                      "variants, %d launches per batch)" % c["launches"], "bound": "mfma",
                            "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
@@ -656,18 +664,19 @@ def spade_leg(args, lib, torch):
     # colorize_with_spade's own shape (testing/test_SPADE_shade.py:30-79): ONE semantic map, 50 z vectors.  gamma/beta depend
     # on the map only, so they are computed once (sln_spade_apply does the per-sample part).
     nz = 50
-    z50 = torch.randn(nz, 256, device="cuda", generator=g)
-    G(seg[:1], z50)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        o50 = G(seg[:1], z50)
-    torch.cuda.synchronize()
-    dt50 = (time.perf_counter() - t0) / 5
-    res["colorize_one_map_50z"] = {"images_per_s": round(nz / dt50, 1), "ms_per_room": round(dt50 * 1e3, 2),
-                                   "speedup_vs_per_sample_path": round((nz / dt50) / (B / dt), 2),
-                                   "finite": bool(torch.isfinite(o50).all().item())}
-    if not args.no_dropin:
+    if not args.no_colorize:
+        z50 = torch.randn(nz, 256, device="cuda", generator=g)
+        G(seg[:1], z50)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            o50 = G(seg[:1], z50)
+        torch.cuda.synchronize()
+        dt50 = (time.perf_counter() - t0) / 5
+        res["colorize_one_map_50z"] = {"images_per_s": round(nz / dt50, 1), "ms_per_room": round(dt50 * 1e3, 2),
+                                       "speedup_vs_per_sample_path": round((nz / dt50) / (B / dt), 2),
+                                       "finite": bool(torch.isfinite(o50).all().item())}
+    if not args.no_dropin and not args.no_colorize:
         res["spade_50x1"] = spade_50x1_leg(args, torch, G, seg, B / dt)
     if not args.no_cpu:
         # CPU baseline: the oracle (PyTorch-CPU restatement = what the reference module computes) on images of the same batch, all cores
@@ -701,6 +710,27 @@ def spade_leg(args, lib, torch):
                                "sample": "%d x batch of %d images of the same input through oracle/spade_ref.py (torch CPU fp32), %.2f s per image"
                                          % (n_it, bc, cdt / bc)}
     return res
+
+
+def vae_gemm_shapes(O, T, E=64, L=5, box_dim=6, n_angle=24):
+    """The Linears of Sg2ScVAEModel at train.py's defaults (decoder_cat, attributes, BatchNorm): (rows, out, in, gathered, bn).
+    -> flops of one training step (forward + dgrad + wgrad = 3 x 2MNK) and the algorithmic fp32 operand bytes of its NT launches
+    (forward + dgrad) and of its TN problems (wgrad)."""
+    D, H, W = 2 * E, 4 * E, 2 * E
+    lin = []
+    for _net in range(2):
+        for _l in range(L):
+            lin += [(T, H, 3 * D, True, True), (T, 2 * H + D, H, False, True), (O, H, H, False, True), (O, D, H, False, True)]
+    lin += [(O, H, W, False, True), (O, W, H, False, True), (O, E * 3 // 4, W, False, False), (O, E * 3 // 4, W, False, False)]
+    lin += [(O, H, W, False, True), (O, W, H, False, True), (O, E // 4, W, False, False), (O, E // 4, W, False, False)]
+    lin += [(O, H, W + E // 4, False, True), (O, box_dim, H, False, False), (O, H, W, False, True), (O, n_angle, H, False, False)]
+    flop = nt = tn = 0.0
+    for M, N, K, _g, bn in lin:
+        flop += 3 * 2.0 * M * N * K
+        nt += 4.0 * (M * K + N * K + M * N)                                   # forward: x, W, y
+        nt += 4.0 * ((2 if bn else 1) * M * N + N * K + M * K + (M * K))        # dgrad: g (+ pre-activation), W^T, dx, mask's xprev (upper bound)
+        tn += 4.0 * ((2 if bn else 1) * M * N + M * K + N * K)                  # wgrad: g (+ pre-activation), x, dW
+    return {"flop_step": flop, "nt_bytes_step": nt, "tn_bytes_step": tn, "linears": len(lin)}
 
 
 def main():
@@ -869,17 +899,43 @@ def main():
         out["kernels"] = kern
         dom = max((k for k in fam if k.startswith("gemm")), key=lambda k: fam[k]["ms"])
         ach = fam[dom]["work"] / (fam[dom]["ms"] * 1e-3) / 1e12
-        # HBM traffic of that kernel family from the committed rocprofv3 PMC passes of this command (FETCH_SIZE / WRITE_SIZE in
-        # separate runs, FETCH doubled as MI355X_MICROARCH.md prescribes for gfx950); launch-weighted mean over its variants;
-        # the training step's launches only: the refinement leg adds eval-mode <0, ...> variants on a 13-object graph
-        traffic, prof_us = profile_rows([dom + "_kernel<1,", dom + "_kernel<2,"] if dom == "gemm_dual" else [dom + "_kernel"])
+        # algorithmic operand bytes of the step's GEMMs, from the model's Linear shapes (vae_gemm_shapes below; its flops are
+        # checked against what the launchers themselves summed): NT = forward Linears + dgrads, TN = the wgrads
+        shp = vae_gemm_shapes(int(O), int(b["triples"].shape[0]))
+        flop_prof = sum(v["work"] for k, v in fam.items() if k.startswith("gemm")) / args.prof_steps
+        require(abs(shp["flop_step"] - flop_prof) <= 0.01 * flop_prof, "GEMM flops of the step: shapes say %.4g, launchers summed %.4g"
+                % (shp["flop_step"], flop_prof))
+        prefixes = {"gemm_nt": ["gemm_nt_kernel", "gemm_nt_small_kernel"], "gemm_tn": ["gemm_tn_multi_kernel", "gemm_tn_kernel"],
+                    "gemm_dual": ["gemm_group_kernel", "gemm_dual_kernel"]}
+        per_family = {}
+        for k in fam:
+            if not k.startswith("gemm"):
+                continue
+            tr_k, us_k = profile_rows(prefixes.get(k, [k + "_kernel"]), "vae")
+            a_k = fam[k]["work"] / (fam[k]["ms"] * 1e-3) / 1e12
+            per_family[k] = {"bound": "mfma", "achieved": round(a_k, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(a_k / MFMA_F32_PEAK_TFLOPS, 4), "traffic": tr_k,
+                             "launches_per_step": fam[k]["launches"] // args.prof_steps,
+                             "flop_per_launch": round(fam[k]["work"] / fam[k]["launches"], 1),
+                             "avg_launch_us": round(fam[k]["ms"] / fam[k]["launches"] * 1e3, 2), "rocprof_avg_launch_us": us_k}
+        per_family["gemm_nt"]["what"] = "forward Linears and dgrads, one launch each (64x64 and 32x32 tiles)"
+        if "gemm_tn" in per_family:
+            per_family["gemm_tn"]["what"] = "every wgrad of a backward pass in one multi-problem launch (two per pass: gathered / plain rows)"
+            per_family["gemm_tn"]["algorithmic_bytes_per_launch"] = int(shp["tn_bytes_step"] / max(per_family["gemm_tn"]["launches_per_step"], 1))
+        if "gemm_dual" in per_family:
+            per_family["gemm_dual"]["what"] = "the twin head branches (box / angle), two Linears per launch"
+        nt_launches = sum(per_family[k]["launches_per_step"] for k in ("gemm_nt", "gemm_dual") if k in per_family)
+        traffic, prof_us = per_family[dom]["traffic"], per_family[dom]["rocprof_avg_launch_us"]
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
                            "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2), "rocprof_avg_launch_us": prof_us,
-                           "traffic_source": (os.path.relpath(PROFILE_CSV, ROOT) + " (bytes per launch)") if traffic else None,
-                           "algorithmic_bytes_per_launch": "dgrad+wgrad pair of one Linear: G (two sources under BatchNorm), X, W^T, "
-                                                           "xprev, dX: 4-56 MB (shape dependent)"}
+                           "traffic_source": (os.path.relpath(profile_csv("vae"), ROOT) + " (bytes per launch)") if traffic else None,
+                           "algorithmic_bytes_per_launch": int(shp["nt_bytes_step"] / max(nt_launches, 1)) if dom != "gemm_tn"
+                           else per_family["gemm_tn"]["algorithmic_bytes_per_launch"],
+                           "algorithmic_bytes_note": "launch-weighted mean over the step: fp32 operand rows (x2 for the two-source BatchNorm-"
+                                                     "backward operand) + weights + output (+ the pre-activation the mask reads)"}
+        out["roofline_kernels"] = per_family
         gemm_flop = sum(v["work"] for k, v in fam.items() if k.startswith("gemm")) / args.prof_steps
         out["roofline_step"] = {"kernel": "whole training step (all launches)", "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS,
                                 "achieved": round(gemm_flop / (ms_per_step * 1e-3) / 1e12, 2),

@@ -184,6 +184,13 @@ int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, f
  * enable=1 starts recording (eager launches only, not under graph capture); sln_prof_read
  * synchronises, sums and clears the recorded intervals. work = FLOPs for GEMM families, bytes else. */
 int sln_prof_enable(int enable);
+/* Deterministic mode (also: environment SLN_DETERMINISTIC=1 at load time).  The reference's CPU path is run-to-run deterministic;
+ * the default HIP path adds partial sums with atomics in arrival order (wgrad row chunks, embedding tables, the renderer's face
+ * gradients).  With the switch on, every such sum is taken in a fixed order: two runs on the same inputs are bit-identical
+ * (scene-graph VAE step and scene backward; cost in DESIGN.md).  Takes effect at the next launch; captured iterations are
+ * re-captured. */
+int sln_set_deterministic(int on);
+int sln_get_deterministic(void);
 int sln_prof_read(double* ms_by_family, double* work_by_family, int64_t* launches_by_family, int n_families);
 
 /* Debug/test tap: copy an internal activation to `dst` (device).  what: 0 A1,1 A2,2 M,3 A3,4 A4 of

@@ -381,3 +381,35 @@ def test_captured_scene_pass_replays_with_new_vertices_and_gradients(n_rooms, ta
         assert_close(dV.detach().cpu().numpy(), Ve.grad.cpu().numpy(), "captured dV %d" % trial, rtol=1e-4, atol=1e-4 * float(Ve.grad.abs().max()))      # float atomics of the face backward: order differs between runs
     image2, dV2 = g()                                             # nothing new: the last inputs again
     assert torch.equal(image2, image) and torch.isfinite(dV2).all()
+
+
+@pytest.mark.parametrize("n_rooms", [1, 9])
+def test_deterministic_mode_makes_the_scene_pass_bit_identical(n_rooms):
+    """sln_set_deterministic(1): the fused scene pass forward + backward gives the same bits on every run - the scene tensor
+    (class depth statistics summed in exact fixed point) and d / d vertices (one stream, no split units, the depth walk behind the
+    edge scans, fixed-order gradient sums, a gather instead of the vertex scatter) - for one room (the refinement loop's shape, where
+    the default mode splits the long walks over several wavefronts) and for a batch that uses the image -> XCD mapping.  The
+    deterministic result agrees with the default mode's."""
+    lib = pkg("_lib"); DR = pkg("host.diff_render"); syn = pkg("host.synthetic")
+    rooms = [syn.synthetic_room(300 + i, n_objects=8, target_faces=700) for i in range(n_rooms)]
+    b = syn.pack_rooms(rooms)
+    go = torch.randn(n_rooms, 70, 128, 128, generator=torch.Generator().manual_seed(5)).cuda()
+
+    def run():
+        Vb = b["V"].clone().requires_grad_(True)
+        out = DR.scene_render_batch(Vb, b["F"], b["C"], b["chan"], b["dch"], b["K"], b["R"], b["t"], 128, 0.001)
+        (out * go).sum().backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), Vb.grad.clone()
+    try:
+        lib.check(lib.lib().sln_set_deterministic(1), "sln_set_deterministic")
+        runs = [run() for _ in range(4)]
+    finally:
+        lib.lib().sln_set_deterministic(0)
+    for o, g in runs[1:]:
+        assert torch.equal(o, runs[0][0]), float((o - runs[0][0]).abs().max())
+        assert torch.equal(g, runs[0][1]), float((g - runs[0][1]).abs().max())
+    o, g = run()
+    assert_close(o.cpu().numpy(), runs[0][0].cpu().numpy(), "scene tensor, default vs deterministic", rtol=1e-5, atol=1e-6)
+    assert_close(g.cpu().numpy(), runs[0][1].cpu().numpy(), "dV, default vs deterministic", rtol=1e-4,
+                 atol=2e-5 * float(runs[0][1].abs().max()))

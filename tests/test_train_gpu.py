@@ -243,3 +243,44 @@ def test_optimizer_state_survives_a_device_or_dtype_re_flatten():
     d = np.abs(a.flat_params.cpu().numpy() - c.flat_params.cpu().numpy())
     assert d.max() <= 2.05e-3 * 3 and np.mean(d > 1e-5) < 0.02, (d.max(), np.mean(d > 1e-5))
     assert a._sync_adam_steps() == 3
+
+
+@pytest.mark.parametrize("mode", ["feedforward", "recurrent"])
+def test_deterministic_mode_makes_fused_steps_bit_identical(mode):
+    """sln_set_deterministic(1) (or SLN_DETERMINISTIC=1): the reference's CPU path is run-to-run deterministic; with the switch on so
+    is the fused training step - three steps (eager, then replayed as a hipGraph) from the same state, batch and eps give
+    bit-identical losses, gradients and parameters, also with shared (recurrent) GraphTripleConv weights, whose layers add into
+    the same dW.  The deterministic result agrees with the default path's within the usual tolerance."""
+    lib = pkg("_lib")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=3, gconv_mode=mode)
+    sd = vae_ref.init_state(cfg, seed=13)
+    b = _dev(*vae_ref.synth_batch(24, 9, 15, seed=4, cfg=cfg)[:5])
+    eps = torch.randn(b[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(3)).cuda()
+
+    def run(use_graph):
+        model = _model(cfg, sd).train()
+        st = torch.cuda.Stream()
+        out = []
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                l = model.train_step(*b, kl_weight=0.1, lr=1e-3, eps=eps, use_graph=use_graph)
+                out.append((l.clone(), model.flat_grads.clone()))
+        torch.cuda.synchronize()
+        return out, model.flat_params.clone()
+    try:
+        lib.check(lib.lib().sln_set_deterministic(1), "sln_set_deterministic")
+        assert lib.lib().sln_get_deterministic() == 1
+        runs = [run(False), run(False), run(True), run(True)]
+    finally:
+        lib.lib().sln_set_deterministic(0)
+    ref_steps, ref_params = runs[0]
+    for steps, params in runs[1:]:
+        for (l0, g0), (l1, g1) in zip(ref_steps, steps):
+            assert torch.equal(l0, l1), (l0, l1)
+            assert torch.equal(g0, g1), float((g0 - g1).abs().max())
+        assert torch.equal(ref_params, params)
+    plain, _ = run(False)
+    assert_close(plain[0][0].cpu().numpy(), ref_steps[0][0].cpu().numpy(), "first-step losses, default vs deterministic", rtol=1e-5)
+    gs = float(ref_steps[0][1].abs().max())
+    assert_close(plain[0][1].cpu().numpy(), ref_steps[0][1].cpu().numpy(), "first-step gradients, default vs deterministic", rtol=2e-3,
+                 atol=2e-5 * gs)

@@ -1,25 +1,53 @@
 #!/bin/bash
 # All rocprofv3 passes behind profiles/<tag>_*: run on the GPU box from the repository root.
-#   tools/profile_round.sh r02 [extra bench.py flags]
-# 1. kernel trace + stats of the DEFAULT bench command (every leg)   -> <tag>_rocprofv3_kernel_stats_raw.csv
-# 2. two PMC passes (FETCH_SIZE, WRITE_SIZE; counters in their own runs) of a short bench run
-# 3. one PMC pass with 8 SQ counters                                    -> <tag>_sq_stalls.csv
-# then tools/summarize_profile.py / summarize_sq.py condense them into profiles/.
+#   tools/profile_round.sh r03
+# Per leg (vae = the 64-graph training step, render = 16 rooms forward + backward, spade = batch 32) a run that executes THAT
+# workload only, so that a kernel's avg_us is the duration on that leg's shapes:
+#   1. kernel trace + stats                                             -> <tag>_<leg>_rocprofv3_kernel_stats_raw.csv
+#   2. two PMC passes (FETCH_SIZE, WRITE_SIZE; counters in their own runs, no tracing domains)
+#   3. one PMC pass with 8 SQ counters                                    -> <tag>_<leg>_sq_stalls.csv
+# plus, for the render leg, a second kernel trace with SLN_SCENE_NO_SIDE=1 (the two chains of the scene backward on ONE stream:
+# every kernel's duration is its own)                                     -> <tag>_render_noside_kernel_stats.csv
+# and the kernel trace of the DEFAULT bench command (all legs)            -> <tag>_rocprofv3_kernel_stats_raw.csv
+# tools/summarize_profile.py / summarize_sq.py condense them into profiles/.
 set -u
-TAG=${1:-r02}; shift || true
+TAG=${1:-r03}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 P=/tmp/prof_$TAG          # raw rocprofv3 output stays on the box (tens of MB); only the summaries travel back
 rm -rf "$P"; mkdir -p "$P" profiles gpurun_out
-SHORT="--steps 20 --warmup 5 --no-cpu --no-check --spade-iters 1 --spade-warmup 1 --render-iters 5 --render-warmup 2 --graph-iters 5 --large-batches= $*"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$P/trace" -o vae -- python bench.py "$@" > "$P/bench_traced.json" 2> "$P/trace.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$P/fetch" -o vae -- python bench.py $SHORT > /dev/null 2> "$P/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$P/write" -o vae -- python bench.py $SHORT > /dev/null 2> "$P/write.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
-  --output-format csv -d "$P/sq" -o sq -- python bench.py $SHORT > /dev/null 2> "$P/sq.err"
-for d in trace fetch write sq; do f=$(find "$P/$d" -name '*.csv' | head -1); [ -n "$f" ] && for g in $(find "$P/$d" -name '*.csv'); do mv "$g" "$P/$d/" 2>/dev/null; done; done
-cp "$P/trace/vae_kernel_stats.csv" "profiles/${TAG}_rocprofv3_kernel_stats_raw.csv"
-python tools/summarize_profile.py "$P" "profiles/${TAG}"
-python tools/summarize_sq.py "$P/sq/sq_counter_collection.csv" "profiles/${TAG}"
-mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* "$P/bench_traced.json" gpurun_out/profiles_$TAG/
-tail -c 600 "$P/bench_traced.json"
+COMMON="--no-cpu --no-check --no-dropin --large-batches= --no-graph-build --no-refine"
+declare -A FLAGS
+FLAGS[vae]="$COMMON --no-render --no-spade --steps 100 --warmup 10"
+FLAGS[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 40 --render-warmup 5"
+FLAGS[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 6 --spade-warmup 2"
+declare -A SHORT
+SHORT[vae]="$COMMON --no-render --no-spade --steps 12 --warmup 3 --prof-steps 0"
+SHORT[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 4 --render-warmup 2"
+SHORT[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 1 --spade-warmup 1"
+flatten() { for g in $(find "$1" -name '*.csv'); do mv "$g" "$1/" 2>/dev/null; done; }
+for leg in vae render spade; do
+  D="$P/$leg"; mkdir -p "$D"
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[$leg]} > "$D/bench.json" 2> "$D/trace.err"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/fetch.err"
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/write.err"
+  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+    --output-format csv -d "$D/sq" -o sq -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/sq.err"
+  for d in trace fetch write sq; do flatten "$D/$d"; done
+  cp "$D/trace/vae_kernel_stats.csv" "profiles/${TAG}_${leg}_rocprofv3_kernel_stats_raw.csv"
+  python tools/summarize_profile.py "$D" "profiles/${TAG}_${leg}"
+  python tools/summarize_sq.py "$D/sq/sq_counter_collection.csv" "profiles/${TAG}_${leg}"
+done
+# render, one stream
+D="$P/render_noside"; mkdir -p "$D"
+SLN_SCENE_NO_SIDE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[render]} > "$D/bench.json" 2> "$D/trace.err"
+flatten "$D/trace"
+python tools/summarize_profile.py "$D" "profiles/${TAG}_render_noside"
+# the default command, all legs
+D="$P/all"; mkdir -p "$D"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py --no-cpu "$@" > "$D/bench.json" 2> "$D/trace.err"
+flatten "$D/trace"
+cp "$D/trace/vae_kernel_stats.csv" "profiles/${TAG}_rocprofv3_kernel_stats_raw.csv"
+mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
+for leg in vae render spade render_noside all; do cp "$P/$leg/bench.json" gpurun_out/profiles_$TAG/bench_$leg.json 2>/dev/null; tail -c 300 "$P/$leg/trace.err" > gpurun_out/profiles_$TAG/err_$leg.txt 2>/dev/null; done
+ls -la profiles/${TAG}_*

@@ -10,7 +10,7 @@ f = glob.glob("/tmp/prof_t/**/e_kernel_trace.csv", recursive=True)[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at the N(0,1) draw / first kernel after the adam kernel: split on the Adam kernel
 names = [r["Kernel_Name"] for r in rows]
-XX
+ends = [i for i, n in enumerate(names) if "step_prologue_kernel(" in n or "randn_kernel(" in n]   # first kernel of an iteration (draw + input assembly)
 out = open(sys.argv[1], "w")
 if len(ends) < 3:
     print("no step boundary found", file=out); sys.exit(0)
