@@ -160,6 +160,8 @@ SIGNATURES = {
     "sln_upsample2x": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_conv_img_tanh": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, c_f32p, C.c_void_p]),
     "sln_graph_plan": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sln_graph_draw": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
     "sln_graph_emit": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(SlnGraphDraws),
                                  C.POINTER(SlnGraphBatch), C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,

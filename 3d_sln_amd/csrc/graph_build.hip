@@ -187,7 +187,58 @@ __global__ __launch_bounds__(64) void graph_emit_kernel(SlnRoomTable tab, const 
   for (int i = trip0 + lane; i < t; i += 64) out.triple_to_img[i] = b;
 }
 
+// The random decisions of a batch drawn on the device in ONE launch (round 3; host/suncg_dataset.py::device_draws used to spell
+// them as ~15 ATen launches): Philox-4x32-10 keyed by two 64-bit words in device memory (the caller takes them from its torch
+// generator, so the generator's stream advances and nothing is read back), counter = the object's row among the non-room rows
+// of the batch; the four words of a counter are the four uniforms of one object (suncg_dataset.py:189-196, 236-282):
+//   other = uniform choice among the n - 1 other objects, swap = u > 0.5, attribute mode = none / height / volume.
+__device__ __forceinline__ void gb_philox(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0], p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned int)p1;
+    const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned int)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+
+__global__ __launch_bounds__(64) void graph_draw_kernel(SlnRoomTable tab, const int* __restrict__ room_idx, int B,
+                                                        const int* __restrict__ off, const long long* __restrict__ key,
+                                                        int* __restrict__ other, unsigned char* __restrict__ swap,
+                                                        unsigned char* __restrict__ mode) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int r = room_idx[b];
+  if (r < 0 || r >= tab.n_rooms) return;
+  const int first = tab.room_off[r], n = tab.room_off[r + 1] - first;
+  const int base = off[b] - b;                       // rows of earlier rooms minus their room rows = first draw slot of this room
+  const unsigned long long k0 = (unsigned long long)key[0], k1 = (unsigned long long)key[1];
+  for (int cur = lane; cur < n; cur += 64) {
+    const unsigned int j = (unsigned int)(base + cur);
+    unsigned int c[4] = {j, (unsigned int)(k1 >> 32), (unsigned int)k1, 0x5ce9e6a1u};
+    gb_philox(c, (unsigned int)k0, (unsigned int)(k0 >> 32));
+    const float u0 = (float)(c[0] >> 8) * 5.9604644775390625e-08f, u1 = (float)(c[1] >> 8) * 5.9604644775390625e-08f;   // [0, 1)
+    const float u2 = (float)(c[2] >> 8) * 5.9604644775390625e-08f, u3 = (float)(c[3] >> 8) * 5.9604644775390625e-08f;
+    int k = min((int)(u0 * (float)(n - 1)), n - 2);
+    k = max(k, 0);
+    other[j] = k + (k >= cur ? 1 : 0);
+    swap[j] = u1 > 0.5f ? 1 : 0;
+    const bool known = tab.has_size[tab.cls[first + cur]] != 0;
+    mode[j] = (u2 > 0.5f || !known) ? 0 : (u3 > 0.5f ? 1 : 2);
+  }
+}
+
 }  // namespace
+
+extern "C" int sln_graph_draw(const SlnRoomTable* tab, const int* room_idx, int B, const int* offsets, const int64_t* key,
+                              int* other, unsigned char* swap, unsigned char* attr_mode, void* stream) {
+  if (!tab || !room_idx || !offsets || !key || !other || !swap || !attr_mode || B < 0) return -1;
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(graph_draw_kernel, dim3(B), dim3(64), 0, static_cast<hipStream_t>(stream), *tab, room_idx, B, offsets,
+                     reinterpret_cast<const long long*>(key), other, swap, attr_mode);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int sln_graph_plan(const SlnRoomTable* tab, const int* room_idx, int B, int* counts, int* offsets, void* stream) {
   if (!tab || !room_idx || !counts || !offsets || B < 0) return -1;

@@ -97,6 +97,23 @@ class SuncgDataset(torch.utils.data.Dataset):
                                       len(rooms), C_, int(self.use_attr_30), 0)
         self.device = dev
         self._room_off_host = off
+        self._room_counts_host = None            # per-room (rows, triples), filled on first use (see _room_counts)
+
+    def _room_counts(self):
+        """Rows and triples every room contributes to a batch: both depend on the room's geometry only (the 'on' pairs; the random
+        draws choose partners and labels, not counts), so they are taken ONCE for the whole table (one sln_graph_plan over all rooms,
+        one read-back) and a batch of host-side indices is then planned on the host - no device->host sync per batch (round 2 read
+        three ints back for every batch: with a real dataset the training loop stalled twice per step)."""
+        if self._room_counts_host is None:
+            N = len(self.room_ids)
+            idx = torch.arange(N, dtype=torch.int32, device=self.device)
+            counts = torch.empty(2 * max(N, 1), dtype=torch.int32, device=self.device)
+            off = torch.empty(2 * N + 3, dtype=torch.int32, device=self.device)
+            if N:
+                _lib.check(_lib.lib().sln_graph_plan(C.byref(self._tab), _lib.ptr(idx), N, _lib.ptr(counts), _lib.ptr(off),
+                                                     _lib.current_stream_ptr()), "sln_graph_plan")
+            self._room_counts_host = counts[:2 * N].cpu().numpy().reshape(N, 2).astype(np.int64)
+        return self._room_counts_host
 
     # ---- reference surface ---------------------------------------------------------------------
     def __len__(self):
@@ -142,7 +159,21 @@ class SuncgDataset(torch.utils.data.Dataset):
         return (np.asarray(other, np.int32), np.asarray(swap, np.uint8), np.asarray(mode, np.uint8))
 
     def device_draws(self, idx_t, row_off, O, generator=None):
-        """The same decisions drawn on the device (torch generator); no host loop, no sync."""
+        """The same decisions drawn on the device: ONE launch (sln_graph_draw, Philox keyed by two words taken from the torch
+        generator - its stream advances, nothing is read back); no host loop, no sync.  (Round 2 spelled the draws as ~15 ATen
+        launches: ``device_draws_torch``.)"""
+        B = int(idx_t.shape[0])
+        dev = self.device
+        n = O - B
+        key = torch.randint(-2 ** 62, 2 ** 62, (2,), dtype=torch.int64, device=dev, generator=generator)
+        other = torch.empty(n, dtype=torch.int32, device=dev)
+        swap = torch.empty(n, dtype=torch.uint8, device=dev); mode = torch.empty(n, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib().sln_graph_draw(C.byref(self._tab), _lib.ptr(idx_t), B, _lib.ptr(row_off), _lib.ptr(key), _lib.ptr(other),
+                                             _lib.ptr(swap), _lib.ptr(mode), _lib.current_stream_ptr()), "sln_graph_draw")
+        return other, swap, mode
+
+    def device_draws_torch(self, idx_t, row_off, O, generator=None):
+        """The decisions as torch ops (the round-2 form; kept as the cross-check of sln_graph_draw's distributions)."""
         B = idx_t.shape[0]
         dev = self.device
         n_room = (row_off[1:B + 1] - row_off[:B] - 1).long()
@@ -164,20 +195,35 @@ class SuncgDataset(torch.utils.data.Dataset):
         ``suncg_collate_fn`` (suncg_dataset.py:310-353) for ``[dataset[i] for i in indices]``."""
         L = _lib.lib()
         dev = self.device
-        if torch.is_tensor(indices):
-            idx_t = indices.to(device=dev, dtype=torch.int32).contiguous()
-        else:
-            idx_t = torch.as_tensor(np.asarray(indices, np.int32), device=dev)
-        B = int(idx_t.shape[0])
         st = _lib.current_stream_ptr()
-        counts = torch.empty(2 * B, dtype=torch.int32, device=dev)
-        off = torch.empty(2 * B + 3, dtype=torch.int32, device=dev)
-        _lib.check(L.sln_graph_plan(C.byref(self._tab), _lib.ptr(idx_t), B, _lib.ptr(counts), _lib.ptr(off), st), "sln_graph_plan")
-        O, T, bad = (int(x) for x in off[[B, 2 * B + 1, 2 * B + 2]].tolist()) if B else (0, 0, 0)
-        if bad:
-            raise IndexError("%d room indices outside the table of %d rooms" % (bad, len(self)))
-        if B and int(counts[0::2].min()) < 3:
-            raise IndexError("Cannot choose from an empty sequence (a room of the batch has fewer than 2 objects)")
+        host_idx = None if (torch.is_tensor(indices) and indices.is_cuda) else np.asarray(indices.cpu() if torch.is_tensor(indices) else indices,
+                                                                                            np.int64).reshape(-1)
+        if host_idx is not None:
+            # indices known on the host (a sampler's permutation, a python list): sizes and offsets from the per-room counts taken
+            # once at the first call - nothing is read back from the device
+            B = int(host_idx.shape[0])
+            bad = int(((host_idx < 0) | (host_idx >= len(self))).sum())
+            if bad:
+                raise IndexError("%d room indices outside the table of %d rooms" % (bad, len(self)))
+            rc = self._room_counts()[host_idx] if B else np.zeros((0, 2), np.int64)
+            if B and int(rc[:, 0].min()) < 3:
+                raise IndexError("Cannot choose from an empty sequence (a room of the batch has fewer than 2 objects)")
+            off_h = np.zeros(2 * B + 3, np.int32)
+            off_h[1:B + 1] = np.cumsum(rc[:, 0]); off_h[B + 2:2 * B + 2] = np.cumsum(rc[:, 1])
+            O, T = int(off_h[B]), int(off_h[2 * B + 1])
+            idx_t = torch.from_numpy(host_idx.astype(np.int32)).to(dev)
+            off = torch.from_numpy(off_h).to(dev)
+        else:
+            idx_t = indices.to(device=dev, dtype=torch.int32).contiguous()
+            B = int(idx_t.shape[0])
+            counts = torch.empty(2 * B, dtype=torch.int32, device=dev)
+            off = torch.empty(2 * B + 3, dtype=torch.int32, device=dev)
+            _lib.check(L.sln_graph_plan(C.byref(self._tab), _lib.ptr(idx_t), B, _lib.ptr(counts), _lib.ptr(off), st), "sln_graph_plan")
+            O, T, bad = (int(x) for x in off[[B, 2 * B + 1, 2 * B + 2]].tolist()) if B else (0, 0, 0)
+            if bad:
+                raise IndexError("%d room indices outside the table of %d rooms" % (bad, len(self)))
+            if B and int(counts[0::2].min()) < 3:
+                raise IndexError("Cannot choose from an empty sequence (a room of the batch has fewer than 2 objects)")
         if draws is None:
             other, swap, mode = self.device_draws(idx_t, off, O, generator)
         else:

@@ -546,8 +546,20 @@ def graph_build_leg(args, lib, torch):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.graph_iters
     O, T = int(out[1].shape[0]), int(out[3].shape[0])
+    # the trainer's form: indices on the HOST (a sampler's permutation) - sizes come from per-room counts taken once, nothing is
+    # read back per batch (round 3)
+    idx_h = idx.cpu()
+    for _ in range(20):
+        ds.build_batch(idx_h, generator=gen)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.graph_iters):
+        ds.build_batch(idx_h, generator=gen)
+    torch.cuda.synchronize()
+    dth = (time.perf_counter() - t0) / args.graph_iters
     nbytes = sum(int(t.numel()) * t.element_size() for t in out) + O * 6 * 4          # outputs + the raw boxes read
-    res = {"graphs_per_s": round(B / dt, 1), "us_per_batch": round(dt * 1e6, 1), "batch": B, "objects": O, "triples": T,
+    res = {"graphs_per_s": round(B / dt, 1), "us_per_batch": round(dt * 1e6, 1), "us_per_batch_host_indices": round(dth * 1e6, 1),
+           "graphs_per_s_host_indices": round(B / dth, 1), "batch": B, "objects": O, "triples": T,
            "algorithmic_bytes_per_batch": nbytes,
            "workload": "%d rooms x %d objects: 'on' pairs over all ordered pairs, one drawn relation per object, in-room rows, "
                        "normalised boxes, size attributes, collate offsets" % (B, args.objs - 1)}

@@ -434,6 +434,11 @@ typedef struct {
 int sln_graph_plan(const SlnRoomTable* tab /* host struct */, const int* room_idx, int B, int* counts, int* offsets, void* stream);
 int sln_graph_emit(const SlnRoomTable* tab /* host struct */, const int* room_idx, int B, const int* offsets,
                    const SlnGraphDraws* draws /* host struct */, const SlnGraphBatch* out /* host struct */, void* stream);
+/* The decisions of SlnGraphDraws drawn on the device (the reference draws them with python's `random`, suncg_dataset.py:189-196,
+ * 236-282): Philox keyed by key[0..1] (two 64-bit words in DEVICE memory - e.g. taken from a torch generator, which keeps its own
+ * stream position), one counter per non-room object of the batch (offsets as written by sln_graph_plan / planned on the host). */
+int sln_graph_draw(const SlnRoomTable* tab /* host struct */, const int* room_idx, int B, const int* offsets, const int64_t* key,
+                   int* other, unsigned char* swap, unsigned char* attr_mode, void* stream);
 
 #ifdef __cplusplus
 }

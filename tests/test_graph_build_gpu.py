@@ -98,6 +98,11 @@ def test_device_draws_large_batch_properties_and_oracle():
     ids, objs, boxes, triples, angles, attrs, o2i, t2i = (t.cpu().numpy() for t in ds.build_batch(idx, generator=gen))
     again = ds.build_batch(idx, generator=torch.Generator(device="cuda").manual_seed(3))
     assert np.array_equal(again[3].cpu().numpy(), triples) and np.array_equal(again[5].cpu().numpy(), attrs)
+    # host-side indices are planned on the host from per-room counts taken once (no read-back per batch); indices that live on
+    # the device go through sln_graph_plan + a read-back: same batch either way
+    on_dev = ds.build_batch(idx.cuda(), generator=torch.Generator(device="cuda").manual_seed(3))
+    for a, b in zip(on_dev, (ids, objs, boxes, triples, angles, attrs, o2i, t2i)):
+        assert np.array_equal(a.cpu().numpy(), b)
     n = np.array([len(rooms[i]["objs"]) for i in idx.tolist()])
     row0 = np.concatenate([[0], np.cumsum(n + 1)])
     assert objs.shape[0] == row0[-1] and np.array_equal(ids, idx.numpy())
@@ -186,3 +191,40 @@ def test_train_script_checkpoints_and_resumes(tmp_path, capsys):
     assert ck2["counters"]["t"] == 6 and float(ck2["optim_state"]["state"][0]["step"]) == 6.0 and ck2["losses_ts"] == [2, 4, 6]
     moved = max(float((ck2["model_state"][k] - ck["model_state"][k]).abs().max()) for k in ck["model_state"] if k.endswith(".weight"))
     assert 0 < moved < 1e-2
+
+
+def test_device_draw_kernel_has_the_reference_distributions():
+    """sln_graph_draw: the partner is uniform over the n - 1 OTHER objects of the room (random.choice, suncg_dataset.py:189-196), the
+    order flips with probability 1/2, the size attribute is 'none' with probability 1/2 (always for classes without statistics)
+    and height / volume with 1/4 each (:236-282); same generator state -> same draws, next call -> new draws."""
+    rooms, names, sd, sd30 = G.synth_rooms(300, seed=5, max_objs=12)
+    D = pkg("host.suncg_dataset")
+    ds = D.SuncgDataset.from_tables(rooms, names, sd, sd30)
+    idx = torch.randint(0, len(rooms), (8192,), generator=torch.Generator().manual_seed(2))
+    n = np.array([len(rooms[i]["objs"]) for i in idx.tolist()])
+    off = torch.from_numpy(np.concatenate([[0], np.cumsum(n + 1)]).astype(np.int32)).cuda()
+    idx_t = idx.int().cuda()
+    O = int(off[-1])
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    other, swap, mode = (t.cpu().numpy() for t in ds.device_draws(idx_t, off, O, gen))
+    o2, s2, m2 = (t.cpu().numpy() for t in ds.device_draws(idx_t, off, O, torch.Generator(device="cuda").manual_seed(11)))
+    assert np.array_equal(other, o2) and np.array_equal(swap, s2) and np.array_equal(mode, m2)
+    o3 = ds.device_draws(idx_t, off, O, gen)[0].cpu().numpy()
+    assert np.mean(o3 != other) > 0.3                                   # the generator moved on
+    cur = np.concatenate([np.arange(k) for k in n]); nn = np.repeat(n, n)
+    assert other.shape[0] == cur.shape[0] and np.all(other != cur) and np.all((other >= 0) & (other < nn))
+    N = other.shape[0]
+    assert abs(swap.mean() - 0.5) < 4 * 0.5 / np.sqrt(N)
+    # uniform partner: position of `other` among the n - 1 others, pooled over rooms of one size
+    for k in (3, 6, 10):
+        sel = nn == k
+        pos = np.where(other[sel] > cur[sel], other[sel] - 1, other[sel])
+        cnt = np.bincount(pos, minlength=k - 1)
+        exp = sel.sum() / (k - 1)
+        assert np.all(np.abs(cnt - exp) < 5 * np.sqrt(exp)), (k, cnt, exp)
+    cls = np.concatenate([np.asarray(rooms[i]["objs"]) for i in idx.tolist()])
+    known = ds._has_host[cls] != 0
+    assert np.all(mode[~known] == 0)
+    mk = mode[known]
+    for v, p in ((0, 0.5), (1, 0.25), (2, 0.25)):
+        assert abs(np.mean(mk == v) - p) < 5 * np.sqrt(p * (1 - p) / mk.shape[0]), (v, np.mean(mk == v))
