@@ -496,6 +496,21 @@ def render_leg(args, lib, torch, rank):
                                       "achieved": round(tr_pm / (us_pm * 1e-6) / 1e9, 1) if (tr_pm and us_pm) else None,
                                       "frac": round(tr_pm / (us_pm * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if (tr_pm and us_pm) else None,
                                       "note": "achieved = measured HBM traffic / duration (L2-resident scans: the kernel is latency / occupancy bound)"}}
+    # the streaming passes of the scene algebra against the HBM roofline: algorithmic bytes of one launch / its duration in the
+    # ONE-STREAM trace (profiles/<tag>_render_noside_kernel_stats.csv: with the side stream the durations of the two chains overlap)
+    plane_b = 256.0 * 256.0 * 4.0
+    live_planes = float((out[:, 1:41] > 0).flatten(2).any(2).sum().item())     # class planes with a visible pixel (the others are skipped)
+    stream_bytes = {"scene_compose_kernel": args.rooms * (70 * plane_b + 3 * plane_b),                       # 70 planes written, 3 maps read
+                    "scene_bwd_plane_sums_kernel": args.rooms * 29 * plane_b,                               # the depth-hot gradient planes, read
+                    "scene_bwd_grad_planes_kernel": live_planes * plane_b * 3,                              # the live class planes: read once, g and g^T written
+                    "scene_bwd_maps_kernel": args.rooms * (plane_b * 3 + 2 * 4 * plane_b)}                  # maps + own-class gradient read, two 16-byte records written
+    for kname, nbytes in stream_bytes.items():
+        _, us = profile_rows([kname], "render_noside")
+        res["roofline_kernels"][kname] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "avg_launch_us": us,
+                                          "algorithmic_bytes_per_launch": int(nbytes),
+                                          "achieved": round(nbytes / (us * 1e-6) / 1e9, 1) if us else None,
+                                          "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us else None, "traffic": None}
+    res["roofline_kernels"]["scene_bwd_grad_planes_kernel"]["note"] = "%d live class planes in the batch (planes of classes without a visible pixel are skipped)" % int(live_planes)
     if not args.no_dropin:
         res["render_33pass"] = render_33pass_leg(args, torch, per_render * 1e3)
     if not args.no_cpu:
@@ -991,6 +1006,12 @@ def main():
             out["cpu_baseline"]["value_at_16_threads"] = round(args.graphs / cdt16, 1)
 
     if rank == 0 and solo:
+        # the BASELINE configs first (render, SPADE), on a memory pool that has only seen the headline loop: behind the
+        # large-batch points (11 GB workspaces allocated and released) the scene backward measured 0.55 instead of 0.43 ms
+        if not args.no_render:
+            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
+        if not args.no_spade:
+            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
         if not args.no_cpu:
             log('c1 leg'); out["c1"] = c1_leg(args, torch, M)
         if not args.no_dropin:
@@ -998,10 +1019,6 @@ def main():
         sizes = [int(x) for x in args.large_batches.split(",") if x.strip()]
         if sizes:
             log('large-batch leg'); out["vae_large_batch"] = large_batch_leg(args, torch, M, syn, sizes)
-        if not args.no_render:
-            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
-        if not args.no_spade:
-            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
         if not args.no_graph_build:
             log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
         if not args.no_refine:
