@@ -110,6 +110,7 @@ SIGNATURES = {
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_set_deterministic": (C.c_int, [C.c_int]),
     "sln_get_deterministic": (C.c_int, []),
+    "sln_debug_tn_plan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "sln_prof_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "sln_vae_tap": (C.c_int64, [C.c_void_p, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_gconv_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

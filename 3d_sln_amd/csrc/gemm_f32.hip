@@ -329,3 +329,26 @@ int sln_launch_gemm_tn_multi(const GemmTNArgs* dev_probs, const TnMultiMeta* dev
   SLN_CHECK_LAUNCH();
   return 0;
 }
+
+// Host-only view of the planner for tests (no device work): problems given by their (rows, outputs, inputs); returns the number
+// of workgroups, writes rows_per_block[n] and one (problem, tile, chunk) triple per workgroup (problem < 0: padding).
+extern "C" int sln_debug_tn_plan(const int* R, const int* Nout, const int* Kin, int n, int* rows_per_block, int* items, int max_items) {
+  if (!R || !Nout || !Kin || !rows_per_block || !items || n < 1 || n > SLN_TN_MULTI_MAX) return -1;
+  static thread_local GemmTNArgs probs[SLN_TN_MULTI_MAX];
+  static thread_local TnMultiMeta meta;
+  std::memset(probs, 0, sizeof(GemmTNArgs) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    probs[i].R = R[i]; probs[i].Nout = Nout[i]; probs[i].Kin = Kin[i];
+    probs[i].G.nseg = 1; probs[i].X.nseg = 1; probs[i].lddw = i;          // lddw carries the caller's index through the planner
+  }
+  int blocks = 0; bool x2 = false, xg = false; double flops = 0.0;
+  const int r = sln_tn_multi_plan(probs, n, &meta, &blocks, &x2, &xg, &flops);
+  if (r) return r;
+  if (blocks > max_items) return -2;
+  for (int i = 0; i < n; ++i) rows_per_block[probs[i].lddw] = probs[i].rows_per_block;
+  for (int b = 0; b < blocks; ++b) {
+    const TnMultiItem& it = meta.item[b];
+    items[3 * b] = it.prob < 0 ? -1 : probs[it.prob].lddw; items[3 * b + 1] = it.tile; items[3 * b + 2] = it.chunk;
+  }
+  return blocks;
+}

@@ -181,8 +181,6 @@ struct SlnVae {
   int flush_deferred(int which, hipStream_t st) {
     if (deferred.empty()) return 0;
     const int set = capturing ? 0 : 1;
-    if (tn_slot_next[which] >= TN_SLOTS / 2) { deferred.clear(); return SLN_E_UNSUPPORTED; }
-    const int slot = which * (TN_SLOTS / 2) + tn_slot_next[which]++;
     hipStream_t lst = st;
     if (tn_side && side) {
       hipEvent_t e = next_event();
@@ -192,37 +190,43 @@ struct SlnVae {
       lst = side; tn_side_busy = true;
     }
     static thread_local TnGroup tmp;
+    // two kinds of problems (X rows gathered: every net1.0; plain rows: the rest), each in launches of at most SLN_TN_MULTI_MAX
+    // problems (a pass of the default model has 10 + 26; deeper stacks take more than one launch per kind)
     for (int k = 0; k < 2; ++k) {
-      tmp.n = 0;
-      for (const GemmTNArgs& t : deferred) {
-        bool gathers = false;
-        for (int s2 = 0; s2 < t.X.nseg; ++s2) gathers |= t.X.seg[s2].which != 0;
-        if ((int)gathers != k) continue;
-        if (tmp.n == SLN_TN_MULTI_MAX) { deferred.clear(); return SLN_E_UNSUPPORTED; }
-        tmp.probs[tmp.n++] = t;
-      }
-      if (tmp.n == 0) continue;
-      int r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
-      if (r) { deferred.clear(); return r; }
-      TnGroup& g = tn_group(set, slot, k);
-      if (g.n != tmp.n || std::memcmp(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n) != 0 ||
-          std::memcmp(&g.meta, &tmp.meta, sizeof(TnMultiMeta)) != 0) {
-        std::memcpy(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n);
-        g.meta = tmp.meta; g.n = tmp.n; g.blocks = tmp.blocks; g.x2 = tmp.x2; g.xg = tmp.xg; g.flops = tmp.flops;
-        g.dirty = true;
-      }
-      if (g.dirty) {
-        if (capturing) tn_upload_pending = true;
-        else {       // eager call with a new problem set (first call, new shape, other BatchNorm mode): rare, blocking
-          hipError_t e = hipStreamSynchronize(st);          // an earlier launch may still read the old table
-          if (e == hipSuccess && side) e = hipStreamSynchronize(side);
-          if (e != hipSuccess) { deferred.clear(); return (int)e; }
-          r = upload_group(g);
-          if (r) { deferred.clear(); return r; }
+      size_t next = 0;
+      while (next < deferred.size()) {
+        tmp.n = 0;
+        for (; next < deferred.size() && tmp.n < SLN_TN_MULTI_MAX; ++next) {
+          const GemmTNArgs& t = deferred[next];
+          bool gathers = false;
+          for (int s2 = 0; s2 < t.X.nseg; ++s2) gathers |= t.X.seg[s2].which != 0;
+          if ((int)gathers == k) tmp.probs[tmp.n++] = t;
         }
+        if (tmp.n == 0) continue;
+        if (tn_slot_next[which] >= TN_SLOTS / 2) { deferred.clear(); return SLN_E_UNSUPPORTED; }
+        const int slot = which * (TN_SLOTS / 2) + tn_slot_next[which]++;
+        int r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
+        if (r) { deferred.clear(); return r; }
+        TnGroup& g = tn_group(set, slot, k);
+        if (g.n != tmp.n || std::memcmp(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n) != 0 ||
+            std::memcmp(&g.meta, &tmp.meta, sizeof(TnMultiMeta)) != 0) {
+          std::memcpy(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n);
+          g.meta = tmp.meta; g.n = tmp.n; g.blocks = tmp.blocks; g.x2 = tmp.x2; g.xg = tmp.xg; g.flops = tmp.flops;
+          g.dirty = true;
+        }
+        if (g.dirty) {
+          if (capturing) tn_upload_pending = true;
+          else {       // eager call with a new problem set (first call, new shape, other BatchNorm mode): rare, blocking
+            hipError_t e = hipStreamSynchronize(st);          // an earlier launch may still read the old table
+            if (e == hipSuccess && side) e = hipStreamSynchronize(side);
+            if (e != hipSuccess) { deferred.clear(); return (int)e; }
+            r = upload_group(g);
+            if (r) { deferred.clear(); return r; }
+          }
+        }
+        r = sln_launch_gemm_tn_multi(g.dev_probs, g.dev_meta, g.blocks, g.x2, g.xg, g.flops, lst);
+        if (r) { deferred.clear(); return r; }
       }
-      r = sln_launch_gemm_tn_multi(g.dev_probs, g.dev_meta, g.blocks, g.x2, g.xg, g.flops, lst);
-      if (r) { deferred.clear(); return r; }
     }
     deferred.clear();
     return 0;
@@ -247,6 +251,7 @@ struct SlnVae {
   bool it_prologue = false;       // enc_assemble + both predicate gathers (+ the N(0,1) draw) already issued as ONE launch
   bool it_fused_loss = false;     // log_softmax is taken inside the loss kernel
   bool it_merge_bn = false;       // ONE running-statistics launch per iteration (after the decoder) and ONE parameter-gradient launch
+  bool no_merge = false;          // SLN_NO_MERGE=1 at creation: none of the three
   bool gconv_only = false;        // a bare GraphTripleConvNet (sln_gconv_net_*): units = the modules' four Linears, one net, no heads
   int unit_of(int net, int l, int k) const { return (gconv_only ? 0 : 8) + (net * nmod + (cfg.recurrent ? 0 : l)) * 4 + k; }
   int unit_boxnet(int k) const { return 8 + 2 * nmod * 4 + k; }
@@ -821,7 +826,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
     HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
     bulk_zeroed = true;
-    static const bool no_merge = std::getenv("SLN_NO_MERGE") != nullptr;          // A/B switch: the round-2 launch sequence
+    const bool no_merge = this->no_merge;                                         // SLN_NO_MERGE=1 (read at creation): the round-2 launch sequence
     it_prologue = it_fused_loss = !no_merge;
     it_merge_bn = !no_merge && (mode == TRAIN_BACKWARD || mode == TRAIN_FULL);    // the two-half form hands the decoder's gradients out early
     if (!it_prologue && draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
@@ -933,6 +938,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     h->use_dual = !(nd && nd[0] == '1');
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
+    { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
     h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
@@ -1315,6 +1321,7 @@ int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, 
   {
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
+    { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
     h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }

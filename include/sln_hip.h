@@ -191,6 +191,10 @@ int sln_prof_enable(int enable);
  * re-captured. */
 int sln_set_deterministic(int on);
 int sln_get_deterministic(void);
+/* Test hook (host only, no device work): the workgroup table of the per-pass wgrad launch (csrc/sln_gemm.h: TnMultiMeta) for n
+ * problems given as (rows, outputs, inputs).  Returns the number of workgroups (< 0: error), fills rows_per_block[n] and
+ * items[3 * workgroup] = (problem or -1 for padding, output tile, row chunk). */
+int sln_debug_tn_plan(const int* R, const int* Nout, const int* Kin, int n, int* rows_per_block, int* items, int max_items);
 int sln_prof_read(double* ms_by_family, double* work_by_family, int64_t* launches_by_family, int n_families);
 
 /* Debug/test tap: copy an internal activation to `dst` (device).  what: 0 A1,1 A2,2 M,3 A3,4 A4 of

@@ -945,11 +945,15 @@ def test_validation_forward_between_training_steps_leaves_training_untouched():
         assert_close(res[True][3][k], res[False][3][k], k, rtol=3e-3, atol=1e-6)     # second-step statistics see the +-lr Adam noise of the first (up to 3e-4 seen)
 
 
-@pytest.mark.parametrize("env", [{"SLN_NO_GROUP": "1"}, {"SLN_NO_DUAL": "1"}, {"SLN_NO_DUAL": "1", "SLN_NO_SIDE_STREAM": "1"}])
+@pytest.mark.parametrize("env", [{"SLN_NO_GROUP": "1"}, {"SLN_NO_DUAL": "1"}, {"SLN_NO_DUAL": "1", "SLN_NO_SIDE_STREAM": "1"},
+                                 {"SLN_NO_DEFER": "1"}, {"SLN_NO_DEFER": "1", "SLN_NO_GROUP": "1"}, {"SLN_NO_DEFER": "1", "SLN_NO_DUAL": "1"},
+                                 {"SLN_NO_DEFER": "1", "SLN_NO_DUAL": "1", "SLN_NO_SIDE_STREAM": "1"}, {"SLN_NO_MERGE": "1"},
+                                 {"SLN_TN_SIDE": "1"}, {"SLN_TN_PER_LAYER": "1"}, {"SLN_TN_SIDE": "1", "SLN_TN_PER_LAYER": "1"}])
 def test_unmerged_launch_paths_give_the_same_step(env):
-    """The merged launches (dgrad + wgrad in one grid, the twin branches grouped) fall back to separate launches - wgrads on a
-    side stream, or everything on one stream - for shapes they do not cover; the switches that force those paths for a whole
-    engine must reproduce the default step (loss, every gradient, BatchNorm buffers)."""
+    """The default step runs every wgrad of a pass in one launch and merges its bookkeeping launches (round 3); before that the dgrad
+    and the wgrad of a Linear shared a grid and the twin branches were grouped (SLN_NO_DEFER=1), with fall-backs to separate launches
+    - wgrads on a side stream, or everything on one stream.  Every switch that selects another launch structure for a whole engine
+    must reproduce the default step (loss, every gradient, BatchNorm buffers)."""
     import os
     cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=3)
     sd = vae_ref.init_state(cfg, seed=8)
