@@ -8,10 +8,12 @@
 //
 //   gemm_nt : Y[M,N]  = op(A)[M,K] * W[N,K]^T (+bias)        forward Linear and dgrad (with W^T)
 //   gemm_tn : dW[N,K] += op(G)[R,N]^T * op(X)[R,K]            wgrad, split over row chunks
+//   gemm_tn_multi : every wgrad of a backward pass in ONE launch (problem table + one item per workgroup in device memory,
+//                   XCD-grouped, ~768-row chunks; sln_tn_multi_plan builds the table on the host)
 //
-// LDS tiles are k-major ([BK][rows+pad]); each lane feeds the MFMA with one ds_read_b32 per
-// operand (conflict-free: consecutive lanes -> consecutive rows).  Global->LDS staging goes
-// through registers (transform on the way), double-buffered so one barrier per K tile.
+// NT: k-contiguous LDS tiles ([rows][BK + 4]: one ds_read_b128 feeds four MFMAs); TN: row-major tiles as the rows arrive, the
+// waves split a tile's rows (gemm_bodies.h).  Global->LDS staging goes through registers (the BatchNorm / ReLU / gather
+// transform happens on the way), double-buffered so one barrier per K tile.
 #include <algorithm>
 #include <vector>
 #include "gemm_bodies.h"

@@ -2,7 +2,9 @@
 // models/Sg2ScVAE_model.py:115-188, models/graph.py:57-143, utils.py:12-33, train.py:62-84) and
 // exposes it through the C ABI of include/sln_hip.h.  One engine per process/GPU; every call
 // enqueues kernels on the caller's stream.  A whole training iteration (zero_grad, forward, loss,
-// backward, Adam) is ~200 launches, captured once into a hipGraph and replayed.
+// backward, Adam) is 145 launches at train.py's defaults (one per forward Linear / dgrad, 30 edge
+// launches, FOUR wgrad launches - every wgrad of a pass runs in one multi-problem grid, see
+// flush_deferred -, a dozen bookkeeping launches), captured once into a hipGraph and replayed.
 #include <new>
 #include <vector>
 #include <cstring>
