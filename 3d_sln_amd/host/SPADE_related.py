@@ -114,6 +114,15 @@ class SPADEGenerator4(nn.Module):
         self.unfused = False          # True: one launch per module (the round-1 schedule; kept for A/B runs and odd sizes)
 
     # ------------------------------------------------------------------ weight packing
+    reuse_map_planes = True          # see forward(): gamma|beta planes of a map kept between consecutive batch-1 calls on it
+    _map_repeat = False
+    _map_memo = None
+    _pack_gen = 0
+
+    def clear_map_cache(self):
+        """Drop the gamma|beta planes kept for the last semantic map (about 0.2 GB at 256x256)."""
+        self._map_memo = None
+
     def _pack_all(self):
         sd = {k: v.detach().float() for k, v in self.state_dict().items()}
         key = tuple((v.data_ptr(), v._version) for v in self.state_dict().values())
@@ -146,6 +155,7 @@ class SPADEGenerator4(nn.Module):
         P["fc_w"], P["fc_b"] = sd["fc.weight"].contiguous(), sd["fc.bias"].contiguous()
         P["img_w"], P["img_b"] = sd["conv_img.weight"].contiguous(), sd["conv_img.bias"].contiguous()
         self._packed, self._packed_key = P, key
+        self._pack_gen += 1              # new weights: planes kept for a map are stale (forward() compares this)
         return P
 
     # ------------------------------------------------------------------ HIP launches
@@ -168,7 +178,7 @@ class SPADEGenerator4(nn.Module):
         B, C = x.shape[:2]
         H, W = seg.shape[2:]
         nd = NHIDDEN // 8
-        if seg.shape[0] == 1 and B > 1 and (H * W) % 4 == 0:
+        if seg.shape[0] == 1 and (B > 1 or self._map_repeat) and (H * W) % 4 == 0:
             return self._spade_shared(e, x, stats, seg, leaky, x_up)
         if seg.shape[0] != B:
             seg = seg.expand(B, -1, -1, -1).contiguous()
@@ -206,15 +216,20 @@ class SPADEGenerator4(nn.Module):
         B, C = x.shape[:2]
         H, W = seg.shape[2:]
         nd = NHIDDEN // 8
-        cat = self._cat_buffer(seg, nd)
-        _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), 1, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
-                                            _lib.ptr(cat), 0, self._st()), "sln_spade_depth_concat")
-        actv = torch.empty(1, NHIDDEN, H, W, device=x.device)
-        _lib.check(L.sln_spade_conv(_lib.ptr(cat), 1, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
-                                    1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
-        gb = torch.empty(1, e["rpg"], H, W, device=x.device)
-        _lib.check(L.sln_spade_conv(_lib.ptr(actv), 1, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), e["rpg"], e["rpg"], 3,
-                                    0, 0.0, _lib.ptr(gb), self._st()), "sln_spade_conv(gamma|beta)")
+        memo = self._map_memo["gb"] if self._map_repeat else None          # gamma|beta planes of THIS map, kept between calls
+        gb = memo.get(id(e)) if memo is not None else None
+        if gb is None:
+            cat = self._cat_buffer(seg, nd)
+            _lib.check(L.sln_spade_depth_concat(_lib.ptr(seg), 1, seg.shape[1], H, W, _lib.ptr(e["wpd"]), _lib.ptr(e["bpd"]), nd,
+                                                _lib.ptr(cat), 0, self._st()), "sln_spade_depth_concat")
+            actv = torch.empty(1, NHIDDEN, H, W, device=x.device)
+            _lib.check(L.sln_spade_conv(_lib.ptr(cat), 1, cat.shape[1], H, W, _lib.ptr(e["wsh"]), _lib.ptr(e["bsh"]), NHIDDEN, e["rps"], 3,
+                                        1, 0.0, _lib.ptr(actv), self._st()), "sln_spade_conv(shared)")
+            gb = torch.empty(1, e["rpg"], H, W, device=x.device)
+            _lib.check(L.sln_spade_conv(_lib.ptr(actv), 1, NHIDDEN, H, W, _lib.ptr(e["wgb"]), _lib.ptr(e["bgb"]), e["rpg"], e["rpg"], 3,
+                                        0, 0.0, _lib.ptr(gb), self._st()), "sln_spade_conv(gamma|beta)")
+            if memo is not None:
+                memo[id(e)] = gb
         out = torch.empty(B, C, H, W, device=x.device)
         _lib.check(L.sln_spade_apply_up(_lib.ptr(x), 1 if x_up else 0, _lib.ptr(gb), B, C, H, W, e["rpg"], _lib.ptr(stats),
                                         2 if leaky else 0, 0.2, _lib.ptr(out), self._st()), "sln_spade_apply_up")
@@ -314,6 +329,17 @@ class SPADEGenerator4(nn.Module):
                 z = torch.randn(B, self.nz, dtype=torch.float32, device=seg.device)
             P = self._pack_all()
             L = _lib.lib()
+            # colorize_with_spade calls the model once per z with the SAME semantic map (testing/test_SPADE_shade.py:77-79: 50 calls
+            # at batch 1).  gamma / beta depend on the map only - 72 % of the MACs -: from the SECOND consecutive call with the very
+            # same input tensor (same object, unmodified: data pointer, shape and version counter; same packed parameters; same
+            # stream) the planes are computed once, kept, and the later calls run only the per-sample part.  (The first call of a
+            # map takes the fused path, which never materialises them: single calls on ever-new maps pay nothing.)
+            mkey = (input.data_ptr(), input._version, tuple(input.shape), input.dtype, self._pack_gen,
+                    int(torch.cuda.current_stream().cuda_stream))
+            memo = getattr(self, "_map_memo", None)
+            self._map_repeat = bool(self.reuse_map_planes and seg.shape[0] == 1 and memo is not None and memo["key"] == mkey)
+            if not self._map_repeat:
+                self._map_memo = dict(key=mkey, gb={}, keep=input if seg.shape[0] == 1 and self.reuse_map_planes else None)
             self._cat_cache = {}                                      # per-forward: keyed by the pyramid level's storage
             nfc = 16 * self.nf * self.sw * self.sh
             x = torch.empty(B, nfc, device=seg.device)

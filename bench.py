@@ -310,21 +310,29 @@ def render_33pass_leg(args, torch, fused_ms_per_room):
 
 
 def spade_50x1_leg(args, torch, G, seg, batched_img_per_s):
-    """testing/test_SPADE_shade.py:77-79 unchanged: for each of 50 z vectors, colorization_model(total, z) at batch 1."""
+    """testing/test_SPADE_shade.py:77-79 unchanged: for each of 50 z vectors, colorization_model(total, z) at batch 1, on the
+    same tensor `total` - from the second call the generator keeps the map's gamma|beta planes (host/SPADE_related.py).  Timed as
+    the reference runs it (a NEW map, then its 50 calls); `without_kept_planes` is the same loop with the reuse switched off."""
     g = torch.Generator(device="cuda").manual_seed(1)
     zs = [torch.randn(1, 256, device="cuda", generator=g) for _ in range(50)]
-    total = seg[:1]
-    with torch.no_grad():
-        for z in zs[:3]:
-            G(total, z)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for z in zs:
-            img = G(total, z)
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"workload": "50 x colorization_model(total[1,41,256,256], z[1,256]), one call per z", "ms_per_room_of_50": round(dt * 1e3, 2),
-            "images_per_s": round(50 / dt, 1), "ratio_to_batch_path": round((50 / dt) / batched_img_per_s, 3),
-            "finite": bool(torch.isfinite(img).all().item())}
+    res = {"workload": "50 x colorization_model(total[1,41,256,256], z[1,256]), one call per z, a new map per room"}
+    for key, reuse in (("kept_planes", True), ("without_kept_planes", False)):
+        G.reuse_map_planes = reuse
+        with torch.no_grad():
+            for z in zs[:3]:
+                G(seg[1:2].contiguous(), z)
+            total = seg[:1].clone()                                  # a new room: a tensor the generator has not seen
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for z in zs:
+                img = G(total, z)
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[key] = {"ms_per_room_of_50": round(dt * 1e3, 2), "images_per_s": round(50 / dt, 1),
+                    "ratio_to_batch_path": round((50 / dt) / batched_img_per_s, 3), "finite": bool(torch.isfinite(img).all().item())}
+    G.reuse_map_planes = True
+    G.clear_map_cache()
+    res["images_per_s"] = res["kept_planes"]["images_per_s"]
+    return res
 
 
 # --------------------------------------------------------------------------------------------------------------- legs

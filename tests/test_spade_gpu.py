@@ -309,3 +309,43 @@ def test_both_conv_kernels_carry_both_epilogues(env):
                         "conv_against_torch_cpu or fused_spade_modulation or conv_epilogue_sums or fused_schedule"],
                        env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_batch_one_calls_on_the_same_map_reuse_its_planes_and_nothing_stale():
+    """testing/test_SPADE_shade.py:77-79 calls the model once per z on the SAME tensor `total`: from the second consecutive call
+    the gamma|beta planes of that map are kept (round 3).  Every call must equal the oracle's answer for its z; a modified map
+    (in place: same address, new version counter), another map at a recycled address, new weights, and the switch
+    `reuse_map_planes = False` must all give fresh answers."""
+    S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
+    sd = spade_ref.init_state(cfg, seed=7)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, _ = spade_ref.synth_input(cfg, 1, seed=5)
+    zs = torch.from_numpy(np.random.default_rng(4).standard_normal((5, cfg.nz)).astype(np.float32))
+    ref = spade_ref.generator(sd, cfg, seg, zs).numpy()
+    total = seg.cuda()
+    outs = [G(total, zs[k:k + 1].cuda()) for k in range(5)]            # call 1: fused path; call 2: planes built; calls 3-5: reused
+    assert G._map_repeat and len(G._map_memo["gb"]) > 0
+    for k in range(5):
+        assert_close(outs[k].cpu().numpy(), ref[k:k + 1], "call %d on the same map" % k, rtol=1e-4, atol=1e-4)
+    G.reuse_map_planes = False
+    plain = [G(total, zs[k:k + 1].cuda()) for k in range(5)]
+    G.reuse_map_planes = True
+    for k in range(5):
+        assert_close(outs[k].cpu().numpy(), plain[k].cpu().numpy(), "kept planes vs fused path, call %d" % k, rtol=1e-5, atol=1e-4)
+    # the map changes in place: same address, new version -> fresh planes
+    G(total, zs[:1].cuda()); G(total, zs[:1].cuda())
+    seg2, _ = spade_ref.synth_input(cfg, 1, seed=6)
+    total.copy_(seg2.cuda())
+    ref2 = spade_ref.generator(sd, cfg, seg2, zs[:1]).numpy()
+    for _ in range(3):
+        assert_close(G(total, zs[:1].cuda()).cpu().numpy(), ref2, "map modified in place", rtol=1e-4, atol=1e-4)
+    # new weights: the kept planes are stale
+    sd8 = spade_ref.init_state(cfg, seed=8)
+    G.load_state_dict(sd8)
+    ref3 = spade_ref.generator(sd8, cfg, seg2, zs[:1]).numpy()
+    for _ in range(3):
+        assert_close(G(total, zs[:1].cuda()).cpu().numpy(), ref3, "weights reloaded", rtol=1e-4, atol=1e-4)
+    G.clear_map_cache()
+    assert G._map_memo is None
