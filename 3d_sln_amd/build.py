@@ -14,7 +14,7 @@ OUT = os.path.join(HERE, "libsln_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
-         "-I" + os.path.join(os.path.dirname(HERE), "include")]
+         "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("SLN_HIPCC_EXTRA", "").split()   # lab: -DSLN_NT_SCHED=0 ...
 # raster kernels: bit-exact agreement with the CPU restatement needs contraction off (see raster.hip)
 # placement: the torch expression it replaces rounds after every elementwise op
 PER_FILE = {"raster.hip": ["-ffp-contract=off"], "graph_build.hip": ["-ffp-contract=off"], "placement.hip": ["-ffp-contract=off"]}

@@ -16,28 +16,45 @@ namespace {
 #define SLN_TRACE(i)
 #endif
 
+// 1: the 64 x 64 NT tile runs its K loop in a hand-ordered schedule (see gemm_nt_body); 0: hipcc's order (lab A/B)
+#ifndef SLN_NT_SCHED
+#define SLN_NT_SCHED 1
+#endif
+#ifndef SLN_ABL           // tools/lab/gemm_lab.hip only: leave parts of the scheduled loop out (1 loads, 2 LDS writes, 4 barrier, 8 fragment reads)
+#define SLN_ABL 0
+#endif
+
 constexpr int BK = 32;
 constexpr int TN_PAD = 32;     // LDS row padding of the TN (wgrad) tiles, see gemm_tn_body
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// v_max_f32 as the instruction: fmaxf() makes hipcc canonicalise both inputs first (one more v_max_f32 per coefficient that comes out
+// of LDS), and every VALU instruction of a GEMM wave is paid in matrix-pipe time (tools/lab/overlap.hip).  Same result: the
+// hardware instruction quiets NaNs itself.
+__device__ __forceinline__ float sln_vmax(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ float4 xform(float4 x1, float4 x2, const float4* cf) {
   float4 r;
   float4 c;
-  c = cf[0]; r.x = fmaxf(fmaf(c.x, x1.x, fmaf(c.y, x2.x, c.z)), c.w);
-  c = cf[1]; r.y = fmaxf(fmaf(c.x, x1.y, fmaf(c.y, x2.y, c.z)), c.w);
-  c = cf[2]; r.z = fmaxf(fmaf(c.x, x1.z, fmaf(c.y, x2.z, c.z)), c.w);
-  c = cf[3]; r.w = fmaxf(fmaf(c.x, x1.w, fmaf(c.y, x2.w, c.z)), c.w);
+  c = cf[0]; r.x = sln_vmax(fmaf(c.x, x1.x, fmaf(c.y, x2.x, c.z)), c.w);
+  c = cf[1]; r.y = sln_vmax(fmaf(c.x, x1.y, fmaf(c.y, x2.y, c.z)), c.w);
+  c = cf[2]; r.z = sln_vmax(fmaf(c.x, x1.z, fmaf(c.y, x2.z, c.z)), c.w);
+  c = cf[3]; r.w = sln_vmax(fmaf(c.x, x1.w, fmaf(c.y, x2.w, c.z)), c.w);
   return r;
 }
 
 // single-source operands: fmaf(c.y, 0, c.z) == c.z, so this is xform(x1, 0, cf) bit for bit without keeping c.y alive
 __device__ __forceinline__ float4 xform1(float4 x1, const float4* cf) {
   float4 r;
-  r.x = fmaxf(fmaf(cf[0].x, x1.x, cf[0].z), cf[0].w);
-  r.y = fmaxf(fmaf(cf[1].x, x1.y, cf[1].z), cf[1].w);
-  r.z = fmaxf(fmaf(cf[2].x, x1.z, cf[2].z), cf[2].w);
-  r.w = fmaxf(fmaf(cf[3].x, x1.w, cf[3].z), cf[3].w);
+  r.x = sln_vmax(fmaf(cf[0].x, x1.x, cf[0].z), cf[0].w);
+  r.y = sln_vmax(fmaf(cf[1].x, x1.y, cf[1].z), cf[1].w);
+  r.z = sln_vmax(fmaf(cf[2].x, x1.z, cf[2].z), cf[2].w);
+  r.w = sln_vmax(fmaf(cf[3].x, x1.w, cf[3].z), cf[3].w);
   return r;
 }
 
@@ -97,7 +114,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   static_assert(WM * WN == 4, "4 waves per block");
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);
-  float* As = reinterpret_cast<float*>(coef + kpad);      // [2][BM][LDT]
+  float* As = reinterpret_cast<float*>(coef + kpad + 4);  // [2][BM][LDT]; coef[kpad .. kpad + 3] = 0 (surplus tiles of the scheduled loop)
   float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
   float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2] floats (EPI_MASK) or doubles (EPI_STATS)
@@ -192,7 +209,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 
   if (!IDENT) {
     sln_fill_coefs(a.A, coef, tid, NT);
-    for (int c = a.K + tid; c < kpad; c += NT) coef[c] = z4;
+    for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
   }
   if (EPI == EPI_MASK) {
     for (int c = tid; c < BN; c += NT) {
@@ -225,7 +242,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   // neither the barrier nor the LDS read latency leaves the matrix pipe idle (each wave has a single dependent MFMA
   // chain when the wave tile is 32x32, nothing else could cover them).
   float4 fa[2][TM], fb[2][TN];
-  auto rd = [&](int buf, int kb, auto set) {
+  auto rd = [&](int buf, int kb, auto set) __attribute__((always_inline)) {
     constexpr int F = decltype(set)::value;
     const float* as = As + buf * BM * LDT + (wm0 + lrow) * LDT + 4 * lk + kb;
     const float* bs = Bs + buf * BN * LDT + (wn0 + lrow) * LDT + 4 * lk + kb;
@@ -273,6 +290,136 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   // surplus tile of zeros.  With three stages and separate remainder bodies behind the loop (round 1) hipcc could not keep the
   // register stages in place: it copied all of them (and the accumulators) at the top of every iteration, and a copy of a
   // register with a load in flight is an s_waitcnt vmcnt(0) - 16 v_mov_b64 + 16 v_accvgpr_mov behind a vmcnt(0) per 3 tiles.
+#if SLN_NT_SCHED
+  // ---- 64 x 64 tile: the same loop with its instruction ORDER written out ---------------------------------------------------
+  // A wavefront owns one 32 x 32 accumulator: its 16 MFMAs per K tile form ONE dependent chain, issue is in order, so MFMA n+1
+  // waits at the issue stage until MFMA n leaves the pipe (64 cycles) - and everything hipcc schedules BEHIND a group of four
+  // MFMAs (the staging arithmetic of the next tile, its LDS writes, the fragment reads, the global loads) only starts when the
+  // last of the four has issued: it overlaps with 64 of the group's 256 cycles and the rest runs with the matrix pipe idle
+  // (tools/lab/gemm_lab.hip: ~1 760 clocks per K tile for ~1 000 of MFMA, one workgroup per CU).  Here every MFMA is followed by
+  // the piece of other work that fits under it, and sched_barrier(0) keeps hipcc from regrouping:
+  //   c0.x  B rows 0-31: mask, ds_write, reload        c1.x  A rows 32-63: transform        c2.*  (nothing: LDS writes land,
+  //   c0.y  B rows 32-63: the same                     c1.y  A rows 32-63: mask, write,            the loads fly)
+  //   c0.z  A rows 0-31: BatchNorm / ReLU transform          reload                          -- barrier --
+  //   c0.w  A rows 0-31: mask, write, reload;          c1.w  fragments of chunk 3            c3.x  next tile's segment / masks
+  //         fragments of chunk 2                                                             c3.y  next tile's coefficients
+  // A register stage is reloaded in the slot that stored it (two K tiles of flight time for every load); the per-tile scalars
+  // and the four coefficient rows of the NEXT body are fetched under the four MFMAs behind the barrier (loop-carried registers).
+  // Arithmetic and summation order are those of the loop above: results are bit-identical.
+  if constexpr (TM == 1 && TN == 1) {
+    // No masks in this loop.  Rows behind M and weight rows behind N are loaded from clamped (valid) addresses and only reach output
+    // rows / columns that the epilogue drops.  Columns behind K: the staged operand is EXACTLY zero there because its coefficient
+    // rows are (coef[K .. kpad) and the four rows at coef[kpad], which a surplus tile of an odd tile count is pointed at), so the
+    // clamped - finite - weight columns meet zeros.  Identity operands (no coefficients) keep a column mask.  A v_cndmask costs 8
+    // clocks of the SIMD and VALU work does NOT run in the shadow of the wave's own MFMAs (tools/lab/overlap.hip: 64 clocks per
+    // MFMA alone, + 4.7 per v_fma, + 8 per v_cndmask behind it; half of that with a second wave on the SIMD).
+    struct Plan { bool cv, x2v; int coff; unsigned cw, cs; const float* pa1[PA]; const float* pa2[PA]; };
+    const float* rowB[PB];
+#pragma unroll
+    for (int q = 0; q < PB; ++q) rowB[q] = Wp + (size_t)min(n0 + r0 + RP * q, Nr - 1) * ldw;
+    const float* rowA1[PA]; const float* rowA2[PA];      // single-segment operands: the row pointers are loop invariants
+#pragma unroll
+    for (int q = 0; q < PA; ++q) {
+      const Seg& g = a.A.seg[0];
+      rowA1[q] = g.x1 + (size_t)rid[q] * g.ld1 + g.c1;
+      rowA2[q] = g.x2 ? g.x2 + (size_t)rid[q] * g.ld2 + g.c2 : rowA1[q];
+    }
+    auto plan = [&](int kt) __attribute__((always_inline)) {               // body(kt) stores tile kt + 1 and loads tile kt + 3
+      Plan p;
+      const int ks_raw = kt + 1, ks = min(ks_raw, last), k0 = ks * BK, col = k0 + 4 * kq;
+      const SegSel ss = pick_seg<MULTI>(a.A, k0, col);
+      p.cv = col < ss.end && ks_raw <= last;
+      p.x2v = HAS_X2 && ss.x2 != nullptr;
+      p.coff = ks_raw <= last ? col : kpad;
+      const int l0 = min(kt + 3, last) * BK;
+      const SegSel sl = pick_seg<MULTI>(a.A, l0, l0 + 4 * kq);
+      p.cs = (unsigned)(min(l0 + 4 * kq, sl.end - 4) - sl.base);
+      p.cw = (unsigned)min(l0 + 4 * kq, Kr - 4);
+      if (MULTI) {
+        const float* x2 = sl.x2 ? sl.x2 : sl.x1;                   // block-uniform select
+        const int ld2 = sl.x2 ? sl.ld2 : sl.ld1, c2 = sl.x2 ? sl.c2 : sl.c1;
+        const int mw1 = -(int)(sl.which == 1), mw2 = -(int)(sl.which == 2);
+#pragma unroll
+        for (int q = 0; q < PA; ++q) {
+          // (bit masks instead of ?: - hipcc turns a select between array elements into an indexed load from a scratch copy)
+          const int r = (rid[q] & ~(mw1 | mw2)) | (ra_idx[q] & mw1) | (rb_idx[q] & mw2);
+          p.pa1[q] = sl.x1 + (size_t)r * sl.ld1 + sl.c1;
+          p.pa2[q] = HAS_X2 ? x2 + (size_t)r * ld2 + c2 : nullptr;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PA; ++q) { p.pa1[q] = nullptr; p.pa2[q] = nullptr; }      // unused: rowA1 / rowA2
+      }
+      return p;
+    };
+    Plan pl = plan(0);
+    float4 cfr[4] = {z4, z4, z4, z4};
+    if (!IDENT) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cfr[j] = coef[pl.coff + j];
+    }
+#define SLN_SB __builtin_amdgcn_sched_barrier(0)
+    auto stB = [&](int buf, int p, auto stage) __attribute__((always_inline)) {
+      constexpr int S = decltype(stage)::value;
+      if (!(SLN_ABL & 2)) *reinterpret_cast<float4*>(Bs + buf * BN * LDT + (r0 + RP * p) * LDT + 4 * kq) = gb[S][p];
+      if (!(SLN_ABL & 1)) gb[S][p] = ld4(rowB[p] + pl.cw);
+    };
+    auto xfA = [&](int p, auto stage) __attribute__((always_inline)) -> float4 {
+      constexpr int S = decltype(stage)::value;
+      // a segment without a second source has c.y == 0 (sln_coef_for) and its ga2 holds x1 again: fma(0, x1, c.z) = c.z, no select
+      return IDENT ? ga1[S][p] : (HAS_X2 ? xform(ga1[S][p], ga2[S][p], cfr) : xform1(ga1[S][p], cfr));
+    };
+    auto wrA = [&](int buf, int p, float4 t, auto stage) __attribute__((always_inline)) {
+      constexpr int S = decltype(stage)::value;
+      if (IDENT) { const bool v = pl.cv; t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f; }
+      if (!(SLN_ABL & 2)) *reinterpret_cast<float4*>(As + buf * BM * LDT + (r0 + RP * p) * LDT + 4 * kq) = t;
+      if (!(SLN_ABL & 1)) {
+        ga1[S][p] = ld4((MULTI ? pl.pa1[p] : rowA1[p]) + pl.cs);
+        if (HAS_X2) ga2[S][p] = ld4((MULTI ? pl.pa2[p] : rowA2[p]) + pl.cs);
+      }
+    };
+    auto mf = [&](auto set, auto comp) __attribute__((always_inline)) {
+      constexpr int F = decltype(set)::value;
+      constexpr int C = decltype(comp)::value;
+      const float av = C == 0 ? fa[F][0].x : (C == 1 ? fa[F][0].y : (C == 2 ? fa[F][0].z : fa[F][0].w));
+      const float bv = C == 0 ? fb[F][0].x : (C == 1 ? fb[F][0].y : (C == 2 ? fb[F][0].z : fb[F][0].w));
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[0][0], 0, 0, 0);
+    };
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>; using C3 = std::integral_constant<int, 3>;
+    auto sbody = [&](int kt, auto stage_next) __attribute__((always_inline)) {
+      const int buf = kt & 1;
+      if (!(SLN_ABL & 8)) rd(buf, 8, S1{});
+      SLN_SB;
+      mf(S0{}, C0{}); SLN_SB; stB(buf ^ 1, 0, stage_next); SLN_SB;
+      mf(S0{}, C1{}); SLN_SB; stB(buf ^ 1, 1, stage_next); SLN_SB;
+      mf(S0{}, C2{}); SLN_SB; float4 t0 = xfA(0, stage_next); SLN_SB;
+      mf(S0{}, C3{}); SLN_SB; wrA(buf ^ 1, 0, t0, stage_next); if (!(SLN_ABL & 8)) rd(buf, 16, S0{}); SLN_SB;
+      mf(S1{}, C0{}); SLN_SB; float4 t1 = xfA(1, stage_next); SLN_SB;
+      mf(S1{}, C1{}); SLN_SB; wrA(buf ^ 1, 1, t1, stage_next); SLN_SB;
+      mf(S1{}, C2{}); SLN_SB;
+      mf(S1{}, C3{}); SLN_SB; if (!(SLN_ABL & 8)) rd(buf, 24, S1{}); SLN_SB;
+      mf(S0{}, C0{}); SLN_SB;
+      mf(S0{}, C1{}); SLN_SB;
+      mf(S0{}, C2{}); SLN_SB;
+      mf(S0{}, C3{}); SLN_SB;
+      if (!(SLN_ABL & 4)) __syncthreads();
+      if (!(SLN_ABL & 8)) rd(buf ^ 1, 0, S0{});
+      SLN_SB;
+      mf(S1{}, C0{}); SLN_SB; pl = plan(kt + 1); SLN_SB;
+      mf(S1{}, C1{}); SLN_SB;
+      if (!IDENT) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cfr[j] = coef[pl.coff + j];
+      }
+      SLN_SB;
+      mf(S1{}, C2{}); SLN_SB;
+      mf(S1{}, C3{}); SLN_SB;
+    };
+#undef SLN_SB
+    for (int kt = 0; kt < ntiles; kt += 2) { sbody(kt, S1{}); sbody(kt + 1, S0{}); }
+  } else
+#endif
   for (int kt = 0; kt < ntiles; kt += 2) { body(kt, S1{}); body(kt + 1, S0{}); }
 
   // ------------------------------- epilogue -------------------------------
@@ -651,10 +798,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int rl = ra0 + RPA * p;
-      const bool v = gs.valid && (rbeg + rt * BK + rl) < rend;
+      // Masks cost matrix-pipe time (8 clocks per v_cndmask, tools/lab/overlap.hip), so only the one that is needed stays: G rows
+      // behind the chunk's end are zeroed - a zero row of G adds nothing to dW or db whatever the (clamped, finite) row of X holds.
+      // Columns behind the operand's width come out as exact zeros by themselves (their coefficient rows are zero), and a segment
+      // without a second source has c.y == 0 and reads x1 twice.
+      const bool v = (rbeg + rt * BK + rl) < rend;
       // two-source gradients (BatchNorm backward) keep their coefficients in LDS: with them in registers the dgrad + wgrad kernels
       // need 172-180 registers and lose the third workgroup per CU
-      float4 t = G_X2 ? xform(g1[S][p], gs.x2 ? g2[S][p] : z4, coefG + ca) : xform1(g1[S][p], cG);
+      float4 t = G_X2 ? xform(g1[S][p], g2[S][p], coefG + ca) : xform1(g1[S][p], cG);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
       *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
@@ -662,10 +813,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
 #pragma unroll
     for (int p = 0; p < PB; ++p) {
       const int rl = rb0 + RPB * p;
-      const bool v = xs.valid && (rbeg + rt * BK + rl) < rend;
-      float4 t = xform1(x1[S][p], cX);
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = t;
+      *reinterpret_cast<float4*>(Bs + buf * BK * SB + rl * SB + cb) = xform1(x1[S][p], cX);
     }
   };
 
@@ -806,7 +954,7 @@ inline bool tn_supported(const GemmTNArgs& a) {     // the gradient operand is a
 
 inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)kpad * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 16;
+  return (size_t)(kpad + 4) * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 16;
 }
 
 inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + TN_PAD + BN + TN_PAD) * 4; }
