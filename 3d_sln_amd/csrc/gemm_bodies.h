@@ -362,6 +362,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     auto stB = [&](int buf, int p, auto stage) __attribute__((always_inline)) {
       constexpr int S = decltype(stage)::value;
       if (!(SLN_ABL & 2)) *reinterpret_cast<float4*>(Bs + buf * BN * LDT + (r0 + RP * p) * LDT + 4 * kq) = gb[S][p];
+      SLN_SB;      // the reload stays behind the write (hipcc otherwise loads into fresh registers and copies them later)
       if (!(SLN_ABL & 1)) gb[S][p] = ld4(rowB[p] + pl.cw);
     };
     auto xfA = [&](int p, auto stage) __attribute__((always_inline)) -> float4 {
@@ -373,6 +374,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       constexpr int S = decltype(stage)::value;
       if (IDENT) { const bool v = pl.cv; t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f; }
       if (!(SLN_ABL & 2)) *reinterpret_cast<float4*>(As + buf * BM * LDT + (r0 + RP * p) * LDT + 4 * kq) = t;
+      SLN_SB;
       if (!(SLN_ABL & 1)) {
         ga1[S][p] = ld4((MULTI ? pl.pa1[p] : rowA1[p]) + pl.cs);
         if (HAS_X2) ga2[S][p] = ld4((MULTI ? pl.pa2[p] : rowA2[p]) + pl.cs);
@@ -500,6 +502,292 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   SLN_TRACE(4);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// NT kernel, 64 x 32J tile on v_mfma_f32_16x16x4_f32: ONE workgroup per CU for the triple-side widths
+// ---------------------------------------------------------------------------------------------
+// At 64 graphs the triple-side Linears have M = 4096 rows: 64 row blocks.  With 64 x 64 tiles N = 640 (net1's second Linear) is
+// 640 tiles = 2.5 per CU and N = 384 (the dgrad of net1's first Linear) 1.5 per CU: the launch lasts as long as the CUs that got
+// the extra tile.  Here the tile is 64 x 160 (J = 5) or 64 x 96 (J = 3): 256 tiles, every CU gets the same work.  A wavefront owns
+// 32 rows x 16J columns as 2 x J accumulators of 16 x 16 (4 registers each), so its MFMAs of a K chunk are independent of one
+// another, and a K tile is two chunks of 16 (lane l reads A[row l % 16][4 (l / 16) .. + 3] with one ds_read_b128: the four MFMAs
+// that consume .x .. .w each see k = c, c + 4, c + 8, c + 12 - any fixed permutation of k is as good as another, A and B use the
+// same one).  Single-segment operands only.  Staging, masks (none: zero coefficient rows) and the statistics are those of
+// gemm_nt_body; sums are taken in a different order (per 16 x 16 block), results agree to fp32 rounding.
+template <int J, int AMODE, int EPI>
+__device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
+  constexpr int NT = 256, BM = 64, BN = 32 * J, WN16 = 16 * J;
+  constexpr bool HAS_X2 = AMODE == 1;
+  constexpr bool IDENT = AMODE == 2;
+  constexpr int LDT = BK + 4, RP = 32, PA = BM / RP, PB = BN / RP;
+  const int kpad = (a.K + 31) & ~31;
+  float4* coef = reinterpret_cast<float4*>(smem);               // [kpad + 4], the last four rows zero
+  float* As = reinterpret_cast<float*>(coef + kpad + 4);        // [2][BM][LDT]
+  float* Bs = As + 2 * BM * LDT;                                // [2][BN][LDT]
+  float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT); // [BN]
+  double* redd = reinterpret_cast<double*>(ecoef + BN);         // [2 row halves][BN][2]
+  float* red = reinterpret_cast<float*>(redd);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  SLN_TRACE(0);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int lb = xcd_remap(bid, nwg);
+  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
+  const int kq = tid & 7, r0 = tid >> 3;
+  const Seg& g = a.A.seg[0];
+  const float* rowA1[PA]; const float* rowA2[PA]; const float* rowB[PB];
+#pragma unroll
+  for (int p = 0; p < PA; ++p) {
+    const int row = min(m0 + r0 + RP * p, a.M - 1);
+    const int r = g.which == 0 ? row : (g.which == 1 ? a.A.idx_a[row] : a.A.idx_b[row]);
+    rowA1[p] = g.x1 + (size_t)r * g.ld1 + g.c1;
+    rowA2[p] = g.x2 ? g.x2 + (size_t)r * g.ld2 + g.c2 : rowA1[p];
+  }
+#pragma unroll
+  for (int p = 0; p < PB; ++p) rowB[p] = a.W + (size_t)min(n0 + r0 + RP * p, a.N - 1) * a.ldw;
+  const int ntiles = kpad / BK, last = ntiles - 1;
+  const int Kr = a.K, glen = g.len;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 ga1[2][PA], ga2[2][PA], gb[2][PB];
+  unsigned cs_n = 0, cw_n = 0;              // column offsets of the loads the next body issues (set under the MFMAs before it)
+  int coff_n = 0; bool cv_n = true;         // coefficient row / identity-operand column mask of the tile the next body stages
+  auto plan = [&](int kt) __attribute__((always_inline)) {        // for body(kt): stores tile kt + 1, loads tile kt + 3
+    const int ks_raw = kt + 1, col = min(ks_raw, last) * BK + 4 * kq;
+    cv_n = col < Kr && ks_raw <= last;
+    coff_n = ks_raw <= last ? col : kpad;                          // surplus tile (odd tile count): the zero rows
+    const int l0 = min(kt + 3, last) * BK + 4 * kq;
+    cs_n = (unsigned)min(l0, glen - 4); cw_n = (unsigned)min(l0, Kr - 4);
+  };
+  auto ldB = [&](int p, auto stage, unsigned cw) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage)::value;
+    gb[S][p] = ld4(rowB[p] + cw);
+  };
+  auto ldA = [&](int p, auto stage, unsigned cs) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage)::value;
+    ga1[S][p] = ld4(rowA1[p] + cs);
+    if (HAS_X2) ga2[S][p] = ld4(rowA2[p] + cs);
+  };
+  auto stB = [&](int buf, int p, auto stage) __attribute__((always_inline)) {
+    constexpr int S = decltype(stage)::value;
+    *reinterpret_cast<float4*>(Bs + buf * BN * LDT + (r0 + RP * p) * LDT + 4 * kq) = gb[S][p];
+  };
+  auto xfA = [&](int p, auto stage, const float4* cf, bool cv) __attribute__((always_inline)) -> float4 {
+    constexpr int S = decltype(stage)::value;
+    float4 t = IDENT ? ga1[S][p] : (HAS_X2 ? xform(ga1[S][p], ga2[S][p], cf) : xform1(ga1[S][p], cf));
+    if (IDENT) { t.x = cv ? t.x : 0.f; t.y = cv ? t.y : 0.f; t.z = cv ? t.z : 0.f; t.w = cv ? t.w : 0.f; }
+    return t;
+  };
+  auto wrA = [&](int buf, int p, float4 t) __attribute__((always_inline)) {
+    *reinterpret_cast<float4*>(As + buf * BM * LDT + (r0 + RP * p) * LDT + 4 * kq) = t;
+  };
+  using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+  {   // tiles 0 and 1 into the two register stages
+    const unsigned c0s = (unsigned)min(4 * kq, glen - 4), c0w = (unsigned)min(4 * kq, Kr - 4);
+    const int l1 = min(1, last) * BK + 4 * kq;
+    const unsigned c1s = (unsigned)min(l1, glen - 4), c1w = (unsigned)min(l1, Kr - 4);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ldB(p, S0{}, c0w);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) ldA(p, S0{}, c0s);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ldB(p, S1{}, c1w);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) ldA(p, S1{}, c1s);
+  }
+  if (!IDENT) {
+    sln_fill_coefs(a.A, coef, tid, NT);
+    for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
+  }
+  if (EPI == EPI_MASK) {
+    for (int c = tid; c < BN; c += NT) {
+      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+      if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+      ecoef[c] = e;
+    }
+  }
+  f32x4 acc[2][J];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  SLN_TRACE(1);
+  {   // tile 0 into LDS buffer 0, tile 2 into stage 0
+    const bool cv0 = 4 * kq < Kr;
+    const float4* cf0 = coef + 4 * kq;
+#pragma unroll
+    for (int p = 0; p < PB; ++p) stB(0, p, S0{});
+#pragma unroll
+    for (int p = 0; p < PA; ++p) wrA(0, p, xfA(p, S0{}, cf0, cv0));
+    const int l2 = min(2, last) * BK + 4 * kq;
+    const unsigned c2s = (unsigned)min(l2, glen - 4), c2w = (unsigned)min(l2, Kr - 4);
+#pragma unroll
+    for (int p = 0; p < PB; ++p) ldB(p, S0{}, c2w);
+#pragma unroll
+    for (int p = 0; p < PA; ++p) ldA(p, S0{}, c2s);
+  }
+  __syncthreads();
+  SLN_TRACE(2);
+
+  const int l16 = lane & 15, lg = lane >> 4;
+  float4 fa[2][2], fb[2][J];
+  // fragment q of a chunk: q < 2 the A row blocks, else the B column blocks
+  auto rd1 = [&](int buf, int kb, auto set, int q) __attribute__((always_inline)) {
+    constexpr int F = decltype(set)::value;
+    if (q < 2) fa[F][q] = *reinterpret_cast<const float4*>(As + buf * BM * LDT + (32 * wr + 16 * q + l16) * LDT + 4 * lg + kb);
+    else fb[F][q - 2] = *reinterpret_cast<const float4*>(Bs + buf * BN * LDT + (WN16 * wc + 16 * (q - 2) + l16) * LDT + 4 * lg + kb);
+  };
+#define SLN_SB __builtin_amdgcn_sched_barrier(0)
+  // the 8J MFMAs of a chunk, component-major (consecutive MFMAs go to different accumulators), hook(n) behind the n-th
+  auto mma = [&](auto set, auto&& hook) __attribute__((always_inline)) {
+    constexpr int F = decltype(set)::value;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+          const float av = c == 0 ? fa[F][i].x : (c == 1 ? fa[F][i].y : (c == 2 ? fa[F][i].z : fa[F][i].w));
+          const float bv = c == 0 ? fb[F][j].x : (c == 1 ? fb[F][j].y : (c == 2 ? fb[F][j].z : fb[F][j].w));
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[i][j], 0, 0, 0);
+          SLN_SB;
+          hook((c * 2 + i) * J + j);
+          SLN_SB;
+        }
+  };
+#pragma unroll
+  for (int q = 0; q < 2 + J; ++q) rd1(0, 0, S0{}, q);
+  plan(0);
+  // body(kt): chunk 0 of tile kt sits in fragment set 0.  Memory instructions issued back to back stall the wave at the issue stage
+  // (tools/lab/overlap.hip: a second ds_write_b128 behind an MFMA costs 52 clocks, a second global_load_dwordx4 64) and the MFMAs
+  // queue up behind them, so every one of them gets its own MFMA to hide under:
+  //   chunk 0   odd slots 1, 3, ..: the 2 + J fragment reads of chunk 1
+  //             slots 4p (p < J): weight rows p: ds_write + the reload of that register stage
+  //             slots 4J, 4J + 2 / 4J + 4, 4J + 6: operand rows: transform, then ds_write + reload
+  //   -- barrier --
+  //   chunk 1   odd slots: the fragment reads of the next tile's chunk 0; slot 0: the next body's column offsets / coefficient row
+  float4 cfr[4] = {z4, z4, z4, z4};          // coefficient rows of the tile the next body stages (fetched one per MFMA in chunk 1)
+  if (!IDENT) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cfr[q] = coef[coff_n + q];
+  }
+  auto body = [&](int kt, auto stage_next) __attribute__((always_inline)) {
+    const int buf = kt & 1;
+    const float4* cf = cfr;
+    const bool cv = cv_n;
+    const unsigned cs = cs_n, cw = cw_n;
+    float4 t0 = z4, t1 = z4;
+    mma(S0{}, [&](int n) __attribute__((always_inline)) {
+      if ((n & 1) && (n >> 1) < 2 + J) rd1(buf, 16, S1{}, n >> 1);
+      // (the fence keeps the reload behind the write: hipcc otherwise loads into fresh registers first and copies them later)
+      if (!(n & 3) && (n >> 2) < J) { stB(buf ^ 1, n >> 2, stage_next); SLN_SB; ldB(n >> 2, stage_next, cw); }
+      if (n == 4 * J) t0 = xfA(0, stage_next, cf, cv);
+      if (n == 4 * J + 2) { wrA(buf ^ 1, 0, t0); SLN_SB; ldA(0, stage_next, cs); }
+      if (n == 4 * J + 4) t1 = xfA(1, stage_next, cf, cv);
+      if (n == 4 * J + 6) { wrA(buf ^ 1, 1, t1); SLN_SB; ldA(1, stage_next, cs); }
+    });
+    __syncthreads();
+    mma(S1{}, [&](int n) __attribute__((always_inline)) {
+      if ((n & 1) && (n >> 1) < 2 + J) rd1(buf ^ 1, 0, S0{}, n >> 1);
+      if (n == 0) plan(kt + 1);
+      if (!IDENT && n >= 2 && n <= 8 && !(n & 1)) cfr[(n >> 1) - 1] = coef[coff_n + (n >> 1) - 1];
+    });
+  };
+#undef SLN_SB
+  for (int kt = 0; kt < ntiles; kt += 2) { body(kt, S1{}); body(kt + 1, S0{}); }
+
+  // ------------------------------- epilogue -------------------------------
+  SLN_TRACE(3);
+  // accumulator layout of the 16 x 16 x 4 shape: register r of lane l is row 4 (l / 16) + r, column l % 16
+  const bool has_add = a.addend != nullptr;
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int cl = WN16 * wc + 16 * j + l16;
+    const int col = n0 + cl;
+    const bool cvalid = col < a.N;
+    const int ccl = cvalid ? col : 0;
+    const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+    float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
+    if (EPI == EPI_MASK) ec = ecoef[cl];
+    float yv[8], xpv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = min(m0 + 32 * wr + 16 * (q >> 2) + 4 * lg + (q & 3), a.M - 1);
+      yv[q] = acc[q >> 2][j][q & 3] + bias;
+      xpv[q] = 0.f;
+      if (EPI == EPI_MASK) xpv[q] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
+    }
+    if (has_add) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = min(m0 + 32 * wr + 16 * (q >> 2) + 4 * lg + (q & 3), a.M - 1);
+        yv[q] += a.addend[(size_t)row * a.ldadd + a.addcol0 + ccl];
+      }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = m0 + 32 * wr + 16 * (q >> 2) + 4 * lg + (q & 3);
+      const bool ok = cvalid && row < a.M;
+      float y = yv[q];
+      if (EPI == EPI_MASK) y = fmaf(ec.x, xpv[q], ec.y) > 0.f ? y : 0.f;
+      y = ok ? y : 0.f;
+      if (EPI == EPI_STATS) { d1 += (double)y; d2 = fma((double)y, (double)y, d2); }
+      if (EPI == EPI_MASK) { s1 += y; s2 = fmaf(y, (xpv[q] - ec.z) * ec.w, s2); }
+      if (ok) a.Y[(size_t)row * a.ldy + a.ycol0 + col] = y;
+    }
+    if (EPI == EPI_STATS) {
+      d1 += __shfl_xor(d1, 16, 64); d2 += __shfl_xor(d2, 16, 64);
+      d1 += __shfl_xor(d1, 32, 64); d2 += __shfl_xor(d2, 32, 64);
+      if (lg == 0) { redd[(wr * BN + cl) * 2 + 0] = d1; redd[(wr * BN + cl) * 2 + 1] = d2; }
+    } else if (EPI == EPI_MASK) {
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      if (lg == 0) { red[(wr * BN + cl) * 2 + 0] = s1; red[(wr * BN + cl) * 2 + 1] = s2; }
+    }
+  }
+  if (EPI != EPI_PLAIN) {
+    __syncthreads();
+    double* out = (EPI == EPI_STATS) ? a.osums : a.ogsums;
+    if (out != nullptr) {
+      for (int c = tid; c < BN; c += NT) {
+        if (n0 + c < a.N) {
+          double s1, s2;
+          if (EPI == EPI_STATS) { s1 = redd[c * 2] + redd[(BN + c) * 2]; s2 = redd[c * 2 + 1] + redd[(BN + c) * 2 + 1]; }
+          else { s1 = (double)red[c * 2] + (double)red[(BN + c) * 2]; s2 = (double)red[c * 2 + 1] + (double)red[(BN + c) * 2 + 1]; }
+          const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;
+          atomicAdd(out + n0 + c, sln_qd(s1, qs));
+          atomicAdd(out + a.ocstride + n0 + c, sln_qd(s2, qs));
+        }
+      }
+    }
+  }
+  SLN_TRACE(4);
+}
+
+inline size_t nt16_smem_bytes(int K, int J) {
+  const int kpad = (K + 31) & ~31;
+  return (size_t)(kpad + 4) * 16 + (size_t)2 * (64 + 32 * J) * (BK + 4) * 4 + (size_t)32 * J * 16 + (size_t)2 * 32 * J * 16;
+}
+
+// Which tile for a single-segment problem?  Cost model: rounds of 256 workgroups x tile width.  Returns J (3 or 5) when the
+// 16 x 16 body with 64 x 32J tiles needs fewer width-rounds than 64 x 64 tiles (J = 2), else 0.
+inline int nt16_pick(const GemmNTArgs& a) {
+  static const int enabled = std::getenv("SLN_NT16") ? std::atoi(std::getenv("SLN_NT16")) : 1;
+  if (!enabled || a.A.nseg != 1 || a.K > 2048) return 0;
+  const long mb = sln_cdiv(a.M, 64);
+  const long base = ((mb * sln_cdiv(a.N, 64) + 255) / 256) * 2;
+  int best = 0; long bc = base;
+  const int cand[2] = {3, 5};
+  for (int q = 0; q < 2; ++q) {
+    const int Jc = cand[q];
+    const long c = ((mb * sln_cdiv(a.N, 32 * Jc) + 255) / 256) * Jc;
+    if (c < bc) { bc = c; best = Jc; }
+  }
+  return best;
+}
 
 // ---------------------------------------------------------------------------------------------
 // NT kernel, small tile: 32 x 32 outputs per workgroup, the K loop SPLIT over its four wavefronts

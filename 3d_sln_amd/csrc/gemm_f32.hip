@@ -24,6 +24,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
   gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI>(a, blockIdx.x, gridDim.x, smem);
 }
 
+template <int J, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void gemm_nt16_kernel(const GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_body16<J, AMODE, EPI>(a, blockIdx.x, gridDim.x, smem);
+}
+
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,6 +48,17 @@ int launch_nt_small(const GemmNTArgs& a, hipStream_t st) {
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
   static const int xcd = std::getenv("SLN_NT_SMALL_NO_XCD") ? 0 : 1;      // lab switch: plain workgroup order
   hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(256), smem, st, a, xcd);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int J, int AMODE, int EPI>
+int launch_nt16(const GemmNTArgs& a, hipStream_t st) {
+  const size_t smem = nt16_smem_bytes(a.K, J);
+  const int grid = sln_cdiv(a.M, 64) * sln_cdiv(a.N, 32 * J);
+  if (grid <= 0) return 0;
+  if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  hipLaunchKernelGGL((gemm_nt16_kernel<J, AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -163,6 +180,15 @@ int sln_gemm_init() {
   SLN_SET_S(0, EPI_PLAIN) SLN_SET_S(0, EPI_STATS) SLN_SET_S(0, EPI_MASK) SLN_SET_S(1, EPI_PLAIN) SLN_SET_S(1, EPI_STATS)
   SLN_SET_S(1, EPI_MASK) SLN_SET_S(2, EPI_PLAIN) SLN_SET_S(2, EPI_STATS) SLN_SET_S(2, EPI_MASK)
 #undef SLN_SET_S
+#define SLN_SET_16(J, AM, EPI)                                                                                    \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt16_kernel<J, AM, EPI>),             \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define SLN_SET_16J(J)                                                                                            \
+  SLN_SET_16(J, 0, EPI_PLAIN) SLN_SET_16(J, 0, EPI_STATS) SLN_SET_16(J, 0, EPI_MASK) SLN_SET_16(J, 1, EPI_PLAIN) SLN_SET_16(J, 1, EPI_STATS) \
+  SLN_SET_16(J, 1, EPI_MASK) SLN_SET_16(J, 2, EPI_PLAIN) SLN_SET_16(J, 2, EPI_STATS) SLN_SET_16(J, 2, EPI_MASK)
+  SLN_SET_16J(3) SLN_SET_16J(5)
+#undef SLN_SET_16J
+#undef SLN_SET_16
   if (!r) r = init_nt_tile<128, 64, 2, 2>();
   if (!r) r = init_nt_tile<128, 128, 2, 2>();
 #define SLN_SET_TN(X2, XG)                                                                                        \
@@ -206,6 +232,19 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
     }
     SLN_DISPATCH_S(0) SLN_DISPATCH_S(1) SLN_DISPATCH_S(2)
 #undef SLN_DISPATCH_S
+  }
+  if (tile < 0) {
+    // widths that leave 64 x 64 tiles with a ragged last round (N = 640: 2.5 tiles per CU at 64 graphs, N = 384: 1.5) run on
+    // 64 x 160 / 64 x 96 tiles of 16 x 16 MFMAs - one workgroup per CU, see gemm_nt_body16
+    const int J16 = nt16_pick(a);
+#define SLN_DISPATCH_16(J, AM)                                                        \
+    if (J16 == J && amode == AM) {                                                    \
+      if (epi == EPI_MASK) return launch_nt16<J, AM, EPI_MASK>(a, st);                \
+      if (epi == EPI_STATS) return launch_nt16<J, AM, EPI_STATS>(a, st);              \
+      return launch_nt16<J, AM, EPI_PLAIN>(a, st);                                    \
+    }
+    SLN_DISPATCH_16(3, 0) SLN_DISPATCH_16(3, 1) SLN_DISPATCH_16(3, 2) SLN_DISPATCH_16(5, 0) SLN_DISPATCH_16(5, 1) SLN_DISPATCH_16(5, 2)
+#undef SLN_DISPATCH_16
   }
   if (tile < 0) tile = nt_heuristic_tile(a);
   if (a.A.nseg > 1 && nt_unaligned(a)) tile = 0;        // the per-thread segment choice exists for the 64x64 tile only

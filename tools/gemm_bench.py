@@ -28,12 +28,12 @@ def main():
         x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
         y = torch.empty(M, N, device="cuda"); sums = torch.zeros(2, N, dtype=torch.float64, device="cuda")
         row = []
-        for tile in (0, 1):
+        for tile in (-1, 0):
             for stats in (True, False):
                 f = lambda: lib.sln_linear_forward(L.ptr(x), M, K, L.ptr(W), L.ptr(b), L.ptr(y), N,
                                                    L.ptr(sums) if stats else None, tile, st)
                 us = timeit(f)
-                row.append("t%d%s %6.1fus %5.1fTF" % (tile, "+stats" if stats else " plain", us, 2.0 * M * N * K / us / 1e6))
+                row.append("t%+d%s %6.1fus %5.1fTF" % (tile, "+stats" if stats else " plain", us, 2.0 * M * N * K / us / 1e6))
         print("M=%5d N=%4d K=%4d | " % (M, N, K) + " | ".join(row))
     print("== TN wgrad dW += g^T x")
     for (R, N, K) in [(4096, 640, 256), (4096, 256, 384), (2048, 256, 256), (2048, 128, 256), (32768, 640, 256)]:

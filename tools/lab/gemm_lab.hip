@@ -16,10 +16,17 @@ __global__ __launch_bounds__(256) void lab_nt(const GemmNTArgs a) {
   gemm_nt_body<BM, BN, 2, 2, AMODE, EPI, 0>(a, bid, gridDim.x, smem);
 }
 
+template <int J, int AMODE, int EPI>
+__global__ __launch_bounds__(256) void lab_nt16(const GemmNTArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int bid = blockIdx.x;
+  gemm_nt_body16<J, AMODE, EPI>(a, bid, gridDim.x, smem);
+}
+
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main() {
-  const int shapes[][3] = {{4096, 256, 384}, {4096, 640, 256}, {2048, 256, 256}, {2048, 128, 256}, {2048, 256, 128}, {32768, 640, 256}};
+  const int shapes[][3] = {{4096, 256, 384}, {4096, 640, 256}, {4096, 384, 256}, {2048, 256, 256}, {2048, 128, 256}, {2048, 256, 128}, {32768, 640, 256}};
   long long* trace; CK(hipMalloc(&trace, sizeof(long long) * 8 * 65536));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &trace, sizeof(trace)));
   for (auto& sh : shapes) {
@@ -75,6 +82,30 @@ int main() {
     printf("M=%5d N=%4d K=%4d grid %4d: %6.2f us/launch (%.1f TF) | span %lld ticks; median ticks: coef/prologue %lld, first tile %lld, main loop %lld (%d k-tiles), epilogue %lld; block start p50 %lld p100 %lld\n",
            M, N, K, grid, ms / 50 * 1e3, 2.0 * M * N * K / (ms / 50 * 1e-3) / 1e12, tmax - tmin, med(ph[0]), med(ph[1]), med(ph[2]), (K + 31) / 32, med(ph[3]),
            starts[starts.size() / 2], starts.back());
+    if (N % 160 == 0 || N % 96 == 0) {
+      const int J = N % 160 == 0 ? 5 : 3;
+      const size_t sm16 = nt16_smem_bytes(K, J);
+      const int g16 = ((M + 63) / 64) * (N / (32 * J));
+      auto launch = [&]() {
+        if (J == 5) hipLaunchKernelGGL((lab_nt16<5, 2, EPI_STATS>), dim3(g16), dim3(256), sm16, 0, a);
+        else hipLaunchKernelGGL((lab_nt16<3, 2, EPI_STATS>), dim3(g16), dim3(256), sm16, 0, a);
+      };
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_nt16<5, 2, EPI_STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_nt16<3, 2, EPI_STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (int i = 0; i < 5; ++i) launch();
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 50; ++i) launch();
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float ms16; CK(hipEventElapsedTime(&ms16, e0, e1));
+      std::vector<long long> t16(8 * g16);
+      CK(hipMemcpy(t16.data(), trace, sizeof(long long) * 8 * g16, hipMemcpyDeviceToHost));
+      std::vector<long long> ph16[4];
+      for (int b2 = 0; b2 < g16; ++b2) for (int p = 0; p < 4; ++p) ph16[p].push_back(t16[8 * b2 + p + 1] - t16[8 * b2 + p]);
+      for (auto& v : ph16) std::sort(v.begin(), v.end());
+      printf("   16x16 body J=%d grid %d: %6.2f us/launch (%.1f TF); median ticks: prologue %lld, first tile %lld, main loop %lld, epilogue %lld\n", J, g16,
+             ms16 / 50 * 1e3, 2.0 * M * N * K / (ms16 / 50 * 1e-3) / 1e12, med(ph16[0]), med(ph16[1]), med(ph16[2]), med(ph16[3]));
+    }
     hipFree(x); hipFree(W); hipFree(b); hipFree(y); hipFree(sums);
   }
   return 0;
