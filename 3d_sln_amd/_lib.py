@@ -169,6 +169,9 @@ SIGNATURES = {
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
     "sln_place_forward": (C.c_int, [C.POINTER(SlnPlacement), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "sln_place_backward": (C.c_int, [C.POINTER(SlnPlacement), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "sln_refine_head_forward": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sln_refine_head_backward": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p]),
+    "sln_refine_sgd": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_void_p]),
     "sln_refine_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sln_refine_loss_init": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, C.c_void_p]),
     "sln_refine_pool": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),

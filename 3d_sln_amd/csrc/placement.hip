@@ -12,6 +12,8 @@
 // where / flip and their autograd nodes), a third of the iteration.  Here: one kernel each way.  Backward runs one workgroup
 // per object over that object's faces (the face list is grouped by object), reduces d centre (3) and d A (3x3) in
 // registers / LDS and applies the chain rule to the box row and the angle - no atomics, deterministic.
+#include <algorithm>
+#include <cstdint>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -202,6 +204,67 @@ __global__ __launch_bounds__(256) void place_backward_kernel(SlnPlacement P, con
   }
 }
 
+// ---- the torch glue between the decoder and the placement as one kernel each way (testing/test_render_refine.py:296-306) ----
+// forward: boxes_full = [boxes_pred[:-1] ; box_last], idx = [softargmax(angles_pred, beta)[:-1] + noise[:-1] / 10 ; angle_last]
+// with softargmax(x) = sum_j softmax(beta x)_j (j + 1) - 1 (:20-25).  One thread per row.
+__global__ void refine_head_forward_kernel(int n, int na, const float* __restrict__ boxes_pred, const float* __restrict__ angles_pred,
+                                           const float* __restrict__ noise, const float* __restrict__ box_last,
+                                           const float* __restrict__ angle_last, float beta, float* __restrict__ boxes_full,
+                                           float* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool lastrow = i == n - 1;
+  for (int j = 0; j < 6; ++j) boxes_full[6 * i + j] = lastrow ? box_last[j] : boxes_pred[6 * i + j];
+  if (lastrow) { idx[i] = angle_last[0]; return; }
+  const float* a = angles_pred + (size_t)i * na;
+  float m = -INFINITY;
+  for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
+  float den = 0.f, num = 0.f;
+  for (int j = 0; j < na; ++j) { const float e = expf(a[j] * beta - m); den += e; num += e * (float)(j + 1); }
+  idx[i] = num / den - 1.0f + (noise ? noise[i] / 10.0f : 0.f);
+}
+// backward, with the two gradient hooks of the reference folded in: quad_grad (x4 on d idx, :226-228) and fix_grad (both halves of a
+// box row receive the mean of the two halves' gradients, :217-224); the frozen last row receives zeros.
+__global__ void refine_head_backward_kernel(int n, int na, const float* __restrict__ angles_pred, const float* __restrict__ g_boxes_full,
+                                            const float* __restrict__ g_idx, float beta, float* __restrict__ g_boxes_pred,
+                                            float* __restrict__ g_angles_pred) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool lastrow = i == n - 1;
+  for (int j = 0; j < 3; ++j) {
+    const float avg = lastrow ? 0.f : g_boxes_full[6 * i + 3 + j] / 2.0f + g_boxes_full[6 * i + j] / 2.0f;
+    g_boxes_pred[6 * i + j] = avg; g_boxes_pred[6 * i + 3 + j] = avg;
+  }
+  float* ga = g_angles_pred + (size_t)i * na;
+  if (lastrow) { for (int j = 0; j < na; ++j) ga[j] = 0.f; return; }
+  const float* a = angles_pred + (size_t)i * na;
+  float m = -INFINITY;
+  for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
+  float den = 0.f, num = 0.f;
+  for (int j = 0; j < na; ++j) { const float e = expf(a[j] * beta - m); den += e; num += e * (float)(j + 1); }
+  const float ev = num / den, g = g_idx[i] * 4.0f;
+  // d idx / d a_j = beta p_j ((j + 1) - E[j + 1])
+  for (int j = 0; j < na; ++j) ga[j] = g * beta * (expf(a[j] * beta - m) / den) * ((float)(j + 1) - ev);
+}
+// p -= step * g, g = 0 (the next backward accumulates into it) and z -= step_z * gz in one launch: the closed form of the
+// reference's per-iteration SGD(momentum = 0.1, nesterov) on a fresh optimizer (:286-292: step = lr * 1.1)
+__global__ void refine_sgd_kernel(float* __restrict__ p, float* __restrict__ g, long n, float step, float* __restrict__ z,
+                                  const float* __restrict__ gz, long nz, float step_z) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n4 = n >> 2;
+  if (i < n4) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    pv.x -= step * gv.x; pv.y -= step * gv.y; pv.z -= step * gv.z; pv.w -= step * gv.w;
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else if (i < n4 + (n & 3)) {
+    const long k = 4 * n4 + (i - n4);
+    p[k] -= step * g[k]; g[k] = 0.f;
+  }
+  if (i < nz) z[i] -= step_z * gz[i];
+}
+
 int check(const SlnPlacement* P) {
   if (!P || P->n <= 0 || P->n_vis < 0 || P->n_vis > P->n || P->F <= 0 || P->Vm <= 0 || P->Vs < 0) return SLN_E_BADARG;
   if (!P->faces || !P->obj_face_ptr || (P->n_vis > 0 && (!P->vis || !P->model_v || !P->msize || !P->mcenter)) || (P->Vs > 0 && !P->shell_v))
@@ -231,6 +294,36 @@ int sln_place_backward(const SlnPlacement* P, const float* boxes, const float* a
   if (!boxes || !angles || !grad_faces || !grad_boxes || !grad_angles) return SLN_E_BADARG;
   hipLaunchKernelGGL(place_backward_kernel, dim3(P->n), dim3(256), 0, (hipStream_t)stream, *P, boxes, angles, size_target, grad_faces,
                      grad_size_loss, grad_boxes, grad_angles);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_head_forward(int n, int n_angle, const float* boxes_pred, const float* angles_pred, const float* noise,
+                            const float* box_last, const float* angle_last, float beta, float* boxes_full, float* idx, void* stream) {
+  if (n <= 0 || n_angle <= 0 || !boxes_pred || !angles_pred || !box_last || !angle_last || !boxes_full || !idx) return SLN_E_BADARG;
+  hipLaunchKernelGGL(refine_head_forward_kernel, dim3(sln_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, n, n_angle, boxes_pred,
+                     angles_pred, noise, box_last, angle_last, beta, boxes_full, idx);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_head_backward(int n, int n_angle, const float* angles_pred, const float* grad_boxes_full, const float* grad_idx,
+                             float beta, float* grad_boxes_pred, float* grad_angles_pred, void* stream) {
+  if (n <= 0 || n_angle <= 0 || !angles_pred || !grad_boxes_full || !grad_idx || !grad_boxes_pred || !grad_angles_pred) return SLN_E_BADARG;
+  hipLaunchKernelGGL(refine_head_backward_kernel, dim3(sln_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, n, n_angle, angles_pred,
+                     grad_boxes_full, grad_idx, beta, grad_boxes_pred, grad_angles_pred);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_sgd(float* params, float* grads, int64_t n, float step, float* z, const float* grad_z, int64_t nz, float step_z,
+                   void* stream) {
+  if (n < 0 || nz < 0 || (n > 0 && (!params || !grads)) || (nz > 0 && (!z || !grad_z))) return SLN_E_BADARG;
+  if ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) return SLN_E_BADARG;
+  const long work = std::max<long>((n >> 2) + (n & 3), nz);
+  if (work <= 0) return 0;
+  hipLaunchKernelGGL(refine_sgd_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params, grads, (long)n, step,
+                     z, grad_z, (long)nz, step_z);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -299,6 +299,38 @@ class _PlaceFn(torch.autograd.Function):
         return gb, ga, None, None
 
 
+class _HeadFn(torch.autograd.Function):
+    """(boxes_pred [n,6], angles_pred [n,24], noise [n], box_last [6], angle_last [1]) -> (boxes_full [n,6], idx [n]): the
+    soft-argmax, the noise, the two ``torch.cat`` with the frozen room row and - in backward - the ``fix_grad`` / ``quad_grad``
+    hooks (testing/test_render_refine.py:20-25, 217-228, 296-306) as one launch each way (csrc/placement.hip) instead of ~25."""
+
+    @staticmethod
+    def forward(ctx, boxes_pred, angles_pred, noise, box_last, angle_last, beta):
+        boxes_pred, angles_pred = boxes_pred.contiguous().float(), angles_pred.contiguous().float()
+        n, na = angles_pred.shape
+        boxes_full, idx = torch.empty_like(boxes_pred), torch.empty(n, device=boxes_pred.device)
+        _lib.check(_lib.lib().sln_refine_head_forward(n, na, _lib.ptr(boxes_pred), _lib.ptr(angles_pred), _lib.ptr(noise), _lib.ptr(box_last),
+                                                      _lib.ptr(angle_last), float(beta), _lib.ptr(boxes_full), _lib.ptr(idx),
+                                                      _lib.current_stream_ptr()), "sln_refine_head_forward")
+        ctx.save_for_backward(angles_pred)
+        ctx.beta = float(beta)
+        return boxes_full, idx
+
+    @staticmethod
+    def backward(ctx, g_boxes, g_idx):
+        angles_pred, = ctx.saved_tensors
+        n, na = angles_pred.shape
+        gb, ga = torch.empty(n, 6, device=angles_pred.device), torch.empty_like(angles_pred)
+        if g_boxes is None:
+            g_boxes = torch.zeros(n, 6, device=angles_pred.device)
+        if g_idx is None:
+            g_idx = torch.zeros(n, device=angles_pred.device)
+        _lib.check(_lib.lib().sln_refine_head_backward(n, na, _lib.ptr(angles_pred), _lib.ptr(g_boxes.contiguous()), _lib.ptr(g_idx.contiguous()),
+                                                       ctx.beta, _lib.ptr(gb), _lib.ptr(ga), _lib.current_stream_ptr()),
+                   "sln_refine_head_backward")
+        return gb, ga, None, None, None, None
+
+
 class RefineScene:
     """The same placement + render as ``assemble_scene`` + ``DR.scene_render`` with every per-object python loop of
     diff_render.py:76-159 turned into ONE batched tensor expression over the visible objects, and fixed tensor shapes:
@@ -400,12 +432,14 @@ class RefineScene:
 
 
 def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, bank=None, learning_rate=1e-4,
-                      noise_seed=13, image_size=256, capture=False, log=None, fused_loss=True):
+                      noise_seed=13, image_size=256, capture=False, log=None, fused_loss=True, fused_head=True):
     """``finetune_vae`` with the batched ``RefineScene`` and no per-iteration python optimiser objects: the reference builds a
     NEW SGD(momentum=0.1, nesterov) every iteration (test_render_refine.py:286-292), so its step is exactly
     ``p -= lr * (1 + momentum) * grad``; that closed form is applied to ``z`` (lr 2e-4) and to the flat parameter buffer
     (lr ``learning_rate``/10).  ``fused_loss``: the PSP-pool / L1 / cross-entropy block runs as ``RefineLoss`` (two C calls)
-    instead of torch ops.  ``capture=True`` records one iteration (decoder, placement, fused render, PSP losses,
+    instead of torch ops; ``fused_head``: the soft-argmax / noise / concatenation glue and the two gradient hooks as one launch
+    each way (``_HeadFn``) and both parameter updates plus the gradient zero-fill as one launch (``sln_refine_sgd``).
+    ``capture=True`` records one iteration (decoder, placement, fused render, PSP losses,
     backward, both updates) into a hipGraph and replays it; the noise of the angle soft-argmax is then drawn on the device.
     Returns (losses [iters] tensor on the device, (boxes_pred, angle_idx))."""
     dev = boxes_gt.device
@@ -431,24 +465,38 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
     flat, flat_grad = model.flat_params, model.flat_grads
     state = {}
 
+    box_last = boxes_gt[-1].detach().float().contiguous()
+    angle_last = angles_gt[-1:].detach().float().contiguous()
+    if fused_head:
+        flat_grad.zero_()                                  # from here on the update kernel leaves the gradient buffer zeroed
+
     def iteration():
         boxes_pred, angles_pred = model.decoder(z, objs, triples, attributes)
-        boxes_pred.register_hook(fix_grad)
-        boxes_full = torch.cat([boxes_pred[:-1], boxes_gt[-1:]], 0)
-        idx = softargmax(angles_pred, sum_dim=1) + noise / 10.0
-        idx.register_hook(quad_grad)
-        idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
+        if fused_head:
+            boxes_full, idx = _HeadFn.apply(boxes_pred, angles_pred, noise, box_last, angle_last, 2.0)
+        else:
+            boxes_pred.register_hook(fix_grad)
+            boxes_full = torch.cat([boxes_pred[:-1], boxes_gt[-1:]], 0)
+            idx = softargmax(angles_pred, sum_dim=1) + noise / 10.0
+            idx.register_hook(quad_grad)
+            idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
         image, size_loss, _ = scene.render(boxes_full, idx, size_target)
         if fused is not None:
-            loss = fused(image)[0] + size_loss * 2.0
+            loss = torch.add(fused(image)[0], size_loss, alpha=2.0)
         else:
             loss, _, _ = refinement_loss(image, target, labels, size_loss)
         z.grad = None
-        flat_grad.zero_()
+        if not fused_head:
+            flat_grad.zero_()
         loss.backward()
         with torch.no_grad():
-            z.add_(z.grad, alpha=-2e-4 * 1.1)
-            flat.add_(flat_grad, alpha=-(learning_rate / 10.0) * 1.1)
+            if fused_head:
+                _lib.check(_lib.lib().sln_refine_sgd(_lib.ptr(flat), _lib.ptr(flat_grad), flat.numel(), (learning_rate / 10.0) * 1.1,
+                                                     _lib.ptr(z), _lib.ptr(z.grad), z.numel(), 2e-4 * 1.1, _lib.current_stream_ptr()),
+                           "sln_refine_sgd")
+            else:
+                z.add_(z.grad, alpha=-2e-4 * 1.1)
+                flat.add_(flat_grad, alpha=-(learning_rate / 10.0) * 1.1)
         model.params_changed()
         state["boxes"], state["idx"] = boxes_full.detach(), idx.detach()
         return loss.detach()

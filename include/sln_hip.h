@@ -299,6 +299,21 @@ int sln_place_forward(const SlnPlacement* P /* host struct */, const float* boxe
 int sln_place_backward(const SlnPlacement* P, const float* boxes, const float* angles, const float* size_target, const float* grad_faces,
                        const float* grad_size_loss, float* grad_boxes, float* grad_angles, void* stream);
 
+/* The tensor glue between the decoder and the placement in one launch each way (testing/test_render_refine.py:296-306):
+ *   boxes_full [n,6] = [boxes_pred[:-1] ; box_last],  idx [n] = [softargmax(angles_pred, beta)[:-1] + noise[:-1] / 10 ; angle_last[0]]
+ * with softargmax(x) = sum_j softmax(beta * x)_j * (j + 1) - 1 (:20-25); noise may be NULL.  backward folds the reference's two
+ * gradient hooks in: quad_grad (d idx * 4, :226-228) and fix_grad (both halves of a box row get the mean of their two
+ * gradients, :217-224); the frozen last row gets zero gradients.  grad_boxes_pred [n,6], grad_angles_pred [n,n_angle]. */
+int sln_refine_head_forward(int n, int n_angle, const float* boxes_pred, const float* angles_pred, const float* noise,
+                            const float* box_last, const float* angle_last, float beta, float* boxes_full, float* idx, void* stream);
+int sln_refine_head_backward(int n, int n_angle, const float* angles_pred, const float* grad_boxes_full, const float* grad_idx,
+                             float beta, float* grad_boxes_pred, float* grad_angles_pred, void* stream);
+/* params -= step * grads; grads = 0; z -= step_z * grad_z  (one launch).  The reference builds a NEW SGD(momentum=0.1,
+ * nesterov=True) every iteration (:286-292), whose single step is p -= lr * 1.1 * grad: pass step = lr * 1.1.
+ * params / grads 16-byte aligned. */
+int sln_refine_sgd(float* params, float* grads, int64_t n, float step, float* z, const float* grad_z, int64_t nz, float step_z,
+                   void* stream);
+
 /* Refinement loss of the layout-refinement loop (testing/test_render_refine.py:192-215 PSP_pool_new, :332-356):
  * null-fill of the last depth channel, bilinear(align_corners=True) resampling of the 40 semantic and 29 depth channels of
  * the [B,70,S,S] scene tensor to each scale and bilinear resampling to pooled_size, L1 against the pooled target depth * 0.5,

@@ -341,3 +341,41 @@ def test_refinement_loss_generic_backward_kernel_and_other_scales():
         scale = float(xi.grad.abs().max())
         bad = (np.abs(g_fast.cpu().numpy() - xi.grad.numpy()) > 1e-4 * scale).mean()
         assert bad < 2e-3, (sizes, bad)                               # L1 sign flips at rounding level only
+
+
+def test_fused_head_and_update_match_the_torch_expressions():
+    """_HeadFn (soft-argmax + noise + the two cats, fix_grad / quad_grad in backward) and sln_refine_sgd against the torch ops
+    of finetune_vae (testing/test_render_refine.py:20-25, 217-228, 286-306)."""
+    R = pkg("host.refine")
+    L = pkg("_lib")
+    torch.manual_seed(3)
+    n, na = 13, 24
+    bp = torch.randn(n, 6, device="cuda", requires_grad=True)
+    ap = (torch.randn(n, na, device="cuda") * 3).requires_grad_(True)
+    noise = torch.randn(n, device="cuda")
+    box_last, angle_last = torch.rand(6, device="cuda"), torch.tensor([7.0], device="cuda")
+    wb, wi = torch.randn(n, 6, device="cuda"), torch.randn(n, device="cuda")
+    # reference expression
+    bp1, ap1 = bp.detach().clone().requires_grad_(True), ap.detach().clone().requires_grad_(True)
+    b1 = bp1 * 1.0
+    b1.register_hook(R.fix_grad)
+    full1 = torch.cat([b1[:-1], box_last[None]], 0)
+    i1 = R.softargmax(ap1, sum_dim=1) + noise / 10.0
+    i1.register_hook(R.quad_grad)
+    i1 = torch.cat([i1[:-1], angle_last], 0)
+    ((full1 * wb).sum() + (i1 * wi).sum()).backward()
+    full2, i2 = R._HeadFn.apply(bp, ap, noise, box_last, angle_last, 2.0)
+    ((full2 * wb).sum() + (i2 * wi).sum()).backward()
+    assert_close(full2.detach().cpu().numpy(), full1.detach().cpu().numpy(), "boxes_full", rtol=0, atol=0)
+    assert_close(i2.detach().cpu().numpy(), i1.detach().cpu().numpy(), "idx", rtol=1e-5, atol=1e-5)
+    assert_close(bp.grad.cpu().numpy(), bp1.grad.cpu().numpy(), "d boxes_pred", rtol=1e-6, atol=1e-7)
+    assert_close(ap.grad.cpu().numpy(), ap1.grad.cpu().numpy(), "d angles_pred", rtol=1e-4, atol=1e-6)
+    # update: p -= step g, g = 0, z -= step_z gz (sizes that are not multiples of four)
+    for npar in (1031, 4096, 3):
+        p, g = torch.randn(npar, device="cuda"), torch.randn(npar, device="cuda")
+        z, gz = torch.randn(13, 64, device="cuda"), torch.randn(13, 64, device="cuda")
+        p0, z0 = p - 0.011 * g, z - 0.00022 * gz
+        L.check(L.lib().sln_refine_sgd(L.ptr(p), L.ptr(g), npar, 0.011, L.ptr(z), L.ptr(gz), z.numel(), 0.00022, L.current_stream_ptr()), "sgd")
+        assert_close(p.cpu().numpy(), p0.cpu().numpy(), "params", rtol=1e-6, atol=1e-7)
+        assert_close(z.cpu().numpy(), z0.cpu().numpy(), "z", rtol=1e-6, atol=1e-7)
+        assert float(g.abs().max()) == 0.0
