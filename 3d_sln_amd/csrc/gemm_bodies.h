@@ -519,7 +519,10 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   constexpr int NT = 256, BM = 64, BN = 32 * J, WN16 = 16 * J;
   constexpr bool HAS_X2 = AMODE == 1;
   constexpr bool IDENT = AMODE == 2;
-  constexpr int LDT = BK + 4, RP = 32, PA = BM / RP, PB = BN / RP;
+  // LDS rows of BK + 8 floats: the 16 x 16 fragment pattern (lane l: row l % 16, floats 4 (l / 16) ..) is conflict-free at a row
+  // stride of 40 floats and 2-way conflicted at the 36 of the 32 x 32 body (ds_read_b128 is served in four groups of 16 lanes over
+  // 64 banks, MI355X_MICROARCH.md)
+  constexpr int LDT = BK + 8, RP = 32, PA = BM / RP, PB = BN / RP;
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);               // [kpad + 4], the last four rows zero
   float* As = reinterpret_cast<float*>(coef + kpad + 4);        // [2][BM][LDT]
@@ -769,7 +772,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
 
 inline size_t nt16_smem_bytes(int K, int J) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)(kpad + 4) * 16 + (size_t)2 * (64 + 32 * J) * (BK + 4) * 4 + (size_t)32 * J * 16 + (size_t)2 * 32 * J * 16;
+  return (size_t)(kpad + 4) * 16 + (size_t)2 * (64 + 32 * J) * (BK + 8) * 4 + (size_t)32 * J * 16 + (size_t)2 * 32 * J * 16;
 }
 
 // Which tile for a single-segment problem?  Cost model: rounds of 256 workgroups x tile width.  Returns J (3 or 5) when the
