@@ -27,7 +27,23 @@ namespace {
 constexpr int BK = 32;
 constexpr int TN_PAD = 32;     // LDS row padding of the TN (wgrad) tiles, see gemm_tn_body
 
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// Operand loads name the GLOBAL address space.  A pointer that a kernel reads out of device memory (the problem table of the
+// per-pass wgrad launch) has no known address space, hipcc then emits flat_load - which counts on BOTH vmcnt and lgkmcnt: every wait
+// for an LDS read also waits for all operand loads in flight, and the prefetch distance of the K loop is gone.  (Pointers that
+// arrive in the kernel arguments are known to be global; the cast costs nothing there.)
+// (a native vector type: dereferencing a HIP float4 goes through its copy constructor, which takes a generic reference)
+typedef float sln_v4f __attribute__((ext_vector_type(4)));
+typedef const sln_v4f __attribute__((address_space(1)))* sln_gf4p;
+typedef const int __attribute__((address_space(1)))* sln_gip;
+__device__ __forceinline__ float4 ld4(const float* p) {
+  const sln_v4f v = *(sln_gf4p)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ int ldi(const int* p) { return *(sln_gip)(p); }
+// dW / db += v as global_atomic_add_f32 (atomicAdd on a pointer of unknown address space is a flat atomic)
+__device__ __forceinline__ void sln_gatomic_add(float* p, float v) {
+  __hip_atomic_fetch_add((float __attribute__((address_space(1)))*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // v_max_f32 as the instruction: fmaxf() makes hipcc canonicalise both inputs first (one more v_max_f32 per coefficient that comes out
 // of LDS), and every VALU instruction of a GEMM wave is paid in matrix-pipe time (tools/lab/overlap.hip).  Same result: the
@@ -1062,7 +1078,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   auto iload = [&](int rt, auto stage) {
     constexpr int S = decltype(stage)::value;
 #pragma unroll
-    for (int p = 0; p < PB; ++p) xi[S][p] = x_ip[min(rbeg + rt * BK + rb0 + RPB * p, rend - 1)];
+    for (int p = 0; p < PB; ++p) xi[S][p] = ldi(x_ip + min(rbeg + rt * BK + rb0 + RPB * p, rend - 1));
   };
   auto gload = [&](int rt, int rt_idx, auto stage) {
     constexpr int S = decltype(stage)::value;
@@ -1195,14 +1211,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
       for (int r = 0; r < 16; ++r) {
         const float v = tn_acc_read(acc[0][r]) + src[r * 64];
         const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk);
-        if (kv && n < a.Nout) atomicAdd(dcol + (size_t)n * a.lddw, v);
+        if (kv && n < a.Nout) sln_gatomic_add(dcol + (size_t)n * a.lddw, v);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = src[r * 64] + tn_acc_read(acc[1][r]);
         const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk) + 1;
-        if (kv && n < a.Nout) atomicAdd(dcol + (size_t)n * a.lddw, v);
+        if (kv && n < a.Nout) sln_gatomic_add(dcol + (size_t)n * a.lddw, v);
       }
     }
   }
@@ -1223,10 +1239,10 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     if (tid < TPRA) {
       const float4 p0 = dbs[tid], p1 = dbs[TPRA + tid], p2 = dbs[2 * TPRA + tid], p3 = dbs[3 * TPRA + tid];
       const int n = n0 + 4 * tid;
-      if (n + 0 < a.Nout) atomicAdd(a.db + n + 0, ((p0.x + p1.x) + p2.x) + p3.x);
-      if (n + 1 < a.Nout) atomicAdd(a.db + n + 1, ((p0.y + p1.y) + p2.y) + p3.y);
-      if (n + 2 < a.Nout) atomicAdd(a.db + n + 2, ((p0.z + p1.z) + p2.z) + p3.z);
-      if (n + 3 < a.Nout) atomicAdd(a.db + n + 3, ((p0.w + p1.w) + p2.w) + p3.w);
+      if (n + 0 < a.Nout) sln_gatomic_add(a.db + n + 0, ((p0.x + p1.x) + p2.x) + p3.x);
+      if (n + 1 < a.Nout) sln_gatomic_add(a.db + n + 1, ((p0.y + p1.y) + p2.y) + p3.y);
+      if (n + 2 < a.Nout) sln_gatomic_add(a.db + n + 2, ((p0.z + p1.z) + p2.z) + p3.z);
+      if (n + 3 < a.Nout) sln_gatomic_add(a.db + n + 3, ((p0.w + p1.w) + p2.w) + p3.w);
     }
   }
 }

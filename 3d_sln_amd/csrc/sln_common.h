@@ -39,6 +39,11 @@ struct BnView {
 // call for (mean, 1/std) that loaded the sums again - hipcc put an s_waitcnt vmcnt(0) in front of every group: three dependent
 // round trips per coefficient table, six in front of a scatter / gather kernel's first row.  Every mode is now one straight
 // block: all loads, then the arithmetic; bn_fwd_coef4 returns the four forward values from ONE set of loads.)
+// BatchNorm parameters / statistics are read as GLOBAL loads: when the view itself was read out of device memory (the problem
+// table of the per-pass wgrad launch) hipcc does not know the address space of its pointers and would emit flat loads.
+__device__ __forceinline__ float sln_ldf(const float* p) { return *(const float __attribute__((address_space(1)))*)p; }
+__device__ __forceinline__ double sln_ldd(const double* p) { return *(const double __attribute__((address_space(1)))*)p; }
+
 __device__ __forceinline__ void bn_train_mean_istd(const BnView& b, double s1, double s2, float& mean, float& istd) {
   const double m = s1 * b.rn;
   double v = fma(-m, m, s2 * b.rn);
@@ -48,10 +53,10 @@ __device__ __forceinline__ void bn_train_mean_istd(const BnView& b, double s1, d
 }
 __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean, float& istd) {
   if (b.mode == SLN_BN_TRAIN) {
-    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    const double s1 = sln_ldd(b.sums + c), s2 = sln_ldd(b.sums + b.cstride + c);
     bn_train_mean_istd(b, s1, s2, mean, istd);
   } else if (b.mode == SLN_BN_EVAL) {
-    const float rm = b.rmean[c], rv = b.rvar[c];
+    const float rm = sln_ldf(b.rmean + c), rv = sln_ldf(b.rvar + c);
     mean = rm;
     istd = __builtin_amdgcn_rsqf(rv + b.eps);
   } else {
@@ -63,14 +68,14 @@ __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean
 __device__ __forceinline__ float4 bn_fwd_coef4(const BnView& b, int c) {
   float mean, istd;
   if (b.mode == SLN_BN_TRAIN) {
-    const float gamma = b.gamma[c], beta = b.beta[c];
-    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    const float gamma = sln_ldf(b.gamma + c), beta = sln_ldf(b.beta + c);
+    const double s1 = sln_ldd(b.sums + c), s2 = sln_ldd(b.sums + b.cstride + c);
     bn_train_mean_istd(b, s1, s2, mean, istd);
     const float scale = gamma * istd;
     return make_float4(scale, beta - mean * scale, mean, istd);
   }
   if (b.mode == SLN_BN_EVAL) {
-    const float gamma = b.gamma[c], beta = b.beta[c], rm = b.rmean[c], rv = b.rvar[c];
+    const float gamma = sln_ldf(b.gamma + c), beta = sln_ldf(b.beta + c), rm = sln_ldf(b.rmean + c), rv = sln_ldf(b.rvar + c);
     mean = rm;
     istd = __builtin_amdgcn_rsqf(rv + b.eps);
     const float scale = gamma * istd;
@@ -81,8 +86,8 @@ __device__ __forceinline__ float4 bn_fwd_coef4(const BnView& b, int c) {
 // two columns of the same BatchNorm at once (the subject / object halves of GraphTripleConv's second Linear): one round trip
 __device__ __forceinline__ void bn_fwd_coef4x2(const BnView& b, int ca, int cb, float4& va, float4& vb) {
   if (b.mode == SLN_BN_TRAIN) {
-    const float ga = b.gamma[ca], ba = b.beta[ca], gb = b.gamma[cb], bb = b.beta[cb];
-    const double a1 = b.sums[ca], a2 = b.sums[b.cstride + ca], b1 = b.sums[cb], b2 = b.sums[b.cstride + cb];
+    const float ga = sln_ldf(b.gamma + ca), ba = sln_ldf(b.beta + ca), gb = sln_ldf(b.gamma + cb), bb = sln_ldf(b.beta + cb);
+    const double a1 = sln_ldd(b.sums + ca), a2 = sln_ldd(b.sums + b.cstride + ca), b1 = sln_ldd(b.sums + cb), b2 = sln_ldd(b.sums + b.cstride + cb);
     float mean, istd;
     bn_train_mean_istd(b, a1, a2, mean, istd);
     float scale = ga * istd;
@@ -103,9 +108,9 @@ __device__ __forceinline__ void bn_fwd_coef(const BnView& b, int c, float& scale
 //   train: dX = scale*(g - mean(g) - xhat*mean(g*xhat)), xhat = (x-mean)*istd
 __device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, float& p1, float& p2) {
   if (b.mode == SLN_BN_TRAIN) {
-    const float gamma = b.gamma[c];
-    const double g1 = b.gsums[c], g2 = b.gsums[b.cstride + c];
-    const double s1 = b.sums[c], s2 = b.sums[b.cstride + c];
+    const float gamma = sln_ldf(b.gamma + c);
+    const double g1 = sln_ldd(b.gsums + c), g2 = sln_ldd(b.gsums + b.cstride + c);
+    const double s1 = sln_ldd(b.sums + c), s2 = sln_ldd(b.sums + b.cstride + c);
     float mean, istd;
     bn_train_mean_istd(b, s1, s2, mean, istd);
     const float scale = gamma * istd;
@@ -117,7 +122,7 @@ __device__ __forceinline__ void bn_bwd_coef(const BnView& b, int c, float& p0, f
     return;
   }
   if (b.mode == SLN_BN_EVAL) {
-    const float gamma = b.gamma[c], rv = b.rvar[c];
+    const float gamma = sln_ldf(b.gamma + c), rv = sln_ldf(b.rvar + c);
     p0 = gamma * __builtin_amdgcn_rsqf(rv + b.eps);
     p1 = 0.f; p2 = 0.f;
     return;

@@ -598,19 +598,27 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     if (a.d_boxes_pred) a.d_boxes_pred[(size_t)r * a.ld_dbp + k] = diff > 0.f ? gb : (diff < 0.f ? -gb : 0.f);
   }
   if (a.from_logits) {
-    for (long r = i0; r < a.O; r += stride) {            // same expressions as log_softmax_kernel
-      const float* xr = a.logits + (size_t)r * a.n_angle;
-      float m = xr[0];
-      for (int k = 1; k < a.n_angle; ++k) m = fmaxf(m, xr[k]);
+    // eight lanes per object row (64 blocks x 256 threads = 8 x 2048 rows at 64 graphs): bins sub, sub + 8, .. per lane, the row
+    // maximum and the sum of exponentials meet through three xor-shuffles (every lane of a group runs the same trip count)
+    const int sub = threadIdx.x & 7;
+    for (long r = i0 >> 3; r < (((long)a.O + 31) & ~31L); r += stride >> 3) {
+      const bool rv = r < a.O;
+      const float* xr = a.logits + (size_t)(rv ? r : 0) * a.n_angle;
+      float m = -INFINITY;
+      for (int k = sub; k < a.n_angle; k += 8) m = fmaxf(m, xr[k]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
       float s = 0.f;
-      for (int k = 0; k < a.n_angle; ++k) s += expf(xr[k] - m);
+      for (int k = sub; k < a.n_angle; k += 8) s += expf(xr[k] - m);
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       const float ls = logf(s) + m;
-      const int tgt = (int)a.angles[r];
-      for (int k = 0; k < a.n_angle; ++k) {
-        const float lp = xr[k] - ls;
-        a.angles_pred[(size_t)r * a.n_angle + k] = lp;
-        if (k == tgt) nll -= (double)lp;
-        if (a.d_logits) a.d_logits[(size_t)r * a.n_angle + k] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+      if (rv) {
+        const int tgt = (int)a.angles[r];
+        for (int k = sub; k < a.n_angle; k += 8) {
+          const float lp = xr[k] - ls;
+          a.angles_pred[(size_t)r * a.n_angle + k] = lp;
+          if (k == tgt) nll -= (double)lp;
+          if (a.d_logits) a.d_logits[(size_t)r * a.n_angle + k] = (expf(lp) - (k == tgt ? 1.f : 0.f)) * go;
+        }
       }
     }
   } else {
@@ -1195,7 +1203,7 @@ int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
                     hipStream_t st) {
   SlnProfScope prof(SLN_FAM_OTHER, 28.0 * n, st);
-  long blocks = (n + 255) / 256;
+  long blocks = (n + 255) / 256;      // (a float4 form with 4 096 blocks measured 51 us against 41)
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars, total_loss);
