@@ -940,7 +940,7 @@ def main():
         flop_prof = sum(v["work"] for k, v in fam.items() if k.startswith("gemm")) / args.prof_steps
         require(abs(shp["flop_step"] - flop_prof) <= 0.01 * flop_prof, "GEMM flops of the step: shapes say %.4g, launchers summed %.4g"
                 % (shp["flop_step"], flop_prof))
-        prefixes = {"gemm_nt": ["gemm_nt_kernel", "gemm_nt_small_kernel"], "gemm_tn": ["gemm_tn_multi_kernel", "gemm_tn_kernel"],
+        prefixes = {"gemm_nt": ["gemm_nt_kernel", "gemm_nt_small_kernel", "gemm_nt16_kernel"], "gemm_tn": ["gemm_tn_multi_kernel", "gemm_tn_kernel"],
                     "gemm_dual": ["gemm_group_kernel", "gemm_dual_kernel"]}
         per_family = {}
         for k in fam:
@@ -953,7 +953,7 @@ def main():
                              "launches_per_step": fam[k]["launches"] // args.prof_steps,
                              "flop_per_launch": round(fam[k]["work"] / fam[k]["launches"], 1),
                              "avg_launch_us": round(fam[k]["ms"] / fam[k]["launches"] * 1e3, 2), "rocprof_avg_launch_us": us_k}
-        per_family["gemm_nt"]["what"] = "forward Linears and dgrads, one launch each (64x64 and 32x32 tiles)"
+        per_family["gemm_nt"]["what"] = "forward Linears and dgrads, one launch each (64x64 tiles of 32x32x2 MFMAs, 64x96 / 64x160 tiles of 16x16x4 MFMAs for N = 384 / 640, 32x32 split-K tiles for the object side)"
         if "gemm_tn" in per_family:
             per_family["gemm_tn"]["what"] = "every wgrad of a backward pass in one multi-problem launch (two per pass: gathered / plain rows)"
             per_family["gemm_tn"]["algorithmic_bytes_per_launch"] = int(shp["tn_bytes_step"] / max(per_family["gemm_tn"]["launches_per_step"], 1))
