@@ -244,6 +244,24 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // what the epilogue reads from memory is requested HERE, in front of the K loop: behind it the bias (and, for the masked dgrad,
+  // the 16 pre-activations of a 64 x 64 tile's lane) were one more memory round trip between the last MFMA and the first store
+  float bias_pre[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn0 + 32 * j + (lane & 31);
+    bias_pre[j] = a.bias ? a.bias[min(col, a.N - 1)] : 0.f;
+  }
+  constexpr bool XP_PRE = EPI == EPI_MASK && TM == 1 && TN == 1;
+  float xp_pre[XP_PRE ? 16 : 1];
+  if (XP_PRE) {
+    const int ccl = min(n0 + wn0 + (lane & 31), a.N - 1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = min(m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), a.M - 1);
+      xp_pre[r] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
+    }
+  }
 
   __syncthreads();            // coef tables visible
   SLN_TRACE(1);
@@ -447,7 +465,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     const int cl = wn0 + 32 * j + lrow;          // column inside the block tile
     const int col = n0 + cl;
     const bool cvalid = col < a.N;
-    const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+    const float bias = cvalid ? bias_pre[j] : 0.f;
     float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
     if (EPI == EPI_MASK) ec = ecoef[cl];
     float s1 = 0.f, s2 = 0.f;
@@ -467,7 +485,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
         const int row = min(m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk, a.M - 1);
         yv[r] = acc[i][j][r] + bias;
         xpv[r] = 0.f;
-        if (EPI == EPI_MASK) xpv[r] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
+        if (EPI == EPI_MASK) xpv[r] = XP_PRE ? xp_pre[r] : a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
       }
       if (has_add) {
 #pragma unroll
@@ -630,6 +648,9 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < J; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bias_pre[J];                    // requested in front of the K loop (see gemm_nt_body)
+#pragma unroll
+  for (int j = 0; j < J; ++j) bias_pre[j] = a.bias ? a.bias[min(n0 + WN16 * wc + 16 * j + (lane & 15), a.N - 1)] : 0.f;
   __syncthreads();
   SLN_TRACE(1);
   {   // tile 0 into LDS buffer 0, tile 2 into stage 0
@@ -726,7 +747,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
     const int col = n0 + cl;
     const bool cvalid = col < a.N;
     const int ccl = cvalid ? col : 0;
-    const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+    const float bias = cvalid ? bias_pre[j] : 0.f;
     float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
     if (EPI == EPI_MASK) ec = ecoef[cl];
     float yv[8], xpv[8];
@@ -897,6 +918,17 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   const int lrow = lane & 31, lk = lane >> 5;
+  // the epilogue's memory reads (bias, the mask's pre-activations, the addend: 4 rows per lane) are requested in front of the loop
+  const int pcol = min(n0 + lrow, a.N - 1);
+  const float bias_pre = a.bias ? a.bias[pcol] : 0.f;
+  float xp_pre[4], add_pre[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = min(m0 + 8 * wave + q + 4 * lk, a.M - 1);
+    xp_pre[q] = 0.f; add_pre[q] = 0.f;
+    if (EPI == EPI_MASK) xp_pre[q] = a.xprev[(size_t)row * a.ldx + a.xcol0 + pcol];
+    if (a.addend) add_pre[q] = a.addend[(size_t)row * a.ldadd + a.addcol0 + pcol];
+  }
   for (int kt = wave; kt < ntiles; kt += 4) {
     lstore(kt);
     if (kt + 4 < ntiles) gload(kt + 4);                     // wave-uniform branch; the refill flies under this tile's MFMAs
@@ -929,17 +961,13 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   const int col = n0 + lrow;
   const bool cvalid = col < a.N;
   const int ccl = cvalid ? col : 0;
-  const float bias = (cvalid && a.bias) ? a.bias[col] : 0.f;
+  const float bias = cvalid ? bias_pre : 0.f;
   float4 ec = make_float4(1.f, 0.f, 0.f, 1.f);
   if (EPI == EPI_MASK) ec = ecoef[lrow];
   float xpv[4], addv[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int row = min(m0 + 8 * wave + q + 4 * lk, a.M - 1);
-    xpv[q] = 0.f; addv[q] = 0.f;
-    if (EPI == EPI_MASK) xpv[q] = a.xprev[(size_t)row * a.ldx + a.xcol0 + ccl];
-    if (a.addend) addv[q] = a.addend[(size_t)row * a.ldadd + a.addcol0 + ccl];
-  }
+  for (int q = 0; q < 4; ++q) { xpv[q] = xp_pre[q]; addv[q] = add_pre[q]; }
+  (void)ccl;
   float s1 = 0.f, s2 = 0.f;
   double d1 = 0.0, d2 = 0.0;
 #pragma unroll
