@@ -5,6 +5,7 @@
 // backward, Adam) is 145 launches at train.py's defaults (one per forward Linear / dgrad, 30 edge
 // launches, FOUR wgrad launches - every wgrad of a pass runs in one multi-problem grid, see
 // flush_deferred -, a dozen bookkeeping launches), captured once into a hipGraph and replayed.
+#include <cstddef>
 #include <new>
 #include <vector>
 #include <cstring>
@@ -161,6 +162,42 @@ struct SlnVae {
     g.dirty = e != hipSuccess;
     return (int)e;
   }
+  // Eager calls whose problem set changed - a batch of another size, i.e. EVERY step of train.py on real rooms - upload their tables
+  // in STREAM ORDER from a ring of pinned staging buffers: the copy runs behind the previous step's launches (which read the old
+  // table) and in front of this step's, the host never waits (the blocking upload behind a hipStreamSynchronize cost 0.35 ms per
+  // step with varying shapes, tools/varshape_time.py).  A slot is reused TN_STAGE_SLOTS uploads later, after its event.
+  struct TnStage { char* host = nullptr; hipEvent_t done = nullptr; };
+  enum { TN_STAGE_SLOTS = 16 };
+  TnStage tn_stage[TN_STAGE_SLOTS];
+  int tn_stage_next = 0;
+  // stream-ordered host -> device copy of up to two pieces through the next ring slot (slot capacity: a wgrad table)
+  int stage_upload(void* dev0, const void* src0, size_t n0, void* dev1, const void* src1, size_t n1, hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return SLN_E_STATE;   // a caller's capture would record a copy out of a ring slot
+    const size_t cap0 = sizeof(GemmTNArgs) * (size_t)SLN_TN_MULTI_MAX, cap = cap0 + sizeof(TnMultiMeta);
+    if (n0 > cap0 || n1 > cap - cap0) return SLN_E_BADARG;
+    TnStage& sl = tn_stage[tn_stage_next];
+    tn_stage_next = (tn_stage_next + 1) % TN_STAGE_SLOTS;
+    hipError_t e = hipSuccess;
+    if (!sl.host) {
+      void* hp = nullptr;
+      if (hipHostMalloc(&hp, cap, hipHostMallocDefault) != hipSuccess) return SLN_E_BADARG;
+      sl.host = static_cast<char*>(hp);
+      if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(hp); sl.host = nullptr; return SLN_E_BADARG; }
+    } else {
+      e = hipEventSynchronize(sl.done);
+    }
+    if (e == hipSuccess && n0) { std::memcpy(sl.host, src0, n0); e = hipMemcpyAsync(dev0, sl.host, n0, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess && n1) { std::memcpy(sl.host + cap0, src1, n1); e = hipMemcpyAsync(dev1, sl.host + cap0, n1, hipMemcpyHostToDevice, st); }
+    if (e == hipSuccess) e = hipEventRecord(sl.done, st);
+    return (int)e;
+  }
+  int upload_group_async(TnGroup& g, hipStream_t st) {
+    const int r = stage_upload(g.dev_probs, g.probs, sizeof(GemmTNArgs) * (size_t)g.n, g.dev_meta, &g.meta,
+                               offsetof(TnMultiMeta, item) + sizeof(TnMultiItem) * (size_t)g.meta.nblocks, st);
+    if (r == 0) g.dirty = false;
+    return r;
+  }
   int upload_pending_tables() {                   // after a capture: everything the captured launches will read
     for (int w = 0; w < TN_SLOTS; ++w)
       for (int k = 0; k < 2; ++k) {
@@ -218,7 +255,10 @@ struct SlnVae {
         }
         if (g.dirty) {
           if (capturing) tn_upload_pending = true;
-          else {       // eager call with a new problem set (first call, new shape, other BatchNorm mode): rare, blocking
+          else if (lst == st) {       // eager call with a new problem set (new shape, other BatchNorm mode): stream-ordered upload
+            r = upload_group_async(g, st);
+            if (r) { deferred.clear(); return r; }
+          } else {                    // wgrads on the side stream (SLN_TN_SIDE=1): blocking, as before
             hipError_t e = hipStreamSynchronize(st);          // an earlier launch may still read the old table
             if (e == hipSuccess && side) e = hipStreamSynchronize(side);
             if (e != hipSuccess) { deferred.clear(); return (int)e; }
@@ -961,6 +1001,10 @@ void sln_vae_destroy(SlnVae* h) {
   for (auto e : h->events) (void)hipEventDestroy(e);
   if (h->side) (void)hipStreamDestroy(h->side);
   delete[] h->tn_groups_store;
+  for (auto& sl : h->tn_stage) {
+    if (sl.done) { (void)hipEventSynchronize(sl.done); (void)hipEventDestroy(sl.done); }
+    if (sl.host) (void)hipHostFree(sl.host);
+  }
   delete h;
 }
 
@@ -1007,7 +1051,7 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
   return 0;
 }
 
-static int upload_bn_table(SlnVae* h) {
+static int upload_bn_table(SlnVae* h, hipStream_t st_async = nullptr) {
   std::vector<BnTableEntry> tab(h->bns.size());
   for (size_t i = 0; i < h->bns.size(); ++i) {
     BnInst& b = h->bns[i];
@@ -1018,7 +1062,13 @@ static int upload_bn_table(SlnVae* h) {
     e.dgamma = u.p.d_bn_weight; e.dbeta = u.p.d_bn_bias;
     tab[i] = e;
   }
-  if (!tab.empty()) HIP_RET(hipMemcpy(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), hipMemcpyHostToDevice));
+  if (tab.empty()) return 0;
+  if (st_async) {      // a bound engine whose batch changed shape: in stream order, the host does not wait (SlnVae::stage_upload)
+    const int r = h->stage_upload(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), nullptr, nullptr, 0, st_async);
+    if (r != SLN_E_STATE && r != SLN_E_BADARG) return r;
+    HIP_RET(hipStreamSynchronize(st_async));      // inside a caller's capture or a table that does not fit a slot: the blocking way
+  }
+  HIP_RET(hipMemcpy(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1037,9 +1087,15 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
         if (ly.bn[k] >= 0) h->bns[ly.bn[k]].rows = k < 2 ? b->T : b->O;
     for (int s = 0; s < 6; ++s)
       if (h->bn_head[s] >= 0) h->bns[h->bn_head[s]].rows = b->O;
-    hipError_t e = hipStreamSynchronize(st);       // table upload below is a blocking copy
-    if (e != hipSuccess) return (int)e;
-    RET_IF(upload_bn_table(h));
+    bool has_graph = false;
+    for (int i = 0; i < 4; ++i) has_graph |= h->graph_exec[i] != nullptr;
+    if (has_graph) HIP_RET(hipStreamSynchronize(st));        // a replay may be in flight: finish it before its hipGraphExec goes away
+    if (st != nullptr) RET_IF(upload_bn_table(h, st));       // stream-ordered: behind the launches that read the old row counts
+    else {
+      hipError_t e = hipStreamSynchronize(st);     // the legacy default stream: a blocking copy
+      if (e != hipSuccess) return (int)e;
+      RET_IF(upload_bn_table(h));
+    }
     h->drop_graphs();
   }
   // The kernels of an iteration read the batch through h->batch.  A captured iteration (hipGraph) has those addresses baked in,
