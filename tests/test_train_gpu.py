@@ -284,3 +284,41 @@ def test_deterministic_mode_makes_fused_steps_bit_identical(mode):
     gs = float(ref_steps[0][1].abs().max())
     assert_close(plain[0][1].cpu().numpy(), ref_steps[0][1].cpu().numpy(), "first-step gradients, default vs deterministic", rtol=2e-3,
                  atol=2e-5 * gs)
+
+
+@pytest.mark.gpu
+def test_eager_steps_on_batches_of_changing_shape_need_no_host_sync():
+    """train.py on real rooms: every batch has another (O, T).  The wgrad problem tables and the BatchNorm row-count table then
+    change every step; they are uploaded in stream order (pinned ring, csrc/vae_engine.hip::stage_upload) while earlier steps
+    are still in flight.  In deterministic mode (fixed-order sums: two runs of the same sequence give the same bits) the run that
+    never drains the stream equals the run that drains it after every step BIT FOR BIT, for more steps than the ring has slots.
+    (In the default mode the arrival order of fp32 atomics differs from run to run and 30 Adam steps on 40-row BatchNorms amplify
+    that to percents - with or without the drain.)"""
+    lib = pkg("_lib").lib()
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2)
+    sd = vae_ref.init_state(cfg, seed=5)
+    sizes = [(9, 8, 12), (7, 9, 14), (12, 6, 9), (5, 8, 12), (11, 7, 13)]
+    batches = [_dev(*vae_ref.synth_batch(g, o, t, seed=20 + i, cfg=cfg)[:5]) for i, (g, o, t) in enumerate(sizes)]
+    n_steps = 30
+    eps = [torch.from_numpy(np.random.default_rng(100 + k).standard_normal((batches[k % 5][0].shape[0], cfg.embedding_dim)).astype(np.float32)).cuda()
+           for k in range(n_steps)]
+    runs = {}
+    try:
+        lib.sln_set_deterministic(1)
+        for drain in (True, False):
+            model = _model(cfg, sd).train()
+            model.validate_inputs = False
+            st = torch.cuda.Stream()
+            losses = []
+            with torch.cuda.stream(st):
+                for k in range(n_steps):
+                    losses.append(model.train_step(*batches[k % 5], kl_weight=0.1, lr=1e-3, eps=eps[k], use_graph=False))
+                    if drain:
+                        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            runs[drain] = (torch.stack(losses).cpu().numpy(), model.flat_params.detach().cpu().numpy().copy())
+    finally:
+        lib.sln_set_deterministic(0)
+    assert np.isfinite(runs[False][0]).all()
+    assert (runs[False][0] == runs[True][0]).all(), "losses without / with a drain per step"
+    assert (runs[False][1] == runs[True][1]).all(), "parameters without / with a drain per step"
