@@ -34,6 +34,7 @@ struct Unit {
 struct BnInst {
   int unit = -1;
   int C = 0, rows = 0;
+  int rows_code = 0;        // -1: runs over the triples, -2: over the objects (what the device table holds: it does not change with the batch)
   double* sums = nullptr;   // [2][C]
   double* gsums = nullptr;  // [2][C]
 };
@@ -166,6 +167,7 @@ struct SlnVae {
   // in STREAM ORDER from a ring of pinned staging buffers: the copy runs behind the previous step's launches (which read the old
   // table) and in front of this step's, the host never waits (the blocking upload behind a hipStreamSynchronize cost 0.35 ms per
   // step with varying shapes, tools/varshape_time.py).  A slot is reused TN_STAGE_SLOTS uploads later, after its event.
+  bool bn_table_live = false;      // the BatchNorm table of this binding is on the device (row counts are codes: one upload per binding)
   struct TnStage { char* host = nullptr; hipEvent_t done = nullptr; };
   enum { TN_STAGE_SLOTS = 16 };
   TnStage tn_stage[TN_STAGE_SLOTS];
@@ -555,7 +557,7 @@ int SlnVae::run_bn_updates(int first, int count, hipStream_t st) {
   if (count <= 0) return 0;
   int maxc = 0;
   for (int i = first; i < first + count; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
-  return sln_launch_bn_running_update(bn_table_dev + first, count, maxc, kBnMomentum, cfg.recurrent ? 0 : 1, st);
+  return sln_launch_bn_running_update(bn_table_dev + first, count, maxc, kBnMomentum, cfg.recurrent ? 0 : 1, st, T, O);
 }
 
 // One GraphTripleConv forward (models/graph.py:57-111) as 5 launches.
@@ -961,13 +963,13 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
       const int Cs[4] = {H, 2 * H + ly.D, H, ly.D};
       for (int k = 0; k < 4; ++k) {
         if (!h->units[ly.u0 + k].bn) continue;
-        BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;   // -1: T rows, -2: O rows (set per batch)
+        BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = b.rows_code = k < 2 ? -1 : -2;   // -1: T rows, -2: O rows (set per batch)
         ly.bn[k] = (int)h->bns.size(); h->bns.push_back(b);
       }
     }
     auto head = [&](int slot, int unit, int C) {
       if (!h->units[unit].bn) return;
-      BnInst b; b.unit = unit; b.C = C; b.rows = -2;
+      BnInst b; b.unit = unit; b.C = C; b.rows = b.rows_code = -2;
       h->bn_head[slot] = (int)h->bns.size(); h->bns.push_back(b);
     };
     if (net == 0) { head(0, 0, H); head(1, 1, W); head(2, 4, H); head(3, 5, W); h->n_bn_enc = (int)h->bns.size(); }
@@ -1046,29 +1048,23 @@ int sln_vae_bind(SlnVae* h, const SlnVaeTensors* t, void* workspace, int64_t wor
   HIP_RET(hipMemcpy(h->scalars, &sc, sizeof(sc), hipMemcpyHostToDevice));
   RET_IF(sln_gemm_init());
   h->host_scalars_valid = false;
-  h->bound = true; h->batch_set = false; h->wt_fresh = false; h->have_enc = h->have_dec = false;
+  h->bound = true; h->batch_set = false; h->wt_fresh = false; h->have_enc = h->have_dec = false; h->bn_table_live = false;
   h->drop_graphs();
   return 0;
 }
 
-static int upload_bn_table(SlnVae* h, hipStream_t st_async = nullptr) {
+static int upload_bn_table(SlnVae* h) {
   std::vector<BnTableEntry> tab(h->bns.size());
   for (size_t i = 0; i < h->bns.size(); ++i) {
     BnInst& b = h->bns[i];
     const Unit& u = h->units[b.unit];
     BnTableEntry e; std::memset(&e, 0, sizeof(e));
-    e.sums = b.sums; e.gsums = b.gsums; e.cstride = b.C; e.C = b.C; e.rows = b.rows;
+    e.sums = b.sums; e.gsums = b.gsums; e.cstride = b.C; e.C = b.C; e.rows = b.rows_code;     // the kernel gets (T, O) with its launch
     e.rmean = u.p.bn_running_mean; e.rvar = u.p.bn_running_var; e.nbt = u.p.bn_num_batches_tracked;
     e.dgamma = u.p.d_bn_weight; e.dbeta = u.p.d_bn_bias;
     tab[i] = e;
   }
-  if (tab.empty()) return 0;
-  if (st_async) {      // a bound engine whose batch changed shape: in stream order, the host does not wait (SlnVae::stage_upload)
-    const int r = h->stage_upload(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), nullptr, nullptr, 0, st_async);
-    if (r != SLN_E_STATE && r != SLN_E_BADARG) return r;
-    HIP_RET(hipStreamSynchronize(st_async));      // inside a caller's capture or a table that does not fit a slot: the blocking way
-  }
-  HIP_RET(hipMemcpy(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), hipMemcpyHostToDevice));
+  if (!tab.empty()) HIP_RET(hipMemcpy(h->bn_table_dev, tab.data(), sizeof(BnTableEntry) * tab.size(), hipMemcpyHostToDevice));
   return 0;
 }
 
@@ -1087,15 +1083,15 @@ int sln_vae_set_batch(SlnVae* h, const SlnVaeBatch* b, void* stream) {
         if (ly.bn[k] >= 0) h->bns[ly.bn[k]].rows = k < 2 ? b->T : b->O;
     for (int s = 0; s < 6; ++s)
       if (h->bn_head[s] >= 0) h->bns[h->bn_head[s]].rows = b->O;
+    // (the device table holds row-count CODES, the running-statistics kernel gets (T, O) with its launch: uploaded once per binding)
+    if (!h->bn_table_live) {
+      HIP_RET(hipStreamSynchronize(st));
+      RET_IF(upload_bn_table(h));
+      h->bn_table_live = true;
+    }
     bool has_graph = false;
     for (int i = 0; i < 4; ++i) has_graph |= h->graph_exec[i] != nullptr;
     if (has_graph) HIP_RET(hipStreamSynchronize(st));        // a replay may be in flight: finish it before its hipGraphExec goes away
-    if (st != nullptr) RET_IF(upload_bn_table(h, st));       // stream-ordered: behind the launches that read the old row counts
-    else {
-      hipError_t e = hipStreamSynchronize(st);     // the legacy default stream: a blocking copy
-      if (e != hipSuccess) return (int)e;
-      RET_IF(upload_bn_table(h));
-    }
     h->drop_graphs();
   }
   // The kernels of an iteration read the batch through h->batch.  A captured iteration (hipGraph) has those addresses baked in,
@@ -1370,7 +1366,7 @@ int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, 
     const int Cs[4] = {H, 2 * H + Dout, H, Dout};
     for (int k = 0; k < 4; ++k) {
       if (!h->units[ly.u0 + k].bn) continue;
-      BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = k < 2 ? -1 : -2;
+      BnInst b; b.unit = ly.u0 + k; b.C = Cs[k]; b.rows = b.rows_code = k < 2 ? -1 : -2;
       ly.bn[k] = (int)h->bns.size(); h->bns.push_back(b);
     }
   }
@@ -1401,8 +1397,12 @@ int sln_gconv_net_set_edges(SlnVae* h, const int64_t* edges, int O, int T, void*
     for (auto& ly : h->layers)
       for (int k = 0; k < 4; ++k)
         if (ly.bn[k] >= 0) h->bns[ly.bn[k]].rows = k < 2 ? T : O;
-    HIP_RET(hipStreamSynchronize(st));
-    RET_IF(upload_bn_table(h));
+    // (the device table holds row-count codes, see sln_vae_set_batch: uploaded once per binding)
+    if (!h->bn_table_live) {
+      HIP_RET(hipStreamSynchronize(st));
+      RET_IF(upload_bn_table(h));
+      h->bn_table_live = true;
+    }
   }
   RET_IF(sln_zero_async(h->err_flag, sizeof(int), st));
   RET_IF(sln_launch_graph_prep(edges, T, O, 1 << 30, h->g, h->err_flag, st, 1, 0));

@@ -123,8 +123,9 @@ struct BnTableEntry {      // one BatchNorm application (module may repeat in 'r
   float* rmean; float* rvar; int64_t* nbt; float* dgamma; float* dbeta;
 };
 // independent != 0: no BatchNorm module occurs twice in the table (feedforward mode) -> one block row per entry
+// table rows == -1 / -2: the batch's triple / object count (rows_t / rows_o), rows > 0: as given
 int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, int independent,
-                                 hipStream_t st);
+                                 hipStream_t st, int rows_t = 0, int rows_o = 0);
 int sln_launch_bn_param_grads(const BnTableEntry* table, int n, int max_c, int independent, hipStream_t st);
 
 struct TransposeEntry { const float* src; float* dst; int rows; int cols; int dst_ld; int pad_; };   // dst[c*dst_ld + r] = src[r*cols + c]

@@ -681,18 +681,21 @@ __global__ void latent_bwd_kernel(const float* __restrict__ mu, const float* __r
 // ----------------------------------------------------------------------------------------------
 // BatchNorm bookkeeping, transposes, Adam
 // ----------------------------------------------------------------------------------------------
-__global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, int n, float mom, int per_entry) {
+// rows_t / rows_o: the batch's triple / object counts; a table entry with rows == -1 / -2 means "the triples" / "the objects" (the
+// engine's table then does not change with the batch's shape: no upload per step on real rooms), rows > 0 is taken as it is
+__global__ void bn_running_update_kernel(const BnTableEntry* __restrict__ tab, int n, float mom, int per_entry, int rows_t, int rows_o) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   const int e0 = per_entry ? blockIdx.y : 0, e1 = per_entry ? blockIdx.y + 1 : n;
   for (int e = e0; e < e1; ++e) {             // sequential form: application order, shared modules see ordered updates
     const BnTableEntry t = tab[e];
     if (c == 0 && t.nbt) t.nbt[0] += 1;
     if (c >= t.C || t.rmean == nullptr) continue;
-    const double N = (double)t.rows;
+    const int rows = t.rows == -1 ? rows_t : (t.rows == -2 ? rows_o : t.rows);
+    const double N = (double)rows;
     const double m = t.sums[c] / N;
     double v = t.sums[t.cstride + c] / N - m * m;
     v = v < 0.0 ? 0.0 : v;
-    const double vu = t.rows > 1 ? v * N / (N - 1.0) : v;
+    const double vu = rows > 1 ? v * N / (N - 1.0) : v;
     t.rmean[c] = (1.f - mom) * t.rmean[c] + mom * (float)m;
     t.rvar[c] = (1.f - mom) * t.rvar[c] + mom * (float)vu;
   }
@@ -1177,10 +1180,10 @@ int sln_launch_latent_bwd(const float* mu, const float* logvar, const float* eps
 }
 
 int sln_launch_bn_running_update(const BnTableEntry* table, int n, int max_c, float momentum, int independent,
-                                 hipStream_t st) {
+                                 hipStream_t st, int rows_t, int rows_o) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(bn_running_update_kernel, dim3(sln_cdiv(max_c, 256), independent ? n : 1), dim3(256), 0, st, table, n,
-                     momentum, independent);
+                     momentum, independent, rows_t, rows_o);
   SLN_CHECK_LAUNCH();
   return 0;
 }
