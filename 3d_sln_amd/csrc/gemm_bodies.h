@@ -20,6 +20,12 @@ namespace {
 #ifndef SLN_NT_SCHED
 #define SLN_NT_SCHED 1
 #endif
+#ifndef SLN_TN_SCHED      // 1: the wgrad K loop in a hand-ordered schedule (gemm_tn_body), 0: hipcc's order (lab A/B)
+#define SLN_TN_SCHED 1
+#endif
+#ifndef SLN_TN_ABL        // lab builds only (SLN_HIPCC_EXTRA=-DSLN_TN_ABL=n): leave parts of the wgrad loop out - 1 loads, 2 staging + LDS writes, 4 barrier, 8 fragment reads
+#define SLN_TN_ABL 0
+#endif
 #ifndef SLN_ABL           // tools/lab/gemm_lab.hip only: leave parts of the scheduled loop out (1 loads, 2 LDS writes, 4 barrier, 8 fragment reads)
 #define SLN_ABL 0
 #endif
@@ -61,6 +67,16 @@ __device__ __forceinline__ float4 xform(float4 x1, float4 x2, const float4* cf) 
   c = cf[1]; r.y = sln_vmax(fmaf(c.x, x1.y, fmaf(c.y, x2.y, c.z)), c.w);
   c = cf[2]; r.z = sln_vmax(fmaf(c.x, x1.z, fmaf(c.y, x2.z, c.z)), c.w);
   c = cf[3]; r.w = sln_vmax(fmaf(c.x, x1.w, fmaf(c.y, x2.w, c.z)), c.w);
+  return r;
+}
+
+// the same with the four coefficient kinds of the thread's four columns as one float4 each (planar table: conflict-free LDS reads)
+__device__ __forceinline__ float4 xform_planar(float4 x1, float4 x2, float4 c0, float4 c1, float4 c2, float4 cw) {
+  float4 r;
+  r.x = sln_vmax(fmaf(c0.x, x1.x, fmaf(c1.x, x2.x, c2.x)), cw.x);
+  r.y = sln_vmax(fmaf(c0.y, x1.y, fmaf(c1.y, x2.y, c2.y)), cw.y);
+  r.z = sln_vmax(fmaf(c0.z, x1.z, fmaf(c1.z, x2.z, c2.z)), cw.z);
+  r.w = sln_vmax(fmaf(c0.w, x1.w, fmaf(c1.w, x2.w, c2.w)), cw.w);
   return r;
 }
 
@@ -1085,8 +1101,17 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   const int rbeg = by * a.rows_per_block;
   const int rend = min(a.R, rbeg + a.rows_per_block);
 
-  // per-column coefficient tables for this block's column ranges
-  for (int c = tid; c < BM; c += 256) coefG[c] = coef_for_col(a.G, n0 + c);
+  // per-column coefficient tables for this block's column ranges.  The two-source path re-reads G's coefficients from LDS for every
+  // staged tile; as an array of float4 per column a lane's four ds_read_b128 (columns 4 i .. 4 i + 3 of lane i % 16: a 64-byte
+  // stride) ran 4-way bank-conflicted - 64 LDS cycles per wave and tile, half of the kernel's LDS time with three workgroups per
+  // CU.  That table is PLANAR here ([kind][column]): the four coefficients of a kind for a lane's four columns are one aligned
+  // float4, 16 lanes read 256 contiguous bytes.
+  float* coefGp = reinterpret_cast<float*>(coefG);            // G_X2: [4 kinds][BM]
+  for (int c = tid; c < BM; c += 256) {
+    const float4 v = coef_for_col(a.G, n0 + c);
+    if (G_X2) { coefGp[c] = v.x; coefGp[BM + c] = v.y; coefGp[2 * BM + c] = v.z; coefGp[3 * BM + c] = v.w; }
+    else coefG[c] = v;
+  }
   for (int c = tid; c < BN; c += 256) coefX[c] = coef_for_col(a.X, k0 + c);
 
   const int ca = 4 * (tid % TPRA), ra0 = tid / TPRA;
@@ -1110,6 +1135,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   };
   auto gload = [&](int rt, int rt_idx, auto stage) {
     constexpr int S = decltype(stage)::value;
+    if (SLN_TN_ABL & 1) return;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int row = min(rbeg + rt * BK + ra0 + RPA * p, rend - 1);
@@ -1130,6 +1156,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   // stored as zeros
   auto lstore = [&](int rt, int buf, auto stage) {
     constexpr int S = decltype(stage)::value;
+    if (SLN_TN_ABL & 2) return;
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
       const int rl = ra0 + RPA * p;
@@ -1140,7 +1167,10 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
       const bool v = (rbeg + rt * BK + rl) < rend;
       // two-source gradients (BatchNorm backward) keep their coefficients in LDS: with them in registers the dgrad + wgrad kernels
       // need 172-180 registers and lose the third workgroup per CU
-      float4 t = G_X2 ? xform(g1[S][p], g2[S][p], coefG + ca) : xform1(g1[S][p], cG);
+      float4 t = G_X2 ? xform_planar(g1[S][p], g2[S][p], *reinterpret_cast<const float4*>(coefGp + ca),
+                                     *reinterpret_cast<const float4*>(coefGp + BM + ca), *reinterpret_cast<const float4*>(coefGp + 2 * BM + ca),
+                                     *reinterpret_cast<const float4*>(coefGp + 3 * BM + ca))
+                      : xform1(g1[S][p], cG);
       t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
       dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
       *reinterpret_cast<float4*>(As + buf * BK * SA + rl * SA + ca) = t;
@@ -1175,7 +1205,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   // first quarter right after the barrier, under the MFMAs of the current tile's last quarter (as in gemm_nt_body)
   const int wr = wave >> 1, wc = wave & 1;
   float2 fa[2][2]; float fb[2][2];
-  auto rd = [&](int buf, int quarter, auto set) {
+  auto rd = [&](int buf, int quarter, auto set) __attribute__((always_inline)) {
     constexpr int F = decltype(set)::value;
     const float* as = As + buf * BK * SA + (16 * wr + 4 * quarter + lk) * SA + 2 * lrow;
     const float* bs = Bs + buf * BK * SB + (16 * wr + 4 * quarter + lk) * SB + 32 * wc + lrow;
@@ -1200,17 +1230,94 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     lstore(rt + 1, buf ^ 1, stage_next);
     gload(min(rt + 3, last), min(rt + 5, last), stage_next);
     __builtin_amdgcn_sched_barrier(0);
-    rd(buf, 1, S1{});
+    if (!(SLN_TN_ABL & 8)) rd(buf, 1, S1{});
     mma(S0{});
-    rd(buf, 2, S0{});
+    if (!(SLN_TN_ABL & 8)) rd(buf, 2, S0{});
     mma(S1{});
-    rd(buf, 3, S1{});
+    if (!(SLN_TN_ABL & 8)) rd(buf, 3, S1{});
     mma(S0{});
-    __syncthreads();
-    rd(buf ^ 1, 0, S0{});
+    if (!(SLN_TN_ABL & 4)) __syncthreads();
+    if (!(SLN_TN_ABL & 8)) rd(buf ^ 1, 0, S0{});
     mma(S1{});
   };
+#if SLN_TN_SCHED
+  // The same loop with its instruction order written out (as gemm_nt_body's): hipcc issues the tile's four to six global loads and
+  // four LDS writes back to back at the top of the body, and a second memory instruction behind the first stalls the wave at the
+  // issue stage (64 / 52 clocks, tools/lab/overlap.hip) with all its MFMAs queued behind - without the loads the stand-alone
+  // 32 k-row wgrad runs at 100 TF instead of 85 (SLN_TN_ABL).  Here every store / reload pair of a staging pass sits behind its own
+  // MFMA: G passes behind MFMAs 0 .. 3 (the second source one slot later), X passes behind 4 and 5, the row indices of a gathered
+  // X behind 6 and 7; fragment reads a quarter ahead as before.  Same arithmetic, same sums.
+  {
+#define SLN_SB __builtin_amdgcn_sched_barrier(0)
+    auto pieceG = [&](int rt, int buf, int p, auto stage) __attribute__((always_inline)) {       // store pass p of tile rt + 1, reload x1 of tile rt + 3
+      constexpr int S = decltype(stage)::value;
+      const int rl = ra0 + RPA * p;
+      const bool v = (rbeg + (rt + 1) * BK + rl) < rend;
+      float4 t = G_X2 ? xform_planar(g1[S][p], g2[S][p], *reinterpret_cast<const float4*>(coefGp + ca),
+                                     *reinterpret_cast<const float4*>(coefGp + BM + ca), *reinterpret_cast<const float4*>(coefGp + 2 * BM + ca),
+                                     *reinterpret_cast<const float4*>(coefGp + 3 * BM + ca))
+                      : xform1(g1[S][p], cG);
+      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+      dbacc.x += t.x; dbacc.y += t.y; dbacc.z += t.z; dbacc.w += t.w;
+      *reinterpret_cast<float4*>(As + (buf ^ 1) * BK * SA + rl * SA + ca) = t;
+      SLN_SB;
+      const int row = min(rbeg + min(rt + 3, last) * BK + ra0 + RPA * p, rend - 1);
+      g1[S][p] = ld4(gs.x1 + (size_t)row * gs.ld1);
+    };
+    auto pieceG2 = [&](int rt, int p, auto stage) __attribute__((always_inline)) {
+      constexpr int S = decltype(stage)::value;
+      const int row = min(rbeg + min(rt + 3, last) * BK + ra0 + RPA * p, rend - 1);
+      if (G_X2) g2[S][p] = ld4(g_x2 + (size_t)row * g_ld2);
+    };
+    auto pieceX = [&](int rt, int buf, int p, auto stage) __attribute__((always_inline)) {
+      constexpr int S = decltype(stage)::value;
+      *reinterpret_cast<float4*>(Bs + (buf ^ 1) * BK * SB + (rb0 + RPB * p) * SB + cb) = xform1(x1[S][p], cX);
+      SLN_SB;
+      const int row = min(rbeg + min(rt + 3, last) * BK + rb0 + RPB * p, rend - 1);
+      const int r = XG ? (xs.which ? xi[S][p] : row) : row;
+      x1[S][p] = ld4(xs.x1 + (size_t)r * xs.ld1);
+    };
+    auto pieceI = [&](int rt, int p, auto stage) __attribute__((always_inline)) {               // indices of the tile this stage loads next
+      constexpr int S = decltype(stage)::value;
+      if (XG) xi[S][p] = ldi(x_ip + min(rbeg + min(rt + 5, last) * BK + rb0 + RPB * p, rend - 1));
+    };
+    // the four MFMAs of a quarter (two k-steps x two accumulators), hook(n) behind the n-th
+    auto mma4 = [&](auto set, auto&& hook) __attribute__((always_inline)) {
+      constexpr int F = decltype(set)::value;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][0].x, fb[F][0], acc[0], 0, 0, 0); SLN_SB; hook(0); SLN_SB;
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][0].y, fb[F][0], acc[1], 0, 0, 0); SLN_SB; hook(1); SLN_SB;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][1].x, fb[F][1], acc[0], 0, 0, 0); SLN_SB; hook(2); SLN_SB;
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[F][1].y, fb[F][1], acc[1], 0, 0, 0); SLN_SB; hook(3); SLN_SB;
+    };
+    static_assert(PA == 2 && PB == 2, "two staging passes per operand and tile");
+    auto sbody = [&](int rt, auto stage_next) __attribute__((always_inline)) {
+      const int buf = rt & 1;
+      rd(buf, 1, S1{});
+      SLN_SB;
+      mma4(S0{}, [&](int n) __attribute__((always_inline)) {
+        if (n == 0) pieceG(rt, buf, 0, stage_next);
+        if (n == 1) pieceG2(rt, 0, stage_next);
+        if (n == 2) pieceG(rt, buf, 1, stage_next);
+        if (n == 3) { pieceG2(rt, 1, stage_next); rd(buf, 2, S0{}); }
+      });
+      mma4(S1{}, [&](int n) __attribute__((always_inline)) {
+        if (n == 0) pieceX(rt, buf, 0, stage_next);
+        if (n == 1) pieceX(rt, buf, 1, stage_next);
+        if (n == 2) pieceI(rt, 0, stage_next);
+        if (n == 3) { pieceI(rt, 1, stage_next); rd(buf, 3, S1{}); }
+      });
+      mma4(S0{}, [&](int) __attribute__((always_inline)) {});
+      __syncthreads();
+      rd(buf ^ 1, 0, S0{});
+      SLN_SB;
+      mma4(S1{}, [&](int) __attribute__((always_inline)) {});
+    };
+#undef SLN_SB
+    for (int rt = 0; rt < ntiles; rt += 2) { sbody(rt, S1{}); sbody(rt + 1, S0{}); }
+  }
+#else
   for (int rt = 0; rt < ntiles; rt += 2) { body(rt, S1{}); body(rt + 1, S0{}); }
+#endif
 
   // ---- the two row halves meet: wave (wr, wc) finishes accumulator ja = wr of column half wc ----
   // Accumulators are read out of the AGPRs at their use (v_accvgpr_read through an "a" constraint): left alone hipcc copies all
