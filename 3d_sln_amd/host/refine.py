@@ -211,6 +211,9 @@ class _RefineLossFn(torch.autograd.Function):
         return g, None
 
 
+_REFINE_TABLES = {}          # (image size, scales, device) -> (device tables, longest CSR row): see RefineLoss.__init__
+
+
 class RefineLoss:
     """``refinement_loss`` for a fixed target as two C calls (csrc/refine_loss.hip) instead of ~200 torch launches.
     ``rl(image)`` -> tensor [100*depth + 100*sem, depth, sem]; gradients flow to ``image`` through element 0.  The
@@ -219,6 +222,19 @@ class RefineLoss:
     def __init__(self, target, sizes=(32, 48, 64, 96)):
         dev = target.device
         B, C, S, _ = target.shape
+        P, ns, pmax = sizes[-1], len(sizes), max(sizes)
+        # the resampling tables depend on the geometry only (image size, scales), not on the room: built once per geometry and device
+        # (python / numpy loops over 4 x 256 image rows: ~5 ms of the ~7 ms per-room set-up of the refinement loop)
+        key = (S, tuple(sizes), str(dev))
+        cached = _REFINE_TABLES.get(key)
+        if cached is None:
+            cached = _REFINE_TABLES[key] = self._build_tables(S, sizes, dev)
+        self._keep, max_col = cached
+        d = self._describe(B, S, P, C, ns, pmax, max_col)
+        self._finish(d, target, B, S, P, C, ns, dev)
+
+    @staticmethod
+    def _build_tables(S, sizes, dev):
         P, ns, pmax = sizes[-1], len(sizes), max(sizes)
         s2 = [np.zeros((ns, P), np.int32), np.zeros((ns, P), np.int32), np.zeros((ns, P), np.float32)]
         s1 = [np.zeros((ns, pmax), np.int32), np.zeros((ns, pmax), np.int32), np.zeros((ns, pmax), np.float32)]
@@ -242,13 +258,19 @@ class RefineLoss:
                 cp.append(cp[-1] + len(nz))
             ptr.append(np.asarray(cp, np.int32))
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        self._keep = [t(x) for x in s2 + s1] + [t(np.stack(ptr)), t(np.concatenate(outs)), t(np.concatenate(ws_))]
+        keep = [t(x) for x in s2 + s1] + [t(np.stack(ptr)), t(np.concatenate(outs)), t(np.concatenate(ws_))]
+        return keep, int(max(len(o) for o in outs))
+
+    def _describe(self, B, S, P, C, ns, pmax, max_col):
         d = _lib.SlnRefineLoss()
         d.B, d.image_size, d.pooled_size, d.channels = B, S, P, C
         d.sem0, d.n_sem, d.dep0, d.n_dep, d.n_scales, d.stage1_stride = 1, 40, 41, C - 41, ns, pmax
         for name, buf in zip(("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w"), self._keep):
             setattr(d, name, buf.data_ptr())
-        d.max_col_entries = int(max(len(o) for o in outs))
+        d.max_col_entries = max_col
+        return d
+
+    def _finish(self, d, target, B, S, P, C, ns, dev):
         self.desc = d
         L = _lib.lib()
         self.ws = torch.empty(int(L.sln_refine_loss_workspace_bytes(B, S, P, ns, 40, C - 41)), dtype=torch.uint8, device=dev)
