@@ -210,8 +210,15 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
   const int deg = e - b;
   for (int k = 0; k < deg; k += EB) {
     int en[EB]; float4 x[EB];
+    // (a select between the LDS copy and the global list makes hipcc emit flat loads, which count on both wait counters: the
+    //  common case - the whole list is cached - reads LDS only; the branch is uniform per row)
+    if (deg <= ECACHE) {
 #pragma unroll
-    for (int u = 0; u < EB; ++u) { const int kk = min(k + u, deg - 1); en[u] = kk < ECACHE ? ents[threadIdx.y][kk] : g.ent[b + kk]; }
+      for (int u = 0; u < EB; ++u) en[u] = ents[threadIdx.y][min(k + u, deg - 1)];
+    } else {
+#pragma unroll
+      for (int u = 0; u < EB; ++u) { const int kk = min(k + u, deg - 1); en[u] = kk < ECACHE ? ents[threadIdx.y][kk] : g.ent[b + kk]; }
+    }
 #pragma unroll
     for (int u = 0; u < EB; ++u) {
       const bool isobj = en[u] >= T;
@@ -302,8 +309,13 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
     const int deg = e - b;
     for (int k = 0; k < deg; k += EB) {
       int en[EB]; float4 x[EB];
+      if (deg <= ECACHE) {           // see scatter_avg_fwd_v4_kernel
 #pragma unroll
-      for (int u = 0; u < EB; ++u) { const int q = min(k + u, deg - 1); en[u] = q < ECACHE ? ents[threadIdx.y][q] : g.ent[b + q]; }
+        for (int u = 0; u < EB; ++u) en[u] = ents[threadIdx.y][min(k + u, deg - 1)];
+      } else {
+#pragma unroll
+        for (int u = 0; u < EB; ++u) { const int q = min(k + u, deg - 1); en[u] = q < ECACHE ? ents[threadIdx.y][q] : g.ent[b + q]; }
+      }
 #pragma unroll
       for (int u = 0; u < EB; ++u) {
         const bool isobj = en[u] >= T;
