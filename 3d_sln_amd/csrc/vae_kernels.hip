@@ -1107,7 +1107,9 @@ int sln_launch_embed_bwd_i32(const int* idx, const float* d, int ld, int col0, i
     return 0;
   }
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
-    const int rpb = 64;
+    // 16 rows per workgroup: 256 workgroups at 64 graphs (64 rows left three quarters of the CUs idle: 16 -> 6 us per launch;
+    // 8 / 4 rows pay more flush atomics than they gain: SLN_EMB_RPB)
+    static const int rpb = std::getenv("SLN_EMB_RPB") ? std::atoi(std::getenv("SLN_EMB_RPB")) : 16;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st, idx,
                        d, ld, col0, rows, n, table_rows, rpb, d_emb);
     SLN_CHECK_LAUNCH();
@@ -1129,7 +1131,9 @@ int sln_launch_embed_bwd_i64(const int64_t* idx, const float* d, int ld, int col
     return 0;
   }
   if (table_rows > 0 && (long)table_rows * n <= 8192) {
-    const int rpb = 64;
+    // 16 rows per workgroup: 256 workgroups at 64 graphs (64 rows left three quarters of the CUs idle: 16 -> 6 us per launch;
+    // 8 / 4 rows pay more flush atomics than they gain: SLN_EMB_RPB)
+    static const int rpb = std::getenv("SLN_EMB_RPB") ? std::atoi(std::getenv("SLN_EMB_RPB")) : 16;
     hipLaunchKernelGGL(embed_bwd_lds_kernel<int64_t>, dim3(sln_cdiv(rows, rpb)), dim3(256), sizeof(float) * table_rows * n, st,
                        idx, d, ld, col0, rows, n, table_rows, rpb, d_emb);
     SLN_CHECK_LAUNCH();
