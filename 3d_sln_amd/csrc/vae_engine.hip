@@ -292,6 +292,7 @@ struct SlnVae {
   // ------------------------------------------------------------------------------------------
   // Round 3: bookkeeping launches of the fused iteration merged (train_iteration sets these around its calls; the stand-alone
   // entry points - sln_vae_encoder / _decoder / _loss / *_backward - keep their own launches):
+  bool it_zero_in_prologue = false;   // ... and that launch also clears the iteration's accumulators
   bool it_prologue = false;       // enc_assemble + both predicate gathers (+ the N(0,1) draw) already issued as ONE launch
   bool it_fused_loss = false;     // log_softmax is taken inside the loss kernel
   bool it_merge_bn = false;       // ONE running-statistics launch per iteration (after the decoder) and ONE parameter-gradient launch
@@ -622,6 +623,7 @@ int SlnVae::encoder_forward(bool training, hipStream_t st) {
     sp.enc = ea; sp.pidx = g.p; sp.T = T;
     sp.pemb_ec = t.pred_emb_ec; sp.n_ec = Dec; sp.p0e = P0e;
     sp.pemb_dc = t.pred_emb_dc; sp.n_dc = Ddc; sp.p0d = P0d;
+    if (it_zero_in_prologue) { sp.zero_ptr = zero_begin; sp.zero_bytes = (long)zero_bytes; }
     RET_IF(sln_launch_step_prologue(sp, st));
   } else {
     RET_IF(sln_launch_enc_assemble(ea, st));
@@ -868,10 +870,13 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
   int r = 0;
   if (mode != TRAIN_ENCODER_BWD) {
     HIP_RET(hipMemsetAsync(t.flat_grads, 0, sizeof(float) * (size_t)t.n_flat, st));
-    HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));      // loss accumulators + every BatchNorm sum of the iteration
-    bulk_zeroed = true;
     const bool no_merge = this->no_merge;                                         // SLN_NO_MERGE=1 (read at creation): the round-2 launch sequence
     it_prologue = it_fused_loss = !no_merge;
+    // loss accumulators + every BatchNorm sum of the iteration: cleared by the prologue launch (the first kernel of the iteration,
+    // nothing in front of it touches them) when the region can be written as 16-byte words, by a memset node otherwise
+    it_zero_in_prologue = it_prologue && (reinterpret_cast<uintptr_t>(zero_begin) & 15) == 0 && (zero_bytes & 15) == 0;
+    if (!it_zero_in_prologue) HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));
+    bulk_zeroed = true;
     it_merge_bn = !no_merge && (mode == TRAIN_BACKWARD || mode == TRAIN_FULL);    // the two-half form hands the decoder's gradients out early
     if (!it_prologue && draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
     if (!r) r = encoder_forward(step_training, st);
@@ -889,7 +894,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     if (!r) r = encoder_backward(st);
   }
   bulk_zeroed = false;
-  it_prologue = it_fused_loss = it_merge_bn = false;
+  it_prologue = it_fused_loss = it_merge_bn = it_zero_in_prologue = false;
   RET_IF(r);
   RET_IF(join_tn_side(st));            // the parameter gradients are complete behind this point (all-reduce, optimizer)
   if (mode == TRAIN_FULL) {

@@ -153,5 +153,6 @@ struct StepPrologue {
   const int* pidx; int T;
   const float* pemb_ec; int n_ec; float* p0e;
   const float* pemb_dc; int n_dc; float* p0d;
+  void* zero_ptr; long zero_bytes;      // optional: a region to clear (16-byte aligned, a multiple of 16 bytes): the iteration's loss accumulators and BatchNorm sums
 };
 int sln_launch_step_prologue(const StepPrologue& a, hipStream_t st);

@@ -813,12 +813,16 @@ __global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ eps, lon
 }
 
 // blocks [0, b0) draw eps, [b0, b1) assemble the encoder input, [b1, b2) / [b2, ..) gather the two predicate embeddings
-__global__ __launch_bounds__(256) void step_prologue_kernel(StepPrologue a, unsigned int b0, unsigned int b1, unsigned int b2) {
+__global__ __launch_bounds__(256) void step_prologue_kernel(StepPrologue a, unsigned int b0, unsigned int b1, unsigned int b2, unsigned int b3) {
   const unsigned int b = blockIdx.x;
   if (b < b0) randn_body(a.eps, a.n_eps, a.scalars, b, b0);
   else if (b < b1) enc_assemble_body(a.enc, b - b0);
   else if (b < b2) embed_gather_body(a.pidx, a.pemb_ec, a.T, a.n_ec, a.p0e, b - b1);
-  else embed_gather_body(a.pidx, a.pemb_dc, a.T, a.n_dc, a.p0d, b - b2);
+  else if (b < b3) embed_gather_body(a.pidx, a.pemb_dc, a.T, a.n_dc, a.p0d, b - b2);
+  else {                                  // the iteration's accumulators (one launch less than a memset node of their own)
+    const long i = (long)(b - b3) * 256 + threadIdx.x;
+    if (i * 16 < a.zero_bytes) reinterpret_cast<uint4*>(a.zero_ptr)[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
 }
 
 // out[r, c] = relu(bn(x[r, col0 + c]))  (materialise a post-activation, standalone GraphTripleConv API only)
@@ -1243,9 +1247,10 @@ int sln_launch_step_prologue(const StepPrologue& a, hipStream_t st) {
   const unsigned int nr = a.eps ? blocks((a.n_eps + 3) / 4) : 0;
   const unsigned int ne = blocks((long)a.enc.O * (a.enc.n_obj + a.enc.n_attr + a.enc.n_box + a.enc.n_angle));
   const unsigned int n1 = blocks((long)a.T * a.n_ec), n2 = blocks((long)a.T * a.n_dc);
-  const unsigned int tot = nr + ne + n1 + n2;
+  const unsigned int nz = a.zero_ptr ? blocks(a.zero_bytes / 16) : 0;
+  const unsigned int tot = nr + ne + n1 + n2 + nz;
   if (tot == 0) return 0;
-  hipLaunchKernelGGL(step_prologue_kernel, dim3(tot), dim3(256), 0, st, a, nr, nr + ne, nr + ne + n1);
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(tot), dim3(256), 0, st, a, nr, nr + ne, nr + ne + n1, nr + ne + n1 + n2);
   SLN_CHECK_LAUNCH();
   return 0;
 }
