@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void lab_nt16(const GemmNTArgs a) {
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 int main() {
-  const int shapes[][3] = {{4096, 256, 384}, {4096, 640, 256}, {4096, 384, 256}, {2048, 256, 256}, {2048, 128, 256}, {2048, 256, 128}, {32768, 640, 256}};
+  const int shapes[][3] = {{4096, 256, 384}, {4096, 256, 640}, {4096, 640, 256}, {4096, 384, 256}, {2048, 256, 256}, {2048, 128, 256}, {2048, 256, 128}, {32768, 640, 256}};
   long long* trace; CK(hipMalloc(&trace, sizeof(long long) * 8 * 65536));
   CK(hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &trace, sizeof(trace)));
   for (auto& sh : shapes) {
@@ -82,6 +82,34 @@ int main() {
     printf("M=%5d N=%4d K=%4d grid %4d: %6.2f us/launch (%.1f TF) | span %lld ticks; median ticks: coef/prologue %lld, first tile %lld, main loop %lld (%d k-tiles), epilogue %lld; block start p50 %lld p100 %lld\n",
            M, N, K, grid, ms / 50 * 1e3, 2.0 * M * N * K / (ms / 50 * 1e-3) / 1e12, tmax - tmin, med(ph[0]), med(ph[1]), med(ph[2]), (K + 31) / 32, med(ph[3]),
            starts[starts.size() / 2], starts.back());
+    {   // the same problem with a train-mode BatchNorm + ReLU operand (AMODE 0): what does the coefficient set-up add to the prologue?
+      float *gamma, *beta; double* bsums;
+      CK(hipMalloc(&gamma, sizeof(float) * K)); CK(hipMalloc(&beta, sizeof(float) * K)); CK(hipMalloc(&bsums, sizeof(double) * 2 * K));
+      std::vector<float> hg(K, 1.0f), hb(K, 0.1f); std::vector<double> hs(2 * K);
+      for (int c = 0; c < K; ++c) { hs[c] = 0.5 * M; hs[K + c] = 1.25 * M; }
+      CK(hipMemcpy(gamma, hg.data(), sizeof(float) * K, hipMemcpyHostToDevice)); CK(hipMemcpy(beta, hb.data(), sizeof(float) * K, hipMemcpyHostToDevice));
+      CK(hipMemcpy(bsums, hs.data(), sizeof(double) * 2 * K, hipMemcpyHostToDevice));
+      GemmNTArgs ab = a;
+      ab.A.seg[0].coef = SLN_COEF_FWD;
+      BnView v; memset(&v, 0, sizeof(v));
+      v.sums = bsums; v.gamma = gamma; v.beta = beta; v.cstride = K; v.mode = SLN_BN_TRAIN; v.n_rows = (float)M; v.eps = 1e-5f; v.rn = 1.0 / M;
+      ab.A.seg[0].bn = v;
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_nt<64, 64, 0, EPI_STATS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 0, EPI_STATS>), dim3(grid), dim3(256), smem, 0, ab);
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 0, EPI_STATS>), dim3(grid), dim3(256), smem, 0, ab);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float msb; CK(hipEventElapsedTime(&msb, e0, e1));
+      std::vector<long long> tb(8 * grid);
+      CK(hipMemcpy(tb.data(), trace, sizeof(long long) * 8 * grid, hipMemcpyDeviceToHost));
+      std::vector<long long> phb[4];
+      for (int b2 = 0; b2 < grid; ++b2) for (int p = 0; p < 4; ++p) phb[p].push_back(tb[8 * b2 + p + 1] - tb[8 * b2 + p]);
+      for (auto& v2 : phb) std::sort(v2.begin(), v2.end());
+      printf("   BatchNorm operand: %6.2f us/launch; median ticks: prologue %lld, first tile %lld, main loop %lld, epilogue %lld\n", msb / 50 * 1e3,
+             med(phb[0]), med(phb[1]), med(phb[2]), med(phb[3]));
+      (void)hipFree(gamma); (void)hipFree(beta); (void)hipFree(bsums);
+    }
     if (N % 160 == 0 || N % 96 == 0) {
       const int J = N % 160 == 0 ? 5 : 3;
       const size_t sm16 = nt16_smem_bytes(K, J);
