@@ -640,21 +640,22 @@ def refine_leg(args, lib, torch):
     with torch.cuda.stream(st):
         R.finetune_vae_fast(model, objs, triples, boxes, angles, attrs, names, iters=3, bank=bank)
         # the per-room set-up (encoder, target render, the loss tables built on the HOST) is timed apart from the iterations: rooms of
-        # `iters` and of 2 x `iters` iterations, three times each; an iteration costs the slope, the set-up the intercept.  (One timing
+        # `iters` and of 2 x `iters` iterations, five times each; an iteration costs the slope, the set-up the intercept.  (One timing
         # of set-up + iterations moved by +-8 % with the host's share.)
         t1s, t2s = [], []
-        for _ in range(3):
+        for _ in range(5):
             dt1, losses = timed(iters)
             dt2, _ = timed(2 * iters)
             t1s.append(dt1); t2s.append(dt2)
         slopes = sorted((b - a) / iters for a, b in zip(t1s, t2s))
-        per_iter = slopes[1]
-        setup = sorted(a - iters * per_iter for a in t1s)[1]
-        dt = sorted(t1s)[1]
+        per_iter = slopes[2]
+        setup = sorted(a - iters * per_iter for a in t1s)[2]
+        dt = sorted(t1s)[2]
+        slopes = [slopes[0], slopes[2], slopes[4]]
     return {"ms_per_iteration": round(per_iter * 1e3, 3), "ms_per_iteration_min_median_max": [round(x * 1e3, 3) for x in slopes],
             "ms_setup_per_room": round(setup * 1e3, 2),
             "ms_per_iteration_incl_setup": round(dt / iters * 1e3, 3), "iterations": iters, "finite": bool(torch.isfinite(losses).all()),
-            "includes": "ms_per_iteration: slope between rooms of 60 and 120 iterations (median of 3); the per-room set-up (encoder, target render, "
+            "includes": "ms_per_iteration: slope between rooms of 60 and 120 iterations (median of 5); the per-room set-up (encoder, target render, "
                         "loss tables built on the host) is ms_setup_per_room, ms_per_iteration_incl_setup amortises it over the iterations",
             "workload": "one room, 12 objects + shell (%d triangles x2 fill_back), 256x256, VAE at train.py defaults" %
                         int(R.RefineScene(names, bank, boxes[-1]).faces.shape[0])}
