@@ -133,7 +133,12 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0, int kc) {
 // NT kernel
 // ---------------------------------------------------------------------------------------------
 // // (An intra-block split-K variant, 8 waves per 64x64 tile, was measured and dropped: same time, see DESIGN.md.)
-template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
+// HELP: the workgroup was launched with 512 threads; wavefronts 4 .. 7 only build the coefficient tables and leave behind the first
+// barrier.  The loads of that set-up (gamma / beta and the fp64 column sums the previous kernel left behind with device-scope
+// atomics) are the slowest round trip in front of a block's first MFMA, and in the staging waves they queue behind the operand
+// loads and hold back - vmcnt retires in order - every later wait.  In wavefronts of their own they go out at once, next to the
+// operand loads of the others.
+template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI, bool HELP = false>
 __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
   constexpr int NT = 256;
   constexpr bool HAS_X2 = AMODE == 1;        // AMODE: 0 = per-column affine (+relu), 1 = two sources (BatchNorm backward), 2 = identity
@@ -157,6 +162,22 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   const int tiles_n = (a.N + BN - 1) / BN;
   const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
+  if (HELP && tid >= NT) {                     // the helper wavefronts: coefficient tables, first barrier, done
+    const int ht = tid - NT;
+    if (!(AMODE == 2)) {
+      sln_fill_coefs(a.A, coef, ht, NT);
+      for (int c = a.K + ht; c < kpad + 4; c += NT) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = ht; c < BN; c += NT) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
   const int kq = tid & 7, r0 = tid >> 3;
@@ -239,17 +260,19 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   gload(0, S0{});
   gload(min(1, last), S1{});
 
-  if (!IDENT) {
-    sln_fill_coefs(a.A, coef, tid, NT);
-    for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
-  }
-  if (EPI == EPI_MASK) {
-    for (int c = tid; c < BN; c += NT) {
-      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-      if (n0 + c < a.N) {
-        e = bn_fwd_coef4(a.obn, n0 + c);
+  if (!HELP) {
+    if (!IDENT) {
+      sln_fill_coefs(a.A, coef, tid, NT);
+      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = tid; c < BN; c += NT) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) {
+          e = bn_fwd_coef4(a.obn, n0 + c);
+        }
+        ecoef[c] = e;
       }
-      ecoef[c] = e;
     }
   }
 
@@ -564,7 +587,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 // that consume .x .. .w each see k = c, c + 4, c + 8, c + 12 - any fixed permutation of k is as good as another, A and B use the
 // same one).  Single-segment operands only.  Staging, masks (none: zero coefficient rows) and the statistics are those of
 // gemm_nt_body; sums are taken in a different order (per 16 x 16 block), results agree to fp32 rounding.
-template <int J, int AMODE, int EPI>
+template <int J, int AMODE, int EPI, bool HELP = false>      // HELP: 512 threads, wavefronts 4 .. 7 build the coefficient tables (see gemm_nt_body)
 __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bid, const int nwg, char* smem) {
   constexpr int NT = 256, BM = 64, BN = 32 * J, WN16 = 16 * J;
   constexpr bool HAS_X2 = AMODE == 1;
@@ -587,6 +610,22 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   const int tiles_n = (a.N + BN - 1) / BN;
   const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
+  if (HELP && tid >= NT) {
+    const int ht = tid - NT;
+    if (!IDENT) {
+      sln_fill_coefs(a.A, coef, ht, NT);
+      for (int c = a.K + ht; c < kpad + 4; c += NT) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = ht; c < BN; c += NT) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   const int kq = tid & 7, r0 = tid >> 3;
   const Seg& g = a.A.seg[0];
   const float* rowA1[PA]; const float* rowA2[PA]; const float* rowB[PB];
@@ -648,15 +687,17 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
 #pragma unroll
     for (int p = 0; p < PA; ++p) ldA(p, S1{}, c1s);
   }
-  if (!IDENT) {
-    sln_fill_coefs(a.A, coef, tid, NT);
-    for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
-  }
-  if (EPI == EPI_MASK) {
-    for (int c = tid; c < BN; c += NT) {
-      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-      if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
-      ecoef[c] = e;
+  if (!HELP) {
+    if (!IDENT) {
+      sln_fill_coefs(a.A, coef, tid, NT);
+      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = tid; c < BN; c += NT) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
     }
   }
   f32x4 acc[2][J];
@@ -854,7 +895,7 @@ inline int nt16_pick(const GemmNTArgs& a) {
 // k-tiles w, w + 4, ... through its OWN LDS tiles (no workgroup barrier in the loop; the LDS queue of a wave is in order), the
 // four partial accumulators meet in LDS once, and every wave finishes 8 of the 32 rows (bias / mask / statistics / store).
 // Single-segment operands only (the gathered concat input stays with gemm_nt_body).
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, bool HELP = false>             // HELP: 512 threads, wavefronts 4 .. 7 build the coefficient tables (see gemm_nt_body)
 __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const int bid, char* smem, const bool small_xcd = true) {
   constexpr bool HAS_X2 = AMODE == 1;
   constexpr bool IDENT = AMODE == 2;
@@ -871,6 +912,22 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   // every A row (profiles/r03: 34 MB per launch for 7 MB of operands)
   const int lb = small_xcd ? xcd_remap(bid, (int)gridDim.x) : bid;
   const int m0 = (lb / tiles_n) * TS, n0 = (lb % tiles_n) * TS;
+  if (HELP && tid >= 256) {
+    const int ht = tid - 256;
+    if (!IDENT) {
+      sln_fill_coefs(a.A, coef, ht, 256);
+      for (int c = a.K + ht; c < kpad; c += 256) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = ht; c < TS; c += 256) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
+    }
+    __syncthreads();
+    return;
+  }
   float* As = wl + wave * 2 * TS * LDT;
   float* Bs = As + TS * LDT;
 
@@ -917,15 +974,17 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   };
 
   if (wave < ntiles) gload(wave);                           // first tile of this wave, issued before the coefficient set-up
-  if (!IDENT) {
-    sln_fill_coefs(a.A, coef, tid, 256);
-    for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
-  }
-  if (EPI == EPI_MASK) {
-    for (int c = tid; c < TS; c += 256) {
-      float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-      if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
-      ecoef[c] = e;
+  if (!HELP) {
+    if (!IDENT) {
+      sln_fill_coefs(a.A, coef, tid, 256);
+      for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+    }
+    if (EPI == EPI_MASK) {
+      for (int c = tid; c < TS; c += 256) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
     }
   }
   __syncthreads();                                          // coefficient tables visible

@@ -18,22 +18,27 @@
 #include <vector>
 #include "gemm_bodies.h"
 namespace {
+// 64 x 64 tiles with a BatchNorm operand or a masked epilogue run with four helper wavefronts (512 threads, see gemm_nt_body)
+template <int BM, int BN, int AMODE, int EPI>
+constexpr bool nt_helpers() { return BM == 64 && BN == 64 && (AMODE != 2 || EPI == EPI_MASK); }
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNTArgs a) {
+__global__ __launch_bounds__((nt_helpers<BM, BN, AMODE, EPI>() ? 512 : 256)) void gemm_nt_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI>(a, blockIdx.x, gridDim.x, smem);
-}
-
-template <int J, int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt16_kernel(const GemmNTArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_body16<J, AMODE, EPI>(a, blockIdx.x, gridDim.x, smem);
+  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI, nt_helpers<BM, BN, AMODE, EPI>()>(a, blockIdx.x, gridDim.x, smem);
 }
 
 template <int AMODE, int EPI>
-__global__ __launch_bounds__(256) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
+constexpr bool nt_helpers2() { return AMODE != 2 || EPI == EPI_MASK; }      // there is a coefficient table to build
+template <int J, int AMODE, int EPI>
+__global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt16_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_small_body<AMODE, EPI>(a, blockIdx.x, smem, xcd != 0);
+  gemm_nt_body16<J, AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, gridDim.x, smem);
+}
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm_nt_small_body<AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, smem, xcd != 0);
 }
 
 }  // namespace
@@ -47,7 +52,7 @@ int launch_nt_small(const GemmNTArgs& a, hipStream_t st) {
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
   static const int xcd = std::getenv("SLN_NT_SMALL_NO_XCD") ? 0 : 1;      // lab switch: plain workgroup order
-  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(256), smem, st, a, xcd);
+  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(nt_helpers2<AMODE, EPI>() ? 512 : 256), smem, st, a, xcd);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -58,7 +63,7 @@ int launch_nt16(const GemmNTArgs& a, hipStream_t st) {
   const int grid = sln_cdiv(a.M, 64) * sln_cdiv(a.N, 32 * J);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
-  hipLaunchKernelGGL((gemm_nt16_kernel<J, AMODE, EPI>), dim3(grid), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((gemm_nt16_kernel<J, AMODE, EPI>), dim3(grid), dim3(nt_helpers2<AMODE, EPI>() ? 512 : 256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -70,12 +75,13 @@ int launch_nt(const GemmNTArgs& a, hipStream_t st) {
   const int grid = sln_cdiv(a.M, BM) * sln_cdiv(a.N, BN);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
+  constexpr int NTHR = nt_helpers<BM, BN, AMODE, EPI>() ? 512 : 256;
   if (a.A.nseg > 1 && nt_unaligned(a)) {
-    if constexpr (BM == 64 && BN == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, WM, WN, AMODE, EPI, 2>), dim3(grid), dim3(256), smem, st, a);
+    if constexpr (BM == 64 && BN == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, WM, WN, AMODE, EPI, 2>), dim3(grid), dim3(NTHR), smem, st, a);
     else return -2;   // SLN_E_UNSUPPORTED (sln_launch_gemm_nt forces tile 0 for such operands)
   }
-  else if (a.A.nseg > 1) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 1>), dim3(grid), dim3(256), smem, st, a);
-  else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 0>), dim3(grid), dim3(256), smem, st, a);
+  else if (a.A.nseg > 1) hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 1>), dim3(grid), dim3(NTHR), smem, st, a);
+  else hipLaunchKernelGGL((gemm_nt_kernel<BM, BN, WM, WN, AMODE, EPI, 0>), dim3(grid), dim3(NTHR), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
