@@ -11,9 +11,16 @@
 //   gemm_tn_multi : every wgrad of a backward pass in ONE launch (problem table + one item per workgroup in device memory,
 //                   XCD-grouped, ~768-row chunks; sln_tn_multi_plan builds the table on the host)
 //
+//   gemm_nt16 : the same product on 64 x 96 / 64 x 160 tiles of v_mfma_f32_16x16x4_f32 for the widths (N = 384, 640) that leave
+//               64 x 64 tiles with a ragged last round of workgroups (nt16_pick)
+//   gemm_nt_small : 32 x 32 tiles, K split over the four wavefronts (the object-side Linears: 64-128 tiles of 64 x 64 for 256 CUs)
+//
 // NT: k-contiguous LDS tiles ([rows][BK + 4]: one ds_read_b128 feeds four MFMAs); TN: row-major tiles as the rows arrive, the
 // waves split a tile's rows (gemm_bodies.h).  Global->LDS staging goes through registers (the BatchNorm / ReLU / gather
-// transform happens on the way), double-buffered so one barrier per K tile.
+// transform happens on the way), double-buffered so one barrier per K tile.  The K loops of the 64 x 64 NT tile, of the 16 x 16
+// body and of the wgrad body are written out instruction by instruction (one piece of staging work behind each MFMA): one
+// wavefront per SIMD hides nothing behind its own MFMAs (tools/lab/overlap.hip).  NT kernels with a
+// coefficient table run 512 threads: wavefronts 4-7 build the table and leave.
 #include <algorithm>
 #include <vector>
 #include "gemm_bodies.h"
