@@ -13,7 +13,11 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libsln_hip.so")
 OBJ = os.path.join(HERE, "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+# kernarg preload: the first 14 dwords of a kernel's leading scalar / pointer arguments arrive in SGPRs with the wavefront instead of
+# through s_load (~400 clocks of scalar-cache miss at every kernel start, tools/lab/kernarg_lat.hip): edge kernels -1.5 %, the step
+# -0.3 %.  (Struct arguments are passed by reference and are not preloaded; hipcc emits the fallback loads for older firmware itself.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value",
+         "-mllvm", "-amdgpu-kernarg-preload-count=16",
          "-I" + os.path.join(os.path.dirname(HERE), "include")] + os.environ.get("SLN_HIPCC_EXTRA", "").split()   # lab: -DSLN_NT_SCHED=0 ...
 # raster kernels: bit-exact agreement with the CPU restatement needs contraction off (see raster.hip)
 # placement: the torch expression it replaces rounds after every elementwise op

@@ -15,6 +15,9 @@ namespace {
 #ifndef SLN_TRACE
 #define SLN_TRACE(i)
 #endif
+#ifndef SLN_TRACEH          // the same for the first helper wavefront (tools/lab/gemm_lab.hip)
+#define SLN_TRACEH(i)
+#endif
 
 // 1: the 64 x 64 NT tile runs its K loop in a hand-ordered schedule (see gemm_nt_body); 0: hipcc's order (lab A/B)
 #ifndef SLN_NT_SCHED
@@ -129,6 +132,34 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0, int kc) {
   return r;
 }
 
+// What the helper wavefronts of an NT kernel do (threads ht = 0 .. nthreads - 1 behind the staging wavefronts): the operand's
+// coefficient table (its zero rows up to kend included) and, for the masked epilogue, the forward coefficients of the TW output
+// columns from n0.  The epilogue table's loads go out first and its arithmetic comes last: its round trip runs under the operand
+// table's instead of behind it.
+template <int NSEG_MAX, bool IDENT, int EPI, int TW>
+__device__ __forceinline__ void nt_helper_tables(const GemmNTArgs& a, float4* coef, float4* ecoef, const int ht, const int nthreads, const int kend, const int n0) {
+  static_assert(TW <= 256, "one epilogue column per helper thread");
+  const bool etrain = EPI == EPI_MASK && a.obn.mode == SLN_BN_TRAIN;
+  BnFwdRaw er;
+  if (etrain) er = bn_fwd_train_load(a.obn, min(n0 + (ht < TW ? ht : 0), a.N - 1));
+  if (!IDENT) {
+    sln_fill_coefs<NSEG_MAX>(a.A, coef, ht, nthreads);
+    for (int c = a.K + ht; c < kend; c += nthreads) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (EPI == EPI_MASK) {
+    if (etrain) {
+      const float4 e = bn_fwd_train_finish(a.obn, er);
+      if (ht < TW) ecoef[ht] = n0 + ht < a.N ? e : make_float4(1.f, 0.f, 0.f, 1.f);
+    } else {
+      for (int c = ht; c < TW; c += nthreads) {
+        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
+        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
+        ecoef[c] = e;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // NT kernel
 // ---------------------------------------------------------------------------------------------
@@ -164,18 +195,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   if (HELP && tid >= NT) {                     // the helper wavefronts: coefficient tables, first barrier, done
     const int ht = tid - NT;
-    if (!(AMODE == 2)) {
-      sln_fill_coefs(a.A, coef, ht, NT);
-      for (int c = a.K + ht; c < kpad + 4; c += NT) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (EPI == EPI_MASK) {
-      for (int c = ht; c < BN; c += NT) {
-        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
-        ecoef[c] = e;
-      }
-    }
+    SLN_TRACEH(8);
+    nt_helper_tables<(MULTI ? 3 : 1), AMODE == 2, EPI, BN>(a, coef, ecoef, ht, NT, kpad + 4, n0);
+    SLN_TRACEH(9);
     __syncthreads();
+    SLN_TRACEH(10);
     return;
   }
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
@@ -196,6 +220,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     const int w0 = a.A.seg[0].which;
     rid[p] = MULTI ? row : (w0 == 0 ? row : (w0 == 1 ? ra_idx[p] : rb_idx[p]));
   }
+  SLN_TRACE(5);
   float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
   const int ntiles = kpad / BK;
   const int last = ntiles - 1;
@@ -227,31 +252,36 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       gb[S][p] = ld4(Wp + (size_t)n * ldw + cw);
     }
   };
-  auto lstore = [&](int kt_raw, int buf, auto stage) {
+  // parts: 1 = the operand rows (A: needs the coefficient table), 2 = the weight rows (B), 3 = both
+  auto lstore = [&](int kt_raw, int buf, auto stage, const int parts = 3) __attribute__((always_inline)) {
     constexpr int S = decltype(stage)::value;
     const int kt = min(kt_raw, last);
     const int k0 = kt * BK, col = k0 + 4 * kq;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0, col);
-    const bool cv = col < sg.end && kt_raw <= last;          // surplus tiles (loop padded to a multiple of 3) are stored as zeros
-    const bool x2v = HAS_X2 && sg.x2 != nullptr;
-    float* as = As + buf * BM * LDT + 4 * kq;
-    float* bs = Bs + buf * BN * LDT + 4 * kq;
-    const float4* cf = coef + min(col, kpad - 4);
+    if (parts & 1) {
+      const SegSel sg = pick_seg<MULTI>(a.A, k0, col);
+      const bool cv = col < sg.end && kt_raw <= last;          // surplus tiles (loop padded to a multiple of 3) are stored as zeros
+      const bool x2v = HAS_X2 && sg.x2 != nullptr;
+      float* as = As + buf * BM * LDT + 4 * kq;
+      const float4* cf = coef + min(col, kpad - 4);
 #pragma unroll
-    for (int p = 0; p < PA; ++p) {
-      const int rl = r0 + RP * p;
-      const bool v = cv && (m0 + rl) < Mr;
-      float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(as + rl * LDT) = t;
+      for (int p = 0; p < PA; ++p) {
+        const int rl = r0 + RP * p;
+        const bool v = cv && (m0 + rl) < Mr;
+        float4 t = IDENT ? ga1[S][p] : xform(ga1[S][p], x2v ? ga2[S][p] : z4, cf);
+        t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+        *reinterpret_cast<float4*>(as + rl * LDT) = t;
+      }
     }
-    const bool kv = col < Kr && kt_raw <= last;
+    if (parts & 2) {
+      float* bs = Bs + buf * BN * LDT + 4 * kq;
+      const bool kv = col < Kr && kt_raw <= last;
 #pragma unroll
-    for (int p = 0; p < PB; ++p) {
-      const bool v = kv && (n0 + r0 + RP * p) < Nr;
-      float4 t = gb[S][p];
-      t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
-      *reinterpret_cast<float4*>(bs + (r0 + RP * p) * LDT) = t;
+      for (int p = 0; p < PB; ++p) {
+        const bool v = kv && (n0 + r0 + RP * p) < Nr;
+        float4 t = gb[S][p];
+        t.x = v ? t.x : 0.f; t.y = v ? t.y : 0.f; t.z = v ? t.z : 0.f; t.w = v ? t.w : 0.f;
+        *reinterpret_cast<float4*>(bs + (r0 + RP * p) * LDT) = t;
+      }
     }
   };
 
@@ -259,10 +289,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
   gload(0, S0{});
   gload(min(1, last), S1{});
+  SLN_TRACE(6);
 
   if (!HELP) {
     if (!IDENT) {
-      sln_fill_coefs(a.A, coef, tid, NT);
+      sln_fill_coefs<(MULTI ? 3 : 1)>(a.A, coef, tid, NT);
       for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
     }
     if (EPI == EPI_MASK) {
@@ -302,6 +333,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     }
   }
 
+  SLN_TRACE(7);
   __syncthreads();            // coef tables visible
   SLN_TRACE(1);
   lstore(0, 0, S0{});
@@ -611,18 +643,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   const int lb = xcd_remap(bid, nwg);
   const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   if (HELP && tid >= NT) {
-    const int ht = tid - NT;
-    if (!IDENT) {
-      sln_fill_coefs(a.A, coef, ht, NT);
-      for (int c = a.K + ht; c < kpad + 4; c += NT) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (EPI == EPI_MASK) {
-      for (int c = ht; c < BN; c += NT) {
-        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
-        ecoef[c] = e;
-      }
-    }
+    nt_helper_tables<1, IDENT, EPI, BN>(a, coef, ecoef, tid - NT, NT, kpad + 4, n0);
     __syncthreads();
     return;
   }
@@ -689,7 +710,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   }
   if (!HELP) {
     if (!IDENT) {
-      sln_fill_coefs(a.A, coef, tid, NT);
+      sln_fill_coefs<1>(a.A, coef, tid, NT);
       for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
     }
     if (EPI == EPI_MASK) {
@@ -910,21 +931,10 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   const int tiles_n = (a.N + TS - 1) / TS;
   // workgroups that share A rows (same m tile, all n tiles) share an XCD and its L2: in plain order the eight XCDs each fetched
   // every A row (profiles/r03: 34 MB per launch for 7 MB of operands)
-  const int lb = small_xcd ? xcd_remap(bid, (int)gridDim.x) : bid;
+  const int lb = small_xcd ? xcd_remap(bid, ((a.M + TS - 1) / TS) * tiles_n) : bid;      // = gridDim.x (launch_nt_small), without the dispatch packet read
   const int m0 = (lb / tiles_n) * TS, n0 = (lb % tiles_n) * TS;
   if (HELP && tid >= 256) {
-    const int ht = tid - 256;
-    if (!IDENT) {
-      sln_fill_coefs(a.A, coef, ht, 256);
-      for (int c = a.K + ht; c < kpad; c += 256) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (EPI == EPI_MASK) {
-      for (int c = ht; c < TS; c += 256) {
-        float4 e = make_float4(1.f, 0.f, 0.f, 1.f);
-        if (n0 + c < a.N) e = bn_fwd_coef4(a.obn, n0 + c);
-        ecoef[c] = e;
-      }
-    }
+    nt_helper_tables<1, IDENT, EPI, TS>(a, coef, ecoef, tid - 256, 256, kpad, n0);
     __syncthreads();
     return;
   }
@@ -976,7 +986,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   if (wave < ntiles) gload(wave);                           // first tile of this wave, issued before the coefficient set-up
   if (!HELP) {
     if (!IDENT) {
-      sln_fill_coefs(a.A, coef, tid, 256);
+      sln_fill_coefs<1>(a.A, coef, tid, 256);
       for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
     }
     if (EPI == EPI_MASK) {

@@ -31,7 +31,9 @@ constexpr bool nt_helpers() { return BM == 64 && BN == 64 && (AMODE != 2 || EPI 
 template <int BM, int BN, int WM, int WN, int AMODE, int EPI, int MULTI>
 __global__ __launch_bounds__((nt_helpers<BM, BN, AMODE, EPI>() ? 512 : 256)) void gemm_nt_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI, nt_helpers<BM, BN, AMODE, EPI>()>(a, blockIdx.x, gridDim.x, smem);
+  // the grid is exactly the tile count (launch_nt): computed from M and N, which the body needs anyway, instead of read from the
+  // dispatch packet's block count - one kernel-argument cache line less in front of the first address
+  gemm_nt_body<BM, BN, WM, WN, AMODE, EPI, MULTI, nt_helpers<BM, BN, AMODE, EPI>()>(a, blockIdx.x, ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN), smem);
 }
 
 template <int AMODE, int EPI>
@@ -39,7 +41,7 @@ constexpr bool nt_helpers2() { return AMODE != 2 || EPI == EPI_MASK; }      // t
 template <int J, int AMODE, int EPI>
 __global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt16_kernel(const GemmNTArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_body16<J, AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, gridDim.x, smem);
+  gemm_nt_body16<J, AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, ((a.M + 63) / 64) * ((a.N + 32 * J - 1) / (32 * J)), smem);
 }
 
 template <int AMODE, int EPI>

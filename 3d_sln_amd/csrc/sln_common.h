@@ -64,6 +64,14 @@ __device__ __forceinline__ void bn_mean_istd(const BnView& b, int c, float& mean
     istd = 1.f;
   }
 }
+// bn_fwd_coef4 for a train-mode view in two steps (loads, arithmetic): the masked epilogue's table is requested in FRONT of the
+// operand's coefficient table and finished behind it - one memory round trip less in the helper wavefronts of a masked dgrad
+struct BnFwdRaw { float gamma, beta; double s1, s2; };
+__device__ __forceinline__ BnFwdRaw bn_fwd_train_load(const BnView& b, int c) {
+  BnFwdRaw r;
+  r.gamma = sln_ldf(b.gamma + c); r.beta = sln_ldf(b.beta + c); r.s1 = sln_ldd(b.sums + c); r.s2 = sln_ldd(b.sums + b.cstride + c);
+  return r;
+}
 // forward coefficients (scale, shift, mean, istd): h = max(scale*x + shift, 0)
 __device__ __forceinline__ float4 bn_fwd_coef4(const BnView& b, int c) {
   float mean, istd;
@@ -82,6 +90,12 @@ __device__ __forceinline__ float4 bn_fwd_coef4(const BnView& b, int c) {
     return make_float4(scale, beta - mean * scale, mean, istd);
   }
   return make_float4(1.f, 0.f, 0.f, 1.f);
+}
+__device__ __forceinline__ float4 bn_fwd_train_finish(const BnView& b, const BnFwdRaw& r) {
+  float mean, istd;
+  bn_train_mean_istd(b, r.s1, r.s2, mean, istd);
+  const float scale = r.gamma * istd;
+  return make_float4(scale, r.beta - mean * scale, mean, istd);
 }
 // two columns of the same BatchNorm at once (the subject / object halves of GraphTripleConv's second Linear): one round trip
 __device__ __forceinline__ void bn_fwd_coef4x2(const BnView& b, int ca, int cb, float4& va, float4& vb) {
@@ -176,7 +190,55 @@ __device__ __forceinline__ float4 sln_coef_for(const Seg& s, int c) {
 }
 
 // Fill an LDS table coef[0..cols) for the whole operand (all threads of the block participate).
+// Column by column (the generic loop at the end) every further column of a thread is another dependent memory round trip in front
+// of the block's first barrier: the helper wavefronts of an NT kernel had their table written 2 200 clocks after the block's start
+// with one column per thread and +950 per additional one (tools/lab/gemm_lab.hip, helper-wave stamps).  The three 128-column
+// segments of GraphTripleConv's concat were three such trips: that case loads what a thread's first column needs in EVERY segment
+// in one basic block (unconditional loads at clamped columns, only the LDS store is predicated), then does the arithmetic (the
+// expressions of bn_fwd_coef4, same order, same bits): -0.8 us per launch.  (The same for several columns of ONE segment - K = 640
+// is three columns per helper thread - shortened the lab kernel's table by 1 000 clocks and left the product kernel 0.3 us slower:
+// not kept.)
+__device__ __forceinline__ bool sln_seg_fwd_train(const Seg& s) { return (s.coef == SLN_COEF_FWD || s.coef == SLN_COEF_FWD_NORELU) && s.bn.mode == SLN_BN_TRAIN; }
+__device__ __forceinline__ float4 sln_fwd_train_coef(const Seg& g, float gamma, float beta, double s1, double s2) {
+  float mean, istd;
+  bn_train_mean_istd(g.bn, s1, s2, mean, istd);
+  const float scale = gamma * istd;
+  return make_float4(scale, 0.f, beta - mean * scale, g.coef == SLN_COEF_FWD ? 0.f : -3.0e38f);
+}
+// NSEG_MAX: what the caller knows at compile time - 1: a single segment (one plain loop: no segment bookkeeping, no reads of the
+// other segments' fields), 3: GraphTripleConv's concat is possible (the three-segment path), 0: nothing (the generic loop only).
+// A cold prologue pays for every kernel-argument field it touches (hipcc fetches them stage by stage, ~400 clocks per scalar-cache
+// miss, tools/lab/kernarg_lines.hip) and for the code it jumps over: with the fast paths in front of the generic loop of EVERY
+// caller the K <= 256 kernels that never take them were 0.5-1.2 us slower per launch; with the single-segment callers on their own
+// three-line loop they are 0.1-1.4 us faster than before.
+template <int NSEG_MAX = 0>
 __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, int tid, int nthreads) {
+  if (NSEG_MAX == 1) {
+    const Seg& g = op.seg[0];
+    for (int c = tid; c < g.len; c += nthreads) coef[c] = sln_coef_for(g, c);
+    return;
+  }
+  if (NSEG_MAX == 3 && op.nseg == 3 && sln_seg_fwd_train(op.seg[0]) && sln_seg_fwd_train(op.seg[1]) && sln_seg_fwd_train(op.seg[2]) &&
+      op.seg[0].len > 0 && op.seg[1].len > 0 && op.seg[2].len > 0) {
+    // GraphTripleConv's concat [obj[s] | pred | obj[o]]: the first column a thread owns in each of the three segments together
+    float ga[3], be[3]; double s1[3], s2[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const BnView& b = op.seg[s].bn;
+      const int c = min(tid, op.seg[s].len - 1);
+      ga[s] = sln_ldf(b.gamma + c); be[s] = sln_ldf(b.beta + c); s1[s] = sln_ldd(b.sums + c); s2[s] = sln_ldd(b.sums + b.cstride + c);
+    }
+    int base = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int len = op.seg[s].len;
+      const float4 v = sln_fwd_train_coef(op.seg[s], ga[s], be[s], s1[s], s2[s]);
+      if (tid < len) coef[base + tid] = v;
+      for (int c = tid + nthreads; c < len; c += nthreads) coef[base + c] = sln_coef_for(op.seg[s], c);
+      base += len;
+    }
+    return;
+  }
   int base = 0;
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
