@@ -190,11 +190,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   SLN_TRACE(0);
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int lb = xcd_remap(bid, nwg);
-  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
+  // (the helpers' branch comes first and computes the tile origin only for the masked epilogue's table: behind the common tile
+  //  arithmetic their kernel-argument loads were a second scalar-cache round trip, ~400 clocks on the block's critical path)
   if (HELP && tid >= NT) {                     // the helper wavefronts: coefficient tables, first barrier, done
     const int ht = tid - NT;
+    int n0 = 0;
+    if (EPI == EPI_MASK) { const int tiles_n = (a.N + BN - 1) / BN; n0 = (xcd_remap(bid, nwg) % tiles_n) * BN; }
     SLN_TRACEH(8);
     nt_helper_tables<(MULTI ? 3 : 1), AMODE == 2, EPI, BN>(a, coef, ecoef, ht, NT, kpad + 4, n0);
     SLN_TRACEH(9);
@@ -202,6 +203,9 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     SLN_TRACEH(10);
     return;
   }
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int lb = xcd_remap(bid, nwg);
+  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   const int wm0 = (wave / WN) * (BM / WM), wn0 = (wave % WN) * (BN / WN);
 
   const int kq = tid & 7, r0 = tid >> 3;
@@ -333,10 +337,13 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     }
   }
 
+  // The staging wavefronts reach this barrier before the coefficient tables are written (tools/lab/gemm_lab.hip: 2 300-2 800 clocks
+  // against 3 200-3 900 for the helpers): the weight rows of the first tile - they need no table - go to LDS while they would wait.
+  lstore(0, 0, S0{}, 2);
   SLN_TRACE(7);
   __syncthreads();            // coef tables visible
   SLN_TRACE(1);
-  lstore(0, 0, S0{});
+  lstore(0, 0, S0{}, 1);
   gload(min(2, last), S0{});
   __syncthreads();
   SLN_TRACE(2);
@@ -639,14 +646,16 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   SLN_TRACE(0);
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_n = (a.N + BN - 1) / BN;
-  const int lb = xcd_remap(bid, nwg);
-  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
-  if (HELP && tid >= NT) {
+  if (HELP && tid >= NT) {                     // first, see gemm_nt_body
+    int n0 = 0;
+    if (EPI == EPI_MASK) { const int tiles_n = (a.N + BN - 1) / BN; n0 = (xcd_remap(bid, nwg) % tiles_n) * BN; }
     nt_helper_tables<1, IDENT, EPI, BN>(a, coef, ecoef, tid - NT, NT, kpad + 4, n0);
     __syncthreads();
     return;
   }
+  const int tiles_n = (a.N + BN - 1) / BN;
+  const int lb = xcd_remap(bid, nwg);
+  const int m0 = (lb / tiles_n) * BM, n0 = (lb % tiles_n) * BN;
   const int kq = tid & 7, r0 = tid >> 3;
   const Seg& g = a.A.seg[0];
   const float* rowA1[PA]; const float* rowA2[PA]; const float* rowB[PB];
@@ -729,13 +738,13 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   float bias_pre[J];                    // requested in front of the K loop (see gemm_nt_body)
 #pragma unroll
   for (int j = 0; j < J; ++j) bias_pre[j] = a.bias ? a.bias[min(n0 + WN16 * wc + 16 * j + (lane & 15), a.N - 1)] : 0.f;
+#pragma unroll
+  for (int p = 0; p < PB; ++p) stB(0, p, S0{});       // tile 0's weight rows: in front of the barrier (see gemm_nt_body)
   __syncthreads();
   SLN_TRACE(1);
   {   // tile 0 into LDS buffer 0, tile 2 into stage 0
     const bool cv0 = 4 * kq < Kr;
     const float4* cf0 = coef + 4 * kq;
-#pragma unroll
-    for (int p = 0; p < PB; ++p) stB(0, p, S0{});
 #pragma unroll
     for (int p = 0; p < PA; ++p) wrA(0, p, xfA(p, S0{}, cf0, cv0));
     const int l2 = min(2, last) * BK + 4 * kq;
@@ -928,16 +937,21 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   double* sred = reinterpret_cast<double*>(ecoef + TS);     // [4][TS][2] column statistics of the four waves
   float* wl = reinterpret_cast<float*>(sred + 4 * TS * 2);  // per wave: A [TS][LDT] | B [TS][LDT]; later its 16 x 64 partial accumulator
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (HELP && tid >= 256) {                    // first, see gemm_nt_body
+    int n0 = 0;
+    if (EPI == EPI_MASK) {
+      const int tiles_n = (a.N + TS - 1) / TS;
+      n0 = ((small_xcd ? xcd_remap(bid, ((a.M + TS - 1) / TS) * tiles_n) : bid) % tiles_n) * TS;
+    }
+    nt_helper_tables<1, IDENT, EPI, TS>(a, coef, ecoef, tid - 256, 256, kpad, n0);
+    __syncthreads();
+    return;
+  }
   const int tiles_n = (a.N + TS - 1) / TS;
   // workgroups that share A rows (same m tile, all n tiles) share an XCD and its L2: in plain order the eight XCDs each fetched
   // every A row (profiles/r03: 34 MB per launch for 7 MB of operands)
   const int lb = small_xcd ? xcd_remap(bid, ((a.M + TS - 1) / TS) * tiles_n) : bid;      // = gridDim.x (launch_nt_small), without the dispatch packet read
   const int m0 = (lb / tiles_n) * TS, n0 = (lb % tiles_n) * TS;
-  if (HELP && tid >= 256) {
-    nt_helper_tables<1, IDENT, EPI, TS>(a, coef, ecoef, tid - 256, 256, kpad, n0);
-    __syncthreads();
-    return;
-  }
   float* As = wl + wave * 2 * TS * LDT;
   float* Bs = As + TS * LDT;
 

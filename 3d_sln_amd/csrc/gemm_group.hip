@@ -19,18 +19,21 @@ struct GroupDims { int nt_blocks[2]; int tn_gx[2], tn_blocks[2]; };
 // the four problem descriptions are SEPARATE kernel parameters: as members of one struct parameter hipcc copied them to
 // scratch memory (2.6 KB per lane) and the two-source variants ran 4x slower
 template <int AMODE, int EPI, bool MULTI, bool XG, bool HAS_TN>
-__global__ __launch_bounds__(256) void gemm_group_kernel(const GemmNTArgs a0, const GemmNTArgs a1, const GemmTNArgs t0, const GemmTNArgs t1,
-                                                         const GroupDims d) {
+// The block counts that decide which problem a workgroup belongs to are LEADING scalar arguments: they arrive in SGPRs with the
+// wavefront (kernarg preload, build.py) - as the last member of the 2.8 KB argument block they were a scalar-cache miss of their own
+// in front of the first field of the chosen problem.
+__global__ __launch_bounds__(256) void gemm_group_kernel(const int nt_blocks0, const int nt_blocks1, const int tn_gx0, const int tn_gx1, const int tn_blocks0,
+                                                         const GemmNTArgs a0, const GemmNTArgs a1, const GemmTNArgs t0, const GemmTNArgs t1) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   int b = blockIdx.x;
-  if (b < d.nt_blocks[0]) { gemm_nt_body<64, 64, 2, 2, AMODE, EPI, MULTI>(a0, b, d.nt_blocks[0], smem); return; }
-  b -= d.nt_blocks[0];
-  if (b < d.nt_blocks[1]) { gemm_nt_body<64, 64, 2, 2, AMODE, EPI, MULTI>(a1, b, d.nt_blocks[1], smem); return; }
-  b -= d.nt_blocks[1];
+  if (b < nt_blocks0) { gemm_nt_body<64, 64, 2, 2, AMODE, EPI, MULTI>(a0, b, nt_blocks0, smem); return; }
+  b -= nt_blocks0;
+  if (b < nt_blocks1) { gemm_nt_body<64, 64, 2, 2, AMODE, EPI, MULTI>(a1, b, nt_blocks1, smem); return; }
+  b -= nt_blocks1;
   if (HAS_TN) {
-    if (b < d.tn_blocks[0]) { gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(t0, b % d.tn_gx[0], b / d.tn_gx[0], smem); return; }
-    b -= d.tn_blocks[0];
-    gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(t1, b % d.tn_gx[1], b / d.tn_gx[1], smem);
+    if (b < tn_blocks0) { gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(t0, b % tn_gx0, b / tn_gx0, smem); return; }
+    b -= tn_blocks0;
+    gemm_tn_body<64, 64, 2, 2, AMODE == 1, XG>(t1, b % tn_gx1, b / tn_gx1, smem);
   }
 }
 
@@ -39,7 +42,8 @@ int launch_group(const GroupArgs& g, size_t smem, int blocks, hipStream_t st) {
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
   GroupDims d;
   for (int i = 0; i < 2; ++i) { d.nt_blocks[i] = g.nt_blocks[i]; d.tn_gx[i] = g.tn_gx[i] > 0 ? g.tn_gx[i] : 1; d.tn_blocks[i] = g.tn_blocks[i]; }
-  hipLaunchKernelGGL((gemm_group_kernel<AMODE, EPI, MULTI, XG, HAS_TN>), dim3(blocks), dim3(256), smem, st, g.nt[0], g.nt[1], g.tn[0], g.tn[1], d);
+  hipLaunchKernelGGL((gemm_group_kernel<AMODE, EPI, MULTI, XG, HAS_TN>), dim3(blocks), dim3(256), smem, st, d.nt_blocks[0], d.nt_blocks[1], d.tn_gx[0], d.tn_gx[1],
+                     d.tn_blocks[0], g.nt[0], g.nt[1], g.tn[0], g.tn[1]);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -166,7 +166,7 @@ __device__ __forceinline__ void commit_col_stats4(const float4& s1, const float4
 // entry list of the block's YT rows, cached in LDS (coalesced) so that the per-entry chain is one level of row loads;
 // rows longer than ECACHE (only the room node of a big graph) read the tail from global memory
 constexpr int ECACHE = 64;
-constexpr int EB = 8;                      // row loads in flight per thread
+constexpr int EB = 16;                     // row loads in flight per thread
 
 // The prologue of an edge kernel is a chain of memory round trips in front of the first row: the CSR bounds of the row are loaded
 // FIRST (row_bounds), the coefficient tables' loads go out next to them, the entry list follows (cache_entries): two round trips
@@ -256,16 +256,28 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
    for (int it = 0; it < NIT; ++it) {
     const int t0 = ((blockIdx.y * NIT + it) * YT + threadIdx.y) * RPT;
     if (t0 >= T) break;
+    // Every load of the pass is unconditional and its address a select (profiles / ISA of round 3: with `part == 1 ? .. : ..`
+    // BRANCHES around the node, gradient and weight loads hipcc waited for each row's loads before it issued the next row's -
+    // eight dependent memory round trips per pass of four rows, most of the kernel's 12.6 us).  A lane of the predicate part reads
+    // the object index and a pooled row it does not use; its values are dropped by the selects below.
     int node[RPT]; float4 d[RPT], x[RPT]; float w[RPT];
+    const int* np = part == 0 ? g.s : g.o;
 #pragma unroll
-    for (int r = 0; r < RPT; ++r) { const int t = min(t0 + r, T - 1); node[r] = part == 0 ? g.s[t] : (part == 2 ? g.o[t] : 0); }
+    for (int r = 0; r < RPT; ++r) { const int t = min(t0 + r, T - 1); node[r] = np[t]; x[r] = ld4g(A2 + (size_t)t * ld + c); }
+    const bool pred = part == 1;
+    const float* dpb = dP ? dP + dpcol0 + (c - H) : A2 + c;          // dP == nullptr: any valid address, the value is replaced by zero
+    const int dpld = dP ? lddp : ld;
+    const float* dmb = dM + (part == 0 ? c : c - H - D);
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
       const int t = min(t0 + r, T - 1);
-      w[r] = 1.f;
-      if (part == 1) d[r] = dP ? ld4g(dP + (size_t)t * lddp + dpcol0 + (c - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
-      else { d[r] = ld4g(dM + (size_t)node[r] * H + (part == 0 ? c : c - H - D)); w[r] = g.invdeg[node[r]]; }
-      x[r] = ld4g(A2 + (size_t)t * ld + c);
+      const float* src = pred ? dpb + (size_t)t * dpld : dmb + (size_t)node[r] * H;
+      d[r] = ld4g(src);
+      w[r] = g.invdeg[node[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < RPT; ++r) {
+      if (pred) { w[r] = 1.f; if (!dP) d[r] = make_float4(0.f, 0.f, 0.f, 0.f); }
     }
 #pragma unroll
     for (int r = 0; r < RPT; ++r) {
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     for (long r = i0 >> 3; r < (((long)a.O + 31) & ~31L); r += stride >> 3) {
       const bool rv = r < a.O;
       const float* xr = a.logits + (size_t)(rv ? r : 0) * a.n_angle;
+      const int tgt = (int)a.angles[rv ? r : 0];              // requested with the row, not behind the two reductions
       float m = -INFINITY;
       for (int k = sub; k < a.n_angle; k += 8) m = fmaxf(m, xr[k]);
       m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
@@ -624,7 +637,6 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
       s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
       const float ls = logf(s) + m;
       if (rv) {
-        const int tgt = (int)a.angles[r];
         for (int k = sub; k < a.n_angle; k += 8) {
           const float lp = xr[k] - ls;
           a.angles_pred[(size_t)r * a.n_angle + k] = lp;
@@ -643,10 +655,20 @@ __global__ __launch_bounds__(256) void loss_kernel(LossArgs a) {
     }
   }
   if (!a.use_ae) {
+    // four elements of a thread per trip, their loads first (clamped, the surplus ones add zero): element by element every trip of
+    // this loop was a memory round trip of its own - eight in a row at 64 graphs, the longest phase of the kernel.  Same order of
+    // additions as before.
     float s = 0.f;
-    for (long i = i0; i < (long)a.O * a.n_z; i += stride) {
-      const float m = a.mu[i], lv = a.logvar[i];
-      s += 1.f + lv - m * m - expf(lv);
+    const long nkl = (long)a.O * a.n_z;
+    for (long i = i0; i < nkl; i += 4 * stride) {
+      float m[4], lv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const long j = min(i + u * stride, nkl - 1); m[u] = a.mu[j]; lv[u] = a.logvar[j]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float term = 1.f + lv[u] - m[u] * m[u] - expf(lv[u]);
+        s += (i + u * stride < nkl) ? term : 0.f;
+      }
     }
     kl = s;
   }
