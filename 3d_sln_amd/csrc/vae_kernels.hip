@@ -768,21 +768,51 @@ __global__ __launch_bounds__(256) void transpose_table_kernel(const TransposeEnt
 // the iteration is skipped (no optimizer step, the step count stays).  Round 3: the scalar bookkeeping (step + 1, the two bias
 // corrections, the skip decision) is taken by every block from the OLD scalars instead of by a one-thread launch in front; the last
 // block to finish commits the new step (every other block has read the old one by then: it arrived before).
-__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long n, AdamScalars* __restrict__ sc, const float* __restrict__ total_loss) {
+// Round 3, last session (tools/lab/adam_lab.hip, 3.7 M parameters, operands cold as in the step): the update itself streams at
+// 4.7 TB/s (22 us) - the kernel took 39 us because its 2 048 workgroups each added 1 to the SAME arrival counter, and same-address
+// atomics are served one at a time (~6 ns each): 27 us without the ticket.  Now 256 workgroups of 1 024 threads (256 arrivals),
+// 16-byte accesses, nontemporal for the gradient and the two moments (touched once per step; 18 us in the lab with everything
+// nontemporal - but the parameters are the next step's weights and stay cached); the per-thread pow() calls, suspected first, cost
+// nothing measurable.
+typedef float adam_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void adam_update(float& p, const float g, float& m, float& v, const float b1, const float b2, const float step_size, const float rs2,
+                                            const float eps) {
+  const float mi = b1 * m + (1.f - b1) * g;
+  const float vi = b2 * v + (1.f - b2) * g * g;
+  m = mi; v = vi;
+  p -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+}
+__global__ __launch_bounds__(1024) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, int vec, AdamScalars* __restrict__ sc,
+                                                    const float* __restrict__ total_loss) {
   const bool skip = total_loss != nullptr && !isfinite(total_loss[0]);
   const int64_t step = sc->step + 1;
   const float b1 = sc->beta1, b2 = sc->beta2, eps = sc->eps;
   const float bc1 = (float)(1.0 - pow((double)b1, (double)step)), bc2 = (float)(1.0 - pow((double)b2, (double)step));
   const float step_size = sc->lr / bc1, rs2 = 1.0f / sqrtf(bc2);
-  if (!skip)
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-      const float gi = g[i];
-      const float mi = b1 * m[i] + (1.f - b1) * gi;
-      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
-      m[i] = mi; v[i] = vi;
-      p[i] -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+  if (!skip) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    const long n4 = vec ? n / 4 : 0;                      // vec: all four arrays 16-byte aligned (checked by the launcher)
+    adam_v4f* p4 = reinterpret_cast<adam_v4f*>(p); const adam_v4f* g4 = reinterpret_cast<const adam_v4f*>(g);
+    adam_v4f* m4 = reinterpret_cast<adam_v4f*>(m); adam_v4f* v4 = reinterpret_cast<adam_v4f*>(v);
+    for (long i = tid; i < n4; i += stride) {
+      adam_v4f pi = p4[i], mi = __builtin_nontemporal_load(m4 + i), vi = __builtin_nontemporal_load(v4 + i);
+      const adam_v4f gi = __builtin_nontemporal_load(g4 + i);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float pk = pi[k], mk = mi[k], vk = vi[k];
+        adam_update(pk, gi[k], mk, vk, b1, b2, step_size, rs2, eps);
+        pi[k] = pk; mi[k] = mk; vi[k] = vk;
+      }
+      __builtin_nontemporal_store(mi, m4 + i); __builtin_nontemporal_store(vi, v4 + i);
+      p4[i] = pi;                                         // cached: the next step's first GEMMs read the weights (nontemporal: +15 us there)
     }
+    for (long i = 4 * n4 + tid; i < n; i += stride) {      // the tail (or everything, for unaligned arrays)
+      float pk = p[i], mk = m[i], vk = v[i];
+      adam_update(pk, g[i], mk, vk, b1, b2, step_size, rs2, eps);
+      m[i] = mk; v[i] = vk; p[i] = pk;
+    }
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned int done = atomicAdd(&sc->adam_done, 1u);
@@ -1248,10 +1278,11 @@ int sln_launch_transpose_table(const TransposeEntry* table, int n, int max_tiles
 int sln_launch_adam(float* params, const float* grads, float* m, float* v, long n, AdamScalars* scalars, const float* total_loss,
                     hipStream_t st) {
   SlnProfScope prof(SLN_FAM_OTHER, 28.0 * n, st);
-  long blocks = (n + 255) / 256;      // (a float4 form with 4 096 blocks measured 51 us against 41)
-  if (blocks > 2048) blocks = 2048;
+  long blocks = (n + 4095) / 4096;    // few workgroups: every one of them is an arrival at ONE counter (see adam_kernel)
+  if (blocks > 256) blocks = 256;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, st, params, grads, m, v, n, scalars, total_loss);
+  const int vec = ((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(1024), 0, st, params, grads, m, v, n, vec, scalars, total_loss);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -45,21 +45,64 @@ __global__ void k_copy(float* __restrict__ p, const float* __restrict__ g, float
     m4[i] = mi + gi; v4[i] = vi + gi; p4[i] = pi + gi * ss;
   }
 }
+// the product's kernel (vae_kernels.hip::adam_kernel), argument for argument
+struct AdamScalars { int64_t step; float lr, beta1, beta2, eps; float kl_weight; float bc1, bc2; int skip, pad_;
+                     unsigned long long rng_seed, rng_offset; unsigned int rng_done, adam_done; };
+template <int VARIANT>        // 0: as shipped, 1: without the pow() calls, 2: without the arrival ticket, 3: neither
+__global__ void k_product(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                          float* __restrict__ v, long n, AdamScalars* __restrict__ sc, const float* __restrict__ total_loss) {
+  const bool skip = total_loss != nullptr && !isfinite(total_loss[0]);
+  const int64_t step = sc->step + 1;
+  const float b1 = sc->beta1, b2 = sc->beta2, eps = sc->eps;
+  float bc1, bc2;
+  if (VARIANT & 1) { bc1 = 1.0f - b1 * (float)step; bc2 = 1.0f - b2 * (float)step; }
+  else { bc1 = (float)(1.0 - pow((double)b1, (double)step)); bc2 = (float)(1.0 - pow((double)b2, (double)step)); }
+  const float step_size = sc->lr / bc1, rs2 = 1.0f / sqrtf(bc2);
+  if (!skip)
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+      const float gi = g[i];
+      const float mi = b1 * m[i] + (1.f - b1) * gi;
+      const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+      m[i] = mi; v[i] = vi;
+      p[i] -= step_size * mi / (sqrtf(vi) * rs2 + eps);
+    }
+  if (VARIANT & 2) return;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int done = atomicAdd(&sc->adam_done, 1u);
+    if (done == gridDim.x - 1) {
+      sc->adam_done = 0; sc->skip = skip ? 1 : 0;
+      if (!skip) { sc->step = step; sc->bc1 = bc1; sc->bc2 = bc2; }
+    }
+  }
+}
+
 int main() {
   const long n = 3700000 / 4 * 4;
-  float *p, *g, *m, *v;
-  hipMalloc(&p, 4 * n); hipMalloc(&g, 4 * n); hipMalloc(&m, 4 * n); hipMalloc(&v, 4 * n);
-  hipMemset(p, 0, 4 * n); hipMemset(g, 0, 4 * n); hipMemset(m, 0, 4 * n); hipMemset(v, 0, 4 * n);
+  // COLD operands: twelve sets (710 MB, more than the 256 MB infinity cache) taken in turn - in the training step two milliseconds
+  // of other traffic pass between two updates
+  constexpr int SETS = 12;
+  float* base; hipMalloc(&base, 4 * n * 4 * SETS); hipMemset(base, 0, 4 * n * 4 * SETS);
+  int turn = 0;
+  float *p = base, *g = base + n, *m = base + 2 * n, *v = base + 3 * n;
+  auto next = [&] { turn = (turn + 1) % SETS; p = base + (long)turn * 4 * n; g = p + n; m = p + 2 * n; v = p + 3 * n; };
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto time = [&](const char* name, auto launch) {
-    for (int i = 0; i < 3; ++i) launch();
+    for (int i = 0; i < 3; ++i) { next(); launch(); }
     hipEventRecord(e0);
-    for (int i = 0; i < 20; ++i) launch();
+    for (int i = 0; i < 20; ++i) { next(); launch(); }
     hipEventRecord(e1); hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-44s %7.2f us  %6.2f TB/s\n", name, ms / 20 * 1e3, 28.0 * n / (ms / 20 * 1e-3) / 1e12);
   };
-  for (int blocks : {1024, 2048, 4096, 8192}) {
+  AdamScalars hs{}; hs.step = 10; hs.lr = 1e-4f; hs.beta1 = 0.9f; hs.beta2 = 0.999f; hs.eps = 1e-8f;
+  AdamScalars* sc; hipMalloc(&sc, sizeof(hs)); hipMemcpy(sc, &hs, sizeof(hs), hipMemcpyHostToDevice);
+  float* tl; hipMalloc(&tl, 4); hipMemset(tl, 0, 4);
+  time("product kernel, 2048 x 256", [&] { hipLaunchKernelGGL(k_product<0>, dim3(2048), dim3(256), 0, 0, p, g, m, v, n, sc, tl); });
+  time("  without pow()", [&] { hipLaunchKernelGGL(k_product<1>, dim3(2048), dim3(256), 0, 0, p, g, m, v, n, sc, tl); });
+  time("  without the ticket", [&] { hipLaunchKernelGGL(k_product<2>, dim3(2048), dim3(256), 0, 0, p, g, m, v, n, sc, tl); });
+  time("  without both", [&] { hipLaunchKernelGGL(k_product<3>, dim3(2048), dim3(256), 0, 0, p, g, m, v, n, sc, tl); });
+  for (int blocks : {2048, 8192}) {
     char nm[96];
     snprintf(nm, sizeof nm, "scalar, %d x 256", blocks); time(nm, [&] { hipLaunchKernelGGL(k_scalar, dim3(blocks), dim3(256), 0, 0, p, g, m, v, n, 1e-3f); });
     snprintf(nm, sizeof nm, "float4, %d x 256", blocks); time(nm, [&] { hipLaunchKernelGGL((k_vec4<false>), dim3(blocks), dim3(256), 0, 0, p, g, m, v, n / 4, 1e-3f); });
