@@ -364,13 +364,27 @@ __global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __rest
   float s1 = 0.f, s2 = 0.f;
   const int r1 = min(rows, (int)(blockIdx.y + 1) * RB);
   if (cv) {
-    for (int r = blockIdx.y * RB + threadIdx.y; r < r1; r += RL) {
-      float d = d1[(size_t)r * ld1 + c];
-      if (d2) d += d2[(size_t)r * ld2 + c];
-      const float x = xprev[(size_t)r * ldx + c];
-      d = fmaf(sc, x, sh) > 0.f ? d : 0.f;
-      out[(size_t)r * ldo + c] = d;
-      s1 += d; s2 = fmaf(d, (x - mean) * istd, s2);
+    // the eight rows of a thread: all their loads first (clamped rows, a uniform select instead of the `if (d2)` branch around the
+    // second load) - row by row this loop was eight dependent memory round trips, half of the kernel's 9 us.  Same order of sums.
+    constexpr int NI = RB / RL;
+    const float* d2p = d2 ? d2 : d1;
+    const int ld2p = d2 ? ld2 : ld1;
+    float dv[NI], ev[NI], xv[NI];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int r = min((int)blockIdx.y * RB + (int)threadIdx.y + u * RL, rows - 1);
+      dv[u] = d1[(size_t)r * ld1 + c]; ev[u] = d2p[(size_t)r * ld2p + c]; xv[u] = xprev[(size_t)r * ldx + c];
+    }
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+      const int r = blockIdx.y * RB + threadIdx.y + u * RL;
+      if (r < r1) {
+        float d = d2 ? dv[u] + ev[u] : dv[u];
+        const float x = xv[u];
+        d = fmaf(sc, x, sh) > 0.f ? d : 0.f;
+        out[(size_t)r * ldo + c] = d;
+        s1 += d; s2 = fmaf(d, (x - mean) * istd, s2);
+      }
     }
   }
   commit_col_stats(s1, s2, cv, gsums, cstride, c);
