@@ -997,7 +997,15 @@ int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int d
   if (T <= 0) return 0;
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * T * (2 * H) + (dP ? 4.0 * T * D : 0.0) + 2.0 * 4.0 * T * (2 * H + D) + 8.0 * T, st);
   if (H % 4 == 0 && D % 4 == 0 && ld % 4 == 0 && (!dP || (lddp % 4 == 0 && dpcol0 % 4 == 0 && al16(dP))) && al16(dM) && al16(A2) && al16(g2)) {
-    constexpr int RPT = 4, NIT = 2;         // 32 rows per block: as many column-statistics atomics as the scalar kernel
+    constexpr int RPT = 4;
+    static const int nit = std::getenv("SLN_SCATTER_NIT") ? std::atoi(std::getenv("SLN_SCATTER_NIT")) : 2;   // lab: passes of 16 rows per workgroup
+    if (nit == 4) {
+      hipLaunchKernelGGL((scatter_avg_bwd_v4_kernel<64, 4, RPT, 4>), dim3(sln_cdiv(2 * H + D, 256), sln_cdiv(T, 4 * RPT * 4)), dim3(64, 4), 0, st, dM, dP,
+                         lddp, dpcol0, A2, ld, H, D, bn2, g, T, g2, gsums, cstride);
+      SLN_CHECK_LAUNCH();
+      return 0;
+    }
+    constexpr int NIT = 2;         // 32 rows per block: as many column-statistics atomics as the scalar kernel
     hipLaunchKernelGGL((scatter_avg_bwd_v4_kernel<64, 4, RPT, NIT>), dim3(sln_cdiv(2 * H + D, 256), sln_cdiv(T, 4 * RPT * NIT)), dim3(64, 4), 0, st, dM, dP,
                        lddp, dpcol0, A2, ld, H, D, bn2, g, T, g2, gsums, cstride);
     SLN_CHECK_LAUNCH();
@@ -1013,7 +1021,15 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * D + (masked ? 2.0 : 1.0) * 4.0 * O * D + 16.0 * g.T, st);
   if (D % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && (!add1 || (ldadd1 % 4 == 0 && al16(add1))) && (!masked || (ldx % 4 == 0 && al16(xprev))) &&
       al16(dG) && al16(out)) {
-    if (D > 64) hipLaunchKernelGGL((gather_bwd_v4_kernel<32, 8>), dim3(sln_cdiv(D, 128), sln_cdiv(O, 8)), dim3(32, 8), 0, st, dG, ldg, D, g, O, g.T, add1,
+    // 16 rows per workgroup: every workgroup ends in one fp64 atomic per statistics address, same-address atomics are served one
+    // at a time, and all workgroups finish together - 256 arrivals (8 rows) cost the launch 0.7 us more than 128; 32 rows are
+    // slower again (64 workgroups of 1 024 threads).  SLN_GATHER_YT = 8 / 16 / 32 for the lab.
+    static const int yt = std::getenv("SLN_GATHER_YT") ? std::atoi(std::getenv("SLN_GATHER_YT")) : 16;
+    if (D > 64 && yt == 16) hipLaunchKernelGGL((gather_bwd_v4_kernel<32, 16>), dim3(sln_cdiv(D, 128), sln_cdiv(O, 16)), dim3(32, 16), 0, st, dG, ldg, D, g, O, g.T, add1,
+                                               ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
+    else if (D > 64 && yt == 32) hipLaunchKernelGGL((gather_bwd_v4_kernel<32, 32>), dim3(sln_cdiv(D, 128), sln_cdiv(O, 32)), dim3(32, 32), 0, st, dG, ldg, D, g, O, g.T, add1,
+                                               ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
+    else if (D > 64) hipLaunchKernelGGL((gather_bwd_v4_kernel<32, 8>), dim3(sln_cdiv(D, 128), sln_cdiv(O, 8)), dim3(32, 8), 0, st, dG, ldg, D, g, O, g.T, add1,
                                    ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
     else hipLaunchKernelGGL((gather_bwd_v4_kernel<16, 16>), dim3(sln_cdiv(D, 64), sln_cdiv(O, 16)), dim3(16, 16), 0, st, dG, ldg, D, g, O, g.T, add1,
                             ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);

@@ -137,6 +137,19 @@ int main() {
       printf("   kernarg %s: %6.2f us/launch; median ticks: indices %lld, whole prologue %lld, block %lld\n", variant ? "leading scalars" : "struct         ", best / 50 * 1e3,
              q[0][grid / 2], q[1][grid / 2], q[2][grid / 2]);
     }
+    {   // the same launch without the column statistics (EPI_PLAIN): what do the fp64 atomics of the epilogue cost?
+      CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&lab_nt<64, 64, 2, EPI_PLAIN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_PLAIN>), dim3(grid), dim3(256), smem, 0, a);
+      CK(hipEventRecord(e0));
+      for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_PLAIN>), dim3(grid), dim3(256), smem, 0, a);
+      CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+      float m3; CK(hipEventElapsedTime(&m3, e0, e1));
+      CK(hipMemcpy(t.data(), trace, sizeof(long long) * 16 * grid, hipMemcpyDeviceToHost));
+      std::vector<long long> q;
+      for (int b2 = 0; b2 < grid; ++b2) q.push_back(t[16 * b2 + 4] - t[16 * b2 + 3]);
+      std::sort(q.begin(), q.end());
+      printf("   without column statistics: %6.2f us/launch, epilogue %lld ticks\n", m3 / 50 * 1e3, q[grid / 2]);
+    }
     for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((lab_nt<64, 64, 2, EPI_STATS>), dim3(grid), dim3(256), smem, 0, a);
     CK(hipDeviceSynchronize());
     CK(hipMemcpy(t.data(), trace, sizeof(long long) * 16 * grid, hipMemcpyDeviceToHost));
