@@ -148,7 +148,11 @@ struct SlnVae {
     GemmTNArgs probs[SLN_TN_MULTI_MAX]; TnMultiMeta meta; int n = 0, blocks = 0; bool x2 = false, xg = false; double flops = 0.0;
     bool dirty = true; GemmTNArgs* dev_probs = nullptr; TnMultiMeta* dev_meta = nullptr;
   };
-  enum { TN_SLOTS = 32 };                        // launches per iteration: slots [0, 16) decoder pass, [16, 32) encoder pass
+  // table slots of the per-pass wgrad launches: [0, tn_slots / 2) decoder pass, the rest encoder pass.  Sized from the layer count
+  // at creation (per-layer flushing - SLN_TN_PER_LAYER, deterministic mode with shared 'recurrent' weights - takes up to two per
+  // layer; a launch that finds none runs its problems one by one)
+  int tn_slots = 32;
+  std::vector<GemmTNArgs> tn_kind_scratch;
   bool defer = true, capturing = false, tn_upload_pending = false;
   int det_seen = 0;                              // g_sln_deterministic the captured iterations were recorded with
   bool tn_per_layer = false;                     // flush after every GraphTripleConv instead of once per pass
@@ -156,7 +160,7 @@ struct SlnVae {
   int tn_slot_next[2] = {0, 0};
   std::vector<GemmTNArgs> deferred;
   TnGroup* tn_groups_store = nullptr;            // [2 sets][TN_SLOTS][2], heap (a TnGroup is 50 KB)
-  TnGroup& tn_group(int set, int slot, int k) { return tn_groups_store[((size_t)set * TN_SLOTS + slot) * 2 + k]; }
+  TnGroup& tn_group(int set, int slot, int k) { return tn_groups_store[((size_t)set * tn_slots + slot) * 2 + k]; }
   int upload_group(TnGroup& g) {
     hipError_t e = hipMemcpy(g.dev_probs, g.probs, sizeof(GemmTNArgs) * (size_t)g.n, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(g.dev_meta, &g.meta, sizeof(TnMultiMeta), hipMemcpyHostToDevice);
@@ -201,7 +205,7 @@ struct SlnVae {
     return r;
   }
   int upload_pending_tables() {                   // after a capture: everything the captured launches will read
-    for (int w = 0; w < TN_SLOTS; ++w)
+    for (int w = 0; w < tn_slots; ++w)
       for (int k = 0; k < 2; ++k) {
         TnGroup& g = tn_group(0, w, k);
         if (g.n > 0 && g.dirty) { int r = upload_group(g); if (r) return r; }
@@ -231,23 +235,44 @@ struct SlnVae {
       lst = side; tn_side_busy = true;
     }
     static thread_local TnGroup tmp;
-    // two kinds of problems (X rows gathered: every net1.0; plain rows: the rest), each in launches of at most SLN_TN_MULTI_MAX
-    // problems (a pass of the default model has 10 + 26; deeper stacks take more than one launch per kind)
+    // two kinds of problems (X rows gathered: every net1.0; plain rows: the rest).  A launch group is closed by problem count
+    // (SLN_TN_MULTI_MAX) AND by planned tile count: all tiles of one (problem, row chunk) sit on one XCD, so the item table
+    // (SLN_TN_MULTI_ITEMS) holds a group only while 8 x the longest XCD list fits - longer row chunks cannot shrink a problem's
+    // (Nout / 64) x (Kin / 64) tiles.  A group the planner still refuses is halved; a single problem it refuses (hidden widths
+    // >= 1024: more than ITEMS / 8 tiles) or one that finds no free table slot runs as a plain per-problem launch.
+    std::vector<GemmTNArgs>& kind = tn_kind_scratch;
     for (int k = 0; k < 2; ++k) {
+      kind.clear();
+      for (const GemmTNArgs& t : deferred) {
+        bool gathers = false;
+        for (int s2 = 0; s2 < t.X.nseg; ++s2) gathers |= t.X.seg[s2].which != 0;
+        if ((int)gathers == k) kind.push_back(t);
+      }
       size_t next = 0;
-      while (next < deferred.size()) {
-        tmp.n = 0;
-        for (; next < deferred.size() && tmp.n < SLN_TN_MULTI_MAX; ++next) {
-          const GemmTNArgs& t = deferred[next];
-          bool gathers = false;
-          for (int s2 = 0; s2 < t.X.nseg; ++s2) gathers |= t.X.seg[s2].which != 0;
-          if ((int)gathers == k) tmp.probs[tmp.n++] = t;
+      while (next < kind.size()) {
+        int want = 0; long tiles = 0;
+        for (size_t i = next; i < kind.size() && want < SLN_TN_MULTI_MAX; ++i) {
+          const long tl = (long)sln_cdiv(kind[i].Nout, 64) * sln_cdiv(kind[i].Kin, 64);
+          if (want > 0 && tiles + tl > SLN_TN_MULTI_ITEMS / 2) break;
+          tiles += tl; ++want;
         }
-        if (tmp.n == 0) continue;
-        if (tn_slot_next[which] >= TN_SLOTS / 2) { deferred.clear(); return SLN_E_UNSUPPORTED; }
-        const int slot = which * (TN_SLOTS / 2) + tn_slot_next[which]++;
-        int r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
-        if (r) { deferred.clear(); return r; }
+        int r = -1;
+        const bool have_slot = tn_slot_next[which] < tn_slots / 2;
+        for (; have_slot && want >= 1; want /= 2) {
+          tmp.n = want;
+          for (int i = 0; i < want; ++i) tmp.probs[i] = kind[next + i];
+          r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
+          if (r == 0) break;
+        }
+        if (r != 0) {                 // one problem, launched on its own (2-D grid: no table)
+          GemmTNArgs one = kind[next++];
+          if (g_sln_deterministic) one.rows_per_block = sln_cdiv(one.R, 32) * 32;         // one add per dW element, as in the planned launches
+          r = sln_launch_gemm_tn(one, -1, lst);
+          if (r) { deferred.clear(); return r; }
+          continue;
+        }
+        next += (size_t)tmp.n;
+        const int slot = which * (tn_slots / 2) + tn_slot_next[which]++;
         TnGroup& g = tn_group(set, slot, k);
         if (g.n != tmp.n || std::memcmp(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n) != 0 ||
             std::memcmp(&g.meta, &tmp.meta, sizeof(TnMultiMeta)) != 0) {
@@ -529,7 +554,7 @@ size_t SlnVae::carve(void* base, int mo, int mt) {
     ly.g4 = b.take<float>(Om * D); ly.g3 = b.take<float>(Om * H); ly.g2 = b.take<float>(Tm * (2 * H + D)); ly.g1 = b.take<float>(Tm * H);
   }
   for (int set = 0; set < 2; ++set)
-    for (int w = 0; w < TN_SLOTS; ++w)
+    for (int w = 0; w < tn_slots; ++w)
       for (int k = 0; k < 2; ++k) {
         // a per-layer slot holds 4 problems, a per-pass slot all of a pass
         GemmTNArgs* dp = b.take<GemmTNArgs>(SLN_TN_MULTI_MAX);
@@ -988,7 +1013,8 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
     { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
-    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
+    h->tn_slots = 2 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
+    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * (size_t)h->tn_slots * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
     { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }
@@ -1381,7 +1407,8 @@ int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, 
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
     { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
-    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * SlnVae::TN_SLOTS * 2];
+    h->tn_slots = 2 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
+    h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * (size_t)h->tn_slots * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
     { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }

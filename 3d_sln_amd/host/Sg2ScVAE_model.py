@@ -520,6 +520,10 @@ class Sg2ScVAEModel(nn.Module):
 
     def adam_step(self, lr=1e-4):
         """torch.optim.Adam(lr).step() over the flat parameter buffer (fused kernel)."""
+        if self._eng is None:
+            # a rank whose shard was empty on its very first step (short last batch, batch_size < world) updates with the reduced
+            # gradients like every other rank: the optimizer only needs the flat buffers, not a bound batch
+            self._ensure_engine(0, 0)
         _lib.check(_lib.lib().sln_vae_adam_step(self._eng, float(lr), _lib.current_stream_ptr()), "sln_vae_adam_step")
         self._adam_steps += 1
 

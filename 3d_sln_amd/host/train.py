@@ -131,20 +131,23 @@ class DataParallelStep:
         if not self.dp:
             return m.train_step(*args, with_adam=True, **kw)
         if self.weighted:
+            # _w = [rows | rows x the four loss values]: one small all-reduce carries the weight total AND the row-weighted global
+            # loss means (what the reduced gradients belong to; a rank's own shard means would be logged and checkpointed otherwise)
             if self._w is None:
-                self._w = torch.zeros(1, dtype=g.dtype, device=g.device)
+                self._w = torch.zeros(5, dtype=g.dtype, device=g.device)
             if rows:
                 losses = m.train_step(*args, with_adam=False, **kw)
                 g.mul_(float(rows))
+                self._w[1:] = losses.detach().to(g.dtype) * float(rows)
             else:
-                losses = torch.zeros(4, dtype=g.dtype, device=g.device)
+                self._w[1:] = 0
                 g.zero_()
-            self._w.fill_(float(rows))
+            self._w[:1] = float(rows)
             self._reduce(g, False)
             self._reduce(self._w, False)
-            g.div_(self._w)                                     # on the device: no host read-back of the total
+            g.div_(self._w[:1])                                 # on the device: no host read-back of the total
             m.adam_step(lr=lr)
-            return losses
+            return self._w[1:] / self._w[:1]
         if self.overlap:
             losses = m.train_step_begin(*args, **kw)
             w_dec = self._reduce(g[self.split:], True)          # waits for the first half, runs beside the second

@@ -268,3 +268,115 @@ def test_ragged_last_batch_empty_shard_and_row_weighted_average(tmp_path):
     g2 = np.load(tmp_path / "g2_0.npy")
     assert (g2 == np.load(tmp_path / "g2_1.npy")).all()
     assert np.abs(g2 - ref.flat_grads.numpy()).max() <= 1e-4 * np.abs(g2).max() + 1e-7
+
+
+# ---------------------------------------------------------------------------------------------- world 8 (BASELINE config 5's shape)
+def _worker8(rank, world, port, out_dir, two_halves):
+    """Config 5 in miniature: 8 ranks, equal shards of whole graphs (24 graphs -> 3 per rank), two iterations."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    model = (CpuStandIn if two_halves else CpuStandInPlain)(cfg, seed=5 + rank)      # different init: the broadcast must fix it
+    os.environ["SLN_DP_OVERLAP"] = "1" if two_halves else "0"
+    order = []
+    if two_halves:                      # the decoder half must be reduced BEFORE the encoder half exists (train_step_finish)
+        fin = model.train_step_finish
+        model.train_step_finish = lambda **k: (order.append("finish"), fin(**k))[1]
+        red = T.DataParallelStep._reduce
+
+        def spy(self, buf, async_op):
+            order.append("reduce%d" % buf.numel())
+            return red(self, buf, async_op)
+        T.DataParallelStep._reduce = spy
+    args = T.build_parser().parse_args(["--batch_size", "24", "--num_iterations", "2", "--print_every", "1000"])
+    full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
+    T.train(args, model, lambda t, lo, hi: _slice_graphs(full, lo, hi), rank, world, log=lambda *_: None)
+    if two_halves:
+        n, s = model.grad_bucket.numel(), model.decoder_grad_offset
+        assert order == ["reduce%d" % (n - s), "finish", "reduce%d" % s] * 2, order
+    assert model.t == 2
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), model.flat_params.numpy())
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), model.flat_grads.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("two_halves", [True, False])
+def test_eight_rank_step_matches_gradient_average(tmp_path, two_halves):
+    port = _free_port()
+    mp.spawn(_worker8, args=(8, port, str(tmp_path), two_halves), nprocs=8, join=True)
+    ps = [np.load(tmp_path / ("p%d.npy" % r)) for r in range(8)]
+    gs = [np.load(tmp_path / ("g%d.npy" % r)) for r in range(8)]
+    assert all((p == ps[0]).all() for p in ps) and all((g == gs[0]).all() for g in gs), "replicas diverged"
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    ref = CpuStandIn(cfg, seed=5)
+    full = vae_ref.synth_batch(24, 5, 8, seed=11, cfg=cfg)
+    for _ in range(2):
+        acc = torch.zeros_like(ref.flat_grads)
+        for rank in range(8):
+            lo, hi = T.shard_range(24, rank, 8)
+            assert hi - lo == 3
+            ref.train_step(**_slice_graphs(full, lo, hi), with_adam=False)
+            acc += ref.flat_grads
+        ref.flat_grads.copy_(acc / 8)
+        ref.adam_step(1e-4)
+    gr = ref.flat_grads.numpy()
+    assert np.abs(gs[0] - gr).max() <= 2e-4 * np.abs(gr).max() + 1e-7       # second step: parameters already moved by Adam's +-lr noise
+    d = np.abs(ps[0] - ref.flat_params.numpy())
+    assert d.max() <= 4.1 * 1e-4 and np.mean(d > 1e-6) < 0.12
+
+
+def _worker8_ragged(rank, world, port, out_dir):
+    """Real rooms on 8 ranks: iteration 1 has 11 graphs (shard_range remainders: 2,2,2,1,1,1,1,1), iteration 2 the short last
+    batch of an epoch with 3 graphs (ranks 3..7 WITHOUT a graph), iteration 3 a single graph (7 empty ranks)."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    T = pkg("host.train")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization="none")
+    model = CpuStandIn(cfg, seed=5)
+    args = T.build_parser().parse_args(["--batch_size", "11", "--num_iterations", "3", "--print_every", "1"])
+    full = vae_ref.synth_batch(15, 5, 8, seed=11, cfg=cfg)
+    base, sizes = {1: 0, 2: 11, 3: 14}, {1: 11, 2: 3, 3: 1}
+    grads = {}
+
+    def batch_fn(t, lo, hi):
+        if t > 1:
+            grads[t - 1] = model.flat_grads.clone()
+        lo2, hi2 = T.shard_range(sizes[t], rank, world)
+        return None if hi2 == lo2 else _slice_graphs(full, base[t] + lo2, base[t] + hi2)
+    batch_fn.ragged = True
+    ck = T.train(args, model, batch_fn, rank, world, log=lambda *_: None)
+    grads[3] = model.flat_grads.clone()
+    assert model.t == 3
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), model.flat_params.numpy())
+    for t in (1, 2, 3):
+        np.save(os.path.join(out_dir, "g%d_%d.npy" % (t, rank)), grads[t].numpy())
+    if rank == 0:
+        np.save(os.path.join(out_dir, "losses.npy"), np.array([ck['losses'][k] for k in ('bbox_pred', 'angle_pred', 'KLD_Gauss', 'total_loss')]))
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_ragged_shards_with_several_empty_ranks(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker8_ragged, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    ps = [np.load(tmp_path / ("p%d.npy" % r)) for r in range(8)]
+    assert all((p == ps[0]).all() for p in ps) and np.isfinite(ps[0]).all(), "replicas diverged"
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2, mlp_normalization="none")
+    full = vae_ref.synth_batch(15, 5, 8, seed=11, cfg=cfg)
+    ref = CpuStandIn(cfg, seed=5)
+    logged = np.load(tmp_path / "losses.npy")                  # [4 names, 3 iterations], rank 0's log
+    for t, (lo, hi) in enumerate(((0, 11), (11, 14), (14, 15)), start=1):
+        # without BatchNorm the graphs are independent: the gradient / the losses of the whole batch ARE the row-weighted means
+        whole_losses = ref.train_step(**_slice_graphs(full, lo, hi), with_adam=False).numpy()
+        whole = ref.flat_grads.numpy().copy()
+        g = [np.load(tmp_path / ("g%d_%d.npy" % (t, r))) for r in range(8)]
+        assert all((x == g[0]).all() for x in g)
+        assert np.abs(g[0] - whole).max() <= 1e-4 * np.abs(whole).max() + 1e-7, t
+        # the logged losses are the global (row-weighted) means, not rank 0's shard means
+        assert np.abs(logged[:, t - 1] - whole_losses).max() <= 1e-4 * np.abs(whole_losses).max() + 1e-6, (t, logged[:, t - 1], whole_losses)
+        ref.adam_step(1e-4)

@@ -504,6 +504,77 @@ def test_tight_gradients_when_no_threshold_is_near(norm, training, n_graphs):
     assert not bad, "\n".join(bad[:40])
 
 
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_wide_model_whose_wgrads_do_not_fit_one_launch_table(deterministic):
+    """embedding_dim 256 (hidden 1024, the reference sets hidden = 4 x gconv_dim, Sg2ScVAE_model.py:19-20): net1's second
+    Linear alone has 40 x 16 = 640 output tiles - more than one XCD list of the per-pass wgrad launch holds - and a pass has
+    ~2 900.  The pass is cut into several launches by planned tile count and the 640-tile problem runs on its own; every gradient
+    within 1e-4 of the fp64 oracle (threshold-free state), in the default and in the deterministic mode."""
+    cfg = vae_ref.VaeConfig(embedding_dim=256, gconv_num_layers=2, mlp_normalization="none")
+    sd = _threshold_free_state(cfg, seed=4)
+    batch = list(vae_ref.synth_batch(3, 8, 12, seed=2, cfg=cfg)[:5])
+    batch[2] = batch[2] - 100.0
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    b64 = (batch[0], batch[1], batch[2].double(), batch[3], batch[4])
+    keys = vae_ref.trainable_keys(cfg)
+    m64 = {k: torch.zeros_like(sd64[k]) for k in keys}; v64 = {k: torch.zeros_like(sd64[k]) for k in keys}
+    total64, parts64, g64 = vae_ref.train_step(sd64, cfg, b64, eps.double(), 0.1, m64, v64, step=1, training=True)
+    L = _lib().lib()
+    try:
+        L.sln_set_deterministic(int(deterministic))
+        model = _model(cfg, sd).train()
+        dev = _dev(*batch, eps)
+        runs = []
+        for _ in range(2 if deterministic else 1):
+            losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=False, with_adam=False).cpu().numpy()
+            runs.append(model.flat_grads.clone())
+    finally:
+        L.sln_set_deterministic(0)
+    if deterministic:
+        assert torch.equal(runs[0], runs[1]), "deterministic mode: repeated steps must agree bit for bit"
+    assert_close(losses[3], float(total64), "total")
+    named = dict(model.named_parameters())
+    bad = []
+    for k in keys:
+        ref = g64[k].numpy() if k in g64 else np.zeros(tuple(sd[k].shape))
+        try:
+            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=1e-7 * max(float(np.abs(ref).max()), 1e-30) + 1e-9)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, "\n".join(bad[:40])
+
+
+def test_deep_recurrent_stack_in_deterministic_mode_has_enough_launch_slots():
+    """'recurrent' weights in deterministic mode flush the wgrads once per layer (two launches each): 12 layers need 24 table
+    slots per pass (the table is sized from the layer count; the reference places no limit on gconv_num_layers)."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=12, gconv_mode="recurrent", mlp_normalization="none")
+    sd = _threshold_free_state(cfg, seed=4)
+    batch = list(vae_ref.synth_batch(4, 8, 12, seed=2, cfg=cfg)[:5])
+    batch[2] = batch[2] - 100.0
+    O = batch[0].shape[0]
+    eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
+    sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    b64 = (batch[0], batch[1], batch[2].double(), batch[3], batch[4])
+    keys = vae_ref.trainable_keys(cfg)
+    m64 = {k: torch.zeros_like(sd64[k]) for k in keys}; v64 = {k: torch.zeros_like(sd64[k]) for k in keys}
+    total64, parts64, g64 = vae_ref.train_step(sd64, cfg, b64, eps.double(), 0.1, m64, v64, step=1, training=True)
+    L = _lib().lib()
+    try:
+        L.sln_set_deterministic(1)
+        model = _model(cfg, sd).train()
+        dev = _dev(*batch, eps)
+        losses = model.train_step(*dev[:5], kl_weight=0.1, lr=1e-4, eps=dev[5], use_graph=False, with_adam=False).cpu().numpy()
+    finally:
+        L.sln_set_deterministic(0)
+    assert_close(losses[3], float(total64), "total")
+    named = dict(model.named_parameters())
+    for k in keys:
+        ref = g64[k].numpy() if k in g64 else np.zeros(tuple(sd[k].shape))
+        assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=1e-7 * max(float(np.abs(ref).max()), 1e-30) + 1e-9)
+
+
 def test_out_of_range_ids_raise_like_the_reference():
     """The reference's embedding / index ops raise IndexError on bad ids; the HIP path must not read out of bounds."""
     cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=1)
