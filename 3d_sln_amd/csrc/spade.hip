@@ -48,6 +48,7 @@ struct ConvArgs {
   // BIAS_ACT, optional reductions of what the epilogue writes (fp64 atomics, zeroed by the caller)
   double* ln_acc;        // [B][LN_ACC_STRIDE]: sum y, sum y^2 of sample b (LayerNorm2D statistics of the NEXT SPADE layer)
   double* gap_acc;       // [B, rows]: sum over pixels (SEBlock2's global average pool)
+  int blocked;           // accumulate in blocks of input channels (see BLK below)
 };
 constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples (one 128-byte line each)
 
@@ -189,8 +190,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   }
 }
 
+// Blocked accumulation: tot += acc; acc = 0 - or, behind the last chunk, acc = the total (the epilogue reads `acc`).
+template <int TM, int TN, int TMT, int TNT>
+__device__ __forceinline__ void conv_flush(f32x16 (&acc)[TM][TN], f32x16 (&tot)[TMT][TNT], bool last) {
+  static_assert(TM == TMT && TN == TNT, "blocked accumulation needs a full second register set");
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float t = tot[i][j][r] + acc[i][j][r];
+        tot[i][j][r] = t;
+        acc[i][j][r] = last ? t : 0.f;
+      }
+}
+
 // BMC: channels (rows) per block (64 or 128); KS: 1 or 3.  4 waves: WM x WN over (rows, pixels).
-template <int BMC, int KS, int EPI>
+//
+// BLK > 0: BLOCKED ACCUMULATION (round 4).  An MFMA accumulator is, bit for bit, a serial fmaf chain over K = 9 Cin
+// (tools/lab/mfma_round.hip): its rounding error grows like K (rms 4e-7 of the output scale at K = 9 216, 1.2e-7 at 1 152)
+// while torch's CPU convolution - what the reference runs - sums in short blocks and stays at 4-6e-8 whatever K is.  With BLK
+// the accumulators hold BLK chunks only (BLK x CK or GK input channels x 9 taps = 144 products), are then added to a second
+// fp32 register set and restart from zero: error ~ sqrt(K/2 (n_b + K/n_b)) instead of K/sqrt(2) - 7.9e-8 at K = 9 216.  The
+// second set costs 64 registers with 64 accumulators per lane (the 8 x 16-pixel / 64-row variants), which is why the 16 x 16
+// x 128-row workgroups (128 accumulators) have no such form; it is used where it matters: the main 3x3 convolutions with
+// Cin >= 512 (tools/spade_error_budget.py section 4: 15 % of the MACs).
+template <int BMC, int KS, int EPI, int BLK = 0>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int TAPS = KS * KS;
   constexpr int WM = BMC / 64;                 // waves along rows (each wave: 64 rows = 2 tiles)
@@ -271,13 +297,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
   const int wr = (wave / WN) * 64;                 // wave's first row inside the block
   const int wp0 = (wave % WN) * (128 / WN);        // wave's first pixel inside the patch
   const int li = lane & 31, lk = lane >> 5;
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TN], tot[BLK ? TM : 1][BLK ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (BLK) tot[i][j][r] = 0.f; }
   // pixel of this lane for pixel-tile j: m = wp0 + 32 j + li -> (py, px)
   int pbase[TN];
 #pragma unroll
@@ -326,6 +352,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
       mma(av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (BLK > 0) { if ((ch + 1) % BLK == 0 || ch + 1 == nchunks) conv_flush(acc, tot, ch + 1 == nchunks); }
     __syncthreads();                     // everyone done reading the LDS slab
     if (ch + 1 < nchunks) { lstore(ch + 1); __syncthreads(); }
   }
@@ -340,7 +367,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // GK = 4) or 16 x 16 (128 accumulators, 144 MFMAs per wave and chunk, half the weight DMA per MFMA; 116 VGPRs + 128 AGPRs and
 // 49 KB of LDS: two workgroups per CU).  Ablation of the staged kernel on the modulation convs of up_3 (B 32, 128 -> 2 x 128
 // channels at 256 x 256, 9.8 ms): 8.84 ms without its per-chunk load / ds_write / second barrier; this kernel: 9.06 ms.
-template <int BMC, int KS, int EPI, int THT, int GK>      // GK input channels per LDS buffer (4 or 8)
+template <int BMC, int KS, int EPI, int THT, int GK, int BLK = 0>      // GK input channels per LDS buffer (4 or 8); BLK: see conv_mfma_kernel
 __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
   constexpr int TAPS = KS * KS;
   constexpr int WM = BMC / 64, WN = 4 / WM, TN = THT * TW / WN / 32, TM = 2;   // THT x 16 pixels per workgroup (THT = 8 or 16)
@@ -399,13 +426,13 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
 
   const int wr = (wave / WN) * 64, wp0 = (wave % WN) * (THT * TW / WN);
   const int li = lane & 31, lk = lane >> 5;
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TN], tot[BLK ? TM : 1][BLK ? TN : 1];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (BLK) tot[i][j][r] = 0.f; }
   int pbase[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -448,12 +475,13 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
       mma(av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if constexpr (BLK > 0) { if ((ch + 1) % BLK == 0 || ch + 1 == nchunks) conv_flush(acc, tot, ch + 1 == nchunks); }
   }
   __syncthreads();                   // the epilogue's reductions reuse the buffers
   conv_epilogue<BMC, EPI, THT>(a, acc, lds, b, r0, x0, y0);
 }
 
-template <int BMC, int KS, int EPI, int THT, int GK>
+template <int BMC, int KS, int EPI, int THT, int GK, int BLK = 0>
 int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? (THT + 2) * (TW + 2) : THT * TW;
@@ -461,13 +489,41 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
   if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;      // the epilogue's row-sum transpose
   static bool raised = false;
   if (!raised) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI, THT, GK>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_glds_kernel<BMC, KS, EPI, THT, GK, BLK>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return (int)e;
     raised = true;
   }
   const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, THT) * a.B;
-  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT, GK>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT, GK, BLK>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// Blocked accumulation (see conv_mfma_kernel): variants with 64 accumulators per lane.  Blocks of 16 input channels (144
+// products): 2 buffers of 8 channels / 4 buffers of 4 / 2 staged chunks of 8.
+template <int BMC>
+int launch_conv_blocked(const ConvArgs& a, hipStream_t st) {
+  static const int variant = getenv("SLN_CONV_BLOCK_VARIANT") ? atoi(getenv("SLN_CONV_BLOCK_VARIANT")) : 0;   // lab: 1 = 8 x 16 x BMC rows, 2 = staged
+  if (a.Cin % 8 == 0 && variant != 2) {
+    // 64-row workgroups of 16 x 16 pixels (the halo is DMA'd once per 64 rows instead of once per 128: 1.2x the operand traffic
+    // of the 128-row workgroups; 8 x 16 x 128 rows re-reads the weights per 128 pixels: 1.8x)
+    const long tall_blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, 16) * a.B * (a.rows_pad / 64);
+    if (variant == 0 && a.H >= 16 && tall_blocks >= 512) return launch_conv_dma<64, 3, CEPI_BIAS_ACT, 16, 8, 2>(a, st);
+    return launch_conv_dma<BMC, 3, CEPI_BIAS_ACT, TH, 4, 4>(a, st);
+  }
+  constexpr int HS = HALO;
+  size_t smem = sizeof(float) * (size_t)(9 * CK * BMC + CK * HS);
+  if (a.gap_acc && smem < sizeof(float) * 4 * 64 * 33) smem = sizeof(float) * 4 * 64 * 33;
+  static bool raised = false;
+  if (!raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<BMC, 3, CEPI_BIAS_ACT, 2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B;
+  hipLaunchKernelGGL((conv_mfma_kernel<BMC, 3, CEPI_BIAS_ACT, 2>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -482,6 +538,7 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   // every 128-row conv (modulation 9.8 -> 9.15 ms, 1 024 -> 512 channels at 32 x 32 2.34 -> 2.26 ms)
   static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
   static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
+  if constexpr (KS == 3 && EPI == CEPI_BIAS_ACT) { if (a.blocked) return launch_conv_blocked<BMC>(a, st); }
   if (a.Cin % 8 == 0 && !staged_only) {
     // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, twice the MFMAs per barrier)
     // (not for launches too small to give every CU two of the tall workgroups: batch-1 convs of the one-map-many-z path)
@@ -594,33 +651,44 @@ __global__ __launch_bounds__(256) void depth_concat_kernel(const float* __restri
 
 __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restrict__ out) {   // one block per (b, c)
   const float* p = x + (size_t)blockIdx.x * hw;
-  float s = 0.f;
-  for (long i = threadIdx.x; i < hw; i += blockDim.x) s += p[i];
-  __shared__ float red[256];
+  double s = 0.0;                           // fp64: the pool feeds the squeeze-excite FCs, see se_fc_kernel
+  for (long i = threadIdx.x; i < hw; i += blockDim.x) s += (double)p[i];
+  __shared__ double red[256];
   red[threadIdx.x] = s;
   __syncthreads();
   for (int off = 128; off > 0; off >>= 1) { if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off]; __syncthreads(); }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0] / (float)hw;
+  if (threadIdx.x == 0) out[blockIdx.x] = (float)(red[0] / (double)hw);
 }
 // scale[b, :] = sigmoid(W2 relu(W0 gap[b, :]))   (SEBlock2, :70-85; reduction 8)
-// gap: the averages, or (gsum != nullptr) the fp64 pixel sums a conv epilogue accumulated, divided here by hw
-__global__ void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw, const float* __restrict__ w0,
-                             const float* __restrict__ w2, int C, int Cr, float* __restrict__ scale) {
-  extern __shared__ float sm[];
-  float* g = sm; float* hdn = sm + C;
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? (float)(gsum[(size_t)b * C + c] / hw) : gap[(size_t)b * C + c];
+// gap: the averages, or (gsum != nullptr) the fp64 pixel sums a conv epilogue accumulated, divided here by hw.
+// Both dot products and the logistic are evaluated in fp64 (round 4).  With the reference's default initialisation the
+// spectral-normalised convolutions produce feature maps of magnitude ~1e2, so the logit v = W2 relu(W0 gap) is a sum of ~1e3
+// terms of magnitude 1e1..1e2: an fp32 chain leaves an ABSOLUTE error of ~1e-4 in v, and the logistic turns it into a RELATIVE
+// error of up to 2.5e-5 in the scale of a whole channel plane - coherent over the plane, so the next convolutions add it up
+// instead of averaging it out.  tools/spade_error_budget.py: with this (and the blocked accumulation of the convolutions) the
+// full-size image is 5e-5 from an fp64 evaluation; with fp32 chains here it was 3e-4 whatever the convolutions did (torch's CPU
+// path, whose blocked dot products are short chains, 1.1e-4).  2 x C x C/8 fp64 FMAs per sample: nothing.
+// Wave-cooperative: a wavefront owns hidden rows r = wave, wave + 4, .. and strides its lanes over the C inputs (coalesced).
+__global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw,
+                                                    const float* __restrict__ w0, const float* __restrict__ w2, int C, int Cr,
+                                                    float* __restrict__ scale) {
+  extern __shared__ double smd[];
+  double* g = smd; double* hdn = smd + C;
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? gsum[(size_t)b * C + c] / hw : (double)gap[(size_t)b * C + c];
   __syncthreads();
-  for (int r = threadIdx.x; r < Cr; r += blockDim.x) {
-    float s = 0.f;
-    for (int c = 0; c < C; ++c) s = fmaf(w0[(size_t)r * C + c], g[c], s);
-    hdn[r] = fmaxf(s, 0.f);
+  for (int r = wave; r < Cr; r += 4) {
+    double s = 0.0;
+    for (int c = lane; c < C; c += 64) s = fma((double)w0[(size_t)r * C + c], g[c], s);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) hdn[r] = s > 0.0 ? s : 0.0;
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int r = 0; r < Cr; ++r) s = fmaf(w2[(size_t)c * Cr + r], hdn[r], s);
-    scale[(size_t)b * C + c] = 1.f / (1.f + expf(-s));
+    double s = 0.0;
+    for (int r = 0; r < Cr; ++r) s = fma((double)w2[(size_t)c * Cr + r], hdn[r], s);
+    scale[(size_t)b * C + c] = (float)(1.0 / (1.0 + exp(-s)));
   }
 }
 __global__ void se_scale_add_kernel(const float* __restrict__ xs, const float* __restrict__ dx, const float* __restrict__ scale,
@@ -862,6 +930,9 @@ int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const floa
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a; a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = rows; a.rows_pad = rows_pad;
   a.act = act; a.slope = slope; a.xin = nullptr; a.stats = nullptr; a.C = 0; a.xin_up = 0; a.ln_acc = ln_acc; a.gap_acc = gap_acc;
+  // blocked accumulation for the long chains (K = 9 Cin >= 4 608), see conv_mfma_kernel; SLN_CONV_BLOCK_CIN moves the threshold (lab)
+  static const int block_cin = getenv("SLN_CONV_BLOCK_CIN") ? atoi(getenv("SLN_CONV_BLOCK_CIN")) : 512;
+  a.blocked = ksize == 3 && Cin >= block_cin;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * ksize * ksize * rows, st);
   const bool big = rows_pad % 128 == 0;
   if (ksize == 3) return big ? launch_conv<128, 3, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 3, CEPI_BIAS_ACT>(a, st);
@@ -882,7 +953,7 @@ int sln_spade_modulate_up(const float* actv, int B, int Cin, int H, int W, const
     return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a; a.x = actv; a.wp = wp; a.bias = bias; a.y = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = 2 * C; a.rows_pad = rows_pad;
-  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C; a.xin_up = xin_up; a.ln_acc = nullptr; a.gap_acc = nullptr;
+  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C; a.xin_up = xin_up; a.ln_acc = nullptr; a.gap_acc = nullptr; a.blocked = 0;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * 9 * 2 * C, st);
   return rows_pad % 128 == 0 ? launch_conv<128, 3, CEPI_MODULATE>(a, st) : launch_conv<64, 3, CEPI_MODULATE>(a, st);
 }
@@ -916,7 +987,7 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   const long hw = (long)H * W;
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   if (!gap_sums) hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, hw, gap);
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale);
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale);
   if (stats) {
     const int e = sln_zero_async(acc, sizeof(double) * LN_ACC_STRIDE * B, st);
     if (e != 0) return e;
@@ -976,7 +1047,7 @@ int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw,
   hipStream_t st = (hipStream_t)stream;
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, (long)hw, gap);
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(float) * (C + C / 8), st, gap, (const double*)nullptr, (double)hw, w0, w2,
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, (const double*)nullptr, (double)hw, w0, w2,
                      C, C / 8, scale);
   const long n = (long)B * C * hw;
   hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xs, dx, scale, (long)hw, n, out);

@@ -130,14 +130,19 @@ __global__ __launch_bounds__(64) void csr_sort_kernel(GraphCsr g, int O) {
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// coefficient table of the block's columns [c0, c0 + 4*XT): (scale, shift, mean, istd); one column per thread
+// coefficient table of the block's columns [c0, c0 + 4*XT): (scale, shift, mean, istd); one column per thread.
+// PLANAR (round 4): column j = 4 x + q of the block sits at tab[q * XT + x], so the read of thread x for its q-th column
+// (tab[q * XT + x], one ds_read_b128) is 16 bytes from its neighbour's - conflict-free.  In column order (tab[4 x + q]) the lanes
+// of a read were 64 bytes apart and touched 16 of the 64 banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.80 in the forward
+// scatter, which re-reads its two tables for every entry of a row (profiles/r03_vae_sq_stalls.csv).
+#define SLN_CTAB(j) ((((j) & 3) * XT) + ((j) >> 2))
 template <int XT, int YT>
 __device__ __forceinline__ void fill_coef_table(float4* tab, const BnView& bn, int c0, int ncols, int coloff) {
   const int tid = threadIdx.y * XT + threadIdx.x;
   for (int j = tid; j < 4 * XT; j += XT * YT) {
     float4 v = make_float4(1.f, 0.f, 0.f, 1.f);
     if (c0 + j < ncols) v = bn_fwd_coef4(bn, coloff + c0 + j);
-    tab[j] = v;
+    tab[SLN_CTAB(j)] = v;
   }
 }
 
@@ -166,6 +171,7 @@ __device__ __forceinline__ void commit_col_stats4(const float4& s1, const float4
 // entry list of the block's YT rows, cached in LDS (coalesced) so that the per-entry chain is one level of row loads;
 // rows longer than ECACHE (only the room node of a big graph) read the tail from global memory
 constexpr int ECACHE = 64;
+constexpr int ESTRIDE = ECACHE + 1;         // row stride of the LDS entry cache: the rows a wavefront covers (XT < 64) sit on different banks
 constexpr int EB = 16;                     // row loads in flight per thread
 
 // The prologue of an edge kernel is a chain of memory round trips in front of the first row: the CSR bounds of the row are loaded
@@ -177,7 +183,7 @@ __device__ __forceinline__ void row_bounds(const GraphCsr& g, int row, int nrows
   if (row >= nrows) { b = 0; e = 0; }
 }
 template <int XT, int YT>
-__device__ __forceinline__ void cache_entries(int (*ents)[ECACHE], const GraphCsr& g, int b, int e) {
+__device__ __forceinline__ void cache_entries(int (*ents)[ESTRIDE], const GraphCsr& g, int b, int e) {
   for (int k = threadIdx.x; k < min(e - b, ECACHE); k += XT) ents[threadIdx.y][k] = g.ent[b + k];
   __syncthreads();
 }
@@ -188,7 +194,7 @@ __device__ __forceinline__ void fill_coef_table2(float4* ta, float4* tb, const B
   for (int j = tid; j < 4 * XT; j += XT * YT) {
     float4 va = make_float4(1.f, 0.f, 0.f, 1.f), vb = va;
     if (c0 + j < ncols) bn_fwd_coef4x2(bn, c0 + j, coloff_b + c0 + j, va, vb);
-    ta[j] = va; tb[j] = vb;
+    ta[SLN_CTAB(j)] = va; tb[SLN_CTAB(j)] = vb;
   }
 }
 
@@ -196,7 +202,7 @@ template <int XT, int YT>
 __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float* __restrict__ A2, int ld, int H, int D, BnView bn,
                                                                     GraphCsr g, int O, int T, float* __restrict__ pooled) {
   __shared__ float4 cs[4 * XT], co[4 * XT];
-  __shared__ int ents[YT][ECACHE];
+  __shared__ int ents[YT][ESTRIDE];
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
   int b, e;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
   const int c = c0 + 4 * threadIdx.x;
   if (c >= H || i >= O) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* ks = cs + 4 * threadIdx.x; const float4* ko = co + 4 * threadIdx.x;
+  const float4* ks = cs + threadIdx.x; const float4* ko = co + threadIdx.x;      // planar: column q at [q * XT]
   const int deg = e - b;
   for (int k = 0; k < deg; k += EB) {
     int en[EB]; float4 x[EB];
@@ -228,8 +234,8 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
     for (int u = 0; u < EB; ++u) {
       if (k + u < deg) {                     // same accumulation order as the scalar kernel / the reference scatter_add
         const float4* kk = en[u] >= T ? ko : ks;
-        acc.x += fmaxf(fmaf(kk[0].x, x[u].x, kk[0].y), 0.f); acc.y += fmaxf(fmaf(kk[1].x, x[u].y, kk[1].y), 0.f);
-        acc.z += fmaxf(fmaf(kk[2].x, x[u].z, kk[2].y), 0.f); acc.w += fmaxf(fmaf(kk[3].x, x[u].w, kk[3].y), 0.f);
+        acc.x += fmaxf(fmaf(kk[0].x, x[u].x, kk[0].y), 0.f); acc.y += fmaxf(fmaf(kk[1 * XT].x, x[u].y, kk[1 * XT].y), 0.f);
+        acc.z += fmaxf(fmaf(kk[2 * XT].x, x[u].z, kk[2 * XT].y), 0.f); acc.w += fmaxf(fmaf(kk[3 * XT].x, x[u].w, kk[3 * XT].y), 0.f);
       }
     }
   }
@@ -250,7 +256,7 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
   const int c = c0 + 4 * threadIdx.x;
   const bool cv = c < C;
   const int part = c < H ? 0 : (c < H + D ? 1 : 2);
-  const float4* kk = cf + 4 * threadIdx.x;
+  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * XT]
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (cv) {
    for (int it = 0; it < NIT; ++it) {
@@ -283,12 +289,12 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
     for (int r = 0; r < RPT; ++r) {
       if (t0 + r < T) {
         float4 gv;
-        gv.x = fmaf(kk[0].x, x[r].x, kk[0].y) > 0.f ? d[r].x * w[r] : 0.f; gv.y = fmaf(kk[1].x, x[r].y, kk[1].y) > 0.f ? d[r].y * w[r] : 0.f;
-        gv.z = fmaf(kk[2].x, x[r].z, kk[2].y) > 0.f ? d[r].z * w[r] : 0.f; gv.w = fmaf(kk[3].x, x[r].w, kk[3].y) > 0.f ? d[r].w * w[r] : 0.f;
+        gv.x = fmaf(kk[0].x, x[r].x, kk[0].y) > 0.f ? d[r].x * w[r] : 0.f; gv.y = fmaf(kk[1 * XT].x, x[r].y, kk[1 * XT].y) > 0.f ? d[r].y * w[r] : 0.f;
+        gv.z = fmaf(kk[2 * XT].x, x[r].z, kk[2 * XT].y) > 0.f ? d[r].z * w[r] : 0.f; gv.w = fmaf(kk[3 * XT].x, x[r].w, kk[3 * XT].y) > 0.f ? d[r].w * w[r] : 0.f;
         st4g(g2 + (size_t)(t0 + r) * ld + c, gv);
         s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
-        s2.x = fmaf(gv.x, (x[r].x - kk[0].z) * kk[0].w, s2.x); s2.y = fmaf(gv.y, (x[r].y - kk[1].z) * kk[1].w, s2.y);
-        s2.z = fmaf(gv.z, (x[r].z - kk[2].z) * kk[2].w, s2.z); s2.w = fmaf(gv.w, (x[r].w - kk[3].z) * kk[3].w, s2.w);
+        s2.x = fmaf(gv.x, (x[r].x - kk[0].z) * kk[0].w, s2.x); s2.y = fmaf(gv.y, (x[r].y - kk[1 * XT].z) * kk[1 * XT].w, s2.y);
+        s2.z = fmaf(gv.z, (x[r].z - kk[2 * XT].z) * kk[2 * XT].w, s2.z); s2.w = fmaf(gv.w, (x[r].w - kk[3 * XT].z) * kk[3 * XT].w, s2.w);
       }
     }
    }
@@ -302,7 +308,7 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
                                                                const float* __restrict__ xprev, int ldx, BnView bn, int masked,
                                                                float* __restrict__ out, int ldo, double* gsums, int cstride) {
   __shared__ float4 cf[4 * XT];
-  __shared__ int ents[YT][ECACHE];
+  __shared__ int ents[YT][ESTRIDE];
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
   int b, e;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
   cache_entries<XT, YT>(ents, g, b, e);
   const int c = c0 + 4 * threadIdx.x;
   const bool cv = c < D && i < O;
-  const float4* kk = cf + 4 * threadIdx.x;
+  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * XT]
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (cv) {
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -339,11 +345,11 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
     }
     if (add1) { d.x += ad.x; d.y += ad.y; d.z += ad.z; d.w += ad.w; }
     if (masked) {
-      d.x = fmaf(kk[0].x, xp.x, kk[0].y) > 0.f ? d.x : 0.f; d.y = fmaf(kk[1].x, xp.y, kk[1].y) > 0.f ? d.y : 0.f;
-      d.z = fmaf(kk[2].x, xp.z, kk[2].y) > 0.f ? d.z : 0.f; d.w = fmaf(kk[3].x, xp.w, kk[3].y) > 0.f ? d.w : 0.f;
+      d.x = fmaf(kk[0].x, xp.x, kk[0].y) > 0.f ? d.x : 0.f; d.y = fmaf(kk[1 * XT].x, xp.y, kk[1 * XT].y) > 0.f ? d.y : 0.f;
+      d.z = fmaf(kk[2 * XT].x, xp.z, kk[2 * XT].y) > 0.f ? d.z : 0.f; d.w = fmaf(kk[3 * XT].x, xp.w, kk[3 * XT].y) > 0.f ? d.w : 0.f;
       s1 = d;
-      s2.x = d.x * ((xp.x - kk[0].z) * kk[0].w); s2.y = d.y * ((xp.y - kk[1].z) * kk[1].w);
-      s2.z = d.z * ((xp.z - kk[2].z) * kk[2].w); s2.w = d.w * ((xp.w - kk[3].z) * kk[3].w);
+      s2.x = d.x * ((xp.x - kk[0].z) * kk[0].w); s2.y = d.y * ((xp.y - kk[1 * XT].z) * kk[1 * XT].w);
+      s2.z = d.z * ((xp.z - kk[2 * XT].z) * kk[2 * XT].w); s2.w = d.w * ((xp.w - kk[3 * XT].z) * kk[3 * XT].w);
     }
     st4g(out + (size_t)i * ldo + c, d);
   }

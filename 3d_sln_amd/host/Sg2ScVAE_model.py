@@ -12,6 +12,7 @@ There is no CPU path: calling the model before ``.cuda()`` raises.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -172,6 +173,9 @@ class Sg2ScVAEModel(nn.Module):
         old_m, old_v = getattr(self, "_adam_m", None), getattr(self, "_adam_v", None)
         steps = self._sync_adam_steps() if getattr(self, "_eng", None) is not None else getattr(self, "_adam_steps", 0)
         self._flat, self._gflat, self._gfull, self._gviews, self._params = flat, gflat, gfull, views, params
+        ref = weakref.ref(self)
+        for p in params:
+            p._sln_owner = ref               # lets an unmodified torch.optim.Adam find the fused update (see _adam_step_pre_hook)
         self._offs = offs
         if old_m is not None and old_m.numel() == n:
             self._adam_m, self._adam_v, self._adam_steps = old_m.to(dev), old_v.to(dev), steps
@@ -625,3 +629,114 @@ class FusedAdam:
     def load_state_dict(self, sd):
         self.model.load_optim_state_dict(sd)
         self.param_groups[0]['lr'] = sd['param_groups'][0].get('lr', self.param_groups[0]['lr'])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# train.py:15 builds ``torch.optim.Adam(model.parameters(), lr=args.learning_rate)`` and calls ``optimizer.step()`` (:84).  On 230
+# parameter tensors that step is ~1.7 ms of host work (state look-ups, a dozen multi-tensor launches with their descriptor
+# tables) next to a 1.9 ms training iteration - although all 230 tensors are views of ONE flat buffer that the engine's fused
+# Adam kernel updates in 20 us.  Two process-wide optimizer hooks route such a step: when the optimizer is a plain
+# ``torch.optim.Adam`` over exactly ``model.parameters()`` with the reference's hyper-parameters (default betas / eps, no weight
+# decay, no amsgrad / maximize / capturable / fused / differentiable, no closure) and every parameter holds its gradient view,
+# the pre-hook runs ``sln_vae_adam_step`` and hands torch an empty parameter list for the duration of its own ``step``; the
+# post-hook puts the list back.  ``optimizer.state`` holds VIEWS of the fused moment buffers, so ``optimizer.state_dict()`` /
+# ``load_state_dict()`` keep torch's layout (train.py:25,94) without conversions; anything else - other hyper-parameters, a
+# parameter subset, a missing gradient - takes torch's own path untouched.  ``Sg2ScVAEModel.route_torch_adam = False`` switches
+# the routing off.
+def _fast_adam_owner(opt):
+    if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    ps = g['params']
+    cached = opt.__dict__.get('_sln_owner_ref')
+    if cached is None:
+        ref = getattr(ps[0], "_sln_owner", None) if ps else None
+        m = ref() if ref is not None else None
+        ok = m is not None and len(ps) == len(m._params) and all(a is b for a, b in zip(ps, m._params))
+        opt.__dict__['_sln_owner_ref'] = (ref, len(ps)) if ok else (None, -1)
+        cached = opt.__dict__['_sln_owner_ref']
+    ref, n = cached
+    m = ref() if ref is not None else None
+    if m is None or n != len(ps) or not m.route_torch_adam or ps[0] is not m._params[0]:
+        return None
+    if tuple(g['betas']) != (0.9, 0.999) or g['eps'] != 1e-8 or g['weight_decay'] != 0 or g['amsgrad'] or g.get('maximize') or \
+            g.get('capturable') or g.get('differentiable') or g.get('fused') or torch.is_tensor(g['lr']):
+        return None
+    return m
+
+
+def _fast_adam_views(opt, m):
+    """optimizer.state <-> the fused moment buffers.  A fresh optimizer (no state) starts from zero moments, like torch's; state
+    that torch owns (its own earlier steps, ``load_state_dict``) is copied in once; afterwards the entries are views."""
+    p0 = m._params[0]
+    st0 = opt.state.get(p0)
+    if st0 is not None and m._adam_m is not None and st0['exp_avg'].data_ptr() == m._adam_m.data_ptr() + 4 * m._offs[0] \
+            and opt.__dict__.get('_sln_views_of') == m._adam_m.data_ptr():
+        return
+    g = opt.param_groups[0]
+    foreign = {i: opt.state[p] for i, p in enumerate(m._params) if p in opt.state and 'exp_avg' in opt.state[p]}
+    m.load_optim_state_dict({'state': foreign, 'param_groups': [dict(g, params=list(range(len(m._params))))]})   # empty: zero moments, step 0
+    if m._eng is None:
+        raise _lib.SlnError("optimizer.step() before the first forward / backward of the model")
+    for p, o in zip(m._params, m._offs):
+        n = p.numel()
+        opt.state[p] = {'step': torch.tensor(float(m._adam_steps)), 'exp_avg': m._adam_m[o:o + n].view(p.shape),
+                        'exp_avg_sq': m._adam_v[o:o + n].view(p.shape)}
+    opt.__dict__['_sln_views_of'] = m._adam_m.data_ptr()
+    if not opt.__dict__.get('_sln_sd_hook'):
+        opt.register_state_dict_pre_hook(_fast_adam_materialize_steps)
+        opt.__dict__['_sln_sd_hook'] = True
+
+
+def _fast_adam_materialize_steps(opt):
+    """The per-parameter ``step`` tensors are refreshed when somebody is about to read them (state_dict, a step on torch's path)."""
+    if not opt.__dict__.get('_sln_steps_stale'):
+        return
+    m = _fast_adam_owner(opt)
+    ref = opt.__dict__.get('_sln_owner_ref', (None, 0))[0]
+    m = m if m is not None else (ref() if ref is not None else None)
+    if m is not None:
+        n = float(m._sync_adam_steps())                 # the device's count: a step skipped for a non-finite loss does not advance it
+        for p in m._params:
+            st = opt.state.get(p)
+            if st is not None:
+                st['step'].fill_(n)
+    opt.__dict__['_sln_steps_stale'] = False
+
+
+def _adam_step_pre_hook(opt, args, kwargs):
+    if type(opt) is not torch.optim.Adam:
+        return None
+    m = _fast_adam_owner(opt)
+    routed = m is not None and not args and kwargs.get('closure') is None and m._flat.device.type == 'cuda' and m._eng is not None
+    if routed:
+        for p, gv in zip(m._params, m._gviews):          # torch skips parameters without a gradient: only the all-views case is routed
+            gr = p.grad
+            if gr is None or gr.data_ptr() != gv.data_ptr():
+                routed = False
+                break
+    if not routed:
+        if opt.__dict__.get('_sln_views_of') is not None:
+            _fast_adam_materialize_steps(opt)            # torch's own path continues on the shared moments with the right counters
+        return None
+    _fast_adam_views(opt, m)
+    m.adam_step(lr=float(opt.param_groups[0]['lr']))
+    opt.__dict__['_sln_saved_params'] = opt.param_groups[0]['params']
+    opt.param_groups[0]['params'] = []                   # torch's step() now has nothing to do
+    opt.__dict__['_sln_steps_stale'] = True
+    return None
+
+
+def _adam_step_post_hook(opt, args, kwargs):
+    saved = opt.__dict__.pop('_sln_saved_params', None)
+    if saved is not None:
+        opt.param_groups[0]['params'] = saved
+    return None
+
+
+Sg2ScVAEModel.route_torch_adam = True
+if not getattr(torch.optim.Optimizer, "_sln_hooks_installed", False):
+    from torch.optim.optimizer import register_optimizer_step_post_hook, register_optimizer_step_pre_hook
+    register_optimizer_step_pre_hook(_adam_step_pre_hook)
+    register_optimizer_step_post_hook(_adam_step_post_hook)
+    torch.optim.Optimizer._sln_hooks_installed = True

@@ -748,16 +748,21 @@ def spade_leg(args, lib, torch):
                 spade_ref.generator(sd, cfg, segc, zc); n_it += 1
             cdt = (time.perf_counter() - t0) / n_it
         if not args.no_check:
-            # full-size parity, conditioned: the image is a 1600-term sum of cancelling products (tanh of a small number), where
-            # any two fp32 evaluations differ by a few 1e-4 of its scale; hold |hip - fp64 oracle| to 1e-4 plus a small multiple of
-            # the fp32 oracle's own distance from the fp64 one (tests/parity.py: assert_close_conditioned)
+            # full-size parity (round 4): |hip - fp64 oracle| <= 1e-4 of the image scale + the fp32 oracle's own distance from the
+            # fp64 one (the CPU path itself is ~1.1e-4 away at these weights: tanh of a 1 600-term cancelling sum), and hip within
+            # 2e-4 of the CPU fp32 path - the quantity north_star names.  Rounds 1-3 needed 4x the CPU distance here (3.0e-4):
+            # the squeeze-excite FCs ran as fp32 chains and the MFMA accumulators as serial chains over K = 9 Cin up to 9 216
+            # (tools/spade_error_budget.py locates both; csrc/spade.hip: se_fc_kernel in fp64, blocked accumulation).
             log('spade full-size parity: fp64 oracle, 1 image')
             with torch.no_grad():
                 ref64 = spade_ref.generator({k: v.double() for k, v in sd.items()}, cfg, segc[:1].double(), zc[:1].double())
             e_hip, e_cpu = rel_err(out[:1].cpu().numpy(), ref64.numpy()), rel_err(ref[:1].numpy(), ref64.numpy())
-            require(e_hip <= 1e-4 + 4.0 * e_cpu, "SPADE full-size generator (110 M parameters, 256x256): image rel err vs fp64 oracle %.2e "
-                                                 "(fp32 oracle: %.2e)" % (e_hip, e_cpu))
-            res["parity"].update({"full_size_image_rel_err_vs_fp64_oracle": e_hip, "fp32_oracle_rel_err_vs_fp64_oracle": e_cpu})
+            e_hip_cpu = rel_err(out[:1].cpu().numpy(), ref[:1].numpy())
+            require(e_hip <= 1e-4 + e_cpu, "SPADE full-size generator (110 M parameters, 256x256): image rel err vs fp64 oracle %.2e "
+                                           "(fp32 oracle: %.2e)" % (e_hip, e_cpu))
+            require(e_hip_cpu <= 2e-4, "SPADE full-size generator: image rel err vs the CPU fp32 oracle %.2e" % e_hip_cpu)
+            res["parity"].update({"full_size_image_rel_err_vs_fp64_oracle": e_hip, "fp32_oracle_rel_err_vs_fp64_oracle": e_cpu,
+                                  "full_size_image_rel_err_vs_fp32_oracle": e_hip_cpu})
         res["cpu_baseline"] = {"value": round(bc / cdt, 3), "unit": "images/s", "cores": n, "kind": "port",
                                "sample": "%d x batch of %d images of the same input through oracle/spade_ref.py (torch CPU fp32), %.2f s per image"
                                          % (n_it, bc, cdt / bc)}

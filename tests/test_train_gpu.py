@@ -195,6 +195,7 @@ def test_fused_adam_is_torch_adam_in_the_reference_loop():
     outs = {}
     for name in ("torch", "fused"):
         model = _model(cfg, sd).train()
+        model.route_torch_adam = name != "torch"                 # torch's OWN update on the 230 tensors (not routed to the fused kernel)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3) if name == "torch" else model.fused_adam(lr=1e-3)
         if name == "fused":
             model(*dev[:5], None, eps=dev[5])                    # engine exists; poison the guard slot as a NaN rank would
@@ -217,6 +218,71 @@ def test_fused_adam_is_torch_adam_in_the_reference_loop():
         a, b2 = st["state"][i]["exp_avg"].cpu().numpy(), sf["state"][i]["exp_avg"].cpu().numpy()
         assert_close(b2, a, "exp_avg %d" % i, rtol=1e-3, atol=1e-5 * max(float(np.abs(a).max()), 1e-30) + 1e-9)
         assert int(float(sf["state"][i]["step"])) == 3
+
+
+def test_unmodified_torch_adam_is_routed_to_the_fused_kernel_and_keeps_torchs_state_layout():
+    """train.py:15's ``torch.optim.Adam(model.parameters(), lr)`` with NO change: its step() runs the fused kernel (two optimizer
+    hooks, host/Sg2ScVAE_model.py), optimizer.state holds views of the fused moments.  Against the same optimizer with the routing
+    off (torch's multi-tensor update): parameters agree to Adam's rounding noise, state_dict() has torch's layout and values, a
+    state_dict loaded into a fresh optimizer continues identically, and a step torch must take itself (one gradient missing)
+    continues from the shared moments with the right step counters."""
+    import types
+    U = pkg("host.utils")
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="none")
+    sd = vae_ref.init_state(cfg, seed=11)
+    batch = vae_ref.synth_batch(6, 9, 14, seed=2, cfg=cfg)
+    eps = torch.randn(batch[0].shape[0], cfg.embedding_dim, generator=torch.Generator().manual_seed(5))
+    dev = _dev(*batch[:5], eps)
+
+    def loop(model, opt, n, drop_grad_at=None):
+        for it in range(n):
+            out = model(*dev[:5], None, eps=dev[5])
+            total, _ = U.calculate_model_losses(types.SimpleNamespace(use_AE=False), model, dev[2], out[2], dev[3], out[3], mu=out[0],
+                                                logvar=out[1], KL_weight=0.1)
+            opt.zero_grad(); total.backward()
+            if drop_grad_at == it:
+                model.box_net[0].bias.grad = None                 # torch skips this parameter: the step cannot be routed
+            opt.step()
+    outs = {}
+    for routed in (False, True):
+        model = _model(cfg, sd).train()
+        model.route_torch_adam = routed
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        calls = []
+        if routed:
+            orig = model.adam_step
+            model.adam_step = lambda lr=1e-4: (calls.append(lr), orig(lr=lr))[1]
+        loop(model, opt, 3)
+        assert len(calls) == (3 if routed else 0)
+        assert len(opt.param_groups[0]['params']) == len(list(model.parameters()))       # the list is back after every step
+        outs[routed] = (model.flat_params.clone(), opt.state_dict(), model, opt)
+    pt, pf = outs[False][0].cpu().numpy(), outs[True][0].cpu().numpy()
+    d = np.abs(pt - pf)
+    assert d.max() <= 3 * 2.05e-3 and np.mean(d > 1e-5) < 0.05, (d.max(), np.mean(d > 1e-5))
+    st, sf = outs[False][1], outs[True][1]
+    assert sorted(st["state"].keys()) == sorted(sf["state"].keys()) == list(range(len(st["state"])))
+    assert sf["param_groups"][0]["params"] == st["param_groups"][0]["params"]
+    for i in st["state"]:
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b2 = st["state"][i][k].cpu().numpy(), sf["state"][i][k].cpu().numpy()
+            assert a.shape == b2.shape
+            assert_close(b2, a, "%s %d" % (k, i), rtol=1e-3, atol=1e-5 * max(float(np.abs(a).max()), 1e-30) + 1e-12)
+        assert int(float(sf["state"][i]["step"])) == int(float(st["state"][i]["step"])) == 3
+    # train.py:25: the saved state into a FRESH optimizer of a fresh model, two more steps on either path
+    import copy
+    ends = {}
+    for routed in (False, True):
+        model = _model(cfg, sd).train()
+        model.load_state_dict(outs[True][2].state_dict())
+        model.route_torch_adam = routed
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        opt.load_state_dict(copy.deepcopy(sf))
+        loop(model, opt, 2, drop_grad_at=1 if routed else None)   # routed arm: second step falls back to torch's own update
+        ends[routed] = (model.flat_params.clone().cpu().numpy(), opt.state_dict())
+    d = np.abs(ends[False][0] - ends[True][0])
+    assert d.max() <= 2 * 2.05e-3 and np.mean(d > 1e-5) < 0.05, (d.max(), np.mean(d > 1e-5))
+    steps = sorted({int(float(v["step"])) for v in ends[True][1]["state"].values()})
+    assert steps == [4, 5], steps                                  # the parameter without a gradient was skipped once, as torch does
 
 
 def vae_ref_flat(cfg, sd, model):

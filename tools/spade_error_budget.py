@@ -251,7 +251,11 @@ if os.environ.get("SLN_BUDGET_BLOCKED", "1") != "0":
                 G._conv, G._spade = orig_conv, orig_spade
                 ei, eu, ri, ru = run(pol)
                 print("%-5d %-26s %10.2e %10.2e %10.2e %10.2e" % (k, name, ei, ri, eu, ru))
-            for name, pol in pols[:2]:
+            se_pols = pols[:2]
+            if os.environ.get("SLN_BUDGET_SE_SWEEP"):
+                se_pols = (("all, S=16", (0, 16)), ("all, S=32", (0, 32)), ("Cin>=256, S=16", (256, 16)), ("Cin>=512, S=16", (512, 16)),
+                           ("Cin>=256, S=32", (256, 32)), ("Cin>=256, S=64", (256, 64)), ("Cin>=128, S=16", (128, 16)))
+            for name, pol in se_pols:
                 ei, eu, ri, ru = run_se64(pol)
                 print("%-5d %-26s %10.2e %10.2e %10.2e %10.2e" % (k, name + " +SE fp64", ei, ri, eu, ru))
     else:
