@@ -137,6 +137,10 @@ SIGNATURES = {
                                             C.c_void_p]),
     "sln_raster_backward_rgb": (C.c_int, [c_f32p, C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                           c_f32p, C.c_void_p]),
+    "sln_raster_texture_sample_chw": (C.c_int, [c_f32p, c_f32p, C.c_void_p, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                                C.c_float, C.c_float, c_f32p, C.c_void_p]),
+    "sln_raster_backward_rgb_multi": (C.c_int, [c_f32p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                                C.c_void_p, c_f32p, C.c_void_p]),
     "sln_scene_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sln_scene_forward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),

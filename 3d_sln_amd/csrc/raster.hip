@@ -245,6 +245,54 @@ __global__ void texture_sample_kernel(const float* __restrict__ faces, const flo
   rgb[3 * i] = px[0]; rgb[3 * i + 1] = px[1]; rgb[3 * i + 2] = px[2];
 }
 
+// The same sampling for the Renderer's rgb mode in one launch (round 4): output [B,3,is,is] with rows flipped (what
+// neural_renderer returns after permute + flip: three torch copies before), ambient light as a factor, and fill_back resolved by
+// index: textures hold F_tex = F / 2 cubes, face f >= F_tex reads cube f - F_tex with its first and third texture axes swapped
+// (the package concatenates textures.permute((0, 1, 4, 3, 2, 5)) - a copy of the whole texture tensor per pass).
+__global__ void texture_sample_chw_kernel(const float* __restrict__ faces, const float* __restrict__ textures,
+                                          const int32_t* __restrict__ fi, const float* __restrict__ w,
+                                          const float* __restrict__ depth, int F, int F_tex, int is, int ts, float eps, float scale,
+                                          long npix, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npix) return;
+  const int fn = fi[i];
+  const long plane = (long)is * is;
+  const long b = i / plane; const int p = (int)(i - b * plane);
+  float px[3] = {0.f, 0.f, 0.f};
+  if (fn >= 0) {
+    const float* f = faces + 9 * (b * F + fn);
+    const bool back = fn >= F_tex;
+    const float* tx = textures + (size_t)(b * F_tex + (back ? fn - F_tex : fn)) * ts * ts * ts * 3;
+    if (!back) {
+      tex_sample(f, tx, ts, eps, w[3 * i], w[3 * i + 1], w[3 * i + 2], depth[i], px);
+    } else {                      // swapped axes: cell (t0, t1, t2) of the permuted cube is cell (t2, t1, t0) of the stored one
+      const float wk[3] = {w[3 * i], w[3 * i + 1], w[3 * i + 2]};
+      float t[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float v = wk[k] * (ts - 1) * (depth[i] / f[3 * k + 2]);
+        v = fmaxf(v, 0.f); v = fminf(v, (float)(ts - 1) - eps);
+        t[k] = v;
+      }
+      for (int c = 0; c < 8; ++c) {
+        float ww = 1.f; int ti[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const float fr = t[k] - (float)(int)t[k];
+          if (((c >> k) & 1) == 0) { ww *= 1.f - fr; ti[k] = (int)t[k]; }
+          else { ww *= fr; ti[k] = (int)t[k] + 1; }
+        }
+        const int cell = ti[2] * ts * ts + ti[1] * ts + ti[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) px[k] += ww * tx[3 * cell + k];
+      }
+    }
+  }
+  const int y = p / is, x = p - y * is;
+  float* o = out + b * 3 * plane + (long)(is - 1 - y) * is + x;
+  o[0] = px[0] * scale; o[plane] = px[1] * scale; o[2 * plane] = px[2] * scale;
+}
+
 // depth backward, atomic-free: one wavefront per face gathers the pixels it won inside its bounding box
 // (a per-pixel scatter serialises on the 9 atomics of large wall / floor faces: 1.45 ms per 16 rooms).
 // gridDim.y > 1 (few images: the launch lasts as long as the largest face's bounding box walk): the windows of 64 pixels
@@ -361,6 +409,67 @@ struct PixDense {            // C-channel image: one positive-part test over the
     return PixDenseView{fi + b * plane, rgb + b * plane * C, grad + b * plane * C, C, is, axis};
   }
 };
+
+// P rgb passes over the SAME geometry in ONE walk (round 4).  mesh_render_func calls nr.Renderer 32 times on identical vertices
+// (models/diff_render.py:381-398) and back-propagates all of them at once: the Renderer defers the pixel-map backward of its
+// rgb passes until autograd reaches the shared projection node and then runs this policy - the edge walk, the prefix sums and
+// the scan windows are paid once instead of P times.  Semantics = the sum over the passes of the package's per-pass gradient
+// (every pass keeps its own positive-part test).  Images are [B,3,is,is] with rows flipped, exactly what the Renderer returned
+// and what autograd hands back.  mask[b][pixel] has bit p set when pass p is non-zero at the pixel in any channel: a pass whose
+// image is zero at both the scanned and the reference pixel contributes exactly nothing (diff = 0), so only the set bits are
+// visited - one or two of 32 for class masks, all of them for dense textures (still exact).
+struct PixMultiView {
+  const int32_t* fi; const float* const* rgb; const float* const* grad; const unsigned long long* mask;
+  unsigned img_off, plane; int is, axis, shift;          // img_off: floats of image b inside a pass tensor; shift: log2(is) or -1
+  __device__ __forceinline__ int idx(int d0, int d1) const { return axis == 0 ? d1 * is + d0 : d0 * is + d1; }
+  __device__ __forceinline__ int flipped(int p) const {
+    const int y = shift >= 0 ? p >> shift : p / is;
+    return p + (is - 1 - 2 * y) * is;
+  }
+  struct __align__(16) Ref { int pf; int fi; unsigned long long m; };
+  __device__ __forceinline__ void ref_pair(int pa, int pb, Ref& ra, Ref& rb) const {
+    ra.pf = flipped(pa); ra.fi = fi[pa]; ra.m = mask[ra.pf];
+    rb.pf = flipped(pb); rb.fi = fi[pb]; rb.m = mask[rb.pf];
+  }
+  struct Loaded { int fq; float tot; };
+  __device__ __forceinline__ Loaded load(int p, const Ref& ref) const {
+    Loaded r; r.fq = fi[p];
+    const int pf = flipped(p);
+    unsigned long long m = mask[pf] | ref.m;
+    float tot = 0.f;
+    while (m) {
+      const int ps = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const float* im = rgb[ps] + img_off; const float* g = grad[ps] + img_off;
+      float diff = 0.f;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) diff += (im[k * plane + pf] - im[k * plane + ref.pf]) * g[k * plane + pf];
+      if (diff > 0.f) tot += diff;
+    }
+    r.tot = tot;
+    return r;
+  }
+  __device__ __forceinline__ float eval(const Loaded& L, const Ref&, int& fq) const { fq = L.fq; return L.tot; }
+};
+struct PixMulti {
+  const int32_t* fi; const float* const* rgb; const float* const* grad; const unsigned long long* mask; int is, shift;
+  __device__ __forceinline__ PixMultiView view(int axis, int b) const {
+    const unsigned plane = (unsigned)is * (unsigned)is;
+    return PixMultiView{fi + (long)b * plane, rgb, grad, mask + (long)b * plane, (unsigned)b * 3u * plane, plane, is, axis, shift};
+  }
+};
+// mask[b][flipped pixel] of PixMulti: one thread per pixel, P <= 64 passes
+__global__ void multi_mask_kernel(const float* const* __restrict__ rgb, int P, int plane, long n, unsigned long long* __restrict__ mask) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const long b = i / plane; const long q = i - b * plane;
+  unsigned long long m = 0;
+  for (int ps = 0; ps < P; ++ps) {
+    const float* im = rgb[ps] + b * 3 * plane + q;
+    if (im[0] != 0.f || im[plane] != 0.f || im[2 * (long)plane] != 0.f) m |= 1ull << ps;
+  }
+  mask[i] = m;
+}
 
 // The reference's 32 class passes fused (models/diff_render.py:381-398): pass c renders value(pixel) where the
 // winning face belongs to class c and 0 elsewhere, into three equal rgb channels whose mean is the class
@@ -830,6 +939,45 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   // is b + a)
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
                      grad_faces, (const FaceRec*)nullptr);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// Renderer rgb mode in one launch: see texture_sample_chw_kernel.
+int sln_raster_texture_sample_chw(const float* faces, const float* textures, const int32_t* face_index, const float* weight,
+                                  const float* depth, int B, int F, int F_tex, int image_size, int texture_size, float eps, float scale,
+                                  float* rgb_chw, void* stream) {
+  if (!faces || !textures || !face_index || !weight || !depth || !rgb_chw || texture_size < 2) return SLN_E_BADARG;
+  if (F_tex != F && 2 * F_tex != F) return SLN_E_BADARG;
+  const long npix = (long)B * image_size * image_size;
+  if (npix <= 0) return 0;
+  hipLaunchKernelGGL(texture_sample_chw_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, textures,
+                     face_index, weight, depth, F, F_tex, image_size, texture_size, eps, scale, npix, rgb_chw);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// backward_pixel_map of P rgb passes over the same face-index map in one walk: see PixMulti.  rgb_chw / grad_chw: DEVICE arrays
+// of P pointers to [B,3,is,is] row-flipped images; mask_ws: B * is * is 8-byte words of scratch; P <= 64.
+int sln_raster_backward_rgb_multi(const float* faces, const int32_t* face_index, const float* const* rgb_chw,
+                                  const float* const* grad_chw, int P, int B, int F, int image_size, float eps, void* mask_ws,
+                                  float* grad_faces, void* stream) {
+  if (!faces || !face_index || !rgb_chw || !grad_chw || !mask_ws || !grad_faces || P < 1 || P > 64) return SLN_E_BADARG;
+  if ((long)image_size * image_size * 3 * B >= (1L << 31)) return SLN_E_UNSUPPORTED;      // 32-bit offsets inside a pass tensor
+  if (!pixel_map_grid_ok(B, F)) return SLN_E_UNSUPPORTED;
+  const long n = (long)B * F;
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const int plane = image_size * image_size;
+  const long npix = (long)B * plane;
+  SlnProfScope prof(SLN_FAM_RASTER_BWD, 24.0 * P * npix + 72.0 * n, st);
+  unsigned long long* mask = static_cast<unsigned long long*>(mask_ws);
+  hipLaunchKernelGGL(multi_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, rgb_chw, P, plane, npix, mask);
+  int shift = -1;
+  if ((image_size & (image_size - 1)) == 0) { shift = 0; while ((1 << shift) < image_size) ++shift; }
+  PixMulti pix{face_index, rgb_chw, grad_chw, mask, image_size, shift};
+  hipLaunchKernelGGL((pixel_map_backward_kernel<PixMulti>), dim3(pixel_map_grid_x(B, F), 6, g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)),
+                     dim3(64), 0, st, faces, pix, B, F, image_size, eps, grad_faces, (const FaceRec*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -890,6 +890,8 @@ def main():
         for k in range(args.steps):
             losses = step()
             marks[k + 1].record()                # per-step GPU time for the percentiles (SURVEY.md 8d protocol); ~1 us each
+        torch.cuda.synchronize()                 # (barrier() starts with the same call)
+        dt_local = time.perf_counter() - t0      # this rank's own time, before it waits for the others
         barrier()
         dt = time.perf_counter() - t0
     per_step = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
@@ -912,6 +914,59 @@ def main():
     final_loss = float(losses[3].item())
     ms_per_step = dt / args.steps * 1e3
     value = args.graphs * world * args.steps / dt
+    dp_diag = None
+    if dp:
+        # Diagnostics BEHIND the timed region (they do not enter `value`), so that the first SCALE line that exists answers what
+        # DESIGN.md section 5 leaves open: (i) every rank's own wall time per step, (ii) the stand-alone all-reduce of the gradient
+        # bucket on communicators created with NCCL_ALGO=Ring and =Tree (RCCL reads the variable when a communicator is
+        # initialised: a new group per setting), (iii) plain vs overlapped (two-half) iteration, same box, same run.
+        dp_diag = {}
+        mine = torch.tensor([dt_local / args.steps * 1e3], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        ranks_ms = [float(x.item()) for x in every]
+        dp_diag["ms_per_step_by_rank_min_max"] = [round(min(ranks_ms), 4), round(max(ranks_ms), 4)]
+        algo_us = {}
+        keep_algo = os.environ.get("NCCL_ALGO")
+        for algo in ("Ring", "Tree"):
+            try:
+                os.environ["NCCL_ALGO"] = algo
+                grp = dist.new_group(ranks=list(range(world)), backend="nccl")
+                with torch.cuda.stream(stream):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    for i in range(25):
+                        if i == 5:
+                            e0.record()
+                        dist.all_reduce(model.grad_bucket, op=dist.ReduceOp.AVG, group=grp)
+                    e1.record()
+                torch.cuda.synchronize()
+                algo_us[algo] = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
+                dist.destroy_process_group(grp)
+            except Exception as ex:                      # a diagnostic must not take the measurement down
+                algo_us[algo] = "failed: %s" % (str(ex)[:80],)
+        if keep_algo is None:
+            os.environ.pop("NCCL_ALGO", None)
+        else:
+            os.environ["NCCL_ALGO"] = keep_algo
+        dp_diag["allreduce_us_by_NCCL_ALGO"] = algo_us
+        ab = {}
+        for name, ov in (("plain", False), ("overlap", True)):
+            st2 = T.DataParallelStep(model, world, overlap=ov, force=force_dp)
+            if st2.overlap != ov:
+                ab[name] = None
+                continue
+            with torch.cuda.stream(stream):
+                for k in range(5):
+                    st2(bdicts[k % len(bdicts)], 0.1, 1e-4, use_graph=use_graph, eps=eps)
+                barrier()
+                t0 = time.perf_counter()
+                for k in range(20):
+                    st2(bdicts[k % len(bdicts)], 0.1, 1e-4, use_graph=use_graph, eps=eps)
+                barrier()
+                d2 = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
+            dist.all_reduce(d2, op=dist.ReduceOp.MAX)
+            ab[name] = round(float(d2.item()) / 20 * 1e3, 4)
+        dp_diag["ms_per_step_plain_vs_overlap"] = ab
 
     out = {
         "metric": "scene-graph VAE steps/sec + 256² diff-render fps, 1/2/4/8 MI355X",
@@ -930,6 +985,8 @@ def main():
                                   % (model.flat_grads.numel(), " in 2 buckets, decoder half overlapped with the encoder backward" if dp_step.overlap else "")) if dp else None,
                    "allreduce_us_standalone": coll_us, "final_total_loss": round(final_loss, 5)},
     }
+    if dp_diag is not None:
+        out["data_parallel"] = dp_diag
     if not (final_loss == final_loss and abs(final_loss) < 1e30):
         raise SystemExit("bench.py: the training loss is not finite (%r): nothing reported" % final_loss)
     if parity is not None:

@@ -263,6 +263,20 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
 /* backward_pixel_map for a `channels`-channel image rgb/grad_rgb [B,is,is,channels]: grad_faces += ... */
 int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const float* rgb, const float* grad_rgb, int B,
                             int F, int image_size, int channels, float eps, float* grad_faces, void* stream);
+/* Renderer.__call__(mode="rgb") (models/diff_render.py:398) behind cached maps, one launch: forward_texture_sampling + ambient
+ * light (factor `scale`) + the package's permute / row flip -> rgb_chw [B,3,is,is].  textures [B,F_tex,ts,ts,ts,3] with
+ * F_tex == F, or F_tex == F / 2 for fill_back: face f >= F_tex samples cube f - F_tex with texture axes 0 and 2 swapped
+ * (the package's torch.cat((textures, textures.permute((0, 1, 4, 3, 2, 5))), dim=1)). */
+int sln_raster_texture_sample_chw(const float* faces, const float* textures, const int32_t* face_index, const float* weight,
+                                  const float* depth, int B, int F, int F_tex, int image_size, int texture_size, float eps, float scale,
+                                  float* rgb_chw, void* stream);
+/* backward_pixel_map of P <= 64 rgb passes rendered over the SAME face-index map (the 32 class passes of mesh_render_func,
+ * models/diff_render.py:381-398, back-propagated together): grad_faces += sum over the passes of the package's per-pass
+ * gradient, in one edge walk.  rgb_chw / grad_chw: device arrays of P device pointers to [B,3,is,is] images as returned by
+ * sln_raster_texture_sample_chw / handed back by autograd; mask_ws: 8 * B * is * is bytes of scratch. */
+int sln_raster_backward_rgb_multi(const float* faces, const int32_t* face_index, const float* const* rgb_chw,
+                                  const float* const* grad_chw, int P, int B, int F, int image_size, float eps, void* mask_ws,
+                                  float* grad_faces, void* stream);
 
 /* Fused scene pass = models/diff_render.py:359-434 (1 depth + one rgb pass per class, masks, per-class mean
  * depth, wall_max normalisation, 70-channel layout) in ONE rasterisation.

@@ -167,6 +167,63 @@ def test_renderer_reuses_the_rasterisation_of_unchanged_geometry():
         NR._rasterize = orig
 
 
+@pytest.mark.parametrize("image_size,n_pass,dense", [(96, 5, True), (100, 3, False), (64, 70, False)])
+def test_shared_geometry_passes_equal_the_plain_one_rasterisation_per_call_path(image_size, n_pass, dense):
+    """The Renderer's fast path (one projection node, one launch per rgb pass, ONE deferred pixel-map backward over all passes:
+    sln_raster_texture_sample_chw / sln_raster_backward_rgb_multi) against its plain path (reuse_rasterisation = False: every call
+    projects, rasterises, concatenates the fill_back textures and back-propagates on its own): images bit-identical, dV to 1e-5.
+    dense: random trilinear textures (every pass non-zero everywhere: all mask bits set); otherwise 0/1 class masks; 70 passes
+    take two launches of the 64-pass kernel; 100 is not a power of two (row flip by division)."""
+    NR = pkg("host.neural_renderer")
+    V, F, ranges, box = rr.synth_room(4, n_objects=6, target_faces=400)
+    K, R, t = [x.cuda() for x in rr.get_cam_mat(torch.from_numpy(box))]
+    zc = (torch.from_numpy(V).cuda() @ R[0].T + t[0])[:, 2].cpu().numpy()
+    F = F[(zc[F] > 0.3).all(1)]
+    kw = dict(camera_mode='projection', image_size=image_size, K=K, R=R, t=t, anti_aliasing=False, orig_size=512, near=0.001,
+              light_intensity_ambient=0.7 if dense else 1.0, light_intensity_directional=0.0)
+    f = torch.from_numpy(F)[None].cuda()
+    g = torch.Generator().manual_seed(3)
+    texs = []
+    for k in range(n_pass):
+        if dense:
+            tex = torch.rand(1, F.shape[0], 2, 2, 2, 3, generator=g).cuda()
+        else:
+            tex = torch.zeros(1, F.shape[0], 2, 2, 2, 3, device="cuda"); tex[:, k::max(n_pass // 2, 2)] = 1.0
+        texs.append(tex)
+    res = {}
+    keep = NR.Renderer.reuse_rasterisation
+    try:
+        for reuse in (False, True):
+            NR.Renderer.reuse_rasterisation = reuse
+            v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+            hip = NR.Renderer(**kw)
+            outs = [hip(v, f, texs[0], mode='depth')] + [hip(v, f, tex, mode='rgb') for tex in texs]
+            w = [torch.randn(o.shape, generator=torch.Generator().manual_seed(i)).cuda() for i, o in enumerate(outs)]
+            sum((o * wi).sum() for o, wi in zip(outs, w)).backward()
+            res[reuse] = ([o.detach().clone() for o in outs], v.grad.clone())
+            if reuse:                                        # a second backward sweep over part of the passes (retain_graph)
+                v2 = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+                o2 = [hip(v2, f, tex, mode='rgb') for tex in texs[:2]]
+                (o2[0] * w[1]).sum().backward(retain_graph=True)
+                g_first = v2.grad.clone()
+                (o2[1] * w[2]).sum().backward()
+                res["two_sweeps"] = (g_first, v2.grad.clone())
+    finally:
+        NR.Renderer.reuse_rasterisation = keep
+    for a, b in zip(res[False][0], res[True][0]):
+        assert a.shape == b.shape
+        if dense:           # ambient light: the plain path scales the texels before it samples, the fast one the sampled pixel
+            assert_close(b.cpu().numpy(), a.cpu().numpy(), "image", rtol=1e-6, atol=1e-6)
+        else:
+            assert torch.equal(a, b)
+    gp, gs = res[False][1].cpu().numpy(), res[True][1].cpu().numpy()
+    assert_close(gs, gp, "dV shared vs plain", rtol=1e-5, atol=2e-6 * float(np.abs(gp).max()))
+    assert np.abs(gp).max() > 0
+    # separate sweeps: each flushes what it recorded, the sum is the gradient of both passes
+    g1, g12 = res["two_sweeps"]
+    assert float(g1.abs().max()) > 0 and float((g12 - g1).abs().max()) > 0
+
+
 @pytest.mark.parametrize("image_size,target", [(96, 500), (256, 2000), (50, 200)])
 def test_fused_scene_matches_33_pass_restatement(image_size, target):
     DR = pkg("host.diff_render")
