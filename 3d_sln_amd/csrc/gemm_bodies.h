@@ -904,6 +904,8 @@ inline size_t nt16_smem_bytes(int K, int J) {
 inline int nt16_pick(const GemmNTArgs& a) {
   static const int enabled = std::getenv("SLN_NT16") ? std::atoi(std::getenv("SLN_NT16")) : 1;
   if (!enabled || a.A.nseg != 1 || a.K > 2048) return 0;
+  // (round 4, measured and dropped: J = 1 / J = 2 - 64 x 32 / 64 x 64 tiles of 16 x 16 MFMAs, two co-resident workgroups per CU - for
+  // the N = 256 dgrad of net1's second Linear: 1.8585 / 1.8688 ms per step against 1.8619-1.8637, same box)
   const long mb = sln_cdiv(a.M, 64);
   const long base = ((mb * sln_cdiv(a.N, 64) + 255) / 256) * 2;
   int best = 0; long bc = base;

@@ -792,14 +792,16 @@ __global__ void project_faces_bwd_kernel(const float* __restrict__ verts, const 
   atomicAdd(g + 2, gx * c.R[2] + gy * c.R[5] + gzc * c.R[8]);
 }
 
-// Deterministic form (SLN_DETERMINISTIC): one thread per vertex walks every face corner of its image in order and adds the
-// contributions of the corners that reference it - the scatter above adds them with float atomics in arrival order.  O(V F) loads
-// (served by L2: the corner list of an image is a few hundred KB) instead of O(F) atomics.
-__global__ void project_faces_bwd_det_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces, const float* __restrict__ K,
-                                             const float* __restrict__ R, const float* __restrict__ t, int V, int F, float os, float eps,
-                                             const float* __restrict__ gout, float* __restrict__ gverts) {
-  const int b = blockIdx.y, vi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (vi >= V) return;
+// Deterministic form (SLN_DETERMINISTIC): one WAVEFRONT per vertex; lane l takes the face corners l, l + 64, .. of its image in
+// ascending order and adds the contributions of those that reference the vertex, then the 64 partial sums meet in a fixed
+// shuffle tree - a fixed association of the same terms on every run (the scatter above adds them with float atomics in arrival
+// order).  Round 3 walked all 3 F corners in ONE thread per vertex (O(V F) dependent L2 loads per thread: 1.2 ms of the 1.8 ms
+// a deterministic 16-room scene pass took); the corner list of an image is ~50 KB and stays in L2.
+__global__ __launch_bounds__(64) void project_faces_bwd_det_kernel(const float* __restrict__ verts, const int32_t* __restrict__ faces,
+                                                                   const float* __restrict__ K, const float* __restrict__ R,
+                                                                   const float* __restrict__ t, int V, int F, float os, float eps,
+                                                                   const float* __restrict__ gout, float* __restrict__ gverts) {
+  const int b = blockIdx.y, vi = blockIdx.x, lane = threadIdx.x;
   const float* p = verts + ((long)b * V + vi) * 3;
   const Cam c = load_cam(K, R, t, b);
   const float x = p[0] * c.R[0] + p[1] * c.R[1] + p[2] * c.R[2] + c.t[0];
@@ -808,7 +810,7 @@ __global__ void project_faces_bwd_det_kernel(const float* __restrict__ verts, co
   const float iz = 1.f / (z + eps), s = 2.f / os;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   const long base = (long)b * F * 3;
-  for (long j = 0; j < 3L * F; ++j) {
+  for (long j = lane; j < 3L * F; j += 64) {
     if (faces[base + j] != vi) continue;
     const float gu = gout[3 * (base + j)], gv = gout[3 * (base + j) + 1], gz = gout[3 * (base + j) + 2];
     if (gu == 0.f && gv == 0.f && gz == 0.f) continue;
@@ -820,8 +822,12 @@ __global__ void project_faces_bwd_det_kernel(const float* __restrict__ verts, co
     a1 += gx * c.R[1] + gy * c.R[4] + gzc * c.R[7];
     a2 += gx * c.R[2] + gy * c.R[5] + gzc * c.R[8];
   }
-  float* g = gverts + ((long)b * V + vi) * 3;
-  g[0] = a0; g[1] = a1; g[2] = a2;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); }
+  if (lane == 0) {
+    float* g = gverts + ((long)b * V + vi) * 3;
+    g[0] = a0; g[1] = a1; g[2] = a2;
+  }
 }
 
 }  // namespace
@@ -872,7 +878,7 @@ int sln_project_faces_backward(const float* vertices, const int32_t* faces, cons
   const long n = (long)B * F * 3;
   if (n == 0) return 0;
   if (g_sln_deterministic)
-    hipLaunchKernelGGL(project_faces_bwd_det_kernel, dim3(sln_cdiv(V, 64), B), dim3(64), 0, st, vertices, faces, K, R, t, V, F, orig_size, eps,
+    hipLaunchKernelGGL(project_faces_bwd_det_kernel, dim3(V, B), dim3(64), 0, st, vertices, faces, K, R, t, V, F, orig_size, eps,
                        grad_faces_xyz, grad_vertices);
   else
   hipLaunchKernelGGL(project_faces_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, vertices, faces, K, R, t, V, F, n, orig_size,

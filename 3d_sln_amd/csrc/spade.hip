@@ -569,7 +569,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ acc) {
+// det (deterministic mode): block k of a sample STORES its sums to slot pair k + 1 of the sample's line (no atomics, at most
+// LN_ACC_STRIDE / 2 - 1 = 7 blocks per sample); ln_finalize_kernel adds the slots in order and leaves the total in slot 0.
+__global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __restrict__ acc, int det) {
   const int b = blockIdx.y;
   const float* xb = x + (size_t)b * n;
   double s = 0.0, q = 0.0;
@@ -585,13 +587,22 @@ __global__ void ln_stats_kernel(const float* __restrict__ x, long n, double* __r
     __syncthreads();
   }
   // one 128-byte line per sample: device atomics to the same line are serialised on the memory side
-  if (threadIdx.x == 0) { atomicAdd(acc + LN_ACC_STRIDE * b, rs[0]); atomicAdd(acc + LN_ACC_STRIDE * b + 1, rq[0]); }
+  if (threadIdx.x == 0) {
+    if (det) { acc[LN_ACC_STRIDE * b + 2 * (blockIdx.x + 1)] = rs[0]; acc[LN_ACC_STRIDE * b + 2 * (blockIdx.x + 1) + 1] = rq[0]; }
+    else { atomicAdd(acc + LN_ACC_STRIDE * b, rs[0]); atomicAdd(acc + LN_ACC_STRIDE * b + 1, rq[0]); }
+  }
 }
 // rep: every accumulated value stands for `rep` elements of the normalised tensor (4 when the tensor is the nearest x2
 // upsampling of what was summed: same mean, n -> 4 n in the unbiased variance)
-__global__ void ln_finalize_kernel(const double* __restrict__ acc, long n_acc, int rep, int B, float eps, float* __restrict__ stats) {
+// nslots > 0: the sums are the slot pairs 1 .. nslots of the sample's line, added here in order (and left in slot 0)
+__global__ void ln_finalize_kernel(double* __restrict__ acc, long n_acc, int rep, int B, float eps, float* __restrict__ stats, int nslots) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
+  if (nslots > 0) {
+    double s = 0.0, q = 0.0;
+    for (int k = 1; k <= nslots; ++k) { s += acc[LN_ACC_STRIDE * b + 2 * k]; q += acc[LN_ACC_STRIDE * b + 2 * k + 1]; }
+    acc[LN_ACC_STRIDE * b] = s; acc[LN_ACC_STRIDE * b + 1] = q;
+  }
   const double n = (double)n_acc * rep;
   const double mean = acc[LN_ACC_STRIDE * b] / (double)n_acc;
   double var = ((double)rep * acc[LN_ACC_STRIDE * b + 1] - n * mean * mean) / (n - 1.0);     // unbiased (torch.std default)
@@ -668,7 +679,10 @@ __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restri
 // instead of averaging it out.  tools/spade_error_budget.py: with this (and the blocked accumulation of the convolutions) the
 // full-size image is 5e-5 from an fp64 evaluation; with fp32 chains here it was 3e-4 whatever the convolutions did (torch's CPU
 // path, whose blocked dot products are short chains, 1.1e-4).  2 x C x C/8 fp64 FMAs per sample: nothing.
-// Wave-cooperative: a wavefront owns hidden rows r = wave, wave + 4, .. and strides its lanes over the C inputs (coalesced).
+// Both FCs read their weight rows with 16-byte loads that are contiguous across the lanes that share a row (a whole wavefront per
+// hidden row, 8 lanes per output row) and keep SEVERAL rows in flight (8 hidden rows / 4 output rows per lane group: their loads
+// and their shuffle trees are independent chains) - one block per sample is all the parallelism there is, so the kernel is a
+// latency chain per row otherwise.
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw,
                                                     const float* __restrict__ w0, const float* __restrict__ w2, int C, int Cr,
                                                     float* __restrict__ scale) {
@@ -677,18 +691,66 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ ga
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? gsum[(size_t)b * C + c] / hw : (double)gap[(size_t)b * C + c];
   __syncthreads();
-  for (int r = wave; r < Cr; r += 4) {
-    double s = 0.0;
-    for (int c = lane; c < C; c += 64) s = fma((double)w0[(size_t)r * C + c], g[c], s);
+  // hidden = relu(W0 g): a wavefront per row, lanes take 4 consecutive columns per step (C % 4 == 0: the callers require C % 8 == 0)
+  constexpr int RB = 8;
+  for (int r0 = wave * RB; r0 < Cr; r0 += 4 * RB) {
+    double s[RB];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) hdn[r] = s > 0.0 ? s : 0.0;
+    for (int k = 0; k < RB; ++k) s[k] = 0.0;
+    for (int c = 4 * lane; c < C; c += 256) {
+      float4 w[RB];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) w[k] = *reinterpret_cast<const float4*>(w0 + (size_t)min(r0 + k, Cr - 1) * C + c);
+      const double g0 = g[c], g1 = g[c + 1], g2 = g[c + 2], g3 = g[c + 3];
+#pragma unroll
+      for (int k = 0; k < RB; ++k) { s[k] = fma((double)w[k].x, g0, s[k]); s[k] = fma((double)w[k].y, g1, s[k]); s[k] = fma((double)w[k].z, g2, s[k]); s[k] = fma((double)w[k].w, g3, s[k]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < RB; ++k) s[k] += __shfl_xor(s[k], off);
+    if (lane < RB && r0 + lane < Cr) {
+      double v = s[0];
+#pragma unroll
+      for (int k = 1; k < RB; ++k) v = lane == k ? s[k] : v;
+      hdn[r0 + lane] = v > 0.0 ? v : 0.0;
+    }
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double s = 0.0;
-    for (int r = 0; r < Cr; ++r) s = fma((double)w2[(size_t)c * Cr + r], hdn[r], s);
-    scale[(size_t)b * C + c] = (float)(1.0 / (1.0 + exp(-s)));
+  // scale = sigmoid(W2 hidden): 8 lanes per output row, each a contiguous eighth of the row when that is whole float4s
+  const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  const bool vec = (Cr & 31) == 0;
+  const int seg = Cr >> 3;
+  constexpr int OB = 4;
+  for (int c0 = grp * OB; c0 < C; c0 += 32 * OB) {
+    double s[OB];
+#pragma unroll
+    for (int k = 0; k < OB; ++k) s[k] = 0.0;
+    if (vec) {
+      for (int q = 0; q < seg; q += 4) {
+        const int r = sub * seg + q;
+        float4 w[OB];
+#pragma unroll
+        for (int k = 0; k < OB; ++k) w[k] = *reinterpret_cast<const float4*>(w2 + (size_t)min(c0 + k, C - 1) * Cr + r);
+        const double h0 = hdn[r], h1 = hdn[r + 1], h2 = hdn[r + 2], h3 = hdn[r + 3];
+#pragma unroll
+        for (int k = 0; k < OB; ++k) { s[k] = fma((double)w[k].x, h0, s[k]); s[k] = fma((double)w[k].y, h1, s[k]); s[k] = fma((double)w[k].z, h2, s[k]); s[k] = fma((double)w[k].w, h3, s[k]); }
+      }
+    } else {
+      for (int r = sub; r < Cr; r += 8)
+#pragma unroll
+        for (int k = 0; k < OB; ++k) s[k] = fma((double)w2[(size_t)min(c0 + k, C - 1) * Cr + r], hdn[r], s[k]);
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1)
+#pragma unroll
+      for (int k = 0; k < OB; ++k) s[k] += __shfl_xor(s[k], off);
+    if (sub < OB && c0 + sub < C) {
+      double v = s[0];
+#pragma unroll
+      for (int k = 1; k < OB; ++k) v = sub == k ? s[k] : v;
+      scale[(size_t)b * C + c0 + sub] = (float)(1.0 / (1.0 + exp(-v)));
+    }
   }
 }
 __global__ void se_scale_add_kernel(const float* __restrict__ xs, const float* __restrict__ dx, const float* __restrict__ scale,
@@ -802,6 +864,10 @@ __global__ __launch_bounds__(256) void block_tail_kernel(const float* __restrict
 // tanh(conv5x5_zero_pad(leaky_0.2(x)))  (:1602-1603).  Cout is tiny (3): VALU FMAs.  A workgroup owns a 16x16 output
 // tile; per chunk of 8 input channels the zero-padded, LeakyReLU'ed (16+4)^2 halo goes to LDS once and is read 25x;
 // the weights are addressed with loop counters only, so hipcc fetches them through the scalar cache.
+// (Round 4, measured and dropped: a 16 x 64 tile with four pixels per thread - two ds_read_b128 of the halo per (channel, tap row)
+// instead of 25 ds_read_b32 per channel - with the weights through the scalar cache, 772 us per batch of 32, and with the
+// weights as LDS broadcasts, 834 us, against 626 us for this one-pixel-per-thread form: its eight small workgroups per CU hide
+// the halo fill and the scalar loads better than three large ones.)
 constexpr int IT = 16, IH = IT + 4, ICK = 8;
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__ x, int Cin, int H, int W,
@@ -966,7 +1032,7 @@ int sln_spade_modulate(const float* actv, int B, int Cin, int H, int W, const fl
 // each standing for `rep` elements of the normalised tensor)
 int sln_layernorm_finalize(const double* acc, int B, int64_t n_acc, int rep, float eps, float* stats, void* stream) {
   if (!acc || !stats || B <= 0 || n_acc < 1 || rep < 1 || n_acc * rep < 2) return SLN_E_BADARG;
-  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, acc, (long)n_acc, rep, B, eps, stats);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, const_cast<double*>(acc), (long)n_acc, rep, B, eps, stats, 0);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1002,7 +1068,7 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   if (up_mode < 0) hipLaunchKernelGGL(block_tail_kernel<0>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
   else if (up_mode == 0) hipLaunchKernelGGL(block_tail_kernel<1>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
   else hipLaunchKernelGGL(block_tail_kernel<2>, grid, dim3(256), 0, st, xs, dx, scale, C, H, W, xs_up, out, ac);
-  if (stats) hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, acc, n_out, stats_rep, B, eps, stats);
+  if (stats) hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, acc, n_out, stats_rep, B, eps, stats, 0);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1014,8 +1080,11 @@ int sln_layernorm_stats(const float* x, int B, int64_t n, float eps, double* scr
   const int e = sln_zero_async(scratch, sizeof(double) * LN_ACC_STRIDE * B, st);
   if (e != 0) return e;
   int gx = (int)((n + 256 * 16 - 1) / (256 * 16)); gx = gx > 128 ? 128 : (gx < 1 ? 1 : gx);
-  hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch);
-  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, 1, B, eps, stats);
+  // deterministic mode: at most 7 blocks per sample, each storing its sums to its own slot; the finalize adds them in order
+  const int det = g_sln_deterministic ? 1 : 0;
+  if (det && gx > LN_ACC_STRIDE / 2 - 1) gx = LN_ACC_STRIDE / 2 - 1;
+  hipLaunchKernelGGL(ln_stats_kernel, dim3(gx, B), dim3(256), 0, st, x, (long)n, scratch, det);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(sln_cdiv(B, 64)), dim3(64), 0, st, scratch, (long)n, 1, B, eps, stats, det ? gx : 0);
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -255,17 +255,25 @@ class SPADEGenerator4(nn.Module):
         L = _lib.lib()
         B = x.shape[0]
         H, W = seg.shape[2:]
+        # Deterministic mode (SLN_DETERMINISTIC / sln_set_deterministic): the sums that conv epilogues and the tail add with fp64
+        # atomics in arrival order are taken by fixed-order kernels instead (sln_layernorm_stats with one slot per block, the
+        # tree-reduced pool of sln_block_tail) - the reference's CPU path gives the same bits on every run, so does this one then.
+        det = bool(L.sln_get_deterministic())
         accs = torch.zeros(32 * B + B * blk.fout, dtype=torch.float64, device=x.device)
         ln_dx, ln_out, gap = accs[:16 * B], accs[16 * B:32 * B], accs[32 * B:]
         if blk.learned_shortcut:
             x_s, xs_up = self._conv(self._spade(e["norm_s"], x, stats_x, seg, False, x_up), e["conv_s"], blk.fout, 1), 0
         else:
             x_s, xs_up = x, 1 if x_up else 0
-        dx = self._conv(self._spade(e["norm_0"], x, stats_x, seg, True, x_up), e["conv_0"], blk.fmiddle, 3, ln_acc=ln_dx)
-        stats_dx = torch.empty(B, 2, device=x.device)
-        _lib.check(L.sln_layernorm_finalize(_lib.ptr(ln_dx), B, blk.fmiddle * H * W, 1, 1e-5, _lib.ptr(stats_dx), self._st()),
-                   "sln_layernorm_finalize")
-        dx = self._conv(self._spade(e["norm_1"], dx, stats_dx, seg, True), e["conv_1"], blk.fout, 3, gap_acc=gap)
+        dx = self._conv(self._spade(e["norm_0"], x, stats_x, seg, True, x_up), e["conv_0"], blk.fmiddle, 3, ln_acc=None if det else ln_dx)
+        if det:
+            stats_dx = self._ln_stats(dx)
+        else:
+            stats_dx = torch.empty(B, 2, device=x.device)
+            _lib.check(L.sln_layernorm_finalize(_lib.ptr(ln_dx), B, blk.fmiddle * H * W, 1, 1e-5, _lib.ptr(stats_dx), self._st()),
+                       "sln_layernorm_finalize")
+        dx = self._conv(self._spade(e["norm_1"], dx, stats_dx, seg, True), e["conv_1"], blk.fout, 3, gap_acc=None if det else gap)
+        gap_p = None if det else _lib.ptr(gap)
         up_mode = 1 if tail == 'bilinear' else -1
         k = 2 if tail == 'bilinear' else 1
         out = torch.empty(B, blk.fout, k * H, k * W, device=x.device)
@@ -273,13 +281,21 @@ class SPADEGenerator4(nn.Module):
         scratch = torch.empty(2 * B * blk.fout, device=x.device)
         if tap is not None:                       # the block's own output, when the caller asked for it and `out` is upsampled
             tap[name] = torch.empty(B, blk.fout, H, W, device=x.device)
-            _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, _lib.ptr(gap), _lib.ptr(e["se0"]),
+            _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, gap_p, _lib.ptr(e["se0"]),
                                         _lib.ptr(e["se2"]), _lib.ptr(scratch), -1, _lib.ptr(tap[name]), None, 1, 1e-5, None, self._st()),
                        "sln_block_tail(tap)")
-        _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, _lib.ptr(gap), _lib.ptr(e["se0"]),
-                                    _lib.ptr(e["se2"]), _lib.ptr(scratch), up_mode, _lib.ptr(out), _lib.ptr(ln_out),
-                                    4 if tail == 'nearest' else 1, 1e-5, _lib.ptr(stats) if want_stats else None, self._st()),
+        fused_stats = want_stats and not det
+        _lib.check(L.sln_block_tail(_lib.ptr(x_s), xs_up, _lib.ptr(dx), B, blk.fout, H, W, gap_p, _lib.ptr(e["se0"]),
+                                    _lib.ptr(e["se2"]), _lib.ptr(scratch), up_mode, _lib.ptr(out), _lib.ptr(ln_out) if fused_stats else None,
+                                    4 if tail == 'nearest' else 1, 1e-5, _lib.ptr(stats) if fused_stats else None, self._st()),
                    "sln_block_tail")
+        if want_stats and det:
+            scr = torch.empty(16 * B, dtype=torch.float64, device=x.device)
+            _lib.check(L.sln_layernorm_stats(_lib.ptr(out), B, out[0].numel(), 1e-5, _lib.ptr(scr), _lib.ptr(stats), self._st()),
+                       "sln_layernorm_stats")
+            if tail == 'nearest':                   # the consumers read `out` through nearest x2: statistics of THAT tensor
+                _lib.check(L.sln_layernorm_finalize(_lib.ptr(scr), B, out[0].numel(), 4, 1e-5, _lib.ptr(stats), self._st()),
+                           "sln_layernorm_finalize")
         return out, tail == 'nearest', stats
 
     def _block_unfused(self, name, x, seg):

@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "gemm_dual"]
 # rocprofv3 summaries, ONE PER LEG (tools/profile_round.sh r03): kernel-trace statistics of a run that executes that leg's
 # workload only, joined with the HBM traffic of two PMC passes of the same command (profiles/README.md)
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 
 
 def profile_csv(leg):
@@ -276,8 +276,10 @@ def vae_dropin_leg(args, torch, M, syn, fused_ms):
 
 def render_33pass_leg(args, torch, fused_ms_per_room):
     """mesh_render_func's own call pattern (diff_render.py:366,381-398): ONE room, 1 depth pass + 32 class passes through the
-    aliased nr.Renderer, forward + backward - what an unchanged diff_render.py gets.  The Renderer keeps the maps of identical
-    geometry between the passes (host/neural_renderer.py); `rasterising_each_pass` switches that off."""
+    aliased nr.Renderer, forward + backward - what an unchanged diff_render.py gets.  The Renderer shares the projection node and
+    the maps of identical geometry between the passes and back-propagates all rgb passes in one edge walk (host/neural_renderer.py);
+    `rasterising_each_pass` switches that off.  `callers_torch_algebra_only_ms` is the same loop with a stub Renderer: the floor
+    the reference's own per-class torch code sets, whatever the Renderer does."""
     DR = importlib.import_module("3d_sln_amd.host.diff_render")
     NR = importlib.import_module("3d_sln_amd.host.neural_renderer")
     syn = importlib.import_module("3d_sln_amd.host.synthetic")
@@ -304,7 +306,42 @@ def render_33pass_leg(args, torch, fused_ms_per_room):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / n * 1e3
         res[key] = {"ms_per_render": round(ms, 3), "renders_per_s": round(1e3 / ms, 1)}
-    NR.Renderer.reuse_rasterisation = keep
+    # What the 33 Renderer calls cost, and what the caller's own torch algebra around them costs (diff_render.py:381-431: per class a
+    # texture tensor, boolean-mask indexing, mean / max / isnan with their host syncs): the same loop with the Renderer replaced by a
+    # stub that hands back recorded images (attached to the vertices, so backward still walks the caller's graph).
+    NR.Renderer.reuse_rasterisation = True
+    recorded, real = {}, NR.Renderer.render
+
+    def rec(self, vertices, faces, textures=None, mode=None, *a, **k):
+        out = real(self, vertices, faces, textures, mode, *a, **k)
+        recorded.setdefault(mode, []).append(out.detach())
+        return out
+    counters = {}
+
+    def stub(self, vertices, faces, textures=None, mode=None, *a, **k):
+        i = counters.get(mode, 0); counters[mode] = i + 1
+        return recorded[mode][i % len(recorded[mode])] + 0.0 * vertices.sum()
+    try:
+        NR.Renderer.render = rec
+        DR.scene_render_passes(torch.from_numpy(V)[None].cuda().requires_grad_(True), f, ranges, room)
+        NR.Renderer.render = stub
+
+        def run_stub():
+            counters.clear()
+            v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+            DR.scene_render_passes(v, f, ranges, room).sum().backward()
+        for _ in range(3):
+            run_stub()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10):
+            run_stub()
+        torch.cuda.synchronize()
+        floor = (time.perf_counter() - t0) / 10 * 1e3
+    finally:
+        NR.Renderer.render = real
+        NR.Renderer.reuse_rasterisation = keep
+    res["callers_torch_algebra_only_ms"] = round(floor, 3)
+    res["renderer_share_ms"] = round(res["maps_reused"]["ms_per_render"] - floor, 3)
     res["ratio_33pass_to_fused_one_room"] = round(res["maps_reused"]["ms_per_render"] / res["fused_one_room"]["ms_per_render"], 1)
     return res
 

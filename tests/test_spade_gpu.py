@@ -407,3 +407,35 @@ def test_blocked_accumulation_of_long_chains_is_as_accurate_as_the_cpu_path(Cin,
     rms_cpu = float(((c32.double() - ref) ** 2).mean().sqrt()) / scale
     assert rms_hip <= 1.6 * rms_cpu + 1e-9, (rms_hip, rms_cpu)
     assert_close(y.cpu().numpy(), ref.numpy(), "blocked conv", rtol=2e-6, atol=1e-7)
+
+
+def test_deterministic_mode_makes_the_generator_bit_identical_run_to_run():
+    """The reference's CPU path (SPADE_related.py:128-149: LayerNorm2D sums, the SE pool) gives the same bits on every run; with
+    SLN_DETERMINISTIC / sln_set_deterministic the HIP generator does too - the statistics the fused schedule adds with fp64 atomics
+    in arrival order come from fixed-order kernels instead - and stays within rounding of the default mode."""
+    L = pkg("_lib"); S = pkg("host.SPADE_related")
+    cfg = spade_ref.SpadeConfig(ngf=16, nz=16, crop_size=128)
+    sd = spade_ref.init_state(cfg, seed=5)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, z = spade_ref.synth_input(cfg, 5, seed=4)
+    seg, z = seg.cuda(), z.cuda()
+    default = G(seg, z)
+    try:
+        L.lib().sln_set_deterministic(1)
+        runs = []
+        for _ in range(4):
+            taps = {}
+            out = G(seg, z, taps=taps)
+            runs.append((out.clone(), {k: v.clone() for k, v in taps.items()}))
+        shared = [G(seg[:1].contiguous(), z).clone() for _ in range(2)]          # one map, many z
+    finally:
+        L.lib().sln_set_deterministic(0)
+    for out, taps in runs[1:]:
+        assert torch.equal(out, runs[0][0])
+        for k in taps:
+            assert torch.equal(taps[k], runs[0][1][k]), k
+    assert torch.equal(shared[0], shared[1])
+    assert_close(runs[0][0].cpu().numpy(), default.cpu().numpy(), "deterministic vs default", rtol=1e-5, atol=2e-5)
+    ref = spade_ref.generator(sd, cfg, seg.cpu(), z.cpu())
+    assert_close(runs[0][0].cpu().numpy(), ref.numpy(), "deterministic vs oracle", rtol=1e-4, atol=1e-4)

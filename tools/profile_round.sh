@@ -11,7 +11,7 @@
 # and the kernel trace of the DEFAULT bench command (all legs)            -> <tag>_rocprofv3_kernel_stats_raw.csv
 # tools/summarize_profile.py / summarize_sq.py condense them into profiles/.
 set -u
-TAG=${1:-r03}; shift || true
+TAG=${1:-r04}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 P=/tmp/prof_$TAG          # raw rocprofv3 output stays on the box (tens of MB); only the summaries travel back

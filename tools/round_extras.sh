@@ -1,7 +1,7 @@
 #!/bin/bash
 # The two small text files of profiles/<tag>_*: cost of SLN_DETERMINISTIC=1 and the data-parallel code path on one GPU.
 #   tools/round_extras.sh r03        (GPU box, repository root)
-TAG=${1:-r03}
+TAG=${1:-r04}
 V="--no-render --no-spade --no-graph-build --no-refine --no-cpu --no-dropin --large-batches= --steps 200 --warmup 20"
 R="--no-spade --no-graph-build --no-refine --no-cpu --no-check --no-dropin --large-batches= --steps 3 --warmup 2 --prof-steps 0"
 pick_vae='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d["kernels"]; print("%-18s %.4f  %s   gemm_tn %.3f ms per step (%d launches)" % (sys.argv[1], d["ms_per_step"], d["ms_per_step_p10_p50_p90"], k["gemm_tn"]["ms_per_step"], k["gemm_tn"]["launches_per_step"]))'
@@ -14,7 +14,11 @@ pick_rnd='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1
   echo "# fused scene pass, 16 rooms x 2k triangles x 256^2, forward + backward, ms per batch [p10, p50, p90]"
   python bench.py $R 2>/dev/null | python -c "$pick_rnd" default
   SLN_DETERMINISTIC=1 python bench.py $R 2>/dev/null | python -c "$pick_rnd" SLN_DETERMINISTIC
+  echo "# SPADEGenerator4, batch 32, 256x256, ms per batch (tools/spade_time.py; deterministic: LayerNorm / pooling sums by fixed-order kernels)"
+  python tools/spade_time.py 6 2>/dev/null | grep "ms per batch"
+  SLN_DETERMINISTIC=1 python tools/spade_time.py 6 2>/dev/null | grep "ms per batch"
   echo "# bit-identity: tests/test_train_gpu.py::test_deterministic_mode_makes_fused_steps_bit_identical[feedforward|recurrent],"
+  echo "#               tests/test_spade_gpu.py::test_deterministic_mode_makes_the_generator_bit_identical_run_to_run,"
   echo "#               tests/test_raster_gpu.py::test_deterministic_mode_makes_the_scene_pass_bit_identical[1|9],"
   echo "#               tests/test_train_gpu.py::test_eager_steps_on_batches_of_changing_shape_need_no_host_sync"
 } > profiles/${TAG}_deterministic.txt
