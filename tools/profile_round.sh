@@ -28,10 +28,10 @@ SHORT[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-step
 flatten() { for g in $(find "$1" -name '*.csv'); do mv "$g" "$1/" 2>/dev/null; done; }
 for leg in vae render spade; do
   D="$P/$leg"; mkdir -p "$D"
-  rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[$leg]} > "$D/bench.json" 2> "$D/trace.err"
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/fetch.err"
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/write.err"
-  rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[$leg]} > "$D/bench.json" 2> "$D/trace.err"
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/fetch" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/fetch.err"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/write" -o vae -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/write.err"
+  timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
     --output-format csv -d "$D/sq" -o sq -- python bench.py ${SHORT[$leg]} > /dev/null 2> "$D/sq.err"
   for d in trace fetch write sq; do flatten "$D/$d"; done
   cp "$D/trace/vae_kernel_stats.csv" "profiles/${TAG}_${leg}_rocprofv3_kernel_stats_raw.csv"
@@ -40,12 +40,12 @@ for leg in vae render spade; do
 done
 # render, one stream
 D="$P/render_noside"; mkdir -p "$D"
-SLN_SCENE_NO_SIDE=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[render]} > "$D/bench.json" 2> "$D/trace.err"
+SLN_SCENE_NO_SIDE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py ${FLAGS[render]} > "$D/bench.json" 2> "$D/trace.err"
 flatten "$D/trace"
 python tools/summarize_profile.py "$D" "profiles/${TAG}_render_noside"
 # the default command, all legs
 D="$P/all"; mkdir -p "$D"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py --no-cpu "$@" > "$D/bench.json" 2> "$D/trace.err"
+timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py --no-cpu "$@" > "$D/bench.json" 2> "$D/trace.err"
 flatten "$D/trace"
 cp "$D/trace/vae_kernel_stats.csv" "profiles/${TAG}_rocprofv3_kernel_stats_raw.csv"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
