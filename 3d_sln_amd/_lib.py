@@ -12,7 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsln_hip.so")
 
-SLN_E = {-1: "SLN_E_BADARG", -2: "SLN_E_UNSUPPORTED", -3: "SLN_E_STATE", -4: "SLN_E_NOGPU"}
+SLN_E = {-1: "SLN_E_BADARG", -2: "SLN_E_UNSUPPORTED", -3: "SLN_E_STATE", -4: "SLN_E_NOGPU", -5: "SLN_E_NOMEM", -6: "SLN_E_CAPTURE"}
 
 c_f32p = C.c_void_p
 c_i64p = C.c_void_p

@@ -179,7 +179,7 @@ struct SlnVae {
   // stream-ordered host -> device copy of up to two pieces through the next ring slot (slot capacity: a wgrad table)
   int stage_upload(void* dev0, const void* src0, size_t n0, void* dev1, const void* src1, size_t n1, hipStream_t st) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return SLN_E_STATE;   // a caller's capture would record a copy out of a ring slot
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return SLN_E_CAPTURE;   // a caller's capture would record a copy out of a ring slot
     const size_t cap0 = sizeof(GemmTNArgs) * (size_t)SLN_TN_MULTI_MAX, cap = cap0 + sizeof(TnMultiMeta);
     if (n0 > cap0 || n1 > cap - cap0) return SLN_E_BADARG;
     TnStage& sl = tn_stage[tn_stage_next];
@@ -187,9 +187,9 @@ struct SlnVae {
     hipError_t e = hipSuccess;
     if (!sl.host) {
       void* hp = nullptr;
-      if (hipHostMalloc(&hp, cap, hipHostMallocDefault) != hipSuccess) return SLN_E_BADARG;
+      if (hipHostMalloc(&hp, cap, hipHostMallocDefault) != hipSuccess) return SLN_E_NOMEM;
       sl.host = static_cast<char*>(hp);
-      if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(hp); sl.host = nullptr; return SLN_E_BADARG; }
+      if (hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { (void)hipHostFree(hp); sl.host = nullptr; return SLN_E_NOMEM; }
     } else {
       e = hipEventSynchronize(sl.done);
     }
@@ -223,9 +223,19 @@ struct SlnVae {
     tn_side_busy = false;
     return (int)r;
   }
+  hipStream_t tn_eager_stream = nullptr;         // the stream whose launches read the eager table set (set 1) last
   int flush_deferred(int which, hipStream_t st) {
     if (deferred.empty()) return 0;
     const int set = capturing ? 0 : 1;
+    if (set == 1 && tn_eager_stream != st) {
+      // eager steps alternating between two caller streams on ONE engine: an upload on the new stream must not overtake the
+      // launches of the old one that still read the tables (uploads are ordered per stream only).  Rare: drain the old stream.
+      if (tn_eager_stream != nullptr) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(tn_eager_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(tn_eager_stream);
+      }
+      tn_eager_stream = st;
+    }
     hipStream_t lst = st;
     if (tn_side && side) {
       hipEvent_t e = next_event();

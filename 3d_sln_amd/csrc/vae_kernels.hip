@@ -135,7 +135,10 @@ __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<flo
 // (tab[q * XT + x], one ds_read_b128) is 16 bytes from its neighbour's - conflict-free.  In column order (tab[4 x + q]) the lanes
 // of a read were 64 bytes apart and touched 16 of the 64 banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.80 in the forward
 // scatter, which re-reads its two tables for every entry of a row (profiles/r03_vae_sq_stalls.csv).
-#define SLN_CTAB(j) ((((j) & 3) * XT) + ((j) >> 2))
+// rows of XT + 4 entries: the FILL (lane j -> row j & 3, entry j >> 2) then spreads every 16 consecutive lanes over the 16
+// 16-byte bank groups as well (rows of XT entries put its four rows on the same banks: a 4-way conflict on each table write)
+#define SLN_CTAB_ROW (XT + 4)
+#define SLN_CTAB(j) ((((j) & 3) * SLN_CTAB_ROW) + ((j) >> 2))
 template <int XT, int YT>
 __device__ __forceinline__ void fill_coef_table(float4* tab, const BnView& bn, int c0, int ncols, int coloff) {
   const int tid = threadIdx.y * XT + threadIdx.x;
@@ -189,19 +192,21 @@ __device__ __forceinline__ void cache_entries(int (*ents)[ESTRIDE], const GraphC
 }
 // the two coefficient tables of the forward scatter (columns c0.. of the subject half and of the object half)
 template <int XT, int YT>
-__device__ __forceinline__ void fill_coef_table2(float4* ta, float4* tb, const BnView& bn, int c0, int ncols, int coloff_b) {
+// (scale, shift) only, 8 bytes per column: the forward scatter uses nothing else, and reading half of a 16-byte entry leaves
+// the lanes of its ds_read_b64 16 bytes apart - every second bank pair idle, SQ_LDS_BANK_CONFLICT share 0.41)
+__device__ __forceinline__ void fill_coef_table2(float2* ta, float2* tb, const BnView& bn, int c0, int ncols, int coloff_b) {
   const int tid = threadIdx.y * XT + threadIdx.x;
   for (int j = tid; j < 4 * XT; j += XT * YT) {
     float4 va = make_float4(1.f, 0.f, 0.f, 1.f), vb = va;
     if (c0 + j < ncols) bn_fwd_coef4x2(bn, c0 + j, coloff_b + c0 + j, va, vb);
-    ta[SLN_CTAB(j)] = va; tb[SLN_CTAB(j)] = vb;
+    ta[SLN_CTAB(j)] = make_float2(va.x, va.y); tb[SLN_CTAB(j)] = make_float2(vb.x, vb.y);
   }
 }
 
 template <int XT, int YT>
 __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float* __restrict__ A2, int ld, int H, int D, BnView bn,
                                                                     GraphCsr g, int O, int T, float* __restrict__ pooled) {
-  __shared__ float4 cs[4 * XT], co[4 * XT];
+  __shared__ float2 cs[4 * SLN_CTAB_ROW], co[4 * SLN_CTAB_ROW];
   __shared__ int ents[YT][ESTRIDE];
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
@@ -212,7 +217,7 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
   const int c = c0 + 4 * threadIdx.x;
   if (c >= H || i >= O) return;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4* ks = cs + threadIdx.x; const float4* ko = co + threadIdx.x;      // planar: column q at [q * XT]
+  const float2* ks = cs + threadIdx.x; const float2* ko = co + threadIdx.x;      // planar: column q at [q * SLN_CTAB_ROW]
   const int deg = e - b;
   for (int k = 0; k < deg; k += EB) {
     int en[EB]; float4 x[EB];
@@ -233,9 +238,9 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
 #pragma unroll
     for (int u = 0; u < EB; ++u) {
       if (k + u < deg) {                     // same accumulation order as the scalar kernel / the reference scatter_add
-        const float4* kk = en[u] >= T ? ko : ks;
-        acc.x += fmaxf(fmaf(kk[0].x, x[u].x, kk[0].y), 0.f); acc.y += fmaxf(fmaf(kk[1 * XT].x, x[u].y, kk[1 * XT].y), 0.f);
-        acc.z += fmaxf(fmaf(kk[2 * XT].x, x[u].z, kk[2 * XT].y), 0.f); acc.w += fmaxf(fmaf(kk[3 * XT].x, x[u].w, kk[3 * XT].y), 0.f);
+        const float2* kk = en[u] >= T ? ko : ks;
+        acc.x += fmaxf(fmaf(kk[0].x, x[u].x, kk[0].y), 0.f); acc.y += fmaxf(fmaf(kk[1 * SLN_CTAB_ROW].x, x[u].y, kk[1 * SLN_CTAB_ROW].y), 0.f);
+        acc.z += fmaxf(fmaf(kk[2 * SLN_CTAB_ROW].x, x[u].z, kk[2 * SLN_CTAB_ROW].y), 0.f); acc.w += fmaxf(fmaf(kk[3 * SLN_CTAB_ROW].x, x[u].w, kk[3 * SLN_CTAB_ROW].y), 0.f);
       }
     }
   }
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
                                                                     int dpcol0, const float* __restrict__ A2, int ld, int H, int D,
                                                                     BnView bn, GraphCsr g, int T, float* __restrict__ g2,
                                                                     double* gsums, int cstride) {
-  __shared__ float4 cf[4 * XT];
+  __shared__ float4 cf[4 * SLN_CTAB_ROW];
   const int C = 2 * H + D;
   const int c0 = blockIdx.x * 4 * XT;
   fill_coef_table<XT, YT>(cf, bn, c0, C, 0);
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
   const int c = c0 + 4 * threadIdx.x;
   const bool cv = c < C;
   const int part = c < H ? 0 : (c < H + D ? 1 : 2);
-  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * XT]
+  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * SLN_CTAB_ROW]
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (cv) {
    for (int it = 0; it < NIT; ++it) {
@@ -289,12 +294,12 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
     for (int r = 0; r < RPT; ++r) {
       if (t0 + r < T) {
         float4 gv;
-        gv.x = fmaf(kk[0].x, x[r].x, kk[0].y) > 0.f ? d[r].x * w[r] : 0.f; gv.y = fmaf(kk[1 * XT].x, x[r].y, kk[1 * XT].y) > 0.f ? d[r].y * w[r] : 0.f;
-        gv.z = fmaf(kk[2 * XT].x, x[r].z, kk[2 * XT].y) > 0.f ? d[r].z * w[r] : 0.f; gv.w = fmaf(kk[3 * XT].x, x[r].w, kk[3 * XT].y) > 0.f ? d[r].w * w[r] : 0.f;
+        gv.x = fmaf(kk[0].x, x[r].x, kk[0].y) > 0.f ? d[r].x * w[r] : 0.f; gv.y = fmaf(kk[1 * SLN_CTAB_ROW].x, x[r].y, kk[1 * SLN_CTAB_ROW].y) > 0.f ? d[r].y * w[r] : 0.f;
+        gv.z = fmaf(kk[2 * SLN_CTAB_ROW].x, x[r].z, kk[2 * SLN_CTAB_ROW].y) > 0.f ? d[r].z * w[r] : 0.f; gv.w = fmaf(kk[3 * SLN_CTAB_ROW].x, x[r].w, kk[3 * SLN_CTAB_ROW].y) > 0.f ? d[r].w * w[r] : 0.f;
         st4g(g2 + (size_t)(t0 + r) * ld + c, gv);
         s1.x += gv.x; s1.y += gv.y; s1.z += gv.z; s1.w += gv.w;
-        s2.x = fmaf(gv.x, (x[r].x - kk[0].z) * kk[0].w, s2.x); s2.y = fmaf(gv.y, (x[r].y - kk[1 * XT].z) * kk[1 * XT].w, s2.y);
-        s2.z = fmaf(gv.z, (x[r].z - kk[2 * XT].z) * kk[2 * XT].w, s2.z); s2.w = fmaf(gv.w, (x[r].w - kk[3 * XT].z) * kk[3 * XT].w, s2.w);
+        s2.x = fmaf(gv.x, (x[r].x - kk[0].z) * kk[0].w, s2.x); s2.y = fmaf(gv.y, (x[r].y - kk[1 * SLN_CTAB_ROW].z) * kk[1 * SLN_CTAB_ROW].w, s2.y);
+        s2.z = fmaf(gv.z, (x[r].z - kk[2 * SLN_CTAB_ROW].z) * kk[2 * SLN_CTAB_ROW].w, s2.z); s2.w = fmaf(gv.w, (x[r].w - kk[3 * SLN_CTAB_ROW].z) * kk[3 * SLN_CTAB_ROW].w, s2.w);
       }
     }
    }
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
                                                                const float* __restrict__ add1, int ldadd1,
                                                                const float* __restrict__ xprev, int ldx, BnView bn, int masked,
                                                                float* __restrict__ out, int ldo, double* gsums, int cstride) {
-  __shared__ float4 cf[4 * XT];
+  __shared__ float4 cf[4 * SLN_CTAB_ROW];
   __shared__ int ents[YT][ESTRIDE];
   const int c0 = blockIdx.x * 4 * XT;
   const int i = blockIdx.y * YT + threadIdx.y;
@@ -317,7 +322,7 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
   cache_entries<XT, YT>(ents, g, b, e);
   const int c = c0 + 4 * threadIdx.x;
   const bool cv = c < D && i < O;
-  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * XT]
+  const float4* kk = cf + threadIdx.x;                 // planar: column q at [q * SLN_CTAB_ROW]
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
   if (cv) {
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -345,11 +350,11 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
     }
     if (add1) { d.x += ad.x; d.y += ad.y; d.z += ad.z; d.w += ad.w; }
     if (masked) {
-      d.x = fmaf(kk[0].x, xp.x, kk[0].y) > 0.f ? d.x : 0.f; d.y = fmaf(kk[1 * XT].x, xp.y, kk[1 * XT].y) > 0.f ? d.y : 0.f;
-      d.z = fmaf(kk[2 * XT].x, xp.z, kk[2 * XT].y) > 0.f ? d.z : 0.f; d.w = fmaf(kk[3 * XT].x, xp.w, kk[3 * XT].y) > 0.f ? d.w : 0.f;
+      d.x = fmaf(kk[0].x, xp.x, kk[0].y) > 0.f ? d.x : 0.f; d.y = fmaf(kk[1 * SLN_CTAB_ROW].x, xp.y, kk[1 * SLN_CTAB_ROW].y) > 0.f ? d.y : 0.f;
+      d.z = fmaf(kk[2 * SLN_CTAB_ROW].x, xp.z, kk[2 * SLN_CTAB_ROW].y) > 0.f ? d.z : 0.f; d.w = fmaf(kk[3 * SLN_CTAB_ROW].x, xp.w, kk[3 * SLN_CTAB_ROW].y) > 0.f ? d.w : 0.f;
       s1 = d;
-      s2.x = d.x * ((xp.x - kk[0].z) * kk[0].w); s2.y = d.y * ((xp.y - kk[1 * XT].z) * kk[1 * XT].w);
-      s2.z = d.z * ((xp.z - kk[2 * XT].z) * kk[2 * XT].w); s2.w = d.w * ((xp.w - kk[3 * XT].z) * kk[3 * XT].w);
+      s2.x = d.x * ((xp.x - kk[0].z) * kk[0].w); s2.y = d.y * ((xp.y - kk[1 * SLN_CTAB_ROW].z) * kk[1 * SLN_CTAB_ROW].w);
+      s2.z = d.z * ((xp.z - kk[2 * SLN_CTAB_ROW].z) * kk[2 * SLN_CTAB_ROW].w); s2.w = d.w * ((xp.w - kk[3 * SLN_CTAB_ROW].z) * kk[3 * SLN_CTAB_ROW].w);
     }
     st4g(out + (size_t)i * ldo + c, d);
   }

@@ -9,6 +9,7 @@ unchanged; ``forward`` runs on libsln_hip.so (csrc/spade.hip).  Weights are fold
 into the kernels' layout once per parameter version.
 """
 import ctypes as C
+import os
 import re
 
 import torch
@@ -123,6 +124,12 @@ class SPADEGenerator4(nn.Module):
         """Drop the gamma|beta planes kept for the last semantic map (about 0.2 GB at 256x256)."""
         self._map_memo = None
 
+    def __getstate__(self):
+        """copy.deepcopy / pickling: the packed weights, the kept planes and the pinned input tensor are caches, not state."""
+        st = self.__dict__.copy()
+        st["_map_memo"] = st["_packed"] = st["_packed_key"] = st["_cat_cache"] = None
+        return st
+
     def _pack_all(self):
         sd = {k: v.detach().float() for k, v in self.state_dict().items()}
         key = tuple((v.data_ptr(), v._version) for v in self.state_dict().values())
@@ -152,6 +159,7 @@ class SPADEGenerator4(nn.Module):
                               wgb=wgb, bgb=bgb, rpg=rpg)
             e["se0"], e["se2"] = sd[name + ".se.fc.0.weight"].contiguous(), sd[name + ".se.fc.2.weight"].contiguous()
             P[name] = e
+        self._map_memo = None            # planes computed with the old weights
         P["fc_w"], P["fc_b"] = sd["fc.weight"].contiguous(), sd["fc.bias"].contiguous()
         P["img_w"], P["img_b"] = sd["conv_img.weight"].contiguous(), sd["conv_img.bias"].contiguous()
         self._packed, self._packed_key = P, key
@@ -350,12 +358,26 @@ class SPADEGenerator4(nn.Module):
             # same input tensor (same object, unmodified: data pointer, shape and version counter; same packed parameters; same
             # stream) the planes are computed once, kept, and the later calls run only the per-sample part.  (The first call of a
             # map takes the fused path, which never materialises them: single calls on ever-new maps pay nothing.)
+            # CONTRACT of the kept planes: "the same map" means the same tensor object whose version counter did not move.  Writes
+            # that do not bump the counter (a raw kernel through data_ptr(), `input.data.copy_`, a DLPack / numpy alias) are NOT
+            # seen: call clear_map_cache() after such a write, or set reuse_map_planes = False.  SLN_SPADE_MEMO_CHECK=1 compares
+            # a checksum of the map on every call (one reduction) and raises on a silent change.  The planes (and the input they
+            # belong to) are released by the next call on another map, by any batched call, by a repack of the weights and by
+            # clear_map_cache(); a copy / pickle of the module does not carry them.
             mkey = (input.data_ptr(), input._version, tuple(input.shape), input.dtype, self._pack_gen,
                     int(torch.cuda.current_stream().cuda_stream))
+            if seg.shape[0] != 1:
+                self._map_memo = None
             memo = getattr(self, "_map_memo", None)
             self._map_repeat = bool(self.reuse_map_planes and seg.shape[0] == 1 and memo is not None and memo["key"] == mkey)
+            check = os.environ.get("SLN_SPADE_MEMO_CHECK") == "1" and seg.shape[0] == 1
+            csum = float(seg.double().sum().item()) if check else None
+            if self._map_repeat and check and memo.get("csum") != csum:
+                raise _lib.SlnError("SPADEGenerator4: the semantic map changed without its version counter moving (kept gamma|beta "
+                                    "planes would be stale): call clear_map_cache() after writing through data_ptr() / .data")
             if not self._map_repeat:
-                self._map_memo = dict(key=mkey, gb={}, keep=input if seg.shape[0] == 1 and self.reuse_map_planes else None)
+                self._map_memo = dict(key=mkey, gb={}, csum=csum,
+                                      keep=input if seg.shape[0] == 1 and self.reuse_map_planes else None) if seg.shape[0] == 1 else None
             self._cat_cache = {}                                      # per-forward: keyed by the pyramid level's storage
             nfc = 16 * self.nf * self.sw * self.sh
             x = torch.empty(B, nfc, device=seg.device)

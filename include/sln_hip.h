@@ -29,6 +29,8 @@ extern "C" {
 #define SLN_E_UNSUPPORTED (-2) /* configuration outside the HIP path (e.g. gconv_num_layers == 0) */
 #define SLN_E_STATE (-3)       /* call order violated (e.g. backward before forward)             */
 #define SLN_E_NOGPU (-4)       /* no gfx950 device visible                                       */
+#define SLN_E_NOMEM (-5)       /* a host staging buffer / event could not be allocated           */
+#define SLN_E_CAPTURE (-6)     /* the caller's stream is being captured and the call needs an eager upload (new batch shape) */
 
 int sln_version(void);                 /* ABI version, bumped on any signature change */
 const char* sln_build_arch(void);      /* "gfx950" */
