@@ -230,11 +230,15 @@ struct SlnVae {
     if (set == 1 && tn_eager_stream != st) {
       // eager steps alternating between two caller streams on ONE engine: an upload on the new stream must not overtake the
       // launches of the old one that still read the tables (uploads are ordered per stream only).  Rare: drain the old stream.
-      if (tn_eager_stream != nullptr) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(tn_eager_stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) (void)hipStreamSynchronize(tn_eager_stream);
+      // (not while the CALLER captures `st` - torch.cuda.graph around an eager-mode call: a synchronisation would invalidate the
+      // capture, and such a call cannot upload anyway: its tables were made resident by the warm-up run the capture follows)
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone, cs_old = hipStreamCaptureStatusNone;
+      const bool st_capt = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+      if (!st_capt) {
+        if (tn_eager_stream != nullptr && hipStreamIsCapturing(tn_eager_stream, &cs_old) == hipSuccess && cs_old == hipStreamCaptureStatusNone)
+          (void)hipStreamSynchronize(tn_eager_stream);
+        tn_eager_stream = st;
       }
-      tn_eager_stream = st;
     }
     hipStream_t lst = st;
     if (tn_side && side) {
