@@ -1069,6 +1069,10 @@ def main():
                              "launches_per_step": fam[k]["launches"] // args.prof_steps,
                              "flop_per_launch": round(fam[k]["work"] / fam[k]["launches"], 1),
                              "avg_launch_us": round(fam[k]["ms"] / fam[k]["launches"] * 1e3, 2), "rocprof_avg_launch_us": us_k}
+            # the same fraction from the two clocks: `frac_event` = HIP events around every eager launch of this run (includes the
+            # gap to the previous launch), `frac_rocprof` = the kernel durations of the committed trace of the same command
+            per_family[k]["frac_event"] = per_family[k]["frac"]
+            per_family[k]["frac_rocprof"] = round(fam[k]["work"] / fam[k]["launches"] / (us_k * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if us_k else None
         per_family["gemm_nt"]["what"] = "forward Linears and dgrads, one launch each (64x64 tiles of 32x32x2 MFMAs, 64x96 / 64x160 tiles of 16x16x4 MFMAs for N = 384 / 640, 32x32 split-K tiles for the object side)"
         if "gemm_tn" in per_family:
             per_family["gemm_tn"]["what"] = "every wgrad of a backward pass in one multi-problem launch (two per pass: gathered / plain rows)"
@@ -1081,6 +1085,9 @@ def main():
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
                            "avg_launch_us": round(fam[dom]["ms"] / fam[dom]["launches"] * 1e3, 2), "rocprof_avg_launch_us": prof_us,
+                           "frac_event": per_family[dom]["frac_event"], "frac_rocprof": per_family[dom]["frac_rocprof"],
+                           "frac_note": "frac = frac_event (HIP events around the eager launches of this run, gaps included); frac_rocprof "
+                                        "divides the same flops by the kernel durations of profiles/%s_vae_kernel_stats.csv" % PROFILE_TAG,
                            "traffic_source": (os.path.relpath(profile_csv("vae"), ROOT) + " (bytes per launch)") if traffic else None,
                            "algorithmic_bytes_per_launch": int(shp["nt_bytes_step"] / max(nt_launches, 1)) if dom != "gemm_tn"
                            else per_family["gemm_tn"]["algorithmic_bytes_per_launch"],
