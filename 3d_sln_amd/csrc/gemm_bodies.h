@@ -926,8 +926,11 @@ inline int nt16_pick(const GemmNTArgs& a) {
 // K = 256 whatever the tile shape.  Here a workgroup owns a 32 x 32 tile (4x the workgroups: every CU gets one), wave w takes the
 // k-tiles w, w + 4, ... through its OWN LDS tiles (no workgroup barrier in the loop; the LDS queue of a wave is in order), the
 // four partial accumulators meet in LDS once, and every wave finishes 8 of the 32 rows (bias / mask / statistics / store).
-// Single-segment operands only (the gathered concat input stays with gemm_nt_body).
-template <int AMODE, int EPI, bool HELP = false>             // HELP: 512 threads, wavefronts 4 .. 7 build the coefficient tables (see gemm_nt_body)
+// NSEG = 1: single-segment operands.  NSEG = 3 (round 4): the gathered concat [obj[s] | pred | obj[o]] of a GraphTripleConv's first
+// Linear with tile-aligned segments - for graphs of a few rows only (the refinement loop's 13-object room, BASELINE config c1):
+// there the 64 x 64 body is 4 workgroups walking 12 k-tiles each (14.8 us per launch, the slowest kernel of a refinement
+// iteration's decoder); at 64 graphs the 64 x 64 body stays (measured in round 2: 2.54 -> 2.57 ms per step with this one).
+template <int AMODE, int EPI, bool HELP = false, int NSEG = 1>   // HELP: 512 threads, wavefronts 4 .. 7 build the coefficient tables (see gemm_nt_body)
 __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const int bid, char* smem, const bool small_xcd = true) {
   constexpr bool HAS_X2 = AMODE == 1;
   constexpr bool IDENT = AMODE == 2;
@@ -945,7 +948,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
       const int tiles_n = (a.N + TS - 1) / TS;
       n0 = ((small_xcd ? xcd_remap(bid, ((a.M + TS - 1) / TS) * tiles_n) : bid) % tiles_n) * TS;
     }
-    nt_helper_tables<1, IDENT, EPI, TS>(a, coef, ecoef, tid - 256, 256, kpad, n0);
+    nt_helper_tables<NSEG, IDENT, EPI, TS>(a, coef, ecoef, tid - 256, 256, kpad, n0);
     __syncthreads();
     return;
   }
@@ -958,32 +961,45 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   float* Bs = As + TS * LDT;
 
   const int kq = lane & 7, r0 = lane >> 3;                  // float4 column, first of this lane's 4 rows (stride 8)
-  const Seg& sg = a.A.seg[0];
-  int rid[4];
+  // segment of a k-tile (NSEG = 3: every segment is a whole number of tiles, checked by nt_wants_small): first column of the tile
+  // inside its segment, and the segment itself - wave-uniform
+  const int e0 = NSEG > 1 ? a.A.seg[0].len : 0, e1 = NSEG > 1 ? e0 + a.A.seg[1].len : 0;
+  int rid[NSEG][4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const int row = min(m0 + r0 + 8 * p, a.M - 1);
-    rid[p] = sg.which == 0 ? row : (sg.which == 1 ? a.A.idx_a[row] : a.A.idx_b[row]);
+  for (int sgi = 0; sgi < NSEG; ++sgi) {
+    const int which = a.A.seg[sgi].which;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = min(m0 + r0 + 8 * p, a.M - 1);
+      rid[sgi][p] = which == 0 ? row : (which == 1 ? a.A.idx_a[row] : a.A.idx_b[row]);
+    }
   }
   const int ntiles = kpad / BK;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 ga1[4], ga2[4], gb[4];
-  const float* x2p = sg.x2 ? sg.x2 : sg.x1;
-  const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
   auto gload = [&](int kt) {                               // kt clamped by the caller; everything unconditional
-    const int cs = min(kt * BK + 4 * kq, sg.len - 4);
+    const int k0 = kt * BK;
+    const int si = NSEG > 1 ? (k0 >= e1 ? 2 : (k0 >= e0 ? 1 : 0)) : 0;
+    const Seg& sg = a.A.seg[si];
+    const int cs = min(k0 - (si == 2 ? e1 : (si == 1 ? e0 : 0)) + 4 * kq, sg.len - 4);
+    const float* x2p = sg.x2 ? sg.x2 : sg.x1;
+    const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      ga1[p] = ld4(sg.x1 + (size_t)rid[p] * sg.ld1 + sg.c1 + cs);
-      if (HAS_X2) ga2[p] = ld4(x2p + (size_t)rid[p] * ld2 + c2 + cs);
+      const int rr = NSEG > 1 ? (si == 2 ? rid[NSEG - 1][p] : (si == 1 ? rid[NSEG > 1 ? 1 : 0][p] : rid[0][p])) : rid[0][p];
+      ga1[p] = ld4(sg.x1 + (size_t)rr * sg.ld1 + sg.c1 + cs);
+      if (HAS_X2) ga2[p] = ld4(x2p + (size_t)rr * ld2 + c2 + cs);
     }
-    const int cw = min(kt * BK + 4 * kq, a.K - 4);
+    const int cw = min(k0 + 4 * kq, a.K - 4);
 #pragma unroll
     for (int p = 0; p < 4; ++p) gb[p] = ld4(a.W + (size_t)min(n0 + r0 + 8 * p, a.N - 1) * a.ldw + cw);
   };
   auto lstore = [&](int kt) {
     const int col = kt * BK + 4 * kq;
-    const bool cv = col < sg.len, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
+    const int k0 = kt * BK;
+    const int si = NSEG > 1 ? (k0 >= e1 ? 2 : (k0 >= e0 ? 1 : 0)) : 0;
+    const Seg& sg = a.A.seg[si];
+    const bool cv = NSEG > 1 ? col < a.K : col < sg.len, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
     const float4* cf = coef + min(col, kpad - 4);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -1002,7 +1018,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   if (wave < ntiles) gload(wave);                           // first tile of this wave, issued before the coefficient set-up
   if (!HELP) {
     if (!IDENT) {
-      sln_fill_coefs<1>(a.A, coef, tid, 256);
+      sln_fill_coefs<NSEG>(a.A, coef, tid, 256);
       for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
     }
     if (EPI == EPI_MASK) {
@@ -1108,6 +1124,15 @@ inline size_t nt_small_smem_bytes(int K) {
 inline bool nt_wants_small(const GemmNTArgs& a) {
   static const int max_tiles = std::getenv("SLN_NT_SMALL_TILES") ? std::atoi(std::getenv("SLN_NT_SMALL_TILES")) : 160;
   return a.A.nseg == 1 && (long)sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64) <= max_tiles && a.K <= 2048;
+}
+// ... and the three-segment gathered operand of graphs of a few rows (see gemm_nt_small_body, NSEG = 3): at most 64 rows, every
+// segment a whole number of k-tiles, the segments filling K exactly
+inline bool nt_wants_small3(const GemmNTArgs& a) {
+  static const int max_rows = std::getenv("SLN_NT_SMALL3_ROWS") ? std::atoi(std::getenv("SLN_NT_SMALL3_ROWS")) : 64;
+  if (a.A.nseg != 3 || a.M > max_rows || a.K > 2048) return false;
+  int tot = 0;
+  for (int s = 0; s < 3; ++s) { if (a.A.seg[s].len % BK != 0 || a.A.seg[s].len < BK) return false; tot += a.A.seg[s].len; }
+  return tot == a.K;
 }
 
 // ---------------------------------------------------------------------------------------------

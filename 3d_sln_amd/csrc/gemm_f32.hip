@@ -44,24 +44,24 @@ __global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_
   gemm_nt_body16<J, AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, ((a.M + 63) / 64) * ((a.N + 32 * J - 1) / (32 * J)), smem);
 }
 
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, int NSEG = 1>
 __global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  gemm_nt_small_body<AMODE, EPI, nt_helpers2<AMODE, EPI>()>(a, blockIdx.x, smem, xcd != 0);
+  gemm_nt_small_body<AMODE, EPI, nt_helpers2<AMODE, EPI>(), NSEG>(a, blockIdx.x, smem, xcd != 0);
 }
 
 }  // namespace
 int sln_gemm_init();
 namespace {
 
-template <int AMODE, int EPI>
+template <int AMODE, int EPI, int NSEG = 1>
 int launch_nt_small(const GemmNTArgs& a, hipStream_t st) {
   const size_t smem = nt_small_smem_bytes(a.K);
   const int grid = sln_cdiv(a.M, 32) * sln_cdiv(a.N, 32);
   if (grid <= 0) return 0;
   if (smem > 48 * 1024) { int r = sln_gemm_init(); if (r) return r; }
   static const int xcd = std::getenv("SLN_NT_SMALL_NO_XCD") ? 0 : 1;      // lab switch: plain workgroup order
-  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI>), dim3(grid), dim3(nt_helpers2<AMODE, EPI>() ? 512 : 256), smem, st, a, xcd);
+  hipLaunchKernelGGL((gemm_nt_small_kernel<AMODE, EPI, NSEG>), dim3(grid), dim3(nt_helpers2<AMODE, EPI>() ? 512 : 256), smem, st, a, xcd);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -190,7 +190,9 @@ int sln_gemm_init() {
   if (done) return 0;
   int r = init_nt_tile<64, 64, 2, 2>();
 #define SLN_SET_S(AM, EPI)                                                                                        \
-  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_kernel<AM, EPI>),            \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_kernel<AM, EPI, 1>),         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+  if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_kernel<AM, EPI, 3>),         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   SLN_SET_S(0, EPI_PLAIN) SLN_SET_S(0, EPI_STATS) SLN_SET_S(0, EPI_MASK) SLN_SET_S(1, EPI_PLAIN) SLN_SET_S(1, EPI_STATS)
   SLN_SET_S(1, EPI_MASK) SLN_SET_S(2, EPI_PLAIN) SLN_SET_S(2, EPI_STATS) SLN_SET_S(2, EPI_MASK)
@@ -247,6 +249,16 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
     }
     SLN_DISPATCH_S(0) SLN_DISPATCH_S(1) SLN_DISPATCH_S(2)
 #undef SLN_DISPATCH_S
+  }
+  if (tile < 0 && !no_small && nt_wants_small3(a)) {          // the gathered concat of a graph of a few rows
+#define SLN_DISPATCH_S3(AM)                                                           \
+    if (amode == AM) {                                                                \
+      if (epi == EPI_MASK) return launch_nt_small<AM, EPI_MASK, 3>(a, st);            \
+      if (epi == EPI_STATS) return launch_nt_small<AM, EPI_STATS, 3>(a, st);          \
+      return launch_nt_small<AM, EPI_PLAIN, 3>(a, st);                                \
+    }
+    SLN_DISPATCH_S3(0) SLN_DISPATCH_S3(1) SLN_DISPATCH_S3(2)
+#undef SLN_DISPATCH_S3
   }
   if (tile < 0) {
     // widths that leave 64 x 64 tiles with a ragged last round (N = 640: 2.5 tiles per CU at 64 graphs, N = 384: 1.5) run on
