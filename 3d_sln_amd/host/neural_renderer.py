@@ -150,13 +150,16 @@ class _Geometry:
         self.refs = [weakref.ref(o) for o in key_objs]
         self.versions = [o._version for o in key_objs]
         self.orig_size = orig_size
+        self.grad_mode = bool(torch.is_grad_enabled() and fxyz.requires_grad)   # a projection recorded under no_grad carries no graph
         self.fxyz = fxyz                      # [B, F(+fill_back), 3, 3], requires grad when the vertices do
         self.gate = _Gate.apply(fxyz, self)   # what the passes consume: its backward runs once, behind all of them
         self.maps = {}
         self.pending = []                     # (rgb_chw, grad_chw) of rgb passes waiting for the shared pixel-map backward
 
     def matches(self, key_objs, orig_size):
-        return self.orig_size == orig_size and all(r() is o and v == o._version for r, v, o in zip(self.refs, self.versions, key_objs))
+        want_grad = bool(torch.is_grad_enabled() and key_objs[0].requires_grad)
+        return self.orig_size == orig_size and self.grad_mode == want_grad and \
+            all(r() is o and v == o._version for r, v, o in zip(self.refs, self.versions, key_objs))
 
 
 class _Gate(torch.autograd.Function):

@@ -167,6 +167,27 @@ def test_renderer_reuses_the_rasterisation_of_unchanged_geometry():
         NR._rasterize = orig
 
 
+def test_geometry_kept_under_no_grad_is_not_reused_when_gradients_are_wanted():
+    """A pass rendered under torch.no_grad() (a target image) and then, on the SAME vertex tensor, one that is back-propagated:
+    the projection kept for the first call carries no autograd graph and must not be handed to the second."""
+    NR = pkg("host.neural_renderer")
+    V, F, ranges, box = rr.synth_room(4, n_objects=6, target_faces=400)
+    K, R, t = [x.cuda() for x in rr.get_cam_mat(torch.from_numpy(box))]
+    zc = (torch.from_numpy(V).cuda() @ R[0].T + t[0])[:, 2].cpu().numpy()
+    F = F[(zc[F] > 0.3).all(1)]
+    hip = NR.Renderer(camera_mode='projection', image_size=64, K=K, R=R, t=t, anti_aliasing=False, orig_size=512, near=0.001,
+                      light_intensity_ambient=1.0, light_intensity_directional=0.0)
+    f = torch.from_numpy(F)[None].cuda()
+    tex = torch.zeros(1, F.shape[0], 2, 2, 2, 3, device="cuda"); tex[:, ::2] = 1.0
+    v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+    with torch.no_grad():
+        a = hip(v, f, tex, mode='rgb')
+    b = hip(v, f, tex, mode='rgb')
+    assert torch.equal(a, b) and b.requires_grad
+    (b * torch.linspace(0, 1, b.numel(), device="cuda").view_as(b)).sum().backward()
+    assert v.grad is not None and float(v.grad.abs().max()) > 0
+
+
 @pytest.mark.parametrize("image_size,n_pass,dense", [(96, 5, True), (100, 3, False), (64, 70, False)])
 def test_shared_geometry_passes_equal_the_plain_one_rasterisation_per_call_path(image_size, n_pass, dense):
     """The Renderer's fast path (one projection node, one launch per rgb pass, ONE deferred pixel-map backward over all passes:
