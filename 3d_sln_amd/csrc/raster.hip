@@ -810,10 +810,9 @@ __global__ __launch_bounds__(64) void project_faces_bwd_det_kernel(const float* 
   const float iz = 1.f / (z + eps), s = 2.f / os;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f;
   const long base = (long)b * F * 3;
-  for (long j = lane; j < 3L * F; j += 64) {
-    if (faces[base + j] != vi) continue;
+  auto corner = [&](long j) {
     const float gu = gout[3 * (base + j)], gv = gout[3 * (base + j) + 1], gz = gout[3 * (base + j) + 2];
-    if (gu == 0.f && gv == 0.f && gz == 0.f) continue;
+    if (gu == 0.f && gv == 0.f && gz == 0.f) return;
     const float gxh = s * (gu * c.K[0] - gv * c.K[3]);
     const float gyh = s * (gu * c.K[1] - gv * c.K[4]);
     const float gx = gxh * iz, gy = gyh * iz;
@@ -821,6 +820,23 @@ __global__ __launch_bounds__(64) void project_faces_bwd_det_kernel(const float* 
     a0 += gx * c.R[0] + gy * c.R[3] + gzc * c.R[6];
     a1 += gx * c.R[1] + gy * c.R[4] + gzc * c.R[7];
     a2 += gx * c.R[2] + gy * c.R[5] + gzc * c.R[8];
+  };
+  // four consecutive corners per lane and step (one 16-byte load when the image's corner list is 16-byte aligned: 3 F % 4 == 0),
+  // two steps in flight: the walk is a chain of L2 round trips otherwise
+  const long n = 3L * F;
+  const bool al = ((base & 3) == 0) && ((n & 3) == 0);
+  if (al) {
+    const int4* f4 = reinterpret_cast<const int4*>(faces + base);
+    const long n4 = n >> 2;
+    for (long j = lane; j < n4; j += 128) {
+      const int4 u = f4[j];
+      const long j2 = j + 64;
+      const int4 w = j2 < n4 ? f4[j2] : make_int4(-1, -1, -1, -1);
+      if (u.x == vi) corner(4 * j); if (u.y == vi) corner(4 * j + 1); if (u.z == vi) corner(4 * j + 2); if (u.w == vi) corner(4 * j + 3);
+      if (w.x == vi) corner(4 * j2); if (w.y == vi) corner(4 * j2 + 1); if (w.z == vi) corner(4 * j2 + 2); if (w.w == vi) corner(4 * j2 + 3);
+    }
+  } else {
+    for (long j = lane; j < n; j += 64) if (faces[base + j] == vi) corner(j);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); }
@@ -1024,7 +1040,8 @@ SceneSide* scene_side() {
   return per_dev[dev];
 }
 
-struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int pad_[2]; };
+constexpr int DET_BANDS = 16;        // row bands of the deterministic masked sums (scene_bwd_masked_sums_det_kernel)
+struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int det_ticket; int pad_; float det_part[DET_BANDS][64]; };
 
 // order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
 __device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }
@@ -1148,6 +1165,7 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
 __global__ void scene_zero_gsum_kernel(SceneStats* st, int B) {      // backward may run more than once per forward
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < B * 64) st[i / 64].gsum[i % 64] = 0.0;
+  if (i < B) st[i].det_ticket = 0;
 }
 
 __global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t* __restrict__ dch, int is, int NC, int nch,
@@ -1185,18 +1203,22 @@ __global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t
   if (threadIdx.x == 0) atomicAdd(&st[b].gsum[owner], (double)(red[0] + red[1] + red[2] + red[3]));
 }
 
-// Deterministic form of the masked sums (SLN_DETERMINISTIC; one workgroup per image): every thread keeps its own accumulator per
-// class in LDS (priv[c][thread]: no atomics, a thread adds its pixels in order), then thread c sums the 256 columns of class c in
-// thread order and adds the result to gsum[c] - the only other add into that value is the plane sum's, and a + b is b + a.
+// Deterministic form of the masked sums (SLN_DETERMINISTIC).  DET_BANDS workgroups per image, each over a band of rows: every
+// thread keeps its own accumulator per class in LDS (priv[c][thread]: no atomics, a thread adds its pixels in order), thread c sums
+// the 256 columns of class c in thread order -> det_part[band][c]; the workgroup that arrives LAST (a ticket: who is last does
+// not matter) adds the bands in band order and adds the result to gsum[c] - the only other add into that value is the plane
+// sum's, and a + b is b + a.  (Round 3: one workgroup per image walked all 65 536 pixels, 283 us per 16 rooms.)
 __global__ __launch_bounds__(256) void scene_bwd_masked_sums_det_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
                                                                         const int32_t* __restrict__ cls, const int32_t* __restrict__ dch,
                                                                         int F, int is, int NC, int nch, const float* __restrict__ gout,
                                                                         SceneStats* __restrict__ st) {
   extern __shared__ float priv[];            // [NC][256]
-  const int b = blockIdx.y;
+  const int b = blockIdx.y, band = blockIdx.x;
   const long plane = (long)is * is;
+  const int rows = (is + DET_BANDS - 1) / DET_BANDS;
+  const long p0 = (long)band * rows * is, p1 = min((long)(band + 1) * rows * is, plane);
   for (int c = 0; c < NC; ++c) priv[c * 256 + threadIdx.x] = 0.f;
-  for (long p = threadIdx.x; p < plane; p += 256) {
+  for (long p = p0 + threadIdx.x; p < p1; p += 256) {
     const long q = b * plane + p;
     const int f = fi_b[q];
     if (f < 0) continue;
@@ -1210,6 +1232,18 @@ __global__ __launch_bounds__(256) void scene_bwd_masked_sums_det_kernel(const in
   if (threadIdx.x < NC) {
     float s = 0.f;
     for (int t = 0; t < 256; ++t) s += priv[threadIdx.x * 256 + t];
+    st[b].det_part[band][threadIdx.x] = s;
+  }
+  __threadfence();
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = atomicAdd(&st[b].det_ticket, 1) == DET_BANDS - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (threadIdx.x < NC) {
+    float s = 0.f;
+    for (int k = 0; k < DET_BANDS; ++k) s += __builtin_nontemporal_load(&st[b].det_part[k][threadIdx.x]);
     if (s != 0.f) atomicAdd(&st[b].gsum[threadIdx.x], -(double)s);
   }
 }
@@ -1452,7 +1486,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(det ? 1 : 8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
                      w.st);
   if (det)
-    hipLaunchKernelGGL(scene_bwd_masked_sums_det_kernel, dim3(1, B), dim3(256), sizeof(float) * 256 * (size_t)num_classes, sd_st, w.fiB, w.val,
+    hipLaunchKernelGGL(scene_bwd_masked_sums_det_kernel, dim3(DET_BANDS, B), dim3(256), sizeof(float) * 256 * (size_t)num_classes, sd_st, w.fiB, w.val,
                        face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st);
   else
   hipLaunchKernelGGL(scene_bwd_masked_sums_kernel, dim3(64, B), dim3(256), 0, sd_st, w.fiB, w.val, face_class, class_depth_channel, F, is,
