@@ -667,11 +667,11 @@ def refine_leg(args, lib, torch):
     sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
     st = torch.cuda.Stream()
     iters = args.refine_iters
-    def timed(n):
+    def timed(n, capture=False):
         model.load_state_dict(sd0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        losses, _ = R.finetune_vae_fast(model, objs, triples, boxes, angles, attrs, names, iters=n, bank=bank)
+        losses, _ = R.finetune_vae_fast(model, objs, triples, boxes, angles, attrs, names, iters=n, bank=bank, capture=capture)
         torch.cuda.synchronize()
         return time.perf_counter() - t0, losses
     with torch.cuda.stream(st):
@@ -689,7 +689,16 @@ def refine_leg(args, lib, torch):
         setup = sorted(a - iters * per_iter for a in t1s)[2]
         dt = sorted(t1s)[2]
         slopes = [slopes[0], slopes[2], slopes[4]]
+        # the same iteration captured once per room and replayed (capture=True): the launches of an iteration leave the host's hands
+        g1s, g2s = [], []
+        for _ in range(3):
+            a_, _ = timed(iters, True)
+            b_, _ = timed(2 * iters, True)
+            g1s.append(a_); g2s.append(b_)
+        gslopes = sorted((b_ - a_) / iters for a_, b_ in zip(g1s, g2s))
     return {"ms_per_iteration": round(per_iter * 1e3, 3), "ms_per_iteration_min_median_max": [round(x * 1e3, 3) for x in slopes],
+            "ms_per_iteration_hipgraph_replay_min_median_max": [round(x * 1e3, 3) for x in gslopes],
+            "ms_setup_per_room_hipgraph": round(sorted(a_ - iters * gslopes[1] for a_ in g1s)[1] * 1e3, 2),
             "ms_setup_per_room": round(setup * 1e3, 2),
             "ms_per_iteration_incl_setup": round(dt / iters * 1e3, 3), "iterations": iters, "finite": bool(torch.isfinite(losses).all()),
             "includes": "ms_per_iteration: slope between rooms of 60 and 120 iterations (median of 5); the per-room set-up (encoder, target render, "

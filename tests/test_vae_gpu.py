@@ -5,6 +5,8 @@ Everything goes through the C ABI (libsln_hip.so via ctypes); the checker is the
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -422,10 +424,12 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
     # the yardstick at 64 graphs: the fp32 scatter of the reference path itself - its gradient and the fp32 oracle with every
     # parameter moved by one ulp (three rounding trajectories) - measured against the fp64 gradient; ONE fp32 sample
     # under-estimates the spread of a tensor by chance (the problem is chaotic at the 1e-2 level, see above)
+    # (round 4) the other sizes get the same kind of yardstick, from more trajectories (their bound is a larger multiple of it, see
+    # below): every size is now held to the reference's own fp32 scatter, tensor by tensor
     spread = {}
-    if n_graphs == 64:
+    if True:
         samples = [{k: g.numpy() for k, g in grads.items()}]
-        for ps in (1, 2, 3):
+        for ps in ((1, 2, 3) if n_graphs == 64 else (1, 2, 3, 4, 5, 6)):
             samples.append(_fp64_grads(cfg, {k: v.clone() for k, v in sd.items()}, batch[:5], eps, perturb_seed=ps))
         for smp in samples:
             for k in grads64:
@@ -439,6 +443,14 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
                 assert np.isfinite(err) and err <= 5e-6 * gscale + 1e-4 * scale + 4.0 * spread[k], \
                     "c2:grad:%s: err %.3e, scale %.3e, fp32-reference spread %.3e" % (k, err, scale, spread[k])
             else:
+                # parity, conditioned: within 4x (256 graphs) / 10x (7 graphs, 161 rows) the largest distance of seven fp32 evaluations
+                # of the reference path (its own gradient + six one-ulp perturbations) from the fp64 gradient - measured 1.9x and
+                # 6.7x, identical over three runs; AND the size-independent sanity bound below
+                err, scale = max_err(got, r64)
+                _RATIOS.append(((err - 5e-6 * gscale - 1e-4 * scale) / max(spread[k], 1e-30), k, err, scale, spread[k]))
+                kk = 4.0 if n_graphs >= 64 else 10.0          # 256 graphs: the batch-64 multiple (measured 1.9x); 7 graphs: 6.7x
+                assert np.isfinite(err) and err <= 5e-6 * gscale + 1e-4 * scale + kk * spread[k], \
+                    "c2:grad:%s: err %.3e, scale %.3e, fp32-reference spread %.3e" % (k, err, scale, spread[k])
                 try:
                     assert_close_conditioned(got, r64, gr.numpy(), "c2:grad:" + k, rtol=2e-2, atol=5e-6 * gscale, k=4.0)
                 except AssertionError:
@@ -446,10 +458,17 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
                     assert l2 <= 0.1, "c2:grad:%s: relative L2 error %.3f" % (k, l2)
         except AssertionError as e:
             bad.append(str(e))
+    if _RATIOS and os.environ.get("SLN_TEST_SPREAD_REPORT"):
+        _RATIOS.sort(reverse=True)
+        print("SPREAD REPORT n_graphs=%d: worst (err - floor) / spread:" % n_graphs, [(round(r, 2), k, "%.2e" % e, "%.2e" % sc, "%.2e" % sp) for r, k, e, sc, sp in _RATIOS[:5]])
+    del _RATIOS[:]
     assert not bad, "\n".join(bad[:40])
     for k in sdg:
         if "running" in k:
             assert_close(model2.state_dict()[k].cpu().numpy(), sdg[k].numpy(), "c2:" + k)
+
+
+_RATIOS = []
 
 
 def _threshold_free_state(cfg, seed):
