@@ -439,3 +439,40 @@ def test_deterministic_mode_makes_the_generator_bit_identical_run_to_run():
     assert_close(runs[0][0].cpu().numpy(), default.cpu().numpy(), "deterministic vs default", rtol=1e-5, atol=2e-5)
     ref = spade_ref.generator(sd, cfg, seg.cpu(), z.cpu())
     assert_close(runs[0][0].cpu().numpy(), ref.numpy(), "deterministic vs oracle", rtol=1e-4, atol=1e-4)
+
+
+def test_kept_planes_contract_release_and_copy(monkeypatch):
+    """The kept gamma|beta planes: a batched call releases them; a deepcopy of the module carries neither the planes
+    nor the packed weights and still computes the same image; a write that does not move the version counter is NOT seen (the
+    documented contract) - and is caught when SLN_SPADE_MEMO_CHECK=1 asks for the checksum."""
+    import copy
+    S = pkg("host.SPADE_related"); L = pkg("_lib")
+    cfg = spade_ref.SpadeConfig(**CASES["spade_small"][0])
+    sd = spade_ref.init_state(cfg, seed=7)
+    G = S.SPADEGenerator4(cfg.semantic_nc, cfg.target_nc, cfg.nz, cfg.ngf, 'spectralspadelayer3x3', cfg.crop_size, 'normal')
+    G.load_state_dict(sd); G = G.cuda().eval()
+    seg, _ = spade_ref.synth_input(cfg, 2, seed=5)
+    z = torch.from_numpy(np.random.default_rng(4).standard_normal((2, cfg.nz)).astype(np.float32)).cuda()
+    total = seg[:1].cuda().contiguous()
+    for _ in range(3):
+        a = G(total, z[:1])
+    assert G._map_memo is not None and len(G._map_memo["gb"]) > 0
+    G(seg.cuda(), z)                                               # a batched call: the planes (and the pinned map) go
+    assert G._map_memo is None
+    for _ in range(3):
+        G(total, z[:1])
+    G2 = copy.deepcopy(G)
+    assert G2._map_memo is None and G2._packed is None
+    assert_close(G2(total, z[:1]).cpu().numpy(), a.cpu().numpy(), "deepcopy", rtol=1e-5, atol=2e-5)   # (its first call takes the fused path)
+    # a silent write (no version bump)
+    monkeypatch.setenv("SLN_SPADE_MEMO_CHECK", "1")
+    G.clear_map_cache()
+    for _ in range(3):
+        G(total, z[:1])
+    seg2, _ = spade_ref.synth_input(cfg, 1, seed=6)
+    total.data.copy_(seg2.cuda())                                  # .data: the version counter of `total` does not move
+    with pytest.raises(L.SlnError):
+        G(total, z[:1])
+    G.clear_map_cache()
+    ref2 = spade_ref.generator(sd, cfg, seg2, z[:1].cpu()).numpy()
+    assert_close(G(total, z[:1]).cpu().numpy(), ref2, "after clear_map_cache", rtol=1e-4, atol=1e-4)

@@ -388,3 +388,24 @@ def test_eager_steps_on_batches_of_changing_shape_need_no_host_sync():
     assert np.isfinite(runs[False][0]).all()
     assert (runs[False][0] == runs[True][0]).all(), "losses without / with a drain per step"
     assert (runs[False][1] == runs[True][1]).all(), "parameters without / with a drain per step"
+
+
+def test_optimizer_step_before_any_forward_creates_the_engine():
+    """An empty-shard rank of the data-parallel trainer may reach adam_step() before it has ever run a forward (short first batch,
+    batch_size < world): the update only needs the flat buffers - it used to raise on that rank alone, behind the
+    collectives, and the others hung in the next all-reduce."""
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=1)
+    sd = vae_ref.init_state(cfg, seed=1)
+    m = _model(cfg, sd).train()
+    assert m._eng is None
+    before = m.flat_params.clone()
+    m.flat_grads.fill_(1e-3)
+    m.adam_step(lr=1e-3)
+    torch.cuda.synchronize()
+    assert m._eng is not None
+    moved = (m.flat_params - before).abs()
+    assert float(moved.max()) <= 1.01e-3 and float(moved.max()) > 0.9e-3       # Adam's first step: lr * g / (|g| + eps)
+    # ... and a normal step still works on the engine created that way
+    b = _dev(*vae_ref.synth_batch(4, 6, 9, seed=2, cfg=cfg)[:5])
+    losses = m.train_step(*b, kl_weight=0.1, lr=1e-3, eps=torch.zeros(b[0].shape[0], cfg.embedding_dim, device="cuda"), use_graph=False)
+    assert torch.isfinite(losses).all()
