@@ -296,8 +296,9 @@ class Renderer:
     # the Renderer keeps that geometry's projection - ONE autograd node that all passes share -, its rasterisations, and defers
     # the pixel-map backward of the rgb passes to the shared node (_Gate): a class pass is one launch forward and a list append
     # backward; all 32 are back-propagated by one edge walk.  Round 3 kept only the maps and still paid, per pass, a projection
-    # each way, a copy of the texture tensor, three layout copies and a full pixel-map backward - and was SLOWER than
-    # rasterising every time (28 vs 20 ms per room: the kept maps made every pass's autograd graph hold 33 projection nodes).
+    # each way, a copy of the texture tensor, three layout copies and a full pixel-map backward: 19.5 ms per room against 20.4
+    # rasterising every time on this round's box (the driver's round-3 run read 28.0 against 20.3 - not reproduced here; either
+    # way those per-pass costs are what is gone: 12.2 ms now, 9.9-12.4 of it the caller's own torch code, bench.py render_33pass).
     def _geometry(self, vertices, faces, K, R, t, orig_size):
         key_objs = (vertices, faces, K, R, t)
         if not self.reuse_rasterisation or not all(torch.is_tensor(o) for o in key_objs):
