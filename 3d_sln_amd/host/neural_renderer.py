@@ -269,8 +269,6 @@ class Renderer:
             d = _RasterizeDepth.apply(geom.gate, self.image_size, 0.1, 100.0, maps)
             return torch.flip(d, dims=[1])
         if mode in ('rgb', None):
-            if not self.fill_back:
-                raise NotImplementedError("fill_back=False with reuse_rasterisation (set Renderer.reuse_rasterisation = False)")
             maps = self._maps(geom, float(self.near), float(self.far))
             return _RgbPass.apply(geom.gate, textures, geom, maps, self.image_size, self.rasterizer_eps, self.light_intensity_ambient)
         raise NotImplementedError("mode=%r (the reference uses 'depth' and 'rgb')" % (mode,))
@@ -301,8 +299,8 @@ class Renderer:
     # way those per-pass costs are what is gone: 12.2 ms now, 9.9-12.4 of it the caller's own torch code, bench.py render_33pass).
     def _geometry(self, vertices, faces, K, R, t, orig_size):
         key_objs = (vertices, faces, K, R, t)
-        if not self.reuse_rasterisation or not all(torch.is_tensor(o) for o in key_objs):
-            return None
+        if not self.reuse_rasterisation or not self.fill_back or not all(torch.is_tensor(o) for o in key_objs):
+            return None                      # (fill_back=False - never used by the reference - takes the plain path)
         geom = getattr(self, "_geom", None)
         if geom is not None and geom.matches(key_objs, orig_size):
             return geom
