@@ -132,6 +132,38 @@ __device__ __forceinline__ SegSel pick_seg(const Operand& op, int k0, int kc) {
   return r;
 }
 
+// MULTI = 1, round 4: the three segments' fields loaded ONCE into scalar registers in front of the K loop (sln_seg_preload) and
+// chosen by value per K tile (pick_pre: s_cselect on registers).  With pick_seg<1> inside the loop hipcc selected the ADDRESS of
+// the chosen segment's fields and re-read them from the kernarg segment: ten s_load_dword and four to five s_waitcnt lgkmcnt(0) -
+// each a scalar-cache round trip that also drains the LDS queue - per pair of K tiles in the gathered first Linear of every
+// GraphTripleConv (ISA of gemm_nt_kernel<64, 64, 2, 2, 0, 1, 1>).
+__device__ __forceinline__ SegSel sln_seg_preload1(const Seg& g, int base) {
+  SegSel r;
+  r.x1 = g.x1; r.x2 = g.x2; r.ld1 = g.ld1; r.ld2 = g.ld2; r.c1 = g.c1; r.c2 = g.c2; r.which = g.which;
+  r.base = base; r.end = base + g.len;
+  asm volatile("" : "+s"(r.x1), "+s"(r.x2), "+s"(r.ld1), "+s"(r.ld2), "+s"(r.c1), "+s"(r.c2), "+s"(r.which), "+s"(r.base), "+s"(r.end));
+  return r;
+}
+// (bit masks, not ?: between the three records: hipcc turns a select between aggregate elements into an indexed load from a
+// scratch copy - the first version of this function did exactly that, 160 bytes of scratch and seven scratch loads per tile)
+__device__ __forceinline__ SegSel pick_pre(const SegSel& p0, const SegSel& p1, const SegSel& p2, int nseg, int e0, int e1, int k0) {
+  const int s = (nseg > 1 && k0 >= e0) ? ((nseg > 2 && k0 >= e1) ? 2 : 1) : 0;
+  const int m1 = -(int)(s == 1), m2 = -(int)(s == 2), m0 = ~(m1 | m2);
+  const unsigned long long M0 = (unsigned long long)(long long)m0, M1 = (unsigned long long)(long long)m1, M2 = (unsigned long long)(long long)m2;
+  auto selp = [&](const float* a, const float* b, const float* c) {
+    return reinterpret_cast<const float*>((reinterpret_cast<unsigned long long>(a) & M0) | (reinterpret_cast<unsigned long long>(b) & M1) |
+                                          (reinterpret_cast<unsigned long long>(c) & M2));
+  };
+  auto seli = [&](int a, int b, int c) { return (a & m0) | (b & m1) | (c & m2); };
+  SegSel r;
+  r.x1 = selp(p0.x1, p1.x1, p2.x1); r.x2 = selp(p0.x2, p1.x2, p2.x2);
+  r.ld1 = seli(p0.ld1, p1.ld1, p2.ld1); r.ld2 = seli(p0.ld2, p1.ld2, p2.ld2);
+  r.c1 = seli(p0.c1, p1.c1, p2.c1); r.c2 = seli(p0.c2, p1.c2, p2.c2);
+  r.which = seli(p0.which, p1.which, p2.which);
+  r.base = seli(p0.base, p1.base, p2.base); r.end = seli(p0.end, p1.end, p2.end);
+  return r;
+}
+
 // What the helper wavefronts of an NT kernel do (threads ht = 0 .. nthreads - 1 behind the staging wavefronts): the operand's
 // coefficient table (its zero rows up to kend included) and, for the masked epilogue, the forward coefficients of the TW output
 // columns from n0.  The epilogue table's loads go out first and its arithmetic comes last: its round trip runs under the operand
@@ -225,6 +257,11 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     rid[p] = MULTI ? row : (w0 == 0 ? row : (w0 == 1 ? ra_idx[p] : rb_idx[p]));
   }
   SLN_TRACE(5);
+  constexpr bool kPreload = MULTI == 1;
+  const int pe0 = a.A.seg[0].len, pe1 = pe0 + a.A.seg[1].len, pnseg = a.A.nseg;
+  SegSel pre0 = {}, pre1 = {}, pre2 = {};
+  if (kPreload) { pre0 = sln_seg_preload1(a.A.seg[0], 0); pre1 = sln_seg_preload1(a.A.seg[1], pe0); pre2 = sln_seg_preload1(a.A.seg[2], pe1); }
+#define SLN_PICK(k0_, kc_) (kPreload ? pick_pre(pre0, pre1, pre2, pnseg, pe0, pe1, (k0_)) : pick_seg<MULTI>(a.A, (k0_), (kc_)))
   float4 ga1[NST][PA], ga2[NST][PA], gb[NST][PB];
   const int ntiles = kpad / BK;
   const int last = ntiles - 1;
@@ -237,7 +274,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   auto gload = [&](int kt, auto stage) {
     constexpr int S = decltype(stage)::value;
     const int k0 = kt * BK;
-    const SegSel sg = pick_seg<MULTI>(a.A, k0, k0 + 4 * kq);
+    const SegSel sg = SLN_PICK(k0, k0 + 4 * kq);
     const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;      // column inside the segment, clamped
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -262,7 +299,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     const int kt = min(kt_raw, last);
     const int k0 = kt * BK, col = k0 + 4 * kq;
     if (parts & 1) {
-      const SegSel sg = pick_seg<MULTI>(a.A, k0, col);
+      const SegSel sg = SLN_PICK(k0, col);
       const bool cv = col < sg.end && kt_raw <= last;          // surplus tiles (loop padded to a multiple of 3) are stored as zeros
       const bool x2v = HAS_X2 && sg.x2 != nullptr;
       float* as = As + buf * BM * LDT + 4 * kq;
@@ -439,12 +476,12 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     auto plan = [&](int kt) __attribute__((always_inline)) {               // body(kt) stores tile kt + 1 and loads tile kt + 3
       Plan p;
       const int ks_raw = kt + 1, ks = min(ks_raw, last), k0 = ks * BK, col = k0 + 4 * kq;
-      const SegSel ss = pick_seg<MULTI>(a.A, k0, col);
+      const SegSel ss = SLN_PICK(k0, col);
       p.cv = col < ss.end && ks_raw <= last;
       p.x2v = HAS_X2 && ss.x2 != nullptr;
       p.coff = ks_raw <= last ? col : kpad;
       const int l0 = min(kt + 3, last) * BK;
-      const SegSel sl = pick_seg<MULTI>(a.A, l0, l0 + 4 * kq);
+      const SegSel sl = SLN_PICK(l0, l0 + 4 * kq);
       p.cs = (unsigned)(min(l0 + 4 * kq, sl.end - 4) - sl.base);
       p.cw = (unsigned)min(l0 + 4 * kq, Kr - 4);
       if (MULTI) {
@@ -612,6 +649,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     }
   }
   SLN_TRACE(4);
+#undef SLN_PICK
 }
 
 
