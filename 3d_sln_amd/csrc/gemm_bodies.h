@@ -1002,6 +1002,10 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   // segment of a k-tile (NSEG = 3: every segment is a whole number of tiles, checked by nt_wants_small): first column of the tile
   // inside its segment, and the segment itself - wave-uniform
   const int e0 = NSEG > 1 ? a.A.seg[0].len : 0, e1 = NSEG > 1 ? e0 + a.A.seg[1].len : 0;
+  // NSEG = 3: the segments' fields preloaded into scalar registers and chosen by masks (pick_pre) - `a.A.seg[si]` with a run-time
+  // si made hipcc keep a 64-byte scratch copy of the records and read the fields back from it per tile
+  SegSel pre0 = sln_seg_preload1(a.A.seg[0], 0), pre1 = pre0, pre2 = pre0;
+  if (NSEG > 1) { pre1 = sln_seg_preload1(a.A.seg[1], e0); pre2 = sln_seg_preload1(a.A.seg[2], e1); }
   int rid[NSEG][4];
 #pragma unroll
   for (int sgi = 0; sgi < NSEG; ++sgi) {
@@ -1017,14 +1021,14 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   float4 ga1[4], ga2[4], gb[4];
   auto gload = [&](int kt) {                               // kt clamped by the caller; everything unconditional
     const int k0 = kt * BK;
-    const int si = NSEG > 1 ? (k0 >= e1 ? 2 : (k0 >= e0 ? 1 : 0)) : 0;
-    const Seg& sg = a.A.seg[si];
-    const int cs = min(k0 - (si == 2 ? e1 : (si == 1 ? e0 : 0)) + 4 * kq, sg.len - 4);
+    const SegSel sg = NSEG > 1 ? pick_pre(pre0, pre1, pre2, NSEG, e0, e1, k0) : pre0;
+    const int cs = min(k0 + 4 * kq, sg.end - 4) - sg.base;
     const float* x2p = sg.x2 ? sg.x2 : sg.x1;
     const int ld2 = sg.x2 ? sg.ld2 : sg.ld1, c2 = sg.x2 ? sg.c2 : sg.c1;
+    const int ms1 = -(int)(NSEG > 1 && k0 >= e0 && k0 < e1), ms2 = -(int)(NSEG > 1 && k0 >= e1);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const int rr = NSEG > 1 ? (si == 2 ? rid[NSEG - 1][p] : (si == 1 ? rid[NSEG > 1 ? 1 : 0][p] : rid[0][p])) : rid[0][p];
+      const int rr = NSEG > 1 ? ((rid[0][p] & ~(ms1 | ms2)) | (rid[NSEG > 1 ? 1 : 0][p] & ms1) | (rid[NSEG - 1][p] & ms2)) : rid[0][p];
       ga1[p] = ld4(sg.x1 + (size_t)rr * sg.ld1 + sg.c1 + cs);
       if (HAS_X2) ga2[p] = ld4(x2p + (size_t)rr * ld2 + c2 + cs);
     }
@@ -1035,9 +1039,8 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   auto lstore = [&](int kt) {
     const int col = kt * BK + 4 * kq;
     const int k0 = kt * BK;
-    const int si = NSEG > 1 ? (k0 >= e1 ? 2 : (k0 >= e0 ? 1 : 0)) : 0;
-    const Seg& sg = a.A.seg[si];
-    const bool cv = NSEG > 1 ? col < a.K : col < sg.len, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
+    const SegSel sg = NSEG > 1 ? pick_pre(pre0, pre1, pre2, NSEG, e0, e1, k0) : pre0;
+    const bool cv = NSEG > 1 ? col < a.K : col < sg.end, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
     const float4* cf = coef + min(col, kpad - 4);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
@@ -1088,14 +1091,22 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
     lstore(kt);
     if (kt + 4 < ntiles) gload(kt + 4);                     // wave-uniform branch; the refill flies under this tile's MFMAs
     __builtin_amdgcn_wave_barrier();
+    // all eight fragment reads of the tile first, then its sixteen MFMAs: read -> wait -> four MFMAs per 8-wide chunk (what hipcc
+    // made of the plain loop: six s_waitcnt lgkmcnt(0) per tile) exposed the LDS latency four times per tile on the one chain a
+    // wave has
+    float4 fa[BK / 8], fb[BK / 8];
 #pragma unroll
-    for (int kb = 0; kb < BK; kb += 8) {
-      const float4 fa = *reinterpret_cast<const float4*>(As + lrow * LDT + 4 * lk + kb);
-      const float4 fb = *reinterpret_cast<const float4*>(Bs + lrow * LDT + 4 * lk + kb);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.x, fb.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.y, fb.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.z, fb.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa.w, fb.w, acc, 0, 0, 0);
+    for (int q = 0; q < BK / 8; ++q) {
+      fa[q] = *reinterpret_cast<const float4*>(As + lrow * LDT + 4 * lk + 8 * q);
+      fb[q] = *reinterpret_cast<const float4*>(Bs + lrow * LDT + 4 * lk + 8 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].x, fb[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].y, fb[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].z, fb[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q].w, fb[q].w, acc, 0, 0, 0);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -1554,10 +1565,22 @@ inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
 
 inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + TN_PAD + BN + TN_PAD) * 4; }
 
-inline int nt_heuristic_tile(const GemmNTArgs& a) {   // enough blocks to cover 256 CUs, otherwise the biggest tile
-  const long b128 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 128);
-  const long b12864 = (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64);
-  return b128 >= 512 ? 2 : (b12864 >= 384 ? 1 : 0);
+inline int nt_heuristic_tile(const GemmNTArgs& a) {
+  // Round 4: always the 64 x 64 tile.  Rounds 1-3 gave launches with >= 512 tiles of 128 x 128 (>= 384 of 128 x 64) the bigger body
+  // - a rule from before the 64 x 64 K loop was scheduled by hand.  The big bodies need 270-380 registers (one
+  // wavefront per SIMD: nothing runs under a workgroup's prologue and epilogue, which at K = 256-640 are as long as its K loop)
+  // and their loop is hipcc's own order; three 64 x 64 workgroups share a CU.  Same box, ms per step at 128 / 256 / 512 / 1 024 /
+  // 4 096 graphs: 3.01 / 5.16 / 9.48 / 18.55 / 72.6 with the old rule, 2.84 / 4.77 / 8.57 / 16.36 / 64.9 with this one
+  // (tools/lab/nt_by_shape.py: the four big Linears 0.50-0.54 -> 0.59-0.64 of the MFMA peak).  SLN_NT_TILE = 1 / 2 or the `tile`
+  // argument of sln_linear_forward still select the bigger bodies.
+  static const int forced = std::getenv("SLN_NT_TILE") ? std::atoi(std::getenv("SLN_NT_TILE")) : -1;      // lab: 0 = 64 x 64, 1 = 128 x 64, 2 = 128 x 128
+  (void)a;
+  return forced >= 0 ? forced : 0;
+}
+
+// launches big enough to fill the chip on their own: the paired (dgrad + wgrad) and grouped launches are for the small ones
+inline bool nt_big_shape(const GemmNTArgs& a) {
+  return (long)sln_cdiv(a.M, 128) * sln_cdiv(a.N, 64) >= 384;      // (pairing them as well: no difference at 128 .. 4 096 graphs, same box)
 }
 
 inline bool nt_unaligned(const GemmNTArgs& a) {        // a segment boundary inside a K tile: needs the MULTI = 2 body

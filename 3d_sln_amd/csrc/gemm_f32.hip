@@ -21,6 +21,8 @@
 // body and of the wgrad body are written out instruction by instruction (one piece of staging work behind each MFMA): one
 // wavefront per SIMD hides nothing behind its own MFMAs (tools/lab/overlap.hip).  NT kernels with a
 // coefficient table run 512 threads: wavefronts 4-7 build the table and leave.
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <vector>
 #include "gemm_bodies.h"
@@ -238,6 +240,9 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
   SlnProfScope prof(SLN_FAM_GEMM_NT, 2.0 * a.M * a.N * a.K, st);
   static const bool no_small = std::getenv("SLN_NO_SMALL_NT") != nullptr;
   const int amode = nt_amode(a);
+  // SLN_NT_LOG=1: one line per launch on stderr (tools/lab/nt_by_shape.sh joins them, in order, with a kernel trace)
+  static const bool nt_log = std::getenv("SLN_NT_LOG") != nullptr;
+  if (nt_log) std::fprintf(stderr, "NTLOG M=%d N=%d K=%d amode=%d epi=%d nseg=%d\n", a.M, a.N, a.K, amode, epi, a.A.nseg);
   // stand-alone launches only: inside a dual launch (dgrad blocks next to wgrad blocks on every CU) the small body measured
   // slower than the 64 x 64 one (pairs 28.8 -> 30.3 us on average): its 4x more workgroups pay 4x the prologues on a busy chip
   if (tile < 0 && !no_small && nt_wants_small(a)) {
@@ -300,7 +305,7 @@ int sln_launch_gemm_dual(const GemmNTArgs& a, int epi, const GemmTNArgs& b0, hip
   const bool x2 = tn_prepare(b);
   const int amode = nt_amode(a);
   const bool nonempty = a.M > 0 && a.N > 0 && b.R > 0 && b.Nout > 0 && b.Kin > 0;
-  if (!nonempty || nt_heuristic_tile(a) != 0 || epi == EPI_STATS || x2 != (amode == 1) || a.A.nseg > 1 || !tn_supported(b)) {   // big or odd shapes: separate launches
+  if (!nonempty || nt_big_shape(a) || epi == EPI_STATS || x2 != (amode == 1) || a.A.nseg > 1 || !tn_supported(b)) {   // big or odd shapes: separate launches
     int r = sln_launch_gemm_tn(b0, -1, st);
     return r ? r : sln_launch_gemm_nt(a, epi, -1, st);
   }

@@ -85,7 +85,7 @@ int sln_launch_gemm_group(const GemmNTArgs* nt, const int* epi, int n_nt, const 
   size_t smem = 0;
   int blocks = 0;
   for (int i = 0; i < n_nt; ++i) {
-    if (nt[i].M <= 0 || nt[i].N <= 0 || nt_heuristic_tile(nt[i]) != 0 || nt_amode(nt[i]) != amode || epi[i] != epi[0]) return 1;
+    if (nt[i].M <= 0 || nt[i].N <= 0 || nt_big_shape(nt[i]) || nt_amode(nt[i]) != amode || epi[i] != epi[0]) return 1;
     multi |= nt_multi(nt[i]);
     if (nt_multi(nt[i]) && nt_unaligned(nt[i])) return 1;
     g.nt[i] = nt[i];
