@@ -48,6 +48,9 @@ D="$P/all"; mkdir -p "$D"
 timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -o vae -- python bench.py --no-cpu "$@" > "$D/bench.json" 2> "$D/trace.err"
 flatten "$D/trace"
 cp "$D/trace/vae_kernel_stats.csv" "profiles/${TAG}_rocprofv3_kernel_stats_raw.csv"
+# the JSON line of the plain default command (reads the traffic columns written above); written BEFORE the copy below, which used
+# to put the committed file of an earlier run over a fresh one
+python bench.py "$@" > "profiles/${TAG}_bench.json" 2> "$P/bench_default.err"
 mkdir -p gpurun_out/profiles_$TAG && cp profiles/${TAG}_* gpurun_out/profiles_$TAG/
 for leg in vae render spade render_noside all; do cp "$P/$leg/bench.json" gpurun_out/profiles_$TAG/bench_$leg.json 2>/dev/null; tail -c 300 "$P/$leg/trace.err" > gpurun_out/profiles_$TAG/err_$leg.txt 2>/dev/null; done
 ls -la profiles/${TAG}_*
