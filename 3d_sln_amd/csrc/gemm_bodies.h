@@ -176,7 +176,7 @@ __device__ __forceinline__ void nt_helper_tables(const GemmNTArgs& a, float4* co
   if (etrain) er = bn_fwd_train_load(a.obn, min(n0 + (ht < TW ? ht : 0), a.N - 1));
   if (!IDENT) {
     sln_fill_coefs<NSEG_MAX>(a.A, coef, ht, nthreads);
-    for (int c = a.K + ht; c < kend; c += nthreads) coef[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = a.K + ht; c < kend; c += nthreads) coef[sln_cidx(c)] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   if (EPI == EPI_MASK) {
     if (etrain) {
@@ -214,7 +214,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   static_assert(WM * WN == 4, "4 waves per block");
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);
-  float* As = reinterpret_cast<float*>(coef + kpad + 4);  // [2][BM][LDT]; coef[kpad .. kpad + 3] = 0 (surplus tiles of the scheduled loop)
+  float* As = reinterpret_cast<float*>(coef + sln_crows(kpad + 4));  // [2][BM][LDT]; columns kpad .. kpad + 3 of the table = 0 (surplus tiles of the scheduled loop)
   float* Bs = As + 2 * BM * LDT;                          // [2][BN][LDT]
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT);
   float* red = reinterpret_cast<float*>(ecoef + BN);      // [WM][BN][2] floats (EPI_MASK) or doubles (EPI_STATS)
@@ -303,7 +303,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       const bool cv = col < sg.end && kt_raw <= last;          // surplus tiles (loop padded to a multiple of 3) are stored as zeros
       const bool x2v = HAS_X2 && sg.x2 != nullptr;
       float* as = As + buf * BM * LDT + 4 * kq;
-      const float4* cf = coef + min(col, kpad - 4);
+      const float4* cf = coef + sln_cidx(min(col, kpad - 4));
 #pragma unroll
       for (int p = 0; p < PA; ++p) {
         const int rl = r0 + RP * p;
@@ -335,7 +335,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
   if (!HELP) {
     if (!IDENT) {
       sln_fill_coefs<(MULTI ? 3 : 1)>(a.A, coef, tid, NT);
-      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
+      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[sln_cidx(c)] = z4;
     }
     if (EPI == EPI_MASK) {
       for (int c = tid; c < BN; c += NT) {
@@ -505,7 +505,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
     float4 cfr[4] = {z4, z4, z4, z4};
     if (!IDENT) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) cfr[j] = coef[pl.coff + j];
+      for (int j = 0; j < 4; ++j) cfr[j] = coef[sln_cidx(pl.coff) + j];
     }
 #define SLN_SB __builtin_amdgcn_sched_barrier(0)
     auto stB = [&](int buf, int p, auto stage) __attribute__((always_inline)) {
@@ -561,7 +561,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
       mf(S1{}, C1{}); SLN_SB;
       if (!IDENT) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cfr[j] = coef[pl.coff + j];
+        for (int j = 0; j < 4; ++j) cfr[j] = coef[sln_cidx(pl.coff) + j];
       }
       SLN_SB;
       mf(S1{}, C2{}); SLN_SB;
@@ -675,7 +675,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   constexpr int LDT = BK + 8, RP = 32, PA = BM / RP, PB = BN / RP;
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);               // [kpad + 4], the last four rows zero
-  float* As = reinterpret_cast<float*>(coef + kpad + 4);        // [2][BM][LDT]
+  float* As = reinterpret_cast<float*>(coef + sln_crows(kpad + 4));        // [2][BM][LDT]
   float* Bs = As + 2 * BM * LDT;                                // [2][BN][LDT]
   float4* ecoef = reinterpret_cast<float4*>(Bs + 2 * BN * LDT); // [BN]
   double* redd = reinterpret_cast<double*>(ecoef + BN);         // [2 row halves][BN][2]
@@ -758,7 +758,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   if (!HELP) {
     if (!IDENT) {
       sln_fill_coefs<1>(a.A, coef, tid, NT);
-      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[c] = z4;
+      for (int c = a.K + tid; c < kpad + 4; c += NT) coef[sln_cidx(c)] = z4;
     }
     if (EPI == EPI_MASK) {
       for (int c = tid; c < BN; c += NT) {
@@ -782,7 +782,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   SLN_TRACE(1);
   {   // tile 0 into LDS buffer 0, tile 2 into stage 0
     const bool cv0 = 4 * kq < Kr;
-    const float4* cf0 = coef + 4 * kq;
+    const float4* cf0 = coef + sln_cidx(4 * kq);
 #pragma unroll
     for (int p = 0; p < PA; ++p) wrA(0, p, xfA(p, S0{}, cf0, cv0));
     const int l2 = min(2, last) * BK + 4 * kq;
@@ -835,7 +835,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
   float4 cfr[4] = {z4, z4, z4, z4};          // coefficient rows of the tile the next body stages (fetched one per MFMA in chunk 1)
   if (!IDENT) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cfr[q] = coef[coff_n + q];
+    for (int q = 0; q < 4; ++q) cfr[q] = coef[sln_cidx(coff_n) + q];
   }
   auto body = [&](int kt, auto stage_next) __attribute__((always_inline)) {
     const int buf = kt & 1;
@@ -856,7 +856,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
     mma(S1{}, [&](int n) __attribute__((always_inline)) {
       if ((n & 1) && (n >> 1) < 2 + J) rd1(buf ^ 1, 0, S0{}, n >> 1);
       if (n == 0) plan(kt + 1);
-      if (!IDENT && n >= 2 && n <= 8 && !(n & 1)) cfr[(n >> 1) - 1] = coef[coff_n + (n >> 1) - 1];
+      if (!IDENT && n >= 2 && n <= 8 && !(n & 1)) cfr[(n >> 1) - 1] = coef[sln_cidx(coff_n) + (n >> 1) - 1];
     });
   };
 #undef SLN_SB
@@ -934,7 +934,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
 
 inline size_t nt16_smem_bytes(int K, int J) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)(kpad + 4) * 16 + (size_t)2 * (64 + 32 * J) * (BK + 8) * 4 + (size_t)32 * J * 16 + (size_t)2 * 32 * J * 16;
+  return (size_t)sln_crows(kpad + 4) * 16 + (size_t)2 * (64 + 32 * J) * (BK + 8) * 4 + (size_t)32 * J * 16 + (size_t)2 * 32 * J * 16;
 }
 
 // Which tile for a single-segment problem?  Cost model: rounds of 256 workgroups x tile width.  Returns J (3 or 5) when the
@@ -976,7 +976,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   constexpr int TS = 32;                                   // tile edge
   const int kpad = (a.K + 31) & ~31;
   float4* coef = reinterpret_cast<float4*>(smem);           // [kpad]
-  float4* ecoef = coef + kpad;                              // [TS]
+  float4* ecoef = coef + sln_crows(kpad);                   // [TS]
   double* sred = reinterpret_cast<double*>(ecoef + TS);     // [4][TS][2] column statistics of the four waves
   float* wl = reinterpret_cast<float*>(sred + 4 * TS * 2);  // per wave: A [TS][LDT] | B [TS][LDT]; later its 16 x 64 partial accumulator
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1041,7 +1041,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
     const int k0 = kt * BK;
     const SegSel sg = NSEG > 1 ? pick_pre(pre0, pre1, pre2, NSEG, e0, e1, k0) : pre0;
     const bool cv = NSEG > 1 ? col < a.K : col < sg.end, x2v = HAS_X2 && sg.x2 != nullptr, kv = col < a.K;
-    const float4* cf = coef + min(col, kpad - 4);
+    const float4* cf = coef + sln_cidx(min(col, kpad - 4));
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const int rl = r0 + 8 * p;
@@ -1060,7 +1060,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
   if (!HELP) {
     if (!IDENT) {
       sln_fill_coefs<NSEG>(a.A, coef, tid, 256);
-      for (int c = a.K + tid; c < kpad; c += 256) coef[c] = z4;
+      for (int c = a.K + tid; c < kpad; c += 256) coef[sln_cidx(c)] = z4;
     }
     if (EPI == EPI_MASK) {
       for (int c = tid; c < TS; c += 256) {
@@ -1166,7 +1166,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
 
 inline size_t nt_small_smem_bytes(int K) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)kpad * 16 + 32 * 16 + 4 * 32 * 2 * 8 + (size_t)4 * 2 * 32 * (BK + 4) * 4;
+  return (size_t)sln_crows(kpad) * 16 + 32 * 16 + 4 * 32 * 2 * 8 + (size_t)4 * 2 * 32 * (BK + 4) * 4;
 }
 
 // under-filled single-segment problems: fewer than this many 64 x 64 tiles (the object-side GEMMs of a 64-graph batch, the heads)
@@ -1560,7 +1560,7 @@ inline bool tn_supported(const GemmTNArgs& a) {     // the gradient operand is a
 
 inline size_t nt_smem_bytes(int K, int BM, int BN, int WM) {
   const int kpad = (K + 31) & ~31;
-  return (size_t)(kpad + 4) * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 16;
+  return (size_t)sln_crows(kpad + 4) * 16 + (size_t)2 * (BM + BN) * (BK + 4) * 4 + (size_t)BN * 16 + (size_t)WM * BN * 16;
 }
 
 inline size_t tn_smem_bytes(int BM, int BN) { return (size_t)(BM + BN) * 16 + (size_t)2 * BK * (BM + TN_PAD + BN + TN_PAD) * 4; }

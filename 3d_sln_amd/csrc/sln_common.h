@@ -211,11 +211,18 @@ __device__ __forceinline__ float4 sln_fwd_train_coef(const Seg& g, float gamma, 
 // miss, tools/lab/kernarg_lines.hip) and for the code it jumps over: with the fast paths in front of the generic loop of EVERY
 // caller the K <= 256 kernels that never take them were 0.5-1.2 us slower per launch; with the single-segment callers on their own
 // three-line loop they are 0.1-1.4 us faster than before.
+// Layout of an NT kernel's coefficient table in LDS: one float4 per operand column, with one unused row behind every 16 columns.
+// A staging lane reads the four rows of its four columns (64 bytes, lanes 64 bytes apart): in a plain array lanes kq and kq + 4 of a
+// ds_read_b128 met on the same bank group - the two-way conflict behind the NT kernels' SQ_LDS_BANK_CONFLICT share of 0.14-0.33
+// (the identity-operand variants, which have no table, showed 0.000).  With the gap the upper four lanes sit one bank group further.
+__host__ __device__ __forceinline__ int sln_cidx(int c) { return c + (c >> 4); }
+__host__ __device__ __forceinline__ int sln_crows(int cols) { return cols + ((cols + 15) >> 4); }      // rows of a table of `cols` columns
+
 template <int NSEG_MAX = 0>
 __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, int tid, int nthreads) {
   if (NSEG_MAX == 1) {
     const Seg& g = op.seg[0];
-    for (int c = tid; c < g.len; c += nthreads) coef[c] = sln_coef_for(g, c);
+    for (int c = tid; c < g.len; c += nthreads) coef[sln_cidx(c)] = sln_coef_for(g, c);
     return;
   }
   if (NSEG_MAX == 3 && op.nseg == 3 && sln_seg_fwd_train(op.seg[0]) && sln_seg_fwd_train(op.seg[1]) && sln_seg_fwd_train(op.seg[2]) &&
@@ -233,8 +240,8 @@ __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, 
     for (int s = 0; s < 3; ++s) {
       const int len = op.seg[s].len;
       const float4 v = sln_fwd_train_coef(op.seg[s], ga[s], be[s], s1[s], s2[s]);
-      if (tid < len) coef[base + tid] = v;
-      for (int c = tid + nthreads; c < len; c += nthreads) coef[base + c] = sln_coef_for(op.seg[s], c);
+      if (tid < len) coef[sln_cidx(base + tid)] = v;
+      for (int c = tid + nthreads; c < len; c += nthreads) coef[sln_cidx(base + c)] = sln_coef_for(op.seg[s], c);
       base += len;
     }
     return;
@@ -243,7 +250,7 @@ __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, 
 #pragma unroll
   for (int s = 0; s < 3; ++s) {
     if (s < op.nseg) {
-      for (int c = tid; c < op.seg[s].len; c += nthreads) coef[base + c] = sln_coef_for(op.seg[s], c);
+      for (int c = tid; c < op.seg[s].len; c += nthreads) coef[sln_cidx(base + c)] = sln_coef_for(op.seg[s], c);
       base += op.seg[s].len;
     }
   }
