@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "../../include/sln_hip.h"
 #include "sln_common.h"
@@ -49,6 +50,11 @@ struct ConvArgs {
   double* ln_acc;        // [B][LN_ACC_STRIDE]: sum y, sum y^2 of sample b (LayerNorm2D statistics of the NEXT SPADE layer)
   double* gap_acc;       // [B, rows]: sum over pixels (SEBlock2's global average pool)
   int blocked;           // accumulate in blocks of input channels (see BLK below)
+  // launches of a few workgroups (batch-1 calls on the 8 x 8 .. 64 x 64 layers): gridDim.z workgroups share the input channels of
+  // an output tile, each stores its raw partial sums to part + blockIdx.z * part_stride ([B, rows, H, W] each) and
+  // conv_split_finish_kernel adds them in order, then bias / activation / the reductions (see launch_conv_blocked)
+  float* part;
+  long part_stride;
 };
 constexpr int LN_ACC_STRIDE = 16;     // doubles between the accumulators of two samples (one 128-byte line each)
 
@@ -80,6 +86,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[2
   // stores: written as "if (valid) { load, load, load, compute, store }" per element, hipcc waited for every element's loads
   // (and the previous element's store) before issuing the next ones - 32 serialized memory round trips per lane, ~10 us per
   // 128 x 128 tile of the modulation convolutions.
+  if (EPI == CEPI_BIAS_ACT && a.part != nullptr) {      // input-channel split: raw sums, no bias, no reductions
+    float* __restrict__ pz = a.part + (size_t)blockIdx.z * a.part_stride;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int m = wp0 + 32 * j + li;
+        const int py = y0 + m / TW, px = x0 + m % TW;
+        const bool pv = py < a.H && px < a.W;
+        const size_t pix = (size_t)py * a.W + px;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = r0 + wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lk;
+          const float v = acc_read(acc[i][j][r]);
+          if (pv && row < a.rows) pz[((size_t)b * a.rows + row) * plane + pix] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    return;
+  }
   if (EPI == CEPI_BIAS_ACT) {
     // one 32 x 32 tile at a time, the scheduler fenced between tiles: with everything hoisted the epilogue, not the K loop, set
     // the kernel's register count and cost a third of the occupancy
@@ -440,9 +466,16 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
     pbase[j] = KS == 3 ? (m / TW) * (TW + 2) + (m % TW) : m;
   }
 
-  const int nchunks = a.Cin / GK;
-  issue(0, 0);
-  for (int ch = 0; ch < nchunks; ++ch) {
+  // input-channel split (a.part): workgroup z of gridDim.z takes the chunks [c0, nchunks) of its share, a whole number of
+  // accumulation blocks each
+  int c0 = 0, nchunks = a.Cin / GK;
+  if (a.part != nullptr) {
+    constexpr int Q = BLK > 0 ? BLK : 1;
+    const int per = ((nchunks + (int)gridDim.z - 1) / (int)gridDim.z + Q - 1) / Q * Q;
+    c0 = min((int)blockIdx.z * per, nchunks); nchunks = min(nchunks, c0 + per);
+  }
+  if (c0 < nchunks) issue(c0, c0 & 1);
+  for (int ch = c0; ch < nchunks; ++ch) {
     __syncthreads();                 // chunk ch has landed (the barrier drains the DMA queue); nobody reads the other buffer any more
     if (ch + 1 < nchunks) issue(ch + 1, (ch + 1) & 1);
     const float* wl = lds + (ch & 1) * BUF;
@@ -475,14 +508,14 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const ConvArgs a) {
       mma(av1, bv1);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if constexpr (BLK > 0) { if ((ch + 1) % BLK == 0 || ch + 1 == nchunks) conv_flush(acc, tot, ch + 1 == nchunks); }
+    if constexpr (BLK > 0) { if ((ch + 1 - c0) % BLK == 0 || ch + 1 == nchunks) conv_flush(acc, tot, ch + 1 == nchunks); }
   }
   __syncthreads();                   // the epilogue's reductions reuse the buffers
   conv_epilogue<BMC, EPI, THT>(a, acc, lds, b, r0, x0, y0);
 }
 
 template <int BMC, int KS, int EPI, int THT, int GK, int BLK = 0>
-int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
+int launch_conv_dma(const ConvArgs& a, hipStream_t st, int ksplit = 1) {
   constexpr int TAPS = KS * KS;
   constexpr int HS = KS == 3 ? (THT + 2) * (TW + 2) : THT * TW;
   size_t smem = sizeof(float) * 2 * (size_t)(TAPS * GK * BMC + ((GK * HS + 255) / 256) * 256);
@@ -495,9 +528,97 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t st) {
     raised = true;
   }
   const int tiles = sln_cdiv(a.W, TW) * sln_cdiv(a.H, THT) * a.B;
-  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT, GK, BLK>), dim3(tiles, a.rows_pad / BMC), dim3(256), smem, st, a);
+  hipLaunchKernelGGL((conv_glds_kernel<BMC, KS, EPI, THT, GK, BLK>), dim3(tiles, a.rows_pad / BMC, ksplit), dim3(256), smem, st, a);
   SLN_CHECK_LAUNCH();
   return 0;
+}
+
+// Second half of an input-channel split: y = act(sum_z part[z] + bias), the partial sums added in z order (a fixed order: the
+// result does not depend on how the workgroups were scheduled), and the optional reductions of conv_epilogue over what was written.
+// One workgroup per (sample, output row); NT threads = one wavefront for planes of up to 64 pixels, else four.
+template <int NT>
+__global__ __launch_bounds__(NT) void conv_split_finish_kernel(const float* __restrict__ part, int S, long stride, const float* __restrict__ bias,
+                                                               int act, float slope, float* __restrict__ y, int rows, int plane,
+                                                               double* __restrict__ ln_acc, double* __restrict__ gap_acc) {
+  const int b = blockIdx.y, row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ double red[4][2];
+  const size_t base = ((size_t)b * rows + row) * plane;
+  const float bs = bias ? bias[row] : 0.f;
+  double l1 = 0.0, l2 = 0.0;
+  for (int p = tid; p < plane; p += NT) {
+    const float* src = part + base + p;
+    // four independent loads at a time, added in z order
+    float v = 0.f;
+    int z = 0;
+    for (; z + 4 <= S; z += 4) {
+      const float t0 = src[(size_t)z * stride], t1 = src[(size_t)(z + 1) * stride], t2 = src[(size_t)(z + 2) * stride], t3 = src[(size_t)(z + 3) * stride];
+      v += t0; v += t1; v += t2; v += t3;
+    }
+    for (; z < S; ++z) v += src[(size_t)z * stride];
+    v += bs;
+    if (act == ACT_RELU) v = fmaxf(v, 0.f);
+    else if (act == ACT_LEAKY) v = v > 0.f ? v : v * slope;
+    y[base + p] = v;
+    l1 += (double)v; l2 = fma((double)v, (double)v, l2);
+  }
+  if (ln_acc == nullptr && gap_acc == nullptr) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { l1 += __shfl_xor(l1, off); l2 += __shfl_xor(l2, off); }
+  if (NT > 64) {
+    if (lane == 0) { red[wave][0] = l1; red[wave][1] = l2; }
+    __syncthreads();
+    l1 = red[0][0] + red[1][0] + red[2][0] + red[3][0]; l2 = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+  }
+  if (tid == 0) {
+    if (gap_acc) atomicAdd(gap_acc + (size_t)b * rows + row, l1);
+    if (ln_acc) { atomicAdd(ln_acc + LN_ACC_STRIDE * b, l1); atomicAdd(ln_acc + LN_ACC_STRIDE * b + 1, l2); }
+  }
+}
+static int launch_conv_split_finish(const ConvArgs& a, const float* part, int S, long stride, hipStream_t st) {
+  const int plane = a.H * a.W;
+  if (plane <= 64) hipLaunchKernelGGL(conv_split_finish_kernel<64>, dim3(a.rows, a.B), dim3(64), 0, st, part, S, stride, a.bias, a.act, a.slope, a.y, a.rows, plane, a.ln_acc, a.gap_acc);
+  else hipLaunchKernelGGL(conv_split_finish_kernel<256>, dim3(a.rows, a.B), dim3(256), 0, st, part, S, stride, a.bias, a.act, a.slope, a.y, a.rows, plane, a.ln_acc, a.gap_acc);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// scratch of the input-channel split (allocated on first use, never during a stream capture)
+static float* g_conv_part = nullptr;
+static size_t g_conv_part_bytes = 0;
+static float* conv_part_scratch(size_t bytes, hipStream_t st) {
+  if (bytes <= g_conv_part_bytes) return g_conv_part;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipDeviceSynchronize() != hipSuccess) return nullptr;          // the old buffer may still be in use
+  if (g_conv_part) (void)hipFree(g_conv_part);
+  g_conv_part = nullptr; g_conv_part_bytes = 0;
+  if (hipMalloc(reinterpret_cast<void**>(&g_conv_part), bytes) != hipSuccess) { g_conv_part = nullptr; return nullptr; }
+  g_conv_part_bytes = bytes;
+  return g_conv_part;
+}
+
+// Batch-1 calls (test_SPADE_shade.py:77-79: one call per z).  The 1 024 / 512-channel layers at 8 x 8 .. 64 x 64 pixels are 8 .. 64
+// workgroups that each walk all input channels: 375-760 us per launch on 3-25 % of the CUs - 6 of the 7.7 ms of a call - and the
+// 256 / 128-channel layers behind them 64-128 workgroups.  Launches of fewer than 192 workgroups split the input channels over
+// gridDim.z workgroups (>= 8 chunks = 32 channels each, ~512 workgroups in all: the 8 x 16-pixel DMA kernel, BLK = accumulation
+// block of the blocked form or 0) and conv_split_finish_kernel adds the partial sums in order.  *done: the launch was taken.
+template <int BMC, int KS, int BLK>
+int launch_conv_split(const ConvArgs& a, hipStream_t st, bool* done) {
+  static const int split_max = getenv("SLN_CONV_KSPLIT") ? atoi(getenv("SLN_CONV_KSPLIT")) : 32;      // 1: never
+  *done = false;
+  if (split_max <= 1 || a.Cin % 4 != 0) return 0;
+  const long blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B * (a.rows_pad / BMC);
+  if (blocks >= 192) return 0;
+  const int nch = a.Cin / 4;
+  const int S = (int)std::min<long>(std::min(split_max, nch / 8), (512 + blocks - 1) / blocks);
+  if (S <= 1) return 0;
+  const size_t one = (size_t)a.B * a.rows * a.H * a.W;
+  float* part = conv_part_scratch(one * S * sizeof(float), st);
+  if (part == nullptr) return 0;
+  ConvArgs p = a; p.part = part; p.part_stride = (long)one;
+  *done = true;
+  const int r = launch_conv_dma<BMC, KS, CEPI_BIAS_ACT, TH, 4, BLK>(p, st, S);
+  return r ? r : launch_conv_split_finish(a, part, S, (long)one, st);
 }
 
 // Blocked accumulation (see conv_mfma_kernel): variants with 64 accumulators per lane.  Blocks of 16 input channels (144
@@ -510,6 +631,7 @@ int launch_conv_blocked(const ConvArgs& a, hipStream_t st) {
     // of the 128-row workgroups; 8 x 16 x 128 rows re-reads the weights per 128 pixels: 1.8x)
     const long tall_blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, 16) * a.B * (a.rows_pad / 64);
     if (variant == 0 && a.H >= 16 && tall_blocks >= 512) return launch_conv_dma<64, 3, CEPI_BIAS_ACT, 16, 8, 2>(a, st);
+    { bool done = false; const int r = launch_conv_split<BMC, 3, 4>(a, st, &done); if (done) return r; }
     return launch_conv_dma<BMC, 3, CEPI_BIAS_ACT, TH, 4, 4>(a, st);
   }
   constexpr int HS = HALO;
@@ -539,6 +661,9 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   static const bool dma_all = getenv("SLN_CONV_DMA") != nullptr;
   static const bool tall = getenv("SLN_CONV_NO_TALL") == nullptr;
   if constexpr (KS == 3 && EPI == CEPI_BIAS_ACT) { if (a.blocked) return launch_conv_blocked<BMC>(a, st); }
+  if constexpr (EPI == CEPI_BIAS_ACT) {
+    if (!staged_only) { bool done = false; const int r = launch_conv_split<BMC, KS, 0>(a, st, &done); if (done) return r; }
+  }
   if (a.Cin % 8 == 0 && !staged_only) {
     // 16 x 16 pixels per workgroup where the image has the rows (half the weight DMA per MFMA, twice the MFMAs per barrier)
     // (not for launches too small to give every CU two of the tall workgroups: batch-1 convs of the one-map-many-z path)
@@ -683,17 +808,23 @@ __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restri
 // hidden row, 8 lanes per output row) and keep SEVERAL rows in flight (8 hidden rows / 4 output rows per lane group: their loads
 // and their shuffle trees are independent chains) - one block per sample is all the parallelism there is, so the kernel is a
 // latency chain per row otherwise.
+// phase 0: the whole block in one workgroup per sample.  Few samples (a batch-1 call: 35 us per launch, 0.25 of the 2 ms of a call):
+// phase 1 = the hidden rows 32 blockIdx.y .. + 31 to `hid` [B, Cr] (fp64, global), phase 2 = the output rows 128 blockIdx.y .. + 127
+// from it - two launches of Cr / 32 and C / 128 workgroups per sample.  Same arithmetic per row in every phase: identical results.
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw,
                                                     const float* __restrict__ w0, const float* __restrict__ w2, int C, int Cr,
-                                                    float* __restrict__ scale) {
+                                                    float* __restrict__ scale, int phase, double* __restrict__ hid) {
   extern __shared__ double smd[];
   double* g = smd; double* hdn = smd + C;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? gsum[(size_t)b * C + c] / hw : (double)gap[(size_t)b * C + c];
+  if (phase != 2) for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? gsum[(size_t)b * C + c] / hw : (double)gap[(size_t)b * C + c];
+  else for (int r = threadIdx.x; r < Cr; r += blockDim.x) hdn[r] = hid[(size_t)b * Cr + r];
   __syncthreads();
   // hidden = relu(W0 g): a wavefront per row, lanes take 4 consecutive columns per step (C % 4 == 0: the callers require C % 8 == 0)
   constexpr int RB = 8;
-  for (int r0 = wave * RB; r0 < Cr; r0 += 4 * RB) {
+  const int r_first = phase == 1 ? 4 * RB * (int)blockIdx.y + wave * RB : wave * RB, r_end = phase == 1 ? min(Cr, 4 * RB * ((int)blockIdx.y + 1)) : Cr;
+  if (phase != 2)
+  for (int r0 = r_first; r0 < r_end; r0 += 4 * RB) {
     double s[RB];
 #pragma unroll
     for (int k = 0; k < RB; ++k) s[k] = 0.0;
@@ -714,15 +845,18 @@ __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ ga
 #pragma unroll
       for (int k = 1; k < RB; ++k) v = lane == k ? s[k] : v;
       hdn[r0 + lane] = v > 0.0 ? v : 0.0;
+      if (phase == 1) hid[(size_t)b * Cr + r0 + lane] = v > 0.0 ? v : 0.0;
     }
   }
+  if (phase == 1) return;
   __syncthreads();
   // scale = sigmoid(W2 hidden): 8 lanes per output row, each a contiguous eighth of the row when that is whole float4s
   const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
   const bool vec = (Cr & 31) == 0;
   const int seg = Cr >> 3;
   constexpr int OB = 4;
-  for (int c0 = grp * OB; c0 < C; c0 += 32 * OB) {
+  const int c_first = phase == 2 ? 32 * OB * (int)blockIdx.y + grp * OB : grp * OB, c_end = phase == 2 ? min(C, 32 * OB * ((int)blockIdx.y + 1)) : C;
+  for (int c0 = c_first; c0 < c_end; c0 += 32 * OB) {
     double s[OB];
 #pragma unroll
     for (int k = 0; k < OB; ++k) s[k] = 0.0;
@@ -1043,6 +1177,7 @@ int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const floa
   // blocked accumulation for the long chains (K = 9 Cin >= 4 608), see conv_mfma_kernel; SLN_CONV_BLOCK_CIN moves the threshold (lab)
   static const int block_cin = getenv("SLN_CONV_BLOCK_CIN") ? atoi(getenv("SLN_CONV_BLOCK_CIN")) : 512;
   a.blocked = ksize == 3 && Cin >= block_cin;
+  a.part = nullptr; a.part_stride = 0;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * ksize * ksize * rows, st);
   const bool big = rows_pad % 128 == 0;
   if (ksize == 3) return big ? launch_conv<128, 3, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 3, CEPI_BIAS_ACT>(a, st);
@@ -1063,7 +1198,7 @@ int sln_spade_modulate_up(const float* actv, int B, int Cin, int H, int W, const
     return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   ConvArgs a; a.x = actv; a.wp = wp; a.bias = bias; a.y = out; a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.rows = 2 * C; a.rows_pad = rows_pad;
-  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C; a.xin_up = xin_up; a.ln_acc = nullptr; a.gap_acc = nullptr; a.blocked = 0;
+  a.act = act; a.slope = slope; a.xin = xin; a.stats = stats; a.C = C; a.xin_up = xin_up; a.ln_acc = nullptr; a.gap_acc = nullptr; a.blocked = 0; a.part = nullptr; a.part_stride = 0;
   SlnProfScope prof(SLN_FAM_CONV, 2.0 * B * H * W * (double)Cin * 9 * 2 * C, st);
   return rows_pad % 128 == 0 ? launch_conv<128, 3, CEPI_MODULATE>(a, st) : launch_conv<64, 3, CEPI_MODULATE>(a, st);
 }
@@ -1097,7 +1232,12 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   const long hw = (long)H * W;
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   if (!gap_sums) hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, hw, gap);
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale);
+  if (gap_sums && B <= 8) {      // few samples: the two FCs as two launches of many workgroups; the hidden rows go through the unused gap buffer
+    double* hid = reinterpret_cast<double*>(gap);                       // B * C / 8 doubles in B * C floats
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C / 8, 32)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 1, hid);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C, 128)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 2, hid);
+  } else
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 0, (double*)nullptr);
   if (stats) {
     const int e = sln_zero_async(acc, sizeof(double) * LN_ACC_STRIDE * B, st);
     if (e != 0) return e;
@@ -1161,7 +1301,7 @@ int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw,
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, (long)hw, gap);
   hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, (const double*)nullptr, (double)hw, w0, w2,
-                     C, C / 8, scale);
+                     C, C / 8, scale, 0, (double*)nullptr);
   const long n = (long)B * C * hw;
   hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xs, dx, scale, (long)hw, n, out);
   SLN_CHECK_LAUNCH();

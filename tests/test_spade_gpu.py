@@ -167,7 +167,9 @@ def test_full_size_batch_of_32_equals_per_sample_calls():
         assert float(out.abs().max()) <= 1.0                                        # tanh
         for b in (0, 13, 31):
             one = G(seg[b:b + 1].contiguous(), z[b:b + 1].contiguous())
-            assert_close(out[b:b + 1].cpu().numpy(), one.cpu().numpy(), "sample %d" % b, rtol=1e-5, atol=1e-5)
+            # (1e-4, not bit-equality: a batch-1 call splits the input channels of the 8 x 8 .. 64 x 64 layers over several
+            #  workgroups - another summation order than the batched launch; leakage between samples would be an O(1) error)
+            assert_close(out[b:b + 1].cpu().numpy(), one.cpu().numpy(), "sample %d" % b, rtol=1e-4, atol=1e-4)
         # different samples give different images (the batch is not broadcast from one sample)
         assert float((out[0] - out[1]).abs().max()) > 1e-3
         # one semantic map, several z (colorize_with_spade) at full size: the shared gamma/beta path against the per-sample path
