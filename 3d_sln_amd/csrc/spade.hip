@@ -608,9 +608,11 @@ int launch_conv_split(const ConvArgs& a, hipStream_t st, bool* done) {
   *done = false;
   if (split_max <= 1 || a.Cin % 4 != 0) return 0;
   const long blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, TH) * a.B * (a.rows_pad / BMC);
-  if (blocks >= 192) return 0;
+  static const int few = getenv("SLN_CONV_KSPLIT_BLOCKS") ? atoi(getenv("SLN_CONV_KSPLIT_BLOCKS")) : 192;      // lab
+  static const int target = getenv("SLN_CONV_KSPLIT_TARGET") ? atoi(getenv("SLN_CONV_KSPLIT_TARGET")) : 512;
+  if (blocks >= few) return 0;
   const int nch = a.Cin / 4;
-  const int S = (int)std::min<long>(std::min(split_max, nch / 8), (512 + blocks - 1) / blocks);
+  const int S = (int)std::min<long>(std::min(split_max, nch / 8), (target + blocks - 1) / blocks);
   if (S <= 1) return 0;
   const size_t one = (size_t)a.B * a.rows * a.H * a.W;
   float* part = conv_part_scratch(one * S * sizeof(float), st);
