@@ -207,10 +207,13 @@ def test_repeated_calls_with_changing_inputs_keep_no_stale_state():
         assert torch.equal(G(segA, zA), a1)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(3, 24, 128, 16, 16, 3), (2, 40, 72, 12, 20, 3), (2, 32, 64, 8, 8, 1), (1, 16, 200, 9, 17, 3)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ks", [(3, 24, 128, 16, 16, 3), (2, 40, 72, 12, 20, 3), (2, 32, 64, 8, 8, 1), (1, 16, 200, 9, 17, 3),
+                                                (1, 128, 64, 16, 16, 3), (2, 512, 128, 8, 8, 3), (1, 256, 72, 8, 8, 1), (1, 1024, 200, 9, 17, 3)])
 def test_conv_epilogue_sums(B, Cin, Cout, H, W, ks):
     """sln_spade_conv_sums: the LayerNorm2D sums and SEBlock2's pixel sums of what the epilogue wrote (models/SPADE_related.py:70-85,
-    128-149) against torch on the conv's own output."""
+    128-149) against torch on the conv's own output.  The last four cases are launches of a few workgroups with many input
+    channels: the input-channel split (conv_split_finish_kernel takes the sums; 3x3 plain, 3x3 with blocked accumulation, 1x1,
+    ragged image and row count)."""
     L = pkg("_lib"); S = pkg("host.SPADE_related")
     g = torch.Generator().manual_seed(Cin + 7 * Cout)
     x = (torch.randn(B, Cin, H, W, generator=g) + 0.3).cuda()
@@ -225,6 +228,9 @@ def test_conv_epilogue_sums(B, Cin, Cout, H, W, ks):
         y2 = torch.empty_like(y)
         L.check(L.lib().sln_spade_conv(L.ptr(x), B, Cin, H, W, L.ptr(wp), L.ptr(bp), Cout, rp, ks, act, 0.2, L.ptr(y2), L.current_stream_ptr()), "conv")
         assert torch.equal(y, y2)
+        ref = F.conv2d(F.pad(x.double(), (1, 1, 1, 1), mode="reflect") if ks == 3 else x.double(), w.double(), bp[:Cout].double())
+        ref = F.leaky_relu(ref, 0.2) if act == 2 else ref
+        assert_close(y.cpu().numpy(), ref.float().cpu().numpy(), "conv (act %d) against torch fp64" % act, rtol=2e-5, atol=2e-5)
         yd = y.double()
         ln = ln.view(B, 16)
         assert_close(ln[:, 0].cpu().numpy(), yd.sum((1, 2, 3)).cpu().numpy(), "sum", rtol=1e-6, atol=1e-4)
