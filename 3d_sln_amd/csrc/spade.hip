@@ -1247,7 +1247,11 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   const long n_out = (long)C * hw * (up_mode >= 0 ? 4 : 1);
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * (2.0 * C * hw + n_out), st);
   long gx = (n_out / 4 + 255) / 256;
-  const long cap = 4096 / B > 16 ? 4096 / B : 16;
+  // workgroups per sample: with the LayerNorm sums on, every workgroup ends in two fp64 atomics on its sample's one 128-byte line,
+  // and the memory side serialises them (~12 ns each): at batch 1 the 4 096 workgroups of the 256 x 256 tail spent 98 of their
+  // 103 us there.  512 per sample at most then (the loop below strides over the grid).
+  long cap = 4096 / B > 16 ? 4096 / B : 16;
+  if (stats && cap > 512) cap = 512;
   gx = gx > cap ? cap : gx;
   const dim3 grid((unsigned)gx, B);
   double* ac = stats ? acc : nullptr;
