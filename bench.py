@@ -957,6 +957,23 @@ def main():
             e1.record()
         torch.cuda.synchronize()
         coll_us = round(e0.elapsed_time(e1) / 20 * 1e3, 1)
+    # SURVEY.md 8(d) asks for >= 20 warm-up + >= 100 timed iterations with median / p10 / p90.  `value` is the EXACT --steps K the
+    # caller asked for; when K < 100 (the driver's short run) the same loop runs once more, behind the timed region, at the
+    # protocol's length - reported next to it, never as `value`.  Single GPU only (no extra collectives in a multi-rank run).
+    survey = None
+    if not dp and args.steps < 100:
+        with torch.cuda.stream(stream):
+            for _ in range(20):
+                losses = step()
+            m2 = [torch.cuda.Event(enable_timing=True) for _ in range(101)]
+            m2[0].record()
+            for k in range(100):
+                losses = step()
+                m2[k + 1].record()
+            torch.cuda.synchronize()
+        ps = sorted(m2[k].elapsed_time(m2[k + 1]) for k in range(100))
+        survey = {"warmup": 20, "steps": 100, "ms_per_step_p10_p50_p90": [round(ps[10], 4), round(ps[50], 4), round(ps[90], 4)],
+                  "graphs_per_s_at_p50": round(args.graphs / ps[50] * 1e3, 1)}
     final_loss = float(losses[3].item())
     ms_per_step = dt / args.steps * 1e3
     value = args.graphs * world * args.steps / dt
@@ -1019,6 +1036,7 @@ def main():
         "value": round(value, 1), "unit": "graphs/s (scene-graph VAE fwd+loss+bwd+Adam)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "ms_per_step_p10_p50_p90": [pct(0.10), pct(0.50), pct(0.90)],
+        "survey_protocol_20_100": survey,
         "steps_per_s": round(args.steps / dt, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: batch=%d scene graphs x (%d objects, %d triples) per GPU, "
