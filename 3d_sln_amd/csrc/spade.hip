@@ -582,18 +582,15 @@ static int launch_conv_split_finish(const ConvArgs& a, const float* part, int S,
   return 0;
 }
 
-// scratch of the input-channel split (allocated on first use, never during a stream capture)
+// scratch of the input-channel split: ONE allocation of 128 MB on first use (never during a capture of the caller's stream), never
+// grown or freed - a launch whose partial sums would not fit splits fewer ways
+constexpr size_t CONV_PART_BYTES = (size_t)128 << 20;
 static float* g_conv_part = nullptr;
-static size_t g_conv_part_bytes = 0;
-static float* conv_part_scratch(size_t bytes, hipStream_t st) {
-  if (bytes <= g_conv_part_bytes) return g_conv_part;
+static float* conv_part_scratch(hipStream_t st) {
+  if (g_conv_part) return g_conv_part;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  if (hipDeviceSynchronize() != hipSuccess) return nullptr;          // the old buffer may still be in use
-  if (g_conv_part) (void)hipFree(g_conv_part);
-  g_conv_part = nullptr; g_conv_part_bytes = 0;
-  if (hipMalloc(reinterpret_cast<void**>(&g_conv_part), bytes) != hipSuccess) { g_conv_part = nullptr; return nullptr; }
-  g_conv_part_bytes = bytes;
+  if (hipMalloc(reinterpret_cast<void**>(&g_conv_part), CONV_PART_BYTES) != hipSuccess) { (void)hipGetLastError(); g_conv_part = nullptr; }
   return g_conv_part;
 }
 
@@ -612,10 +609,11 @@ int launch_conv_split(const ConvArgs& a, hipStream_t st, bool* done) {
   static const int target = getenv("SLN_CONV_KSPLIT_TARGET") ? atoi(getenv("SLN_CONV_KSPLIT_TARGET")) : 512;
   if (blocks >= few) return 0;
   const int nch = a.Cin / 4;
-  const int S = (int)std::min<long>(std::min(split_max, nch / 8), (target + blocks - 1) / blocks);
-  if (S <= 1) return 0;
   const size_t one = (size_t)a.B * a.rows * a.H * a.W;
-  float* part = conv_part_scratch(one * S * sizeof(float), st);
+  int S = (int)std::min<long>(std::min(split_max, nch / 8), (target + blocks - 1) / blocks);
+  S = (int)std::min<size_t>((size_t)S, CONV_PART_BYTES / (one * sizeof(float)));
+  if (S <= 1) return 0;
+  float* part = conv_part_scratch(st);
   if (part == nullptr) return 0;
   ConvArgs p = a; p.part = part; p.part_stride = (long)one;
   *done = true;
