@@ -1105,6 +1105,70 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
     for (int co = 0; co < COUT; ++co) y[((size_t)b * COUT + co) * plane + (long)yy * W + xx] = tanhf(acc[co] + bias[co]);
 }
 
+// The same convolution for launches of a few hundred 16 x 16 tiles (batch 1: 256 workgroups, one per CU, each a chain of eight
+// halo fills and 8 x 25 x COUT dependent FMAs per thread - 109 us for what costs 20 us per image inside a batch of 32): 8 x 8-pixel
+// tiles, and the four wavefronts of a workgroup take the channels c = wave (mod 4) of every chunk; their sums meet in LDS.  Sums:
+// 25 taps -> a wavefront's two channels of a chunk -> the chunks -> the four wavefronts (short chains, as above).
+constexpr int IT2 = 8, IH2 = IT2 + 4;
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_img_small_kernel(const float* __restrict__ x, int Cin, int H, int W,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float* __restrict__ y) {
+  __shared__ float halo[ICK][IH2 * IH2];
+  __shared__ float red[4][COUT][64];
+  const int tiles_x = (W + IT2 - 1) / IT2;
+  const int tx0 = (blockIdx.x % tiles_x) * IT2, ty0 = (blockIdx.x / tiles_x) * IT2, b = blockIdx.y;
+  const int pix = threadIdx.x & 63, wv = threadIdx.x >> 6, lx = pix & (IT2 - 1), ly = pix >> 3;
+  const long plane = (long)H * W;
+  float acc[COUT];
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += ICK) {
+    for (int e = threadIdx.x; e < ICK * IH2 * IH2; e += 256) {
+      const int c = e / (IH2 * IH2), p = e % (IH2 * IH2);
+      const int sy = ty0 + p / IH2 - 2, sx = tx0 + p % IH2 - 2;
+      float v = 0.f;
+      if (c0 + c < Cin && sy >= 0 && sy < H && sx >= 0 && sx < W) {
+        v = x[((size_t)b * Cin + c0 + c) * plane + (long)sy * W + sx];
+        v = v > 0.f ? v : 0.2f * v;
+      }
+      halo[c][p] = v;
+    }
+    __syncthreads();
+    const int cn = min(ICK, Cin - c0);
+    float chunk[COUT];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) chunk[co] = 0.f;
+    for (int c = wv; c < cn; c += 4) {                        // wave-uniform: the weights still come through the scalar cache
+      const float* wc = w + (size_t)(c0 + c) * 25;
+      float part[COUT];
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) part[co] = 0.f;
+#pragma unroll
+      for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 5; ++kx) {
+          const float v = halo[c][(ly + ky) * IH2 + lx + kx];
+#pragma unroll
+          for (int co = 0; co < COUT; ++co) part[co] = fmaf(wc[(size_t)co * Cin * 25 + ky * 5 + kx], v, part[co]);
+        }
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) chunk[co] += part[co];
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) acc[co] += chunk[co];
+    __syncthreads();
+  }
+#pragma unroll
+  for (int co = 0; co < COUT; ++co) red[wv][co][pix] = acc[co];
+  __syncthreads();
+  const int yy = ty0 + ly, xx = tx0 + lx;
+  if (wv == 0 && yy < H && xx < W)
+#pragma unroll
+    for (int co = 0; co < COUT; ++co)
+      y[((size_t)b * COUT + co) * plane + (long)yy * W + xx] = tanhf((((red[0][co][pix] + red[1][co][pix]) + red[2][co][pix]) + red[3][co][pix]) + bias[co]);
+}
+
 // SPADE modulation with gamma/beta shared by the whole batch (one semantic map, many z): gb [rows_pad, plane] is the
 // output of the packed [32 gamma | 32 beta] conv for that map; out[b,c,p] = ((x - mu_b) * inv_b) * (1 + gamma) + beta.
 // HBM-bound: x read once, out written once, gb stays in L2/MALL across the batch (blockIdx.y = sample is the slow index).
@@ -1324,6 +1388,18 @@ int sln_conv_img_tanh(const float* x, int B, int Cin, int H, int W, const float*
   if (!x || !w || !bias || !y || Cout > 4 || Cout <= 0) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * H * W * (Cin + Cout), st);
+  static const bool no_small = getenv("SLN_CONV_IMG_NO_SMALL") != nullptr;      // lab
+  if (!no_small && (long)sln_cdiv(W, IT) * sln_cdiv(H, IT) * B < 512) {      // a few hundred 16 x 16 tiles: 8 x 8 tiles, channels over the wavefronts
+    const dim3 g2(sln_cdiv(W, IT2) * sln_cdiv(H, IT2), B);
+    switch (Cout) {
+      case 1: hipLaunchKernelGGL(conv_img_small_kernel<1>, g2, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+      case 2: hipLaunchKernelGGL(conv_img_small_kernel<2>, g2, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+      case 3: hipLaunchKernelGGL(conv_img_small_kernel<3>, g2, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+      default: hipLaunchKernelGGL(conv_img_small_kernel<4>, g2, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;
+    }
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   const dim3 grid(sln_cdiv(W, IT) * sln_cdiv(H, IT), B);
   switch (Cout) {
     case 1: hipLaunchKernelGGL(conv_img_kernel<1>, grid, dim3(256), 0, st, x, Cin, H, W, w, bias, y); break;

@@ -36,6 +36,20 @@ def test_conv_against_torch_cpu(B, Cin, Cout, H, W, ks):
         assert_close(y.cpu().numpy(), fn(ref).numpy(), "conv act=%d" % act, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(1, 64, 40, 24, 3), (2, 20, 17, 9, 3), (1, 8, 8, 8, 1), (40, 16, 64, 64, 3), (3, 64, 128, 128, 4)])
+def test_conv_img_tanh_against_torch(B, Cin, H, W, Cout):
+    """tanh(conv5x5(leaky_relu(x, 0.2), padding 2)) (models/SPADE_related.py:1602-1603): the 16 x 16-tile kernel (many tiles) and
+    the 8 x 8-tile / channels-over-wavefronts kernel of launches with fewer than 512 tiles (batch-1 calls), ragged sizes."""
+    L = pkg("_lib")
+    g = torch.Generator().manual_seed(Cin + 13 * H)
+    x = torch.randn(B, Cin, H, W, generator=g); w = torch.randn(Cout, Cin, 5, 5, generator=g) / (Cin * 25) ** 0.5; b = torch.randn(Cout, generator=g) * 0.1
+    ref = torch.tanh(F.conv2d(F.leaky_relu(x.double(), 0.2), w.double(), b.double(), padding=2)).float()
+    xd, wd, bd = x.cuda(), w.cuda().contiguous(), b.cuda()
+    y = torch.empty(B, Cout, H, W, device="cuda")
+    L.check(L.lib().sln_conv_img_tanh(L.ptr(xd), B, Cin, H, W, L.ptr(wd), L.ptr(bd), Cout, L.ptr(y), L.current_stream_ptr()), "conv_img")
+    assert_close(y.cpu().numpy(), ref.numpy(), "conv_img", rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("C,H,W", [(64, 16, 16), (8, 8, 24), (100, 10, 10)])
 def test_fused_spade_modulation_against_oracle(C, H, W):
     """SPADE4 (:1438-1454): LayerNorm2D stats + depth conv/concat + shared conv + fused gamma/beta modulation."""

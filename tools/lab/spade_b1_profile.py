@@ -22,3 +22,10 @@ with torch.no_grad():
         img = G(seg, z)
     torch.cuda.synchronize()
 print("%.3f ms per call (batch 1, kept planes)" % ((time.perf_counter() - t0) / 50 * 1e3))
+with torch.no_grad():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for z in zs:
+        img = G(seg, z)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+print("host enqueue %.3f ms per call, GPU tail after the last enqueue %.3f ms (of 50 calls)" % ((t1 - t0) / 50 * 1e3, (t2 - t1) * 1e3))
