@@ -131,10 +131,13 @@ class SPADEGenerator4(nn.Module):
         return st
 
     def _pack_all(self):
-        sd = {k: v.detach().float() for k, v in self.state_dict().items()}
-        key = tuple((v.data_ptr(), v._version) for v in self.state_dict().values())
+        # the signature of the weights - (address, version counter) of every parameter and buffer - is taken on every call; walking
+        # parameters() / buffers() costs ~0.1 ms where two state_dict() walks with 230 detach().float() copies cost ~1 ms, which at
+        # batch 1 was half of the host time of a call (tools/lab/spade_b1_hostprof.py)
+        key = tuple((v.data_ptr(), v._version) for v in self.parameters()) + tuple((v.data_ptr(), v._version) for v in self.buffers())
         if self._packed is not None and key == self._packed_key:
             return self._packed
+        sd = {k: v.detach().float() for k, v in self.state_dict().items()}
         P = {}
         for name in ("head_0", "G_middle_0", "G_middle_1", "up_0", "up_1", "up_2", "up_3"):
             blk = getattr(self, name)
@@ -167,9 +170,11 @@ class SPADEGenerator4(nn.Module):
         return P
 
     # ------------------------------------------------------------------ HIP launches
-    @staticmethod
-    def _st():
-        return _lib.current_stream_ptr()
+    _cur_st = None
+
+    def _st(self):
+        # forward() looks the current stream up once; torch.cuda.current_stream() per launch was 59 look-ups (~0.3 ms) per call
+        return self._cur_st if self._cur_st is not None else _lib.current_stream_ptr()
 
     def _ln_stats(self, x):
         B = x.shape[0]
@@ -341,6 +346,13 @@ class SPADEGenerator4(nn.Module):
         """seg [B, semantic_nc, S, S] (channel 0 depth, 1.. masks), z [B, nz] -> image [B, target_nc, S, S] in (-1, 1)."""
         if input.device.type != 'cuda':
             raise _lib.SlnError("SPADEGenerator4 runs on the MI355X only (no CPU fallback)")
+        self._cur_st = _lib.current_stream_ptr()
+        try:
+            return self._forward(input, z, taps)
+        finally:
+            self._cur_st = None
+
+    def _forward(self, input, z, taps):
         with torch.no_grad():
             seg = input.float().contiguous()
             B = seg.shape[0]
