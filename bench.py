@@ -37,7 +37,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "gemm_dual"]
 # rocprofv3 summaries, ONE PER LEG (tools/profile_round.sh r03): kernel-trace statistics of a run that executes that leg's
 # workload only, joined with the HBM traffic of two PMC passes of the same command (profiles/README.md)
-PROFILE_TAG = "r04"
+PROFILE_TAG = "r05"
 
 
 def profile_csv(leg):
@@ -73,7 +73,7 @@ def parse():
     ap.add_argument("--no-graph-build", action="store_true")
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
-    ap.add_argument("--large-batches", type=str, default="256,1024,4096", help="extra VAE points (graphs per step), '' = none")
+    ap.add_argument("--large-batches", type=str, default="128,256,512,1024,4096", help="extra VAE points (graphs per step; 128 = options/options.py:34, 512 = configs[4]'s global batch on one GPU), '' = none")
     ap.add_argument("--no-colorize", action="store_true", help="skip the one-map / 50-z SPADE leg (per-leg profiles: batch-32 launches only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-call-sequence legs (vae_dropin, render_33pass, spade_50x1)")
     ap.add_argument("--dropin-steps", type=int, default=40)
@@ -102,23 +102,43 @@ def prof_read(lib):
     return {FAMILIES[i]: dict(ms=ms[i], work=work[i], launches=int(cnt[i])) for i in range(n) if cnt[i]}
 
 
+PROFILE_STATUS = {}        # leg -> "ok" | "missing: <reason>" (why a `traffic` entry is null; printed next to it, never silent)
+
+
 def profile_rows(prefixes, leg):
     """Rows of the committed rocprofv3 summary of `leg` ("vae" / "render" / "spade": kernel-trace stats joined with the PMC traffic
     passes) whose kernel name starts with one of `prefixes`: -> (launch-weighted HBM bytes per launch or None, launch-weighted
-    avg us or None)."""
+    avg us or None).  A missing file / row / traffic column is recorded in PROFILE_STATUS[leg] and logged."""
+    import csv
+    path = profile_csv(leg)
+    why = None
+    tot_b, tot_us, n_b, n_us = 0.0, 0.0, 0, 0
     try:
-        import csv
-        tot_b, tot_us, n_b, n_us = 0.0, 0.0, 0, 0
-        for r in csv.DictReader(open(profile_csv(leg))):
-            if not r["kernel"].startswith(tuple(prefixes)):
-                continue
-            calls = int(r["calls"])
-            tot_us += float(r["avg_us"]) * calls; n_us += calls
-            if r.get("hbm_MB_per_launch_corrected"):
-                tot_b += float(r["hbm_MB_per_launch_corrected"]) * 1e6 * calls; n_b += calls
-        return (round(tot_b / n_b) if n_b else None), (round(tot_us / n_us, 2) if n_us else None)
-    except Exception:
-        return None, None
+        rows = list(csv.DictReader(open(path)))
+    except OSError as ex:
+        rows, why = [], "missing: %s not readable (%s)" % (os.path.relpath(path, ROOT), ex.__class__.__name__)
+    for r in rows:
+        if not r["kernel"].startswith(tuple(prefixes)):
+            continue
+        calls = int(r["calls"])
+        tot_us += float(r["avg_us"]) * calls; n_us += calls
+        if r.get("hbm_MB_per_launch_corrected"):
+            tot_b += float(r["hbm_MB_per_launch_corrected"]) * 1e6 * calls; n_b += calls
+    if why is None and not n_us:
+        why = "missing: no row of %s starts with %s" % (os.path.relpath(path, ROOT), "/".join(prefixes))
+    elif why is None and not n_b:
+        why = ("missing: %s has no hbm_MB_per_launch_corrected value for %s (the FETCH_SIZE / WRITE_SIZE passes of "
+               "tools/profile_round.sh gave no rows)" % (os.path.relpath(path, ROOT), "/".join(prefixes)))
+    if why is not None:
+        log("profile_rows(%s): %s" % (leg, why))
+        PROFILE_STATUS.setdefault(leg, why)
+    elif not PROFILE_STATUS.get(leg, "").startswith("missing"):
+        PROFILE_STATUS[leg] = "ok"
+    return (round(tot_b / n_b) if n_b else None), (round(tot_us / n_us, 2) if n_us else None)
+
+
+def traffic_source(leg, traffic):
+    return (os.path.relpath(profile_csv(leg), ROOT) + " (bytes per launch)") if traffic else PROFILE_STATUS.get(leg, "missing: not looked up")
 
 
 def cpu_threads(torch=None):
@@ -758,7 +778,7 @@ def spade_leg(args, lib, torch):
                                      "variants, %d launches per batch)" % c["launches"], "bound": "mfma",
                            "achieved": round(tf, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                            "traffic": tr, "flop_per_launch": round(c["work"] / c["launches"], 1), "avg_launch_us": round(c["ms"] / c["launches"] * 1e3, 2),
-                           "rocprof_avg_launch_us": us}
+                           "rocprof_avg_launch_us": us, "traffic_source": traffic_source("spade", tr)}
     # colorize_with_spade's own shape (testing/test_SPADE_shade.py:30-79): ONE semantic map, 50 z vectors.  gamma/beta depend
     # on the map only, so they are computed once (sln_spade_apply does the per-sample part).
     nz = 50
@@ -1107,6 +1127,18 @@ def main():
         if "gemm_dual" in per_family:
             per_family["gemm_dual"]["what"] = "the twin head branches (box / angle), two Linears per launch"
         nt_launches = sum(per_family[k]["launches_per_step"] for k in ("gemm_nt", "gemm_dual") if k in per_family)
+        # counter bytes against algorithmic bytes (the tier's wasted-re-read check), per launch: NT = forward Linears + dgrads (the
+        # gemm_nt and gemm_dual rows together, as nt_bytes_step counts them), TN = the per-pass wgrad launches
+        tr_ntd, _ = profile_rows(prefixes["gemm_nt"] + prefixes["gemm_dual"], "vae")
+        for fam_k, tr_k, algo_k in (("gemm_nt", tr_ntd, shp["nt_bytes_step"] / max(nt_launches, 1)),
+                                    ("gemm_tn", per_family.get("gemm_tn", {}).get("traffic"),
+                                     shp["tn_bytes_step"] / max(per_family.get("gemm_tn", {}).get("launches_per_step", 1), 1))):
+            if fam_k in per_family:
+                per_family[fam_k]["algorithmic_bytes_per_launch"] = int(algo_k)
+                per_family[fam_k]["traffic_over_algorithmic"] = round(tr_k / algo_k, 3) if tr_k else None
+                per_family[fam_k]["traffic_source"] = traffic_source("vae", tr_k)
+        if "gemm_nt" in per_family:
+            per_family["gemm_nt"]["traffic_nt_and_dual_rows"] = tr_ntd
         traffic, prof_us = per_family[dom]["traffic"], per_family[dom]["rocprof_avg_launch_us"]
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
@@ -1115,9 +1147,9 @@ def main():
                            "frac_event": per_family[dom]["frac_event"], "frac_rocprof": per_family[dom]["frac_rocprof"],
                            "frac_note": "frac = frac_event (HIP events around the eager launches of this run, gaps included); frac_rocprof "
                                         "divides the same flops by the kernel durations of profiles/%s_vae_kernel_stats.csv" % PROFILE_TAG,
-                           "traffic_source": (os.path.relpath(profile_csv("vae"), ROOT) + " (bytes per launch)") if traffic else None,
-                           "algorithmic_bytes_per_launch": int(shp["nt_bytes_step"] / max(nt_launches, 1)) if dom != "gemm_tn"
-                           else per_family["gemm_tn"]["algorithmic_bytes_per_launch"],
+                           "traffic_source": traffic_source("vae", traffic),
+                           "algorithmic_bytes_per_launch": per_family[dom if dom in ("gemm_nt", "gemm_tn") else "gemm_nt"]["algorithmic_bytes_per_launch"],
+                           "traffic_over_algorithmic": per_family[dom if dom in ("gemm_nt", "gemm_tn") else "gemm_nt"]["traffic_over_algorithmic"],
                            "algorithmic_bytes_note": "launch-weighted mean over the step: fp32 operand rows (x2 for the two-source BatchNorm-"
                                                      "backward operand) + weights + output (+ the pre-activation the mask reads)"}
         out["roofline_kernels"] = per_family

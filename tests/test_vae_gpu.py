@@ -533,13 +533,27 @@ def test_c2_full_size_train_step_vs_oracle(n_graphs, n_obj, n_tri):
 _RATIOS = []
 
 
-def _threshold_free_state(cfg, seed):
+def _threshold_free_state(cfg, seed, train_bn=False):
     """A state in which no ReLU pre-activation and no L1 residual sits near its threshold: weights at a tenth of their initial
     scale, every Linear bias in front of a ReLU at +8 (|W x| stays below ~1.5), posterior-head biases 0.  The network is then
     a smooth function of its parameters and fp32 evaluations agree with fp64 to ~1e-6 - unlike the random-init state, where
     ~1e2 of the ~4e8 pre-activations of a 256-graph step lie within fp32 rounding of 0 and every flipped mask moves the
-    gradients by 1e-3 of their scale in ANY fp32 evaluation (the reference's included)."""
+    gradients by 1e-3 of their scale in ANY fp32 evaluation (the reference's included).
+
+    `train_bn`: the variant for train-mode BatchNorm, which removes whatever the Linear in front of it adds: the +8 sits on the
+    BatchNorm beta (`*.1.bias`, `*.4.bias`) instead, gamma is squeezed into [0.5, 1], the Linear biases stay free.  A normalised
+    pre-activation is a z-score of its column (|.| <= sqrt(rows - 1), ~4.5 for Gaussian columns of 16 k rows), so every ReLU
+    input is >= 8 - gamma |z| > 0 by a wide margin in train mode too (the test asserts that on the fp64 oracle's trace)."""
     sd = vae_ref.init_state(cfg, seed=seed, scale=0.1)
+    if train_bn:
+        assert cfg.mlp_normalization == "batch"
+        for k, v in sd.items():
+            mod = k.rsplit(".", 2)[-2] if k.count(".") >= 2 else ""
+            if mod in ("1", "4") and v.dim() == 1 and k.endswith(".bias"):
+                v.fill_(8.0)
+            elif mod in ("1", "4") and v.dim() == 1 and k.endswith(".weight"):
+                v.copy_(0.5 + (v - 0.5) * 0.5)                 # init_state draws gamma ~ U(0.5, 1.5)
+        return sd
     relu_free = ("box_mean.", "box_var.", "angle_mean.", "angle_var.", "box_net.%d." % (3 if cfg.mlp_normalization == "batch" else 2),
                  "angle_net.%d." % (3 if cfg.mlp_normalization == "batch" else 2))
     for k, v in sd.items():
@@ -550,23 +564,46 @@ def _threshold_free_state(cfg, seed):
     return sd
 
 
-@pytest.mark.parametrize("norm,training", [("none", True), ("batch", False)])
-@pytest.mark.parametrize("n_graphs", [256, 1])
+@pytest.mark.parametrize("norm,training,n_graphs", [("none", True, 256), ("none", True, 1), ("batch", False, 256), ("batch", False, 1),
+                                                    ("batch", True, 256), ("batch", True, 64), ("batch", True, 1)])
 def test_tight_gradients_when_no_threshold_is_near(norm, training, n_graphs):
     """1e-4 on EVERY gradient of a full-width step, (a) at 256 graphs (O = 8192, T = 16384): the >= 128-row tiles and the
     separately launched dgrad / wgrad kernels the engine switches to above the batch-64 sizes, (b) at BASELINE config c1's shape
     (1 graph, 8 objects, 12 triples), without BatchNorm and with eval-mode BatchNorm (train.py:63-65 keeps training after
-    model.eval()).  Train-mode BatchNorm cannot be made threshold-free (it removes the bias), see the conditioned tests."""
+    model.eval()), (c) with TRAIN-mode BatchNorm (models/graph.py:14-15, the default of train.py) at 1 / 64 / 256 graphs: the +8
+    sits on the BatchNorm beta there (`_threshold_free_state(train_bn=True)`), so the two-source BatchNorm-backward operand, the
+    statistics epilogues, `bn_param_grads_kernel` and the running statistics get the same 1e-4 as the other modes."""
     cfg = vae_ref.VaeConfig(mlp_normalization=norm)
-    sd = _threshold_free_state(cfg, seed=3)
+    train_bn = norm == "batch" and training
+    sd = _threshold_free_state(cfg, seed=3, train_bn=train_bn)
     batch = list(vae_ref.synth_batch(n_graphs, 32 if n_graphs > 1 else 8, 64 if n_graphs > 1 else 12, seed=0, cfg=cfg)[:5])
-    batch[2] = batch[2] - 100.0                             # every L1 residual positive, far from 0
+    if train_bn:
+        # every L1 residual ~ +-20, the sign drawn per element: with ONE sign the loss gradient is the same row vector on every row
+        # and the first train-mode BatchNorm backward (N dY - sum dY - ...) annihilates it - box_net would get no gradient at all
+        sg = torch.from_numpy(np.random.default_rng(7).integers(0, 2, tuple(batch[2].shape)).astype(np.float32)) * 2 - 1
+        batch[2] = batch[2] + 20.0 * sg
+    else:
+        batch[2] = batch[2] - 100.0                         # every L1 residual positive, far from 0
     O = batch[0].shape[0]
     eps = torch.from_numpy(np.random.default_rng(1).standard_normal((O, cfg.embedding_dim)).astype(np.float32))
     sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
     b64 = (batch[0], batch[1], batch[2].double(), batch[3], batch[4])
     keys = vae_ref.trainable_keys(cfg)
     m64 = {k: torch.zeros_like(sd64[k]) for k in keys}; v64 = {k: torch.zeros_like(sd64[k]) for k in keys}
+    if train_bn:
+        # the premise, checked on the fp64 oracle: every BatchNorm'ed pre-activation ends up >= 2 (no ReLU mask near its threshold)
+        (_, trace) = _trace_oracle({k: v.clone() for k, v in sd64.items()}, cfg, b64, eps.double(), True)     # _ = (mu, logvar, boxes_pred, angles_pred)
+        lo = 1e30
+        for base, taps in trace.items():
+            pre, idx = base.rsplit(".", 1)
+            bn = "%s.%d" % (pre, int(idx) + 1) if idx.isdigit() else ""
+            if bn + ".running_mean" not in sd64:
+                continue
+            for a in taps:
+                z = (a - a.mean(0)) / torch.sqrt(a.var(0, unbiased=False) + 1e-5)
+                lo = min(lo, float((z * sd64[bn + ".weight"] + sd64[bn + ".bias"]).min()))
+        assert lo >= 1.0, "threshold-free premise: smallest BatchNorm output %.3f" % lo
+        assert float((_[2] - b64[2]).abs().min()) >= 10.0
     total64, parts64, g64 = vae_ref.train_step(sd64, cfg, b64, eps.double(), 0.1, m64, v64, step=1, training=training)
     model = _model(cfg, sd).train(training)
     dev = _dev(*batch, eps)
@@ -578,11 +615,25 @@ def test_tight_gradients_when_no_threshold_is_near(norm, training, n_graphs):
     bad = []
     for k in keys:
         ref = g64[k].numpy() if k in g64 else np.zeros(tuple(sd[k].shape))
+        atol = 1e-7 * max(float(np.abs(ref).max()), 1e-30) + 1e-9
+        if train_bn and k.endswith(".bias") and (k[:-len("bias")] + "weight") in g64 and float(np.abs(ref).max()) < 1e-12:
+            # biases whose exact gradient is 0 (fp64 returns 1e-17): a Linear bias in front of a train-mode BatchNorm (the sum over
+            # rows of the BatchNorm backward vanishes identically) and, with every ReLU open, a BatchNorm beta in front of another
+            # Linear -> BatchNorm (a constant shift of that Linear's output).  Any fp32 evaluation returns the rounding residue of
+            # the cancelling sum: held to 1e-4 of the scale of the same module's weight gradient (same rows, same dY).
+            atol = 1e-4 * float(np.abs(g64[k[:-len("bias")] + "weight"].numpy()).max())
         try:
-            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=1e-7 * max(float(np.abs(ref).max()), 1e-30) + 1e-9)
+            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=atol)
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, "\n".join(bad[:40])
+    if train_bn:                                            # running statistics of the step (momentum 0.1, unbiased variance)
+        got = model.state_dict()
+        for k in sd64:
+            if "running" in k:
+                assert_close(got[k].cpu().numpy(), sd64[k].numpy(), k, rtol=1e-4, atol=1e-6)
+            elif "num_batches" in k:
+                assert int(got[k]) == int(sd64[k]), k
 
 
 @pytest.mark.parametrize("deterministic", [False, True])

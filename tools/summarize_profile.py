@@ -11,7 +11,7 @@ def short(n):
     return n.split("(")[0][:70]
 
 
-def main(src, dst):
+def main(src, dst, require_traffic=False):
     stats = list(csv.DictReader(open(os.path.join(src, "trace", "vae_kernel_stats.csv"))))
     traffic = collections.defaultdict(lambda: {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})
     for sub, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
@@ -22,7 +22,15 @@ def main(src, dst):
             if r["Counter_Name"] == ctr:
                 t = traffic[short(r["Kernel_Name"])][ctr]
                 t[0] += float(r["Counter_Value"]); t[1] += 1
-    with open(dst + "_kernel_stats.csv", "w", newline="") as f:
+    n_rows = {c: sum(1 for t in traffic.values() if t[c][1]) for c in ("FETCH_SIZE", "WRITE_SIZE")}
+    if require_traffic and not (n_rows["FETCH_SIZE"] and n_rows["WRITE_SIZE"]):
+        # round 4 lost its traffic columns to two empty PMC passes without anybody noticing: an incomplete summary never
+        # replaces a complete one
+        sys.stderr.write("summarize_profile: %s: PMC passes gave %r kernels with counters - NOT writing %s_kernel_stats.csv "
+                         "(the previous file stays)\n" % (src, n_rows, dst))
+        return 3
+    tmp = dst + "_kernel_stats.csv.tmp"
+    with open(tmp, "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ms", "avg_us", "pct", "fetch_KB_per_launch_raw", "write_KB_per_launch_raw",
                     "hbm_MB_per_launch_corrected"])
@@ -37,8 +45,11 @@ def main(src, dst):
             w.writerow([k, r["Calls"], "%.3f" % (float(r["TotalDurationNs"]) / 1e6), "%.2f" % (float(r["AverageNs"]) / 1e3),
                         r["Percentage"], "%.1f" % fk if fk != "" else "", "%.1f" % wk if wk != "" else "",
                         "%.3f" % corr if corr != "" else ""])
-    print("wrote", dst + "_kernel_stats.csv")
+    os.replace(tmp, dst + "_kernel_stats.csv")
+    print("wrote", dst + "_kernel_stats.csv", "(kernels with FETCH / WRITE counters: %d / %d)" % (n_rows["FETCH_SIZE"], n_rows["WRITE_SIZE"]))
+    return 0
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    a = [x for x in sys.argv[1:] if not x.startswith("--")]
+    sys.exit(main(a[0], a[1], require_traffic="--require-traffic" in sys.argv))
