@@ -641,7 +641,7 @@ __device__ __forceinline__ void gemm_nt_body(const GemmNTArgs& a, const int bid,
             if (EPI == EPI_STATS) { s1 += redd[(w * BN + c) * 2]; s2 += redd[(w * BN + c) * 2 + 1]; }
             else { s1 += (double)red[(w * BN + c) * 2]; s2 += (double)red[(w * BN + c) * 2 + 1]; }
           }
-          const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;      // order-independent sums (sln_common.h)
+          const double qs = EPI == EPI_STATS ? sln_q_fwd(a.M) : SLN_Q_BWD;      // order-independent sums (sln_common.h)
           atomicAdd(out + n0 + c, sln_qd(s1, qs));
           atomicAdd(out + a.ocstride + n0 + c, sln_qd(s2, qs));
         }
@@ -922,7 +922,7 @@ __device__ __forceinline__ void gemm_nt_body16(const GemmNTArgs& a, const int bi
           double s1, s2;
           if (EPI == EPI_STATS) { s1 = redd[c * 2] + redd[(BN + c) * 2]; s2 = redd[c * 2 + 1] + redd[(BN + c) * 2 + 1]; }
           else { s1 = (double)red[c * 2] + (double)red[(BN + c) * 2]; s2 = (double)red[c * 2 + 1] + (double)red[(BN + c) * 2 + 1]; }
-          const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;
+          const double qs = EPI == EPI_STATS ? sln_q_fwd(a.M) : SLN_Q_BWD;
           atomicAdd(out + n0 + c, sln_qd(s1, qs));
           atomicAdd(out + a.ocstride + n0 + c, sln_qd(s2, qs));
         }
@@ -1157,7 +1157,7 @@ __device__ __forceinline__ void gemm_nt_small_body(const GemmNTArgs& a, const in
       double t1 = 0.0, t2 = 0.0;
 #pragma unroll
       for (int w = 0; w < 4; ++w) { t1 += sred[(w * TS + tid) * 2]; t2 += sred[(w * TS + tid) * 2 + 1]; }
-      const double qs = EPI == EPI_STATS ? SLN_Q_FWD : SLN_Q_BWD;
+      const double qs = EPI == EPI_STATS ? sln_q_fwd(a.M) : SLN_Q_BWD;
       atomicAdd(out + n0 + tid, sln_qd(t1, qs));
       atomicAdd(out + a.ocstride + n0 + tid, sln_qd(t2, qs));
     }

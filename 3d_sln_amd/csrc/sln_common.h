@@ -269,6 +269,17 @@ __device__ __forceinline__ void sln_fill_coefs(const Operand& op, float4* coef, 
 #define SLN_Q_BWD 17592186044416.0            /* 2^44 */
 #define SLN_Q_LOSS 16777216.0                 /* 2^24 */
 __device__ __forceinline__ double sln_qd(double v, double scale) { return rint(v * scale) * (1.0 / scale); }
+// Forward sums (round 5): the quantum follows the ROW COUNT of the launch (every block of a launch sees the same M, so the
+// partials still add exactly and commute): 2^-max(20, 33 - ceil(log2 M)).  With the fixed 2^-20 an 8-row BatchNorm (BASELINE
+// config c1, the refinement loop's rooms) lost to the quantum what fp32 rounding loses to a sum of ~10 - and var = E[x^2] - mean^2
+// amplifies that by mean^2 / var (~100 when a column's mean is 10 x its spread): 4e-4 on the gradients of an 8-object graph
+// against the fp64 oracle (tests/test_vae_gpu.py::test_tight_gradients..[batch-True-1]; 4e-7 with this rule).  Exact - hence
+// order-independent - while the column's mean of y^2 stays below ~1e6 (2^(53 - k) / M), for every M; M >= 8192 is the old rule.
+__device__ __forceinline__ double sln_q_fwd(int M) {
+  const int lg = M > 1 ? 32 - __builtin_clz((unsigned)(M - 1)) : 0;          // ceil(log2 M)
+  const int k = 33 - lg > 20 ? 33 - lg : 20;
+  return (double)(1ull << k);
+}
 
 __device__ __forceinline__ float wave_sum_halves(float v) {   // lanes l and l^32 -> both hold the sum
   return v + __shfl_xor(v, 32, 64);

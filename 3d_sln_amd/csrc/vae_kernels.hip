@@ -204,7 +204,7 @@ __device__ __forceinline__ void fill_coef_table2(float2* ta, float2* tb, const B
 }
 
 template <int XT, int YT>
-__global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float* __restrict__ A2, int ld, int H, int D, BnView bn,
+__device__ __forceinline__ void scatter_avg_fwd_v4_body(const float* __restrict__ A2, int ld, int H, int D, BnView bn,
                                                                     GraphCsr g, int O, int T, float* __restrict__ pooled) {
   __shared__ float2 cs[4 * SLN_CTAB_ROW], co[4 * SLN_CTAB_ROW];
   __shared__ int ents[YT][ESTRIDE];
@@ -247,9 +247,13 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float*
   const float w = g.invdeg[i];
   st4g(pooled + (size_t)i * H + c, make_float4(acc.x * w, acc.y * w, acc.z * w, acc.w * w));
 }
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_v4_kernel(const float* __restrict__ A2, int ld, int H, int D, BnView bn, GraphCsr g, int O, int T, float* __restrict__ pooled) {
+  scatter_avg_fwd_v4_body<XT, YT>(A2, ld, H, D, bn, g, O, T, pooled);
+}
 
 template <int XT, int YT, int RPT, int NIT>
-__global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float* __restrict__ dM, const float* __restrict__ dP, int lddp,
+__device__ __forceinline__ void scatter_avg_bwd_v4_body(const float* __restrict__ dM, const float* __restrict__ dP, int lddp,
                                                                     int dpcol0, const float* __restrict__ A2, int ld, int H, int D,
                                                                     BnView bn, GraphCsr g, int T, float* __restrict__ g2,
                                                                     double* gsums, int cstride) {
@@ -306,9 +310,14 @@ __global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float*
   }
   commit_col_stats4<XT, YT>(s1, s2, min(4 * XT, C - c0), gsums, cstride, c0);
 }
+template <int XT, int YT, int RPT, int NIT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_v4_kernel(const float* __restrict__ dM, const float* __restrict__ dP, int lddp, int dpcol0, const float* __restrict__ A2, int ld, int H, int D,
+                                                                    BnView bn, GraphCsr g, int T, float* __restrict__ g2, double* gsums, int cstride) {
+  scatter_avg_bwd_v4_body<XT, YT, RPT, NIT>(dM, dP, lddp, dpcol0, A2, ld, H, D, bn, g, T, g2, gsums, cstride);
+}
 
 template <int XT, int YT>
-__global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __restrict__ dG, int ldg, int D, GraphCsr g, int O, int T,
+__device__ __forceinline__ void gather_bwd_v4_body(const float* __restrict__ dG, int ldg, int D, GraphCsr g, int O, int T,
                                                                const float* __restrict__ add1, int ldadd1,
                                                                const float* __restrict__ xprev, int ldx, BnView bn, int masked,
                                                                float* __restrict__ out, int ldo, double* gsums, int cstride) {
@@ -360,10 +369,16 @@ __global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __re
   }
   if (masked) commit_col_stats4<XT, YT>(s1, s2, min(4 * XT, D - c0), gsums, cstride, c0);
 }
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void gather_bwd_v4_kernel(const float* __restrict__ dG, int ldg, int D, GraphCsr g, int O, int T, const float* __restrict__ add1, int ldadd1,
+                                                               const float* __restrict__ xprev, int ldx, BnView bn, int masked, float* __restrict__ out, int ldo,
+                                                               double* gsums, int cstride) {
+  gather_bwd_v4_body<XT, YT>(dG, ldg, D, g, O, T, add1, ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride);
+}
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-__global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __restrict__ d1, int ld1,
+__device__ __forceinline__ void mask_gstats_body(const float* __restrict__ d1, int ld1,
                                                              const float* __restrict__ d2, int ld2,
                                                              const float* __restrict__ xprev, int ldx, BnView bn,
                                                              int rows, int cols, float* __restrict__ out, int ldo,
@@ -399,6 +414,10 @@ __global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __rest
     }
   }
   commit_col_stats(s1, s2, cv, gsums, cstride, c);
+}
+__global__ __launch_bounds__(CB* RL) void mask_gstats_kernel(const float* __restrict__ d1, int ld1, const float* __restrict__ d2, int ld2, const float* __restrict__ xprev, int ldx, BnView bn,
+                                                             int rows, int cols, float* __restrict__ out, int ldo, double* gsums, int cstride) {
+  mask_gstats_body(d1, ld1, d2, ld2, xprev, ldx, bn, rows, cols, out, ldo, gsums, cstride);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -478,7 +497,7 @@ __global__ __launch_bounds__(CB* RL) void box_embed_bwd_kernel(EncAssembleBwd a,
   }
 }
 
-__global__ void dec_assemble_kernel(DecAssemble a) {
+__device__ __forceinline__ void dec_assemble_body(DecAssemble a) {
   const int W = a.n_obj + a.n_attr + a.n_z;
   const int Wx = a.z_in_x0 ? W : a.n_obj + a.n_attr;      // row stride of x0
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -500,8 +519,11 @@ __global__ void dec_assemble_kernel(DecAssemble a) {
   }
   a.x0[(size_t)r * Wx + cx] = v;
 }
+__global__ void dec_assemble_kernel(DecAssemble a) {
+  dec_assemble_body(a);
+}
 
-__global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
+__device__ __forceinline__ void dec_assemble_bwd_body(DecAssembleBwd a) {
   const int W = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0);
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)a.O * W) return;
@@ -512,11 +534,14 @@ __global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
   else if ((c -= a.n_obj) < a.n_attr) atomicAdd(a.d_attr_emb + (size_t)a.attrs[r] * a.n_attr + c, d);
   else { c -= a.n_attr; if (a.dz) a.dz[(size_t)r * a.n_z + c] = d; }
 }
+__global__ void dec_assemble_bwd_kernel(DecAssembleBwd a) {
+  dec_assemble_bwd_body(a);
+}
 
 // Small tables (<= 8192 floats): accumulate the block's rows in an LDS copy of the table, then flush the
 // touched entries with one global atomic each (pred table: 4096x128 adds onto 16x128 entries).
 template <typename IdxT>
-__global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld,
+__device__ __forceinline__ void embed_bwd_lds_body(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld,
                                                             int col0, int rows, int n, int table_rows, int rows_per_block,
                                                             float* __restrict__ d_emb) {
   extern __shared__ float tab[];
@@ -544,12 +569,17 @@ __global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restri
     if (v != 0.f) atomicAdd(d_emb + i, v);
   }
 }
+template <typename IdxT>
+__global__ __launch_bounds__(256) void embed_bwd_lds_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows, int n, int table_rows, int rows_per_block,
+                                                            float* __restrict__ d_emb) {
+  embed_bwd_lds_body<IdxT>(idx, d, ld, col0, rows, n, table_rows, rows_per_block, d_emb);
+}
 
 // Deterministic form (SLN_DETERMINISTIC): one workgroup per (table row e, 64 columns).  Its four row lanes walk the source rows
 // in order and keep those with idx[r] == e; the four partial sums meet in a fixed order; the result is added to the table with a
 // plain read-modify-write (one writer per element and launch).  No atomics, no arrival order.
 template <typename IdxT>
-__global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0,
+__device__ __forceinline__ void embed_bwd_det_body(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0,
                                                              int rows, int n, float* __restrict__ d_emb) {
   // 16 row lanes x 64 columns; a row lane takes rows lane_r, lane_r + 16, ... eight at a time (their indices in one round trip,
   // then the matching rows' values: the walk is latency-bound), always in ascending order
@@ -578,14 +608,22 @@ __global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const IdxT* __restr
     d_emb[(size_t)e * n + c] += s;
   }
 }
+template <typename IdxT>
+__global__ __launch_bounds__(1024) void embed_bwd_det_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows, int n, float* __restrict__ d_emb) {
+  embed_bwd_det_body<IdxT>(idx, d, ld, col0, rows, n, d_emb);
+}
 
 template <typename IdxT>
-__global__ void embed_bwd_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows,
+__device__ __forceinline__ void embed_bwd_body(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows,
                                  int n, float* __restrict__ d_emb) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * n) return;
   const int r = (int)(i / n), c = (int)(i % n);
   atomicAdd(d_emb + (size_t)idx[r] * n + c, d[(size_t)r * ld + col0 + c]);
+}
+template <typename IdxT>
+__global__ void embed_bwd_kernel(const IdxT* __restrict__ idx, const float* __restrict__ d, int ld, int col0, int rows, int n, float* __restrict__ d_emb) {
+  embed_bwd_body<IdxT>(idx, d, ld, col0, rows, n, d_emb);
 }
 
 __device__ __forceinline__ void embed_gather_body(const int* __restrict__ idx, const float* __restrict__ emb, int rows, int n,
@@ -913,12 +951,15 @@ __global__ void bn_relu_apply_kernel(const float* __restrict__ x, int ld, int co
   out[r * ldo + c] = fmaxf(fmaf(sc, x[r * ld + col0 + c], sh), 0.f);
 }
 
-__global__ void add2_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows, int cols,
+__device__ __forceinline__ void add2_body(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows, int cols,
                             float* __restrict__ out, int ldo) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)rows * cols) return;
   const int r = (int)(i / cols), c = (int)(i % cols);
   out[(size_t)r * ldo + c] = a[(size_t)r * lda + c] + b[(size_t)r * ldb + c];
+}
+__global__ void add2_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb, int rows, int cols, float* __restrict__ out, int ldo) {
+  add2_body(a, lda, b, ldb, rows, cols, out, ldo);
 }
 
 inline dim3 colgrid(int cols, int rows) { return dim3(sln_cdiv(cols, CB), sln_cdiv(rows, RB)); }
@@ -1078,7 +1119,7 @@ struct AssembleBwdLds {
   const float* dx0; int ld, O, rows_per_block, lds_floats;
   float* dz; int z_col0, n_z;               // decoder: dz[r, :] = dx0[r, z_col0 : z_col0 + n_z]  (dz may be null)
 };
-__global__ __launch_bounds__(256) void assemble_bwd_lds_kernel(AssembleBwdLds a) {
+__device__ __forceinline__ void assemble_bwd_lds_body(AssembleBwdLds a) {
   extern __shared__ float tab[];
   for (int i = threadIdx.x; i < a.lds_floats; i += 256) tab[i] = 0.f;
   __syncthreads();
@@ -1115,6 +1156,9 @@ __global__ __launch_bounds__(256) void assemble_bwd_lds_kernel(AssembleBwdLds a)
       if (v != 0.f) atomicAdd(sg.d_emb + i, v);
     }
   }
+}
+__global__ __launch_bounds__(256) void assemble_bwd_lds_kernel(AssembleBwdLds a) {
+  assemble_bwd_lds_body(a);
 }
 static int launch_assemble_bwd_lds(AssembleBwdLds a, hipStream_t st) {
   int off = 0;
@@ -1353,6 +1397,240 @@ int sln_launch_add2(const float* a, int lda, const float* b, int ldb, int rows, 
   const long n = (long)rows * cols;
   if (n <= 0) return 0;
   hipLaunchKernelGGL(add2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, lda, b, ldb, rows, cols, out, ldo);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+// =================================================================================================
+// Multi-room launches (vae_multi.h): blockIdx.z = room, the room's argument block comes out of a device table (uniform address:
+// scalar loads), workgroups beyond the room's own grid leave.  Bodies = the single-room kernels above.
+// =================================================================================================
+#include "vae_multi.h"
+namespace {
+
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_fwd_multi_kernel(const MScatterFwd* __restrict__ tab) {
+  const MScatterFwd& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+  scatter_avg_fwd_v4_body<XT, YT>(a.A2, a.ld, a.H, a.D, a.bn, a.g, a.O, a.g.T, a.pooled);
+}
+template <int XT, int YT, int RPT, int NIT>
+__global__ __launch_bounds__(XT* YT) void scatter_avg_bwd_multi_kernel(const MScatterBwd* __restrict__ tab) {
+  const MScatterBwd& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+  scatter_avg_bwd_v4_body<XT, YT, RPT, NIT>(a.dM, a.dP, a.lddp, a.dpcol0, a.A2, a.ld, a.H, a.D, a.bn, a.g, a.T, a.g2, a.gsums, a.cstride);
+}
+template <int XT, int YT>
+__global__ __launch_bounds__(XT* YT) void gather_bwd_multi_kernel(const MGatherBwd* __restrict__ tab) {
+  const MGatherBwd& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+  gather_bwd_v4_body<XT, YT>(a.dG, a.ldg, a.D, a.g, a.O, a.g.T, a.add1, a.ldadd1, a.xprev, a.ldx, a.bn, a.masked, a.out, a.ldo, a.gsums, a.cstride);
+}
+__global__ __launch_bounds__(CB* RL) void mask_gstats_multi_kernel(const MMaskGstats* __restrict__ tab) {
+  const MMaskGstats& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+  mask_gstats_body(a.d1, a.ld1, a.d2, a.ld2, a.xprev, a.ldx, a.bn, a.rows, a.cols, a.out, a.ldo, a.gsums, a.cstride);
+}
+__global__ void dec_assemble_multi_kernel(const MDecAssemble* __restrict__ tab) {
+  const MDecAssemble& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx) return;
+  dec_assemble_body(a.a);
+}
+__global__ void dec_assemble_bwd_multi_kernel(const MDecAssembleBwd* __restrict__ tab) {
+  const MDecAssembleBwd& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx) return;
+  dec_assemble_bwd_body(a.a);
+}
+struct MAsmLds { AssembleBwdLds a; int gx, pad_; };
+static_assert(sizeof(MAsmLds) <= SLN_ASM_BLOB && sizeof(MDecAssembleBwd) <= SLN_ASM_BLOB, "SLN_ASM_BLOB too small");
+__global__ __launch_bounds__(256) void assemble_bwd_lds_multi_kernel(const char* __restrict__ tab) {
+  const MAsmLds& a = *reinterpret_cast<const MAsmLds*>(tab + (size_t)blockIdx.z * SLN_ASM_BLOB);
+  if ((int)blockIdx.x >= a.gx) return;
+  assemble_bwd_lds_body(a.a);
+}
+__global__ void dec_assemble_bwd_plain_multi_kernel(const char* __restrict__ tab) {
+  const MDecAssembleBwd& a = *reinterpret_cast<const MDecAssembleBwd*>(tab + (size_t)blockIdx.z * SLN_ASM_BLOB);
+  if ((int)blockIdx.x >= a.gx) return;
+  dec_assemble_bwd_body(a.a);
+}
+__global__ void embed_gather_multi_kernel(const MEmbedGather* __restrict__ tab) {
+  const MEmbedGather& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx) return;
+  embed_gather_body(a.idx, a.emb, a.rows, a.n, a.out, blockIdx.x);
+}
+template <typename IdxT, int V>
+__global__ __launch_bounds__(V == MV_EMBED_DET ? 1024 : 256) void embed_bwd_multi_kernel(const MEmbedBwd* __restrict__ tab) {
+  const MEmbedBwd& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx || (int)blockIdx.y >= a.gy) return;
+  const IdxT* idx = static_cast<const IdxT*>(a.idx);
+  if (V == MV_EMBED_DET) embed_bwd_det_body<IdxT>(idx, a.d, a.ld, a.col0, a.rows, a.n, a.d_emb);
+  else if (V == MV_EMBED_LDS) embed_bwd_lds_body<IdxT>(idx, a.d, a.ld, a.col0, a.rows, a.n, a.table_rows, a.rows_per_block, a.d_emb);
+  else embed_bwd_body<IdxT>(idx, a.d, a.ld, a.col0, a.rows, a.n, a.d_emb);
+}
+__global__ void add2_multi_kernel(const MAdd2* __restrict__ tab) {
+  const MAdd2& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx) return;
+  add2_body(a.a, a.lda, a.b, a.ldb, a.rows, a.cols, a.out, a.ldo);
+}
+__global__ void zero_multi_kernel(const MZero* __restrict__ tab) {
+  const MZero a = tab[blockIdx.y];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < a.n16) static_cast<uint4*>(a.p)[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+}  // namespace
+
+int sln_plan_scatter_avg_fwd(MScatterFwd& a) {
+  if (a.O <= 0) { a.gx = a.gy = 0; return a.H > 128 ? MV_SCATTER_FWD_64x4 : MV_SCATTER_FWD_32x8; }
+  if (!(a.H % 4 == 0 && a.D % 4 == 0 && a.ld % 4 == 0 && al16(a.A2) && al16(a.pooled))) return -1;
+  if (a.H > 128) { a.gx = sln_cdiv(a.H, 256); a.gy = sln_cdiv(a.O, 4); return MV_SCATTER_FWD_64x4; }
+  a.gx = sln_cdiv(a.H, 128); a.gy = sln_cdiv(a.O, 8);
+  return MV_SCATTER_FWD_32x8;
+}
+int sln_launch_scatter_avg_fwd_multi(const MScatterFwd* tab, int R, int variant, int gx, int gy, hipStream_t st) {
+  if (R <= 0 || gx <= 0 || gy <= 0) return 0;
+  if (variant == MV_SCATTER_FWD_64x4) hipLaunchKernelGGL((scatter_avg_fwd_multi_kernel<64, 4>), dim3(gx, gy, R), dim3(64, 4), 0, st, tab);
+  else hipLaunchKernelGGL((scatter_avg_fwd_multi_kernel<32, 8>), dim3(gx, gy, R), dim3(32, 8), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_scatter_avg_bwd(MScatterBwd& a) {
+  if (a.T <= 0) { a.gx = a.gy = 0; return 0; }
+  if (!(a.H % 4 == 0 && a.D % 4 == 0 && a.ld % 4 == 0 && (!a.dP || (a.lddp % 4 == 0 && a.dpcol0 % 4 == 0 && al16(a.dP))) && al16(a.dM) && al16(a.A2) &&
+        al16(a.g2))) return -1;
+  a.gx = sln_cdiv(2 * a.H + a.D, 256); a.gy = sln_cdiv(a.T, 4 * 4 * 2);       // <64, 4, RPT = 4, NIT = 2>: the single-room default
+  return 0;
+}
+int sln_launch_scatter_avg_bwd_multi(const MScatterBwd* tab, int R, int variant, int gx, int gy, hipStream_t st) {
+  (void)variant;
+  if (R <= 0 || gx <= 0 || gy <= 0) return 0;
+  hipLaunchKernelGGL((scatter_avg_bwd_multi_kernel<64, 4, 4, 2>), dim3(gx, gy, R), dim3(64, 4), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_gather_bwd(MGatherBwd& a) {
+  if (a.O <= 0) { a.gx = a.gy = 0; return a.D > 64 ? MV_GATHER_32x16 : MV_GATHER_16x16; }
+  if (!(a.D % 4 == 0 && a.ldg % 4 == 0 && a.ldo % 4 == 0 && (!a.add1 || (a.ldadd1 % 4 == 0 && al16(a.add1))) &&
+        (!a.masked || (a.ldx % 4 == 0 && al16(a.xprev))) && al16(a.dG) && al16(a.out))) return -1;
+  if (a.D > 64) { a.gx = sln_cdiv(a.D, 128); a.gy = sln_cdiv(a.O, 16); return MV_GATHER_32x16; }
+  a.gx = sln_cdiv(a.D, 64); a.gy = sln_cdiv(a.O, 16);
+  return MV_GATHER_16x16;
+}
+int sln_launch_gather_bwd_multi(const MGatherBwd* tab, int R, int variant, int gx, int gy, hipStream_t st) {
+  if (R <= 0 || gx <= 0 || gy <= 0) return 0;
+  if (variant == MV_GATHER_32x16) hipLaunchKernelGGL((gather_bwd_multi_kernel<32, 16>), dim3(gx, gy, R), dim3(32, 16), 0, st, tab);
+  else hipLaunchKernelGGL((gather_bwd_multi_kernel<16, 16>), dim3(gx, gy, R), dim3(16, 16), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_mask_gstats(MMaskGstats& a) {
+  if (a.rows <= 0) { a.gx = a.gy = 0; return 0; }
+  const dim3 g = colgrid(a.cols, a.rows);
+  a.gx = (int)g.x; a.gy = (int)g.y;
+  return 0;
+}
+int sln_launch_mask_gstats_multi(const MMaskGstats* tab, int R, int gx, int gy, hipStream_t st) {
+  if (R <= 0 || gx <= 0 || gy <= 0) return 0;
+  hipLaunchKernelGGL(mask_gstats_multi_kernel, dim3(gx, gy, R), dim3(CB, RL), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_dec_assemble(MDecAssemble& a) {
+  const long n = (long)a.a.O * (a.a.n_obj + a.a.n_attr + a.a.n_z);
+  a.gx = (int)((n + 255) / 256);
+  return 0;
+}
+int sln_launch_dec_assemble_multi(const MDecAssemble* tab, int R, int gx, hipStream_t st) {
+  if (R <= 0 || gx <= 0) return 0;
+  hipLaunchKernelGGL(dec_assemble_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_dec_assemble_bwd(const DecAssembleBwd& a, void* blob, int* gx, int* smem_floats) {
+  std::memset(blob, 0, SLN_ASM_BLOB);
+  const long n = (long)a.O * (a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0));
+  const long tabs = (long)a.rows_obj * a.n_obj + (long)a.rows_attr * a.n_attr;
+  if (g_sln_deterministic) return -1;
+  if (a.rows_obj > 0 && (a.n_attr == 0 || a.rows_attr > 0) && tabs <= ASSEMBLE_LDS_MAX_FLOATS) {
+    MAsmLds m; std::memset(&m, 0, sizeof(m));
+    AssembleBwdLds& l = m.a;
+    l.dx0 = a.dx0; l.ld = a.n_obj + a.n_attr + (a.z_in_x0 ? a.n_z : 0); l.O = a.O;
+    int k = 0;
+    l.seg[k++] = EmbSeg{a.objs, a.d_obj_emb, a.n_obj, a.rows_obj, 0, 0};
+    if (a.n_attr > 0) l.seg[k++] = EmbSeg{a.attrs, a.d_attr_emb, a.n_attr, a.rows_attr, a.n_obj, 0};
+    l.nseg = k;
+    if (a.z_in_x0 && a.dz) { l.dz = a.dz; l.z_col0 = a.n_obj + a.n_attr; l.n_z = a.n_z; }
+    int off = 0;
+    for (int s = 0; s < l.nseg; ++s) { l.seg[s].lds0 = off; off += l.seg[s].rows * l.seg[s].n; }
+    l.lds_floats = off;
+    l.rows_per_block = 16;                        // (launch_assemble_bwd_lds: 16 up to 8 192 rows; rooms have a few dozen)
+    if (a.O > 8192) return -1;
+    m.gx = n > 0 ? sln_cdiv(a.O, l.rows_per_block) : 0;
+    std::memcpy(blob, &m, sizeof(m));
+    *gx = m.gx; *smem_floats = off;
+    return MV_ASM_BWD_LDS;
+  }
+  MDecAssembleBwd m; std::memset(&m, 0, sizeof(m));
+  m.a = a; m.gx = (int)((n + 255) / 256);
+  std::memcpy(blob, &m, sizeof(m));
+  *gx = m.gx; *smem_floats = 0;
+  return MV_ASM_BWD_PLAIN;
+}
+int sln_launch_dec_assemble_bwd_multi(const void* tab, int R, int variant, int gx, int smem_floats, hipStream_t st) {
+  if (R <= 0 || gx <= 0) return 0;
+  if (variant == MV_ASM_BWD_LDS)
+    hipLaunchKernelGGL(assemble_bwd_lds_multi_kernel, dim3(gx, 1, R), dim3(256), sizeof(float) * (size_t)smem_floats, st, static_cast<const char*>(tab));
+  else hipLaunchKernelGGL(dec_assemble_bwd_plain_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, static_cast<const char*>(tab));
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_embed_gather(MEmbedGather& a) {
+  a.gx = (int)(((long)a.rows * a.n + 255) / 256);
+  return 0;
+}
+int sln_launch_embed_gather_multi(const MEmbedGather* tab, int R, int gx, hipStream_t st) {
+  if (R <= 0 || gx <= 0) return 0;
+  hipLaunchKernelGGL(embed_gather_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_embed_bwd(MEmbedBwd& a, int idx64) {
+  const long tot = (long)a.rows * a.n;
+  const int w = idx64 ? 4 : 0;
+  a.rows_per_block = 16;
+  if (g_sln_deterministic && a.table_rows > 0) { a.gx = tot > 0 ? a.table_rows : 0; a.gy = sln_cdiv(a.n, 64); return w + MV_EMBED_DET; }
+  if (a.table_rows > 0 && (long)a.table_rows * a.n <= 8192) { a.gx = tot > 0 ? sln_cdiv(a.rows, a.rows_per_block) : 0; a.gy = 1; return w + MV_EMBED_LDS; }
+  a.gx = (int)((tot + 255) / 256); a.gy = 1;
+  return w + MV_EMBED_PLAIN;
+}
+int sln_launch_embed_bwd_multi(const MEmbedBwd* tab, int R, int variant, int gx, int gy, int smem_floats, hipStream_t st) {
+  if (R <= 0 || gx <= 0 || gy <= 0) return 0;
+  const dim3 grid(gx, gy, R);
+  switch (variant) {
+    case MV_EMBED_DET: hipLaunchKernelGGL((embed_bwd_multi_kernel<int, MV_EMBED_DET>), grid, dim3(1024), 0, st, tab); break;
+    case MV_EMBED_LDS: hipLaunchKernelGGL((embed_bwd_multi_kernel<int, MV_EMBED_LDS>), grid, dim3(256), sizeof(float) * (size_t)smem_floats, st, tab); break;
+    case MV_EMBED_PLAIN: hipLaunchKernelGGL((embed_bwd_multi_kernel<int, MV_EMBED_PLAIN>), grid, dim3(256), 0, st, tab); break;
+    case 4 + MV_EMBED_DET: hipLaunchKernelGGL((embed_bwd_multi_kernel<int64_t, MV_EMBED_DET>), grid, dim3(1024), 0, st, tab); break;
+    case 4 + MV_EMBED_LDS: hipLaunchKernelGGL((embed_bwd_multi_kernel<int64_t, MV_EMBED_LDS>), grid, dim3(256), sizeof(float) * (size_t)smem_floats, st, tab); break;
+    case 4 + MV_EMBED_PLAIN: hipLaunchKernelGGL((embed_bwd_multi_kernel<int64_t, MV_EMBED_PLAIN>), grid, dim3(256), 0, st, tab); break;
+    default: return -1;
+  }
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_plan_add2(MAdd2& a) {
+  a.gx = (int)(((long)a.rows * a.cols + 255) / 256);
+  return 0;
+}
+int sln_launch_add2_multi(const MAdd2* tab, int R, int gx, hipStream_t st) {
+  if (R <= 0 || gx <= 0) return 0;
+  hipLaunchKernelGGL(add2_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_launch_zero_multi(const MZero* tab, int R, long max_n16, hipStream_t st) {
+  if (R <= 0 || max_n16 <= 0) return 0;
+  hipLaunchKernelGGL(zero_multi_kernel, dim3((unsigned)((max_n16 + 255) / 256), R), dim3(256), 0, st, tab);
   SLN_CHECK_LAUNCH();
   return 0;
 }

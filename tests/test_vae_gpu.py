@@ -622,8 +622,11 @@ def test_tight_gradients_when_no_threshold_is_near(norm, training, n_graphs):
             # Linear -> BatchNorm (a constant shift of that Linear's output).  Any fp32 evaluation returns the rounding residue of
             # the cancelling sum: held to 1e-4 of the scale of the same module's weight gradient (same rows, same dY).
             atol = 1e-4 * float(np.abs(g64[k[:-len("bias")] + "weight"].numpy()).max())
+        # 8 rows under train-mode BatchNorm (1 graph): the problem itself is that ill-conditioned - the reference's own fp32 evaluation
+        # is up to 1.7e-4 from the fp64 gradient there (median 5.7e-5; ours: worst 1.3e-4, median 4.5e-5, tools/lab/bn_rows_probe.py)
+        rtol = 3e-4 if (train_bn and n_graphs == 1) else 1e-4
         try:
-            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=1e-4, atol=atol)
+            assert_close(named[k].grad.cpu().numpy(), ref, "grad:" + k, rtol=rtol, atol=atol)
         except AssertionError as e:
             bad.append(str(e))
     assert not bad, "\n".join(bad[:40])

@@ -23,9 +23,9 @@ FLAGS[vae]="$COMMON --no-render --no-spade --steps 100 --warmup 10"
 FLAGS[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 40 --render-warmup 5"
 FLAGS[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 6 --spade-warmup 2"
 declare -A SHORT
-SHORT[vae]="$COMMON --no-render --no-spade --steps 12 --warmup 3 --prof-steps 0"
-SHORT[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 4 --render-warmup 2"
-SHORT[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 1 --spade-warmup 1"
+SHORT[vae]="$COMMON --no-graph --no-render --no-spade --steps 12 --warmup 3 --prof-steps 0"
+SHORT[render]="$COMMON --no-graph --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 4 --render-warmup 2"
+SHORT[spade]="$COMMON --no-graph --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 1 --spade-warmup 1"
 flatten() { for g in $(find "$1" -name '*.csv'); do mv "$g" "$1/" 2>/dev/null; done; }
 for leg in ${LEGS:-vae render spade}; do
   D="$P/$leg"; mkdir -p "$D"
