@@ -74,7 +74,18 @@ class SlnRefineLoss(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "image_size", "pooled_size", "channels", "sem0", "n_sem", "dep0", "n_dep", "n_scales",
                                        "stage1_stride")] + \
                [(n, C.c_void_p) for n in ("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w")] + \
-               [("max_col_entries", C.c_int), ("reserved", C.c_int)]
+               [("max_col_entries", C.c_int), ("per_room", C.c_int)]
+
+
+class SlnPlacementRoom(C.Structure):
+    _fields_ = [("P", SlnPlacement)] + \
+               [(n, C.c_void_p) for n in ("boxes", "angles", "size_target", "faces_out", "sizes", "size_loss", "grad_faces", "grad_size_loss",
+                                          "grad_boxes", "grad_angles")]
+
+
+class SlnVaeGroupIO(C.Structure):
+    _fields_ = [("rows_total", C.c_int), ("row0_host", C.POINTER(C.c_int))] + \
+               [(n, C.c_void_p) for n in ("z", "boxes_pred", "angles_pred", "d_boxes_pred", "d_angles_pred", "dz")]
 
 
 # name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
@@ -107,6 +118,11 @@ SIGNATURES = {
     "sln_vae_last_eps": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
     "sln_vae_set_training": (C.c_int, [C.c_void_p, C.c_int]),
     "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int, C.c_void_p]),
+    "sln_vae_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SlnVaeGroupIO), C.POINTER(C.c_void_p)]),
+    "sln_vae_group_decoder": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sln_vae_group_decoder_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sln_vae_group_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sln_vae_group_destroy": (None, [C.c_void_p]),
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_set_deterministic": (C.c_int, [C.c_int]),
     "sln_get_deterministic": (C.c_int, []),
@@ -176,6 +192,14 @@ SIGNATURES = {
     "sln_refine_head_forward": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     "sln_refine_head_backward": (C.c_int, [C.c_int, C.c_int, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, c_f32p, C.c_void_p]),
     "sln_refine_sgd": (C.c_int, [c_f32p, c_f32p, C.c_int64, C.c_float, c_f32p, c_f32p, C.c_int64, C.c_float, C.c_void_p]),
+    "sln_refine_head_forward_rooms": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p,
+                                                c_f32p, C.c_void_p]),
+    "sln_refine_head_backward_rooms": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, c_f32p, c_f32p, c_f32p, C.c_float, c_f32p, C.c_int, c_f32p,
+                                                 C.c_void_p]),
+    "sln_place_forward_rooms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sln_place_backward_rooms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "sln_refine_sgd_rooms": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_float, c_f32p, c_f32p,
+                                       C.c_int64, C.c_float, C.c_void_p]),
     "sln_refine_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "sln_refine_loss_init": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, C.c_void_p]),
     "sln_refine_pool": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),

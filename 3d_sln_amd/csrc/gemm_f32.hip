@@ -26,6 +26,7 @@
 #include <algorithm>
 #include <vector>
 #include "gemm_bodies.h"
+#include "vae_multi.h"
 namespace {
 // 64 x 64 tiles with a BatchNorm operand or a masked epilogue run with four helper wavefronts (512 threads, see gemm_nt_body)
 template <int BM, int BN, int AMODE, int EPI>
@@ -50,6 +51,25 @@ template <int AMODE, int EPI, int NSEG = 1>
 __global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt_small_kernel(const GemmNTArgs a, const int xcd) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   gemm_nt_small_body<AMODE, EPI, nt_helpers2<AMODE, EPI>(), NSEG>(a, blockIdx.x, smem, xcd != 0);
+}
+
+// Forward Linears / dgrads of R rooms (R parameter copies) in one grid: blockIdx.y = room, the room's problem comes out of a device
+// table, workgroups beyond its tile count leave (vae_multi.h).  Plain tile order inside a room (a room is a handful of tiles).
+template <int AMODE, int EPI, int NSEG>
+__global__ __launch_bounds__((nt_helpers2<AMODE, EPI>() ? 512 : 256)) void gemm_nt_small_multi_kernel(const GemmNTArgs* __restrict__ tab, const int* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int r = blockIdx.y;
+  if ((int)blockIdx.x >= tiles[r]) return;
+  gemm_nt_small_body<AMODE, EPI, nt_helpers2<AMODE, EPI>(), NSEG>(tab[r], blockIdx.x, smem, false);
+}
+// ... and of the 64 x 64 body, for the operands the small body does not take (box_net's two-segment input [obj_vecs | attr_emb[attrs]])
+template <int AMODE, int EPI, int MULTI>
+__global__ __launch_bounds__((nt_helpers<64, 64, AMODE, EPI>() ? 512 : 256)) void gemm_nt64_multi_kernel(const GemmNTArgs* __restrict__ tab, const int* __restrict__ tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int r = blockIdx.y;
+  const int nt = tiles[r];
+  if ((int)blockIdx.x >= nt) return;
+  gemm_nt_body<64, 64, 2, 2, AMODE, EPI, MULTI, nt_helpers<64, 64, AMODE, EPI>()>(tab[r], blockIdx.x, nt, smem);
 }
 
 }  // namespace
@@ -288,6 +308,73 @@ int sln_launch_gemm_nt(const GemmNTArgs& a, int epi, int tile, hipStream_t st) {
   }
   SLN_DISPATCH(0) SLN_DISPATCH(1) SLN_DISPATCH(2)
 #undef SLN_DISPATCH
+  return -1;
+}
+
+// ---- multi-room form of the 32 x 32 split-K body (vae_multi.h) -------------------------------------------------------------
+int sln_plan_nt_small(const GemmNTArgs& a, int epi, int* tiles) {
+  static const bool no_small = std::getenv("SLN_NO_SMALL_NT") != nullptr;
+  if (no_small || a.M <= 0 || a.N <= 0) return -1;
+  int nseg = 0;
+  const int amode = nt_amode(a);
+  if (amode == 1 || epi == EPI_STATS) return -1;    // train-mode BatchNorm: not instantiated (the refinement loop runs in eval mode)
+  if (nt_wants_small(a)) nseg = 1;                  // the single-room dispatcher's own rules, in its order (sln_launch_gemm_nt)
+  else if (nt_wants_small3(a)) nseg = 3;
+  if (nseg) { *tiles = sln_cdiv(a.M, 32) * sln_cdiv(a.N, 32); return amode * 16 + epi * 4 + nseg; }
+  if (nt_big_shape(a)) return -1;
+  // everything else of a room's size: the 64 x 64 body (key 1000 + ...; last digit: 0 one segment, 1 segments on k-tile
+  // boundaries, 2 a boundary inside a k-tile)
+  *tiles = sln_cdiv(a.M, 64) * sln_cdiv(a.N, 64);
+  return 1000 + amode * 16 + epi * 4 + (a.A.nseg > 1 ? (nt_unaligned(a) ? 2 : 1) : 0);
+}
+
+template <int AMODE, int EPI, int NSEG>
+static int launch_nt_small_multi(const GemmNTArgs* tab, const int* tiles, int R, int max_tiles, size_t smem, hipStream_t st) {
+  static bool raised = false;
+  if (smem > 48 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_small_multi_kernel<AMODE, EPI, NSEG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_small_multi_kernel<AMODE, EPI, NSEG>), dim3(max_tiles, R), dim3(nt_helpers2<AMODE, EPI>() ? 512 : 256), smem, st, tab, tiles);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+template <int AMODE, int EPI, int MULTI>
+static int launch_nt64_multi(const GemmNTArgs* tab, const int* tiles, int R, int max_tiles, size_t smem, hipStream_t st) {
+  static bool raised = false;
+  if (smem > 48 * 1024 && !raised) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt64_multi_kernel<AMODE, EPI, MULTI>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL((gemm_nt64_multi_kernel<AMODE, EPI, MULTI>), dim3(max_tiles, R), dim3(nt_helpers<64, 64, AMODE, EPI>() ? 512 : 256), smem, st, tab, tiles);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_launch_gemm_nt_small_multi(const GemmNTArgs* tab, const int* tiles_dev, int R, int key, int max_tiles, int max_K, double flops,
+                                   hipStream_t st) {
+  if (R <= 0 || max_tiles <= 0) return 0;
+  SlnProfScope prof(SLN_FAM_GEMM_NT, flops, st);
+  if (key >= 1000) {
+    const size_t smem64 = nt_smem_bytes(max_K, 64, 64, 2);
+    const int am = (key - 1000) / 16, ep = ((key - 1000) / 4) % 4, mu = (key - 1000) % 4;
+#define SLN_NT64M(AM, EP, MU) if (am == AM && ep == EP && mu == MU) return launch_nt64_multi<AM, EP, MU>(tab, tiles_dev, R, max_tiles, smem64, st);
+    SLN_NT64M(0, EPI_PLAIN, 0) SLN_NT64M(0, EPI_PLAIN, 1) SLN_NT64M(0, EPI_PLAIN, 2) SLN_NT64M(0, EPI_MASK, 0) SLN_NT64M(0, EPI_MASK, 1) SLN_NT64M(0, EPI_MASK, 2)
+    SLN_NT64M(2, EPI_PLAIN, 0) SLN_NT64M(2, EPI_PLAIN, 1) SLN_NT64M(2, EPI_PLAIN, 2) SLN_NT64M(2, EPI_MASK, 0) SLN_NT64M(2, EPI_MASK, 1) SLN_NT64M(2, EPI_MASK, 2)
+#undef SLN_NT64M
+    return -1;
+  }
+  const size_t smem = nt_small_smem_bytes(max_K);
+  const int amode = key / 16, epi = (key / 4) % 4, nseg = key % 4;
+#define SLN_NTM(AM, EP, NS) if (amode == AM && epi == EP && nseg == NS) return launch_nt_small_multi<AM, EP, NS>(tab, tiles_dev, R, max_tiles, smem, st);
+  SLN_NTM(0, EPI_PLAIN, 1) SLN_NTM(0, EPI_PLAIN, 3) SLN_NTM(0, EPI_MASK, 1) SLN_NTM(0, EPI_MASK, 3)
+  SLN_NTM(2, EPI_PLAIN, 1) SLN_NTM(2, EPI_PLAIN, 3) SLN_NTM(2, EPI_MASK, 1) SLN_NTM(2, EPI_MASK, 3)
+#undef SLN_NTM
   return -1;
 }
 

@@ -14,6 +14,7 @@
 // registers / LDS and applies the chain rule to the box row and the angle - no atomics, deterministic.
 #include <algorithm>
 #include <cstdint>
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -73,9 +74,9 @@ __device__ __forceinline__ int object_of_face(const SlnPlacement& P, int f) {
   return k;                                         // == n_vis: room shell
 }
 
-__global__ __launch_bounds__(256) void place_forward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
-                                                            const float* __restrict__ size_target, float* __restrict__ fxyz,
-                                                            float* __restrict__ sizes, float* __restrict__ size_loss) {
+__device__ __forceinline__ void place_forward_body(const SlnPlacement& P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                   const float* __restrict__ size_target, float* __restrict__ fxyz,
+                                                   float* __restrict__ sizes, float* __restrict__ size_loss) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0 && threadIdx.x < 64) {        // sizes and the size loss: one wavefront
     float l = 0.f;
@@ -123,11 +124,22 @@ __global__ __launch_bounds__(256) void place_forward_kernel(SlnPlacement P, cons
   }
 }
 
+__global__ __launch_bounds__(256) void place_forward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                            const float* __restrict__ size_target, float* __restrict__ fxyz,
+                                                            float* __restrict__ sizes, float* __restrict__ size_loss) {
+  place_forward_body(P, boxes, angles, size_target, fxyz, sizes, size_loss);
+}
+__global__ __launch_bounds__(256) void place_forward_rooms_kernel(const SlnPlacementRoom* __restrict__ rooms) {
+  const SlnPlacementRoom& r = rooms[blockIdx.y];
+  if ((int)blockIdx.x * 256 >= r.P.F && blockIdx.x != 0) return;
+  place_forward_body(r.P, r.boxes, r.angles, r.size_target, r.faces_out, r.sizes, r.size_loss);
+}
+
 // one workgroup per row of `boxes`; rows without a visible object get zero gradients
-__global__ __launch_bounds__(256) void place_backward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
-                                                             const float* __restrict__ size_target, const float* __restrict__ gf,
-                                                             const float* __restrict__ g_size_loss, float* __restrict__ g_boxes,
-                                                             float* __restrict__ g_angles) {
+__device__ __forceinline__ void place_backward_body(const SlnPlacement& P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                    const float* __restrict__ size_target, const float* __restrict__ gf,
+                                                    const float* __restrict__ g_size_loss, float* __restrict__ g_boxes,
+                                                    float* __restrict__ g_angles) {
   const int row = blockIdx.x;
   int k = -1;
   for (int q = 0; q < P.n_vis; ++q) k = P.vis[q] == row ? q : k;
@@ -204,18 +216,32 @@ __global__ __launch_bounds__(256) void place_backward_kernel(SlnPlacement P, con
   }
 }
 
+__global__ __launch_bounds__(256) void place_backward_kernel(SlnPlacement P, const float* __restrict__ boxes, const float* __restrict__ angles,
+                                                             const float* __restrict__ size_target, const float* __restrict__ gf,
+                                                             const float* __restrict__ g_size_loss, float* __restrict__ g_boxes,
+                                                             float* __restrict__ g_angles) {
+  place_backward_body(P, boxes, angles, size_target, gf, g_size_loss, g_boxes, g_angles);
+}
+__global__ __launch_bounds__(256) void place_backward_rooms_kernel(const SlnPlacementRoom* __restrict__ rooms) {
+  const SlnPlacementRoom& r = rooms[blockIdx.y];
+  if ((int)blockIdx.x >= r.P.n) return;
+  place_backward_body(r.P, r.boxes, r.angles, r.size_target, r.grad_faces, r.grad_size_loss, r.grad_boxes, r.grad_angles);
+}
+
 // ---- the torch glue between the decoder and the placement as one kernel each way (testing/test_render_refine.py:296-306) ----
 // forward: boxes_full = [boxes_pred[:-1] ; box_last], idx = [softargmax(angles_pred, beta)[:-1] + noise[:-1] / 10 ; angle_last]
 // with softargmax(x) = sum_j softmax(beta x)_j (j + 1) - 1 (:20-25).  One thread per row.
+// (room_of_row / last_row: rows of several rooms concatenated - box_last [R,6], angle_last [R]; nullptr: one room of n rows)
 __global__ void refine_head_forward_kernel(int n, int na, const float* __restrict__ boxes_pred, const float* __restrict__ angles_pred,
                                            const float* __restrict__ noise, const float* __restrict__ box_last,
                                            const float* __restrict__ angle_last, float beta, float* __restrict__ boxes_full,
-                                           float* __restrict__ idx) {
+                                           float* __restrict__ idx, const int* __restrict__ room_of_row, const int* __restrict__ last_row) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool lastrow = i == n - 1;
-  for (int j = 0; j < 6; ++j) boxes_full[6 * i + j] = lastrow ? box_last[j] : boxes_pred[6 * i + j];
-  if (lastrow) { idx[i] = angle_last[0]; return; }
+  const int room = room_of_row ? room_of_row[i] : 0;
+  const bool lastrow = i == (room_of_row ? last_row[room] : n - 1);
+  for (int j = 0; j < 6; ++j) boxes_full[6 * i + j] = lastrow ? box_last[6 * room + j] : boxes_pred[6 * i + j];
+  if (lastrow) { idx[i] = angle_last[room]; return; }
   const float* a = angles_pred + (size_t)i * na;
   float m = -INFINITY;
   for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
@@ -227,14 +253,16 @@ __global__ void refine_head_forward_kernel(int n, int na, const float* __restric
 // box row receive the mean of the two halves' gradients, :217-224); the frozen last row receives zeros.
 __global__ void refine_head_backward_kernel(int n, int na, const float* __restrict__ angles_pred, const float* __restrict__ g_boxes_full,
                                             const float* __restrict__ g_idx, float beta, float* __restrict__ g_boxes_pred,
-                                            float* __restrict__ g_angles_pred) {
+                                            float* __restrict__ g_angles_pred, const int* __restrict__ room_of_row,
+                                            const int* __restrict__ last_row, const int ld_gb) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const bool lastrow = i == n - 1;
+  const bool lastrow = i == (room_of_row ? last_row[room_of_row[i]] : n - 1);
   for (int j = 0; j < 3; ++j) {
     const float avg = lastrow ? 0.f : g_boxes_full[6 * i + 3 + j] / 2.0f + g_boxes_full[6 * i + j] / 2.0f;
-    g_boxes_pred[6 * i + j] = avg; g_boxes_pred[6 * i + 3 + j] = avg;
+    g_boxes_pred[(size_t)ld_gb * i + j] = avg; g_boxes_pred[(size_t)ld_gb * i + 3 + j] = avg;
   }
+  for (int j = 6; j < ld_gb; ++j) g_boxes_pred[(size_t)ld_gb * i + j] = 0.f;
   float* ga = g_angles_pred + (size_t)i * na;
   if (lastrow) { for (int j = 0; j < na; ++j) ga[j] = 0.f; return; }
   const float* a = angles_pred + (size_t)i * na;
@@ -263,6 +291,23 @@ __global__ void refine_sgd_kernel(float* __restrict__ p, float* __restrict__ g, 
     p[k] -= step * g[k]; g[k] = 0.f;
   }
   if (i < nz) z[i] -= step_z * gz[i];
+}
+
+// R parameter copies, up to four ranges each (see sln_refine_sgd_rooms); blockIdx.y = room * n_ranges + range
+struct SgdRanges { long off[4], len[4]; int n; };
+__global__ void refine_sgd_rooms_kernel(float* __restrict__ p, float* __restrict__ g, long stride, SgdRanges rg, float step, float* __restrict__ z,
+                                        const float* __restrict__ gz, long nz, float step_z) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int room = blockIdx.y / rg.n, k = blockIdx.y % rg.n;
+  if (i < (rg.len[k] >> 2)) {
+    const long e = (long)room * stride + rg.off[k] + 4 * i;
+    float4 pv = *reinterpret_cast<float4*>(p + e);
+    const float4 gv = *reinterpret_cast<const float4*>(g + e);
+    pv.x -= step * gv.x; pv.y -= step * gv.y; pv.z -= step * gv.z; pv.w -= step * gv.w;
+    *reinterpret_cast<float4*>(p + e) = pv;
+    *reinterpret_cast<float4*>(g + e) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (blockIdx.y == 0 && i < nz) z[i] -= step_z * gz[i];
 }
 
 int check(const SlnPlacement* P) {
@@ -302,7 +347,7 @@ int sln_refine_head_forward(int n, int n_angle, const float* boxes_pred, const f
                             const float* box_last, const float* angle_last, float beta, float* boxes_full, float* idx, void* stream) {
   if (n <= 0 || n_angle <= 0 || !boxes_pred || !angles_pred || !box_last || !angle_last || !boxes_full || !idx) return SLN_E_BADARG;
   hipLaunchKernelGGL(refine_head_forward_kernel, dim3(sln_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, n, n_angle, boxes_pred,
-                     angles_pred, noise, box_last, angle_last, beta, boxes_full, idx);
+                     angles_pred, noise, box_last, angle_last, beta, boxes_full, idx, (const int*)nullptr, (const int*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -311,7 +356,62 @@ int sln_refine_head_backward(int n, int n_angle, const float* angles_pred, const
                              float beta, float* grad_boxes_pred, float* grad_angles_pred, void* stream) {
   if (n <= 0 || n_angle <= 0 || !angles_pred || !grad_boxes_full || !grad_idx || !grad_boxes_pred || !grad_angles_pred) return SLN_E_BADARG;
   hipLaunchKernelGGL(refine_head_backward_kernel, dim3(sln_cdiv(n, 64)), dim3(64), 0, (hipStream_t)stream, n, n_angle, angles_pred,
-                     grad_boxes_full, grad_idx, beta, grad_boxes_pred, grad_angles_pred);
+                     grad_boxes_full, grad_idx, beta, grad_boxes_pred, grad_angles_pred, (const int*)nullptr, (const int*)nullptr, 6);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_head_forward_rooms(int rows_total, int n_angle, const int32_t* room_of_row, const int32_t* last_row, const float* boxes_pred,
+                                  const float* angles_pred, const float* noise, const float* box_last, const float* angle_last, float beta,
+                                  float* boxes_full, float* idx, void* stream) {
+  if (rows_total <= 0 || n_angle <= 0 || !room_of_row || !last_row || !boxes_pred || !angles_pred || !box_last || !angle_last || !boxes_full || !idx)
+    return SLN_E_BADARG;
+  hipLaunchKernelGGL(refine_head_forward_kernel, dim3(sln_cdiv(rows_total, 64)), dim3(64), 0, (hipStream_t)stream, rows_total, n_angle, boxes_pred,
+                     angles_pred, noise, box_last, angle_last, beta, boxes_full, idx, room_of_row, last_row);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_head_backward_rooms(int rows_total, int n_angle, const int32_t* room_of_row, const int32_t* last_row, const float* angles_pred,
+                                   const float* grad_boxes_full, const float* grad_idx, float beta, float* grad_boxes_pred, int ld_gb,
+                                   float* grad_angles_pred, void* stream) {
+  if (rows_total <= 0 || n_angle <= 0 || !room_of_row || !last_row || !angles_pred || !grad_boxes_full || !grad_idx || !grad_boxes_pred ||
+      !grad_angles_pred || ld_gb < 6) return SLN_E_BADARG;
+  hipLaunchKernelGGL(refine_head_backward_kernel, dim3(sln_cdiv(rows_total, 64)), dim3(64), 0, (hipStream_t)stream, rows_total, n_angle, angles_pred,
+                     grad_boxes_full, grad_idx, beta, grad_boxes_pred, grad_angles_pred, room_of_row, last_row, ld_gb);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_place_forward_rooms(const SlnPlacementRoom* rooms, int R, int F_max, void* stream) {
+  if (!rooms || R <= 0 || F_max <= 0) return SLN_E_BADARG;
+  hipLaunchKernelGGL(place_forward_rooms_kernel, dim3(sln_cdiv(F_max, 256), R), dim3(256), 0, (hipStream_t)stream, rooms);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_place_backward_rooms(const SlnPlacementRoom* rooms, int R, int n_max, void* stream) {
+  if (!rooms || R <= 0 || n_max <= 0) return SLN_E_BADARG;
+  hipLaunchKernelGGL(place_backward_rooms_kernel, dim3(n_max, R), dim3(256), 0, (hipStream_t)stream, rooms);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
+int sln_refine_sgd_rooms(float* params, float* grads, int R, int64_t stride, const int64_t* off_host, const int64_t* len_host, int n_ranges,
+                         float step, float* z, const float* grad_z, int64_t nz, float step_z, void* stream) {
+  if (!params || !grads || R <= 0 || n_ranges < 1 || n_ranges > 4 || !off_host || !len_host || nz < 0 || (nz > 0 && (!z || !grad_z))) return SLN_E_BADARG;
+  if (((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) || (stride & 3)) return SLN_E_BADARG;
+  SgdRanges rg; std::memset(&rg, 0, sizeof(rg));
+  rg.n = n_ranges;
+  long work = nz;
+  for (int k = 0; k < n_ranges; ++k) {
+    if ((off_host[k] & 3) || (len_host[k] & 3) || off_host[k] < 0 || len_host[k] < 0 || off_host[k] + len_host[k] > stride) return SLN_E_BADARG;
+    rg.off[k] = (long)off_host[k]; rg.len[k] = (long)len_host[k];
+    work = std::max<long>(work, len_host[k] >> 2);
+  }
+  if (work <= 0) return 0;
+  hipLaunchKernelGGL(refine_sgd_rooms_kernel, dim3((unsigned)((work + 255) / 256), R * n_ranges), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     (long)stride, rg, step, z, grad_z, (long)nz, step_z);
   SLN_CHECK_LAUNCH();
   return 0;
 }

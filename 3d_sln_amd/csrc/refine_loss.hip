@@ -27,6 +27,7 @@ struct RefineDims {
   int B, S, P, C;                 // batch, image size, pooled size, image channels (70)
   int sem0, n_sem, dep0, n_dep;   // semantic channels [sem0, sem0 + n_sem), depth channels [dep0, dep0 + n_dep) (contiguous)
   int n_scales, pmax;             // pmax: row length of the stage-1 tables (largest intermediate size)
+  int per_room, pad_;             // per_room: B independent rooms - every room's loss is normalised by its OWN element / label counts
 };
 
 __global__ void null_mask_kernel(const float* __restrict__ img, RefineDims d, unsigned char* __restrict__ null) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
 #pragma unroll
         for (int c = 0; c < NSEM; ++c) z += expf(v[c] - m);
         const float lse = m + logf(z);
-        const float k = inv_count[s] * (1.f / 800.f);
+        const float k = inv_count[d.per_room ? b * d.n_scales + s : s] * (1.f / 800.f);
         float vt = 0.f;
 #pragma unroll
         for (int c = 0; c < NSEM; ++c) {
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
         for (int c = 0; c < NSEM; ++c) p[c * pp] = 0.f;
       }
     } else {                                                                       // depth channels, DCH per thread
-      const float gd = 50.f / (float)((double)d.B * d.n_scales * d.n_dep * pp);      // 100 * 0.5 / numel
+      const float gd = 50.f / (float)((double)(d.per_room ? 1 : d.B) * d.n_scales * d.n_dep * pp);      // 100 * 0.5 / numel
       const float* tg = tgt_depth + ((long)(b * d.n_scales + s) * d.n_dep) * pp + pix;
       float* q = p + (long)d.n_sem * pp;
       const int c0 = ((int)blockIdx.y - 1) * DCH;
@@ -159,16 +160,24 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
   if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = make_float2(red[0][0] + red[1][0], red[0][1] + red[1][1]);
 }
 
-__global__ __launch_bounds__(256) void loss_finalize_kernel(const float2* __restrict__ partial, int n, RefineDims d, float* __restrict__ loss_out) {
+// per_room: workgroup b sums room b's partials - gx blocks per part row of which the room owns bpr consecutive ones (a block of
+// loss_kernel never straddles two rooms, checked by the launcher) - in the order the B = 1 launch sums its own
+__global__ __launch_bounds__(256) void loss_finalize_kernel(const float2* __restrict__ partial, int n, RefineDims d, float* __restrict__ loss_out,
+                                                            const int gx, const int bpr) {
   __shared__ double red[4][2];
   double a = 0.0, c = 0.0;
+  if (d.per_room) {
+    const int b = blockIdx.x, ny = n / gx;
+    loss_out += 3 * b;
+    for (int i = threadIdx.x; i < ny * bpr; i += 256) { const float2 v = partial[(i / bpr) * gx + b * bpr + (i % bpr)]; a += (double)v.x; c += (double)v.y; }
+  } else
   for (int i = threadIdx.x; i < n; i += 256) { const float2 v = partial[i]; a += (double)v.x; c += (double)v.y; }
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); c += __shfl_down(c, o, 64); }
   if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
     a = red[0][0] + red[1][0] + red[2][0] + red[3][0]; c = red[0][1] + red[1][1] + red[2][1] + red[3][1];
-    const double depth = 0.5 * a / ((double)d.B * d.n_scales * d.n_dep * d.P * d.P);
+    const double depth = 0.5 * a / ((double)(d.per_room ? 1 : d.B) * d.n_scales * d.n_dep * d.P * d.P);
     loss_out[0] = (float)(100.0 * depth + 100.0 * c); loss_out[1] = (float)depth; loss_out[2] = (float)c;
   }
 }
@@ -308,6 +317,7 @@ static RefineDims dims_of(const SlnRefineLoss* L) {
   RefineDims d;
   d.B = L->B; d.S = L->image_size; d.P = L->pooled_size; d.C = L->channels; d.sem0 = L->sem0; d.n_sem = L->n_sem; d.dep0 = L->dep0;
   d.n_dep = L->n_dep; d.n_scales = L->n_scales; d.pmax = L->stage1_stride;
+  d.per_room = L->per_room != 0; d.pad_ = 0;
   return d;
 }
 
@@ -355,7 +365,10 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   const long nl = (long)d.B * d.n_scales * d.P * d.P;
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
   hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial);
-  hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out);
+  const long per_room_rows = (long)d.n_scales * d.P * d.P;
+  if (d.per_room && per_room_rows % 128 != 0) return SLN_E_UNSUPPORTED;       // a block of loss_kernel would cover two rooms
+  hipLaunchKernelGGL(loss_finalize_kernel, dim3(d.per_room ? d.B : 1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out, (int)lg.x,
+                     (int)(per_room_rows / 128));
   SLN_CHECK_LAUNCH();
   return 0;
 }

@@ -14,9 +14,23 @@
 #include "../../include/sln_hip.h"
 #include "sln_gemm.h"
 #include "vae_kernels.h"
+#include "vae_multi.h"
 #include "sln_prof.h"
 
 namespace {
+
+// ---- recording (round 5: R rooms in flight, see SlnVaeGroup at the end of this file) ----------------------------------------
+// With `rec` set, the decoder's forward / backward pass of an engine does not launch anything: every launch site appends its
+// fully resolved argument block to the list.  The group walks the lists of its R engines in lock step and turns step s of all
+// rooms into ONE multi-room launch (vae_multi.h).
+enum { SK_DEC_ASSEMBLE = 0, SK_EMBED_GATHER, SK_NT, SK_SCATTER_FWD, SK_TN, SK_TN_FLUSH, SK_MASK_GSTATS, SK_ADD2, SK_EMBED_BWD,
+       SK_SCATTER_BWD, SK_GATHER_BWD, SK_DEC_ASSEMBLE_BWD, SK_COPY2D };
+struct RecStep {
+  int kind = -1, epi = 0, idx64 = 0;
+  GemmNTArgs nt; GemmTNArgs tn;
+  MScatterFwd sf; MScatterBwd sb; MGatherBwd gb; MMaskGstats mg; MDecAssemble da; DecAssembleBwd dab; MEmbedGather eg; MEmbedBwd eb; MAdd2 a2;
+};
+struct Recorder { std::vector<RecStep> steps; };
 
 constexpr float kBnEps = 1e-5f;
 constexpr float kBnMomentum = 0.1f;
@@ -225,6 +239,7 @@ struct SlnVae {
   }
   hipStream_t tn_eager_stream = nullptr;         // the stream whose launches read the eager table set (set 1) last
   int flush_deferred(int which, hipStream_t st) {
+    if (rec) { rec_push(SK_TN_FLUSH); return 0; }
     if (deferred.empty()) return 0;
     const int set = capturing ? 0 : 1;
     if (set == 1 && tn_eager_stream != st) {
@@ -442,6 +457,7 @@ struct SlnVae {
     a.M = M; a.N = u.out; a.K = u.in; a.ldw = u.in;
     int epi = EPI_PLAIN;
     if (inst >= 0 && bn_mode(bns[inst], training) == SLN_BN_TRAIN) { epi = EPI_STATS; a.osums = bns[inst].sums; a.ocstride = bns[inst].C; }
+    if (rec) { RecStep& r = rec_push(SK_NT); r.nt = a; r.epi = epi; return 0; }
     if (grouping) { GroupItem it; it.nt = a; it.epi = epi; it.has_tn = false; group_items.push_back(it); return 0; }
     return sln_launch_gemm_nt(a, epi, -1, st);
   }
@@ -459,6 +475,7 @@ struct SlnVae {
       a.obn = view(mask_inst, 0, training);
       if (a.obn.mode != SLN_BN_NONE) { a.ogsums = bns[mask_inst].gsums; a.ocstride = bns[mask_inst].C; }
     }
+    if (rec) { RecStep& r = rec_push(SK_NT); r.nt = a; r.epi = epi; return 0; }
     if (grouping) {
       GroupItem it; it.nt = a; it.epi = epi; it.has_tn = !pending.empty();
       if (it.has_tn) { it.tn = pending.front(); pending.erase(pending.begin()); }
@@ -477,6 +494,7 @@ struct SlnVae {
     GemmTNArgs a; std::memset(&a, 0, sizeof(a));
     a.G = G; a.X = X; a.dW = u.p.d_weight; a.db = u.p.d_bias; a.lddw = u.in;
     a.R = R; a.Nout = u.out; a.Kin = u.in; a.rows_per_block = 0;
+    if (rec) { rec_push(SK_TN).tn = a; return 0; }
     if (defer) { deferred.push_back(a); return 0; }
     if (use_dual) { pending.push_back(a); return 0; }
     if (use_side && side) {
@@ -485,6 +503,83 @@ struct SlnVae {
       return sln_launch_gemm_tn(a, -1, side);
     }
     return sln_launch_gemm_tn(a, -1, st);
+  }
+
+  // ---- launch sites of the decoder path: launch, or record (see Recorder) ----
+  Recorder* rec = nullptr;
+  RecStep& rec_push(int kind) { rec->steps.emplace_back(); RecStep& r = rec->steps.back(); r.kind = kind; return r; }
+  int k_scatter_fwd(const float* A2, int ld, int Hh, int D, BnView bn, GraphCsr gg, int Oo, float* pooled, hipStream_t st) {
+    if (!rec) return sln_launch_scatter_avg_fwd(A2, ld, Hh, D, bn, gg, Oo, pooled, st);
+    MScatterFwd& m = rec_push(SK_SCATTER_FWD).sf; std::memset(&m, 0, sizeof(m));
+    m.A2 = A2; m.ld = ld; m.H = Hh; m.D = D; m.bn = bn; m.g = gg; m.O = Oo; m.pooled = pooled;
+    return 0;
+  }
+  int k_scatter_bwd(const float* dM_, const float* dP, int lddp, int dpcol0, const float* A2, int ld, int Hh, int D, BnView bn, GraphCsr gg, int Tt,
+                    float* g2, double* gsums, int cstride, hipStream_t st) {
+    if (!rec) return sln_launch_scatter_avg_bwd(dM_, dP, lddp, dpcol0, A2, ld, Hh, D, bn, gg, Tt, g2, gsums, cstride, st);
+    MScatterBwd& m = rec_push(SK_SCATTER_BWD).sb; std::memset(&m, 0, sizeof(m));
+    m.dM = dM_; m.dP = dP; m.lddp = lddp; m.dpcol0 = dpcol0; m.A2 = A2; m.ld = ld; m.H = Hh; m.D = D; m.bn = bn; m.g = gg; m.T = Tt; m.g2 = g2;
+    m.gsums = gsums; m.cstride = cstride;
+    return 0;
+  }
+  int k_gather_bwd(const float* dGp, int ldg, int D, GraphCsr gg, int Oo, const float* add1, int ldadd1, const float* xprev, int ldx, BnView bn,
+                   int masked, float* out, int ldo, double* gsums, int cstride, hipStream_t st) {
+    if (!rec) return sln_launch_gather_bwd(dGp, ldg, D, gg, Oo, add1, ldadd1, xprev, ldx, bn, masked, out, ldo, gsums, cstride, st);
+    MGatherBwd& m = rec_push(SK_GATHER_BWD).gb; std::memset(&m, 0, sizeof(m));
+    m.dG = dGp; m.ldg = ldg; m.D = D; m.g = gg; m.O = Oo; m.add1 = add1; m.ldadd1 = ldadd1; m.xprev = xprev; m.ldx = ldx; m.bn = bn; m.masked = masked;
+    m.out = out; m.ldo = ldo; m.gsums = gsums; m.cstride = cstride;
+    return 0;
+  }
+  int k_mask_gstats(const float* d1, int ld1, const float* d2, int ld2, const float* xprev, int ldx, BnView bn, int rows, int cols, float* out, int ldo,
+                    double* gsums, int cstride, hipStream_t st) {
+    if (!rec) return sln_launch_mask_gstats(d1, ld1, d2, ld2, xprev, ldx, bn, rows, cols, out, ldo, gsums, cstride, st);
+    MMaskGstats& m = rec_push(SK_MASK_GSTATS).mg; std::memset(&m, 0, sizeof(m));
+    m.d1 = d1; m.ld1 = ld1; m.d2 = d2; m.ld2 = ld2; m.xprev = xprev; m.ldx = ldx; m.bn = bn; m.rows = rows; m.cols = cols; m.out = out; m.ldo = ldo;
+    m.gsums = gsums; m.cstride = cstride;
+    return 0;
+  }
+  int k_embed_gather(const int* idx, const float* emb, int rows, int n, float* out, hipStream_t st) {
+    if (!rec) return sln_launch_embed_gather_i32(idx, emb, rows, n, out, st);
+    MEmbedGather& m = rec_push(SK_EMBED_GATHER).eg; std::memset(&m, 0, sizeof(m));
+    m.idx = idx; m.emb = emb; m.rows = rows; m.n = n; m.out = out;
+    return 0;
+  }
+  int k_embed_bwd(const void* idx, int idx64, const float* d, int ld, int col0, int rows, int n, int table_rows, float* d_emb, hipStream_t st) {
+    if (!rec) return idx64 ? sln_launch_embed_bwd_i64(static_cast<const int64_t*>(idx), d, ld, col0, rows, n, table_rows, d_emb, st)
+                           : sln_launch_embed_bwd_i32(static_cast<const int*>(idx), d, ld, col0, rows, n, table_rows, d_emb, st);
+    RecStep& r = rec_push(SK_EMBED_BWD); r.idx64 = idx64;
+    MEmbedBwd& m = r.eb; std::memset(&m, 0, sizeof(m));
+    m.idx = idx; m.d = d; m.ld = ld; m.col0 = col0; m.rows = rows; m.n = n; m.table_rows = table_rows; m.d_emb = d_emb;
+    return 0;
+  }
+  int k_add2(const float* a, int lda, const float* b, int ldb, int rows, int cols, float* out, int ldo, hipStream_t st) {
+    if (!rec) return sln_launch_add2(a, lda, b, ldb, rows, cols, out, ldo, st);
+    MAdd2& m = rec_push(SK_ADD2).a2; std::memset(&m, 0, sizeof(m));
+    m.a = a; m.lda = lda; m.b = b; m.ldb = ldb; m.rows = rows; m.cols = cols; m.out = out; m.ldo = ldo;
+    return 0;
+  }
+  int k_dec_assemble(const DecAssemble& da, hipStream_t st) {
+    if (!rec) return sln_launch_dec_assemble(da, st);
+    MDecAssemble& m = rec_push(SK_DEC_ASSEMBLE).da; std::memset(&m, 0, sizeof(m));
+    m.a = da;
+    return 0;
+  }
+  int k_dec_assemble_bwd(const DecAssembleBwd& db, hipStream_t st) {
+    if (!rec) return sln_launch_dec_assemble_bwd(db, st);
+    if (g_sln_deterministic && db.rows_obj > 0 && (db.n_attr == 0 || db.rows_attr > 0)) {
+      // the deterministic form of sln_launch_dec_assemble_bwd, piece by piece: one table at a time in row order, then the dz columns
+      const int ld = db.n_obj + db.n_attr + (db.z_in_x0 ? db.n_z : 0);
+      int r = k_embed_bwd(db.objs, 1, db.dx0, ld, 0, db.O, db.n_obj, db.rows_obj, db.d_obj_emb, st);
+      if (!r && db.n_attr > 0) r = k_embed_bwd(db.attrs, 1, db.dx0, ld, db.n_obj, db.O, db.n_attr, db.rows_attr, db.d_attr_emb, st);
+      if (r) return r;
+      if (db.z_in_x0 && db.dz) {
+        MAdd2& m = rec_push(SK_COPY2D).a2; std::memset(&m, 0, sizeof(m));
+        m.a = db.dx0 + db.n_obj + db.n_attr; m.lda = ld; m.b = nullptr; m.ldb = 0; m.rows = db.O; m.cols = db.n_z; m.out = db.dz; m.ldo = db.n_z;
+      }
+      return 0;
+    }
+    rec_push(SK_DEC_ASSEMBLE_BWD).dab = db;
+    return 0;
   }
 
   size_t carve(void* base, int mo, int mt);
@@ -607,7 +702,7 @@ int SlnVae::gconv_forward(int gi, bool training, hipStream_t st) {
   RET_IF(linear_fwd(layer_input(gi, training), ly.u0 + 0, ly.A1, H, 0, T, ly.bn[0], training, st));
   RET_IF(linear_fwd(op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, training), T), ly.u0 + 1, ly.A2, 2 * H + Do, 0, T, ly.bn[1],
                     training, st));
-  RET_IF(sln_launch_scatter_avg_fwd(ly.A2, 2 * H + Do, H, Do, view(ly.bn[1], 0, training), g, O, ly.M, st));
+  RET_IF(k_scatter_fwd(ly.A2, 2 * H + Do, H, Do, view(ly.bn[1], 0, training), g, O, ly.M, st));
   RET_IF(linear_fwd(op1(seg_ident(ly.M, H, 0, H, 0), O), ly.u0 + 2, ly.A3, H, 0, O, ly.bn[2], training, st));
   RET_IF(linear_fwd(op1(seg_act(ly.A3, H, 0, H, ly.bn[2], 0, training), O), ly.u0 + 3, ly.A4, Do, 0, O, ly.bn[3], training,
                     st));
@@ -632,8 +727,8 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   RET_IF(linear_dgrad(G3, ly.u0 + 2, dM, H, O, nullptr, 0, -1, false, nullptr, 0, tr, st));
   // avg-pool backward (a gather) + relu/BN mask of A2
   BnView v2 = view(ly.bn[1], 0, tr);
-  RET_IF(sln_launch_scatter_avg_bwd(dM, dP, lddp, dpcol0, ly.A2, C2, H, Do, v2, g, T, g2,
-                                    v2.mode != SLN_BN_NONE ? bns[ly.bn[1]].gsums : nullptr, C2, st));
+  RET_IF(k_scatter_bwd(dM, dP, lddp, dpcol0, ly.A2, C2, H, Do, v2, g, T, g2,
+                       v2.mode != SLN_BN_NONE ? bns[ly.bn[1]].gsums : nullptr, C2, st));
   // net1.1 : h1 -> A2
   Operand G2 = op1(seg_bwd(g2, C2, ly.A2, C2, C2, ly.bn[1], tr), T);
   RET_IF(linear_wgrad(G2, op1(seg_act(ly.A1, H, 0, H, ly.bn[0], 0, tr), T), ly.u0 + 1, T, st));
@@ -702,8 +797,8 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   da.mu = mu; da.logvar = logvar; da.eps = eps; da.z_in = z_ext;
   da.O = O; da.n_obj = n_obj_e; da.n_attr = n_attr_e; da.n_z = E; da.use_ae = cfg.use_ae;
   da.z = z; da.x0 = X0d; da.z_in_x0 = cfg.decoder_cat ? 1 : 0;
-  RET_IF(sln_launch_dec_assemble(da, st));
-  if (!it_prologue) RET_IF(sln_launch_embed_gather_i32(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
+  RET_IF(k_dec_assemble(da, st));
+  if (!it_prologue) RET_IF(k_embed_gather(g.p, t.pred_emb_dc, T, Ddc, P0d, st));
   for (int l = 0; l < L; ++l) RET_IF(gconv_forward(L + l, training, st));
   // box_net([obj_vecs | attr_vecs]) and angle_net(obj_vecs)  (Sg2ScVAE_model.py:166-171)
   begin_group();
@@ -716,7 +811,7 @@ int SlnVae::decoder_forward(const float* z_ext, const float* eps, bool training,
   RET_IF(linear_fwd(op1(seg_act(anA1, H, 0, H, bn_head[5], 0, training), O), unit_anglenet(1), logits, cfg.n_angle, 0, O, -1,
                     training, st));
   RET_IF(end_group(st));
-  if (!it_fused_loss) RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));
+  if (!it_fused_loss && !rec) RET_IF(sln_launch_log_softmax(logits, angles_pred, O, cfg.n_angle, st));     // (a group takes it over all rooms' rows at once)
   if (training) {
     if (it_merge_bn) RET_IF(run_bn_updates(0, (int)bns.size(), st));      // encoder's and decoder's tables: one launch, application order
     else RET_IF(run_bn_updates(n_bn_enc, (int)bns.size() - n_bn_enc, st));
@@ -744,8 +839,8 @@ int SlnVae::decoder_backward(hipStream_t st) {
   ev_next = 0;
   tn_slot_next[0] = 0;
   const size_t dec_doubles = stats_doubles - enc_stats_doubles;
-  if (dec_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base + enc_stats_doubles, dec_doubles * sizeof(double), st));
-  RET_IF(refresh_transposes(st));
+  if (dec_doubles && !bulk_zeroed && !rec) RET_IF(sln_zero_async(gstats_base + enc_stats_doubles, dec_doubles * sizeof(double), st));
+  if (!rec) RET_IF(refresh_transposes(st));        // (a group clears the sums and rebuilds the decoder's W^T of all rooms in one launch each)
   const int last = 2 * L - 1;
   const Layer& ll = layers[last];
   // W: width of the gconv vectors; Wh: width of the heads' input without the attribute columns (= W, plus z when decoder_cat is off)
@@ -775,12 +870,12 @@ int SlnVae::decoder_backward(hipStream_t st) {
   // junction: obj_vecs feeds box_net (first W columns of d_bx) and angle_net
   {
     BnView v = view(ll.bn[3], 0, tr);
-    RET_IF(sln_launch_mask_gstats(d_bx, WA, d_ax, Wh, ll.A4, W, v, O, W, ll.g4, W,
-                                  v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
+    RET_IF(k_mask_gstats(d_bx, WA, d_ax, Wh, ll.A4, W, v, O, W, ll.g4, W,
+                         v.mode != SLN_BN_NONE ? bns[ll.bn[3]].gsums : nullptr, W, st));
   }
   // decoder_cat off: z entered behind the gconv net, its gradient is the sum of the two heads' (Sg2ScVAE_model.py:164)
-  if (!cfg.decoder_cat) RET_IF(sln_launch_add2(d_bx + W, WA, d_ax + W, Wh, O, E, dz, E, st));
-  if (n_attr_e > 0) RET_IF(sln_launch_embed_bwd_i64(batch.attributes, d_bx, WA, Wh, O, n_attr_e, cfg.num_attrs, t.d_attr_emb_dc, st));
+  if (!cfg.decoder_cat) RET_IF(k_add2(d_bx + W, WA, d_ax + W, Wh, O, E, dz, E, st));
+  if (n_attr_e > 0) RET_IF(k_embed_bwd(batch.attributes, 1, d_bx, WA, Wh, O, n_attr_e, cfg.num_attrs, t.d_attr_emb_dc, st));
   // gconv layers, last to first
   for (int l = L - 1; l >= 0; --l) {
     const int gi = L + l, slot = l & 1;
@@ -789,21 +884,21 @@ int SlnVae::decoder_backward(hipStream_t st) {
     if (l > 0) {
       const Layer& pv = layers[gi - 1];
       BnView v = view(pv.bn[3], 0, tr);
-      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, pv.g4, W,
-                                   v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
+      RET_IF(k_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, pv.A4, W, v, 1, pv.g4, W,
+                          v.mode != SLN_BN_NONE ? bns[pv.bn[3]].gsums : nullptr, W, st));
     } else {
       BnView none = view(-1, 0, tr);
-      RET_IF(sln_launch_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
-      RET_IF(sln_launch_embed_bwd_i32(g.p, dG[slot], 3 * W, W, T, W, cfg.num_preds, t.d_pred_emb_dc, st));
+      RET_IF(k_gather_bwd(dG[slot], 3 * W, W, g, O, nullptr, 0, nullptr, 0, none, 0, dX0, W, nullptr, 0, st));
+      RET_IF(k_embed_bwd(g.p, 0, dG[slot], 3 * W, W, T, W, cfg.num_preds, t.d_pred_emb_dc, st));
     }
   }
   DecAssembleBwd db; std::memset(&db, 0, sizeof(db));
   db.objs = batch.objs; db.attrs = batch.attributes; db.dx0 = dX0; db.O = O; db.n_obj = n_obj_e; db.n_attr = n_attr_e; db.n_z = E;
   db.d_obj_emb = t.d_obj_emb_dc; db.d_attr_emb = t.d_attr_emb_dc; db.dz = dz; db.z_in_x0 = cfg.decoder_cat ? 1 : 0;
   db.rows_obj = cfg.num_objs; db.rows_attr = cfg.num_attrs;
-  RET_IF(sln_launch_dec_assemble_bwd(db, st));
+  RET_IF(k_dec_assemble_bwd(db, st));
   const int nb = (int)bns.size() - n_bn_enc;
-  if (nb > 0 && !it_merge_bn) {
+  if (nb > 0 && !it_merge_bn && !rec) {
     int maxc = 0;
     for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, cfg.recurrent ? 0 : 1, st));
@@ -1527,6 +1622,368 @@ int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new
   RET_IF(h->join_tn_side(st));
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// R rooms in flight (round 5): the decoder forward / backward of R engines - R rooms, R parameter copies, eval-mode BatchNorm
+// (testing/test_render_refine.py:250-263,279-359: every trial reloads the checkpoint and steps its own copy) - as ONE launch
+// sequence.  At creation every engine RECORDS its two passes (SlnVae::rec); step s of all rooms becomes one multi-room launch
+// whose per-room argument blocks sit in device memory (vae_multi.h).  Nothing depends on the iteration: the program is built and
+// uploaded once and then only replayed - by plain launches, or from inside a caller's hipGraph capture.
+// A room's arithmetic is the single-room kernels' own (same bodies, same dispatch rules, one room per blockIdx.z slice): results
+// do not depend on how many rooms share the launches.
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct SlnVaeGroup {
+  std::vector<SlnVae*> eng;
+  int R = 0, rows_total = 0, n_angle = 0;
+  SlnVaeGroupIO io;
+  float* logits = nullptr; float* dlogits = nullptr;
+  std::vector<void*> allocs;
+  enum { L_NT = 100, L_NT_SINGLE, L_TN_MULTI, L_TN_SINGLE, L_SINGLE_STEP, L_ZERO, L_TRANSPOSE, L_BN_GRADS, L_LOG_SOFTMAX, L_LOG_SOFTMAX_BWD };
+  struct Launch {
+    int kind = -1, variant = 0, count = 0, gx = 0, gy = 0, smem_floats = 0, maxK = 0; double flops = 0.0;
+    const void* tab = nullptr; const int* tiles = nullptr;
+    const GemmTNArgs* tn_probs = nullptr; const TnMultiMeta* tn_meta = nullptr; int blocks = 0; bool x2 = false, xg = false;
+    long max_n16 = 0; int single = -1;
+  };
+  std::vector<Launch> fwd, bwd;
+  std::vector<RecStep> singles;          // steps without a multi form: replayed through the single-room launchers
+  std::vector<int> single_room;
+
+  template <typename T> int upload(const std::vector<T>& v, const T** out) {
+    void* d = nullptr;
+    const size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) return (int)e;
+    allocs.push_back(d);
+    if (!v.empty()) { e = hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice); if (e != hipSuccess) return (int)e; }
+    *out = static_cast<const T*>(d);
+    return 0;
+  }
+  ~SlnVaeGroup() { for (void* p : allocs) (void)hipFree(p); }
+
+  int add_single(std::vector<Launch>& prog, const RecStep& st, int room) {
+    Launch l; l.kind = L_SINGLE_STEP; l.single = (int)singles.size();
+    singles.push_back(st); single_room.push_back(room);
+    prog.push_back(l);
+    return 0;
+  }
+  // the TN problems gathered since the last flush marker -> per-pass wgrad launches over all rooms (flush_deferred's grouping)
+  int flush_tn(std::vector<Launch>& prog, std::vector<GemmTNArgs>& pend) {
+    static thread_local SlnVae::TnGroup tmp;
+    for (int k = 0; k < 2; ++k) {
+      std::vector<GemmTNArgs> kind;
+      for (const GemmTNArgs& t : pend) if ((int)tn_gathers_host(t) == k) kind.push_back(t);
+      size_t next = 0;
+      while (next < kind.size()) {
+        int want = 0; long tiles = 0;
+        for (size_t i = next; i < kind.size() && want < SLN_TN_MULTI_MAX; ++i) {
+          const long tl = (long)sln_cdiv(kind[i].Nout, 64) * sln_cdiv(kind[i].Kin, 64);
+          if (want > 0 && tiles + tl > SLN_TN_MULTI_ITEMS / 2) break;
+          tiles += tl; ++want;
+        }
+        int r = -1;
+        for (; want >= 1; want /= 2) {
+          tmp.n = want;
+          for (int i = 0; i < want; ++i) tmp.probs[i] = kind[next + i];
+          r = sln_tn_multi_plan(tmp.probs, tmp.n, &tmp.meta, &tmp.blocks, &tmp.x2, &tmp.xg, &tmp.flops);
+          if (r == 0) break;
+        }
+        if (r != 0) {                                     // one problem the planner refuses: its own launch
+          RecStep st; st.kind = SK_TN; st.tn = kind[next++];
+          if (g_sln_deterministic) st.tn.rows_per_block = sln_cdiv(st.tn.R, 32) * 32;
+          Launch l; l.kind = L_TN_SINGLE; l.single = (int)singles.size();
+          singles.push_back(st); single_room.push_back(-1);
+          prog.push_back(l);
+          continue;
+        }
+        next += (size_t)tmp.n;
+        Launch l; l.kind = L_TN_MULTI; l.blocks = tmp.blocks; l.x2 = tmp.x2; l.xg = tmp.xg; l.flops = tmp.flops;
+        std::vector<GemmTNArgs> pv(tmp.probs, tmp.probs + tmp.n);
+        RET_IF(upload(pv, &l.tn_probs));
+        std::vector<TnMultiMeta> mv(1, tmp.meta);
+        RET_IF(upload(mv, &l.tn_meta));
+        prog.push_back(l);
+      }
+    }
+    pend.clear();
+    return 0;
+  }
+  static bool tn_gathers_host(const GemmTNArgs& t) {
+    bool g = false;
+    for (int s2 = 0; s2 < t.X.nseg; ++s2) g |= t.X.seg[s2].which != 0;
+    return g;
+  }
+
+  // step s of every room -> launches
+  int merge(std::vector<Launch>& prog, const std::vector<Recorder>& recs) {
+    const size_t n = recs[0].steps.size();
+    for (int r = 1; r < R; ++r) {
+      if (recs[r].steps.size() != n) return SLN_E_UNSUPPORTED;
+      for (size_t s = 0; s < n; ++s) if (recs[r].steps[s].kind != recs[0].steps[s].kind) return SLN_E_UNSUPPORTED;
+    }
+    std::vector<GemmTNArgs> pend;
+    for (size_t s = 0; s < n; ++s) {
+      const int kind = recs[0].steps[s].kind;
+      if (kind == SK_TN) { for (int r = 0; r < R; ++r) pend.push_back(recs[r].steps[s].tn); continue; }
+      if (kind == SK_TN_FLUSH) { RET_IF(flush_tn(prog, pend)); continue; }
+      // rooms whose block plans to the same variant share a launch
+      std::vector<int> var(R, -1), gxs(R, 0), gys(R, 0), smf(R, 0);
+      std::vector<RecStep> blk(R);
+      std::vector<char> asm_blob((size_t)R * SLN_ASM_BLOB);
+      for (int r = 0; r < R; ++r) {
+        blk[r] = recs[r].steps[s];
+        RecStep& b = blk[r];
+        switch (kind) {
+          case SK_NT: { int t = 0; var[r] = sln_plan_nt_small(b.nt, b.epi, &t); if (var[r] >= 0) var[r] = var[r] * 4 + b.epi * 0; gxs[r] = t; break; }
+          case SK_SCATTER_FWD: var[r] = sln_plan_scatter_avg_fwd(b.sf); gxs[r] = b.sf.gx; gys[r] = b.sf.gy; break;
+          case SK_SCATTER_BWD: var[r] = sln_plan_scatter_avg_bwd(b.sb); gxs[r] = b.sb.gx; gys[r] = b.sb.gy; break;
+          case SK_GATHER_BWD: var[r] = sln_plan_gather_bwd(b.gb); gxs[r] = b.gb.gx; gys[r] = b.gb.gy; break;
+          case SK_MASK_GSTATS: var[r] = sln_plan_mask_gstats(b.mg); gxs[r] = b.mg.gx; gys[r] = b.mg.gy; break;
+          case SK_DEC_ASSEMBLE: var[r] = sln_plan_dec_assemble(b.da); gxs[r] = b.da.gx; gys[r] = 1; break;
+          case SK_EMBED_GATHER: var[r] = sln_plan_embed_gather(b.eg); gxs[r] = b.eg.gx; gys[r] = 1; break;
+          case SK_EMBED_BWD: var[r] = sln_plan_embed_bwd(b.eb, b.idx64); gxs[r] = b.eb.gx; gys[r] = b.eb.gy; smf[r] = b.eb.table_rows * b.eb.n; break;
+          case SK_ADD2: case SK_COPY2D: var[r] = sln_plan_add2(b.a2); gxs[r] = b.a2.gx; gys[r] = 1; break;
+          case SK_DEC_ASSEMBLE_BWD: var[r] = sln_plan_dec_assemble_bwd(b.dab, asm_blob.data() + (size_t)r * SLN_ASM_BLOB, &gxs[r], &smf[r]); gys[r] = 1; break;
+          default: return SLN_E_UNSUPPORTED;
+        }
+      }
+      std::vector<bool> done(R, false);
+      for (int r0 = 0; r0 < R; ++r0) {
+        if (done[r0]) continue;
+        if (var[r0] < 0) { done[r0] = true; RET_IF(add_single(prog, recs[r0].steps[s], r0)); continue; }
+        std::vector<int> rooms;
+        for (int r = r0; r < R; ++r) if (!done[r] && var[r] == var[r0]) { rooms.push_back(r); done[r] = true; }
+        Launch l; l.kind = kind; l.variant = var[r0]; l.count = (int)rooms.size();
+        for (int r : rooms) { l.gx = gxs[r] > l.gx ? gxs[r] : l.gx; l.gy = gys[r] > l.gy ? gys[r] : l.gy; l.smem_floats = smf[r] > l.smem_floats ? smf[r] : l.smem_floats; }
+#define SLN_UP(FIELD, TYPE) { std::vector<TYPE> v; for (int r : rooms) v.push_back(blk[r].FIELD); const TYPE* d = nullptr; RET_IF(upload(v, &d)); l.tab = d; }
+        switch (kind) {
+          case SK_NT: {
+            l.kind = L_NT; l.variant = var[r0] / 4;
+            std::vector<GemmNTArgs> v; std::vector<int> tl;
+            for (int r : rooms) { v.push_back(blk[r].nt); tl.push_back(gxs[r]); l.maxK = blk[r].nt.K > l.maxK ? blk[r].nt.K : l.maxK; l.flops += 2.0 * blk[r].nt.M * blk[r].nt.N * blk[r].nt.K; }
+            const GemmNTArgs* d = nullptr; RET_IF(upload(v, &d)); l.tab = d;
+            RET_IF(upload(tl, &l.tiles));
+            break;
+          }
+          case SK_SCATTER_FWD: SLN_UP(sf, MScatterFwd) break;
+          case SK_SCATTER_BWD: SLN_UP(sb, MScatterBwd) break;
+          case SK_GATHER_BWD: SLN_UP(gb, MGatherBwd) break;
+          case SK_MASK_GSTATS: SLN_UP(mg, MMaskGstats) break;
+          case SK_DEC_ASSEMBLE: SLN_UP(da, MDecAssemble) break;
+          case SK_EMBED_GATHER: SLN_UP(eg, MEmbedGather) break;
+          case SK_EMBED_BWD: SLN_UP(eb, MEmbedBwd) break;
+          case SK_ADD2: case SK_COPY2D: SLN_UP(a2, MAdd2) break;
+          case SK_DEC_ASSEMBLE_BWD: {
+            std::vector<char> v;
+            for (int r : rooms) v.insert(v.end(), asm_blob.begin() + (size_t)r * SLN_ASM_BLOB, asm_blob.begin() + (size_t)(r + 1) * SLN_ASM_BLOB);
+            const char* d = nullptr; RET_IF(upload(v, &d)); l.tab = d;
+            break;
+          }
+        }
+#undef SLN_UP
+        prog.push_back(l);
+      }
+    }
+    if (!pend.empty()) RET_IF(flush_tn(prog, pend));
+    return 0;
+  }
+
+  int run(const std::vector<Launch>& prog, hipStream_t st) {
+    for (const Launch& l : prog) {
+      int r = 0;
+      switch (l.kind) {
+        case L_NT: r = sln_launch_gemm_nt_small_multi(static_cast<const GemmNTArgs*>(l.tab), l.tiles, l.count, l.variant, l.gx, l.maxK, l.flops, st); break;
+        case L_TN_MULTI: r = sln_launch_gemm_tn_multi(l.tn_probs, l.tn_meta, l.blocks, l.x2, l.xg, l.flops, st); break;
+        case L_TN_SINGLE: r = sln_launch_gemm_tn(singles[l.single].tn, -1, st); break;
+        case L_SINGLE_STEP: r = run_single(singles[l.single], st); break;
+        case SK_SCATTER_FWD: r = sln_launch_scatter_avg_fwd_multi(static_cast<const MScatterFwd*>(l.tab), l.count, l.variant, l.gx, l.gy, st); break;
+        case SK_SCATTER_BWD: r = sln_launch_scatter_avg_bwd_multi(static_cast<const MScatterBwd*>(l.tab), l.count, l.variant, l.gx, l.gy, st); break;
+        case SK_GATHER_BWD: r = sln_launch_gather_bwd_multi(static_cast<const MGatherBwd*>(l.tab), l.count, l.variant, l.gx, l.gy, st); break;
+        case SK_MASK_GSTATS: r = sln_launch_mask_gstats_multi(static_cast<const MMaskGstats*>(l.tab), l.count, l.gx, l.gy, st); break;
+        case SK_DEC_ASSEMBLE: r = sln_launch_dec_assemble_multi(static_cast<const MDecAssemble*>(l.tab), l.count, l.gx, st); break;
+        case SK_EMBED_GATHER: r = sln_launch_embed_gather_multi(static_cast<const MEmbedGather*>(l.tab), l.count, l.gx, st); break;
+        case SK_EMBED_BWD: r = sln_launch_embed_bwd_multi(static_cast<const MEmbedBwd*>(l.tab), l.count, l.variant, l.gx, l.gy, l.smem_floats, st); break;
+        case SK_ADD2: r = sln_launch_add2_multi(static_cast<const MAdd2*>(l.tab), l.count, l.gx, st); break;
+        case SK_COPY2D: r = sln_launch_copy2d_multi(static_cast<const MAdd2*>(l.tab), l.count, l.gx, st); break;
+        case SK_DEC_ASSEMBLE_BWD: r = sln_launch_dec_assemble_bwd_multi(l.tab, l.count, l.variant, l.gx, l.smem_floats, st); break;
+        case L_ZERO: r = sln_launch_zero_multi(static_cast<const MZero*>(l.tab), l.count, l.max_n16, st); break;
+        case L_TRANSPOSE: r = sln_launch_transpose_table(static_cast<const TransposeEntry*>(l.tab), l.count, l.gx, st); break;
+        case L_BN_GRADS: r = sln_launch_bn_param_grads(static_cast<const BnTableEntry*>(l.tab), l.count, l.gx, 1, st); break;
+        case L_LOG_SOFTMAX: r = sln_launch_log_softmax(logits, io.angles_pred, rows_total, n_angle, st); break;
+        case L_LOG_SOFTMAX_BWD: r = sln_launch_log_softmax_bwd(io.angles_pred, io.d_angles_pred, dlogits, rows_total, n_angle, st); break;
+        default: r = SLN_E_UNSUPPORTED;
+      }
+      if (r) return r;
+    }
+    return 0;
+  }
+  // a recorded step through the single-room launcher (a room whose block has no multi form)
+  int run_single(const RecStep& b, hipStream_t st) {
+    switch (b.kind) {
+      case SK_NT: return sln_launch_gemm_nt(b.nt, b.epi, -1, st);
+      case SK_SCATTER_FWD: return sln_launch_scatter_avg_fwd(b.sf.A2, b.sf.ld, b.sf.H, b.sf.D, b.sf.bn, b.sf.g, b.sf.O, b.sf.pooled, st);
+      case SK_SCATTER_BWD: return sln_launch_scatter_avg_bwd(b.sb.dM, b.sb.dP, b.sb.lddp, b.sb.dpcol0, b.sb.A2, b.sb.ld, b.sb.H, b.sb.D, b.sb.bn, b.sb.g, b.sb.T,
+                                                             b.sb.g2, b.sb.gsums, b.sb.cstride, st);
+      case SK_GATHER_BWD: return sln_launch_gather_bwd(b.gb.dG, b.gb.ldg, b.gb.D, b.gb.g, b.gb.O, b.gb.add1, b.gb.ldadd1, b.gb.xprev, b.gb.ldx, b.gb.bn,
+                                                       b.gb.masked, b.gb.out, b.gb.ldo, b.gb.gsums, b.gb.cstride, st);
+      case SK_MASK_GSTATS: return sln_launch_mask_gstats(b.mg.d1, b.mg.ld1, b.mg.d2, b.mg.ld2, b.mg.xprev, b.mg.ldx, b.mg.bn, b.mg.rows, b.mg.cols, b.mg.out,
+                                                         b.mg.ldo, b.mg.gsums, b.mg.cstride, st);
+      case SK_DEC_ASSEMBLE: return sln_launch_dec_assemble(b.da.a, st);
+      case SK_EMBED_GATHER: return sln_launch_embed_gather_i32(b.eg.idx, b.eg.emb, b.eg.rows, b.eg.n, b.eg.out, st);
+      case SK_EMBED_BWD: return b.idx64 ? sln_launch_embed_bwd_i64(static_cast<const int64_t*>(b.eb.idx), b.eb.d, b.eb.ld, b.eb.col0, b.eb.rows, b.eb.n, b.eb.table_rows, b.eb.d_emb, st)
+                                        : sln_launch_embed_bwd_i32(static_cast<const int*>(b.eb.idx), b.eb.d, b.eb.ld, b.eb.col0, b.eb.rows, b.eb.n, b.eb.table_rows, b.eb.d_emb, st);
+      case SK_ADD2: return sln_launch_add2(b.a2.a, b.a2.lda, b.a2.b, b.a2.ldb, b.a2.rows, b.a2.cols, b.a2.out, b.a2.ldo, st);
+      case SK_COPY2D: return (int)hipMemcpy2DAsync(b.a2.out, sizeof(float) * b.a2.ldo, b.a2.a, sizeof(float) * b.a2.lda, sizeof(float) * b.a2.cols, (size_t)b.a2.rows,
+                                                   hipMemcpyDeviceToDevice, st);
+      case SK_DEC_ASSEMBLE_BWD: return sln_launch_dec_assemble_bwd(b.dab, st);
+      default: return SLN_E_UNSUPPORTED;
+    }
+  }
+};
+
+extern "C" {
+
+int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io, SlnVaeGroup** out) {
+  if (!engines || R < 1 || !io || !out || !io->row0_host || !io->z || !io->boxes_pred || !io->angles_pred || !io->d_boxes_pred ||
+      !io->d_angles_pred || !io->dz || io->rows_total < 1) return SLN_E_BADARG;
+  for (int r = 0; r < R; ++r) {
+    SlnVae* h = engines[r];
+    if (!h || !h->bound || !h->batch_set || h->gconv_only) return SLN_E_STATE;
+    if (std::memcmp(&h->cfg, &engines[0]->cfg, sizeof(SlnVaeConfig)) != 0) return SLN_E_BADARG;
+    if (io->row0_host[r] < 0 || io->row0_host[r] + h->O > io->rows_total) return SLN_E_BADARG;
+  }
+  SlnVaeGroup* g = new (std::nothrow) SlnVaeGroup();
+  if (!g) return SLN_E_NOMEM;
+  g->R = R; g->io = *io; g->io.row0_host = nullptr; g->rows_total = io->rows_total; g->n_angle = engines[0]->cfg.n_angle;
+  g->eng.assign(engines, engines + R);
+  int rc = sln_gemm_init();
+  auto fail = [&](int code) { for (SlnVae* h : g->eng) h->rec = nullptr; delete g; return code; };
+  if (rc) return fail(rc);
+  {
+    void* p = nullptr;
+    if (hipMalloc(&p, sizeof(float) * (size_t)g->rows_total * g->n_angle * 2) != hipSuccess) return fail(SLN_E_NOMEM);
+    g->allocs.push_back(p);
+    g->logits = static_cast<float*>(p); g->dlogits = g->logits + (size_t)g->rows_total * g->n_angle;
+  }
+  std::vector<Recorder> rf(R), rb(R);
+  std::vector<MZero> zeros; std::vector<TransposeEntry> trs; std::vector<BnTableEntry> bnt;
+  long max_n16 = 0; int tr_tiles = 0, bn_maxc = 0;
+  for (int r = 0; r < R; ++r) {
+    SlnVae* h = g->eng[r];
+    const size_t row0 = (size_t)io->row0_host[r];
+    const int E = h->E, na = h->cfg.n_angle;
+    // the engine's outputs / gradient inputs of the decoder become slices of the group's row-concatenated arrays
+    h->boxes_pred = io->boxes_pred + row0 * h->cfg.box_dim; h->logits = g->logits + row0 * na; h->angles_pred = io->angles_pred + row0 * na;
+    if (h->dbp_ld != 8 && h->dbp_ld != h->cfg.box_dim) return fail(SLN_E_UNSUPPORTED);
+    h->dbp = io->d_boxes_pred + row0 * h->dbp_ld; h->dlogits = g->dlogits + row0 * na; h->dz = io->dz + row0 * E;
+    h->drop_graphs();
+    h->rec = &rf[r];
+    rc = h->decoder_forward(io->z + row0 * E, nullptr, false, nullptr);
+    if (!rc) { h->rec = &rb[r]; rc = h->decoder_backward(nullptr); }
+    h->rec = nullptr;
+    if (rc) return fail(rc);
+    // per-room pieces of the three table-driven launches: the BatchNorm backward sums to clear, W^T of the decoder's units,
+    // the BatchNorm parameter gradients of the decoder's applications
+    const size_t dec_doubles = h->stats_doubles - h->enc_stats_doubles;
+    if (dec_doubles) {
+      MZero z; z.p = h->gstats_base + h->enc_stats_doubles; z.n16 = (long)(dec_doubles * sizeof(double) / 16);
+      if ((reinterpret_cast<uintptr_t>(z.p) & 15) || (dec_doubles * sizeof(double)) % 16) return fail(SLN_E_UNSUPPORTED);
+      zeros.push_back(z); max_n16 = z.n16 > max_n16 ? z.n16 : max_n16;
+    }
+    std::vector<int> dec_units;
+    for (int l = 0; l < h->L; ++l) for (int k = 0; k < 4; ++k) {
+      const int u = h->unit_of(1, l, k);
+      bool seen = false; for (int q : dec_units) seen |= q == u;
+      if (!seen) dec_units.push_back(u);
+    }
+    for (int k = 0; k < 2; ++k) { dec_units.push_back(h->unit_boxnet(k)); dec_units.push_back(h->unit_anglenet(k)); }
+    for (int ui : dec_units) {
+      const Unit& u = h->units[ui];
+      TransposeEntry e; e.src = u.p.weight; e.dst = u.wt; e.rows = u.out; e.cols = u.in; e.dst_ld = u.wt_ld; e.pad_ = 0;
+      trs.push_back(e);
+      const int tiles = sln_cdiv(u.out, 32) * sln_cdiv(u.in, 32);
+      tr_tiles = tiles > tr_tiles ? tiles : tr_tiles;
+    }
+    if (h->cfg.recurrent && (int)h->bns.size() > h->n_bn_enc && R > 0) {
+      // (shared 'recurrent' modules: the per-entry form of the parameter-gradient kernel would let two applications of one module
+      //  add to the same dgamma from different workgroups)
+      return fail(SLN_E_UNSUPPORTED);
+    }
+    for (size_t i = (size_t)h->n_bn_enc; i < h->bns.size(); ++i) {
+      const BnInst& b = h->bns[i];
+      const Unit& u = h->units[b.unit];
+      BnTableEntry e; std::memset(&e, 0, sizeof(e));
+      e.sums = b.sums; e.gsums = b.gsums; e.cstride = b.C; e.C = b.C; e.rows = b.rows_code;
+      e.rmean = u.p.bn_running_mean; e.rvar = u.p.bn_running_var; e.nbt = u.p.bn_num_batches_tracked;
+      e.dgamma = u.p.d_bn_weight; e.dbeta = u.p.d_bn_bias;
+      bnt.push_back(e); bn_maxc = b.C > bn_maxc ? b.C : bn_maxc;
+    }
+  }
+  // forward program: the recorded steps, then ONE log-softmax over every room's rows
+  rc = g->merge(g->fwd, rf);
+  if (rc) return fail(rc);
+  { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_LOG_SOFTMAX; g->fwd.push_back(l); }
+  // backward program: log-softmax backward, the cleared sums, W^T, the recorded steps, the BatchNorm parameter gradients
+  { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_LOG_SOFTMAX_BWD; g->bwd.push_back(l); }
+  if (!zeros.empty()) {
+    SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_ZERO; l.count = (int)zeros.size(); l.max_n16 = max_n16;
+    const MZero* d = nullptr; rc = g->upload(zeros, &d); if (rc) return fail(rc); l.tab = d;
+    g->bwd.push_back(l);
+  }
+  {
+    SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles;
+    const TransposeEntry* d = nullptr; rc = g->upload(trs, &d); if (rc) return fail(rc); l.tab = d;
+    g->bwd.push_back(l);
+  }
+  {
+    std::vector<SlnVaeGroup::Launch> rest;
+    rc = g->merge(rest, rb);
+    if (rc) return fail(rc);
+    // the parameter-gradient launch of the BatchNorm applications reads the sums every masked dgrad / edge kernel has finished:
+    // in front of the wgrad launches at the end of the pass (any position behind the last layer's gather works)
+    size_t first_tn = rest.size();
+    for (size_t i = 0; i < rest.size(); ++i)
+      if (rest[i].kind == SlnVaeGroup::L_TN_MULTI || rest[i].kind == SlnVaeGroup::L_TN_SINGLE) { first_tn = i; break; }
+    if (engines[0]->cfg.recurrent || engines[0]->tn_per_layer) first_tn = rest.size();
+    for (size_t i = 0; i < rest.size(); ++i) {
+      if (i == first_tn && !bnt.empty()) {
+        SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_BN_GRADS; l.count = (int)bnt.size(); l.gx = bn_maxc;
+        const BnTableEntry* d = nullptr; rc = g->upload(bnt, &d); if (rc) return fail(rc); l.tab = d;
+        g->bwd.push_back(l);
+      }
+      g->bwd.push_back(rest[i]);
+    }
+    if (first_tn == rest.size() && !bnt.empty()) {
+      SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_BN_GRADS; l.count = (int)bnt.size(); l.gx = bn_maxc;
+      const BnTableEntry* d = nullptr; rc = g->upload(bnt, &d); if (rc) return fail(rc); l.tab = d;
+      g->bwd.push_back(l);
+    }
+  }
+  *out = g;
+  return 0;
+}
+
+int sln_vae_group_decoder(SlnVaeGroup* g, void* stream) {
+  if (!g) return SLN_E_BADARG;
+  return g->run(g->fwd, (hipStream_t)stream);
+}
+
+int sln_vae_group_decoder_backward(SlnVaeGroup* g, void* stream) {
+  if (!g) return SLN_E_BADARG;
+  return g->run(g->bwd, (hipStream_t)stream);
+}
+
+int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single_room_fallbacks) {
+  if (!g) return SLN_E_BADARG;
+  if (fwd) *fwd = (int)g->fwd.size();
+  if (bwd) *bwd = (int)g->bwd.size();
+  if (single_room_fallbacks) *single_room_fallbacks = (int)g->singles.size();
+  return 0;
+}
+
+void sln_vae_group_destroy(SlnVaeGroup* g) { delete g; }
 
 int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream) {
   if (!h || layer < 0 || layer >= (int)h->layers.size() || !dst) return SLN_E_BADARG;

@@ -1472,6 +1472,14 @@ __global__ void add2_multi_kernel(const MAdd2* __restrict__ tab) {
   if ((int)blockIdx.x >= a.gx) return;
   add2_body(a.a, a.lda, a.b, a.ldb, a.rows, a.cols, a.out, a.ldo);
 }
+__global__ void copy2d_multi_kernel(const MAdd2* __restrict__ tab) {
+  const MAdd2& a = tab[blockIdx.z];
+  if ((int)blockIdx.x >= a.gx) return;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)a.rows * a.cols) return;
+  const int r = (int)(i / a.cols), c = (int)(i % a.cols);
+  a.out[(size_t)r * a.ldo + c] = a.a[(size_t)r * a.lda + c];
+}
 __global__ void zero_multi_kernel(const MZero* __restrict__ tab) {
   const MZero a = tab[blockIdx.y];
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1625,6 +1633,12 @@ int sln_plan_add2(MAdd2& a) {
 int sln_launch_add2_multi(const MAdd2* tab, int R, int gx, hipStream_t st) {
   if (R <= 0 || gx <= 0) return 0;
   hipLaunchKernelGGL(add2_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, tab);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+int sln_launch_copy2d_multi(const MAdd2* tab, int R, int gx, hipStream_t st) {
+  if (R <= 0 || gx <= 0) return 0;
+  hipLaunchKernelGGL(copy2d_multi_kernel, dim3(gx, 1, R), dim3(256), 0, st, tab);
   SLN_CHECK_LAUNCH();
   return 0;
 }

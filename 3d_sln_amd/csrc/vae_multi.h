@@ -62,8 +62,10 @@ int sln_plan_add2(MAdd2& a);
 int sln_launch_add2_multi(const MAdd2* tab, int R, int gx, hipStream_t st);
 int sln_launch_zero_multi(const MZero* tab, int R, long max_n16, hipStream_t st);
 
-// forward Linears / dgrads of all rooms on the 32 x 32 split-K body (gemm_f32.hip).  sln_plan_nt_small: the body's template key
-// (amode * 16 + epi * 4 + nseg) for a problem the single-room dispatcher would give to that body, -1 otherwise; `tiles` = its grid.
+int sln_launch_copy2d_multi(const MAdd2* tab, int R, int gx, hipStream_t st);       // out[r, :cols] = a[r, :cols] (b unused)
+// forward Linears / dgrads of all rooms (gemm_f32.hip).  sln_plan_nt_small: the template key of the body the single-room dispatcher
+// would pick for the problem - amode * 16 + epi * 4 + nseg for the 32 x 32 split-K body, 1000 + amode * 16 + epi * 4 + segment class
+// for the 64 x 64 body, -1 when there is no multi form (train-mode BatchNorm, chip-filling shapes); `tiles` = its grid.
 int sln_plan_nt_small(const GemmNTArgs& a, int epi, int* tiles);
 int sln_launch_gemm_nt_small_multi(const GemmNTArgs* tab, const int* tiles_dev, int R, int key, int max_tiles, int max_K, double flops,
                                    hipStream_t st);

@@ -303,6 +303,78 @@ class Sg2ScVAEModel(nn.Module):
             out += mlp_linears(s)
         return out
 
+    def _tensor_table(self, cfg, pbase, gbase):
+        """SlnVaeTensors (+ the unit array it points to) for a parameter / gradient buffer pair laid out like this model's flat
+        buffers and starting at device addresses ``pbase`` / ``gbase``: the model's own (``_ensure_engine``) or a per-room COPY
+        (``room_engine``: layout refinement fine-tunes one copy of the checkpoint per room).  BatchNorm running statistics are
+        buffers, not parameters: every table points at the model's own (eval-mode engines only read them)."""
+        L = _lib.lib()
+        units = self._unit_modules()
+        n_units = L.sln_vae_num_units(C.byref(cfg))
+        assert n_units == len(units), (n_units, len(units))
+        arr = (_lib.SlnVaeUnit * n_units)()
+        p0, g0 = self._flat.data_ptr(), self._gflat.data_ptr()
+        gptr = {id(p): gbase + (gv.data_ptr() - g0) for p, gv in zip(self._params, self._gviews)}
+        pp = lambda p: pbase + (p.data_ptr() - p0)
+        for u, (lin, bn) in zip(arr, units):
+            u.weight, u.bias = pp(lin.weight), pp(lin.bias)
+            u.d_weight, u.d_bias = gptr[id(lin.weight)], gptr[id(lin.bias)]
+            if bn is not None:
+                u.bn_weight, u.bn_bias = pp(bn.weight), pp(bn.bias)
+                u.bn_running_mean, u.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                u.bn_num_batches_tracked = bn.num_batches_tracked.data_ptr()
+                u.d_bn_weight, u.d_bn_bias = gptr[id(bn.weight)], gptr[id(bn.bias)]
+        t = _lib.SlnVaeTensors()
+        embs = dict(obj_emb_ec=self.obj_embeddings_ec.weight, pred_emb_ec=self.pred_embeddings_ec.weight,
+                    obj_emb_dc=self.obj_embeddings_dc.weight, pred_emb_dc=self.pred_embeddings_dc.weight,
+                    box_emb_w=self.box_embeddings.weight, box_emb_b=self.box_embeddings.bias,
+                    angle_emb=self.angle_embeddings.weight)
+        if self.use_attr:
+            embs.update(attr_emb_ec=self.attr_embedding_ec.weight, attr_emb_dc=self.attr_embedding_dc.weight)
+        for k, p in embs.items():
+            setattr(t, k, pp(p))
+            setattr(t, "d_" + k, gptr[id(p)])
+        t.units_host = arr
+        t.flat_params, t.flat_grads, t.n_flat = pbase, gbase, self._flat.numel()
+        return t, arr
+
+    def room_engines(self, params, grads, max_objs, max_triples):
+        """One engine per row of ``params`` / ``grads`` ([R, n_flat] copies of ``flat_params`` / zeroed gradients, rows 16-byte
+        aligned): -> list of (handle, workspace, keep-alive).  The caller owns the handles (``sln_vae_destroy``)."""
+        if self._flat.device.type != 'cuda':
+            raise _lib.SlnError("Sg2ScVAEModel runs on the MI355X only: call model.cuda() first (no CPU fallback)")
+        L = _lib.lib()
+        cfg = self._config()
+        maxO, maxT = max(int(max_objs), 64), max(int(max_triples), 64)
+        out = []
+        for r in range(params.shape[0]):
+            h = C.c_void_p()
+            _lib.check(L.sln_vae_create(C.byref(cfg), C.byref(h)), "sln_vae_create")
+            nbytes = L.sln_vae_workspace_bytes(h, maxO, maxT)
+            if nbytes < 0:
+                _lib.check(int(nbytes), "sln_vae_workspace_bytes")
+            out.append([h, torch.zeros(int(nbytes), dtype=torch.uint8, device=self._flat.device), None, int(nbytes)])
+        torch.cuda.current_stream(self._flat.device).synchronize()         # sln_vae_bind writes into the workspaces with blocking copies
+        for r, e in enumerate(out):
+            t, arr = self._tensor_table(cfg, params[r].data_ptr(), grads[r].data_ptr())
+            e[2] = arr
+            _lib.check(L.sln_vae_bind(e[0], C.byref(t), C.c_void_p(e[1].data_ptr()), e[3], maxO, maxT), "sln_vae_bind")
+        return [(e[0], e[1], e[2]) for e in out]
+
+    def decoder_param_ranges(self):
+        """(offset, length) runs of ``flat_params`` that hold every parameter the DECODER reads: the *_dc embedding tables
+        (registered in front, between the encoder's) and the trailing gconv_net_dc / box_net / angle_net run."""
+        spans, o = [], 0
+        for name, p in self.named_parameters():
+            n = (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+            if name.startswith(self._DECODER_ONLY) or name.startswith(("obj_embeddings_dc.", "pred_embeddings_dc.", "attr_embedding_dc.")):
+                if spans and spans[-1][0] + spans[-1][1] == o:
+                    spans[-1][1] += n
+                else:
+                    spans.append([o, n])
+            o += n
+        return [(a, b) for a, b in spans]
+
     def _ensure_engine(self, O, T):
         if self._flat.device.type != 'cuda':
             raise _lib.SlnError("Sg2ScVAEModel runs on the MI355X only: call model.cuda() first (no CPU fallback)")
@@ -327,32 +399,8 @@ class Sg2ScVAEModel(nn.Module):
         if self._adam_m is None:
             self._adam_m = torch.zeros_like(self._flat)
             self._adam_v = torch.zeros_like(self._flat)
-        units = self._unit_modules()
-        n_units = L.sln_vae_num_units(C.byref(cfg))
-        assert n_units == len(units), (n_units, len(units))
-        arr = (_lib.SlnVaeUnit * n_units)()
-        gptr = {id(p): gv.data_ptr() for p, gv in zip(self._params, self._gviews)}
-        for u, (lin, bn) in zip(arr, units):
-            u.weight, u.bias = lin.weight.data_ptr(), lin.bias.data_ptr()
-            u.d_weight, u.d_bias = gptr[id(lin.weight)], gptr[id(lin.bias)]
-            if bn is not None:
-                u.bn_weight, u.bn_bias = bn.weight.data_ptr(), bn.bias.data_ptr()
-                u.bn_running_mean, u.bn_running_var = bn.running_mean.data_ptr(), bn.running_var.data_ptr()
-                u.bn_num_batches_tracked = bn.num_batches_tracked.data_ptr()
-                u.d_bn_weight, u.d_bn_bias = gptr[id(bn.weight)], gptr[id(bn.bias)]
-        t = _lib.SlnVaeTensors()
-        embs = dict(obj_emb_ec=self.obj_embeddings_ec.weight, pred_emb_ec=self.pred_embeddings_ec.weight,
-                    obj_emb_dc=self.obj_embeddings_dc.weight, pred_emb_dc=self.pred_embeddings_dc.weight,
-                    box_emb_w=self.box_embeddings.weight, box_emb_b=self.box_embeddings.bias,
-                    angle_emb=self.angle_embeddings.weight)
-        if self.use_attr:
-            embs.update(attr_emb_ec=self.attr_embedding_ec.weight, attr_emb_dc=self.attr_embedding_dc.weight)
-        for k, p in embs.items():
-            setattr(t, k, p.data_ptr())
-            setattr(t, "d_" + k, gptr[id(p)])
-        t.units_host = arr
-        t.flat_params, t.flat_grads = self._flat.data_ptr(), self._gflat.data_ptr()
-        t.adam_m, t.adam_v, t.n_flat = self._adam_m.data_ptr(), self._adam_v.data_ptr(), self._flat.numel()
+        t, arr = self._tensor_table(cfg, self._flat.data_ptr(), self._gflat.data_ptr())
+        t.adam_m, t.adam_v = self._adam_m.data_ptr(), self._adam_v.data_ptr()
         self._units_keepalive = arr
         _lib.check(L.sln_vae_bind(h, C.byref(t), C.c_void_p(self._ws.data_ptr()), int(nbytes), maxO, maxT), "sln_vae_bind")
         if self._adam_steps:

@@ -16,6 +16,7 @@ What is replaced
   * the 33 raster passes per call: one fused HIP pass (diff_render.scene_render semantics).
 ``render_fn`` is injectable so that the tests can run the very same loss graph on the CPU oracle.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -219,7 +220,8 @@ class RefineLoss:
     ``rl(image)`` -> tensor [100*depth + 100*sem, depth, sem]; gradients flow to ``image`` through element 0.  The
     workspace holds d loss / d pooled between forward and backward: one outstanding forward per instance."""
 
-    def __init__(self, target, sizes=(32, 48, 64, 96)):
+    def __init__(self, target, sizes=(32, 48, 64, 96), per_room=False):
+        self.per_room = bool(per_room)
         dev = target.device
         B, C, S, _ = target.shape
         P, ns, pmax = sizes[-1], len(sizes), max(sizes)
@@ -268,6 +270,7 @@ class RefineLoss:
         for name, buf in zip(("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w"), self._keep):
             setattr(d, name, buf.data_ptr())
         d.max_col_entries = max_col
+        d.per_room = int(getattr(self, "per_room", False))
         return d
 
     def _finish(self, d, target, B, S, P, C, ns, dev):
@@ -285,7 +288,8 @@ class RefineLoss:
         lab = torch.argmax(sem, dim=2)
         lab[sem.sum(dim=2) < 0.5] = -100                                                                # :341-343
         self.labels = lab.to(torch.int32).contiguous()                                                  # [B, ns, P, P]
-        cnt = (lab >= 0).sum(dim=(0, 2, 3)).to(torch.float32)
+        # per_room: every image is its own room - its cross-entropy means run over its own labels ([B, ns] counts)
+        cnt = (lab >= 0).sum(dim=(2, 3) if self.per_room else (0, 2, 3)).to(torch.float32)
         self.inv_count = (1.0 / cnt).contiguous()                                                       # 1/0: nan loss, as torch's empty mean
 
     def __call__(self, image):
@@ -546,6 +550,229 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
         if log:
             log("iter %d: loss %.4f" % (k, float(losses[k])))
     return losses, (state["boxes"], state["idx"])
+
+
+class RefineBatch:
+    """R rooms in flight: one refinement iteration of R independent rooms (testing/test_render_refine.py:250-263 runs its trials
+    one after the other; each reloads the checkpoint, ``model.eval()``, and :279-359 steps ``z`` AND its own copy of the parameters)
+    as ONE sequence of launches - no autograd graph, no per-room python:
+
+        decoder of all rooms (sln_vae_group_decoder: R parameter copies, one launch per step) -> soft-argmax / noise / frozen room
+        row (sln_refine_head_forward_rooms) -> placement + projection + cull + fill_back (sln_place_forward_rooms) -> fused scene
+        pass over the R padded face lists (sln_scene_forward) -> PSP / L1 / cross-entropy per room (SlnRefineLoss.per_room) ->
+        the same chain backwards -> decoder backward of all rooms -> SGD on every room's parameter copy and on z (one launch).
+
+    ``rooms``: list of dicts with ``objs, triples, boxes, angles, attributes`` (one room's collated graph, room row last) and
+    ``class_names``.  Every room starts from ``model``'s parameters (the checkpoint), encoded with ``model`` in eval mode.
+    A room's numbers do not depend on the other rooms of the batch: the kernels are the single-room ones over a (room) grid axis.
+    After ``run(iters)``: ``losses`` [iters, R], ``boxes`` / ``idx`` (row-concatenated, ``row0`` / ``rows`` per room), ``params``
+    [R, n_flat] the fine-tuned copies, ``z`` the refined latents."""
+
+    def __init__(self, model, rooms, bank=None, learning_rate=1e-4, noise_seed=13, image_size=256, iters=60):
+        L = _lib.lib()
+        self.model, self.R, self.iters, self.lr = model, len(rooms), int(iters), float(learning_rate)
+        R = self.R
+        if R < 1:
+            raise ValueError("RefineBatch needs at least one room")
+        dev = model.flat_params.device
+        names_all = set(n for rm in rooms for n in rm["class_names"])
+        bank = bank or MeshBank([n for n in names_all if n not in DO_NOT_VIS and n != "__room__"], dev)
+        model.eval()
+        E, na, S = model.embedding_dim, model.Nangle, int(image_size)
+        self.rows = [int(rm["objs"].shape[0]) for rm in rooms]
+        self.row0 = [0]
+        for n in self.rows[:-1]:
+            self.row0.append(self.row0[-1] + n)
+        N = sum(self.rows)
+        self.N = N
+        f32 = dict(dtype=torch.float32, device=dev)
+        # ---- per room: encoder (the checkpoint model), z draw, noise of every iteration, scene, target render ----
+        z = torch.empty(N, E, **f32)
+        noise = torch.zeros(max(self.iters, 1), N)
+        scenes, targets, size_targets = [], [], []
+        box_last, angle_last = torch.empty(R, 6, **f32), torch.empty(R, **f32)
+        for r, rm in enumerate(rooms):
+            with torch.no_grad():
+                mu, logvar = model.encoder(rm["objs"], rm["triples"], rm["boxes"], rm["angles"], rm["attributes"])
+            gen = torch.Generator(device="cpu").manual_seed(noise_seed)          # torch.manual_seed(13) in front of every trial (:274-275)
+            a, n = self.row0[r], self.rows[r]
+            z[a:a + n] = mu + torch.randn(mu.shape, generator=gen).to(dev) * torch.exp(0.5 * logvar)
+            for k in range(self.iters):
+                noise[k, a:a + n] = torch.randn(n, generator=gen)
+            sc = RefineScene(rm["class_names"], bank, rm["boxes"][-1].detach().clone(), S)
+            with torch.no_grad():
+                tgt, _, sizes = sc.render(rm["boxes"], rm["angles"].float())
+            scenes.append(sc); targets.append(tgt); size_targets.append(sizes.detach().clone().contiguous())
+            box_last[r] = rm["boxes"][-1].detach().float(); angle_last[r] = rm["angles"][-1].detach().float()
+        self.z, self.scenes = z, scenes
+        self.noise_all = noise.to(dev)
+        self.box_last, self.angle_last = box_last, angle_last
+        # ---- the loss of all rooms: one descriptor, per-room normalisation ----
+        self.loss = RefineLoss(torch.cat(targets, 0), per_room=True)
+        del targets
+        # ---- R parameter copies, R engines, one launch program ----
+        nflat = model.flat_params.numel()
+        self.params = model.flat_params.detach().unsqueeze(0).repeat(R, 1).contiguous()
+        self.grads = torch.zeros(R, nflat, **f32)
+        self._engines = model.room_engines(self.params, self.grads, max(self.rows), max(int(rm["triples"].shape[0]) for rm in rooms))
+        st = _lib.current_stream_ptr()
+        self._keep = []
+        for (h, _ws, _arr), rm in zip(self._engines, rooms):
+            n = int(rm["objs"].shape[0])
+            objs, tri, attrs = (rm[k].to(torch.int64).contiguous() for k in ("objs", "triples", "attributes"))
+            zb, za = torch.zeros(n, model.box_dim, **f32), torch.zeros(n, dtype=torch.int64, device=dev)
+            b = _lib.SlnVaeBatch()
+            b.objs, b.triples, b.boxes, b.angles, b.attributes = objs.data_ptr(), tri.data_ptr(), zb.data_ptr(), za.data_ptr(), attrs.data_ptr()
+            b.O, b.T = n, int(tri.shape[0])
+            _lib.check(L.sln_vae_set_batch(h, C.byref(b), st), "sln_vae_set_batch")
+            self._keep.append((objs, tri, attrs, zb, za))
+        self.boxes_pred, self.angles_pred = torch.empty(N, model.box_dim, **f32), torch.empty(N, na, **f32)
+        self.d_boxes_pred, self.d_angles_pred = torch.zeros(N, 8, **f32), torch.empty(N, na, **f32)
+        self.dz = torch.empty(N, E, **f32)
+        io = _lib.SlnVaeGroupIO()
+        io.rows_total = N
+        self._row0_c = (C.c_int * R)(*self.row0)
+        io.row0_host = self._row0_c
+        io.z, io.boxes_pred, io.angles_pred = self.z.data_ptr(), self.boxes_pred.data_ptr(), self.angles_pred.data_ptr()
+        io.d_boxes_pred, io.d_angles_pred, io.dz = self.d_boxes_pred.data_ptr(), self.d_angles_pred.data_ptr(), self.dz.data_ptr()
+        harr = (C.c_void_p * R)(*[e[0] for e in self._engines])
+        g = C.c_void_p()
+        torch.cuda.current_stream(dev).synchronize()          # the tables of the program are uploaded with blocking copies
+        _lib.check(L.sln_vae_group_create(harr, R, C.byref(io), C.byref(g)), "sln_vae_group_create")
+        self._group = g
+        # ---- head / placement tables ----
+        self.room_of_row = torch.cat([torch.full((n,), r, dtype=torch.int32) for r, n in enumerate(self.rows)]).to(dev)
+        self.last_row = torch.tensor([a + n - 1 for a, n in zip(self.row0, self.rows)], dtype=torch.int32, device=dev)
+        self.boxes, self.idx = torch.empty(N, 6, **f32), torch.empty(N, **f32)
+        self.g_boxes, self.g_idx = torch.empty(N, 6, **f32), torch.empty(N, **f32)
+        self.F2 = 2 * max(sc.desc.F for sc in scenes)
+        self.n_max = max(self.rows)
+        self.faces = torch.zeros(R, self.F2, 3, 3, **f32)             # rows beyond a room's 2 F stay degenerate triangles of no class
+        self.g_faces = torch.empty(R, self.F2, 3, 3, **f32)
+        cls = torch.full((R, self.F2), -1, dtype=torch.int32, device=dev)
+        self.sizes = torch.zeros(R, max(max(sc.n_vis for sc in scenes), 1), 3, **f32)
+        self.size_loss = torch.zeros(R, **f32)
+        self.g_size_loss = torch.full((1,), 2.0, **f32)               # loss = ... + 2 * size_loss (test_render_refine.py:350-352)
+        self._size_targets = size_targets
+        tab = (_lib.SlnPlacementRoom * R)()
+        for r, sc in enumerate(scenes):
+            cls[r, :2 * sc.desc.F] = sc.cls2[0]
+            e, a = tab[r], self.row0[r]
+            e.P = sc.desc
+            e.boxes, e.angles = self.boxes.data_ptr() + 24 * a, self.idx.data_ptr() + 4 * a
+            e.size_target = size_targets[r].data_ptr() if sc.n_vis else None
+            e.faces_out, e.sizes, e.size_loss = self.faces[r].data_ptr(), self.sizes[r].data_ptr(), self.size_loss.data_ptr() + 4 * r
+            e.grad_faces, e.grad_size_loss = self.g_faces[r].data_ptr(), self.g_size_loss.data_ptr()
+            e.grad_boxes, e.grad_angles = self.g_boxes.data_ptr() + 24 * a, self.g_idx.data_ptr() + 4 * a
+        self._place_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
+        self.cls = cls
+        self.chan, self.dch = scenes[0].chan, scenes[0].dch
+        for sc in scenes[1:]:
+            if not (torch.equal(sc.chan, self.chan) and torch.equal(sc.dch, self.dch)):
+                raise _lib.SlnError("rooms of one batch must share the class tables")
+        self.S = S
+        self.scene_ws = torch.empty(int(L.sln_scene_workspace_bytes(R, self.F2, S)), dtype=torch.uint8, device=dev)
+        self.image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
+        self.g_image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
+        self.loss_out = torch.empty(R, 3, **f32)
+        self.one = torch.ones(1, **f32)
+        self.losses = torch.zeros(max(self.iters, 1), R, **f32)
+        rg = model.decoder_param_ranges()
+        self._sgd_off = (C.c_int64 * len(rg))(*[a for a, _ in rg])
+        self._sgd_len = (C.c_int64 * len(rg))(*[b for _, b in rg])
+        self._n_rg = len(rg)
+        self.noise = torch.zeros(N, **f32)
+        self._graph = None
+        self.k = 0
+
+    def launches(self):
+        f, b, s1 = C.c_int(0), C.c_int(0), C.c_int(0)
+        _lib.check(_lib.lib().sln_vae_group_launches(self._group, C.byref(f), C.byref(b), C.byref(s1)), "sln_vae_group_launches")
+        return dict(decoder_forward=f.value, decoder_backward=b.value, single_room_fallbacks=s1.value)
+
+    def _iteration(self, noise, out):
+        """one iteration of every room on the current stream; ``noise`` [N], ``out`` [R] receives the rooms' losses"""
+        L, st, P = _lib.lib(), _lib.current_stream_ptr(), _lib.ptr
+        N, R, na, S = self.N, self.R, self.model.Nangle, self.S
+        _lib.check(L.sln_vae_group_decoder(self._group, st), "sln_vae_group_decoder")
+        _lib.check(L.sln_refine_head_forward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.boxes_pred), P(self.angles_pred), P(noise),
+                                                   P(self.box_last), P(self.angle_last), 2.0, P(self.boxes), P(self.idx), st), "sln_refine_head_forward_rooms")
+        _lib.check(L.sln_place_forward_rooms(P(self._place_tab), R, self.F2 // 2, st), "sln_place_forward_rooms")
+        _lib.check(L.sln_scene_forward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0, 1e-3,
+                                       P(self.scene_ws), P(self.image), st), "sln_scene_forward")
+        rl = self.loss
+        _lib.check(L.sln_refine_loss_forward(rl.desc, P(self.image), P(rl.target_depth), P(rl.labels), P(rl.inv_count), P(rl.ws), P(self.loss_out), st),
+                   "sln_refine_loss_forward")
+        torch.add(self.loss_out[:, 0], self.size_loss, alpha=2.0, out=out)
+        _lib.check(L.sln_refine_loss_backward(rl.desc, P(rl.ws), P(self.one), P(self.g_image), st), "sln_refine_loss_backward")
+        _lib.check(L.sln_scene_backward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 1e-3, P(self.scene_ws),
+                                        P(self.g_image), P(self.g_faces), st), "sln_scene_backward")
+        _lib.check(L.sln_place_backward_rooms(P(self._place_tab), R, self.n_max, st), "sln_place_backward_rooms")
+        _lib.check(L.sln_refine_head_backward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.angles_pred), P(self.g_boxes), P(self.g_idx), 2.0,
+                                                    P(self.d_boxes_pred), 8, P(self.d_angles_pred), st), "sln_refine_head_backward_rooms")
+        _lib.check(L.sln_vae_group_decoder_backward(self._group, st), "sln_vae_group_decoder_backward")
+        _lib.check(L.sln_refine_sgd_rooms(P(self.params), P(self.grads), R, self.params.shape[1], self._sgd_off, self._sgd_len, self._n_rg,
+                                          (self.lr / 10.0) * 1.1, P(self.z), P(self.dz), self.z.numel(), 2e-4 * 1.1, st), "sln_refine_sgd_rooms")
+
+    def run(self, iters=None, capture=False):
+        """``iters`` more iterations (default: all that remain).  ``capture``: one iteration recorded into a hipGraph and replayed."""
+        n = (self.iters - self.k) if iters is None else int(iters)
+        if self.k + n > self.iters:
+            raise ValueError("RefineBatch was built for %d iterations (the noise of every iteration is drawn at construction)" % self.iters)
+        scratch = self.loss_out.new_empty(self.R)
+        for _ in range(n):
+            k = self.k
+            if capture:
+                self.noise.copy_(self.noise_all[k])
+                if self._graph is None:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):                  # warm-up outside the capture (lazy kernel attributes)
+                        self._iteration(self.noise, self.losses[k])
+                    torch.cuda.current_stream().wait_stream(side)
+                    self._graph = torch.cuda.CUDAGraph()
+                    self._graph_out = scratch
+                    with torch.cuda.graph(self._graph):
+                        self._iteration(self.noise, self._graph_out)
+                else:
+                    self._graph.replay()
+                    self.losses[k].copy_(self._graph_out)
+            else:
+                self._iteration(self.noise_all[k], self.losses[k])
+            self.k += 1
+        return self.losses[:self.k]
+
+    def results(self):
+        """[(boxes_full [n,6], angle idx [n]) per room] of the last iteration"""
+        return [(self.boxes[a:a + n], self.idx[a:a + n]) for a, n in zip(self.row0, self.rows)]
+
+    def close(self):
+        L = _lib.lib()
+        if getattr(self, "_group", None) is not None:
+            torch.cuda.synchronize()
+            L.sln_vae_group_destroy(self._group)
+            self._group = None
+        for e in getattr(self, "_engines", []):
+            L.sln_vae_destroy(e[0])
+        self._engines = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def finetune_vae_fast_batch(model, rooms, iters=60, bank=None, learning_rate=1e-4, noise_seed=13, image_size=256, capture=False):
+    """``finetune_vae_fast`` for R rooms at once (see ``RefineBatch``): every room from ``model``'s parameters, its own z, its own
+    noise stream (seeded like a single-room call).  -> (losses [iters, R] on the device, [(boxes, angle idx) per room])."""
+    rb = RefineBatch(model, rooms, bank=bank, learning_rate=learning_rate, noise_seed=noise_seed, image_size=image_size, iters=iters)
+    try:
+        losses = rb.run(capture=capture).clone()
+        res = [(b.clone(), i.clone()) for b, i in rb.results()]
+    finally:
+        rb.close()
+    return losses, res
 
 
 def finetune_vae(model, objs, triples, boxes_gt, angles_gt, attributes, class_names, iters=60, render_fn=None, bank=None,

@@ -181,6 +181,34 @@ int sln_vae_set_training(SlnVae* h, int training);
 int sln_vae_train_step(SlnVae* h, const float* eps, float kl_weight, float lr, float* losses_out, int use_graph,
                        int with_adam, void* stream);
 
+/* R rooms in flight: the decoder of R engines as one launch sequence (layout refinement, testing/test_render_refine.py:250-263:
+ * every trial - room - reloads the checkpoint, model.eval(), and :279-359 runs 60 dependent iterations of
+ * decoder -> render -> loss -> backward -> SGD on z AND on its own copy of the parameters; trials are independent).
+ * `engines`: R handles created and bound by the caller on R parameter copies (sln_vae_create / sln_vae_bind) with their rooms'
+ * graphs set (sln_vae_set_batch; the boxes / angles of a decoder-only room are not read); same SlnVaeConfig; eval-mode BatchNorm.
+ * The group takes the engines over: their decoder outputs and gradient inputs become slices [row0[r], row0[r] + O_r) of the
+ * row-concatenated arrays below, and sln_vae_group_decoder / _backward run sln_vae_decoder(training = 0) /
+ * sln_vae_decoder_backward of all rooms - one launch per step for all rooms instead of one per step and room.  A room's results
+ * do not depend on R (same kernel bodies, one room per grid slice).  The engines must outlive the group; destroy the group first. */
+typedef struct SlnVaeGroup SlnVaeGroup;
+typedef struct SlnVaeGroupIO {
+  int rows_total;                 /* sum over the rooms of their object rows                                            */
+  const int* row0_host;           /* HOST [R]: first row of room r                                                       */
+  const float* z;                 /* [rows_total, E]        decoder input, read by every forward                         */
+  float* boxes_pred;              /* [rows_total, box_dim]  written by forward                                           */
+  float* angles_pred;             /* [rows_total, n_angle]  log-softmax, written by forward, read by backward            */
+  float* d_boxes_pred;            /* [rows_total, 8]        gradient w.r.t. boxes_pred, row stride 8 (columns >= box_dim 0) */
+  float* d_angles_pred;           /* [rows_total, n_angle]  gradient w.r.t. the log-softmax output                       */
+  float* dz;                      /* [rows_total, E]        written by backward                                          */
+} SlnVaeGroupIO;
+int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io, SlnVaeGroup** out);
+int sln_vae_group_decoder(SlnVaeGroup* g, void* stream);
+/* parameter gradients are accumulated (+=) into every room's gradient buffer, dz is written */
+int sln_vae_group_decoder_backward(SlnVaeGroup* g, void* stream);
+/* launches per forward / backward pass and how many of them are single-room fallbacks (diagnostics) */
+int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single_room_fallbacks);
+void sln_vae_group_destroy(SlnVaeGroup* g);
+
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline figures).
  * Families: 0 gemm_nt (forward/dgrad), 1 gemm_tn (wgrad), 2 edge scatter/gather, 3 other.
  * enable=1 starts recording (eager launches only, not under graph capture); sln_prof_read
@@ -330,11 +358,38 @@ int sln_refine_head_backward(int n, int n_angle, const float* angles_pred, const
 int sln_refine_sgd(float* params, float* grads, int64_t n, float step, float* z, const float* grad_z, int64_t nz, float step_z,
                    void* stream);
 
+/* ---- R rooms per launch (the rooms of testing/test_render_refine.py:250-263 are independent: one iteration of all of them) ----
+ * Rows of all rooms concatenated (rows_total); room_of_row [rows_total] int32; last_row [R] = the room's frozen last row.
+ * head forward / backward as sln_refine_head_forward / _backward per room: box_last [R,6], angle_last [R]; the backward writes
+ * grad_boxes_pred with row stride ld_gb (8 = the engine's padded gradient layout, the padding columns are zeroed). */
+int sln_refine_head_forward_rooms(int rows_total, int n_angle, const int32_t* room_of_row, const int32_t* last_row, const float* boxes_pred,
+                                  const float* angles_pred, const float* noise, const float* box_last, const float* angle_last, float beta,
+                                  float* boxes_full, float* idx, void* stream);
+int sln_refine_head_backward_rooms(int rows_total, int n_angle, const int32_t* room_of_row, const int32_t* last_row, const float* angles_pred,
+                                   const float* grad_boxes_full, const float* grad_idx, float beta, float* grad_boxes_pred, int ld_gb,
+                                   float* grad_angles_pred, void* stream);
+/* sln_place_forward / _backward of R rooms in one launch each: `rooms` is a DEVICE array of R blocks (the room's descriptor and its
+ * tensors); F_max / n_max the largest face / row count (grid sizing). */
+typedef struct {
+  SlnPlacement P;
+  const float* boxes; const float* angles; const float* size_target;      /* [n,6], [n], [n_vis,3] or NULL */
+  float* faces_out; float* sizes; float* size_loss;                        /* [2F,3,3], [n_vis,3], [1] */
+  const float* grad_faces; const float* grad_size_loss; float* grad_boxes; float* grad_angles;   /* backward */
+} SlnPlacementRoom;
+int sln_place_forward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int F_max, void* stream);
+int sln_place_backward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int n_max, void* stream);
+/* sln_refine_sgd over R parameter copies: for every room r and every range k: p[r * stride + off_k + i] -= step * g[...], g = 0
+ * (i < len_k; off_k, len_k multiples of 4 floats; n_ranges <= 4: the decoder's parameters are the three *_dc embedding tables in
+ * front and the trailing gconv_net_dc / box_net / angle_net run - encoder-only parameters have zero gradients in this loop and are
+ * not touched); z [nz] -= step_z * grad_z. */
+int sln_refine_sgd_rooms(float* params, float* grads, int R, int64_t stride, const int64_t* off_host, const int64_t* len_host, int n_ranges,
+                         float step, float* z, const float* grad_z, int64_t nz, float step_z, void* stream);
+
 /* Refinement loss of the layout-refinement loop (testing/test_render_refine.py:192-215 PSP_pool_new, :332-356):
  * null-fill of the last depth channel, bilinear(align_corners=True) resampling of the 40 semantic and 29 depth channels of
  * the [B,70,S,S] scene tensor to each scale and bilinear resampling to pooled_size, L1 against the pooled target depth * 0.5,
  * sum over the scales of cross-entropy against the target's labels / 800;  loss_out = {100 * depth + 100 * sem, depth, sem}
- * (the caller adds 2 * size_loss).  All table pointers are DEVICE arrays the caller builds once per geometry:
+ * (the caller adds 2 * size_loss; per_room: one such triple per image).  All table pointers are DEVICE arrays the caller builds once per geometry:
  *   stage 2 (scale -> pooled, align_corners=False), per scale and pooled index: source rows k0, k1 and the weight of k1;
  *   stage 1 (image -> scale, align_corners=True), per scale and scale index (row stride stage1_stride): i0, i1, weight of i1;
  *   transposed composite operator for backward, CSR per scale over the image index: col_ptr [n_scales][S+1] (global offsets),
@@ -348,7 +403,9 @@ typedef struct {
   const int32_t* s2_k0; const int32_t* s2_k1; const float* s2_l1;     /* [n_scales][pooled_size] */
   const int32_t* s1_i0; const int32_t* s1_i1; const float* s1_l1;     /* [n_scales][stage1_stride] */
   const int32_t* col_ptr; const int32_t* col_out; const float* col_w;
-  int max_col_entries, reserved;                /* longest CSR row (selects the register-list backward kernel when <= 5); 0 = unknown */
+  int max_col_entries;                          /* longest CSR row (selects the register-list backward kernel when <= 5); 0 = unknown */
+  int per_room;                                 /* != 0: the B images are B independent rooms (one refinement loop each): loss_out is
+                                                 * [B][3], every room's L1 mean runs over its own elements, inv_count is [B][n_scales] */
 } SlnRefineLoss;
 int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
 int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */
