@@ -367,6 +367,16 @@ inline int small_batch_split(long units, int max_split, long budget = 32768) {
   while (s < max_split && units * s * 2 <= budget) s *= 2;        // stay below `budget` workgroups
   return s;
 }
+// depth backward: one wavefront per (face, slice of its bounding-box walk).  A face's walk is a serial chain of dependent loads; a
+// few big faces (the wall / floor quads of a refinement room fill the view) set the launch's duration whatever the face count, and
+// a slice without pixels costs a wavefront that reads nine floats and leaves: split by default while the grid stays below
+// `budget` wavefronts (16 refinement rooms, 22 k faces: 247 -> us with the split of 8 the face count alone denied)
+// ... but only for images of FEW faces (<= 2 048: few faces over a fixed image area are big faces): the 16 x 4 000-face batch of
+// BASELINE config c3 went 0.596 -> 0.643 ms per batch with the split everywhere, 16 refinement rooms (1 400 faces each) 247 -> 130 us
+inline int depth_bwd_split(long units, int F) {
+  static const int few = std::getenv("SLN_DEPTH_SPLIT_FACES") ? std::atoi(std::getenv("SLN_DEPTH_SPLIT_FACES")) : 2048;
+  return F <= few ? small_batch_split(units, 8, 1L << 20) : small_batch_split(units, 8);
+}
 inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F); }
 inline bool pixel_map_grid_ok(int B, int F) { return (long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F * 6 < (1L << 31); }   // 32-bit workgroup ids in the kernel
 inline int pixel_map_scan_split(long faces_total, int B) {
@@ -941,7 +951,7 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
   (void)npix;
   if ((long)B * F > 0)
     // (deterministic mode: one wavefront per face - a single add per value onto the caller's zeros)
-    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), g_sln_deterministic ? 1 : small_batch_split((long)B * F, 8)), dim3(64), 0, st, faces,
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), g_sln_deterministic ? 1 : depth_bwd_split((long)B * F, F)), dim3(64), 0, st, faces,
                        face_index, weight, depth, grad_depth, F, image_size, grad_faces);
   SLN_CHECK_LAUNCH();
   return 0;
@@ -1494,7 +1504,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipLaunchKernelGGL(scene_bwd_depthgrad_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, sd_st, w.fiB, w.val, w.dA,
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   if (!det)
-    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, small_batch_split(n, 8)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, depth_bwd_split(n, F)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
                        grad_faces);
   hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
                      num_classes, 70, w.prec, w.precT);

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "sln_common.h"
 #include "sln_hip.h"
@@ -88,6 +89,47 @@ __global__ __launch_bounds__(256) void pool_kernel(const float* __restrict__ img
       }
     }
     dst[(long)cc * pp] = ly0 * (lx0 * inter[0][0] + lx1 * inter[0][1]) + ly1 * (lx0 * inter[1][0] + lx1 * inter[1][1]);
+  }
+}
+
+// The same resampling with the INTERMEDIATE image of a (plane, scale) in LDS (round 5): one workgroup per (image b, loss channel,
+// scale).  Phase A evaluates the align_corners=True stage once per intermediate pixel (4 image taps each: sz^2 evaluations instead of
+// the 4 P^2 the per-pixel kernel above repeats - 16 640 against 147 456 per plane over the four scales), phase B the second stage
+// from LDS with coalesced stores.  Same expressions, same order: the results are bit-identical to pool_kernel's.  With 16 rooms in
+// flight pool_kernel was the largest kernel of a refinement iteration (510 us: 680 M scattered 4-byte taps).
+constexpr int POOL_LDS_MAX = 96;
+__global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__ img, const unsigned char* __restrict__ null, const int null_fill,
+                                                       RefineDims d,
+                                                       const int* __restrict__ s2_k0, const int* __restrict__ s2_k1, const float* __restrict__ s2_l1,
+                                                       const int* __restrict__ s1_i0, const int* __restrict__ s1_i1, const float* __restrict__ s1_l1,
+                                                       float* __restrict__ pooled) {
+  __shared__ float inter[POOL_LDS_MAX * POOL_LDS_MAX];
+  const int nc = d.n_sem + d.n_dep;
+  const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
+  const int c = d.sem0 + cc;
+  const int sz = s2_k1[s * d.P + d.P - 1] + 1;                    // intermediate size of this scale (the last pooled index reads its last row)
+  const long plane = (long)d.S * d.S;
+  const bool fill = null_fill && c == d.dep0 + d.n_dep - 1;       // the last depth channel is set to 1 where no class has depth
+  const float* src = img + ((long)b * d.C + c) * plane;
+  const unsigned char* nm = null + (long)b * plane;
+  for (int i = threadIdx.x; i < sz * sz; i += 256) {
+    const int ky = i / sz, kx = i % sz;
+    const int y0 = s1_i0[s * d.pmax + ky], y1 = s1_i1[s * d.pmax + ky], x0 = s1_i0[s * d.pmax + kx], x1 = s1_i1[s * d.pmax + kx];
+    const float h1 = s1_l1[s * d.pmax + ky], h0 = 1.f - h1, w1 = s1_l1[s * d.pmax + kx], w0 = 1.f - w1;
+    float v00 = src[(long)y0 * d.S + x0], v01 = src[(long)y0 * d.S + x1], v10 = src[(long)y1 * d.S + x0], v11 = src[(long)y1 * d.S + x1];
+    if (fill) {
+      v00 = nm[(long)y0 * d.S + x0] ? 1.f : v00; v01 = nm[(long)y0 * d.S + x1] ? 1.f : v01;
+      v10 = nm[(long)y1 * d.S + x0] ? 1.f : v10; v11 = nm[(long)y1 * d.S + x1] ? 1.f : v11;
+    }
+    inter[i] = h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11);
+  }
+  __syncthreads();
+  float* dst = pooled + ((long)(b * d.n_scales + s) * nc + cc) * ((long)d.P * d.P);
+  for (int o = threadIdx.x; o < d.P * d.P; o += 256) {
+    const int oy = o / d.P, ox = o % d.P;
+    const int ky0 = s2_k0[s * d.P + oy], ky1 = s2_k1[s * d.P + oy], kx0 = s2_k0[s * d.P + ox], kx1 = s2_k1[s * d.P + ox];
+    const float ly1 = s2_l1[s * d.P + oy], lx1 = s2_l1[s * d.P + ox], ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+    dst[o] = ly0 * (lx0 * inter[ky0 * sz + kx0] + lx1 * inter[ky0 * sz + kx1]) + ly1 * (lx0 * inter[ky1 * sz + kx0] + lx1 * inter[ky1 * sz + kx1]);
   }
 }
 
@@ -262,13 +304,31 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   }
   __syncthreads();
   const long pp = (long)d.P * d.P;
-  for (int i = threadIdx.x; i < d.n_scales * ROWS * d.P; i += 256) {
-    const int o = i % d.P, r = (i / d.P) % ROWS, s = i / (d.P * ROWS);
-    const float* dp = dpooled + ((long)(b * d.n_scales + s) * nc + cc) * pp + o;
-    float t = 0.f;
+  // four elements per pass, their 4 x MAXX loads issued together: one element at a time (MAXX loads in flight per thread, 24 dependent
+  // round trips per workgroup) left the kernel latency-bound - 405 us for 16 rooms against ~130 us of LDS + L1 issue time
+  {
+    const int n1 = d.n_scales * ROWS * d.P;
+    constexpr int U = 4;
+    for (int i0 = threadIdx.x; i0 < n1; i0 += 256 * U) {
+      float v[U][MAXX]; float wgt[U][MAXX]; int si[U], ri[U], oi[U];
 #pragma unroll
-    for (int e = 0; e < MAXX; ++e) t = fmaf(yw[s * ROWS + r][e], dp[(long)yo[s * ROWS + r][e] * d.P], t);
-    T[s][r][o] = t;
+      for (int u = 0; u < U; ++u) {
+        const int i = min(i0 + 256 * u, n1 - 1);
+        oi[u] = i % d.P; ri[u] = (i / d.P) % ROWS; si[u] = i / (d.P * ROWS);
+        const float* dp = dpooled + ((long)(b * d.n_scales + si[u]) * nc + cc) * pp + oi[u];
+#pragma unroll
+        for (int e = 0; e < MAXX; ++e) { wgt[u][e] = yw[si[u] * ROWS + ri[u]][e]; v[u][e] = dp[(long)yo[si[u] * ROWS + ri[u]][e] * d.P]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (i0 + 256 * u < n1) {
+          float t = 0.f;
+#pragma unroll
+          for (int e = 0; e < MAXX; ++e) t = fmaf(wgt[u][e], v[u][e], t);
+          T[si[u]][ri[u]][oi[u]] = t;
+        }
+      }
+    }
   }
   __syncthreads();
   if (!active) return;
@@ -335,6 +395,12 @@ static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float
                         hipStream_t st) {
   const long npix = (long)d.B * d.S * d.S;
   if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask);
+  static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
+  if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
+    hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
+                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled);
+    return;
+  }
   const long np = (long)d.B * d.n_scales * sln_cdiv(d.n_sem + d.n_dep, CG) * d.P * d.P;
   hipLaunchKernelGGL(pool_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1, L->s2_l1,
                      L->s1_i0, L->s1_i1, L->s1_l1, pooled);
