@@ -116,6 +116,8 @@ SIGNATURES = {
     "sln_vae_set_grad_guard": (C.c_int, [C.c_void_p, c_f32p]),
     "sln_vae_seed": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "sln_vae_last_eps": (C.c_int, [C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_vae_randn": (C.c_int, [C.c_void_p, c_f32p, C.c_int64, C.c_void_p]),
+    "sln_layout_heatmap": (C.c_int, [c_f32p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, C.c_void_p]),
     "sln_vae_set_training": (C.c_int, [C.c_void_p, C.c_int]),
     "sln_vae_train_step": (C.c_int, [C.c_void_p, c_f32p, C.c_float, C.c_float, c_f32p, C.c_int, C.c_int, C.c_void_p]),
     "sln_vae_group_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(SlnVaeGroupIO), C.POINTER(C.c_void_p)]),

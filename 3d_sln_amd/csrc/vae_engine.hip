@@ -1412,6 +1412,19 @@ int sln_vae_seed(SlnVae* h, uint64_t seed, uint64_t offset, void* stream) {
   return 0;
 }
 
+int sln_vae_randn(SlnVae* h, float* out, int64_t n, void* stream) {
+  if (!h || !h->bound || !out || n < 0) return SLN_E_BADARG;
+  if (n == 0) return 0;
+  return sln_launch_randn(out, (long)n, h->scalars, (hipStream_t)stream);
+}
+
+int sln_layout_heatmap(const float* boxes_pred, int64_t n_trials, int O, int box_dim, int container_size, int clip_coor, float* counts,
+                       void* stream) {
+  if (!boxes_pred || !counts || n_trials < 0 || O < 2 || container_size < 2) return SLN_E_BADARG;
+  if (box_dim != 6) return SLN_E_UNSUPPORTED;
+  return sln_launch_layout_heatmap(boxes_pred, (long)n_trials, O, container_size, clip_coor, counts, (hipStream_t)stream);
+}
+
 int sln_vae_last_eps(SlnVae* h, float* eps_out, void* stream) {
   if (!h || !h->batch_set || !eps_out) return SLN_E_STATE;
   return copy_out(eps_out, h->eps_buf, (size_t)h->O * h->E, (hipStream_t)stream);

@@ -156,3 +156,5 @@ struct StepPrologue {
   void* zero_ptr; long zero_bytes;      // optional: a region to clear (16-byte aligned, a multiple of 16 bytes): the iteration's loss accumulators and BatchNorm sums
 };
 int sln_launch_step_prologue(const StepPrologue& a, hipStream_t st);
+// counts[obj][floor(cz (cs - 1))][floor(cx (cs - 1))] += 1 for every (trial, object != room row): testing/test_heatmap.py:80-99
+int sln_launch_layout_heatmap(const float* boxes, long n_trials, int O, int cs, int clip, float* counts, hipStream_t st);

@@ -1648,3 +1648,32 @@ int sln_launch_zero_multi(const MZero* tab, int R, long max_n16, hipStream_t st)
   SLN_CHECK_LAUNCH();
   return 0;
 }
+
+// ---- posterior heat map (testing/test_heatmap.py:80-99): counts[obj][rd_z][rd_x] += 1 over the trials, one thread per (trial, object) ----
+namespace {
+__global__ void layout_heatmap_kernel(const float* __restrict__ boxes, long n_trials, int O, int cs, int clip, float* __restrict__ counts) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_trials * (O - 1)) return;
+  const long trial = i / (O - 1); const int obj = (int)(i % (O - 1));
+  const float* room = boxes + (trial * O + (O - 1)) * 6;
+  const float* b = boxes + (trial * O + obj) * 6;
+  float ct[3]; bool keep = true;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const float ext = room[3 + j] - room[j];
+    ct[j] = (b[j] * ext + b[3 + j] * ext) * 0.5f;
+    if (!clip) keep = keep && ct[j] > 0.f && ct[j] < 1.f;
+    ct[j] = fminf(fmaxf(ct[j], 0.f), 1.f);
+  }
+  if (!keep) return;
+  const int rz = (int)floorf(ct[2] * (float)(cs - 1)), rx = (int)floorf(ct[0] * (float)(cs - 1));
+  atomicAdd(counts + ((long)obj * cs + rz) * cs + rx, 1.0f);
+}
+}  // namespace
+int sln_launch_layout_heatmap(const float* boxes, long n_trials, int O, int cs, int clip, float* counts, hipStream_t st) {
+  const long n = n_trials * (O - 1);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(layout_heatmap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, boxes, n_trials, O, cs, clip, counts);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}

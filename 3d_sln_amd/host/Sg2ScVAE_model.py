@@ -234,6 +234,15 @@ class Sg2ScVAEModel(nn.Module):
         _lib.check(_lib.lib().sln_vae_last_eps(self._eng, _lib.ptr(out), _lib.current_stream_ptr()), "sln_vae_last_eps")
         return out
 
+    def device_randn(self, rows, cols):
+        """[rows, cols] ~ N(0,1) drawn ON THE DEVICE from the engine's Philox stream (``manual_seed``): the z draws of posterior
+        sampling (host/sampling.py) - no host generator, no host-to-device copy of the sample."""
+        if self._eng is None:
+            self._ensure_engine(1, 1)
+        out = self._new(int(rows), int(cols))
+        _lib.check(_lib.lib().sln_vae_randn(self._eng, _lib.ptr(out), out.numel(), _lib.current_stream_ptr()), "sln_vae_randn")
+        return out
+
     def params_changed(self):
         """Call after modifying parameters outside the engine (e.g. a torch optimizer step)."""
         if self._eng is not None:

@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--no-graph-build", action="store_true")
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
+    ap.add_argument("--refine-rooms", type=int, default=16, help="rooms in flight of the batched refinement leg")
+    ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--sampling-draws", type=int, default=20000, help="posterior draws of the heat-map leg (testing/test_heatmap.py:39: num_iter)")
     ap.add_argument("--large-batches", type=str, default="128,256,512,1024,4096", help="extra VAE points (graphs per step; 128 = options/options.py:34, 512 = configs[4]'s global batch on one GPU), '' = none")
     ap.add_argument("--no-colorize", action="store_true", help="skip the one-map / 50-z SPADE leg (per-leg profiles: batch-32 launches only)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the unchanged-call-sequence legs (vae_dropin, render_33pass, spade_50x1)")
@@ -638,7 +641,11 @@ def graph_build_leg(args, lib, torch):
     torch.cuda.synchronize()
     dth = (time.perf_counter() - t0) / args.graph_iters
     nbytes = sum(int(t.numel()) * t.element_size() for t in out) + O * 6 * 4          # outputs + the raw boxes read
-    res = {"graphs_per_s": round(B / dt, 1), "us_per_batch": round(dt * 1e6, 1), "us_per_batch_host_indices": round(dth * 1e6, 1),
+    res = {"roofline": {"kernel": "sln_graph_plan + sln_graph_draw + sln_graph_emit of one batch (host-indexed form)", "bound": "hbm", "unit": "GB/s",
+                        "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_launch": int(nbytes), "achieved": round(nbytes / dth / 1e9, 2),
+                        "frac": round(nbytes / dth / 1e9 / HBM_PEAK_GBS, 5), "traffic": None,
+                        "note": "a batch is ~1.5 MB of outputs: three launches at the launch floor, not a bandwidth problem"},
+           "graphs_per_s": round(B / dt, 1), "us_per_batch": round(dt * 1e6, 1), "us_per_batch_host_indices": round(dth * 1e6, 1),
            "graphs_per_s_host_indices": round(B / dth, 1), "batch": B, "objects": O, "triples": T,
            "algorithmic_bytes_per_batch": nbytes,
            "workload": "%d rooms x %d objects: 'on' pairs over all ordered pairs, one drawn relation per object, in-room rows, "
@@ -716,7 +723,92 @@ def refine_leg(args, lib, torch):
             b_, _ = timed(2 * iters, True)
             g1s.append(a_); g2s.append(b_)
         gslopes = sorted((b_ - a_) / iters for a_, b_ in zip(g1s, g2s))
-    return {"ms_per_iteration": round(per_iter * 1e3, 3), "ms_per_iteration_min_median_max": [round(x * 1e3, 3) for x in slopes],
+    # ---- R rooms in flight (round 5): testing/test_render_refine.py:250-263 runs its rooms one after the other; RefineBatch runs
+    # `--refine-rooms` of them (each on its own copy of the parameters) as one launch sequence per iteration
+    nr = args.refine_rooms
+    rooms = []
+    for r in range(nr):
+        gr = torch.Generator().manual_seed(100 + r)
+        lo_r = torch.rand(n, 3, generator=gr) * 0.45 + 0.05; lo_r[:, 1] = 0.0; lo_r[:, 2] *= 0.6
+        hi_r = lo_r + torch.rand(n, 3, generator=gr) * 0.2 + 0.12
+        bx = torch.cat([lo_r, hi_r], 1); bx[-1] = torch.tensor([0, 0, 0, 4.0, 2.7, 5.0])
+        rooms.append(dict(objs=objs, triples=triples, boxes=bx.cuda(), angles=torch.randint(0, 24, (n,), generator=gr).cuda(), attributes=attrs,
+                          class_names=names))
+    model.load_state_dict(sd0)
+    batch = {}
+    with torch.cuda.stream(st):
+        runs = []
+        for n_it in (iters, 2 * iters, iters, 2 * iters, iters, 2 * iters):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            rb.run()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            runs.append((n_it, t1 - t0, t2 - t1))
+            info, fin = rb.launches(), bool(torch.isfinite(rb.losses).all().item())
+            rb.close()
+        a_ = sorted(x[2] for x in runs if x[0] == iters)[1]; b_ = sorted(x[2] for x in runs if x[0] == 2 * iters)[1]
+        it_ms = (b_ - a_) / iters * 1e3
+        plane = 256.0 * 256.0 * 4.0
+        dec_bytes = 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
+        # algorithmic HBM bytes of one room-iteration: the 70-plane scene tensor written, read by the pooling, its gradient written
+        # and read by the scene backward; the pooled tensor (4 scales x 69 planes of 96 x 96) written, read, its gradient written,
+        # read; the decoder's parameters read by the forward Linears, transposed (read + write), read by the dgrads, their
+        # gradient written by the wgrads, and the SGD update (read p, g; write p, g)
+        algo = 4 * 70 * plane + 4 * (4 * 69 * 96 * 96 * 4.0) + 9 * dec_bytes
+        batch = {"rooms": nr, "ms_per_iteration": round(it_ms, 3), "ms_per_room_iteration": round(it_ms / nr, 4),
+                 "ms_setup_per_room": round(sorted(x[1] for x in runs)[len(runs) // 2] * 1e3 / nr, 2), "iterations": iters, "finite": fin,
+                 "launches": info, "speedup_vs_one_room_at_a_time": round(per_iter * 1e3 / (it_ms / nr), 2),
+                 "roofline": {"kernel": "one refinement iteration of %d rooms (all launches)" % nr, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_room_iteration": int(algo), "achieved": round(algo * nr / (it_ms * 1e-3) / 1e9, 1),
+                              "frac": round(algo * nr / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}
+    cpu_base = None
+    if not args.no_cpu:
+        # CPU baseline: ONE refinement iteration of the same room through the oracle - decoder (oracle/vae_ref.py, autograd),
+        # placement + PSP / L1 / CE loss (oracle/refine_ref.py), 33-pass renderer (oracle/raster_ref.py), all cores; bounded sample
+        from oracle import vae_ref, refine_ref, raster_ref as rr
+        ncores = cpu_threads(torch)
+        torch.set_num_threads(ncores)
+        cfg = vae_ref.VaeConfig()
+        sdc = {k: (v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "running" not in k)) for k, v in sd0.items()}
+        cb, ca = boxes.cpu(), angles.cpu()
+        cbank = R.MeshBank([x for x in names if x != "__room__"], "cpu", seed=3)
+        v0, f0, ranges, sizes0, _ = R.assemble_scene(cb, ca.float(), names, cbank, cb[-1].clone())      # topology + shell vertices (constants)
+        n_objv = sum(cbank.models[x]["v"].shape[0] for x in names[:-1] if x in cbank.models and x not in R.DO_NOT_VIS)
+        shell_v = v0[0, n_objv:].detach()
+        with torch.no_grad():
+            tgt = rr.scene_render(v0.detach(), f0, ranges, cb[-1], image_size=256)
+        lab = refine_ref.target_labels(tgt)
+        zc = torch.randn(n, 64, generator=torch.Generator().manual_seed(13)).requires_grad_(True)
+        co, ct, cat_ = objs.cpu(), triples.cpu(), attrs.cpu()
+        n_cpu, t_cpu = 0, 0.0
+        while n_cpu < 3 and t_cpu < 25.0:
+            t0 = time.perf_counter()
+            bp, ap = vae_ref.decoder(sdc, cfg, zc, co, ct, cat_, training=False)
+            bp.register_hook(R.fix_grad)
+            bfull = torch.cat([bp[:-1], cb[-1:]], 0)
+            idx = R.softargmax(ap, sum_dim=1) + torch.randn(n) / 10.0
+            idx.register_hook(R.quad_grad)
+            idx = torch.cat([idx[:-1], ca[-1:].float()], 0)
+            vo, _, sl = refine_ref.place_scene(bfull, idx, names, cbank.models, [s_.clone() for s_ in sizes0])
+            img = rr.scene_render(torch.cat([vo, shell_v])[None], f0, ranges, cb[-1], image_size=256)
+            loss_c, _, _ = refine_ref.refinement_loss(img, tgt, lab, sl)
+            loss_c.backward()
+            with torch.no_grad():
+                zc -= 2e-4 * 1.1 * zc.grad; zc.grad = None
+                for k_, v_ in sdc.items():
+                    if v_.grad is not None:
+                        v_ -= 1e-5 * 1.1 * v_.grad; v_.grad = None
+            t_cpu += time.perf_counter() - t0; n_cpu += 1
+        cpu_base = {"value": round(n_cpu / t_cpu, 3), "unit": "room-iterations/s", "cores": ncores, "kind": "port",
+                    "sample": "%d iteration(s) of the same 12-object room through oracle/vae_ref.py + refine_ref.py + raster_ref.py (33 brute-force raster "
+                              "passes per render), %.2f s per iteration" % (n_cpu, t_cpu / n_cpu)}
+    one_room_bytes = 4 * 70 * 256.0 * 256.0 * 4.0 + 4 * (4 * 69 * 96 * 96 * 4.0) + 9 * 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
+    return {"rooms_%d" % nr: batch, "cpu_baseline": cpu_base,
+            "roofline": {"kernel": "one refinement iteration of ONE room (all launches; latency-bound: ~110 dependent launches)", "bound": "hbm", "unit": "GB/s",
+                         "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_room_iteration": int(one_room_bytes),
+                         "achieved": round(one_room_bytes / (per_iter) / 1e9, 1), "frac": round(one_room_bytes / per_iter / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},
+            "ms_per_iteration": round(per_iter * 1e3, 3), "ms_per_iteration_min_median_max": [round(x * 1e3, 3) for x in slopes],
             "ms_per_iteration_hipgraph_replay_min_median_max": [round(x * 1e3, 3) for x in gslopes],
             "ms_setup_per_room_hipgraph": round(sorted(a_ - iters * gslopes[1] for a_ in g1s)[1] * 1e3, 2),
             "ms_setup_per_room": round(setup * 1e3, 2),
@@ -725,6 +817,81 @@ def refine_leg(args, lib, torch):
                         "loss tables built on the host) is ms_setup_per_room, ms_per_iteration_incl_setup amortises it over the iterations",
             "workload": "one room, 12 objects + shell (%d triangles x2 fill_back), 256x256, VAE at train.py defaults" %
                         int(R.RefineScene(names, bank, boxes[-1]).faces.shape[0])}
+
+
+def sampling_leg(args, lib, torch):
+    """posterior sampling / heat map of a worded scene (testing/test_heatmap.py:39-64: the default 5-object
+    room, 20 000 draws of z ~ N(mean, cov) per object, one decoder call per draw in the reference).  Here: eps drawn on the device,
+    z = mean + eps L^T as one GEMM, ONE decoder call over the 20 000 replicated graphs, one histogram launch."""
+    S = importlib.import_module("3d_sln_amd.host.sampling")
+    M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    import numpy as np
+    torch.manual_seed(3)
+    vocab = syn.default_vocab()
+    model = M.Sg2ScVAEModel(vocab=vocab, batch_size=1, train_3d=True, decoder_cat=True, embedding_dim=64, gconv_mode='feedforward',
+                            gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0, layout_noise_dim=32, use_AE=False).cuda().eval()
+    model.validate_inputs = False
+    E = 64
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((E, E)) * 0.2
+    mean = torch.from_numpy(rng.standard_normal(E) * 0.1); cov = torch.from_numpy(A @ A.T + 0.05 * np.eye(E))
+    objs5 = ["bed", "desk", "cabinet", "chair", "lamp"]
+    rels5 = [("bed", "behind", "desk"), ("cabinet", "left of", "bed"), ("chair", "left of", "desk"), ("lamp", "on", "desk")]
+    n = args.sampling_draws
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for _ in range(2):
+            h = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=n)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            h = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=n)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+    dt = sorted(ts)[2]
+    O, T = 6, 9
+    shp = vae_gemm_shapes(O, T)                      # flops of a training step (forward + dgrad + wgrad) of the 6-object graph
+    dec_fwd = 0.0                                    # forward Linears of the DECODER: gconv_net_dc + box_net + angle_net
+    Eh, H, D = 64, 256, 128
+    for _l in range(5):
+        dec_fwd += 2.0 * (T * H * 3 * D + T * (2 * H + D) * H + O * H * H + O * D * H)
+    dec_fwd += 2.0 * (O * H * (D + Eh // 4) + O * 6 * H + O * H * D + O * 24 * H)
+    tf = dec_fwd * n / dt / 1e12
+    res = {"layouts_per_s": round(n / dt, 1), "ms_per_heatmap": round(dt * 1e3, 3), "draws": n,
+           "ms_min_median_max": [round(sorted(ts)[0] * 1e3, 3), round(dt * 1e3, 3), round(sorted(ts)[-1] * 1e3, 3)],
+           "workload": "testing/test_heatmap.py:39-64: 5 objects + room row, 9 triples, %d posterior draws -> 5 centre histograms of 100 x 100; "
+                       "eps drawn on the device, one decoder call over %d rows / %d triples, train.py-default model in eval mode" % (n, n * O, n * T),
+           "finite": bool(torch.isfinite(h).all().item()), "histograms_sum_to_one": bool(((h.sum((1, 2)) - 1).abs() < 1e-4).all().item()),
+           "roofline": {"kernel": "decoder forward of the replicated graphs (gemm_nt family, eval-mode BatchNorm folded into the operand loads)",
+                        "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_F32_PEAK_TFLOPS, "achieved": round(tf, 2), "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                        "flop_per_layout": round(dec_fwd, 1), "traffic": None,
+                        "note": "whole heat map (draw, z GEMM, decoder, histogram) over the decoder's forward flops; no per-kernel rocprof split for this leg"}}
+    if not args.no_cpu:
+        # CPU baseline: the reference's own loop shape - one multivariate-normal draw and ONE single-graph decoder call per layout
+        # (test_heatmap.py:52-60) - through the oracle, bounded sample
+        from oracle import vae_ref
+        ncores = cpu_threads(torch)
+        torch.set_num_threads(ncores)
+        cfg = vae_ref.VaeConfig()
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        objs, triples, attrs = S.scene_graph_from_words(objs5, rels5)
+        m_np, c_np = mean.numpy(), cov.numpy()
+        n_cpu = 200
+        with torch.no_grad():
+            vae_ref.decoder(sd, cfg, torch.zeros(O, E), objs, triples, attrs, training=False)
+            t0 = time.perf_counter()
+            for _ in range(n_cpu):
+                zc = torch.from_numpy(np.random.multivariate_normal(m_np, c_np, O)).float()
+                vae_ref.decoder(sd, cfg, zc, objs, triples, attrs, training=False)
+            cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(n_cpu / cdt, 1), "unit": "layouts/s", "cores": ncores, "kind": "port",
+                               "sample": "%d draws, one numpy multivariate-normal draw + one single-graph eval-mode decoder call each "
+                                         "(oracle/vae_ref.py), %.2f ms per layout" % (n_cpu, cdt / n_cpu * 1e3)}
+    del model
+    torch.cuda.empty_cache()
+    return res
 
 
 def spade_leg(args, lib, torch):
@@ -1213,6 +1380,8 @@ def main():
             log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
         if not args.no_refine:
             log('refine leg'); out["refine"] = refine_leg(args, lib, torch)
+        if not args.no_sampling:
+            log('sampling leg'); out["sampling"] = sampling_leg(args, lib, torch)
         log('done')
     if rank == 0:
         print(json.dumps(out))

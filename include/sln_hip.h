@@ -166,6 +166,15 @@ int sln_vae_set_grad_guard(SlnVae* h, float* slot);
  * the last forward / iteration (the injected one or the drawn one) to eps_out[O, embedding_dim]. */
 int sln_vae_seed(SlnVae* h, uint64_t seed, uint64_t offset, void* stream);
 int sln_vae_last_eps(SlnVae* h, float* eps_out, void* stream);
+/* n values ~ N(0,1) from the engine's Philox stream (one offset per call, as the reparameterisation draws): the z draws of
+ * posterior sampling (testing/test_VAE.py:83-84, testing/test_heatmap.py:57-58 call np.random.multivariate_normal on the host and
+ * copy the sample to the device once per decode) */
+int sln_vae_randn(SlnVae* h, float* out, int64_t n, void* stream);
+/* The accumulation of testing/test_heatmap.py:80-99 for all trials in one launch: boxes_pred [n_trials, O, 6] (room row last in
+ * every trial) -> counts [O - 1, container_size, container_size] += 1 at (floor(cz (cs - 1)), floor(cx (cs - 1))) of every object
+ * centre in the room's own frame (clip_coor: centres clamped to [0, 1]; otherwise trials with a centre outside (0, 1) are dropped). */
+int sln_layout_heatmap(const float* boxes_pred, int64_t n_trials, int O, int box_dim, int container_size, int clip_coor, float* counts,
+                       void* stream);
 
 /* One iteration of the train.py:62-84 loop on the bound batch: zero_grad, forward, loss, backward and
  * (with_adam == SLN_TRAIN_FULL) the Adam update.  `use_graph`: replay a captured hipGraph while shapes are unchanged

@@ -69,7 +69,7 @@ def test_bench_data_parallel_path_end_to_end_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.update(SLN_BENCH_FORCE_DP="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu",
-                        "--no-render", "--no-spade", "--no-graph-build", "--no-refine", "--no-dropin", "--large-batches=", "--prof-steps", "1"],
+                        "--no-render", "--no-spade", "--no-graph-build", "--no-refine", "--no-sampling", "--no-dropin", "--large-batches=", "--prof-steps", "1"],
                        capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]

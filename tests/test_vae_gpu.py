@@ -903,6 +903,53 @@ def test_heatmap_from_words_runs_chunked_decodes():
     assert_close(h1.cpu().numpy(), S.layout_heatmap(bp, 40).cpu().numpy(), "single chunk", rtol=1e-6, atol=1e-7)
 
 
+def test_device_drawn_posterior_samples_follow_the_requested_distribution():
+    """testing/test_heatmap.py:52-64 draws z with np.random.multivariate_normal on the host; host/sampling.py draws eps on the device
+    (the engine's Philox stream) and forms z = mean + eps L^T there.  20 000 draws: mean / covariance of z within sampling noise of
+    the requested ones, the per-object centre histograms within sampling noise of the host-drawn path's (total-variation distance
+    against two host-drawn runs with different seeds), the histogram kernel == the torch accumulation, and two runs differ
+    (the stream advances) unless the model is re-seeded."""
+    S = pkg("host.sampling")
+    cfg = vae_ref.VaeConfig(embedding_dim=16, gconv_num_layers=2)
+    model = _model(cfg, vae_ref.init_state(cfg, seed=2)).eval()
+    E = cfg.embedding_dim
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((E, E)) * 0.3
+    mean = torch.from_numpy(rng.standard_normal(E) * 0.2); cov = torch.from_numpy(A @ A.T + 0.05 * np.eye(E))
+    objs5 = ["bed", "desk", "cabinet", "chair", "lamp"]
+    rels5 = [("bed", "behind", "desk"), ("cabinet", "left of", "bed"), ("chair", "left of", "desk"), ("lamp", "on", "desk")]
+    objs, triples, attrs = S.scene_graph_from_words(objs5, rels5, device="cuda")
+    n = 20000
+    model.manual_seed(11)
+    bp, _, z = S.sample_layouts(model, objs, triples, attrs, n_samples=n, mean=mean, cov=cov)
+    zf = z.reshape(-1, E).double().cpu().numpy()
+    sd_mean = np.sqrt(np.diag(cov.numpy()) / zf.shape[0])
+    assert np.all(np.abs(zf.mean(0) - mean.numpy()) <= 6 * sd_mean), "mean of the device draws"
+    emp = np.cov(zf.T)
+    scale = np.sqrt(np.outer(np.diag(cov.numpy()), np.diag(cov.numpy())))
+    assert np.abs(emp - cov.numpy()).max() <= 8 * scale.max() / np.sqrt(zf.shape[0]), "covariance of the device draws"
+    # the histogram kernel against the torch accumulation on the same boxes
+    counts = S.layout_counts(bp, 40)
+    ref = S.layout_heatmap(bp, 40)
+    assert_close((counts / counts.sum((1, 2), keepdim=True).clamp(min=1.0)).cpu().numpy(), ref.cpu().numpy(), "histogram kernel", rtol=1e-6, atol=1e-7)
+    assert float(counts.sum()) == n * 5
+    # distribution: device-drawn histograms against host-drawn ones
+    h_dev = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=n, container_size=40).cpu().numpy()
+    h_a = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=n, container_size=40, generator=torch.Generator().manual_seed(1)).cpu().numpy()
+    h_b = S.heatmap_from_words(model, objs5, rels5, mean, cov, num_iter=n, container_size=40, generator=torch.Generator().manual_seed(2)).cpu().numpy()
+    for o in range(5):
+        tv_noise = 0.5 * np.abs(h_a[o] - h_b[o]).sum()
+        tv = 0.5 * np.abs(h_dev[o] - h_a[o]).sum()
+        assert tv <= 1.5 * tv_noise + 0.01, "object %d: TV(device, host) %.4f vs TV(host, host) %.4f" % (o, tv, tv_noise)
+    # the stream advances; re-seeding replays it
+    b1, _, z1 = S.sample_layouts(model, objs, triples, attrs, n_samples=64, mean=mean, cov=cov)
+    b2, _, z2 = S.sample_layouts(model, objs, triples, attrs, n_samples=64, mean=mean, cov=cov)
+    assert not torch.equal(z1, z2)
+    model.manual_seed(11)
+    _, _, z3 = S.sample_layouts(model, objs, triples, attrs, n_samples=n, mean=mean, cov=cov)
+    assert torch.equal(z3, z)
+
+
 def test_large_batch_equals_per_graph_evaluation():
     """256 graphs (O = 8192, T = 16384: the 128x64 / 128x128 GEMM tiles, long CSR lists) in eval mode: graphs never share rows
     (suncg_collate_fn offsets), so every graph of the batch must come out as it does alone - a size-independent check of the

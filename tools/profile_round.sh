@@ -17,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 P=/tmp/prof_$TAG          # raw rocprofv3 output stays on the box (tens of MB); only the summaries travel back
 rm -rf "$P"; mkdir -p "$P" profiles gpurun_out
 FAILED=""
-COMMON="--no-cpu --no-check --no-dropin --large-batches= --no-graph-build --no-refine"
+COMMON="--no-cpu --no-check --no-dropin --large-batches= --no-graph-build --no-refine --no-sampling"
 declare -A FLAGS
 FLAGS[vae]="$COMMON --no-render --no-spade --steps 100 --warmup 10"
 FLAGS[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 40 --render-warmup 5"

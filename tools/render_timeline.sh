@@ -4,7 +4,7 @@
 #                                                so that every kernel's duration is its own)
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_rt; mkdir -p /tmp/prof_rt
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_rt -o e -- python bench.py --steps 3 --warmup 2 --no-spade --no-graph-build --no-refine --no-cpu --no-check --no-dropin --large-batches= --render-iters 12 --render-warmup 4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_rt -o e -- python bench.py --steps 3 --warmup 2 --no-spade --no-graph-build --no-refine --no-sampling --no-cpu --no-check --no-dropin --large-batches= --render-iters 12 --render-warmup 4 > /dev/null 2>&1
 python - "${1:-/dev/stdout}" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/prof_rt/**/e_kernel_trace.csv", recursive=True)[0]

@@ -2,8 +2,8 @@
 # The two small text files of profiles/<tag>_*: cost of SLN_DETERMINISTIC=1 and the data-parallel code path on one GPU.
 #   tools/round_extras.sh r03        (GPU box, repository root)
 TAG=${1:-r04}
-V="--no-render --no-spade --no-graph-build --no-refine --no-cpu --no-dropin --large-batches= --steps 200 --warmup 20"
-R="--no-spade --no-graph-build --no-refine --no-cpu --no-check --no-dropin --large-batches= --steps 3 --warmup 2 --prof-steps 0"
+V="--no-render --no-spade --no-graph-build --no-refine --no-sampling --no-cpu --no-dropin --large-batches= --steps 200 --warmup 20"
+R="--no-spade --no-graph-build --no-refine --no-sampling --no-cpu --no-check --no-dropin --large-batches= --steps 3 --warmup 2 --prof-steps 0"
 pick_vae='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d["kernels"]; print("%-18s %.4f  %s   gemm_tn %.3f ms per step (%d launches)" % (sys.argv[1], d["ms_per_step"], d["ms_per_step_p10_p50_p90"], k["gemm_tn"]["ms_per_step"], k["gemm_tn"]["launches_per_step"]))'
 pick_rnd='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1])["render"]; print("%-18s %s   forward %.3f, backward %.3f" % (sys.argv[1], d["ms_per_batch_p10_p50_p90"], d["scene_forward"]["avg_ms_per_batch"], d["scene_backward"]["avg_ms_per_batch"]))'
 {
@@ -24,10 +24,10 @@ pick_rnd='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1
 } > profiles/${TAG}_deterministic.txt
 pick_dp='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps({k: (d[k] if k in d else d["config"].get(k)) for k in ("value","ms_per_step","ms_per_step_p10_p50_p90","n_gpus","collective","allreduce_us_standalone")}))'
 {
-  echo "# SLN_BENCH_FORCE_DP=1 python bench.py --no-cpu --no-render --no-spade --no-graph-build --no-refine --no-dropin --large-batches=   (one MI355X, world of one: the collective path of the 8-GPU run)"
+  echo "# SLN_BENCH_FORCE_DP=1 python bench.py --no-cpu --no-render --no-spade --no-graph-build --no-refine --no-sampling --no-dropin --large-batches=   (one MI355X, world of one: the collective path of the 8-GPU run)"
   for e in "SLN_X=0" "SLN_BENCH_FORCE_DP=1" "SLN_BENCH_FORCE_DP=1 SLN_DP_OVERLAP=1"; do
     echo "## $e"
-    env $e python bench.py --no-cpu --no-render --no-spade --no-graph-build --no-refine --no-dropin --large-batches= 2>/dev/null | python -c "$pick_dp"
+    env $e python bench.py --no-cpu --no-render --no-spade --no-graph-build --no-refine --no-sampling --no-dropin --large-batches= 2>/dev/null | python -c "$pick_dp"
   done
   echo "# batches of changing shape, eager launches (tools/varshape_time.py)"
   python tools/varshape_time.py 2>/dev/null | tail -4

@@ -3,7 +3,7 @@
 #   tools/step_timeline.sh [out.txt]
 cd /tmp && export TMPDIR=/tmp; cd ${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/prof_t; mkdir -p /tmp/prof_t
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o e -- python bench.py --steps 12 --warmup 4 --no-spade --no-render --no-graph-build --no-refine --no-cpu --no-check --no-dropin --large-batches= > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -o e -- python bench.py --steps 12 --warmup 4 --no-spade --no-render --no-graph-build --no-refine --no-sampling --no-cpu --no-check --no-dropin --large-batches= > /dev/null 2>&1
 python - "${1:-/dev/stdout}" <<'PY'
 import csv, glob, sys
 f = glob.glob("/tmp/prof_t/**/e_kernel_trace.csv", recursive=True)[0]
