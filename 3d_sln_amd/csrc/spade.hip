@@ -16,6 +16,8 @@
 //     of one feature land in the same lane/register of two accumulators (weights are packed [32 gamma | 32
 //     beta] per 64 rows), so out = (x - mu_b) * inv_b * (1 + gamma) + beta [-> LeakyReLU(0.2)] is computed in
 //     registers and gamma/beta never touch HBM.
+#include <mutex>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -584,14 +586,27 @@ static int launch_conv_split_finish(const ConvArgs& a, const float* part, int S,
 
 // scratch of the input-channel split: ONE allocation of 128 MB on first use (never during a capture of the caller's stream), never
 // grown or freed - a launch whose partial sums would not fit splits fewer ways
+// One scratch per (device, stream), under a mutex (round 5; it was one process-wide buffer: two calls on two streams - the plane
+// memo of the host mirror is keyed per stream for exactly that use - interleaved their partial sums, and a second GPU of the
+// process dereferenced device 0's memory).  Launches of one stream are ordered, so a stream's buffer needs no further guard.
+// A stream first seen while the caller captures it gets none (an allocation would be recorded): such a launch takes the unsplit
+// path, which rounds differently - run one eager call on the stream (or sln_spade_prepare) before capturing.
 constexpr size_t CONV_PART_BYTES = (size_t)128 << 20;
-static float* g_conv_part = nullptr;
+struct ConvPartSlot { int dev; hipStream_t st; float* p; };
+static std::mutex g_conv_part_mu;
+static std::vector<ConvPartSlot> g_conv_parts;
 static float* conv_part_scratch(hipStream_t st) {
-  if (g_conv_part) return g_conv_part;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(g_conv_part_mu);
+  for (const ConvPartSlot& e : g_conv_parts) if (e.dev == dev && e.st == st) return e.p;
+  if (g_conv_parts.size() >= 32) return nullptr;                 // 4 GB of scratch: stop growing, later streams run unsplit
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&g_conv_part), CONV_PART_BYTES) != hipSuccess) { (void)hipGetLastError(); g_conv_part = nullptr; }
-  return g_conv_part;
+  float* p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&p), CONV_PART_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  g_conv_parts.push_back(ConvPartSlot{dev, st, p});
+  return p;
 }
 
 // Batch-1 calls (test_SPADE_shade.py:77-79: one call per z).  The 1 024 / 512-channel layers at 8 x 8 .. 64 x 64 pixels are 8 .. 64
@@ -626,7 +641,8 @@ int launch_conv_split(const ConvArgs& a, hipStream_t st, bool* done) {
 template <int BMC>
 int launch_conv_blocked(const ConvArgs& a, hipStream_t st) {
   static const int variant = getenv("SLN_CONV_BLOCK_VARIANT") ? atoi(getenv("SLN_CONV_BLOCK_VARIANT")) : 0;   // lab: 1 = 8 x 16 x BMC rows, 2 = staged
-  if (a.Cin % 8 == 0 && variant != 2) {
+  static const bool staged_only = getenv("SLN_CONV_STAGED") != nullptr;      // the A/B switch of launch_conv covers the Cin >= 512 convolutions too
+  if (a.Cin % 8 == 0 && variant != 2 && !staged_only) {
     // 64-row workgroups of 16 x 16 pixels (the halo is DMA'd once per 64 rows instead of once per 128: 1.2x the operand traffic
     // of the 128-row workgroups; 8 x 16 x 128 rows re-reads the weights per 128 pixels: 1.8x)
     const long tall_blocks = (long)sln_cdiv(a.W, TW) * sln_cdiv(a.H, 16) * a.B * (a.rows_pad / 64);
@@ -1247,6 +1263,10 @@ int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const floa
   if (ksize == 3) return big ? launch_conv<128, 3, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 3, CEPI_BIAS_ACT>(a, st);
   return big ? launch_conv<128, 1, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 1, CEPI_BIAS_ACT>(a, st);
 }
+int sln_spade_prepare(void* stream) {
+  return conv_part_scratch((hipStream_t)stream) != nullptr ? 0 : SLN_E_NOMEM;
+}
+
 int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
                    int ksize, int act, float slope, float* y, void* stream) {
   return sln_spade_conv_sums(x, B, Cin, H, W, wp, bias, rows, rows_pad, ksize, act, slope, y, nullptr, nullptr, stream);

@@ -11,12 +11,15 @@ into the kernels' layout once per parameter version.
 import ctypes as C
 import os
 import re
+import threading
 
 import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
 from .. import _lib
+
+_STREAM_TLS = threading.local()          # the stream of the forward() in flight on this host thread (SPADEGenerator4._st)
 
 NHIDDEN = 128
 
@@ -170,11 +173,11 @@ class SPADEGenerator4(nn.Module):
         return P
 
     # ------------------------------------------------------------------ HIP launches
-    _cur_st = None
 
     def _st(self):
         # forward() looks the current stream up once; torch.cuda.current_stream() per launch was 59 look-ups (~0.3 ms) per call
-        return self._cur_st if self._cur_st is not None else _lib.current_stream_ptr()
+        st = getattr(_STREAM_TLS, "st", None)
+        return st if st is not None else _lib.current_stream_ptr()
 
     def _ln_stats(self, x):
         B = x.shape[0]
@@ -346,11 +349,15 @@ class SPADEGenerator4(nn.Module):
         """seg [B, semantic_nc, S, S] (channel 0 depth, 1.. masks), z [B, nz] -> image [B, target_nc, S, S] in (-1, 1)."""
         if input.device.type != 'cuda':
             raise _lib.SlnError("SPADEGenerator4 runs on the MI355X only (no CPU fallback)")
-        self._cur_st = _lib.current_stream_ptr()
+        # one stream look-up per call, kept per THREAD and restored (not cleared) on the way out: a nested forward (a hook) or a
+        # concurrent one on another host thread / stream no longer redirects the rest of this call's launches
+        tl = _STREAM_TLS
+        prev = getattr(tl, "st", None)
+        tl.st = _lib.current_stream_ptr()
         try:
             return self._forward(input, z, taps)
         finally:
-            self._cur_st = None
+            tl.st = prev
 
     def _forward(self, input, z, taps):
         with torch.no_grad():

@@ -746,6 +746,10 @@ def _fast_adam_views(opt, m):
             and opt.__dict__.get('_sln_views_of') == m._adam_m.data_ptr():
         return
     g = opt.param_groups[0]
+    # (re-flatten / .cuda() after routed steps: the per-parameter `step` tensors are only refreshed lazily - bring them up to the
+    # device's count BEFORE they are read back as "foreign" state, or the rebuilt moments would restart their bias correction)
+    if opt.__dict__.get('_sln_views_of') is not None:
+        _fast_adam_materialize_steps(opt)
     foreign = {i: opt.state[p] for i, p in enumerate(m._params) if p in opt.state and 'exp_avg' in opt.state[p]}
     m.load_optim_state_dict({'state': foreign, 'param_groups': [dict(g, params=list(range(len(m._params))))]})   # empty: zero moments, step 0
     if m._eng is None:
@@ -757,7 +761,15 @@ def _fast_adam_views(opt, m):
     opt.__dict__['_sln_views_of'] = m._adam_m.data_ptr()
     if not opt.__dict__.get('_sln_sd_hook'):
         opt.register_state_dict_pre_hook(_fast_adam_materialize_steps)
+        # optimizer.load_state_dict replaces the state with torch-owned tensors: a stale flag left from routed steps must not let
+        # the next state_dict() overwrite the LOADED step counts with the device's count from before the load
+        opt.register_load_state_dict_post_hook(_fast_adam_loaded)
         opt.__dict__['_sln_sd_hook'] = True
+
+
+def _fast_adam_loaded(opt):
+    opt.__dict__['_sln_steps_stale'] = False
+    opt.__dict__['_sln_views_of'] = None                 # the entries are torch's again: the next routed step copies them in
 
 
 def _fast_adam_materialize_steps(opt):

@@ -183,11 +183,96 @@ class _GconvNetFn(torch.autograd.Function):
         return (dx if need[0] else None, dp if need[1] else None, None, None, None) + pg
 
 
+def _rup4(n):
+    return (n + 3) // 4 * 4
+
+
+class _PaddedShadow:
+    """Dimensions that are not multiples of 4 (the kernels' 16-byte rows): the layer runs on a SHADOW of itself whose widths are
+    rounded up - extra weight rows / columns and BatchNorm gammas are zero, so the padded channels carry exact zeros through
+    Linear, BatchNorm and ReLU and the real channels see the arithmetic of the unpadded layer.  The shadow's parameters are rebuilt
+    from the real ones on every forward by a differentiable scatter (``index_put``): gradients reach the real parameters through
+    it.  (The reference places no constraint on the three widths, models/graph.py:36-56.)"""
+
+    def __init__(self, modules, device):
+        m0 = modules[0]
+        D, H, Do = m0.input_dim, m0.hidden_dim, m0.output_dim
+        self.D, self.H, self.Do = D, H, Do
+        Dp, Hp, Dop = _rup4(D), _rup4(H), _rup4(Do)
+        norm = 'batch' if any(bn is not None for _, bn in mlp_linears(m0.net1)) else 'none'
+        self.shadow = [GraphTripleConv(Dp, Dop, Hp, mlp_normalization=norm).to(device) for _ in modules]
+        ar = lambda n, o=0: torch.arange(n, device=device) + o
+        in1 = torch.cat([ar(D, k * Dp) for k in range(3)])
+        out2 = torch.cat([ar(H), ar(Do, Hp), ar(H, Hp + Dop)])
+        self.maps = [(ar(H), in1), (out2, ar(H)), (ar(H), ar(H)), (ar(Do), ar(H))]       # (rows, cols) of net1.0, net1.1, net2.0, net2.1
+        for sm in self.shadow:
+            for p in sm.parameters():
+                p.requires_grad_(False)
+            for _, bn in mlp_linears(sm.net1) + mlp_linears(sm.net2):
+                if bn is not None:
+                    bn.weight.zero_(); bn.bias.zero_()
+
+    def sync(self, modules):
+        """-> the padded parameter tensors (functions of the real parameters, in ``shadow.parameters()`` order); the shadow's own
+        storage (what the engine is bound to) receives the same values."""
+        padded = []
+        for m, sm in zip(modules, self.shadow):
+            pairs, spairs = mlp_linears(m.net1) + mlp_linears(m.net2), mlp_linears(sm.net1) + mlp_linears(sm.net2)
+            per = {}
+            for (lin, bn), (slin, sbn), (rows, cols) in zip(pairs, spairs, self.maps):
+                per[id(slin.weight)] = torch.zeros_like(slin.weight).index_put((rows[:, None], cols[None, :]), lin.weight.float())
+                per[id(slin.bias)] = torch.zeros_like(slin.bias).index_put((rows,), lin.bias.float())
+                if bn is not None:
+                    per[id(sbn.weight)] = torch.zeros_like(sbn.weight).index_put((rows,), bn.weight.float())
+                    per[id(sbn.bias)] = torch.zeros_like(sbn.bias).index_put((rows,), bn.bias.float())
+                    with torch.no_grad():
+                        sbn.running_mean.zero_(); sbn.running_var.fill_(1.0)
+                        sbn.running_mean[rows] = bn.running_mean; sbn.running_var[rows] = bn.running_var
+                        sbn.num_batches_tracked.copy_(bn.num_batches_tracked)
+            for sp in sm.parameters():
+                pv = per[id(sp)]
+                with torch.no_grad():
+                    sp.copy_(pv)
+                padded.append(pv)
+        return padded
+
+    def write_back_running_stats(self, modules):
+        with torch.no_grad():
+            for m, sm in zip(modules, self.shadow):
+                for (lin, bn), (slin, sbn), (rows, _c) in zip(mlp_linears(m.net1) + mlp_linears(m.net2),
+                                                               mlp_linears(sm.net1) + mlp_linears(sm.net2), self.maps):
+                    if bn is not None:
+                        bn.running_mean.copy_(sbn.running_mean[rows]); bn.running_var.copy_(sbn.running_var[rows])
+                        bn.num_batches_tracked.copy_(sbn.num_batches_tracked)
+
+
+def _gconv_autograd_padded(owner, modules, num_layers, obj_vecs, pred_vecs, edges, training):
+    sh = getattr(owner, "_sln_shadow", None)
+    if sh is None or sh.shadow[0].net1[0].weight.device != obj_vecs.device:
+        sh = _PaddedShadow(modules, obj_vecs.device)
+        object.__setattr__(owner, "_sln_shadow", sh)
+    padded = sh.sync(modules)
+    eng = getattr(owner, "_sln_engine", None)
+    key = tuple(p.data_ptr() for m in sh.shadow for p in m.parameters())
+    if eng is None or eng.key_ptrs != key or eng.device != obj_vecs.device:
+        eng = _GconvEngine(sh.shadow, num_layers, obj_vecs.device)
+        eng.key_ptrs = key
+        object.__setattr__(owner, "_sln_engine", eng)
+    F = torch.nn.functional
+    Dp = sh.shadow[0].input_dim
+    new_obj, new_pred = _GconvNetFn.apply(F.pad(obj_vecs.float(), (0, Dp - sh.D)), F.pad(pred_vecs.float(), (0, Dp - sh.D)), edges, eng, training,
+                                          *padded)
+    if training:
+        sh.write_back_running_stats(modules)
+    return new_obj[:, :sh.Do], new_pred[:, :sh.Do]
+
+
 def _gconv_autograd(owner, modules, num_layers, obj_vecs, pred_vecs, edges, training):
     m0 = modules[0]
+    if num_layers > 1 and m0.input_dim != m0.output_dim:
+        raise ValueError("a stack of GraphTripleConv layers needs output_dim == input_dim (models/graph.py:121-131)")
     if m0.input_dim % 4 or m0.hidden_dim % 4 or m0.output_dim % 4:
-        raise NotImplementedError("autograd through a standalone GraphTripleConv needs dimensions that are multiples of 4; "
-                                  "train other shapes through Sg2ScVAEModel")
+        return _gconv_autograd_padded(owner, modules, num_layers, obj_vecs, pred_vecs, edges, training)
     if num_layers > 1 and m0.input_dim != m0.output_dim:
         raise ValueError("a stack of GraphTripleConv layers needs output_dim == input_dim (models/graph.py:121-131)")
     eng = getattr(owner, "_sln_engine", None)
@@ -210,6 +295,10 @@ def _gconv_forward(modules, num_layers, obj_vecs, pred_vecs, edges, training, ow
         return _gconv_autograd(owner if owner is not None else modules[0], modules, num_layers, obj_vecs, pred_vecs, edges, training)
     m0 = modules[0]
     D, H, Do = m0.input_dim, m0.hidden_dim, m0.output_dim
+    if D % 32 or H % 4 or Do % 4:
+        # widths the workspace-per-call entry point does not take (it stages 32-column k-tiles of the input): the engine path runs
+        # them - padded to multiples of 4 where needed - with or without gradients
+        return _gconv_autograd(owner if owner is not None else modules[0], modules, num_layers, obj_vecs, pred_vecs, edges, training)
     units = (_lib.SlnVaeUnit * (4 * len(modules)))()
     bn_any = False
     for mi, m in enumerate(modules):

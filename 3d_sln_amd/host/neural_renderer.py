@@ -55,13 +55,17 @@ class _ProjectFaces(torch.autograd.Function):
         out = torch.empty(B, F, 3, 3, device=vertices.device)
         _lib.check(_lib.lib().sln_project_faces(_lib.ptr(vertices), _lib.ptr(faces), _lib.ptr(cam[0]), _lib.ptr(cam[1]), _lib.ptr(cam[2]), B, V, F,
                                                 float(orig_size), float(eps), _lib.ptr(out), _lib.current_stream_ptr()), "sln_project_faces")
-        ctx.save_for_backward(vertices, faces, *cam)
+        # Plain attributes, not save_for_backward: every pass of a cached geometry (Renderer._geometry) hangs off THIS node, and the
+        # caller may back-propagate the passes in separate sweeps (loss_depth.backward(); loss_rgb.backward()) or render again
+        # after a backward - autograd frees saved tensors after the first sweep ("Trying to backward through the graph a second
+        # time"), it does not free attributes.  All of them are inputs or fresh detached copies: no reference cycle.
+        ctx.kept = (vertices.detach(), faces, *cam)
         ctx.orig_size, ctx.eps = float(orig_size), float(eps)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        vertices, faces, K, R, t = ctx.saved_tensors
+        vertices, faces, K, R, t = ctx.kept
         B, V = vertices.shape[:2]
         g = torch.empty_like(vertices)
         _lib.check(_lib.lib().sln_project_faces_backward(_lib.ptr(vertices), _lib.ptr(faces), _lib.ptr(K), _lib.ptr(R), _lib.ptr(t), B, V,
@@ -94,14 +98,14 @@ class _RasterizeDepth(torch.autograd.Function):
     def forward(ctx, faces, image_size, near, far, maps=None):
         faces = faces.contiguous()
         fi, w, d = maps if maps is not None else _rasterize(faces, image_size, near, far)
-        ctx.save_for_backward(faces, fi, w, d)
+        ctx.kept = (faces.detach(), fi, w, d)          # attributes: see _ProjectFaces (the node may be walked by several sweeps)
         ctx.image_size = image_size
         ctx.maps = (fi, w, d)
         return d.clone()
 
     @staticmethod
     def backward(ctx, gd):
-        faces, fi, w, d = ctx.saved_tensors
+        faces, fi, w, d = ctx.kept
         B, F = faces.shape[0], faces.shape[1]
         g = torch.zeros_like(faces)
         _lib.check(_lib.lib().sln_raster_backward_depth(_lib.ptr(faces), _lib.ptr(fi), _lib.ptr(w), _lib.ptr(d),
@@ -218,22 +222,21 @@ class _RgbPass(torch.autograd.Function):
                                                             textures.shape[1], image_size, textures.shape[2], eps, float(scale), _lib.ptr(out),
                                                             _lib.current_stream_ptr()), "sln_raster_texture_sample_chw")
         ctx.geom, ctx.fi, ctx.image_size, ctx.eps = geom, fi, image_size, eps
-        ctx.save_for_backward(out)
+        ctx.image = out.detach()                       # (a detached alias: no cycle through the output's grad_fn; see _ProjectFaces)
         ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, gout):
         if gout is not None:
-            (out,) = ctx.saved_tensors
-            ctx.geom.pending.append((ctx.fi, ctx.image_size, ctx.eps, out, gout.contiguous()))
+            ctx.geom.pending.append((ctx.fi, ctx.image_size, ctx.eps, ctx.image, gout.contiguous()))
         return None, None, None, None, None, None, None      # the gate adds the gradient of the projected faces
 
 
 class Renderer:
     """Constructor / call signature of ``neural_renderer.Renderer`` restricted to what the reference passes."""
 
-    reuse_rasterisation = True      # see _projected(); False rasterises on every call
+    reuse_rasterisation = True      # see _geometry(); False rasterises (and projects) on every call
 
     def __init__(self, image_size=256, anti_aliasing=True, background_color=(0, 0, 0), fill_back=True,
                  camera_mode='projection', K=None, R=None, t=None, dist_coeffs=None, orig_size=1024, perspective=True,

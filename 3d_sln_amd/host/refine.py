@@ -65,6 +65,25 @@ class MeshBank:
                                      bbox_min=v.min(0).values, bbox_max=v.max(0).values)
 
 
+    @classmethod
+    def from_arrays(cls, meshes, device):
+        """Caller-supplied meshes - the seam of models/diff_render.py:62,131, where the reference hands the retrieved SUNCG model's
+        vertices / faces to the placement: ``meshes`` = {class name: (V [n,3] float, F [m,3] int)} (one model per class, any
+        topology; faces index V).  The bounding box the placement scales by is the vertices' own (models/misc.py:88-94 reads it from
+        the model table)."""
+        bank = cls.__new__(cls)
+        bank.models = {}
+        for name, (V, F) in meshes.items():
+            v = torch.as_tensor(np.asarray(V, dtype=np.float32)).reshape(-1, 3).to(device)
+            f = torch.as_tensor(np.asarray(F).astype(np.int32)).reshape(-1, 3).to(device)
+            if v.shape[0] == 0 or f.shape[0] == 0:
+                raise ValueError("mesh of class %r is empty" % (name,))
+            if int(f.min()) < 0 or int(f.max()) >= v.shape[0]:
+                raise IndexError("faces of class %r index vertices outside [0, %d)" % (name, v.shape[0]))
+            bank.models[name] = dict(v=v.contiguous(), f=f.contiguous(), bbox_min=v.min(0).values, bbox_max=v.max(0).values)
+        return bank
+
+
 def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=None):
     """diff_render.py:76-165 for one room: returns vertices_buf [1,V,3] (differentiable w.r.t. boxes / angles),
     face_buf [1,F,3] int32, class_ranges, obj sizes, size_loss.  ``boxes`` [n,6] in room-normalised units with the

@@ -437,6 +437,10 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
  *   (W = W_orig / (u . (W_mat v))); for the modulation conv the rows of gamma and beta are interleaved in
  *   groups of 32: rows [64 g, 64 g + 32) = gamma of channels [32 g, 32 g + 32), the next 32 rows their beta.
  * ============================================================================================= */
+/* Allocates the per-(device, stream) scratch of the small-launch input-channel split (128 MB) for `stream` now.  Optional: the first
+ * eager convolution on a stream does the same; a stream that is first seen while it is being captured gets no scratch and runs
+ * those launches unsplit (other rounding, ~1e-6) - call this (or run one eager forward) on the stream before capturing it. */
+int sln_spade_prepare(void* stream);
 /* y = act(conv_ks(x) + bias): ks = 3 (ReflectionPad2d(1)) or 1; act 0 none, 1 ReLU, 2 LeakyReLU(slope) */
 int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
                    int ksize, int act, float slope, float* y, void* stream);

@@ -188,6 +188,39 @@ def test_geometry_kept_under_no_grad_is_not_reused_when_gradients_are_wanted():
     assert v.grad is not None and float(v.grad.abs().max()) > 0
 
 
+def test_shared_geometry_survives_separate_backward_sweeps_and_a_render_after_backward():
+    """One cached geometry (same tensor objects), passes back-propagated in SEPARATE sweeps without retain_graph
+    (loss_depth.backward(); loss_rgb.backward()), then another pass on the same Renderer and tensors and a third sweep: the
+    upstream package projects per call and allows all of this; the gradients must equal those of the plain
+    one-rasterisation-per-call path accumulated the same way."""
+    NR = pkg("host.neural_renderer"); syn = pkg("host.synthetic"); DR = pkg("host.diff_render")
+    V, F, ranges, box = syn.synthetic_room(3, n_objects=6, target_faces=500)
+    K, R, t = DR.get_cam_mat(torch.from_numpy(box), "cuda")
+    f = torch.from_numpy(F)[None].cuda()
+    tex_a = (torch.rand(1, f.shape[1], 2, 2, 2, 3, device="cuda") > 0.5).float()
+    tex_b = (torch.rand(1, f.shape[1], 2, 2, 2, 3, device="cuda") > 0.5).float()
+    gd, ga, gb = torch.randn(1, 64, 64, device="cuda"), torch.randn(1, 3, 64, 64, device="cuda"), torch.randn(1, 3, 64, 64, device="cuda")
+    grads = {}
+    keep = NR.Renderer.reuse_rasterisation
+    try:
+        for reuse in (True, False):
+            NR.Renderer.reuse_rasterisation = reuse
+            v = torch.from_numpy(V)[None].cuda().requires_grad_(True)
+            r = NR.Renderer(camera_mode='projection', image_size=64, K=K, R=R, t=t, anti_aliasing=False, orig_size=DR.inter_out, near=0.001,
+                            light_intensity_ambient=1.0, light_intensity_directional=0.0)
+            depth = r(v, f, tex_a, mode='depth')
+            rgb = r(v, f, tex_a, mode='rgb')
+            (depth * gd).sum().backward()                 # first sweep: the depth pass alone
+            (rgb * ga).sum().backward()                   # second sweep through the same projection / gate nodes
+            rgb2 = r(v, f, tex_b, mode='rgb')             # same Renderer, same tensors, after two backward sweeps
+            (rgb2 * gb).sum().backward()
+            grads[reuse] = v.grad.detach().cpu().numpy().copy()
+            assert np.isfinite(grads[reuse]).all() and np.abs(grads[reuse]).max() > 0
+    finally:
+        NR.Renderer.reuse_rasterisation = keep
+    assert_close(grads[True], grads[False], "vertex gradients over three sweeps", rtol=1e-4, atol=1e-6 * np.abs(grads[False]).max())
+
+
 @pytest.mark.parametrize("image_size,n_pass,dense", [(96, 5, True), (100, 3, False), (64, 70, False)])
 def test_shared_geometry_passes_equal_the_plain_one_rasterisation_per_call_path(image_size, n_pass, dense):
     """The Renderer's fast path (one projection node, one launch per rgb pass, ONE deferred pixel-map backward over all passes:

@@ -112,6 +112,48 @@ def test_mesh_render_func_call_contract():
     assert any(float(b.grad.abs().max()) > 0 for b in b2[:-1])
 
 
+def test_caller_supplied_meshes_render_through_mesh_render_func():
+    """MeshBank.from_arrays: non-cuboid meshes handed in as (V, F) arrays (the reference retrieves SUNCG models at
+    models/diff_render.py:62,131) go through mesh_render_func, the fused placement (RefineScene) and the CPU restatement with the
+    same image and gradients."""
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    octa_v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1.3, 0], [0, -0.7, 0], [0, 0, 0.8], [0, 0, -0.8]], np.float32) * 0.4
+    octa_f = np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]])
+    wedge_v = np.array([[0, 0, 0], [1, 0, 0], [1, 0, 0.6], [0, 0, 0.6], [0, 0.9, 0], [0, 0.9, 0.6]], np.float32)
+    wedge_f = np.array([[0, 1, 2], [0, 2, 3], [0, 4, 1], [3, 2, 5], [0, 3, 5], [0, 5, 4], [1, 4, 5], [1, 5, 2]])
+    meshes = {"bed": (octa_v, octa_f), "chair": (wedge_v, wedge_f), "table": (octa_v * 1.5 + 0.1, octa_f[:, ::-1]), "sofa": (wedge_v, wedge_f),
+              "desk": (octa_v, octa_f)}
+    with pytest.raises(IndexError):
+        R.MeshBank.from_arrays({"bed": (octa_v, octa_f + 3)}, "cuda")
+    res = {}
+    for dev, render in (("cpu", rr.scene_render), ("cuda", DR.scene_render)):
+        boxes, angles = _inputs(dev)
+        bank = R.MeshBank.from_arrays(meshes, dev)
+        assert bank.models["bed"]["v"].shape == (6, 3) and torch.allclose(bank.models["chair"]["bbox_max"].cpu(), torch.tensor([1.0, 0.9, 0.6]))
+        room = boxes[-1].clone()
+        b2 = boxes.detach().clone().requires_grad_(True); a2 = (angles + 0.3).detach().requires_grad_(True)
+        v, f, ranges, sizes, _ = R.assemble_scene(b2, a2, NAMES, bank, room)
+        img = render(v, f, ranges, room, image_size=96)
+        (img[:, 41:].sum() + img[:, 0].mean()).backward()
+        res[dev] = (img.detach().cpu().numpy(), b2.grad.cpu().numpy(), a2.grad.cpu().numpy(), bank)
+    assert (np.abs(res["cpu"][0] - res["cuda"][0]) > 1e-4).mean() < 1e-3
+    assert_close(res["cuda"][1], res["cpu"][1], "d boxes", rtol=2e-2, atol=2e-2 * np.abs(res["cpu"][1]).max())
+    assert_close(res["cuda"][2], res["cpu"][2], "d angles", rtol=2e-2, atol=2e-2 * np.abs(res["cpu"][2]).max())
+    assert np.abs(res["cpu"][1]).max() > 0
+    # the reference's entry point on the same bank, and the fused placement against the per-object assembly
+    bank = res["cuda"][3]
+    boxes, angles = _inputs("cuda")
+    R.configure_meshes(NAMES, bank=bank)
+    final, ids, sizes, size_loss = R.mesh_render_func([b for b in boxes], [a for a in angles], list(range(len(NAMES))))
+    assert final.shape == (1, 70, 256, 256) and float(final[0, 0].max()) > 0
+    sc = R.RefineScene(NAMES, bank, boxes[-1], 96)
+    with torch.no_grad():
+        fused, _, _ = sc.render(boxes, angles)
+        v, f, ranges, _, _ = R.assemble_scene(boxes, angles, NAMES, bank, boxes[-1])
+        plain = DR.scene_render(v, f, ranges, boxes[-1], image_size=96)
+    assert (np.abs(fused.cpu().numpy() - plain.cpu().numpy()) > 1e-4).mean() < 1e-3
+
+
 def _pretrained_room():
     M = pkg("host.Sg2ScVAE_model")
     torch.manual_seed(0)                                            # train_step draws eps from the global device generator

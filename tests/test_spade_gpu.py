@@ -431,6 +431,42 @@ def test_blocked_accumulation_of_long_chains_is_as_accurate_as_the_cpu_path(Cin,
     assert_close(y.cpu().numpy(), ref.numpy(), "blocked conv", rtol=2e-6, atol=1e-7)
 
 
+def test_small_convolutions_on_two_streams_do_not_share_their_split_scratch():
+    """The input-channel split of small launches (batch-1 calls: 1 024 -> 256 channels at 8 x 8 is 8 workgroups unsplit) leaves
+    partial sums in a scratch buffer; two streams running such convolutions at the same time each need their own (round 4 kept one
+    process-wide buffer).  Interleaved launches on two streams must give, bit for bit, what each stream gives alone."""
+    L = pkg("_lib"); S = pkg("host.SPADE_related")
+    Cin, Cout, H = 1024, 256, 8
+    g = torch.Generator().manual_seed(7)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5
+    wp, rp = S._pack(w.cuda())
+    bp = torch.zeros(rp, device="cuda")
+    xs = [torch.randn(1, Cin, H, H, generator=g).cuda() for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def conv(x, y, st):
+        L.check(L.lib().sln_spade_conv(L.ptr(x), 1, Cin, H, H, L.ptr(wp), L.ptr(bp), Cout, rp, 3, 0, 0.0, L.ptr(y), C.c_void_p(st.cuda_stream)), "conv")
+    import ctypes as C
+    for st in streams:
+        assert L.lib().sln_spade_prepare(C.c_void_p(st.cuda_stream)) == 0
+    torch.cuda.synchronize()
+    alone = []
+    for x, st in zip(xs, streams):
+        y = torch.empty(1, Cout, H, H, device="cuda")
+        conv(x, y, st); st.synchronize()
+        alone.append(y.clone())
+    outs = [[torch.empty(1, Cout, H, H, device="cuda") for _ in range(40)] for _ in range(2)]
+    for k in range(40):                                   # no synchronisation in between: the two streams' launches overlap
+        for i in range(2):
+            conv(xs[i], outs[i][k], streams[i])
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k in range(40):
+            assert torch.equal(outs[i][k], alone[i]), "stream %d, launch %d" % (i, k)
+    ref = F.conv2d(F.pad(xs[0].cpu().double(), (1, 1, 1, 1), mode="reflect"), w.double())
+    assert_close(alone[0].cpu().numpy(), ref.numpy(), "split conv", rtol=2e-6, atol=1e-7)
+
+
 def test_deterministic_mode_makes_the_generator_bit_identical_run_to_run():
     """The reference's CPU path (SPADE_related.py:128-149: LayerNorm2D sums, the SE pool) gives the same bits on every run; with
     SLN_DETERMINISTIC / sln_set_deterministic the HIP generator does too - the statistics the fused schedule adds with fp64 atomics

@@ -856,6 +856,55 @@ def test_bare_graph_triple_conv_with_other_output_dim(norm):
         G._gconv_autograd(bad, list(bad.gconvs), 2, x2, p2, edges.cuda(), True)
 
 
+@pytest.mark.parametrize("norm", ["batch", "none"])
+def test_bare_graph_triple_conv_with_widths_that_are_not_multiples_of_four(norm):
+    """models/graph.py:36-56 places no constraint on input_dim / hidden_dim / output_dim.  Widths like 30 / 50 / 22 run on a
+    zero-padded shadow of the layer (host/graph.py::_PaddedShadow); forward, the gradients of both inputs and of every parameter
+    and the BatchNorm running statistics against fp64 CPU autograd through the oracle's gconv_apply."""
+    G = pkg("host.graph")
+    torch.manual_seed(5)
+    D, H, Do = 30, 50, 22
+    conv = G.GraphTripleConv(D, output_dim=Do, hidden_dim=H, mlp_normalization=norm)
+    sd = {"g." + k: v.clone() for k, v in conv.state_dict().items()}
+    conv = conv.cuda().train()
+    g = torch.Generator().manual_seed(1)
+    O, T = 37, 61
+    x = torch.randn(O, D, generator=g); p = torch.randn(T, D, generator=g)
+    edges = torch.randint(0, O, (T, 2), generator=g)
+    wo = torch.randn(O, Do, generator=g); wp = torch.randn(T, Do, generator=g)
+    keys = [k for k in sd if sd[k].is_floating_point() and "running" not in k]
+    sdr = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    for k in keys:
+        sdr[k].requires_grad_(True)
+    x1 = x.double().requires_grad_(True); p1 = p.double().requires_grad_(True)
+    ro, rp = vae_ref.gconv_apply(sdr, "g", x1, p1, edges, H, norm, True)
+    ref = torch.autograd.grad((ro * wo.double()).sum() + (rp * wp.double()).sum(), [x1, p1] + [sdr[k] for k in keys])
+    x2 = x.cuda().requires_grad_(True); p2 = p.cuda().requires_grad_(True)
+    ho, hp = conv(x2, p2, edges.cuda())
+    assert ho.shape == (O, Do) and hp.shape == (T, Do)
+    assert_close(ho.detach().cpu().numpy(), ro.detach().numpy(), "new_obj")
+    assert_close(hp.detach().cpu().numpy(), rp.detach().numpy(), "new_pred")
+    named = dict(conv.named_parameters())
+    prm = [named[k[2:]] for k in keys]
+    got = torch.autograd.grad((ho * wo.cuda()).sum() + (hp * wp.cuda()).sum(), [x2, p2] + prm)
+    gs = max(float(r.abs().max()) for r in ref[2:])
+    for name, a, b in zip(["d obj_vecs", "d pred_vecs"] + keys, got, ref):
+        assert a.shape == b.shape, name
+        scale = float(b.abs().max()) if name.startswith("d ") else gs
+        assert_close(a.cpu().numpy(), b.numpy(), name, rtol=2e-4, atol=2e-6 * scale + 1e-9)
+    if norm == "batch":
+        got_sd = conv.state_dict()
+        for k in sdr:
+            if "running" in k:
+                assert_close(got_sd[k[2:]].cpu().numpy(), sdr[k].numpy(), k, rtol=1e-4, atol=1e-6)
+    with torch.no_grad():                                  # eval / no-grad calls of the same odd-width layer
+        conv.eval()
+        eo, ep = conv(x.cuda(), p.cuda(), edges.cuda())
+    sde = {k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in {"g." + k: v.cpu() for k, v in conv.state_dict().items()}.items()}
+    reo, rep = vae_ref.gconv_apply(sde, "g", x.double(), p.double(), edges, H, norm, False)
+    assert_close(eo.cpu().numpy(), reo.numpy(), "eval new_obj"); assert_close(ep.cpu().numpy(), rep.numpy(), "eval new_pred")
+
+
 def test_high_degree_room_node_beyond_the_lds_entry_cache():
     """One graph with 150 objects: the room node is incident to >= 149 triples, past the 64-entry LDS cache of the CSR
     edge kernels (vae_kernels.hip: ECACHE), so the tail of its entry list is read from global memory."""
