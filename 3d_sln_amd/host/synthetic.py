@@ -151,3 +151,22 @@ def pack_rooms(rooms, device="cuda"):
                 chan=torch.tensor(chan, dtype=torch.int32, device=device), dch=torch.tensor(dch, dtype=torch.int32, device=device),
                 K=torch.stack([p[3] for p in prepared]).to(device), R=torch.stack([p[4] for p in prepared]).to(device),
                 t=torch.stack([p[5] for p in prepared]).to(device), tris=tris)
+
+
+def spade_input(batch, crop=256, semantic_nc=41, nz=256, seed=0):
+    """Synthetic input of SPADEGenerator4 (the tensor contract of testing/test_SPADE_shade.py:50-76): channel 0 = smooth depth in
+    [-1, 1], channels 1.. = one-hot of the argmax of upsampled noise maps; z ~ N(0, 1).  CPU tensors from numpy generators, one
+    per image (image i is the same whatever the batch size): bench.py's SPADE leg and the reference-generated fixture
+    tests/golden/spade_bench.npz (oracle/gen_golden_spade.py) use the same call."""
+    import torch.nn.functional as F
+    segs, zs = [], []
+    for i in range(batch):
+        rng = np.random.default_rng(1000003 * seed + i)
+        low = torch.from_numpy(rng.uniform(-1, 1, size=(1, 1, 16, 16)).astype(np.float32))
+        depth = F.interpolate(low, size=(crop, crop), mode="bilinear", align_corners=False).clamp(-1, 1)
+        noise = torch.from_numpy(rng.standard_normal((1, semantic_nc - 1, 16, 16)).astype(np.float32))
+        lab = F.interpolate(noise, size=(crop, crop), mode="bilinear", align_corners=False).argmax(1)
+        onehot = F.one_hot(lab, semantic_nc - 1).permute(0, 3, 1, 2).float()
+        segs.append(torch.cat([depth, onehot], 1))
+        zs.append(torch.from_numpy(rng.standard_normal((1, nz)).astype(np.float32)))
+    return torch.cat(segs).contiguous(), torch.cat(zs).contiguous()

@@ -901,17 +901,17 @@ def spade_leg(args, lib, torch):
     res = {}
     if not args.no_check:
         res["parity"] = check_spade(torch, S)
-    torch.manual_seed(0)
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    SPADE_SEED, IMG_GAIN = 0, 0.04          # = oracle/gen_golden_spade.py BENCH_SEED / BENCH_IMG_GAIN (tests/golden/spade_bench.npz)
+    torch.manual_seed(SPADE_SEED)
     G = S.SPADEGenerator4(41, 3, 256, 64, 'spectralspadelayer3x3', 256, 'normal')        # torch's default init, as the reference's constructor
+    with torch.no_grad():                   # ... except conv_img: at the default gain tanh sits at |0.97| and hides every error in front of it
+        G.conv_img.weight.mul_(IMG_GAIN); G.conv_img.bias.mul_(IMG_GAIN)
     G = G.cuda().eval()
     B = args.spade_batch
+    seg, z = syn.spade_input(B, seed=SPADE_SEED)
+    seg, z = seg.cuda(), z.cuda()
     g = torch.Generator(device="cuda").manual_seed(0)
-    low = torch.rand(B, 1, 16, 16, device="cuda", generator=g) * 2 - 1
-    depth = torch.nn.functional.interpolate(low, size=(256, 256), mode="bilinear", align_corners=False)
-    lab = torch.nn.functional.interpolate(torch.randn(B, 40, 16, 16, device="cuda", generator=g), size=(256, 256), mode="bilinear",
-                                          align_corners=False).argmax(1)
-    seg = torch.cat([depth, torch.nn.functional.one_hot(lab, 40).permute(0, 3, 1, 2).float()], 1).contiguous()
-    z = torch.randn(B, 256, device="cuda", generator=g)
     for _ in range(args.spade_warmup):
         out = G(seg, z)
     torch.cuda.synchronize()
@@ -996,6 +996,15 @@ def spade_leg(args, lib, torch):
             require(e_hip_cpu <= 2e-4, "SPADE full-size generator: image rel err vs the CPU fp32 oracle %.2e" % e_hip_cpu)
             res["parity"].update({"full_size_image_rel_err_vs_fp64_oracle": e_hip, "fp32_oracle_rel_err_vs_fp64_oracle": e_cpu,
                                   "full_size_image_rel_err_vs_fp32_oracle": e_hip_cpu})
+            # ... and against the REFERENCE's own output on these weights and this image (tests/golden/spade_bench.npz, generated by
+            # oracle/gen_golden_spade.py from the reference class in the build container): a crop and seven full rows
+            import numpy as np
+            fx = np.load(os.path.join(ROOT, "tests", "golden", "spade_bench.npz"))
+            sc_f = float(np.abs(fx["out_rows"]).max())
+            o0 = out[:1].cpu().numpy()
+            e_fix = max(float(np.abs(o0[:, :, 100:132, 60:92] - fx["out_crop"]).max()), float(np.abs(o0[:, :, ::37, :] - fx["out_rows"]).max())) / sc_f
+            require(e_fix <= 2e-4, "SPADE full-size generator: image rel err vs the reference-generated fixture %.2e" % e_fix)
+            res["parity"].update({"full_size_image_rel_err_vs_reference_fixture": e_fix, "reference_fixture_out_abs_mean": float(fx["out_abs_mean"][0])})
         res["cpu_baseline"] = {"value": round(bc / cdt, 3), "unit": "images/s", "cores": n, "kind": "port",
                                "sample": "%d x batch of %d images of the same input through oracle/spade_ref.py (torch CPU fp32), %.2f s per image"
                                          % (n_it, bc, cdt / bc)}

@@ -66,7 +66,7 @@ def state_layout(cfg: SpadeConfig):
     return L
 
 
-def init_state(cfg: SpadeConfig, seed: int = 0) -> State:
+def init_state(cfg: SpadeConfig, seed: int = 0, img_gain: float = 0.15) -> State:
     """Deterministic fill (numpy Generator, sorted key order): weights ~ N(0, 1/fan_in) (activations stay O(1)
     through the 14 residual stages), biases ~ N(0, 0.05^2), spectral u/v = random unit vectors."""
     rng = np.random.default_rng(seed)
@@ -76,7 +76,7 @@ def init_state(cfg: SpadeConfig, seed: int = 0) -> State:
             fan_in = int(np.prod(shape[1:]))
             v = rng.standard_normal(shape, dtype=np.float32) * np.float32(1.0 / np.sqrt(fan_in))
             if key == "conv_img.weight":
-                v *= np.float32(0.15)                 # keep the final tanh out of saturation
+                v *= np.float32(img_gain)             # keep the final tanh out of saturation (full width: see gen_golden_spade.CASES)
         elif kind == "b":
             v = rng.standard_normal(shape, dtype=np.float32) * np.float32(0.05)
         else:

@@ -17,9 +17,9 @@ def _checks(t):
 @pytest.mark.parametrize("name", list(CASES))
 def test_oracle_matches_reference_fixture(name):
     g = load_golden(name)
-    over, B = CASES[name]
+    over, B, skw = CASES[name]
     cfg = spade_ref.SpadeConfig(**over)
-    sd = spade_ref.init_state(cfg, seed=7)
+    sd = spade_ref.init_state(cfg, seed=7, **skw)
     assert len(sd) == 230
     seg, z = spade_ref.synth_input(cfg, B, seed=3)
     taps = {}
@@ -33,4 +33,27 @@ def test_oracle_matches_reference_fixture(name):
         assert_close(taps["head_0"].numpy(), g["tap:head_0"], name + ":head_0")
     else:
         assert_close(out[:, :, 100:132, 60:92].numpy(), g["out_crop"], name + ":crop")
-    assert out.abs().mean() < 0.9            # not saturated: the comparison is meaningful
+    assert out.abs().mean() < 0.6            # not saturated: the comparison is meaningful (the full-size fixture was 0.82 in round 4)
+    if "out_rows" in g.files:
+        assert_close(out[:, :, ::37, :].numpy(), g["out_rows"], name + ":rows")
+        assert float(g["out_abs_mean"][0]) < 0.5
+
+
+def test_oracle_matches_the_reference_at_the_bench_weights():
+    """tests/golden/spade_bench.npz: the reference class on bench.py's weights (torch default init, seed 0, conv_img gain) and first
+    input image - the oracle must reproduce its crop, rows and block checksums (what BENCH's full-size parity is measured against)."""
+    from oracle.gen_golden_spade import bench_state, BENCH_SEED
+    import importlib
+    syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    g = load_golden("spade_bench")
+    cfg = spade_ref.SpadeConfig()
+    sd = bench_state()
+    seg, z = syn.spade_input(1, seed=BENCH_SEED)
+    taps = {}
+    with torch.no_grad():
+        out = spade_ref.generator(sd, cfg, seg, z, taps)
+    for n, t in taps.items():
+        assert_close(_checks(t)[1:], g["check:" + n][1:], "spade_bench:" + n, rtol=1e-4)
+    assert_close(out[:, :, 100:132, 60:92].numpy(), g["out_crop"], "spade_bench:crop")
+    assert_close(out[:, :, ::37, :].numpy(), g["out_rows"], "spade_bench:rows")
+    assert float(out.abs().mean()) < 0.5
