@@ -740,7 +740,7 @@ int SlnVae::gconv_backward(int gi, const float* dP, int lddp, int dpcol0, int sl
   RET_IF(join_side(st));      // (pairing / side-stream modes: their wgrads are launched before the next layer starts)
   // deterministic mode with shared (recurrent) weights: the layers' wgrads add into the SAME dW, so they run as separate
   // launches in stream order instead of side by side in one
-  if (tn_per_layer || (g_sln_deterministic && cfg.recurrent)) RET_IF(flush_deferred(ly.net == 0 ? 1 : 0, st));
+  if (tn_per_layer || (g_sln_deterministic && cfg.recurrent) || rec) RET_IF(flush_deferred(ly.net == 0 ? 1 : 0, st));     // (a group runs a layer's wgrads on its side stream, next to the following layers' dgrad chain)
   return 0;
 }
 
@@ -1653,14 +1653,23 @@ struct SlnVaeGroup {
   SlnVaeGroupIO io;
   float* logits = nullptr; float* dlogits = nullptr;
   std::vector<void*> allocs;
-  enum { L_NT = 100, L_NT_SINGLE, L_TN_MULTI, L_TN_SINGLE, L_SINGLE_STEP, L_ZERO, L_TRANSPOSE, L_BN_GRADS, L_LOG_SOFTMAX, L_LOG_SOFTMAX_BWD };
+  enum { L_NT = 100, L_NT_SINGLE, L_TN_MULTI, L_TN_SINGLE, L_SINGLE_STEP, L_ZERO, L_TRANSPOSE, L_BN_GRADS, L_LOG_SOFTMAX, L_LOG_SOFTMAX_BWD,
+         L_FORK, L_JOIN, L_JOIN_TR };
   struct Launch {
     int kind = -1, variant = 0, count = 0, gx = 0, gy = 0, smem_floats = 0, maxK = 0; double flops = 0.0;
     const void* tab = nullptr; const int* tiles = nullptr;
     const GemmTNArgs* tn_probs = nullptr; const TnMultiMeta* tn_meta = nullptr; int blocks = 0; bool x2 = false, xg = false;
     long max_n16 = 0; int single = -1;
+    bool on_side = false;
   };
   std::vector<Launch> fwd, bwd;
+  // Side stream: the decoder chain is ~80 dependent launches of a few microseconds each - the chip is mostly waiting for the next
+  // launch - so work that nothing in the chain waits for runs next to it: W^T of the decoder's weights (needed by the first
+  // dgrad only) under the forward pass and everything between the two calls (render, loss), a layer's wgrads under the following
+  // layers' dgrads.  Fork / join are events (legal inside a caller's stream capture: the side stream joins the capture).
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_tr = nullptr, ev_join = nullptr;
+  bool tr_pending = false, use_side = true;
   std::vector<RecStep> singles;          // steps without a multi form: replayed through the single-room launchers
   std::vector<int> single_room;
 
@@ -1674,7 +1683,18 @@ struct SlnVaeGroup {
     *out = static_cast<const T*>(d);
     return 0;
   }
-  ~SlnVaeGroup() { for (void* p : allocs) (void)hipFree(p); }
+  ~SlnVaeGroup() {
+    for (void* p : allocs) (void)hipFree(p);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_tr) (void)hipEventDestroy(ev_tr);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+  }
+  int fork_side(hipStream_t st) {
+    hipError_t e = hipEventRecord(ev_fork, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(side, ev_fork, 0);
+    return (int)e;
+  }
 
   int add_single(std::vector<Launch>& prog, const RecStep& st, int room) {
     Launch l; l.kind = L_SINGLE_STEP; l.single = (int)singles.size();
@@ -1685,6 +1705,7 @@ struct SlnVaeGroup {
   // the TN problems gathered since the last flush marker -> per-pass wgrad launches over all rooms (flush_deferred's grouping)
   int flush_tn(std::vector<Launch>& prog, std::vector<GemmTNArgs>& pend) {
     static thread_local SlnVae::TnGroup tmp;
+    if (!pend.empty()) { Launch f; f.kind = L_FORK; prog.push_back(f); }      // the side stream picks up behind the producers of these gradients
     for (int k = 0; k < 2; ++k) {
       std::vector<GemmTNArgs> kind;
       for (const GemmTNArgs& t : pend) if ((int)tn_gathers_host(t) == k) kind.push_back(t);
@@ -1706,13 +1727,13 @@ struct SlnVaeGroup {
         if (r != 0) {                                     // one problem the planner refuses: its own launch
           RecStep st; st.kind = SK_TN; st.tn = kind[next++];
           if (g_sln_deterministic) st.tn.rows_per_block = sln_cdiv(st.tn.R, 32) * 32;
-          Launch l; l.kind = L_TN_SINGLE; l.single = (int)singles.size();
+          Launch l; l.kind = L_TN_SINGLE; l.single = (int)singles.size(); l.on_side = true;
           singles.push_back(st); single_room.push_back(-1);
           prog.push_back(l);
           continue;
         }
         next += (size_t)tmp.n;
-        Launch l; l.kind = L_TN_MULTI; l.blocks = tmp.blocks; l.x2 = tmp.x2; l.xg = tmp.xg; l.flops = tmp.flops;
+        Launch l; l.kind = L_TN_MULTI; l.blocks = tmp.blocks; l.x2 = tmp.x2; l.xg = tmp.xg; l.flops = tmp.flops; l.on_side = true;
         std::vector<GemmTNArgs> pv(tmp.probs, tmp.probs + tmp.n);
         RET_IF(upload(pv, &l.tn_probs));
         std::vector<TnMultiMeta> mv(1, tmp.meta);
@@ -1806,7 +1827,16 @@ struct SlnVaeGroup {
   int run(const std::vector<Launch>& prog, hipStream_t st) {
     for (const Launch& l : prog) {
       int r = 0;
+      hipStream_t main_st = st;
+      hipStream_t st = (l.on_side && use_side) ? side : main_st;       // (shadows the parameter for the launches below)
       switch (l.kind) {
+        case L_FORK: if (use_side) r = fork_side(main_st); break;
+        case L_JOIN:
+          if (use_side) { hipError_t e = hipEventRecord(ev_join, side); if (e == hipSuccess) e = hipStreamWaitEvent(main_st, ev_join, 0); r = (int)e; }
+          break;
+        case L_JOIN_TR:
+          if (use_side && tr_pending) { r = (int)hipStreamWaitEvent(main_st, ev_tr, 0); tr_pending = false; }
+          break;
         case L_NT: r = sln_launch_gemm_nt_small_multi(static_cast<const GemmNTArgs*>(l.tab), l.tiles, l.count, l.variant, l.gx, l.maxK, l.flops, st); break;
         case L_TN_MULTI: r = sln_launch_gemm_tn_multi(l.tn_probs, l.tn_meta, l.blocks, l.x2, l.xg, l.flops, st); break;
         case L_TN_SINGLE: r = sln_launch_gemm_tn(singles[l.single].tn, -1, st); break;
@@ -1822,7 +1852,10 @@ struct SlnVaeGroup {
         case SK_COPY2D: r = sln_launch_copy2d_multi(static_cast<const MAdd2*>(l.tab), l.count, l.gx, st); break;
         case SK_DEC_ASSEMBLE_BWD: r = sln_launch_dec_assemble_bwd_multi(l.tab, l.count, l.variant, l.gx, l.smem_floats, st); break;
         case L_ZERO: r = sln_launch_zero_multi(static_cast<const MZero*>(l.tab), l.count, l.max_n16, st); break;
-        case L_TRANSPOSE: r = sln_launch_transpose_table(static_cast<const TransposeEntry*>(l.tab), l.count, l.gx, st); break;
+        case L_TRANSPOSE:
+          r = sln_launch_transpose_table(static_cast<const TransposeEntry*>(l.tab), l.count, l.gx, st);
+          if (!r && l.on_side && use_side) { r = (int)hipEventRecord(ev_tr, side); tr_pending = true; }
+          break;
         case L_BN_GRADS: r = sln_launch_bn_param_grads(static_cast<const BnTableEntry*>(l.tab), l.count, l.gx, 1, st); break;
         case L_LOG_SOFTMAX: r = sln_launch_log_softmax(logits, io.angles_pred, rows_total, n_angle, st); break;
         case L_LOG_SOFTMAX_BWD: r = sln_launch_log_softmax_bwd(io.angles_pred, io.d_angles_pred, dlogits, rows_total, n_angle, st); break;
@@ -1934,7 +1967,18 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
       bnt.push_back(e); bn_maxc = b.C > bn_maxc ? b.C : bn_maxc;
     }
   }
-  // forward program: the recorded steps, then ONE log-softmax over every room's rows
+  if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&g->ev_tr, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess)
+    return fail(SLN_E_NOMEM);
+  { const char* v = std::getenv("SLN_GROUP_NO_SIDE"); g->use_side = !(v && v[0] == '1'); }      // lab: everything on the caller's stream
+  // forward program: W^T of the decoder's weights on the side stream (the parameters are final: the previous iteration's update
+  // is in front of the fork), the recorded steps, then ONE log-softmax over every room's rows
+  { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_FORK; g->fwd.push_back(l); }
+  {
+    SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles; l.on_side = true;
+    const TransposeEntry* d = nullptr; rc = g->upload(trs, &d); if (rc) return fail(rc); l.tab = d;
+    g->fwd.push_back(l);
+  }
   rc = g->merge(g->fwd, rf);
   if (rc) return fail(rc);
   { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_LOG_SOFTMAX; g->fwd.push_back(l); }
@@ -1946,33 +1990,28 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
     g->bwd.push_back(l);
   }
   {
-    SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles;
-    const TransposeEntry* d = nullptr; rc = g->upload(trs, &d); if (rc) return fail(rc); l.tab = d;
-    g->bwd.push_back(l);
+    // W^T: built by the forward call's side-stream launch (join); a backward without a forward in front of it (or with the side
+    // stream switched off) builds it here
+    SlnVaeGroup::Launch j; j.kind = SlnVaeGroup::L_JOIN_TR; g->bwd.push_back(j);
+    if (!g->use_side) {
+      SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles;
+      l.tab = g->fwd[1].tab;
+      g->bwd.push_back(l);
+    }
   }
   {
     std::vector<SlnVaeGroup::Launch> rest;
     rc = g->merge(rest, rb);
     if (rc) return fail(rc);
     // the parameter-gradient launch of the BatchNorm applications reads the sums every masked dgrad / edge kernel has finished:
-    // in front of the wgrad launches at the end of the pass (any position behind the last layer's gather works)
-    size_t first_tn = rest.size();
-    for (size_t i = 0; i < rest.size(); ++i)
-      if (rest[i].kind == SlnVaeGroup::L_TN_MULTI || rest[i].kind == SlnVaeGroup::L_TN_SINGLE) { first_tn = i; break; }
-    if (engines[0]->cfg.recurrent || engines[0]->tn_per_layer) first_tn = rest.size();
-    for (size_t i = 0; i < rest.size(); ++i) {
-      if (i == first_tn && !bnt.empty()) {
-        SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_BN_GRADS; l.count = (int)bnt.size(); l.gx = bn_maxc;
-        const BnTableEntry* d = nullptr; rc = g->upload(bnt, &d); if (rc) return fail(rc); l.tab = d;
-        g->bwd.push_back(l);
-      }
-      g->bwd.push_back(rest[i]);
-    }
-    if (first_tn == rest.size() && !bnt.empty()) {
+    // behind the last recorded step (the wgrads run on the side stream and do not touch them)
+    for (size_t i = 0; i < rest.size(); ++i) g->bwd.push_back(rest[i]);
+    if (!bnt.empty()) {
       SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_BN_GRADS; l.count = (int)bnt.size(); l.gx = bn_maxc;
       const BnTableEntry* d = nullptr; rc = g->upload(bnt, &d); if (rc) return fail(rc); l.tab = d;
       g->bwd.push_back(l);
     }
+    { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_JOIN; g->bwd.push_back(l); }     // every wgrad has landed behind this point
   }
   *out = g;
   return 0;

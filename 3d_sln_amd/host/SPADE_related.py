@@ -131,8 +131,12 @@ class SPADEGenerator4(nn.Module):
     # Batch-1 calls on ONE map (testing/test_SPADE_shade.py:77-79: 50 z per room): from the third consecutive call on the same
     # tensor the launch sequence is fixed - the planes are kept, nothing depends on z but the fc input - so that call is captured
     # into a hipGraph once per map and the later ones are a copy of z, one graph launch and a copy of the image: the ~1 ms of
-    # python / ctypes per call (57 launches) leaves the loop.  Set False to run every call eagerly.
-    graph_batch1 = True
+    # python / ctypes per call (57 launches) leaves the loop.  OFF by default: measured on the bench's 50 x 1 loop (a new map, 50 calls)
+    # 103 ms per room with the capture against 91 ms eager, identical images - a batch-1 call is ~1.7 ms of GPU time (57 dependent
+    # launches on one image), which the ~1 ms of host work already hides behind; the capture only adds its set-up (two eager calls
+    # on a side stream, capture, instantiation) to every new map.  The one-call-many-z form (forward(map, z[50])) is the fast path
+    # (1 082 images/s); this switch is kept for callers whose host is slower than the GPU.
+    graph_batch1 = False
 
     def _graph_eligible(self, input, z, taps):
         return (self.graph_batch1 and self.reuse_map_planes and taps is None and z is not None and input.dim() == 4 and input.shape[0] == 1 and
@@ -146,7 +150,10 @@ class SPADEGenerator4(nn.Module):
         key = (input.data_ptr(), input._version, tuple(input.shape), input.dtype, str(input.device), wkey)
         ent = getattr(self, "_b1_graph", None)
         if ent is None or ent["key"] != key:
-            ent = self._b1_graph = dict(key=key, calls=0, graph=None, stream=torch.cuda.Stream(device=input.device), keep=input)
+            side = getattr(self, "_b1_stream", None)
+            if side is None or side.device != input.device:
+                side = self._b1_stream = torch.cuda.Stream(device=input.device)     # ONE capture stream per module: its split scratch is allocated once
+            ent = self._b1_graph = dict(key=key, calls=0, graph=None, stream=side, keep=input)
             # the split scratch of the small convolutions is per stream and cannot be allocated while that stream is captured
             _lib.check(_lib.lib().sln_spade_prepare(C.c_void_p(ent["stream"].cuda_stream)), "sln_spade_prepare")
         if ent["graph"] is not None:
@@ -174,7 +181,7 @@ class SPADEGenerator4(nn.Module):
     def __getstate__(self):
         """copy.deepcopy / pickling: the packed weights, the kept planes and the pinned input tensor are caches, not state."""
         st = self.__dict__.copy()
-        st["_map_memo"] = st["_packed"] = st["_packed_key"] = st["_cat_cache"] = st["_b1_graph"] = None
+        st["_map_memo"] = st["_packed"] = st["_packed_key"] = st["_cat_cache"] = st["_b1_graph"] = st["_b1_stream"] = None
         return st
 
     def _pack_all(self):
