@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
                                                        float* __restrict__ pooled) {
   __shared__ float inter[POOL_LDS_MAX * POOL_LDS_MAX];
   const int nc = d.n_sem + d.n_dep;
+  // (planes x scales grid.  Round 5 tried the four scale-workgroups of a plane on one XCD, adjacent in launch order, so that the
+  //  plane is read from HBM once: 280 us against 223 - the scales differ 9x in work and interleaving them unbalances the XCDs)
   const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
   const int c = d.sem0 + cc;
   const int sz = s2_k1[s * d.P + d.P - 1] + 1;                    // intermediate size of this scale (the last pooled index reads its last row)
@@ -266,7 +268,7 @@ template <int MAXX, int ROWS, int PMAX>
 __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __restrict__ dpooled, const unsigned char* __restrict__ null,
                                                              RefineDims d, const int* __restrict__ col_ptr, const int* __restrict__ col_out,
                                                              const float* __restrict__ col_w, const float* __restrict__ gscale,
-                                                             float* __restrict__ dimg) {
+                                                             float* __restrict__ dimg, const int abl) {
   __shared__ float T[MAX_SCALES][ROWS][PMAX];
   const int x = blockIdx.z * 256 + threadIdx.x;
   const int c = blockIdx.y % d.C, b = blockIdx.y / d.C;
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   // four elements per pass, their 4 x MAXX loads issued together: one element at a time (MAXX loads in flight per thread, 24 dependent
   // round trips per workgroup) left the kernel latency-bound - 405 us for 16 rooms against ~130 us of LDS + L1 issue time
   {
-    const int n1 = d.n_scales * ROWS * d.P;
+    const int n1 = (abl & 1) ? 0 : d.n_scales * ROWS * d.P;
     constexpr int U = 4;
     for (int i0 = threadIdx.x; i0 < n1; i0 += 256 * U) {
       float v[U][MAXX]; float wgt[U][MAXX]; int si[U], ri[U], oi[U];
@@ -336,12 +338,130 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   const bool last = c == d.dep0 + d.n_dep - 1;
   for (int r = 0; r < ROWS && y0 + r < d.S; ++r) {
     float g = 0.f;
+    if (!(abl & 2))
 #pragma unroll
     for (int s = 0; s < MAX_SCALES; ++s)
 #pragma unroll
       for (int f = 0; f < MAXX; ++f) g = fmaf(wx[s][f], T[s][r][ox[s][f]], g);
     if (last && null[(long)b * d.S * d.S + (long)(y0 + r) * d.S + x]) g = 0.f;
     out[(long)(y0 + r) * d.S + x] = g * gs;
+  }
+}
+
+// Round 5: the same separable sum for NSTRIP strips of ROWS image rows per workgroup, rebuilt around what the kernel above is
+// actually bound by - LDS instruction issue (SLN_RBWD_ABL: stage 1 = 235 of its 390 us for 16 rooms; per T element it issues 10
+// LDS reads for the row's tap list next to 5 operand loads, per output pixel 20 single-word reads of T):
+//   * the pooled-gradient rows the workgroup's image rows touch are staged in LDS once (coalesced; each pooled row is read ~1.3
+//     times overall instead of by 13 strips: 2.2 GB through L2 before);
+//   * stage 1 runs one (scale, image row) pair per WAVEFRONT pass: the pair's tap list is wave-uniform and comes through SCALAR
+//     loads (no LDS traffic), the lanes walk the pooled columns: 5 LDS reads per T element instead of 15;
+//   * stage 2: a column's taps are consecutive pooled columns (checked per lane when the list is loaded), so the five T values
+//     of a scale are adjacent words: ds_read2 pairs, 12 LDS instructions per pixel instead of 20.
+// Same products, same order of additions (absent taps are skipped instead of added with weight 0): bit-identical output
+// (tools/lab/rbwd_compare.py).
+template <int MAXX, int ROWS, int NSTRIP, int PMAX, int RMAX>
+__global__ __launch_bounds__(256) void refine_bwd_sep2_kernel(const float* __restrict__ dpooled, const unsigned char* __restrict__ null,
+                                                              RefineDims d, const int* __restrict__ col_ptr, const int* __restrict__ col_out,
+                                                              const float* __restrict__ col_w, const float* __restrict__ gscale,
+                                                              float* __restrict__ dimg) {
+  static_assert(MAXX == 5, "the stage-2 read pattern is written for five taps");
+  constexpr int WR = ROWS * NSTRIP;                              // image rows per workgroup
+  constexpr int TP = PMAX + 4;                                   // T row: four words of slack behind the last pooled column
+  extern __shared__ __attribute__((aligned(16))) float sm2[];
+  float (*dP)[RMAX][PMAX] = reinterpret_cast<float (*)[RMAX][PMAX]>(sm2);                              // [MAX_SCALES]
+  float (*T)[ROWS][TP] = reinterpret_cast<float (*)[ROWS][TP]>(sm2 + MAX_SCALES * RMAX * PMAX);         // [MAX_SCALES]
+  __shared__ int lo_s[MAX_SCALES], n_s[MAX_SCALES];
+  const int x = blockIdx.z * 256 + threadIdx.x;
+  const int c = blockIdx.y % d.C, b = blockIdx.y / d.C;
+  const int yw0 = blockIdx.x * WR;                               // first image row of the workgroup
+  const bool active = x < d.S;
+  const int xs = active ? x : d.S - 1;
+  const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
+  float* out = dimg + ((long)(b * d.C + c) * d.S) * d.S;
+  if (cc < 0 || cc >= nc) {
+    if (active) for (int r = 0; r < WR && yw0 + r < d.S; ++r) out[(long)(yw0 + r) * d.S + x] = 0.f;
+    return;
+  }
+  int ox[MAX_SCALES][MAXX]; float wx[MAX_SCALES][MAXX];
+  bool contig = true;
+#pragma unroll
+  for (int s = 0; s < MAX_SCALES; ++s) {
+    const int sv = s < d.n_scales ? s : 0;
+    const int xb = col_ptr[sv * (d.S + 1) + xs], xe = s < d.n_scales ? col_ptr[sv * (d.S + 1) + xs + 1] : xb;
+#pragma unroll
+    for (int f = 0; f < MAXX; ++f) {
+      const bool v = xb + f < xe;
+      ox[s][f] = v ? col_out[xb + f] : 0;
+      wx[s][f] = v ? col_w[xb + f] : 0.f;
+    }
+#pragma unroll
+    for (int f = 1; f < MAXX; ++f) contig = contig && (wx[s][f] == 0.f || ox[s][f] == ox[s][0] + f);
+  }
+  const int ylast = min(yw0 + WR, d.S) - 1;
+  if (threadIdx.x < d.n_scales) {
+    // pooled rows the workgroup's image rows touch (the lists are ascending): first entry of the first row, last entry of the last
+    const int s = threadIdx.x;
+    const int* cp = col_ptr + s * (d.S + 1);
+    int lo = 1 << 30, hi = -1;
+    const int e0 = cp[yw0], e1 = cp[ylast + 1];
+    if (e1 > e0) { lo = col_out[e0]; hi = col_out[e1 - 1]; }
+    lo_s[s] = hi >= lo ? lo : 0; n_s[s] = hi >= lo ? hi - lo + 1 : 0;
+  }
+  for (int i = threadIdx.x; i < MAX_SCALES * ROWS * 4; i += 256) T[i / (ROWS * 4)][(i / 4) % ROWS][PMAX + i % 4] = 0.f;     // the slack words: read with weight 0
+  __syncthreads();
+  const long pp = (long)d.P * d.P;
+  bool fits = true;
+  for (int s = 0; s < d.n_scales; ++s) fits = fits && n_s[s] <= RMAX;
+  if (fits)
+    for (int s = 0; s < d.n_scales; ++s) {
+      const float* dp = dpooled + ((long)(b * d.n_scales + s) * nc + cc) * pp + (long)lo_s[s] * d.P;
+      for (int i = threadIdx.x; i < n_s[s] * d.P; i += 256) dP[s][i / d.P][i % d.P] = dp[i];
+    }
+  const float gs = gscale[0];
+  const bool last = c == d.dep0 + d.n_dep - 1;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int st = 0; st < NSTRIP; ++st) {
+    const int y0 = yw0 + st * ROWS;
+    if (y0 >= d.S) break;
+    __syncthreads();                                            // dP staged (first strip) / T of the previous strip consumed
+    // stage 1: wavefront w takes the pairs (scale, row) = w, w + 4, ...; the pair's taps are scalars
+    for (int p = wave; p < d.n_scales * ROWS; p += 4) {
+      const int s = p / ROWS, r = p % ROWS;
+      const int y = min(y0 + r, d.S - 1);
+      const int yb = col_ptr[s * (d.S + 1) + y];
+      const int ne = (y0 + r < d.S) ? min(col_ptr[s * (d.S + 1) + y + 1] - yb, MAXX) : 0;
+      int ro[MAXX]; float we[MAXX];
+#pragma unroll
+      for (int e = 0; e < MAXX; ++e) { const int q = yb + min(e, max(ne - 1, 0)); ro[e] = col_out[q]; we[e] = col_w[q]; }
+      const float* dg = dpooled + ((long)(b * d.n_scales + s) * nc + cc) * pp;
+      for (int o = lane; o < d.P; o += 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < MAXX; ++e)
+          if (e < ne) t = fmaf(we[e], fits ? dP[s][ro[e] - lo_s[s]][o] : dg[(long)ro[e] * d.P + o], t);
+        T[s][r][o] = t;
+      }
+    }
+    __syncthreads();
+    if (active)
+      for (int r = 0; r < ROWS && y0 + r < d.S; ++r) {
+        float g = 0.f;
+        if (contig) {
+#pragma unroll
+          for (int s = 0; s < MAX_SCALES; ++s) {
+            const float* tp = &T[s][r][ox[s][0]];               // five adjacent words (the slack covers ox + 4 > P - 1, weight 0 there)
+            const float t0 = tp[0], t1 = tp[1], t2 = tp[2], t3 = tp[3], t4 = tp[4];
+            g = fmaf(wx[s][0], t0, g); g = fmaf(wx[s][1], t1, g); g = fmaf(wx[s][2], t2, g); g = fmaf(wx[s][3], t3, g); g = fmaf(wx[s][4], t4, g);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < MAX_SCALES; ++s)
+#pragma unroll
+            for (int f = 0; f < MAXX; ++f) g = fmaf(wx[s][f], T[s][r][ox[s][f]], g);
+        }
+        if (last && null[(long)b * d.S * d.S + (long)(y0 + r) * d.S + x]) g = 0.f;
+        out[(long)(y0 + r) * d.S + x] = g * gs;
+      }
   }
 }
 
@@ -446,10 +566,33 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   const RefineDims d = dims_of(L);
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, const_cast<void*>(workspace), &pooled, &mask, &partial);
+  static const int abl = std::getenv("SLN_RBWD_ABL") ? std::atoi(std::getenv("SLN_RBWD_ABL")) : 0;      // lab: 1 no stage-1 loads, 2 no stage-2 sums
+  static const bool new_sep = std::getenv("SLN_RBWD_NEW") != nullptr;          // lab: the LDS-staged multi-strip kernel (slower so far, see LAB_NOTES)
+  static const int rows8 = std::getenv("SLN_RBWD_ROWS") ? std::atoi(std::getenv("SLN_RBWD_ROWS")) : 16;
+  if (!new_sep && rows8 == 8 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
+    hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 8, 96>), dim3(sln_cdiv(d.S, 8), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (!new_sep && rows8 == 32 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
+    hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 32, 96>), dim3(sln_cdiv(d.S, 32), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
+  if (new_sep && abl == 0 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96 && d.n_scales <= MAX_SCALES) {
+    constexpr int ROWS = 8, NSTRIP = 4, RMAX = 20;
+    constexpr size_t smem = sizeof(float) * (MAX_SCALES * RMAX * 96 + MAX_SCALES * ROWS * (96 + 4));
+    hipLaunchKernelGGL((refine_bwd_sep2_kernel<5, ROWS, NSTRIP, 96, RMAX>), dim3(sln_cdiv(d.S, ROWS * NSTRIP), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), smem,
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image);
+    SLN_CHECK_LAUNCH();
+    return 0;
+  }
   if (L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     constexpr int ROWS = 16;
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, ROWS, 96>), dim3(sln_cdiv(d.S, ROWS), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
   } else {
     const long n = (long)d.B * d.C * d.S * d.S;
     hipLaunchKernelGGL(refine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, mask, d, L->col_ptr,

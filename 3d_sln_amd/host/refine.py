@@ -214,7 +214,7 @@ class _RefineLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, rl):
         image = image.contiguous()
-        out = torch.empty(3, device=image.device)
+        out = torch.empty((image.shape[0], 3) if rl.per_room else (3,), device=image.device)     # per_room: one (loss, depth, sem) triple per image
         _lib.check(_lib.lib().sln_refine_loss_forward(rl.desc, _lib.ptr(image), _lib.ptr(rl.target_depth), _lib.ptr(rl.labels),
                                                       _lib.ptr(rl.inv_count), _lib.ptr(rl.ws), _lib.ptr(out), _lib.current_stream_ptr()),
                    "sln_refine_loss_forward")
@@ -225,7 +225,9 @@ class _RefineLossFn(torch.autograd.Function):
     def backward(ctx, gout):
         rl = ctx.rl
         g = torch.empty(ctx.shape, device=gout.device)
-        scale = gout[0:1].contiguous()                  # d/d(out[0]); out[1:] (the two parts) are reporting values
+        # d/d(out[0]); out[1:] (the two parts) are reporting values.  per_room: ONE scale for every room (the rooms' losses are
+        # independent objectives, each back-propagated with the same weight: element [0, 0])
+        scale = gout.reshape(-1)[0:1].contiguous()
         _lib.check(_lib.lib().sln_refine_loss_backward(rl.desc, _lib.ptr(rl.ws), _lib.ptr(scale), _lib.ptr(g), _lib.current_stream_ptr()),
                    "sln_refine_loss_backward")
         return g, None
