@@ -521,3 +521,45 @@ def test_rooms_in_flight_equal_the_one_room_loop(which):
             assert_close(dflt["idx"][r], i1.cpu().numpy(), "angles of room %d" % r, rtol=1e-5, atol=1e-5)
             assert_close(dflt["params"][r], m1.flat_params.detach().cpu().numpy(), "parameters of room %d" % r, rtol=1e-5, atol=1e-7)
     torch.cuda.synchronize()
+
+
+def test_rooms_in_flight_edge_cases():
+    """A batch that mixes an ordinary room, a room whose objects are all of classes the renderer skips (door / window: no visible
+    object, only the shell - diff_render.py:93-97), and a two-object room; hipGraph replay of a batch of ONE room; use_attr=False.
+    Every room equals its own single-room run bit for bit (deterministic mode) and the skipped-class room keeps a finite loss with
+    zero layout gradient."""
+    R = pkg("host.refine")
+    L = pkg("_lib").lib()
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="batch", use_attr=False)
+    model, sd = _room_model(cfg)
+    rooms = _random_rooms(3, cfg, seed=11)
+    k = len(rooms[1]["class_names"]) - 1
+    rooms[1]["class_names"] = ["door", "window"] * (k // 2) + ["door"] * (k % 2) + ["__room__"]
+    r2 = rooms[2]
+    keep = [0, 1, len(r2["class_names"]) - 1]
+    rooms[2] = dict(objs=r2["objs"][keep], triples=torch.tensor([[0, 3, 1], [0, 0, 2], [1, 0, 2]], device="cuda"), boxes=r2["boxes"][keep],
+                    angles=r2["angles"][keep], attributes=r2["attributes"][keep], class_names=[r2["class_names"][i] for i in keep])
+    bank = R.MeshBank(FURN, "cuda", seed=3)
+    kw = dict(bank=bank, learning_rate=1e-3, image_size=96, iters=3)
+    try:
+        L.sln_set_deterministic(1)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            rb = R.RefineBatch(model, rooms, **kw)
+            full = rb.run().cpu().numpy().copy()
+            boxes = [b.cpu().numpy().copy() for b, _ in rb.results()]
+            z_all, rows, row0 = rb.z.cpu().numpy().copy(), rb.rows, rb.row0
+            rb.close()
+            for r in range(3):
+                one = R.RefineBatch(model, [rooms[r]], **kw)
+                l1 = one.run(capture=(r == 0)).cpu().numpy()
+                assert np.array_equal(l1[:, 0], full[:, r]), "room %d alone (capture=%s)" % (r, r == 0)
+                assert np.array_equal(one.results()[0][0].cpu().numpy(), boxes[r])
+                assert np.array_equal(one.z.cpu().numpy(), z_all[row0[r]:row0[r] + rows[r]])
+                one.close()
+        torch.cuda.synchronize()
+    finally:
+        L.sln_set_deterministic(0)
+    assert np.isfinite(full).all()
+    assert len(set(full[:, 1].tolist())) == 1, "a room without a visible object has nothing to optimise: its loss stays put"
+    assert len(set(full[:, 0].tolist())) > 1
