@@ -74,6 +74,7 @@ def parse():
     ap.add_argument("--refine-iters", type=int, default=60, help="iterations of the layout-refinement leg (one room)")
     ap.add_argument("--no-refine", action="store_true")
     ap.add_argument("--refine-rooms", type=int, default=16, help="rooms in flight of the batched refinement leg")
+    ap.add_argument("--refine-rooms-large", type=int, default=64, help="a second, larger batch of rooms in flight (0 = skip)")
     ap.add_argument("--no-sampling", action="store_true")
     ap.add_argument("--sampling-draws", type=int, default=20000, help="posterior draws of the heat-map leg (testing/test_heatmap.py:39: num_iter)")
     ap.add_argument("--large-batches", type=str, default="128,256,512,1024,4096", help="extra VAE points (graphs per step; 128 = options/options.py:34, 512 = configs[4]'s global batch on one GPU), '' = none")
@@ -727,7 +728,7 @@ def refine_leg(args, lib, torch):
     # `--refine-rooms` of them (each on its own copy of the parameters) as one launch sequence per iteration
     nr = args.refine_rooms
     rooms = []
-    for r in range(nr):
+    for r in range(max(nr, args.refine_rooms_large)):
         gr = torch.Generator().manual_seed(100 + r)
         lo_r = torch.rand(n, 3, generator=gr) * 0.45 + 0.05; lo_r[:, 1] = 0.0; lo_r[:, 2] *= 0.6
         hi_r = lo_r + torch.rand(n, 3, generator=gr) * 0.2 + 0.12
@@ -736,6 +737,22 @@ def refine_leg(args, lib, torch):
                           class_names=names))
     model.load_state_dict(sd0)
     batch = {}
+    all_rooms = rooms
+    larger = None
+    if args.refine_rooms_large > nr:
+        # the same loop with more rooms in flight: the ~1 ms chain of dependent decoder launches is paid once per iteration whatever R
+        with torch.cuda.stream(st):
+            tl = []
+            for n_it in (iters, 2 * iters, iters, 2 * iters):
+                rb = R.RefineBatch(model, all_rooms[:args.refine_rooms_large], bank=bank, iters=n_it)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                rb.run()
+                torch.cuda.synchronize(); tl.append((n_it, time.perf_counter() - t1))
+                finl = bool(torch.isfinite(rb.losses).all().item()); rb.close()
+            a_ = min(x[1] for x in tl if x[0] == iters); b_ = min(x[1] for x in tl if x[0] == 2 * iters)
+            larger = {"rooms": args.refine_rooms_large, "ms_per_iteration": round((b_ - a_) / iters * 1e3, 3),
+                      "ms_per_room_iteration": round((b_ - a_) / iters * 1e3 / args.refine_rooms_large, 4), "finite": finl}
+    rooms = all_rooms[:nr]
     with torch.cuda.stream(st):
         runs = []
         for n_it in (iters, 2 * iters, iters, 2 * iters, iters, 2 * iters):
@@ -804,7 +821,7 @@ def refine_leg(args, lib, torch):
                     "sample": "%d iteration(s) of the same 12-object room through oracle/vae_ref.py + refine_ref.py + raster_ref.py (33 brute-force raster "
                               "passes per render), %.2f s per iteration" % (n_cpu, t_cpu / n_cpu)}
     one_room_bytes = 4 * 70 * 256.0 * 256.0 * 4.0 + 4 * (4 * 69 * 96 * 96 * 4.0) + 9 * 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
-    return {"rooms_%d" % nr: batch, "cpu_baseline": cpu_base,
+    return {"rooms_%d" % nr: batch, "rooms_%d" % args.refine_rooms_large: larger, "cpu_baseline": cpu_base,
             "roofline": {"kernel": "one refinement iteration of ONE room (all launches; latency-bound: ~110 dependent launches)", "bound": "hbm", "unit": "GB/s",
                          "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_room_iteration": int(one_room_bytes),
                          "achieved": round(one_room_bytes / (per_iter) / 1e9, 1), "frac": round(one_room_bytes / per_iter / 1e9 / HBM_PEAK_GBS, 4), "traffic": None},

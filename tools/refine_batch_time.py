@@ -39,7 +39,8 @@ def main():
                 res = []
                 for n_it in (iters, 2 * iters, iters, 2 * iters, iters, 2 * iters):
                     torch.cuda.synchronize(); t0 = time.perf_counter()
-                    rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it)
+                    G = int(os.environ.get("GROUPS", "1"))
+                    rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it) if G <= 1 else R.RefineBatches(model, rooms, groups=G, bank=bank, iters=n_it)
                     torch.cuda.synchronize(); t1 = time.perf_counter()
                     rb.run(capture=capture)
                     torch.cuda.synchronize(); t2 = time.perf_counter()
