@@ -1438,6 +1438,30 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
   return 0;
 }
 
+// live[b][ch] = 1 when channel ch of image b of the last sln_scene_forward can hold a non-zero value / its gradient can be read by
+// sln_scene_backward: channel 0 and the depth-hot channels always; semantic channel 1 + k only when the class mapped to NYU index k
+// has a visible pixel in image b (the planes of the other classes are exact zeros, and the backward pass never reads their
+// gradients: scene_bwd_grad_planes_kernel).  Lets the refinement loss skip those planes (SlnRefineLoss::live_planes).
+__global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, const int32_t* __restrict__ chan, int NC, int nch, int B,
+                                           unsigned char* __restrict__ live) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * nch) return;
+  const int b = i / nch, ch = i % nch;
+  unsigned char v = (ch == 0 || ch >= 41) ? 1 : 0;
+  if (!v)
+    for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && st[b].cnt[c] > 0.0) v = 1;
+  live[i] = v;
+}
+
+int sln_scene_live_channels(void* workspace, int B, int F, int image_size, int num_classes, const int32_t* class_channel,
+                            unsigned char* live, void* stream) {
+  if (!workspace || !class_channel || !live || B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
+  SceneWs w = carve_scene(workspace, B, F, image_size);
+  hipLaunchKernelGGL(scene_live_channels_kernel, dim3(sln_cdiv(B * 70, 256)), dim3(256), 0, (hipStream_t)stream, w.st, class_channel, num_classes, 70, B, live);
+  SLN_CHECK_LAUNCH();
+  return 0;
+}
+
 int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                        const int32_t* class_channel, const int32_t* class_depth_channel, float pix_eps, void* workspace,
                        const float* grad_final, float* grad_faces, void* stream) {

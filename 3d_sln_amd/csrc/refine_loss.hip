@@ -102,13 +102,18 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
                                                        RefineDims d,
                                                        const int* __restrict__ s2_k0, const int* __restrict__ s2_k1, const float* __restrict__ s2_l1,
                                                        const int* __restrict__ s1_i0, const int* __restrict__ s1_i1, const float* __restrict__ s1_l1,
-                                                       float* __restrict__ pooled) {
+                                                       float* __restrict__ pooled, const unsigned char* __restrict__ live) {
   __shared__ float inter[POOL_LDS_MAX * POOL_LDS_MAX];
   const int nc = d.n_sem + d.n_dep;
   // (planes x scales grid.  Round 5 tried the four scale-workgroups of a plane on one XCD, adjacent in launch order, so that the
   //  plane is read from HBM once: 280 us against 223 - the scales differ 9x in work and interleaving them unbalances the XCDs)
   const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
   const int c = d.sem0 + cc;
+  if (live != nullptr && !live[b * d.C + c]) {                    // an all-zero plane: its pooled plane is zero (what the taps would give)
+    float* dz = pooled + ((long)(b * d.n_scales + s) * nc + cc) * ((long)d.P * d.P);
+    for (int o = threadIdx.x; o < d.P * d.P; o += 256) dz[o] = 0.f;
+    return;
+  }
   const int sz = s2_k1[s * d.P + d.P - 1] + 1;                    // intermediate size of this scale (the last pooled index reads its last row)
   const long plane = (long)d.S * d.S;
   const bool fill = null_fill && c == d.dep0 + d.n_dep - 1;       // the last depth channel is set to 1 where no class has depth
@@ -268,7 +273,7 @@ template <int MAXX, int ROWS, int PMAX>
 __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __restrict__ dpooled, const unsigned char* __restrict__ null,
                                                              RefineDims d, const int* __restrict__ col_ptr, const int* __restrict__ col_out,
                                                              const float* __restrict__ col_w, const float* __restrict__ gscale,
-                                                             float* __restrict__ dimg, const int abl) {
+                                                             float* __restrict__ dimg, const int abl, const unsigned char* __restrict__ live) {
   __shared__ float T[MAX_SCALES][ROWS][PMAX];
   const int x = blockIdx.z * 256 + threadIdx.x;
   const int c = blockIdx.y % d.C, b = blockIdx.y / d.C;
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   const int xs = active ? x : d.S - 1;
   const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
   float* out = dimg + ((long)(b * d.C + c) * d.S) * d.S;
-  if (cc < 0 || cc >= nc) {
+  if (cc < 0 || cc >= nc || (live != nullptr && !live[b * d.C + c])) {      // channel 0, or a plane nobody reads the gradient of (live_planes)
     if (active) for (int r = 0; r < ROWS && y0 + r < d.S; ++r) out[(long)(y0 + r) * d.S + x] = 0.f;
     return;
   }
@@ -512,13 +517,13 @@ int sln_refine_loss_init(const SlnRefineLoss* L, void* workspace, void* stream) 
 }
 
 static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float* image, int null_fill, unsigned char* mask, float* pooled,
-                        hipStream_t st) {
+                        const unsigned char* live, hipStream_t st) {
   const long npix = (long)d.B * d.S * d.S;
   if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask);
   static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
   if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
     hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
-                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled);
+                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled, live);
     return;
   }
   const long np = (long)d.B * d.n_scales * sln_cdiv(d.n_sem + d.n_dep, CG) * d.P * d.P;
@@ -533,7 +538,7 @@ int sln_refine_pool(const SlnRefineLoss* L, const float* image, int null_fill, v
   const RefineDims d = dims_of(L);
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, workspace, &pooled, &mask, &partial);
-  launch_pool(L, d, image, null_fill, mask, pooled_out, (hipStream_t)stream);
+  launch_pool(L, d, image, null_fill, mask, pooled_out, nullptr, (hipStream_t)stream);      // any image: no plane is known dead
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -547,7 +552,7 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   const RefineDims d = dims_of(L);
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, workspace, &pooled, &mask, &partial);
-  launch_pool(L, d, image, 1, mask, pooled, st);
+  launch_pool(L, d, image, 1, mask, pooled, L->live_planes, st);
   const long nl = (long)d.B * d.n_scales * d.P * d.P;
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
   hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial);
@@ -571,13 +576,13 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   static const int rows8 = std::getenv("SLN_RBWD_ROWS") ? std::atoi(std::getenv("SLN_RBWD_ROWS")) : 16;
   if (!new_sep && rows8 == 8 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 8, 96>), dim3(sln_cdiv(d.S, 8), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
     SLN_CHECK_LAUNCH();
     return 0;
   }
   if (!new_sep && rows8 == 32 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 32, 96>), dim3(sln_cdiv(d.S, 32), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
     SLN_CHECK_LAUNCH();
     return 0;
   }
@@ -592,7 +597,7 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   if (L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     constexpr int ROWS = 16;
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, ROWS, 96>), dim3(sln_cdiv(d.S, ROWS), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
   } else {
     const long n = (long)d.B * d.C * d.S * d.S;
     hipLaunchKernelGGL(refine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, mask, d, L->col_ptr,

@@ -459,7 +459,7 @@ def _room_model(cfg, seed=1):
 
 
 @pytest.mark.parametrize("which", ["train_py_defaults", "small_no_norm_z_behind_the_gconvs"])
-def test_rooms_in_flight_equal_the_one_room_loop(which):
+def test_rooms_in_flight_equal_the_one_room_loop(which, monkeypatch):
     """testing/test_render_refine.py:250-263 refines its rooms one after the other, every one on a fresh copy of the checkpoint.
     RefineBatch runs R of them as one launch sequence: a room's losses, boxes, angles, latents and fine-tuned parameters must not
     depend on the other rooms of the batch - BIT-identical between R = 16, R = 3 and R = 1 in deterministic mode, also under
@@ -490,6 +490,11 @@ def test_rooms_in_flight_equal_the_one_room_loop(which):
             three = run([4, 9, 15])
             ones = {r: run([r]) for r in (0, 9, 15)}
             graph = run(range(16), capture=True)
+            # the loss skips the semantic planes of classes without a visible pixel (SlnRefineLoss::live_planes): the same run
+            # with every plane processed must give the same bits
+            monkeypatch.setenv("SLN_REFINE_ALL_PLANES", "1")
+            every_plane = run(range(16))
+            monkeypatch.delenv("SLN_REFINE_ALL_PLANES")
         torch.cuda.synchronize()
     finally:
         L.sln_set_deterministic(0)
@@ -497,7 +502,8 @@ def test_rooms_in_flight_equal_the_one_room_loop(which):
     assert np.isfinite(full["losses"]).all()
     moved = sum(len(set(full["losses"][:, r].tolist())) > 1 for r in range(16))
     assert moved >= 12, "only %d of 16 rooms saw a gradient" % moved
-    for name, other, sel in [("repeat", again, list(range(16))), ("R=3", three, [4, 9, 15]), ("graph", graph, list(range(16)))] + \
+    for name, other, sel in [("repeat", again, list(range(16))), ("R=3", three, [4, 9, 15]), ("graph", graph, list(range(16))),
+                             ("every plane", every_plane, list(range(16)))] + \
                             [("R=1 room %d" % r, o, [r]) for r, o in ones.items()]:
         for j, r in enumerate(sel):
             assert np.array_equal(other["losses"][:, j], full["losses"][:, r]), "%s: losses of room %d" % (name, r)
