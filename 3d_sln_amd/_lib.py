@@ -188,7 +188,7 @@ SIGNATURES = {
                                  C.c_void_p]),
     "sln_graph_emit": (C.c_int, [C.POINTER(SlnRoomTable), C.c_void_p, C.c_int, C.c_void_p, C.POINTER(SlnGraphDraws),
                                  C.POINTER(SlnGraphBatch), C.c_void_p]),
-    "sln_scene_live_channels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sln_scene_live_channels": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sln_scene_backward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                      C.c_float, C.c_void_p, c_f32p, c_f32p, C.c_void_p]),
     "sln_place_forward": (C.c_int, [C.POINTER(SlnPlacement), c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_void_p]),

@@ -1190,6 +1190,7 @@ __global__ __launch_bounds__(256) void scene_bwd_plane_sums_kernel(const int32_t
   __syncthreads();
   const int owner = s_owner;
   if (owner < 0) return;
+  if (!(st[b].cnt[owner] > 0.0)) return;                          // gsum[owner] is only used at the class's own pixels (scene_bwd_depthgrad_kernel)
   const long plane = (long)is * is;
   const float4* src = reinterpret_cast<const float4*>(gout + ((long)b * nch + 41 + k) * plane);
   const long n4 = plane / 4;
@@ -1438,26 +1439,38 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
   return 0;
 }
 
-// live[b][ch] = 1 when channel ch of image b of the last sln_scene_forward can hold a non-zero value / its gradient can be read by
-// sln_scene_backward: channel 0 and the depth-hot channels always; semantic channel 1 + k only when the class mapped to NYU index k
-// has a visible pixel in image b (the planes of the other classes are exact zeros, and the backward pass never reads their
-// gradients: scene_bwd_grad_planes_kernel).  Lets the refinement loss skip those planes (SlnRefineLoss::live_planes).
-__global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, const int32_t* __restrict__ chan, int NC, int nch, int B,
-                                           unsigned char* __restrict__ live) {
+// live[b][ch] of the last sln_scene_forward, two bits.  Bit 0: the plane can hold a non-zero value (clear: it is all zeros).
+// Bit 1: sln_scene_backward reads the plane's incoming gradient (clear: it never does).
+//   channel 0, the last depth-hot channel (the loss fills it where no class has depth): 3
+//   semantic channel 1 + k: 3 when the class mapped to NYU index k has a visible pixel in image b, else 0 - the plane is zeros
+//     and scene_bwd_grad_planes_kernel skips it
+//   depth-hot channel 41 + k: 3 when its class has a visible pixel; 1 when it has none - the plane is the constant 1
+//     (scene_fill_table: mean / wall_max with the mean replaced by wall_max) and its gradient only enters gsum[owner], which
+//     scene_bwd_depthgrad_kernel uses at the class's own pixels; 0 when no class owns the channel
+// Lets the refinement loss skip those planes (SlnRefineLoss::live_planes).
+__global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, const int32_t* __restrict__ chan, const int32_t* __restrict__ dch,
+                                           int NC, int nch, int B, unsigned char* __restrict__ live) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nch) return;
   const int b = i / nch, ch = i % nch;
-  unsigned char v = (ch == 0 || ch >= 41) ? 1 : 0;
-  if (!v)
-    for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && st[b].cnt[c] > 0.0) v = 1;
+  unsigned char v = (ch == 0 || ch == nch - 1) ? 3 : 0;
+  if (!v) {
+    if (ch < 41) {
+      for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && st[b].cnt[c] > 0.0) v = 3;
+    } else {
+      for (int c = 0; c < NC; ++c) if (dch[c] + 41 == ch) v |= st[b].cnt[c] > 0.0 ? 3 : 1;
+    }
+  }
   live[i] = v;
 }
 
 int sln_scene_live_channels(void* workspace, int B, int F, int image_size, int num_classes, const int32_t* class_channel,
-                            unsigned char* live, void* stream) {
-  if (!workspace || !class_channel || !live || B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
+                            const int32_t* class_depth_channel, unsigned char* live, void* stream) {
+  if (!workspace || !class_channel || !class_depth_channel || !live || B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64)
+    return SLN_E_BADARG;
   SceneWs w = carve_scene(workspace, B, F, image_size);
-  hipLaunchKernelGGL(scene_live_channels_kernel, dim3(sln_cdiv(B * 70, 256)), dim3(256), 0, (hipStream_t)stream, w.st, class_channel, num_classes, 70, B, live);
+  hipLaunchKernelGGL(scene_live_channels_kernel, dim3(sln_cdiv(B * 70, 256)), dim3(256), 0, (hipStream_t)stream, w.st, class_channel,
+                     class_depth_channel, num_classes, 70, B, live);
   SLN_CHECK_LAUNCH();
   return 0;
 }

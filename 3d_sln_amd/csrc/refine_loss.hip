@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
   //  plane is read from HBM once: 280 us against 223 - the scales differ 9x in work and interleaving them unbalances the XCDs)
   const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
   const int c = d.sem0 + cc;
-  if (live != nullptr && !live[b * d.C + c]) {                    // an all-zero plane: its pooled plane is zero (what the taps would give)
+  if (live != nullptr && !(live[b * d.C + c] & 1)) {              // an all-zero plane: its pooled plane is zero (what the taps would give)
     float* dz = pooled + ((long)(b * d.n_scales + s) * nc + cc) * ((long)d.P * d.P);
     for (int o = threadIdx.x; o < d.P * d.P; o += 256) dz[o] = 0.f;
     return;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   const int xs = active ? x : d.S - 1;
   const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
   float* out = dimg + ((long)(b * d.C + c) * d.S) * d.S;
-  if (cc < 0 || cc >= nc || (live != nullptr && !live[b * d.C + c])) {      // channel 0, or a plane nobody reads the gradient of (live_planes)
+  if (cc < 0 || cc >= nc || (live != nullptr && !(live[b * d.C + c] & 2))) {      // channel 0, or a plane nobody reads the gradient of (live_planes)
     if (active) for (int r = 0; r < ROWS && y0 + r < d.S; ++r) out[(long)(y0 + r) * d.S + x] = 0.f;
     return;
   }

@@ -697,9 +697,9 @@ class RefineBatch:
         self.image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
         self.g_image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
         self.loss_out = torch.empty(R, 3, **f32)
-        # the semantic planes of classes without a visible pixel are zeros and the scene pass never reads their gradients: the
-        # loss skips them (SlnRefineLoss::live_planes, refreshed after every scene pass)
-        self.live = torch.ones(R, DR.N_SCENE_CHANNELS, dtype=torch.uint8, device=dev)
+        # the semantic planes of classes without a visible pixel are zeros, and the scene pass never reads their gradients nor
+        # those of such classes' depth-hot planes: the loss skips them (SlnRefineLoss::live_planes, refreshed after every scene pass)
+        self.live = torch.full((R, DR.N_SCENE_CHANNELS), 3, dtype=torch.uint8, device=dev)
         if not os.environ.get("SLN_REFINE_ALL_PLANES"):
             self.loss.desc.live_planes = self.live.data_ptr()
         self.one = torch.ones(1, **f32)
@@ -729,7 +729,7 @@ class RefineBatch:
                                        P(self.scene_ws), P(self.image), st), "sln_scene_forward")
         rl = self.loss
         if rl.desc.live_planes:
-            _lib.check(L.sln_scene_live_channels(P(self.scene_ws), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.live), st),
+            _lib.check(L.sln_scene_live_channels(P(self.scene_ws), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), P(self.live), st),
                        "sln_scene_live_channels")
         _lib.check(L.sln_refine_loss_forward(rl.desc, P(self.image), P(rl.target_depth), P(rl.labels), P(rl.inv_count), P(rl.ws), P(self.loss_out), st),
                    "sln_refine_loss_forward")

@@ -327,11 +327,12 @@ int64_t sln_scene_workspace_bytes(int B, int F, int image_size);
 int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                       const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
                       float far, float tex_eps, void* workspace, float* final_out, void* stream);
-/* live [B, 70] (bytes) of the last sln_scene_forward on `workspace`: 1 for channel 0, the depth-hot channels and the semantic
- * channels of classes with a visible pixel in that image; 0 for semantic planes that are all zero (and whose gradient
- * sln_scene_backward never reads).  The refinement loss skips planes marked 0 (SlnRefineLoss::live_planes). */
+/* live [B, 70] (bytes) of the last sln_scene_forward on `workspace`, two bits per channel: bit 0 clear = the plane is all zeros
+ * (semantic channels of classes without a visible pixel in that image), bit 1 clear = sln_scene_backward never reads the
+ * plane's gradient (those, and the depth-hot planes of such classes, which hold the constant 1).  The refinement loss skips
+ * what the bits allow (SlnRefineLoss::live_planes). */
 int sln_scene_live_channels(void* workspace, int B, int F, int image_size, int num_classes, const int32_t* class_channel,
-                            unsigned char* live, void* stream);
+                            const int32_t* class_depth_channel, unsigned char* live, void* stream);
 int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                        const int32_t* class_channel, const int32_t* class_depth_channel, float pix_eps, void* workspace,
                        const float* grad_final, float* grad_faces, void* stream);
@@ -420,10 +421,10 @@ typedef struct {
   int max_col_entries;                          /* longest CSR row (selects the register-list backward kernel when <= 5); 0 = unknown */
   int per_room;                                 /* != 0: the B images are B independent rooms (one refinement loop each): loss_out is
                                                  * [B][3], every room's L1 mean runs over its own elements, inv_count is [B][n_scales] */
-  const unsigned char* live_planes;             /* optional [B, channels] (device): planes marked 0 are known to be all zero in `image`
-                                                 * (sln_scene_live_channels): forward writes their pooled planes as zeros without reading
-                                                 * them, backward zero-fills their gradient instead of computing it (the scene pass never
-                                                 * reads it).  NULL: every plane is processed. */
+  const unsigned char* live_planes;             /* optional [B, channels] (device), as written by sln_scene_live_channels for `image`:
+                                                 * bit 0 clear - the plane is all zeros: forward writes its pooled plane as zeros
+                                                 * without reading it; bit 1 clear - nobody reads the plane's gradient: backward
+                                                 * zero-fills it instead of computing it.  NULL: every plane is processed. */
 } SlnRefineLoss;
 int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
 int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */
