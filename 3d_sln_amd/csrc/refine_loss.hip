@@ -31,13 +31,19 @@ struct RefineDims {
   int per_room, pad_;             // per_room: B independent rooms - every room's loss is normalised by its OWN element / label counts
 };
 
-__global__ void null_mask_kernel(const float* __restrict__ img, RefineDims d, unsigned char* __restrict__ null) {
+// `live` (SlnRefineLoss::live_planes): a plane marked 0 is all zeros, a plane marked 1 the constant 1 - the same sum without the load
+__global__ void null_mask_kernel(const float* __restrict__ img, RefineDims d, unsigned char* __restrict__ null,
+                                 const unsigned char* __restrict__ live) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long plane = (long)d.S * d.S;
   if (i >= d.B * plane) return;
   const long b = i / plane, pix = i % plane;
   const float* p = img + (b * d.C + d.dep0) * plane + pix;
   float s = 0.f;
+  if (live != nullptr) {
+    const unsigned char* lv = live + b * d.C + d.dep0;
+    for (int c = 0; c < d.n_dep; ++c) { const int k = lv[c]; s += k == 3 ? p[c * plane] : (k == 1 ? 1.f : 0.f); }
+  } else
   for (int c = 0; c < d.n_dep; ++c) s += p[c * plane];
   null[i] = s < 0.5f ? 1 : 0;
 }
@@ -109,11 +115,14 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
   //  plane is read from HBM once: 280 us against 223 - the scales differ 9x in work and interleaving them unbalances the XCDs)
   const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
   const int c = d.sem0 + cc;
-  if (live != nullptr && !(live[b * d.C + c] & 1)) {              // an all-zero plane: its pooled plane is zero (what the taps would give)
+  const int lv = live != nullptr ? live[b * d.C + c] : 3;
+  if (!(lv & 1)) {                                                // an all-zero plane: its pooled plane is zero (what the taps would give)
+    if (cc < d.n_sem) return;                                     // ... and loss_kernel does not read the dead semantic planes at all
     float* dz = pooled + ((long)(b * d.n_scales + s) * nc + cc) * ((long)d.P * d.P);
     for (int o = threadIdx.x; o < d.P * d.P; o += 256) dz[o] = 0.f;
     return;
   }
+  const bool ones = lv == 1;                                      // the constant 1: the same expressions on 1.f instead of the four taps
   const int sz = s2_k1[s * d.P + d.P - 1] + 1;                    // intermediate size of this scale (the last pooled index reads its last row)
   const long plane = (long)d.S * d.S;
   const bool fill = null_fill && c == d.dep0 + d.n_dep - 1;       // the last depth channel is set to 1 where no class has depth
@@ -123,7 +132,8 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
     const int ky = i / sz, kx = i % sz;
     const int y0 = s1_i0[s * d.pmax + ky], y1 = s1_i1[s * d.pmax + ky], x0 = s1_i0[s * d.pmax + kx], x1 = s1_i1[s * d.pmax + kx];
     const float h1 = s1_l1[s * d.pmax + ky], h0 = 1.f - h1, w1 = s1_l1[s * d.pmax + kx], w0 = 1.f - w1;
-    float v00 = src[(long)y0 * d.S + x0], v01 = src[(long)y0 * d.S + x1], v10 = src[(long)y1 * d.S + x0], v11 = src[(long)y1 * d.S + x1];
+    float v00 = 1.f, v01 = 1.f, v10 = 1.f, v11 = 1.f;
+    if (!ones) { v00 = src[(long)y0 * d.S + x0]; v01 = src[(long)y0 * d.S + x1]; v10 = src[(long)y1 * d.S + x0]; v11 = src[(long)y1 * d.S + x1]; }
     if (fill) {
       v00 = nm[(long)y0 * d.S + x0] ? 1.f : v00; v01 = nm[(long)y0 * d.S + x1] ? 1.f : v01;
       v10 = nm[(long)y1 * d.S + x0] ? 1.f : v10; v11 = nm[(long)y1 * d.S + x1] ? 1.f : v11;
@@ -146,7 +156,7 @@ constexpr int DCH = 8;               // depth channels per thread of loss_kernel
 template <int NSEM>
 __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, RefineDims d, const float* __restrict__ tgt_depth,
                                                    const int* __restrict__ labels, const float* __restrict__ inv_count,
-                                                   float2* __restrict__ partial) {
+                                                   float2* __restrict__ partial, const unsigned char* __restrict__ live) {
   const int nc = d.n_sem + d.n_dep;
   const long pp = (long)d.P * d.P;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -158,9 +168,17 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
     float* p = pooled + ((long)(b * d.n_scales + s) * nc) * pp + pix;
     if (blockIdx.y == 0) {
       const int t = labels[i];
+      // semantic planes marked all-zero (live_planes) enter as the zeros they are, unread (pool_lds_kernel did not write them), and
+      // their gradient, which nobody reads, is not stored
+      unsigned long long lm = ~0ull;
+      if (live != nullptr) {
+        lm = 0;
+        const unsigned char* lv = live + b * d.C + d.sem0;
+        for (int c = 0; c < NSEM; ++c) lm |= (unsigned long long)(lv[c] & 1) << c;
+      }
       float v[NSEM];
 #pragma unroll
-      for (int c = 0; c < NSEM; ++c) v[c] = p[c * pp];
+      for (int c = 0; c < NSEM; ++c) v[c] = (lm >> c & 1) ? p[c * pp] : 0.f;
       if (t >= 0) {
         float m = v[0];
 #pragma unroll
@@ -174,12 +192,12 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
 #pragma unroll
         for (int c = 0; c < NSEM; ++c) {
           vt = c == t ? v[c] : vt;
-          p[c * pp] = (expf(v[c] - lse) - (c == t ? 1.f : 0.f)) * (k * 100.f);
+          if (lm >> c & 1) p[c * pp] = (expf(v[c] - lse) - (c == t ? 1.f : 0.f)) * (k * 100.f);
         }
         l_ce = (lse - vt) * k;
       } else {
 #pragma unroll
-        for (int c = 0; c < NSEM; ++c) p[c * pp] = 0.f;
+        for (int c = 0; c < NSEM; ++c) if (lm >> c & 1) p[c * pp] = 0.f;
       }
     } else {                                                                       // depth channels, DCH per thread
       const float gd = 50.f / (float)((double)(d.per_room ? 1 : d.B) * d.n_scales * d.n_dep * pp);      // 100 * 0.5 / numel
@@ -516,10 +534,18 @@ int sln_refine_loss_init(const SlnRefineLoss* L, void* workspace, void* stream) 
   return 0;
 }
 
+// live_planes is honoured only where every kernel of the forward / backward pair knows about it (the LDS pooling kernel and the
+// separable backward kernel: the shapes of the refinement loop); elsewhere every plane is processed
+static const unsigned char* live_of(const SlnRefineLoss* L, const RefineDims& d) {
+  static const bool lab = std::getenv("SLN_POOL_NO_LDS") != nullptr || std::getenv("SLN_RBWD_NEW") != nullptr;
+  const bool ok = !lab && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.n_sem == 40;
+  return ok ? L->live_planes : nullptr;
+}
+
 static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float* image, int null_fill, unsigned char* mask, float* pooled,
                         const unsigned char* live, hipStream_t st) {
   const long npix = (long)d.B * d.S * d.S;
-  if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask);
+  if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask, live);
   static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
   if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
     hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
@@ -552,10 +578,11 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   const RefineDims d = dims_of(L);
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, workspace, &pooled, &mask, &partial);
-  launch_pool(L, d, image, 1, mask, pooled, L->live_planes, st);
+  const unsigned char* live = live_of(L, d);
+  launch_pool(L, d, image, 1, mask, pooled, live, st);
   const long nl = (long)d.B * d.n_scales * d.P * d.P;
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
-  hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial);
+  hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial, live);
   const long per_room_rows = (long)d.n_scales * d.P * d.P;
   if (d.per_room && per_room_rows % 128 != 0) return SLN_E_UNSUPPORTED;       // a block of loss_kernel would cover two rooms
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(d.per_room ? d.B : 1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out, (int)lg.x,
@@ -571,18 +598,19 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   const RefineDims d = dims_of(L);
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, const_cast<void*>(workspace), &pooled, &mask, &partial);
+  const unsigned char* live = live_of(L, d);
   static const int abl = std::getenv("SLN_RBWD_ABL") ? std::atoi(std::getenv("SLN_RBWD_ABL")) : 0;      // lab: 1 no stage-1 loads, 2 no stage-2 sums
   static const bool new_sep = std::getenv("SLN_RBWD_NEW") != nullptr;          // lab: the LDS-staged multi-strip kernel (slower so far, see LAB_NOTES)
   static const int rows8 = std::getenv("SLN_RBWD_ROWS") ? std::atoi(std::getenv("SLN_RBWD_ROWS")) : 16;
   if (!new_sep && rows8 == 8 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 8, 96>), dim3(sln_cdiv(d.S, 8), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, live);
     SLN_CHECK_LAUNCH();
     return 0;
   }
   if (!new_sep && rows8 == 32 && L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, 32, 96>), dim3(sln_cdiv(d.S, 32), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, live);
     SLN_CHECK_LAUNCH();
     return 0;
   }
@@ -597,7 +625,7 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   if (L->max_col_entries > 0 && L->max_col_entries <= 5 && d.P <= 96) {
     constexpr int ROWS = 16;
     hipLaunchKernelGGL((refine_bwd_sep_kernel<5, ROWS, 96>), dim3(sln_cdiv(d.S, ROWS), d.B * d.C, sln_cdiv(d.S, 256)), dim3(256), 0,
-                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, L->live_planes);
+                       (hipStream_t)stream, pooled, mask, d, L->col_ptr, L->col_out, L->col_w, grad_scale, grad_image, abl, live);
   } else {
     const long n = (long)d.B * d.C * d.S * d.S;
     hipLaunchKernelGGL(refine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pooled, mask, d, L->col_ptr,
