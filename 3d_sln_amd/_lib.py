@@ -85,7 +85,7 @@ class SlnPlacementRoom(C.Structure):
 
 class SlnVaeGroupIO(C.Structure):
     _fields_ = [("rows_total", C.c_int), ("row0_host", C.POINTER(C.c_int))] + \
-               [(n, C.c_void_p) for n in ("z", "boxes_pred", "angles_pred", "d_boxes_pred", "d_angles_pred", "dz")]
+               [(n, C.c_void_p) for n in ("z", "boxes_pred", "angles_pred", "d_boxes_pred", "d_angles_pred", "dz", "sgd_step")]
 
 
 # name -> (restype, argtypes); every symbol include/sln_hip.h declares must be listed here
@@ -124,6 +124,7 @@ SIGNATURES = {
     "sln_vae_group_decoder": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_group_decoder_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_group_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sln_vae_group_fused_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "sln_vae_group_destroy": (None, [C.c_void_p]),
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_set_deterministic": (C.c_int, [C.c_int]),

@@ -1501,6 +1501,7 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
   __syncthreads();
   {
     const float* src = red + ((wave ^ 2) * 16) * 64 + lane;      // the partner's copy of the accumulator this wave keeps
+    const float sc = a.sgd_step != nullptr ? -a.sgd_step[0] : 1.f;   // GemmTNArgs::sgd_step (x 1 is exact)
     const int k = k0 + 32 * wc + lrow;
     float* dcol = a.dW + min(k, a.Kin - 1);
     const bool kv = k < a.Kin;
@@ -1508,14 +1509,14 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     if (wr == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = tn_acc_read(acc[0][r]) + src[r * 64];
+        const float v = (tn_acc_read(acc[0][r]) + src[r * 64]) * sc;
         const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk);
         if (kv && n < a.Nout) sln_gatomic_add(dcol + (size_t)n * a.lddw, v);
       }
     } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = src[r * 64] + tn_acc_read(acc[1][r]);
+        const float v = (src[r * 64] + tn_acc_read(acc[1][r])) * sc;
         const int n = n0 + 2 * ((r & 3) + 8 * (r >> 2) + 4 * lk) + 1;
         if (kv && n < a.Nout) sln_gatomic_add(dcol + (size_t)n * a.lddw, v);
       }
@@ -1538,10 +1539,11 @@ __device__ __forceinline__ void gemm_tn_body(const GemmTNArgs& a, const int bx, 
     if (tid < TPRA) {
       const float4 p0 = dbs[tid], p1 = dbs[TPRA + tid], p2 = dbs[2 * TPRA + tid], p3 = dbs[3 * TPRA + tid];
       const int n = n0 + 4 * tid;
-      if (n + 0 < a.Nout) sln_gatomic_add(a.db + n + 0, ((p0.x + p1.x) + p2.x) + p3.x);
-      if (n + 1 < a.Nout) sln_gatomic_add(a.db + n + 1, ((p0.y + p1.y) + p2.y) + p3.y);
-      if (n + 2 < a.Nout) sln_gatomic_add(a.db + n + 2, ((p0.z + p1.z) + p2.z) + p3.z);
-      if (n + 3 < a.Nout) sln_gatomic_add(a.db + n + 3, ((p0.w + p1.w) + p2.w) + p3.w);
+      const float sb = a.sgd_step != nullptr ? -a.sgd_step[0] : 1.f;
+      if (n + 0 < a.Nout) sln_gatomic_add(a.db + n + 0, (((p0.x + p1.x) + p2.x) + p3.x) * sb);
+      if (n + 1 < a.Nout) sln_gatomic_add(a.db + n + 1, (((p0.y + p1.y) + p2.y) + p3.y) * sb);
+      if (n + 2 < a.Nout) sln_gatomic_add(a.db + n + 2, (((p0.z + p1.z) + p2.z) + p3.z) * sb);
+      if (n + 3 < a.Nout) sln_gatomic_add(a.db + n + 3, (((p0.w + p1.w) + p2.w) + p3.w) * sb);
     }
   }
 }

@@ -293,8 +293,9 @@ __global__ void refine_sgd_kernel(float* __restrict__ p, float* __restrict__ g, 
   if (i < nz) z[i] -= step_z * gz[i];
 }
 
-// R parameter copies, up to four ranges each (see sln_refine_sgd_rooms); blockIdx.y = room * n_ranges + range
-struct SgdRanges { long off[4], len[4]; int n; };
+// R parameter copies, up to SGD_MAX_RANGES ranges each (see sln_refine_sgd_rooms); blockIdx.y = room * n_ranges + range
+constexpr int SGD_MAX_RANGES = 96;
+struct SgdRanges { long off[SGD_MAX_RANGES], len[SGD_MAX_RANGES]; int n; };
 __global__ void refine_sgd_rooms_kernel(float* __restrict__ p, float* __restrict__ g, long stride, SgdRanges rg, float step, float* __restrict__ z,
                                         const float* __restrict__ gz, long nz, float step_z) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -399,7 +400,7 @@ int sln_place_backward_rooms(const SlnPlacementRoom* rooms, int R, int n_max, vo
 
 int sln_refine_sgd_rooms(float* params, float* grads, int R, int64_t stride, const int64_t* off_host, const int64_t* len_host, int n_ranges,
                          float step, float* z, const float* grad_z, int64_t nz, float step_z, void* stream) {
-  if (!params || !grads || R <= 0 || n_ranges < 1 || n_ranges > 4 || !off_host || !len_host || nz < 0 || (nz > 0 && (!z || !grad_z))) return SLN_E_BADARG;
+  if (!params || !grads || R <= 0 || n_ranges < 1 || n_ranges > SGD_MAX_RANGES || !off_host || !len_host || nz < 0 || (nz > 0 && (!z || !grad_z))) return SLN_E_BADARG;
   if (((reinterpret_cast<uintptr_t>(params) | reinterpret_cast<uintptr_t>(grads)) & 15) || (stride & 3)) return SLN_E_BADARG;
   SgdRanges rg; std::memset(&rg, 0, sizeof(rg));
   rg.n = n_ranges;

@@ -33,6 +33,10 @@ struct GemmTNArgs {
   int lddw;
   int R, Nout, Kin;
   int rows_per_block;   // <= 0: choose
+  // SGD in the epilogue (the refinement loop's R rooms in flight, vae_engine.hip SlnVaeGroup): when set (DEVICE pointer to the step),
+  // dW / db point at the PARAMETERS and receive -step * (the gradient) - the same atomic add, one pass over the weights instead of
+  // three (gradient +=, then the optimizer's read of both and write)
+  const float* sgd_step;
 };
 
 // epi: EPI_*; tile: -1 = heuristic, 0 = 64x64, 1 = 128x64, 2 = 128x128

@@ -7,6 +7,7 @@
 // flush_deferred -, a dozen bookkeeping launches), captured once into a hipGraph and replayed.
 #include <cstddef>
 #include <new>
+#include <utility>
 #include <vector>
 #include <cstring>
 #include <cstdlib>
@@ -1670,6 +1671,7 @@ struct SlnVaeGroup {
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_tr = nullptr, ev_join = nullptr;
   bool tr_pending = false, use_side = true;
+  std::vector<std::pair<const float*, int64_t>> fused;      // room 0's parameter tensors stepped by the wgrad launches (io.sgd_step)
   std::vector<RecStep> singles;          // steps without a multi form: replayed through the single-room launchers
   std::vector<int> single_room;
 
@@ -1760,7 +1762,25 @@ struct SlnVaeGroup {
     std::vector<GemmTNArgs> pend;
     for (size_t s = 0; s < n; ++s) {
       const int kind = recs[0].steps[s].kind;
-      if (kind == SK_TN) { for (int r = 0; r < R; ++r) pend.push_back(recs[r].steps[s].tn); continue; }
+      if (kind == SK_TN) {
+        for (int r = 0; r < R; ++r) {
+          GemmTNArgs t = recs[r].steps[s].tn;
+          if (io.sgd_step != nullptr && t.lddw == t.Kin) {      // SGD in the wgrad's epilogue: the add lands in the parameter itself
+            for (const Unit& u : eng[r]->units)
+              if (u.p.d_weight == t.dW && (t.db == nullptr || u.p.d_bias == t.db)) {
+                t.dW = u.p.weight; if (t.db != nullptr) t.db = u.p.bias;
+                t.sgd_step = io.sgd_step;
+                if (r == 0) {
+                  fused.push_back(std::make_pair((const float*)u.p.weight, (int64_t)u.out * u.in));
+                  if (t.db != nullptr) fused.push_back(std::make_pair((const float*)u.p.bias, (int64_t)u.out));
+                }
+                break;
+              }
+          }
+          pend.push_back(t);
+        }
+        continue;
+      }
       if (kind == SK_TN_FLUSH) { RET_IF(flush_tn(prog, pend)); continue; }
       // rooms whose block plans to the same variant share a launch
       std::vector<int> var(R, -1), gxs(R, 0), gys(R, 0), smf(R, 0);
@@ -2033,6 +2053,13 @@ int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single
   if (bwd) *bwd = (int)g->bwd.size();
   if (single_room_fallbacks) *single_room_fallbacks = (int)g->singles.size();
   return 0;
+}
+
+int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64_t* numel, int max) {
+  if (!g || max < 0 || (max > 0 && (!params || !numel))) return SLN_E_BADARG;
+  const int n = (int)g->fused.size();
+  for (int i = 0; i < n && i < max; ++i) { params[i] = g->fused[i].first; numel[i] = g->fused[i].second; }
+  return n;
 }
 
 void sln_vae_group_destroy(SlnVaeGroup* g) { delete g; }

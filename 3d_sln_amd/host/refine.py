@@ -657,6 +657,11 @@ class RefineBatch:
         io.row0_host = self._row0_c
         io.z, io.boxes_pred, io.angles_pred = self.z.data_ptr(), self.boxes_pred.data_ptr(), self.angles_pred.data_ptr()
         io.d_boxes_pred, io.d_angles_pred, io.dz = self.d_boxes_pred.data_ptr(), self.d_angles_pred.data_ptr(), self.dz.data_ptr()
+        # SGD of the Linear weights / biases in the epilogue of their wgrads (one pass over the R parameter copies instead of the
+        # gradient += and the optimizer's read of both and write; SLN_REFINE_SEPARATE_SGD=1: the stand-alone step over everything)
+        self._step = torch.full((1,), (self.lr / 10.0) * 1.1, **f32)
+        if not os.environ.get("SLN_REFINE_SEPARATE_SGD"):
+            io.sgd_step = self._step.data_ptr()
         harr = (C.c_void_p * R)(*[e[0] for e in self._engines])
         g = C.c_void_p()
         torch.cuda.current_stream(dev).synchronize()          # the tables of the program are uploaded with blocking copies
@@ -705,6 +710,28 @@ class RefineBatch:
         self.one = torch.ones(1, **f32)
         self.losses = torch.zeros(max(self.iters, 1), R, **f32)
         rg = model.decoder_param_ranges()
+        nf = int(L.sln_vae_group_fused_params(self._group, None, None, 0))
+        if nf > 0:                                                   # ... minus the tensors the wgrad launches step themselves
+            ptrs, lens = (C.c_void_p * nf)(), (C.c_int64 * nf)()
+            L.sln_vae_group_fused_params(self._group, ptrs, lens, nf)
+            base = self.params.data_ptr()
+            offs = [(int(ptrs[i]) - base) // 4 for i in range(nf)]
+            al = 64 if all(o % 64 == 0 for o in offs) else 4         # the flat layout pads every tensor to 64 floats (nothing lives in the pad)
+            cut = sorted((o, -(-int(lens[i]) // al) * al) for i, o in enumerate(offs))
+            out = []
+            for a, n in rg:
+                pos, end = a, a + n
+                for c0, cn in cut:
+                    if c0 + cn <= pos or c0 >= end:
+                        continue
+                    if c0 % 4 or c0 < pos:
+                        raise _lib.SlnError("a fused parameter tensor does not start on a 16-byte boundary of the decoder run")
+                    if c0 > pos:
+                        out.append((pos, c0 - pos))
+                    pos = c0 + cn
+                if pos < end:
+                    out.append((pos, end - pos))
+            rg = out
         self._sgd_off = (C.c_int64 * len(rg))(*[a for a, _ in rg])
         self._sgd_len = (C.c_int64 * len(rg))(*[b for _, b in rg])
         self._n_rg = len(rg)

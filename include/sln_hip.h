@@ -209,11 +209,18 @@ typedef struct SlnVaeGroupIO {
   float* d_boxes_pred;            /* [rows_total, 8]        gradient w.r.t. boxes_pred, row stride 8 (columns >= box_dim 0) */
   float* d_angles_pred;           /* [rows_total, n_angle]  gradient w.r.t. the log-softmax output                       */
   float* dz;                      /* [rows_total, E]        written by backward                                          */
+  const float* sgd_step;          /* optional DEVICE scalar: when set, the wgrads of backward apply  W -= step * dW,  b -= step * db
+                                   * to every room's Linear parameters in their epilogue instead of accumulating into the
+                                   * gradient buffers (sln_vae_group_fused_params lists the tensors; the caller's optimizer
+                                   * steps the others: sln_refine_sgd_rooms over the remaining ranges)                     */
 } SlnVaeGroupIO;
 int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io, SlnVaeGroup** out);
 int sln_vae_group_decoder(SlnVaeGroup* g, void* stream);
-/* parameter gradients are accumulated (+=) into every room's gradient buffer, dz is written */
+/* parameter gradients are accumulated (+=) into every room's gradient buffer (but see SlnVaeGroupIO::sgd_step), dz is written */
 int sln_vae_group_decoder_backward(SlnVaeGroup* g, void* stream);
+/* the tensors of ROOM 0's parameter copy that backward steps itself (SlnVaeGroupIO::sgd_step; the same tensors of every room):
+ * returns their number, writes at most `max` (pointer, element count) pairs */
+int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64_t* numel, int max);
 /* launches per forward / backward pass and how many of them are single-room fallbacks (diagnostics) */
 int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single_room_fallbacks);
 void sln_vae_group_destroy(SlnVaeGroup* g);
@@ -394,9 +401,10 @@ typedef struct {
 int sln_place_forward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int F_max, void* stream);
 int sln_place_backward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int n_max, void* stream);
 /* sln_refine_sgd over R parameter copies: for every room r and every range k: p[r * stride + off_k + i] -= step * g[...], g = 0
- * (i < len_k; off_k, len_k multiples of 4 floats; n_ranges <= 4: the decoder's parameters are the three *_dc embedding tables in
+ * (i < len_k; off_k, len_k multiples of 4 floats; n_ranges <= 96: the decoder's parameters are the three *_dc embedding tables in
  * front and the trailing gconv_net_dc / box_net / angle_net run - encoder-only parameters have zero gradients in this loop and are
- * not touched); z [nz] -= step_z * grad_z. */
+ * not touched - or, with SlnVaeGroupIO::sgd_step, what is left of those runs between the Linear tensors the wgrads step
+ * themselves); z [nz] -= step_z * grad_z. */
 int sln_refine_sgd_rooms(float* params, float* grads, int R, int64_t stride, const int64_t* off_host, const int64_t* len_host, int n_ranges,
                          float step, float* z, const float* grad_z, int64_t nz, float step_z, void* stream);
 
