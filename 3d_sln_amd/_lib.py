@@ -163,6 +163,8 @@ SIGNATURES = {
     "sln_scene_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "sln_scene_forward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),
+    "sln_scene_forward_live": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p]),
     "sln_spade_prepare": (C.c_int, [C.c_void_p]),
     "sln_spade_conv": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, c_f32p, C.c_void_p]),

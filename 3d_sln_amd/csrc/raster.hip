@@ -1104,12 +1104,24 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   }
 }
 
-struct ComposeTabs { int chan[64]; int dch[64]; int owner[32]; float fill[32]; float wall; };
+struct ComposeTabs { int chan[64]; int dch[64]; int owner[32]; float fill[32]; float wall; unsigned char live[72]; };
+// live flag of channel ch of an image (see sln_scene_live_channels)
+__device__ __forceinline__ unsigned char scene_live_flag(const SceneStats& sb, const int* chan, const int* dch, int NC, int nch, int ch) {
+  unsigned char v = (ch == 0 || ch == nch - 1) ? 3 : 0;
+  if (!v) {
+    if (ch < 41) {
+      for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && sb.cnt[c] > 0.0) v = 3;
+    } else {
+      for (int c = 0; c < NC; ++c) if (dch[c] + 41 == ch) v |= sb.cnt[c] > 0.0 ? 3 : 1;
+    }
+  }
+  return v;
+}
 // The class tables go to LDS in one round trip; the owner search then walks LDS.  (It walked dch[] in global memory with a
 // break - up to 32 dependent loads in front of every workgroup's first pixel - and every pixel divided each of its 29
 // depth-hot values by wall_max.)
 __device__ __forceinline__ void compose_tables(ComposeTabs& t, const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int NC,
-                                               int ndch, const SceneStats& sb) {
+                                               int ndch, const SceneStats& sb, const bool want_live = false) {
   if (threadIdx.x < 64) {
     t.chan[threadIdx.x] = threadIdx.x < NC ? chan[threadIdx.x] : -1;      // image channel (0-based among the 40) of class c
     t.dch[threadIdx.x] = threadIdx.x < NC ? dch[threadIdx.x] : -1;        // depth channel of class c
@@ -1129,6 +1141,10 @@ __device__ __forceinline__ void compose_tables(ComposeTabs& t, const int32_t* __
     t.fill[k] = fill / wall_max;                                            // mean_c / wall_max: the same quotient for every pixel
     if (k == 0) t.wall = wall_max;
   }
+  if (want_live && threadIdx.x >= 64 && threadIdx.x < 64 + 72) {
+    const int ch = threadIdx.x - 64;
+    t.live[ch] = ch < 41 + ndch ? scene_live_flag(sb, t.chan, t.dch, NC, 41 + ndch, ch) : 0;
+  }
   __syncthreads();
 }
 
@@ -1138,11 +1154,15 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
                                                             const float* __restrict__ d_a, const int32_t* __restrict__ cls,
                                                             const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, unsigned char* __restrict__ live) {
   __shared__ ComposeTabs t;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
-  compose_tables(t, chan, dch, NC, ndch, st[b]);
+  compose_tables(t, chan, dch, NC, ndch, st[b], live != nullptr);
+  // live != nullptr (sln_scene_forward_live): the image's flags go out, and only the planes flagged 3 are written - the others are
+  // all zeros (flag 0) or the constant 1 (flag 1) and the flags say so
+  const bool sparse = live != nullptr;
+  if (sparse && blockIdx.x == 0 && threadIdx.x < nch) live[b * nch + threadIdx.x] = t.live[threadIdx.x];
   const long plane = (long)is * is;
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= plane) return;
@@ -1157,14 +1177,15 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
   float* o = out + ((long)b * nch * is + (is - 1 - y)) * is + x;       // channel stride = plane
   o[0] = dd;
   const int mych = cvalid ? t.chan[c] : -1;
-  for (int ch = 1; ch <= 40 && ch < nch; ++ch) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
+  for (int ch = 1; ch <= 40 && ch < nch; ++ch)
+    if (!sparse || t.live[ch] == 3) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
   const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
   const bool own_ok = img > 0.1f;
   for (int k = 0; k < ndch; ++k) {
     const int owner = t.owner[k];
     float v = 0.f;
     if (owner >= 0) v = (c == owner && own_ok) ? ddq : t.fill[k];
-    o[(long)(41 + k) * plane] = v;
+    if (!sparse || t.live[41 + k] == 3) o[(long)(41 + k) * plane] = v;
   }
 }
 
@@ -1412,9 +1433,9 @@ __global__ void scene_prep_kernel(const float* __restrict__ faces, long n, int i
   }
 }
 
-int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
-                      const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
-                      float far, float tex_eps, void* workspace, float* final_out, void* stream) {
+static int scene_forward_impl(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                              const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                              float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream) {
   if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !final_out) return SLN_E_BADARG;
   if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1434,9 +1455,27 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
   // wall_max starts at -inf surrogate
   hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
   hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
-                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out);
+                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out, live);
   SLN_CHECK_LAUNCH();
   return 0;
+}
+
+int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                      const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                      float far, float tex_eps, void* workspace, float* final_out, void* stream) {
+  return scene_forward_impl(faces, face_class, B, F, image_size, num_classes, class_channel, class_depth_channel, near_depth, near_rgb, far,
+                            tex_eps, workspace, final_out, nullptr, stream);
+}
+
+// The same pass for a consumer that reads the image through its flags (the refinement loss, SlnRefineLoss::live_planes): `live`
+// [B, 70] receives what sln_scene_live_channels would write, and only the planes flagged 3 of final_out are written - a plane
+// flagged 0 WOULD hold zeros, a plane flagged 1 the constant 1; their memory is left as it was.
+int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                           const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream) {
+  if (!live) return SLN_E_BADARG;
+  return scene_forward_impl(faces, face_class, B, F, image_size, num_classes, class_channel, class_depth_channel, near_depth, near_rgb, far,
+                            tex_eps, workspace, final_out, live, stream);
 }
 
 // live[b][ch] of the last sln_scene_forward, two bits.  Bit 0: the plane can hold a non-zero value (clear: it is all zeros).
@@ -1453,14 +1492,7 @@ __global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, co
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nch) return;
   const int b = i / nch, ch = i % nch;
-  unsigned char v = (ch == 0 || ch == nch - 1) ? 3 : 0;
-  if (!v) {
-    if (ch < 41) {
-      for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && st[b].cnt[c] > 0.0) v = 3;
-    } else {
-      for (int c = 0; c < NC; ++c) if (dch[c] + 41 == ch) v |= st[b].cnt[c] > 0.0 ? 3 : 1;
-    }
-  }
+  const unsigned char v = scene_live_flag(st[b], chan, dch, NC, nch, ch);
   live[i] = v;
 }
 

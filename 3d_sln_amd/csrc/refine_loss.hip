@@ -300,7 +300,8 @@ __global__ __launch_bounds__(256) void refine_bwd_sep_kernel(const float* __rest
   const int xs = active ? x : d.S - 1;
   const int nc = d.n_sem + d.n_dep, cc = c - d.sem0;
   float* out = dimg + ((long)(b * d.C + c) * d.S) * d.S;
-  if (cc < 0 || cc >= nc || (live != nullptr && !(live[b * d.C + c] & 2))) {      // channel 0, or a plane nobody reads the gradient of (live_planes)
+  if (live != nullptr && cc >= 0 && cc < nc && !(live[b * d.C + c] & 2)) return;      // a plane nobody reads the gradient of (live_planes): left as it is
+  if (cc < 0 || cc >= nc) {                                                            // channel 0
     if (active) for (int r = 0; r < ROWS && y0 + r < d.S; ++r) out[(long)(y0 + r) * d.S + x] = 0.f;
     return;
   }

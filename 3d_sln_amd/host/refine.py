@@ -699,8 +699,8 @@ class RefineBatch:
                 raise _lib.SlnError("rooms of one batch must share the class tables")
         self.S = S
         self.scene_ws = torch.empty(int(L.sln_scene_workspace_bytes(R, self.F2, S)), dtype=torch.uint8, device=dev)
-        self.image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
-        self.g_image = torch.empty(R, DR.N_SCENE_CHANNELS, S, S, **f32)
+        self.image = torch.zeros(R, DR.N_SCENE_CHANNELS, S, S, **f32)         # (planes flagged dead are never written, nor read)
+        self.g_image = torch.zeros(R, DR.N_SCENE_CHANNELS, S, S, **f32)
         self.loss_out = torch.empty(R, 3, **f32)
         # the semantic planes of classes without a visible pixel are zeros, and the scene pass never reads their gradients nor
         # those of such classes' depth-hot planes: the loss skips them (SlnRefineLoss::live_planes, refreshed after every scene pass)
@@ -752,12 +752,13 @@ class RefineBatch:
         _lib.check(L.sln_refine_head_forward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.boxes_pred), P(self.angles_pred), P(noise),
                                                    P(self.box_last), P(self.angle_last), 2.0, P(self.boxes), P(self.idx), st), "sln_refine_head_forward_rooms")
         _lib.check(L.sln_place_forward_rooms(P(self._place_tab), R, self.F2 // 2, st), "sln_place_forward_rooms")
-        _lib.check(L.sln_scene_forward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0, 1e-3,
-                                       P(self.scene_ws), P(self.image), st), "sln_scene_forward")
         rl = self.loss
         if rl.desc.live_planes:
-            _lib.check(L.sln_scene_live_channels(P(self.scene_ws), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), P(self.live), st),
-                       "sln_scene_live_channels")
+            _lib.check(L.sln_scene_forward_live(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0,
+                                                1e-3, P(self.scene_ws), P(self.image), P(self.live), st), "sln_scene_forward_live")
+        else:
+            _lib.check(L.sln_scene_forward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0,
+                                           1e-3, P(self.scene_ws), P(self.image), st), "sln_scene_forward")
         _lib.check(L.sln_refine_loss_forward(rl.desc, P(self.image), P(rl.target_depth), P(rl.labels), P(rl.inv_count), P(rl.ws), P(self.loss_out), st),
                    "sln_refine_loss_forward")
         torch.add(self.loss_out[:, 0], self.size_loss, alpha=2.0, out=out)

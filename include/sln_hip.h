@@ -334,6 +334,12 @@ int64_t sln_scene_workspace_bytes(int B, int F, int image_size);
 int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                       const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
                       float far, float tex_eps, void* workspace, float* final_out, void* stream);
+/* sln_scene_forward for a consumer that reads the image through its flags (SlnRefineLoss::live_planes): `live` [B, 70] receives
+ * the flags described below, and only the planes flagged 3 of final_out are written (a plane flagged 0 would hold zeros, a plane
+ * flagged 1 the constant 1: their memory is left as it was). */
+int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
+                           const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
+                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream);
 /* live [B, 70] (bytes) of the last sln_scene_forward on `workspace`, two bits per channel: bit 0 clear = the plane is all zeros
  * (semantic channels of classes without a visible pixel in that image), bit 1 clear = sln_scene_backward never reads the
  * plane's gradient (those, and the depth-hot planes of such classes, which hold the constant 1).  The refinement loss skips
@@ -432,7 +438,7 @@ typedef struct {
   const unsigned char* live_planes;             /* optional [B, channels] (device), as written by sln_scene_live_channels for `image`:
                                                  * bit 0 clear - the plane is all zeros: forward writes its pooled plane as zeros
                                                  * without reading it; bit 1 clear - nobody reads the plane's gradient: backward
-                                                 * zero-fills it instead of computing it.  NULL: every plane is processed. */
+                                                 * leaves that plane of grad_image as it is.  NULL: every plane is processed. */
 } SlnRefineLoss;
 int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
 int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */

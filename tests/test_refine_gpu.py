@@ -569,3 +569,49 @@ def test_rooms_in_flight_edge_cases():
     assert np.isfinite(full).all()
     assert len(set(full[:, 1].tolist())) == 1, "a room without a visible object has nothing to optimise: its loss stays put"
     assert len(set(full[:, 0].tolist())) > 1
+
+
+def test_sparse_scene_image_and_its_flags_describe_the_full_image():
+    """sln_scene_forward_live (what RefineBatch renders with): the flags equal sln_scene_live_channels' after a full
+    sln_scene_forward of the same faces; planes flagged 3 are the full image's, planes flagged 0 ARE zeros there and planes
+    flagged 1 ARE the constant 1 - what the refinement loss assumes without reading them."""
+    R = pkg("host.refine"); DR = pkg("host.diff_render")
+    _lib = pkg("_lib"); L = _lib.lib(); P = _lib.ptr
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="batch")
+    model, sd = _room_model(cfg)
+    rooms = _random_rooms(3, cfg, seed=5)
+    bank = R.MeshBank(FURN, "cuda", seed=3)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        rb = R.RefineBatch(model, rooms, bank=bank, learning_rate=1e-3, image_size=96, iters=2)
+        rb.image.fill_(-7.0)                                   # what the sparse pass does not write stays -7
+        rb.run(1)
+        sp = _lib.current_stream_ptr()
+        full = torch.full_like(rb.image, -7.0)
+        flags = torch.zeros_like(rb.live)
+        _lib.check(L.sln_scene_forward(P(rb.faces), P(rb.cls), rb.R, rb.F2, rb.S, rb.chan.numel(), P(rb.chan), P(rb.dch), 0.1, 0.001, 100.0, 1e-3,
+                                       P(rb.scene_ws), P(full), sp), "sln_scene_forward")
+        _lib.check(L.sln_scene_live_channels(P(rb.scene_ws), rb.R, rb.F2, rb.S, rb.chan.numel(), P(rb.chan), P(rb.dch), P(flags), sp),
+                   "sln_scene_live_channels")
+        torch.cuda.synchronize()
+        live, img = rb.live.cpu().numpy(), rb.image.cpu().numpy()
+        rb.close()
+    full, flags = full.cpu().numpy(), flags.cpu().numpy()
+    assert set(np.unique(flags).tolist()) <= {0, 1, 3}
+    n = {k: int((flags == k).sum()) for k in (0, 1, 3)}
+    assert n[0] > 0 and n[1] > 0 and n[3] >= 3 * 3, n
+    for b in range(flags.shape[0]):
+        for ch in range(flags.shape[1]):
+            if flags[b, ch] == 0:
+                assert not full[b, ch].any(), (b, ch)
+            elif flags[b, ch] == 1:
+                assert (full[b, ch] == 1.0).all(), (b, ch)
+    assert (full != -7.0).all()
+    # the batch's own render of the same faces (rb.faces is rewritten by the next iteration's placement only)
+    assert np.array_equal(live, flags)
+    for b in range(live.shape[0]):
+        for ch in range(live.shape[1]):
+            if live[b, ch] == 3:
+                assert np.array_equal(img[b, ch], full[b, ch]), (b, ch)
+            else:
+                assert (img[b, ch] == -7.0).all(), (b, ch, live[b, ch])
