@@ -80,7 +80,9 @@ class SlnRefineLoss(C.Structure):
 class SlnPlacementRoom(C.Structure):
     _fields_ = [("P", SlnPlacement)] + \
                [(n, C.c_void_p) for n in ("boxes", "angles", "size_target", "faces_out", "sizes", "size_loss", "grad_faces", "grad_size_loss",
-                                          "grad_boxes", "grad_angles")]
+                                          "grad_boxes", "grad_angles", "boxes_pred", "angles_pred", "noise", "noise_step")] + \
+               [("noise_stride", C.c_int64)] + [(n, C.c_void_p) for n in ("box_last", "angle_last", "grad_boxes_pred", "grad_angles_pred")] + \
+               [("n_angle", C.c_int), ("ld_gb", C.c_int), ("beta", C.c_float), ("pad_", C.c_int)]
 
 
 class SlnVaeGroupIO(C.Structure):

@@ -129,10 +129,41 @@ __global__ __launch_bounds__(256) void place_forward_kernel(SlnPlacement P, cons
                                                             float* __restrict__ sizes, float* __restrict__ size_loss) {
   place_forward_body(P, boxes, angles, size_target, fxyz, sizes, size_loss);
 }
+// (defined with the stand-alone head kernels below)
+__device__ __forceinline__ void head_forward_row(const int i, const int room, const bool lastrow, const int na, const float* __restrict__ boxes_pred,
+                                                 const float* __restrict__ angles_pred, const float* __restrict__ noise,
+                                                 const float* __restrict__ box_last, const float* __restrict__ angle_last, const float beta,
+                                                 float* __restrict__ box_out, float* __restrict__ idx_out);
+__device__ __forceinline__ void head_backward_row(const int i, const bool lastrow, const int na, const float* __restrict__ angles_pred,
+                                                  const float* __restrict__ g_box_row, const float g_idx_row, const float beta,
+                                                  float* __restrict__ g_boxes_pred, float* __restrict__ g_angles_pred, const int ld_gb);
+// With the head fields of a room set (SlnPlacementRoom::boxes_pred), the glue between the decoder and the placement runs inside the
+// two placement launches (round 5: two launches less per iteration): every workgroup derives the room's [n, 6] boxes and [n] angle
+// indices from the decoder's outputs into LDS - a dozen rows, the stand-alone head kernel's own arithmetic - and places its faces
+// from there; workgroup 0 also stores them (backward and the caller read them).
+constexpr int HEAD_ROWS = 128;
 __global__ __launch_bounds__(256) void place_forward_rooms_kernel(const SlnPlacementRoom* __restrict__ rooms) {
   const SlnPlacementRoom& r = rooms[blockIdx.y];
   if ((int)blockIdx.x * 256 >= r.P.F && blockIdx.x != 0) return;
-  place_forward_body(r.P, r.boxes, r.angles, r.size_target, r.faces_out, r.sizes, r.size_loss);
+  __shared__ float s_box[HEAD_ROWS * 6];
+  __shared__ float s_idx[HEAD_ROWS];
+  const float* boxes = r.boxes; const float* angles = r.angles;
+  if (r.boxes_pred != nullptr) {
+    const int n = r.P.n;
+    if (n > HEAD_ROWS) __builtin_trap();                       // the host checks this before it sets the head fields
+    // the noise of iteration k = noise_step[0] (a device counter, advanced by the backward launch): row k of a [iterations, stride] table
+    const float* nz = r.noise != nullptr && r.noise_step != nullptr ? r.noise + (long)r.noise_step[0] * r.noise_stride : r.noise;
+    for (int i = threadIdx.x; i < n; i += 256) {
+      head_forward_row(i, 0, i == n - 1, r.n_angle, r.boxes_pred, r.angles_pred, nz, r.box_last, r.angle_last, r.beta, s_box + 6 * i, s_idx + i);
+      if (blockIdx.x == 0) {
+        for (int j = 0; j < 6; ++j) const_cast<float*>(r.boxes)[6 * i + j] = s_box[6 * i + j];
+        const_cast<float*>(r.angles)[i] = s_idx[i];
+      }
+    }
+    __syncthreads();
+    boxes = s_box; angles = s_idx;
+  }
+  place_forward_body(r.P, boxes, angles, r.size_target, r.faces_out, r.sizes, r.size_loss);
 }
 
 // one workgroup per row of `boxes`; rows without a visible object get zero gradients
@@ -226,12 +257,33 @@ __global__ __launch_bounds__(256) void place_backward_rooms_kernel(const SlnPlac
   const SlnPlacementRoom& r = rooms[blockIdx.y];
   if ((int)blockIdx.x >= r.P.n) return;
   place_backward_body(r.P, r.boxes, r.angles, r.size_target, r.grad_faces, r.grad_size_loss, r.grad_boxes, r.grad_angles);
+  if (r.boxes_pred == nullptr) return;
+  __syncthreads();                                             // the row's gradients are in memory (written by this workgroup)
+  if (threadIdx.x == 0) {
+    const int row = blockIdx.x;
+    head_backward_row(row, row == r.P.n - 1, r.n_angle, r.angles_pred, r.grad_boxes + 6 * row, r.grad_angles[row], r.beta, r.grad_boxes_pred,
+                      r.grad_angles_pred, r.ld_gb);
+    if (row == 0 && blockIdx.y == 0 && r.noise_step != nullptr) r.noise_step[0] += 1;      // the next forward reads the next row of the noise table
+  }
 }
 
 // ---- the torch glue between the decoder and the placement as one kernel each way (testing/test_render_refine.py:296-306) ----
 // forward: boxes_full = [boxes_pred[:-1] ; box_last], idx = [softargmax(angles_pred, beta)[:-1] + noise[:-1] / 10 ; angle_last]
 // with softargmax(x) = sum_j softmax(beta x)_j (j + 1) - 1 (:20-25).  One thread per row.
 // (room_of_row / last_row: rows of several rooms concatenated - box_last [R,6], angle_last [R]; nullptr: one room of n rows)
+__device__ __forceinline__ void head_forward_row(const int i, const int room, const bool lastrow, const int na, const float* __restrict__ boxes_pred,
+                                                 const float* __restrict__ angles_pred, const float* __restrict__ noise,
+                                                 const float* __restrict__ box_last, const float* __restrict__ angle_last, const float beta,
+                                                 float* __restrict__ box_out /* [6] */, float* __restrict__ idx_out /* [1] */) {
+  for (int j = 0; j < 6; ++j) box_out[j] = lastrow ? box_last[6 * room + j] : boxes_pred[6 * i + j];
+  if (lastrow) { idx_out[0] = angle_last[room]; return; }
+  const float* a = angles_pred + (size_t)i * na;
+  float m = -INFINITY;
+  for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
+  float den = 0.f, num = 0.f;
+  for (int j = 0; j < na; ++j) { const float e = expf(a[j] * beta - m); den += e; num += e * (float)(j + 1); }
+  idx_out[0] = num / den - 1.0f + (noise ? noise[i] / 10.0f : 0.f);
+}
 __global__ void refine_head_forward_kernel(int n, int na, const float* __restrict__ boxes_pred, const float* __restrict__ angles_pred,
                                            const float* __restrict__ noise, const float* __restrict__ box_last,
                                            const float* __restrict__ angle_last, float beta, float* __restrict__ boxes_full,
@@ -240,26 +292,15 @@ __global__ void refine_head_forward_kernel(int n, int na, const float* __restric
   if (i >= n) return;
   const int room = room_of_row ? room_of_row[i] : 0;
   const bool lastrow = i == (room_of_row ? last_row[room] : n - 1);
-  for (int j = 0; j < 6; ++j) boxes_full[6 * i + j] = lastrow ? box_last[6 * room + j] : boxes_pred[6 * i + j];
-  if (lastrow) { idx[i] = angle_last[room]; return; }
-  const float* a = angles_pred + (size_t)i * na;
-  float m = -INFINITY;
-  for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
-  float den = 0.f, num = 0.f;
-  for (int j = 0; j < na; ++j) { const float e = expf(a[j] * beta - m); den += e; num += e * (float)(j + 1); }
-  idx[i] = num / den - 1.0f + (noise ? noise[i] / 10.0f : 0.f);
+  head_forward_row(i, room, lastrow, na, boxes_pred, angles_pred, noise, box_last, angle_last, beta, boxes_full + 6 * i, idx + i);
 }
 // backward, with the two gradient hooks of the reference folded in: quad_grad (x4 on d idx, :226-228) and fix_grad (both halves of a
 // box row receive the mean of the two halves' gradients, :217-224); the frozen last row receives zeros.
-__global__ void refine_head_backward_kernel(int n, int na, const float* __restrict__ angles_pred, const float* __restrict__ g_boxes_full,
-                                            const float* __restrict__ g_idx, float beta, float* __restrict__ g_boxes_pred,
-                                            float* __restrict__ g_angles_pred, const int* __restrict__ room_of_row,
-                                            const int* __restrict__ last_row, const int ld_gb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const bool lastrow = i == (room_of_row ? last_row[room_of_row[i]] : n - 1);
+__device__ __forceinline__ void head_backward_row(const int i, const bool lastrow, const int na, const float* __restrict__ angles_pred,
+                                                  const float* __restrict__ g_box_row /* [6] */, const float g_idx_row, const float beta,
+                                                  float* __restrict__ g_boxes_pred, float* __restrict__ g_angles_pred, const int ld_gb) {
   for (int j = 0; j < 3; ++j) {
-    const float avg = lastrow ? 0.f : g_boxes_full[6 * i + 3 + j] / 2.0f + g_boxes_full[6 * i + j] / 2.0f;
+    const float avg = lastrow ? 0.f : g_box_row[3 + j] / 2.0f + g_box_row[j] / 2.0f;
     g_boxes_pred[(size_t)ld_gb * i + j] = avg; g_boxes_pred[(size_t)ld_gb * i + 3 + j] = avg;
   }
   for (int j = 6; j < ld_gb; ++j) g_boxes_pred[(size_t)ld_gb * i + j] = 0.f;
@@ -270,9 +311,18 @@ __global__ void refine_head_backward_kernel(int n, int na, const float* __restri
   for (int j = 0; j < na; ++j) m = fmaxf(m, a[j] * beta);
   float den = 0.f, num = 0.f;
   for (int j = 0; j < na; ++j) { const float e = expf(a[j] * beta - m); den += e; num += e * (float)(j + 1); }
-  const float ev = num / den, g = g_idx[i] * 4.0f;
+  const float ev = num / den, g = g_idx_row * 4.0f;
   // d idx / d a_j = beta p_j ((j + 1) - E[j + 1])
   for (int j = 0; j < na; ++j) ga[j] = g * beta * (expf(a[j] * beta - m) / den) * ((float)(j + 1) - ev);
+}
+__global__ void refine_head_backward_kernel(int n, int na, const float* __restrict__ angles_pred, const float* __restrict__ g_boxes_full,
+                                            const float* __restrict__ g_idx, float beta, float* __restrict__ g_boxes_pred,
+                                            float* __restrict__ g_angles_pred, const int* __restrict__ room_of_row,
+                                            const int* __restrict__ last_row, const int ld_gb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool lastrow = i == (room_of_row ? last_row[room_of_row[i]] : n - 1);
+  head_backward_row(i, lastrow, na, angles_pred, g_boxes_full + 6 * i, g_idx[i], beta, g_boxes_pred, g_angles_pred, ld_gb);
 }
 // p -= step * g, g = 0 (the next backward accumulates into it) and z -= step_z * gz in one launch: the closed form of the
 // reference's per-iteration SGD(momentum = 0.1, nesterov) on a fresh optimizer (:286-292: step = lr * 1.1)

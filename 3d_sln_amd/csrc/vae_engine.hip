@@ -1760,6 +1760,7 @@ struct SlnVaeGroup {
       for (size_t s = 0; s < n; ++s) if (recs[r].steps[s].kind != recs[0].steps[s].kind) return SLN_E_UNSUPPORTED;
     }
     std::vector<GemmTNArgs> pend;
+    int n_flush = 0;
     for (size_t s = 0; s < n; ++s) {
       const int kind = recs[0].steps[s].kind;
       if (kind == SK_TN) {
@@ -1781,7 +1782,14 @@ struct SlnVaeGroup {
         }
         continue;
       }
-      if (kind == SK_TN_FLUSH) { RET_IF(flush_tn(prog, pend)); continue; }
+      if (kind == SK_TN_FLUSH) {
+        // lab: SLN_GROUP_FLUSH_EVERY=n hands the wgrads to the side stream at every n-th marker only (fewer forks, later wgrads)
+        static const int every = std::getenv("SLN_GROUP_FLUSH_EVERY") ? std::max(1, std::atoi(std::getenv("SLN_GROUP_FLUSH_EVERY"))) : 1;
+        bool last = true;
+        for (size_t s2 = s + 1; s2 < n; ++s2) if (recs[0].steps[s2].kind == SK_TN) { last = false; break; }
+        if (last || ++n_flush % every == 0) RET_IF(flush_tn(prog, pend));
+        continue;
+      }
       // rooms whose block plans to the same variant share a launch
       std::vector<int> var(R, -1), gxs(R, 0), gys(R, 0), smf(R, 0);
       std::vector<RecStep> blk(R);

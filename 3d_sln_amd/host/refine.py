@@ -681,6 +681,10 @@ class RefineBatch:
         self.size_loss = torch.zeros(R, **f32)
         self.g_size_loss = torch.full((1,), 2.0, **f32)               # loss = ... + 2 * size_loss (test_render_refine.py:350-352)
         self._size_targets = size_targets
+        # the soft-argmax / noise / frozen-row glue inside the two placement launches (SlnPlacementRoom's head fields; the noise of
+        # iteration k is row k of noise_all, k a device counter the backward launch advances)
+        self._fused_head = max(self.rows) <= 128 and not os.environ.get("SLN_REFINE_SEPARATE_HEAD")
+        self._noise_step = torch.zeros(1, dtype=torch.int32, device=dev)
         tab = (_lib.SlnPlacementRoom * R)()
         for r, sc in enumerate(scenes):
             cls[r, :2 * sc.desc.F] = sc.cls2[0]
@@ -691,6 +695,12 @@ class RefineBatch:
             e.faces_out, e.sizes, e.size_loss = self.faces[r].data_ptr(), self.sizes[r].data_ptr(), self.size_loss.data_ptr() + 4 * r
             e.grad_faces, e.grad_size_loss = self.g_faces[r].data_ptr(), self.g_size_loss.data_ptr()
             e.grad_boxes, e.grad_angles = self.g_boxes.data_ptr() + 24 * a, self.g_idx.data_ptr() + 4 * a
+            if self._fused_head:
+                e.boxes_pred, e.angles_pred = self.boxes_pred.data_ptr() + 24 * a, self.angles_pred.data_ptr() + 4 * na * a
+                e.noise, e.noise_step, e.noise_stride = self.noise_all.data_ptr() + 4 * a, self._noise_step.data_ptr(), N
+                e.box_last, e.angle_last = self.box_last.data_ptr() + 24 * r, self.angle_last.data_ptr() + 4 * r
+                e.grad_boxes_pred, e.grad_angles_pred = self.d_boxes_pred.data_ptr() + 32 * a, self.d_angles_pred.data_ptr() + 4 * na * a
+                e.n_angle, e.ld_gb, e.beta = na, 8, 2.0
         self._place_tab = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(dev)
         self.cls = cls
         self.chan, self.dch = scenes[0].chan, scenes[0].dch
@@ -749,8 +759,10 @@ class RefineBatch:
         L, st, P = _lib.lib(), _lib.current_stream_ptr(), _lib.ptr
         N, R, na, S = self.N, self.R, self.model.Nangle, self.S
         _lib.check(L.sln_vae_group_decoder(self._group, st), "sln_vae_group_decoder")
-        _lib.check(L.sln_refine_head_forward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.boxes_pred), P(self.angles_pred), P(noise),
-                                                   P(self.box_last), P(self.angle_last), 2.0, P(self.boxes), P(self.idx), st), "sln_refine_head_forward_rooms")
+        if not self._fused_head:
+            _lib.check(L.sln_refine_head_forward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.boxes_pred), P(self.angles_pred), P(noise),
+                                                       P(self.box_last), P(self.angle_last), 2.0, P(self.boxes), P(self.idx), st),
+                       "sln_refine_head_forward_rooms")
         _lib.check(L.sln_place_forward_rooms(P(self._place_tab), R, self.F2 // 2, st), "sln_place_forward_rooms")
         rl = self.loss
         if rl.desc.live_planes:
@@ -766,8 +778,9 @@ class RefineBatch:
         _lib.check(L.sln_scene_backward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 1e-3, P(self.scene_ws),
                                         P(self.g_image), P(self.g_faces), st), "sln_scene_backward")
         _lib.check(L.sln_place_backward_rooms(P(self._place_tab), R, self.n_max, st), "sln_place_backward_rooms")
-        _lib.check(L.sln_refine_head_backward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.angles_pred), P(self.g_boxes), P(self.g_idx), 2.0,
-                                                    P(self.d_boxes_pred), 8, P(self.d_angles_pred), st), "sln_refine_head_backward_rooms")
+        if not self._fused_head:
+            _lib.check(L.sln_refine_head_backward_rooms(N, na, P(self.room_of_row), P(self.last_row), P(self.angles_pred), P(self.g_boxes), P(self.g_idx),
+                                                        2.0, P(self.d_boxes_pred), 8, P(self.d_angles_pred), st), "sln_refine_head_backward_rooms")
         _lib.check(L.sln_vae_group_decoder_backward(self._group, st), "sln_vae_group_decoder_backward")
         _lib.check(L.sln_refine_sgd_rooms(P(self.params), P(self.grads), R, self.params.shape[1], self._sgd_off, self._sgd_len, self._n_rg,
                                           (self.lr / 10.0) * 1.1, P(self.z), P(self.dz), self.z.numel(), 2e-4 * 1.1, st), "sln_refine_sgd_rooms")
@@ -781,7 +794,8 @@ class RefineBatch:
         for _ in range(n):
             k = self.k
             if capture:
-                self.noise.copy_(self.noise_all[k])
+                if not self._fused_head:
+                    self.noise.copy_(self.noise_all[k])
                 if self._graph is None:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())

@@ -763,19 +763,22 @@ def refine_leg(args, lib, torch):
             torch.cuda.synchronize(); t2 = time.perf_counter()
             runs.append((n_it, t1 - t0, t2 - t1))
             info, fin = rb.launches(), bool(torch.isfinite(rb.losses).all().item())
+            lv = rb.live.cpu()
+            n3, n1 = float((lv == 3).sum()) / nr, float((lv == 1).sum()) / nr     # planes per room: written and read / known constant
             rb.close()
         a_ = sorted(x[2] for x in runs if x[0] == iters)[1]; b_ = sorted(x[2] for x in runs if x[0] == 2 * iters)[1]
         it_ms = (b_ - a_) / iters * 1e3
         plane = 256.0 * 256.0 * 4.0
         dec_bytes = 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
-        # algorithmic HBM bytes of one room-iteration: the 70-plane scene tensor written, read by the pooling, its gradient written
-        # and read by the scene backward; the pooled tensor (4 scales x 69 planes of 96 x 96) written, read, its gradient written,
-        # read; the decoder's parameters read by the forward Linears, transposed (read + write), read by the dgrads, their
-        # gradient written by the wgrads, and the SGD update (read p, g; write p, g)
-        algo = 4 * 70 * plane + 4 * (4 * 69 * 96 * 96 * 4.0) + 9 * dec_bytes
+        # algorithmic HBM bytes of one room-iteration: the LIVE planes of the 70-plane scene tensor (channel 0 and the planes of the
+        # classes visible in the room: n3 of 70, measured on the last iteration) written, read by the pooling, their gradient
+        # written and read by the scene backward; the pooled tensor (4 scales x (n3 - 1 live + n1 constant) planes of 96 x 96)
+        # written, read, its gradient written, read; the decoder's parameters read by the forward Linears, transposed (read +
+        # write), read by the dgrads, and stepped in the wgrads' epilogue (read + write)
+        algo = 4 * n3 * plane + 4 * (4 * (n3 - 1 + n1) * 96 * 96 * 4.0) + 6 * dec_bytes
         batch = {"rooms": nr, "ms_per_iteration": round(it_ms, 3), "ms_per_room_iteration": round(it_ms / nr, 4),
                  "ms_setup_per_room": round(sorted(x[1] for x in runs)[len(runs) // 2] * 1e3 / nr, 2), "iterations": iters, "finite": fin,
-                 "launches": info, "speedup_vs_one_room_at_a_time": round(per_iter * 1e3 / (it_ms / nr), 2),
+                 "launches": info, "live_planes_per_room": round(n3, 1), "constant_planes_per_room": round(n1, 1), "speedup_vs_one_room_at_a_time": round(per_iter * 1e3 / (it_ms / nr), 2),
                  "roofline": {"kernel": "one refinement iteration of %d rooms (all launches)" % nr, "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                               "algorithmic_bytes_per_room_iteration": int(algo), "achieved": round(algo * nr / (it_ms * 1e-3) / 1e9, 1),
                               "frac": round(algo * nr / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}}

@@ -403,6 +403,15 @@ typedef struct {
   const float* boxes; const float* angles; const float* size_target;      /* [n,6], [n], [n_vis,3] or NULL */
   float* faces_out; float* sizes; float* size_loss;                        /* [2F,3,3], [n_vis,3], [1] */
   const float* grad_faces; const float* grad_size_loss; float* grad_boxes; float* grad_angles;   /* backward */
+  /* optional head (boxes_pred != NULL; needs P.n <= 128): the two placement launches then do sln_refine_head_forward / _backward of
+   * the room themselves - forward derives `boxes` / `angles` from the decoder's outputs (and stores them there), backward turns
+   * grad_boxes / grad_angles into the gradients of the decoder's outputs - with the stand-alone kernels' arithmetic */
+  const float* boxes_pred; const float* angles_pred; const float* noise;     /* [n,6], [n,n_angle] log-softmax, [n] or NULL */
+  int* noise_step; int64_t noise_stride;                                      /* optional device counter k: forward reads noise + k * noise_stride,
+                                                                               * backward (room 0 of the launch) advances it by one */
+  const float* box_last; const float* angle_last;                             /* [6], [1]: the frozen last row */
+  float* grad_boxes_pred; float* grad_angles_pred;                            /* [n,ld_gb], [n,n_angle] */
+  int n_angle, ld_gb; float beta; int pad_;
 } SlnPlacementRoom;
 int sln_place_forward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int F_max, void* stream);
 int sln_place_backward_rooms(const SlnPlacementRoom* rooms /* device */, int R, int n_max, void* stream);

@@ -36,19 +36,22 @@ def main():
         bank = R.MeshBank(names, "cuda", seed=3)
         with torch.cuda.stream(st):
             for capture in (False, True):
-                res = []
+                res = []; enq = []
                 for n_it in (iters, 2 * iters, iters, 2 * iters, iters, 2 * iters):
                     torch.cuda.synchronize(); t0 = time.perf_counter()
                     G = int(os.environ.get("GROUPS", "1"))
                     rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it) if G <= 1 else R.RefineBatches(model, rooms, groups=G, bank=bank, iters=n_it)
                     torch.cuda.synchronize(); t1 = time.perf_counter()
                     rb.run(capture=capture)
+                    t_enq = time.perf_counter() - t1                  # host time to enqueue everything (the GPU may still be running)
                     torch.cuda.synchronize(); t2 = time.perf_counter()
+                    enq.append(t_enq / n_it)
                     res.append((n_it, t1 - t0, t2 - t1)); info = rb.launches(); fin = bool(torch.isfinite(rb.losses).all()); rb.close()
                 a = sorted(x[2] for x in res if x[0] == iters)[1]; b = sorted(x[2] for x in res if x[0] == 2 * iters)[1]
                 setup = sorted(x[1] for x in res)[len(res) // 2]
                 print("rooms %2d %s: %.3f ms / iteration (%.4f per room-iteration), run-intercept %.2f ms, set-up %.2f ms per room, %s, finite %s"
                       % (nr, "graph" if capture else "eager", (b - a) / iters * 1e3, (b - a) / iters * 1e3 / nr, (a - (b - a)) * 1e3, setup * 1e3 / nr, info, fin), flush=True)
+                print("   host enqueue time per iteration: %.3f ms (min over runs)" % (min(enq) * 1e3), flush=True)
 
 
 if __name__ == "__main__":
