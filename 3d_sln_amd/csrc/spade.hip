@@ -1075,7 +1075,35 @@ __global__ __launch_bounds__(256) void conv_img_kernel(const float* __restrict__
   float acc[COUT];
 #pragma unroll
   for (int co = 0; co < COUT; ++co) acc[co] = 0.f;
+  // Where a thread's NF halo elements of a chunk come from does not depend on the chunk: the offsets (relative to the chunk's first
+  // channel plane, -1 outside the image) are worked out once.  (Round 5: the two divisions and the bounds tests per element, every
+  // chunk, were ~500 of the ~1 300 instructions a thread issues per chunk - the 25 LDS reads and 75 FMAs of a channel are 800 per
+  // chunk.)  The element's LDS slot is its running index e.
+  constexpr int NF = (ICK * IH * IH + 255) / 256;
+  const bool fast = Cin % ICK == 0 && (long)ICK * plane < (1L << 31);
+  int goff[NF];
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      const int c = e / (IH * IH), p = e % (IH * IH);
+      const int sy = ty0 + p / IH - 2, sx = tx0 + p % IH - 2;
+      goff[k] = (e < ICK * IH * IH && sy >= 0 && sy < H && sx >= 0 && sx < W) ? c * (int)plane + sy * W + sx : -1;
+    }
+  }
+  float* hflat = &halo[0][0];
   for (int c0 = 0; c0 < Cin; c0 += ICK) {
+    if (fast) {
+      const float* xc = x + ((size_t)b * Cin + c0) * plane;
+      float v[NF];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) v[k] = goff[k] >= 0 ? xc[goff[k]] : 0.f;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < ICK * IH * IH) hflat[e] = v[k] > 0.f ? v[k] : 0.2f * v[k];
+      }
+    } else
     for (int e = threadIdx.x; e < ICK * IH * IH; e += 256) {
       const int c = e / (IH * IH), p = e % (IH * IH);
       const int sy = ty0 + p / IH - 2, sx = tx0 + p % IH - 2;

@@ -170,3 +170,35 @@ def spade_input(batch, crop=256, semantic_nc=41, nz=256, seed=0):
         segs.append(torch.cat([depth, onehot], 1))
         zs.append(torch.from_numpy(rng.standard_normal((1, nz)).astype(np.float32)))
     return torch.cat(segs).contiguous(), torch.cat(zs).contiguous()
+
+
+def overfit_to_rooms(model, rooms, steps=400, lr=2e-3, kl_weight=1e-3, settle=80):
+    """``steps`` fused Adam steps of the VAE on the collated batch of ``rooms`` (dicts as ``refine.RefineBatch`` takes them: object
+    rows room-normalised, last row the room's metric box - the encoder sees that row in training and in refinement alike).  Afterwards the decoder places every room's objects near their targets -
+    what a trained checkpoint does (testing/test_render_refine.py:250-263 reloads one per trial) - so that a refinement benchmark
+    renders the furniture: a randomly initialised decoder predicts near-degenerate boxes and the iterate shows the empty room.
+    The refinement evaluates BatchNorm on its RUNNING statistics (model.eval()): ``settle`` more steps with lr = 0 let them converge
+    to the final weights' batch statistics (after 400 steps at 2e-3 the 10-step moving averages lag the weights, and five stacked
+    gconv layers amplify the mismatch: boxes of magnitude 1e2..1e5 in eval mode with a train-mode loss of 0.03).
+    Returns the last step's losses [bbox, angle, KL, total] (device tensor)."""
+    import torch
+    objs, triples, boxes, angles, attrs, off = [], [], [], [], [], 0
+    for rm in rooms:
+        n = int(rm["objs"].shape[0])
+        nb = rm["boxes"].detach().clone().float()        # as the dataset hands them out (data/suncg_dataset.py:113-143): object rows
+        #                                                   room-normalised, the room row [0, 0, 0, W, H, D] in metres - the refinement
+        #                                                   feeds the encoder the same rows (test_render_refine.py:273)
+        t = rm["triples"].clone()
+        t[:, 0] += off; t[:, 2] += off
+        objs.append(rm["objs"]); triples.append(t); boxes.append(nb); angles.append(rm["angles"].long()); attrs.append(rm["attributes"])
+        off += n
+    objs, triples, boxes, angles, attrs = (torch.cat(x) for x in (objs, triples, boxes, angles, attrs))
+    was_training = model.training
+    model.train()
+    losses = None
+    for _ in range(int(steps)):
+        losses = model.train_step(objs, triples, boxes, angles, attrs, kl_weight=kl_weight, lr=lr, use_graph=False)
+    for _ in range(int(settle) if steps > 0 else 0):
+        losses = model.train_step(objs, triples, boxes, angles, attrs, kl_weight=kl_weight, lr=0.0, use_graph=False)
+    model.train(was_training)
+    return losses

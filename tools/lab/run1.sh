@@ -1,2 +1,3 @@
 cd /root/repo
-timeout 300 python tools/refine_batch_time.py 16,64 2>&1 | tail -8 | cut -c1-100
+SLN_BENCH_DEBUG=1 timeout 1500 python bench.py > gpurun_out/bench_now.json 2> gpurun_out/bench_now.err; echo bench rc=$?
+grep "refine debug" gpurun_out/bench_now.err | tail -2

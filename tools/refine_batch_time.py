@@ -31,6 +31,10 @@ def main():
     model = M.Sg2ScVAEModel(vocab=syn.default_vocab(), batch_size=1, train_3d=True, decoder_cat=True, embedding_dim=64, gconv_mode='feedforward',
                             gconv_num_layers=5, mlp_normalization='batch', vec_noise_dim=0, layout_noise_dim=32, use_AE=False).cuda().eval()
     st = torch.cuda.Stream()
+    if not os.environ.get("NO_OVERFIT"):           # a trained checkpoint places the furniture in view; a random decoder renders the empty room
+        with torch.cuda.stream(st):
+            l = syn.overfit_to_rooms(model, bench_rooms(64)[0], steps=int(os.environ.get("OVERFIT_STEPS", "400")))
+        print("over-fitted to 64 rooms: losses [bbox, angle, KL, total] =", [round(float(x), 4) for x in l], flush=True)
     for nr in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "1,4,16").split(",")]:
         rooms, names = bench_rooms(nr)
         bank = R.MeshBank(names, "cuda", seed=3)
@@ -46,12 +50,13 @@ def main():
                     t_enq = time.perf_counter() - t1                  # host time to enqueue everything (the GPU may still be running)
                     torch.cuda.synchronize(); t2 = time.perf_counter()
                     enq.append(t_enq / n_it)
+                    lv = rb.live.cpu(); live = (float((lv == 3).sum()) / nr, float((lv == 1).sum()) / nr)
                     res.append((n_it, t1 - t0, t2 - t1)); info = rb.launches(); fin = bool(torch.isfinite(rb.losses).all()); rb.close()
                 a = sorted(x[2] for x in res if x[0] == iters)[1]; b = sorted(x[2] for x in res if x[0] == 2 * iters)[1]
                 setup = sorted(x[1] for x in res)[len(res) // 2]
                 print("rooms %2d %s: %.3f ms / iteration (%.4f per room-iteration), run-intercept %.2f ms, set-up %.2f ms per room, %s, finite %s"
                       % (nr, "graph" if capture else "eager", (b - a) / iters * 1e3, (b - a) / iters * 1e3 / nr, (a - (b - a)) * 1e3, setup * 1e3 / nr, info, fin), flush=True)
-                print("   host enqueue time per iteration: %.3f ms (min over runs)" % (min(enq) * 1e3), flush=True)
+                print("   host enqueue time per iteration: %.3f ms (min over runs); planes per room: %.1f live, %.1f constant" % (min(enq) * 1e3, live[0], live[1]), flush=True)
 
 
 if __name__ == "__main__":
