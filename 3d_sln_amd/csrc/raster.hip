@@ -1304,12 +1304,11 @@ __global__ __launch_bounds__(256) void scene_bwd_masked_sums_kernel(const int32_
 }
 
 // per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
-__global__ __launch_bounds__(256) void scene_bwd_maps_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
-                                                             const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
-                                                             const float* __restrict__ gout, int F, int is, int NC, int nch,
-                                                             PixRec* __restrict__ rec, PixRec* __restrict__ recT) {
-  __shared__ PixRec tile[32][33];
-  const int b = blockIdx.z, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+__device__ __forceinline__ void scene_bwd_maps_body(const int b, PixRec (*tile)[33], const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                    const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
+                                                    const float* __restrict__ gout, int F, int is, int NC, int nch,
+                                                    PixRec* __restrict__ rec, PixRec* __restrict__ recT) {
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   const long plane = (long)is * is;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8) {
@@ -1335,11 +1334,10 @@ __global__ __launch_bounds__(256) void scene_bwd_maps_kernel(const int32_t* __re
 }
 
 // g[b,c,y,x] = d final[b, 1+chan[c], flip(y), x] / 3  and its transpose
-__global__ __launch_bounds__(256) void scene_bwd_grad_planes_kernel(const float* __restrict__ gout, const int32_t* __restrict__ chan,
-                                                                    int is, int NC, int nch, const SceneStats* __restrict__ st,
-                                                                    float* __restrict__ g, float* __restrict__ gT) {
-  __shared__ float t[32][33];
-  const int bc = blockIdx.z, b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+__device__ __forceinline__ void scene_bwd_grad_planes_body(const int bc, float (*t)[33], const float* __restrict__ gout, const int32_t* __restrict__ chan,
+                                                           int is, int NC, int nch, const SceneStats* __restrict__ st,
+                                                           float* __restrict__ g, float* __restrict__ gT) {
+  const int b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   // a plane is only ever read for the class of a VISIBLE pixel (the reference pixel of a scan): classes without a single
   // visible pixel in this image (typically half of the 32) are skipped
   if (!(st[b].cnt[c] > 0.0)) return;
@@ -1357,6 +1355,19 @@ __global__ __launch_bounds__(256) void scene_bwd_grad_planes_kernel(const float*
     const int x = x0 + r, y = y0 + tx;
     if (x < is && y < is) gT[(long)bc * plane + (long)x * is + y] = t[tx][r];
   }
+}
+// Both tables the edge scans read - the per-pixel records and the class-gradient planes, each with its transpose - in ONE launch
+// (blockIdx.z < B: records of image z; above: plane (b, c) = z - B).  Round 5: they were two launches on two streams with an event
+// between them and the scan kernel; the scan kernel (the longest of the pass, on the critical path) started ~40 us after the
+// records were done - the planes' launch began a fork later and the event took another ~13 us to arrive.
+__global__ __launch_bounds__(256) void scene_bwd_tables_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+                                                               const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
+                                                               const float* __restrict__ gout, int B, int F, int is, int NC, int nch,
+                                                               const SceneStats* __restrict__ st, PixRec* __restrict__ rec,
+                                                               PixRec* __restrict__ recT, float* __restrict__ g, float* __restrict__ gT) {
+  __shared__ PixRec tile[32][33];
+  if ((int)blockIdx.z < B) scene_bwd_maps_body(blockIdx.z, tile, fi_b, val, cls, chan, gout, F, is, NC, nch, rec, recT);
+  else scene_bwd_grad_planes_body(blockIdx.z - B, reinterpret_cast<float (*)[33]>(&tile[0][0]), gout, chan, is, NC, nch, st, g, gT);
 }
 
 // d(loss)/d(raw depth map of the depth pass), unflipped [B,is,is]
@@ -1482,7 +1493,7 @@ int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B,
 // Bit 1: sln_scene_backward reads the plane's incoming gradient (clear: it never does).
 //   channel 0, the last depth-hot channel (the loss fills it where no class has depth): 3
 //   semantic channel 1 + k: 3 when the class mapped to NYU index k has a visible pixel in image b, else 0 - the plane is zeros
-//     and scene_bwd_grad_planes_kernel skips it
+//     and scene_bwd_grad_planes_body skips it
 //   depth-hot channel 41 + k: 3 when its class has a visible pixel; 1 when it has none - the plane is the constant 1
 //     (scene_fill_table: mean / wall_max with the mean replaced by wall_max) and its gradient only enters gsum[owner], which
 //     scene_bwd_depthgrad_kernel uses at the class's own pixels; 0 when no class owns the channel
@@ -1522,10 +1533,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // Two independent chains add into grad_faces: the depth channel's (gradient sums -> depth-map gradient -> per-face walk,
   // five launches, ~0.12 ms per 16 rooms) and the class planes' (packed records, gradient planes, edge scans: ~0.25 ms, bound by
   // instruction issue and by the number of WORKING wavefronts).  The depth chain runs on a side stream next to the class
-  // chain; in a stream capture the event edges become graph dependencies (fork / join inside this call).  The side stream
-  // also takes the two launches the edge scans need but the record pass does not - the zero-fill of the face gradient and the
-  // gradient planes - in front of the depth chain: the caller's stream runs the record pass meanwhile and waits (`mid`) before
-  // the scans.
+  // chain; in a stream capture the event edges become graph dependencies (fork / join inside this call).
   // Batches only: with one room (the refinement loop, a captured iteration of ~240 small launches) the three event edges cost
   // more than the overlap returns - 1.37 ms per iteration with the side stream, 1.22 ms without (same-box A/B).
   // Deterministic mode (SLN_DETERMINISTIC): ONE stream, no split units, the depth walk BEHIND the edge scans - every face-gradient
@@ -1539,6 +1547,16 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // used to leave the side stream un-joined - work on grad_faces still in flight, and an active stream capture invalidated.
   static std::mutex side_mu;
   std::unique_lock<std::mutex> side_lock(side_mu, std::defer_lock);
+  // (round 5) what BOTH chains wait for runs first, on the caller's stream: the zero-fill of the face gradient and the one launch
+  // that builds the scan kernel's tables (records + gradient planes); the fork comes behind it, and the scan kernel - the longest
+  // launch of the pass - starts as soon as its tables exist instead of a fork and an event later (see scene_bwd_tables_kernel)
+  const int t32 = sln_cdiv(is, 32);
+  {
+    const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(scene_bwd_tables_kernel, dim3(t32, t32, B + B * num_classes), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel,
+                       grad_final, B, F, is, num_classes, 70, w.st, w.prec, w.precT, w.g, w.gT);
+  }
   hipStream_t sd_st = st;
   if (sd != nullptr) {
     side_lock.lock();
@@ -1555,12 +1573,6 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
     }
     ~Join() { run(); }
   } join{sd, st, hipSuccess};
-  const int t32 = sln_cdiv(is, 32);
-  const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, sd_st);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(scene_bwd_grad_planes_kernel, dim3(t32, t32, B * num_classes), dim3(256), 0, sd_st, grad_final, class_channel, is,
-                     num_classes, 70, w.st, w.g, w.gT);
-  if (sd != nullptr && hipEventRecord(sd->mid, sd->stream) != hipSuccess) return SLN_E_STATE;
   hipLaunchKernelGGL(scene_zero_gsum_kernel, dim3(sln_cdiv(B * 64, 256)), dim3(256), 0, sd_st, w.st, B);
   hipLaunchKernelGGL(scene_bwd_plane_sums_kernel, dim3(det ? 1 : 8, 70 - 41, B), dim3(256), 0, sd_st, class_depth_channel, is, num_classes, 70, grad_final,
                      w.st);
@@ -1575,9 +1587,6 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   if (!det)
     hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, depth_bwd_split(n, F)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
                        grad_faces);
-  hipLaunchKernelGGL(scene_bwd_maps_kernel, dim3(t32, t32, B), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel, grad_final, F, is,
-                     num_classes, 70, w.prec, w.precT);
-  if (sd != nullptr && hipStreamWaitEvent(st, sd->mid, 0) != hipSuccess) return SLN_E_STATE;
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
   hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, det ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
                      grad_faces, (const FaceRec*)w.rec);

@@ -571,17 +571,20 @@ def render_leg(args, lib, torch, rank):
     # ONE-STREAM trace (profiles/<tag>_render_noside_kernel_stats.csv: with the side stream the durations of the two chains overlap)
     plane_b = 256.0 * 256.0 * 4.0
     live_planes = float((out[:, 1:41] > 0).flatten(2).any(2).sum().item())     # class planes with a visible pixel (the others are skipped)
+    live_depth = float(((out[:, 41:] != 1.0) & (out[:, 41:] != 0.0)).flatten(2).any(2).sum().item())   # depth-hot planes that are not a constant
     stream_bytes = {"scene_compose_kernel": args.rooms * (70 * plane_b + 3 * plane_b),                       # 70 planes written, 3 maps read
-                    "scene_bwd_plane_sums_kernel": args.rooms * 29 * plane_b,                               # the depth-hot gradient planes, read
-                    "scene_bwd_grad_planes_kernel": live_planes * plane_b * 3,                              # the live class planes: read once, g and g^T written
-                    "scene_bwd_maps_kernel": args.rooms * (plane_b * 3 + 2 * 4 * plane_b)}                  # maps + own-class gradient read, two 16-byte records written
+                    "scene_bwd_plane_sums_kernel": live_depth * plane_b,                                     # the depth-hot gradient planes of visible classes, read
+                    # one launch since round 5: the live class planes read once, g and g^T written; the three per-pixel maps + the
+                    # own-class gradient read, two 16-byte records per pixel written
+                    "scene_bwd_tables_kernel": live_planes * plane_b * 3 + args.rooms * (plane_b * 3 + 2 * 4 * plane_b)}
     for kname, nbytes in stream_bytes.items():
         _, us = profile_rows([kname], "render_noside")
         res["roofline_kernels"][kname] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "avg_launch_us": us,
                                           "algorithmic_bytes_per_launch": int(nbytes),
                                           "achieved": round(nbytes / (us * 1e-6) / 1e9, 1) if us else None,
                                           "frac": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us else None, "traffic": None}
-    res["roofline_kernels"]["scene_bwd_grad_planes_kernel"]["note"] = "%d live class planes in the batch (planes of classes without a visible pixel are skipped)" % int(live_planes)
+    res["roofline_kernels"]["scene_bwd_tables_kernel"]["note"] = "%d live class planes in the batch (planes of classes without a visible pixel are skipped)" % int(live_planes)
+    res["roofline_kernels"]["scene_bwd_plane_sums_kernel"]["note"] = "%d depth-hot planes of visible classes (the others are skipped since round 5)" % int(live_depth)
     if not args.no_dropin:
         res["render_33pass"] = render_33pass_leg(args, torch, per_render * 1e3)
     if not args.no_cpu:
