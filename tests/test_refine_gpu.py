@@ -424,6 +424,10 @@ def test_fused_head_and_update_match_the_torch_expressions():
 
 
 # ----------------------------------------------------------------------------- R rooms in flight (round 5)
+def sd_flat(model):
+    return model.flat_params.detach().cpu().numpy()
+
+
 FURN = ["bed", "chair", "table", "sofa", "desk", "cabinet", "lamp", "television", "bookshelf", "dresser", "night_stand", "shelves"]
 
 
@@ -495,6 +499,15 @@ def test_rooms_in_flight_equal_the_one_room_loop(which, monkeypatch):
             monkeypatch.setenv("SLN_REFINE_ALL_PLANES", "1")
             every_plane = run(range(16))
             monkeypatch.delenv("SLN_REFINE_ALL_PLANES")
+            # the head glue as its own two launches instead of inside the placement launches: the same arithmetic, the same bits
+            monkeypatch.setenv("SLN_REFINE_SEPARATE_HEAD", "1")
+            separate_head = run(range(16))
+            monkeypatch.delenv("SLN_REFINE_SEPARATE_HEAD")
+            # the stand-alone SGD step over gradient buffers instead of the step in the wgrads' epilogue: p - step * g as one FMA
+            # against -step * g rounded and then added - the last bit of an update, 1e-6 of a parameter after four steps
+            monkeypatch.setenv("SLN_REFINE_SEPARATE_SGD", "1")
+            separate_sgd = run(range(16))
+            monkeypatch.delenv("SLN_REFINE_SEPARATE_SGD")
         torch.cuda.synchronize()
     finally:
         L.sln_set_deterministic(0)
@@ -503,7 +516,7 @@ def test_rooms_in_flight_equal_the_one_room_loop(which, monkeypatch):
     moved = sum(len(set(full["losses"][:, r].tolist())) > 1 for r in range(16))
     assert moved >= 12, "only %d of 16 rooms saw a gradient" % moved
     for name, other, sel in [("repeat", again, list(range(16))), ("R=3", three, [4, 9, 15]), ("graph", graph, list(range(16))),
-                             ("every plane", every_plane, list(range(16)))] + \
+                             ("every plane", every_plane, list(range(16))), ("separate head launches", separate_head, list(range(16)))] + \
                             [("R=1 room %d" % r, o, [r]) for r, o in ones.items()]:
         for j, r in enumerate(sel):
             assert np.array_equal(other["losses"][:, j], full["losses"][:, r]), "%s: losses of room %d" % (name, r)
@@ -512,6 +525,9 @@ def test_rooms_in_flight_equal_the_one_room_loop(which, monkeypatch):
             b = other["row0"][j]
             assert np.array_equal(other["z"][b:b + n], full["z"][a:a + n]), "%s: z of room %d" % (name, r)
             assert np.array_equal(other["params"][j], full["params"][r]), "%s: parameters of room %d" % (name, r)
+    assert_close(separate_sgd["losses"], full["losses"], "losses, stand-alone SGD step", rtol=1e-5)
+    assert_close(separate_sgd["params"], full["params"], "parameters, stand-alone SGD step", rtol=1e-5, atol=1e-7)
+    assert not np.array_equal(separate_sgd["params"], sd_flat(model)[None].repeat(16, 0)), "the parameters moved"
     # default mode against the autograd-based one-room loop on its own copy of the checkpoint
     M = pkg("host.Sg2ScVAE_model")
     st = torch.cuda.Stream()
