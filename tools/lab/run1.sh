@@ -1,3 +1,4 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_refine_gpu.py -x -q 2>&1 | tail -3
-timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep -v amdgpu.ids | tail -4 | cut -c1-120
+echo "default"; timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
+echo "all planes"; SLN_REFINE_ALL_PLANES=1 timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
+echo "all planes, separate sgd, separate head"; SLN_REFINE_ALL_PLANES=1 SLN_REFINE_SEPARATE_SGD=1 SLN_REFINE_SEPARATE_HEAD=1 timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
