@@ -829,10 +829,13 @@ __global__ void gap_kernel(const float* __restrict__ x, long hw, float* __restri
 // from it - two launches of Cr / 32 and C / 128 workgroups per sample.  Same arithmetic per row in every phase: identical results.
 __global__ __launch_bounds__(256) void se_fc_kernel(const float* __restrict__ gap, const double* __restrict__ gsum, double hw,
                                                     const float* __restrict__ w0, const float* __restrict__ w2, int C, int Cr,
-                                                    float* __restrict__ scale, int phase, double* __restrict__ hid) {
+                                                    float* __restrict__ scale, int phase, double* __restrict__ hid,
+                                                    double* __restrict__ zero_acc, int n_zero) {
   extern __shared__ double smd[];
   double* g = smd; double* hdn = smd + C;
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the LayerNorm accumulator the tail kernel (next launch) adds into starts at zero: cleared here instead of by a launch of its own
+  if (zero_acc != nullptr && blockIdx.x == 0 && blockIdx.y == 0) for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_acc[i] = 0.0;
   if (phase != 2) for (int c = threadIdx.x; c < C; c += blockDim.x) g[c] = gsum ? gsum[(size_t)b * C + c] / hw : (double)gap[(size_t)b * C + c];
   else for (int r = threadIdx.x; r < Cr; r += blockDim.x) hdn[r] = hid[(size_t)b * Cr + r];
   __syncthreads();
@@ -1344,16 +1347,17 @@ int sln_block_tail(const float* xs, int xs_up, const float* dx, int B, int C, in
   const long hw = (long)H * W;
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   if (!gap_sums) hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, hw, gap);
+  double* zacc = stats ? acc : nullptr;                                  // cleared by the (last) FC launch, in front of the tail kernel
+  const int nz = LN_ACC_STRIDE * B;
   if (gap_sums && B <= 8) {      // few samples: the two FCs as two launches of many workgroups; the hidden rows go through the unused gap buffer
     double* hid = reinterpret_cast<double*>(gap);                       // B * C / 8 doubles in B * C floats
-    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C / 8, 32)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 1, hid);
-    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C, 128)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 2, hid);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C / 8, 32)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 1, hid,
+                       (double*)nullptr, 0);
+    hipLaunchKernelGGL(se_fc_kernel, dim3(B, sln_cdiv(C, 128)), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 2, hid,
+                       zacc, nz);
   } else
-  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 0, (double*)nullptr);
-  if (stats) {
-    const int e = sln_zero_async(acc, sizeof(double) * LN_ACC_STRIDE * B, st);
-    if (e != 0) return e;
-  }
+  hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, gap_sums, (double)hw, w0, w2, C, C / 8, scale, 0, (double*)nullptr,
+                     zacc, nz);
   const long n_out = (long)C * hw * (up_mode >= 0 ? 4 : 1);
   SlnProfScope prof(SLN_FAM_OTHER, 4.0 * B * (2.0 * C * hw + n_out), st);
   long gx = (n_out / 4 + 255) / 256;
@@ -1417,7 +1421,7 @@ int sln_se_scale_add(const float* xs, const float* dx, int B, int C, int64_t hw,
   float* gap = scratch; float* scale = scratch + (size_t)B * C;
   hipLaunchKernelGGL(gap_kernel, dim3(B * C), dim3(256), 0, st, dx, (long)hw, gap);
   hipLaunchKernelGGL(se_fc_kernel, dim3(B), dim3(256), sizeof(double) * (C + C / 8), st, gap, (const double*)nullptr, (double)hw, w0, w2,
-                     C, C / 8, scale, 0, (double*)nullptr);
+                     C, C / 8, scale, 0, (double*)nullptr, (double*)nullptr, 0);
   const long n = (long)B * C * hw;
   hipLaunchKernelGGL(se_scale_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, xs, dx, scale, (long)hw, n, out);
   SLN_CHECK_LAUNCH();

@@ -326,7 +326,14 @@ class SPADEGenerator4(nn.Module):
         # atomics in arrival order are taken by fixed-order kernels instead (sln_layernorm_stats with one slot per block, the
         # tree-reduced pool of sln_block_tail) - the reference's CPU path gives the same bits on every run, so does this one then.
         det = bool(L.sln_get_deterministic())
-        accs = torch.zeros(32 * B + B * blk.fout, dtype=torch.float64, device=x.device)
+        # fp64 accumulators of the block: one zero-filled buffer per forward holds every block's (seven fills per call were 2 % of a
+        # batch-1 call); the tail launch clears its own (ln_out)
+        n_acc = 32 * B + B * blk.fout
+        pool = getattr(self, "_acc_pool", None)
+        if pool is not None and self._acc_off + n_acc <= pool.numel():
+            accs = pool[self._acc_off:self._acc_off + n_acc]; self._acc_off += n_acc
+        else:
+            accs = torch.zeros(n_acc, dtype=torch.float64, device=x.device)
         ln_dx, ln_out, gap = accs[:16 * B], accs[16 * B:32 * B], accs[32 * B:]
         if blk.learned_shortcut:
             x_s, xs_up = self._conv(self._spade(e["norm_s"], x, stats_x, seg, False, x_up), e["conv_s"], blk.fout, 1), 0
@@ -471,6 +478,8 @@ class SPADEGenerator4(nn.Module):
             fused = self.sw % 4 == 0 and self.sh % 4 == 0 and not self.unfused
             if fused:
                 x, x_up, stats = x.contiguous(), False, None
+                self._acc_pool = torch.zeros(sum(32 * B + B * getattr(self, nm).fout for nm, _, _ in chain), dtype=torch.float64, device=seg.device)
+                self._acc_off = 0
                 stats = self._ln_stats(x)
                 for name, s, tail in chain:
                     x, x_up, stats = self._block(name, x, x_up, stats, s, tail, want_stats=name != "up_3",
@@ -489,4 +498,5 @@ class SPADEGenerator4(nn.Module):
             _lib.check(L.sln_conv_img_tanh(_lib.ptr(x), B, self.nf, S, S, _lib.ptr(P["img_w"]), _lib.ptr(P["img_b"]), self.target_nc,
                                            _lib.ptr(out), self._st()), "sln_conv_img_tanh")
             self._cat_cache = None
+            self._acc_pool = None
             return out
