@@ -7,6 +7,7 @@
 // flush_deferred -, a dozen bookkeeping launches), captured once into a hipGraph and replayed.
 #include <cstddef>
 #include <new>
+#include <type_traits>
 #include <utility>
 #include <vector>
 #include <cstring>
@@ -1675,14 +1676,29 @@ struct SlnVaeGroup {
   std::vector<RecStep> singles;          // steps without a multi form: replayed through the single-room launchers
   std::vector<int> single_room;
 
+  // The program's tables (a hundred-odd, a few hundred bytes to 64 KB each) are staged on the host and go to the device as ONE
+  // allocation and ONE copy when the program is complete (commit_tables): a hipMalloc + blocking hipMemcpy per table was 3 ms of a
+  // 16-room batch's set-up.  Until then a table's pointer holds 1 + its byte offset in the stage.
+  std::vector<char> stage;
   template <typename T> int upload(const std::vector<T>& v, const T** out) {
-    void* d = nullptr;
+    const size_t off = (stage.size() + 255) / 256 * 256;
     const size_t bytes = sizeof(T) * (v.empty() ? 1 : v.size());
-    hipError_t e = hipMalloc(&d, bytes);
-    if (e != hipSuccess) return (int)e;
+    stage.resize(off + bytes);
+    if (!v.empty()) std::memcpy(stage.data() + off, v.data(), sizeof(T) * v.size());
+    *out = reinterpret_cast<const T*>(static_cast<uintptr_t>(off + 1));
+    return 0;
+  }
+  int commit_tables() {
+    void* d = nullptr;
+    hipError_t e = hipMalloc(&d, stage.empty() ? 256 : stage.size());
+    if (e != hipSuccess) return SLN_E_NOMEM;
     allocs.push_back(d);
-    if (!v.empty()) { e = hipMemcpy(d, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice); if (e != hipSuccess) return (int)e; }
-    *out = static_cast<const T*>(d);
+    if (!stage.empty()) { e = hipMemcpy(d, stage.data(), stage.size(), hipMemcpyHostToDevice); if (e != hipSuccess) return (int)e; }
+    const char* base = static_cast<const char*>(d);
+    auto fix = [&](auto& p) { if (p != nullptr) p = reinterpret_cast<std::remove_reference_t<decltype(p)>>(base + (reinterpret_cast<uintptr_t>(p) - 1)); };
+    for (std::vector<Launch>* prog : {&fwd, &bwd})
+      for (Launch& l : *prog) { fix(l.tab); fix(l.tiles); fix(l.tn_probs); fix(l.tn_meta); }
+    stage.clear(); stage.shrink_to_fit();
     return 0;
   }
   ~SlnVaeGroup() {
@@ -2041,6 +2057,8 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
     }
     { SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_JOIN; g->bwd.push_back(l); }     // every wgrad has landed behind this point
   }
+  rc = g->commit_tables();
+  if (rc) return fail(rc);
   *out = g;
   return 0;
 }
