@@ -1,4 +1,4 @@
 cd /root/repo
-timeout 1500 python -m pytest tests/test_refine_gpu.py -x -q 2>&1 | tail -3
-SLN_REFINE_SETUP_LOG=1 ITERS=5 timeout 900 python tools/refine_batch_time.py 16 2>&1 | grep "set-up:" | tail -6
-timeout 900 python tools/refine_batch_time.py 16,64 2>&1 | grep "eager" | cut -c1-130
+timeout 2400 bash tools/round_extras.sh r05 > gpurun_out/round_extras.log 2>&1; echo extras rc=$?
+timeout 900 python bench.py > gpurun_out/profiles_r05/r05_bench.json 2> gpurun_out/bench_final.err; echo bench rc=$?
+tail -2 gpurun_out/bench_final.err
