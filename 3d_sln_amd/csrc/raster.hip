@@ -1498,7 +1498,7 @@ int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B,
 //     (scene_fill_table: mean / wall_max with the mean replaced by wall_max) and its gradient only enters gsum[owner], which
 //     scene_bwd_depthgrad_kernel uses at the class's own pixels; 0 when no class owns the channel
 // Lets the refinement loss skip those planes (SlnRefineLoss::live_planes).
-__global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, const int32_t* __restrict__ chan, const int32_t* __restrict__ dch,
+static __global__ void scene_live_channels_kernel(const SceneStats* __restrict__ st, const int32_t* __restrict__ chan, const int32_t* __restrict__ dch,
                                            int NC, int nch, int B, unsigned char* __restrict__ live) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * nch) return;
