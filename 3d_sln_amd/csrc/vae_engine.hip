@@ -1787,9 +1787,13 @@ struct SlnVaeGroup {
               if (u.p.d_weight == t.dW && (t.db == nullptr || u.p.d_bias == t.db)) {
                 t.dW = u.p.weight; if (t.db != nullptr) t.db = u.p.bias;
                 t.sgd_step = io.sgd_step;
-                if (r == 0) {
-                  fused.push_back(std::make_pair((const float*)u.p.weight, (int64_t)u.out * u.in));
-                  if (t.db != nullptr) fused.push_back(std::make_pair((const float*)u.p.bias, (int64_t)u.out));
+                if (r == 0) {                              // (a recurrent stack steps the same weight from several wgrads: listed once)
+                  bool listed = false;
+                  for (const auto& f : fused) listed = listed || f.first == (const float*)u.p.weight;
+                  if (!listed) {
+                    fused.push_back(std::make_pair((const float*)u.p.weight, (int64_t)u.out * u.in));
+                    if (t.db != nullptr) fused.push_back(std::make_pair((const float*)u.p.bias, (int64_t)u.out));
+                  }
                 }
                 break;
               }
@@ -1900,7 +1904,7 @@ struct SlnVaeGroup {
           r = sln_launch_transpose_table(static_cast<const TransposeEntry*>(l.tab), l.count, l.gx, st);
           if (!r && l.on_side && use_side) { r = (int)hipEventRecord(ev_tr, side); tr_pending = true; }
           break;
-        case L_BN_GRADS: r = sln_launch_bn_param_grads(static_cast<const BnTableEntry*>(l.tab), l.count, l.gx, 1, st); break;
+        case L_BN_GRADS: r = sln_launch_bn_param_grads(static_cast<const BnTableEntry*>(l.tab), l.count, l.gx, eng[0]->cfg.recurrent ? 0 : 1, st); break;
         case L_LOG_SOFTMAX: r = sln_launch_log_softmax(logits, io.angles_pred, rows_total, n_angle, st); break;
         case L_LOG_SOFTMAX_BWD: r = sln_launch_log_softmax_bwd(io.angles_pred, io.d_angles_pred, dlogits, rows_total, n_angle, st); break;
         default: r = SLN_E_UNSUPPORTED;
@@ -1996,11 +2000,8 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
       const int tiles = sln_cdiv(u.out, 32) * sln_cdiv(u.in, 32);
       tr_tiles = tiles > tr_tiles ? tiles : tr_tiles;
     }
-    if (h->cfg.recurrent && (int)h->bns.size() > h->n_bn_enc && R > 0) {
-      // (shared 'recurrent' modules: the per-entry form of the parameter-gradient kernel would let two applications of one module
-      //  add to the same dgamma from different workgroups)
-      return fail(SLN_E_UNSUPPORTED);
-    }
+    // (shared 'recurrent' modules: the per-entry form of the parameter-gradient kernel would let two applications of one module add
+    //  to the same dgamma from different workgroups - that launch then takes the serial form, see L_BN_GRADS in run())
     for (size_t i = (size_t)h->n_bn_enc; i < h->bns.size(); ++i) {
       const BnInst& b = h->bns[i];
       const Unit& u = h->units[b.unit];

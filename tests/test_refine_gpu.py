@@ -631,3 +631,41 @@ def test_sparse_scene_image_and_its_flags_describe_the_full_image():
                 assert np.array_equal(img[b, ch], full[b, ch]), (b, ch)
             else:
                 assert (img[b, ch] == -7.0).all(), (b, ch, live[b, ch])
+
+
+def test_rooms_in_flight_with_a_recurrent_decoder():
+    """gconv_mode='recurrent' applies ONE GraphTripleConv gconv_num_layers times: every weight of it receives that many wgrads per
+    backward pass, and with the SGD step in the wgrads' epilogue each of them steps the weight (the sum of the steps is the step of
+    the summed gradient).  Rooms in flight equal the autograd one-room loop; deterministic runs are bit-identical per room."""
+    R = pkg("host.refine"); M = pkg("host.Sg2ScVAE_model")
+    L = pkg("_lib").lib()
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=3, gconv_mode="recurrent", mlp_normalization="batch")
+    model, sd = _room_model(cfg)
+    rooms = _random_rooms(3, cfg, seed=21)
+    bank = R.MeshBank(FURN, "cuda", seed=3)
+    kw = dict(bank=bank, learning_rate=1e-3, image_size=96, iters=3)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        rb = R.RefineBatch(model, rooms, **kw)
+        losses = rb.run().cpu().numpy().copy()
+        params = rb.params.cpu().numpy().copy()
+        res = [(b.cpu().numpy().copy(), i.cpu().numpy().copy()) for b, i in rb.results()]
+        rb.close()
+        assert np.isfinite(losses).all()
+        assert not np.array_equal(params[0], model.flat_params.detach().cpu().numpy()), "the parameters moved"
+        for r in (0, 2):
+            m1 = M.Sg2ScVAEModel(**cfg.model_kwargs()); m1.load_state_dict(sd); m1 = m1.cuda().eval()
+            rm = rooms[r]
+            l1, (b1, i1) = R.finetune_vae_fast(m1, rm["objs"], rm["triples"], rm["boxes"], rm["angles"], rm["attributes"], rm["class_names"], iters=3,
+                                               bank=bank, learning_rate=1e-3, image_size=96)
+            assert_close(losses[:, r], l1.cpu().numpy(), "losses of room %d vs finetune_vae_fast" % r, rtol=1e-5)
+            assert_close(res[r][0], b1.cpu().numpy(), "boxes of room %d" % r, rtol=1e-5, atol=1e-6)
+            assert_close(params[r], m1.flat_params.detach().cpu().numpy(), "parameters of room %d" % r, rtol=1e-5, atol=1e-7)
+        try:
+            L.sln_set_deterministic(1)
+            a = R.RefineBatch(model, rooms, **kw); la = a.run().cpu().numpy().copy(); pa = a.params.cpu().numpy().copy(); a.close()
+            b = R.RefineBatch(model, [rooms[1]], **kw); lb = b.run().cpu().numpy().copy(); pb = b.params.cpu().numpy().copy(); b.close()
+        finally:
+            L.sln_set_deterministic(0)
+        assert np.array_equal(la[:, 1], lb[:, 0]) and np.array_equal(pa[1], pb[0])
+    torch.cuda.synchronize()
