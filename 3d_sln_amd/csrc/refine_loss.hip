@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
                                                        RefineDims d,
                                                        const int* __restrict__ s2_k0, const int* __restrict__ s2_k1, const float* __restrict__ s2_l1,
                                                        const int* __restrict__ s1_i0, const int* __restrict__ s1_i1, const float* __restrict__ s1_l1,
-                                                       float* __restrict__ pooled, const unsigned char* __restrict__ live) {
+                                                       float* __restrict__ pooled, const unsigned char* __restrict__ live, const int skip_ones) {
   __shared__ float inter[POOL_LDS_MAX * POOL_LDS_MAX];
   const int nc = d.n_sem + d.n_dep;
   // (planes x scales grid.  Round 5 tried the four scale-workgroups of a plane on one XCD, adjacent in launch order, so that the
@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
     return;
   }
   const bool ones = lv == 1;                                      // the constant 1: the same expressions on 1.f instead of the four taps
+  if (ones && skip_ones) return;                                  // ... or not at all: loss_kernel takes the pooled constant plane from pooled_ones
   const int sz = s2_k1[s * d.P + d.P - 1] + 1;                    // intermediate size of this scale (the last pooled index reads its last row)
   const long plane = (long)d.S * d.S;
   const bool fill = null_fill && c == d.dep0 + d.n_dep - 1;       // the last depth channel is set to 1 where no class has depth
@@ -156,7 +157,8 @@ constexpr int DCH = 8;               // depth channels per thread of loss_kernel
 template <int NSEM>
 __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, RefineDims d, const float* __restrict__ tgt_depth,
                                                    const int* __restrict__ labels, const float* __restrict__ inv_count,
-                                                   float2* __restrict__ partial, const unsigned char* __restrict__ live) {
+                                                   float2* __restrict__ partial, const unsigned char* __restrict__ live,
+                                                   const float* __restrict__ pooled_ones) {
   const int nc = d.n_sem + d.n_dep;
   const long pp = (long)d.P * d.P;
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,15 +206,23 @@ __global__ __launch_bounds__(128) void loss_kernel(float* __restrict__ pooled, R
       const float* tg = tgt_depth + ((long)(b * d.n_scales + s) * d.n_dep) * pp + pix;
       float* q = p + (long)d.n_sem * pp;
       const int c0 = ((int)blockIdx.y - 1) * DCH;
-      float a[DCH], t[DCH];
+      // a depth-hot plane flagged "the constant 1" (live_planes == 1) was not pooled per room: its pooled plane is the same for every
+      // room and lives in pooled_ones [n_scales][P][P] (built with the pooling kernel itself); its gradient, which nobody reads, is
+      // not stored
+      const float one_p = (live != nullptr && pooled_ones != nullptr) ? pooled_ones[(long)s * pp + pix] : 0.f;
+      float a[DCH], t[DCH]; bool cst[DCH];
 #pragma unroll
-      for (int u = 0; u < DCH; ++u) { const int c = min(c0 + u, d.n_dep - 1); a[u] = q[c * pp]; t[u] = tg[c * pp]; }
+      for (int u = 0; u < DCH; ++u) {
+        const int c = min(c0 + u, d.n_dep - 1);
+        cst[u] = live != nullptr && pooled_ones != nullptr && live[b * d.C + d.dep0 + c] == 1;
+        a[u] = cst[u] ? one_p : q[c * pp]; t[u] = tg[c * pp];
+      }
 #pragma unroll
       for (int u = 0; u < DCH; ++u) {
         if (c0 + u < d.n_dep) {
           const float diff = a[u] - t[u];
           l_abs += fabsf(diff);
-          q[(c0 + u) * pp] = diff > 0.f ? gd : (diff < 0.f ? -gd : 0.f);
+          if (!cst[u]) q[(c0 + u) * pp] = diff > 0.f ? gd : (diff < 0.f ? -gd : 0.f);
         }
       }
     }
@@ -550,7 +560,7 @@ static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float
   static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
   if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
     hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
-                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled, live);
+                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled, live, (live != nullptr && L->pooled_ones != nullptr) ? 1 : 0);
     return;
   }
   const long np = (long)d.B * d.n_scales * sln_cdiv(d.n_sem + d.n_dep, CG) * d.P * d.P;
@@ -583,7 +593,7 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   launch_pool(L, d, image, 1, mask, pooled, live, st);
   const long nl = (long)d.B * d.n_scales * d.P * d.P;
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
-  hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial, live);
+  hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial, live, L->pooled_ones);
   const long per_room_rows = (long)d.n_scales * d.P * d.P;
   if (d.per_room && per_room_rows % 128 != 0) return SLN_E_UNSUPPORTED;       // a block of loss_kernel would cover two rooms
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(d.per_room ? d.B : 1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out, (int)lg.x,

@@ -315,6 +315,24 @@ class RefineLoss:
         cnt = (lab >= 0).sum(dim=(2, 3) if self.per_room else (0, 2, 3)).to(torch.float32)
         self.inv_count = (1.0 / cnt).contiguous()                                                       # 1/0: nan loss, as torch's empty mean
 
+    def pooled_ones(self):
+        """[n_scales, P, P]: what the resampling kernel makes of an all-ones plane (one per geometry and device; see
+        SlnRefineLoss::pooled_ones)"""
+        d = self.desc
+        key = ("ones", d.image_size, d.pooled_size, d.n_scales, d.stage1_stride, str(self.ws.device), self._keep[0].data_ptr())
+        t = _REFINE_TABLES.get(key)
+        if t is None:
+            L, dev = _lib.lib(), self.ws.device
+            d1 = type(d).from_buffer_copy(d)
+            d1.B, d1.per_room, d1.live_planes, d1.pooled_ones = 1, 0, None, None
+            C_, S, P, ns = d.channels, d.image_size, d.pooled_size, d.n_scales
+            ws1 = torch.empty(int(L.sln_refine_loss_workspace_bytes(1, S, P, ns, 40, C_ - 41)), dtype=torch.uint8, device=dev)
+            pooled = torch.empty(1, ns, C_ - 1, P, P, device=dev)
+            _lib.check(L.sln_refine_pool(d1, _lib.ptr(torch.ones(1, C_, S, S, device=dev)), 0, _lib.ptr(ws1), _lib.ptr(pooled),
+                                         _lib.current_stream_ptr()), "sln_refine_pool(ones)")
+            t = _REFINE_TABLES[key] = pooled[0, :, 40].contiguous()
+        return t
+
     def __call__(self, image):
         return _RefineLossFn.apply(image, self)
 
@@ -749,6 +767,9 @@ class RefineBatch:
         self.live = torch.full((R, DR.N_SCENE_CHANNELS), 3, dtype=torch.uint8, device=dev)
         if not os.environ.get("SLN_REFINE_ALL_PLANES"):
             self.loss.desc.live_planes = self.live.data_ptr()
+            if not os.environ.get("SLN_REFINE_POOL_ONES"):             # (lab switch: pool the constant planes per room)
+                self._pooled_ones = self.loss.pooled_ones()
+                self.loss.desc.pooled_ones = self._pooled_ones.data_ptr()
         self.one = torch.ones(1, **f32)
         self.losses = torch.zeros(max(self.iters, 1), R, **f32)
         rg = model.decoder_param_ranges()

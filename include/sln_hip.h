@@ -448,6 +448,8 @@ typedef struct {
                                                  * bit 0 clear - the plane is all zeros: forward writes its pooled plane as zeros
                                                  * without reading it; bit 1 clear - nobody reads the plane's gradient: backward
                                                  * leaves that plane of grad_image as it is.  NULL: every plane is processed. */
+  const float* pooled_ones;                     /* optional [n_scales, P, P] (device): sln_refine_pool of an all-ones plane.  With live_planes,
+                                                 * the planes flagged "constant 1" are then not pooled per image: the loss reads this table */
 } SlnRefineLoss;
 int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
 int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */

@@ -1,4 +1,4 @@
 cd /root/repo
-timeout 2400 bash tools/round_extras.sh r05 > gpurun_out/round_extras.log 2>&1; echo extras rc=$?
-timeout 900 python bench.py > gpurun_out/profiles_r05/r05_bench.json 2> gpurun_out/bench_final.err; echo bench rc=$?
-tail -2 gpurun_out/bench_final.err
+timeout 900 python -m pytest tests/test_refine_gpu.py -x -q 2>&1 | tail -3
+timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
+SLN_REFINE_POOL_ONES=1 timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
