@@ -794,10 +794,10 @@ def refine_leg(args, lib, torch):
         dec_bytes = 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
         # algorithmic HBM bytes of one room-iteration: the LIVE planes of the 70-plane scene tensor (channel 0 and the planes of the
         # classes visible in the room: n3 of 70, measured on the last iteration) written, read by the pooling, their gradient
-        # written and read by the scene backward; the pooled tensor (4 scales x (n3 - 1 live + n1 constant) planes of 96 x 96)
-        # written, read, its gradient written, read; the decoder's parameters read by the forward Linears, transposed (read +
-        # write), read by the dgrads, and stepped in the wgrads' epilogue (read + write)
-        algo = 4 * n3 * plane + 4 * (4 * (n3 - 1 + n1) * 96 * 96 * 4.0) + 6 * dec_bytes
+        # written and read by the scene backward; the pooled tensor (4 scales x (n3 - 1) live planes of 96 x 96; the n1 constant
+        # planes share one pooled plane per scale) written, read, its gradient written, read; the decoder's parameters read by the
+        # forward Linears, transposed (read + write), read by the dgrads, and stepped in the wgrads' epilogue (read + write)
+        algo = 4 * n3 * plane + 4 * (4 * (n3 - 1) * 96 * 96 * 4.0) + 6 * dec_bytes
         batch = {"rooms": nr, "ms_per_iteration": round(it_ms, 3), "ms_per_room_iteration": round(it_ms / nr, 4),
                  "ms_setup_per_room": round(sorted(x[1] for x in runs)[len(runs) // 2] * 1e3 / nr, 2), "iterations": iters, "finite": fin,
                  "launches": info, "live_planes_per_room": round(n3, 1), "constant_planes_per_room": round(n1, 1), "speedup_vs_one_room_at_a_time": round(per_iter * 1e3 / (it_ms / nr), 2),
