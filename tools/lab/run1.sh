@@ -1,4 +1,5 @@
 cd /root/repo
-timeout 900 python -m pytest tests/test_refine_gpu.py -x -q 2>&1 | tail -3
-timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
-SLN_REFINE_POOL_ONES=1 timeout 600 python tools/refine_batch_time.py 16 2>&1 | grep "eager" | cut -c1-70
+for r in 1 2 4; do
+echo "R=$r side"; timeout 600 python tools/refine_batch_time.py $r 2>&1 | grep "eager\|graph:" | cut -c1-70
+echo "R=$r no side"; SLN_GROUP_NO_SIDE=1 timeout 600 python tools/refine_batch_time.py $r 2>&1 | grep "eager\|graph:" | cut -c1-70
+done
