@@ -1041,7 +1041,7 @@ SceneSide* scene_side() {
   std::lock_guard<std::mutex> lk(mu);
   if (per_dev[dev] == nullptr && !failed[dev]) {
     SceneSide* s = new SceneSide{nullptr, nullptr, nullptr, nullptr};
-    if (hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (sln_side_stream_create(&s->stream) != hipSuccess ||
         hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) { failed[dev] = true; delete s; return nullptr; }

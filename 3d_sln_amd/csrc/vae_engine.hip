@@ -1129,11 +1129,11 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
     { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }
-    if (h->tn_side && !h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
+    if (h->tn_side && !h->side && sln_side_stream_create(&h->side) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
     const char* ng = std::getenv("SLN_NO_GROUP");
     h->use_group = h->use_dual && !(ng && ng[0] == '1');
     h->use_side = !h->use_dual && !(ns && ns[0] == '1');
-    if (h->use_side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->use_side = false; }
+    if (h->use_side && sln_side_stream_create(&h->side) != hipSuccess) { h->side = nullptr; h->use_side = false; }
   }
   *out = h;
   return 0;
@@ -1536,7 +1536,7 @@ int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, 
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
     { const char* v = std::getenv("SLN_TN_SIDE"); h->tn_side = h->defer && v && v[0] == '1'; }
-    if (h->tn_side && !h->side && hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
+    if (h->tn_side && !h->side && sln_side_stream_create(&h->side) != hipSuccess) { h->side = nullptr; h->tn_side = false; }
   }
   *out = h;
   return 0;
@@ -2012,7 +2012,7 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
       bnt.push_back(e); bn_maxc = b.C > bn_maxc ? b.C : bn_maxc;
     }
   }
-  if (hipStreamCreateWithFlags(&g->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+  if (sln_side_stream_create(&g->side) != hipSuccess || hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_tr, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SLN_E_NOMEM);
   // the side stream pays from four rooms on (one / two rooms: 0.86 / 0.93 ms per iteration without it, 0.90 / 0.96 with; four: equal);

@@ -510,8 +510,9 @@ def render_leg(args, lib, torch, rank):
     torch.cuda.synchronize()
     fam = prof_read(lib)
     lib.check(lib.lib().sln_prof_enable(0), "prof")
-    # the median batch (HIP events around every iteration): the wall-clock mean of the loop moved by 2x when ONE iteration of a
-    # run stalled for ~50 ms (seen once in five runs of the round-5 profile script, p10 / p50 / p90 unchanged); the mean is printed too
+    # the median batch (HIP events around every iteration): in the default run (parity checks in front: the oracle's OpenMP threads
+    # are still spinning) the first few of the 100 iterations are host-starved and the wall-clock mean is ~2x the median; with
+    # --no-check the two agree.  The mean is printed too
     p50_ms = per[int(0.5 * (len(per) - 1))]
     per_render = p50_ms * 1e-3 / args.rooms
     tris = tri_count / args.rooms

@@ -1,5 +1,3 @@
 cd /root/repo
-for r in 1 2 4; do
-echo "R=$r side"; timeout 600 python tools/refine_batch_time.py $r 2>&1 | grep "eager\|graph:" | cut -c1-70
-echo "R=$r no side"; SLN_GROUP_NO_SIDE=1 timeout 600 python tools/refine_batch_time.py $r 2>&1 | grep "eager\|graph:" | cut -c1-70
-done
+timeout 2500 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -3
+python bench.py > gpurun_out/bench_now.json 2>/dev/null; echo rc=$?
