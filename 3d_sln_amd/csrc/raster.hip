@@ -1029,7 +1029,7 @@ namespace {
 
 // Side stream of the scene backward (one per device, created on first use, kept for the life of the process).  SLN_SCENE_NO_SIDE=1
 // keeps every launch on the caller's stream.
-struct SceneSide { hipStream_t stream; hipEvent_t fork, mid, join; };
+struct SceneSide { hipStream_t stream; hipEvent_t fork, mid, join; };      // stream: a pooled one that overlaps with the caller's, per call
 SceneSide* scene_side() {
   static const bool off = [] { const char* v = std::getenv("SLN_SCENE_NO_SIDE"); return v && v[0] == '1'; }();
   if (off) return nullptr;
@@ -1041,8 +1041,7 @@ SceneSide* scene_side() {
   std::lock_guard<std::mutex> lk(mu);
   if (per_dev[dev] == nullptr && !failed[dev]) {
     SceneSide* s = new SceneSide{nullptr, nullptr, nullptr, nullptr};
-    if (sln_side_stream_create(&s->stream) != hipSuccess ||
-        hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&s->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s->join, hipEventDisableTiming) != hipSuccess) { failed[dev] = true; delete s; return nullptr; }
     per_dev[dev] = s;
@@ -1560,7 +1559,8 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   hipStream_t sd_st = st;
   if (sd != nullptr) {
     side_lock.lock();
-    if (hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
+    sd->stream = sln_overlapping_stream(st);                                    // (under side_mu: one caller at a time)
+    if (sd->stream != nullptr && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
     else { sd = nullptr; side_lock.unlock(); }
   }
   struct Join {

@@ -317,17 +317,11 @@ static inline int sln_zero_async(void* p, size_t bytes, hipStream_t st) {
     if (e__ != hipSuccess) return (int)e__;                                 \
   } while (0)
 
-// A side stream that does not share a hardware queue with the caller's stream.  The runtime deals streams of one priority to a
-// few hardware queues round-robin (GPU_MAX_HW_QUEUES, 4 by default): a side stream created as the n-th stream of a process can land
-// on the caller's queue, and then nothing on it overlaps the caller's launches - found in round 5 when the 16-room refinement took
-// 1.63 ms per iteration in a fresh process and 1.84 behind another leg of bench.py that had created streams of its own (and 1.63
-// again with GPU_MAX_HW_QUEUES=8).  Streams of another priority level live on queues of their own: the side streams ask for the
-// highest priority (callers run on default-priority streams: torch's current and pool streams).  SLN_SIDE_PRIORITY=0: plain streams.
-inline hipError_t sln_side_stream_create(hipStream_t* s) {
-  static const bool plain = std::getenv("SLN_SIDE_PRIORITY") != nullptr && std::getenv("SLN_SIDE_PRIORITY")[0] == '0';
-  int lo = 0, hi = 0;
-  if (!plain && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo) {
-    if (hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess) return hipSuccess;
-  }
-  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+// A pooled stream that overlaps with `main` (streams.hip: two streams on one hardware queue do not; probed once per caller stream);
+// nullptr when none can be had right now (first use inside a stream capture).  Plain engine side streams: sln_side_stream_create.
+hipStream_t sln_overlapping_stream(hipStream_t main);
+inline hipError_t sln_side_stream_create(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+inline bool sln_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
 }

@@ -1,0 +1,85 @@
+// Side streams that really run next to the caller's stream (round 5).
+//
+// The runtime deals a process's streams to a few hardware queues round-robin (GPU_MAX_HW_QUEUES, 4 by default), and two streams
+// on one hardware queue do not overlap: their packets are ordered.  A side stream created as the n-th stream of a process can
+// therefore be worthless - the 16-room refinement ran 1.63 ms per iteration in a fresh process and 1.84 behind another leg of
+// bench.py that had created streams of its own (1.63 again with GPU_MAX_HW_QUEUES=8, 1.84 in the fresh process with =2).
+// High-priority side streams (another priority level has queues of its own) fixed that case and broke others: a hipGraph replay
+// of the same iteration went from 1.76 to 4.2 ms and eager launches of the process stayed slow afterwards.
+//
+// So the library keeps a small pool of plain streams per device and, per caller stream, PROBES which of them overlaps with it:
+// a kernel on the caller's stream waits (at most ~150 us) for a flag that a kernel on the candidate sets - if the candidate
+// shares the caller's hardware queue its kernel sits behind the waiting one and the wait times out.  One probe per (caller
+// stream, candidate), a few hundred microseconds once; never inside a stream capture (a capture of a stream not probed before
+// takes the pool's first stream).  SLN_SIDE_PROBE=0: no probing, first stream of the pool.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
+
+#include "sln_common.h"
+
+namespace {
+
+constexpr int POOL = 4;
+constexpr long long PROBE_TICKS = 15000;          // wall_clock64 runs at 100 MHz: 150 us
+
+__global__ void probe_wait_kernel(int* flag, int* result, long long max_ticks) {
+  const long long t0 = wall_clock64();
+  int seen = 0;
+  while (!(seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+  result[0] = seen ? 1 : 0;
+}
+__global__ void probe_set_kernel(int* flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct DevPool {
+  hipStream_t s[POOL] = {};
+  int n = 0;
+  int* words = nullptr;                            // flag, result
+  std::map<hipStream_t, int> pick;                 // caller stream -> index into s
+};
+std::mutex g_mu;
+DevPool g_pools[64];
+
+bool overlaps(DevPool& p, hipStream_t main, hipStream_t cand) {
+  if (hipMemsetAsync(p.words, 0, 2 * sizeof(int), main) != hipSuccess) return false;
+  if (hipStreamSynchronize(main) != hipSuccess) return false;
+  hipLaunchKernelGGL(probe_wait_kernel, dim3(1), dim3(1), 0, main, p.words, p.words + 1, PROBE_TICKS);
+  hipLaunchKernelGGL(probe_set_kernel, dim3(1), dim3(1), 0, cand, p.words);
+  int res = 0;
+  if (hipStreamSynchronize(main) != hipSuccess || hipStreamSynchronize(cand) != hipSuccess) return false;
+  if (hipMemcpy(&res, p.words + 1, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  (void)hipGetLastError();
+  return res == 1;
+}
+
+}  // namespace
+
+hipStream_t sln_overlapping_stream(hipStream_t main) {
+  static const bool no_probe = std::getenv("SLN_SIDE_PROBE") != nullptr && std::getenv("SLN_SIDE_PROBE")[0] == '0';
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevPool& p = g_pools[dev];
+  const bool capturing = sln_capturing(main);
+  if (p.n == 0) {
+    if (capturing) return nullptr;                 // nothing may be created while the caller records: no side stream this time
+    for (int i = 0; i < POOL; ++i) {
+      hipStream_t s = nullptr;
+      if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+      p.s[p.n++] = s;
+    }
+    if (p.n == 0) return nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&p.words), 2 * sizeof(int)) != hipSuccess) p.words = nullptr;
+  }
+  auto it = p.pick.find(main);
+  if (it != p.pick.end()) return p.s[it->second];
+  if (capturing || no_probe || p.words == nullptr) return p.s[0];
+  int chosen = 0;
+  for (int i = 0; i < p.n; ++i)
+    if (overlaps(p, main, p.s[i])) { chosen = i; break; }
+  p.pick[main] = chosen;
+  return p.s[chosen];
+}

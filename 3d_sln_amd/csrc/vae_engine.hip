@@ -1669,7 +1669,7 @@ struct SlnVaeGroup {
   // launch - so work that nothing in the chain waits for runs next to it: W^T of the decoder's weights (needed by the first
   // dgrad only) under the forward pass and everything between the two calls (render, loss), a layer's wgrads under the following
   // layers' dgrads.  Fork / join are events (legal inside a caller's stream capture: the side stream joins the capture).
-  hipStream_t side = nullptr;
+  hipStream_t side = nullptr;                      // a pooled stream that overlaps with the caller's (sln_overlapping_stream), per run()
   hipEvent_t ev_fork = nullptr, ev_tr = nullptr, ev_join = nullptr;
   bool tr_pending = false, use_side = true;
   std::vector<std::pair<const float*, int64_t>> fused;      // room 0's parameter tensors stepped by the wgrad launches (io.sgd_step)
@@ -1706,7 +1706,6 @@ struct SlnVaeGroup {
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_tr) (void)hipEventDestroy(ev_tr);
     if (ev_join) (void)hipEventDestroy(ev_join);
-    if (side) (void)hipStreamDestroy(side);
   }
   int fork_side(hipStream_t st) {
     hipError_t e = hipEventRecord(ev_fork, st);
@@ -1873,6 +1872,10 @@ struct SlnVaeGroup {
   }
 
   int run(const std::vector<Launch>& prog, hipStream_t st) {
+    const bool want_side = use_side;
+    side = want_side ? sln_overlapping_stream(st) : nullptr;
+    struct Restore { bool& flag; bool v; ~Restore() { flag = v; } } restore{use_side, want_side};
+    if (side == nullptr) use_side = false;          // none to be had (first use inside a capture): this pass on the caller's stream
     for (const Launch& l : prog) {
       int r = 0;
       hipStream_t main_st = st;
@@ -1883,7 +1886,7 @@ struct SlnVaeGroup {
           if (use_side) { hipError_t e = hipEventRecord(ev_join, side); if (e == hipSuccess) e = hipStreamWaitEvent(main_st, ev_join, 0); r = (int)e; }
           break;
         case L_JOIN_TR:
-          if (use_side && tr_pending) { r = (int)hipStreamWaitEvent(main_st, ev_tr, 0); tr_pending = false; }
+          if (tr_pending) { r = (int)hipStreamWaitEvent(main_st, ev_tr, 0); tr_pending = false; }
           break;
         case L_NT: r = sln_launch_gemm_nt_small_multi(static_cast<const GemmNTArgs*>(l.tab), l.tiles, l.count, l.variant, l.gx, l.maxK, l.flops, st); break;
         case L_TN_MULTI: r = sln_launch_gemm_tn_multi(l.tn_probs, l.tn_meta, l.blocks, l.x2, l.xg, l.flops, st); break;
@@ -2012,7 +2015,7 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
       bnt.push_back(e); bn_maxc = b.C > bn_maxc ? b.C : bn_maxc;
     }
   }
-  if (sln_side_stream_create(&g->side) != hipSuccess || hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
+  if (hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&g->ev_tr, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g->ev_join, hipEventDisableTiming) != hipSuccess)
     return fail(SLN_E_NOMEM);
   // the side stream pays from four rooms on (one / two rooms: 0.86 / 0.93 ms per iteration without it, 0.90 / 0.96 with; four: equal);
