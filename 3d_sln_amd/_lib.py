@@ -128,6 +128,7 @@ SIGNATURES = {
     "sln_vae_group_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sln_vae_group_fused_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "sln_vae_group_destroy": (None, [C.c_void_p]),
+    "sln_debug_side_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_set_deterministic": (C.c_int, [C.c_int]),
     "sln_get_deterministic": (C.c_int, []),

@@ -83,3 +83,20 @@ hipStream_t sln_overlapping_stream(hipStream_t main) {
   p.pick[main] = chosen;
   return p.s[chosen];
 }
+
+// diagnostics (tests): the side stream the library uses next to `stream`, its index in the pool, and whether a fresh probe sees the
+// two overlap.  Returns 0, or SLN_E_STATE when no side stream can be had (first use inside a capture).
+extern "C" int sln_debug_side_stream(void* stream, int* index, int* overlapped) {
+  hipStream_t main = (hipStream_t)stream;
+  hipStream_t side = sln_overlapping_stream(main);
+  if (side == nullptr) return -3;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevPool& p = g_pools[dev];
+  int idx = -1;
+  for (int i = 0; i < p.n; ++i) if (p.s[i] == side) idx = i;
+  if (index) *index = idx;
+  if (overlapped) *overlapped = (p.words != nullptr && !sln_capturing(main) && overlaps(p, main, side)) ? 1 : 0;
+  return 0;
+}

@@ -225,6 +225,12 @@ int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64
 int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single_room_fallbacks);
 void sln_vae_group_destroy(SlnVaeGroup* g);
 
+/* Diagnostics: the pooled side stream the library runs next to `stream` (wgrads of a room group, the depth chain of the scene
+ * backward): its index in the per-device pool and whether a probe sees the two streams overlap.  Two streams that share a hardware
+ * queue do not - the runtime deals streams to a few queues round-robin - so the library probes once per caller stream and keeps a
+ * pooled stream that does (csrc/streams.hip). */
+int sln_debug_side_stream(void* stream, int* index, int* overlapped);
+
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline figures).
  * Families: 0 gemm_nt (forward/dgrad), 1 gemm_tn (wgrad), 2 edge scatter/gather, 3 other.
  * enable=1 starts recording (eager launches only, not under graph capture); sln_prof_read

@@ -669,3 +669,24 @@ def test_rooms_in_flight_with_a_recurrent_decoder():
             L.sln_set_deterministic(0)
         assert np.array_equal(la[:, 1], lb[:, 0]) and np.array_equal(pa[1], pb[0])
     torch.cuda.synchronize()
+
+
+def test_the_side_stream_of_a_caller_stream_overlaps_with_it():
+    """csrc/streams.hip: the runtime deals a process's streams to a few hardware queues round-robin and two streams on one queue
+    serialise; the library probes, per caller stream, which stream of its pool really runs next to it.  Whatever streams this
+    process created before: for several caller streams the chosen side stream passes a fresh probe."""
+    _lib = pkg("_lib"); L = _lib.lib()
+    import ctypes as C
+    junk = [torch.cuda.Stream() for _ in range(5)]          # shift the round-robin
+    seen = []
+    for _ in range(4):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            torch.zeros(8, device="cuda").add_(1)          # the stream exists on the device
+            idx, ov = C.c_int(-1), C.c_int(-1)
+            _lib.check(L.sln_debug_side_stream(_lib.current_stream_ptr(), C.byref(idx), C.byref(ov)), "sln_debug_side_stream")
+            seen.append((idx.value, ov.value))
+    torch.cuda.synchronize()
+    assert all(0 <= i < 4 for i, _ in seen), seen
+    assert all(o == 1 for _, o in seen), "a side stream that does not overlap with its caller stream: %s" % (seen,)
+    del junk
