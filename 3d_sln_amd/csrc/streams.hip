@@ -11,7 +11,8 @@
 // a kernel on the caller's stream waits (at most ~150 us) for a flag that a kernel on the candidate sets - if the candidate
 // shares the caller's hardware queue its kernel sits behind the waiting one and the wait times out.  One probe per (caller
 // stream, candidate), a few hundred microseconds once; never inside a stream capture (a capture of a stream not probed before
-// takes the pool's first stream).  SLN_SIDE_PROBE=0: no probing, first stream of the pool.
+// takes the pool's first stream).  No candidate overlaps (one hardware queue): no side stream at all - the callers run their
+// side work on their own stream.  SLN_SIDE_PROBE=0: no probing, first stream of the pool.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -38,7 +39,8 @@ struct DevPool {
   hipStream_t s[POOL] = {};
   int n = 0;
   int* words = nullptr;                            // flag, result
-  std::map<hipStream_t, int> pick;                 // caller stream -> index into s
+  std::map<hipStream_t, int> pick;                 // caller stream -> index into s, -1: no stream of the pool overlaps with it
+  bool any_ok = false;                             // some probe of this process has seen two streams overlap
 };
 std::mutex g_mu;
 DevPool g_pools[64];
@@ -75,13 +77,18 @@ hipStream_t sln_overlapping_stream(hipStream_t main) {
     if (hipMalloc(reinterpret_cast<void**>(&p.words), 2 * sizeof(int)) != hipSuccess) p.words = nullptr;
   }
   auto it = p.pick.find(main);
-  if (it != p.pick.end()) return p.s[it->second];
-  if (capturing || no_probe || p.words == nullptr) return p.s[0];
-  int chosen = 0;
+  if (it != p.pick.end()) return it->second >= 0 ? p.s[it->second] : nullptr;
+  if (no_probe || p.words == nullptr) return p.s[0];
+  // a stream met for the first time while it is being captured cannot be probed: it gets the pool's first stream - unless no probe
+  // of this process has ever seen an overlap (a single hardware queue: GPU_MAX_HW_QUEUES=1; a fork then buys nothing, and the
+  // runtime of this image crashes on a captured cross-stream fork in that configuration)
+  if (capturing) return p.any_ok ? p.s[0] : nullptr;
+  int chosen = -1;
   for (int i = 0; i < p.n; ++i)
     if (overlaps(p, main, p.s[i])) { chosen = i; break; }
-  p.pick[main] = chosen;
-  return p.s[chosen];
+  p.pick[main] = chosen;                           // -1: none overlaps - the caller keeps everything on its own stream
+  p.any_ok = p.any_ok || chosen >= 0;
+  return chosen >= 0 ? p.s[chosen] : nullptr;
 }
 
 // diagnostics (tests): the side stream the library uses next to `stream`, its index in the pool, and whether a fresh probe sees the
