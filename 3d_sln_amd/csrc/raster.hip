@@ -102,12 +102,17 @@ struct ZState { float z; int idx; float w0, w1, w2; };
 
 // DUAL: track a second z-buffer with its own near plane (the reference's depth pass runs with the package
 // default near=0.1 while its class passes use the constructor's near, SURVEY.md 2.1 "known asymmetry").
-template <bool DUAL>
+__device__ __forceinline__ void tex_sample(const float* f, const float* tx, int ts, float eps, float w0, float w1, float w2,
+                                           float depth, float* px);
+// TEX (fused scene pass, round 5): the class pass's texture sample of the pixel in the same launch (it was a launch of its own
+// between the tile kernel and the statistics: one pixel per thread, inputs = what this kernel has just written)
+template <bool DUAL, bool TEX = false>
 __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ rec, const BBox8* __restrict__ bbox, int F, int is, float near_a,
                                                           float near_b, float far, int32_t* __restrict__ fi_a,
                                                           float* __restrict__ w_a, float* __restrict__ d_a,
                                                           int32_t* __restrict__ fi_b, float* __restrict__ w_b,
-                                                          float* __restrict__ d_b) {
+                                                          float* __restrict__ d_b, const float* __restrict__ tex_faces,
+                                                          const float* __restrict__ tex, int tex_ts, float tex_eps, float* __restrict__ tex_rgb) {
   __shared__ float sf[CHUNK][19];          // 9 vertex words, 9 inverse words, the face's depth lower bound
   __shared__ int sid[CHUNK];
   __shared__ int wave_cnt[4];
@@ -198,6 +203,13 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     if (DUAL) {
       fi_b[p] = Bz.idx; d_b[p] = Bz.idx >= 0 ? Bz.z : far;
       w_b[3 * p] = Bz.w0; w_b[3 * p + 1] = Bz.w1; w_b[3 * p + 2] = Bz.w2;
+      if (TEX) {                                       // texture_sample_kernel's work for the pixel, from the registers that hold its inputs
+        float px[3] = {0.f, 0.f, 0.f};
+        if (Bz.idx >= 0)
+          tex_sample(tex_faces + 9 * ((size_t)b * F + Bz.idx), tex + ((size_t)b * F + Bz.idx) * tex_ts * tex_ts * tex_ts * 3, tex_ts, tex_eps,
+                     Bz.w0, Bz.w1, Bz.w2, Bz.z, px);
+        tex_rgb[3 * p] = px[0]; tex_rgb[3 * p + 1] = px[1]; tex_rgb[3 * p + 2] = px[2];
+      }
     }
   }
 }
@@ -876,7 +888,8 @@ int sln_raster_forward(const float* faces, int B, int F, int image_size, float n
   if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec, bbox);
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
   hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near, near, far,
-                     face_index, weight, depth, nullptr, nullptr, nullptr);
+                     face_index, weight, depth, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f,
+                     (float*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -926,7 +939,7 @@ int sln_raster_forward_dual(const float* faces, int B, int F, int image_size, fl
   if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec, bbox);
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
   hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near_a, near_b, far,
-                     fi_a, w_a, d_a, fi_b, w_b, d_b);
+                     fi_a, w_a, d_a, fi_b, w_b, d_b, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1458,10 +1471,16 @@ static int scene_forward_impl(const float* faces, const int32_t* face_class, int
     hipLaunchKernelGGL(scene_prep_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, faces, n, is, w.rec, w.bbox, w.ones, w.st, B);
   }
   const int tiles = sln_cdiv(is, TS) * sln_cdiv(is, TS);
-  hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
-                     w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB);
-  hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
-                     w.dB, F, is, 2, tex_eps, npix, w.val);
+  static const bool tex_apart = std::getenv("SLN_SCENE_TEX_APART") != nullptr;       // lab: the texture sample as its own launch
+  if (tex_apart) {
+    hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
+                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+    hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
+                       w.dB, F, is, 2, tex_eps, npix, w.val);
+  } else {
+    hipLaunchKernelGGL((raster_tile_kernel<true, true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
+                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, faces, (const float*)w.ones, 2, tex_eps, w.val);
+  }
   // wall_max starts at -inf surrogate
   hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
   hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
