@@ -102,17 +102,31 @@ struct ZState { float z; int idx; float w0, w1, w2; };
 
 // DUAL: track a second z-buffer with its own near plane (the reference's depth pass runs with the package
 // default near=0.1 while its class passes use the constructor's near, SURVEY.md 2.1 "known asymmetry").
+// (statistics of the fused scene pass: defined here because the tile kernel's TEX form takes them along)
+constexpr int DET_BANDS = 16;        // row bands of the deterministic masked sums (scene_bwd_masked_sums_det_kernel)
+struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int det_ticket; int pad_; float det_part[DET_BANDS][64]; };
+
+// order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
+__device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+__device__ __forceinline__ float wall_max_of(const SceneStats& s) { return s.wall_any ? funkey(s.wall_key) : 10.0f; }
+
+__device__ __forceinline__ float class_image_value(float v) { float s = 0.f; s += v; s += v; s += v; return s / 3.0f; }
+__device__ __forceinline__ float depth_value(float d) { return d > 15.f ? -1.f : d; }
+
 __device__ __forceinline__ void tex_sample(const float* f, const float* tx, int ts, float eps, float w0, float w1, float w2,
                                            float depth, float* px);
-// TEX (fused scene pass, round 5): the class pass's texture sample of the pixel in the same launch (it was a launch of its own
-// between the tile kernel and the statistics: one pixel per thread, inputs = what this kernel has just written)
+// TEX (fused scene pass, round 5): the class pass's texture sample of the pixel and the per-class statistics in the same launch
+// (they were two launches between the tile kernel and the compose kernel: one pixel per thread, inputs = what this kernel has
+// just written)
 template <bool DUAL, bool TEX = false>
 __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restrict__ rec, const BBox8* __restrict__ bbox, int F, int is, float near_a,
                                                           float near_b, float far, int32_t* __restrict__ fi_a,
                                                           float* __restrict__ w_a, float* __restrict__ d_a,
                                                           int32_t* __restrict__ fi_b, float* __restrict__ w_b,
                                                           float* __restrict__ d_b, const float* __restrict__ tex_faces,
-                                                          const float* __restrict__ tex, int tex_ts, float tex_eps, float* __restrict__ tex_rgb) {
+                                                          const float* __restrict__ tex, int tex_ts, float tex_eps, float* __restrict__ tex_rgb,
+                                                          const int32_t* __restrict__ st_cls, int st_nc, SceneStats* __restrict__ st_out) {
   __shared__ float sf[CHUNK][19];          // 9 vertex words, 9 inverse words, the face's depth lower bound
   __shared__ int sid[CHUNK];
   __shared__ int wave_cnt[4];
@@ -196,6 +210,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     }
     __syncthreads();
   }
+  float tpx[3] = {0.f, 0.f, 0.f};
   if (inimg) {
     const size_t p = ((size_t)b * is + yi) * is + xi;
     fi_a[p] = A.idx; d_a[p] = A.idx >= 0 ? A.z : far;
@@ -204,12 +219,39 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
       fi_b[p] = Bz.idx; d_b[p] = Bz.idx >= 0 ? Bz.z : far;
       w_b[3 * p] = Bz.w0; w_b[3 * p + 1] = Bz.w1; w_b[3 * p + 2] = Bz.w2;
       if (TEX) {                                       // texture_sample_kernel's work for the pixel, from the registers that hold its inputs
-        float px[3] = {0.f, 0.f, 0.f};
         if (Bz.idx >= 0)
           tex_sample(tex_faces + 9 * ((size_t)b * F + Bz.idx), tex + ((size_t)b * F + Bz.idx) * tex_ts * tex_ts * tex_ts * 3, tex_ts, tex_eps,
-                     Bz.w0, Bz.w1, Bz.w2, Bz.z, px);
-        tex_rgb[3 * p] = px[0]; tex_rgb[3 * p + 1] = px[1]; tex_rgb[3 * p + 2] = px[2];
+                     Bz.w0, Bz.w1, Bz.w2, Bz.z, tpx);
+        tex_rgb[3 * p] = tpx[0]; tex_rgb[3 * p + 1] = tpx[1]; tex_rgb[3 * p + 2] = tpx[2];
       }
+    }
+  }
+  if (TEX && st_out != nullptr) {
+    // ... and scene_stats_kernel's (per-class depth sums in exact fixed point, visible-face marks, the wall's maximum depth): the
+    // tile's sums in LDS, one set of device atomics per tile.  Exact integer / power-of-two arithmetic: the statistics are the
+    // same bits as the separate pass gave, whatever the order of the tiles.
+    __shared__ unsigned long long ssum[64]; __shared__ int scnt[64];
+    __shared__ int s_wkey, s_wany;
+    if (tid < 64) { ssum[tid] = 0ull; scnt[tid] = 0; }
+    if (tid == 0) { s_wkey = (int)0x80000000; s_wany = 0; }
+    __syncthreads();
+    if (inimg && Bz.idx >= 0) {
+      const_cast<FaceRec*>(rb)[Bz.idx].pad_[1] = 1;
+      const int c = st_cls[(long)b * F + Bz.idx];
+      if (c >= 0 && c < st_nc && class_image_value(tpx[0]) > 0.1f) {
+        const float dd = depth_value(A.idx >= 0 ? A.z : far);
+        atomicAdd(&ssum[c], (unsigned long long)(long long)rint((double)dd * 4294967296.0)); atomicAdd(&scnt[c], 1);
+        if (c == 0) { s_wany = 1; atomicMax(&s_wkey, fkey(dd)); }
+      }
+    }
+    __syncthreads();
+    if (tid < st_nc && scnt[tid] > 0) {
+      atomicAdd(&st_out[b].sum[tid], (double)(long long)ssum[tid] * (1.0 / 4294967296.0));
+      atomicAdd(&st_out[b].cnt[tid], (double)scnt[tid]);
+    }
+    if (tid == 0 && s_wany) {
+      atomicMax(&st_out[b].wall_any, 1);
+      atomicMax(&st_out[b].wall_key, s_wkey);
     }
   }
 }
@@ -889,7 +931,7 @@ int sln_raster_forward(const float* faces, int B, int F, int image_size, float n
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
   hipLaunchKernelGGL((raster_tile_kernel<false>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near, near, far,
                      face_index, weight, depth, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0, 0.f,
-                     (float*)nullptr);
+                     (float*)nullptr, (const int32_t*)nullptr, 0, (SceneStats*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -939,7 +981,8 @@ int sln_raster_forward_dual(const float* faces, int B, int F, int image_size, fl
   if (n > 0) hipLaunchKernelGGL(raster_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, faces, n, image_size, rec, bbox);
   const int tiles = sln_cdiv(image_size, TS) * sln_cdiv(image_size, TS);
   hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, rec, bbox, F, image_size, near_a, near_b, far,
-                     fi_a, w_a, d_a, fi_b, w_b, d_b, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+                     fi_a, w_a, d_a, fi_b, w_b, d_b, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr, (const int32_t*)nullptr, 0,
+                     (SceneStats*)nullptr);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1061,17 +1104,6 @@ SceneSide* scene_side() {
   }
   return per_dev[dev];
 }
-
-constexpr int DET_BANDS = 16;        // row bands of the deterministic masked sums (scene_bwd_masked_sums_det_kernel)
-struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int det_ticket; int pad_; float det_part[DET_BANDS][64]; };
-
-// order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
-__device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }
-__device__ __forceinline__ float funkey(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
-__device__ __forceinline__ float wall_max_of(const SceneStats& s) { return s.wall_any ? funkey(s.wall_key) : 10.0f; }
-
-__device__ __forceinline__ float class_image_value(float v) { float s = 0.f; s += v; s += v; s += v; return s / 3.0f; }
-__device__ __forceinline__ float depth_value(float d) { return d > 15.f ? -1.f : d; }
 
 __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float* __restrict__ val, const float* __restrict__ d_a,
                                    const int32_t* __restrict__ cls, int F, int is, int NC, SceneStats* __restrict__ st,
@@ -1474,15 +1506,16 @@ static int scene_forward_impl(const float* faces, const int32_t* face_class, int
   static const bool tex_apart = std::getenv("SLN_SCENE_TEX_APART") != nullptr;       // lab: the texture sample as its own launch
   if (tex_apart) {
     hipLaunchKernelGGL((raster_tile_kernel<true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
-                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr);
+                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, (const float*)nullptr, (const float*)nullptr, 0, 0.f, (float*)nullptr,
+                       (const int32_t*)nullptr, 0, (SceneStats*)nullptr);
     hipLaunchKernelGGL(texture_sample_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, faces, w.ones, w.fiB, w.wB,
                        w.dB, F, is, 2, tex_eps, npix, w.val);
+    // wall_max starts at -inf surrogate
+    hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
   } else {
     hipLaunchKernelGGL((raster_tile_kernel<true, true>), dim3(tiles, B), dim3(256), 0, st, w.rec, w.bbox, F, is, near_depth, near_rgb, far,
-                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, faces, (const float*)w.ones, 2, tex_eps, w.val);
+                       w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, faces, (const float*)w.ones, 2, tex_eps, w.val, face_class, num_classes, w.st);
   }
-  // wall_max starts at -inf surrogate
-  hipLaunchKernelGGL(scene_stats_kernel, dim3(64, B), dim3(256), 0, st, w.fiB, w.val, w.dA, face_class, F, is, num_classes, w.st, w.rec);
   hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
                      face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out, live);
   SLN_CHECK_LAUNCH();
