@@ -74,7 +74,7 @@ class SlnRefineLoss(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("B", "image_size", "pooled_size", "channels", "sem0", "n_sem", "dep0", "n_dep", "n_scales",
                                        "stage1_stride")] + \
                [(n, C.c_void_p) for n in ("s2_k0", "s2_k1", "s2_l1", "s1_i0", "s1_i1", "s1_l1", "col_ptr", "col_out", "col_w")] + \
-               [("max_col_entries", C.c_int), ("per_room", C.c_int), ("live_planes", C.c_void_p), ("pooled_ones", C.c_void_p)]
+               [("max_col_entries", C.c_int), ("per_room", C.c_int), ("live_planes", C.c_void_p), ("null_mask", C.c_void_p), ("pooled_ones", C.c_void_p)]
 
 
 class SlnPlacementRoom(C.Structure):
@@ -167,7 +167,7 @@ SIGNATURES = {
     "sln_scene_forward": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                     C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p]),
     "sln_scene_forward_live": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p]),
+                                         C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sln_spade_prepare": (C.c_int, [C.c_void_p]),
     "sln_spade_conv": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, c_f32p, C.c_void_p]),

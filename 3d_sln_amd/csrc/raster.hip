@@ -1198,7 +1198,8 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
                                                             const float* __restrict__ d_a, const int32_t* __restrict__ cls,
                                                             const int32_t* __restrict__ chan, const int32_t* __restrict__ dch, int F,
                                                             int is, int NC, int nch, const SceneStats* __restrict__ st,
-                                                            float* __restrict__ out, unsigned char* __restrict__ live) {
+                                                            float* __restrict__ out, unsigned char* __restrict__ live,
+                                                            unsigned char* __restrict__ null_mask) {
   __shared__ ComposeTabs t;
   const int b = blockIdx.y;
   const int ndch = nch - 41;
@@ -1225,12 +1226,15 @@ __global__ __launch_bounds__(256) void scene_compose_kernel(const int32_t* __res
     if (!sparse || t.live[ch] == 3) o[(long)ch * plane] = (mych == ch - 1) ? img : 0.f;
   const float ddq = dd / wall_max;               // one division per pixel: (own depth) / wall_max is the same in every plane it appears in
   const bool own_ok = img > 0.1f;
+  float dsum = 0.f;                                // sum of the pixel's depth-hot values in channel order (refine_loss.hip null_mask_kernel)
   for (int k = 0; k < ndch; ++k) {
     const int owner = t.owner[k];
     float v = 0.f;
     if (owner >= 0) v = (c == owner && own_ok) ? ddq : t.fill[k];
     if (!sparse || t.live[41 + k] == 3) o[(long)(41 + k) * plane] = v;
+    dsum += v;
   }
+  if (null_mask != nullptr) null_mask[(long)b * plane + (long)(is - 1 - y) * is + x] = dsum < 0.5f ? 1 : 0;
 }
 
 // sum over the NOT-masked pixels of each depth-hot channel's incoming gradient (-> d mean_c), as (sum over ALL pixels of the
@@ -1490,7 +1494,8 @@ __global__ void scene_prep_kernel(const float* __restrict__ faces, long n, int i
 
 static int scene_forward_impl(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                               const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
-                              float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream) {
+                              float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, unsigned char* null_mask,
+                              void* stream) {
   if (!faces || !face_class || !class_channel || !class_depth_channel || !workspace || !final_out) return SLN_E_BADARG;
   if (B <= 0 || F <= 0 || image_size <= 0 || num_classes <= 0 || num_classes > 64) return SLN_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1517,7 +1522,7 @@ static int scene_forward_impl(const float* faces, const int32_t* face_class, int
                        w.fiA, w.wA, w.dA, w.fiB, w.wB, w.dB, faces, (const float*)w.ones, 2, tex_eps, w.val, face_class, num_classes, w.st);
   }
   hipLaunchKernelGGL(scene_compose_kernel, dim3((unsigned)((plane + 255) / 256), B), dim3(256), 0, st, w.fiB, w.val, w.dA,
-                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out, live);
+                     face_class, class_channel, class_depth_channel, F, is, num_classes, 70, w.st, final_out, live, null_mask);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1526,7 +1531,7 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
                       const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
                       float far, float tex_eps, void* workspace, float* final_out, void* stream) {
   return scene_forward_impl(faces, face_class, B, F, image_size, num_classes, class_channel, class_depth_channel, near_depth, near_rgb, far,
-                            tex_eps, workspace, final_out, nullptr, stream);
+                            tex_eps, workspace, final_out, nullptr, nullptr, stream);
 }
 
 // The same pass for a consumer that reads the image through its flags (the refinement loss, SlnRefineLoss::live_planes): `live`
@@ -1534,10 +1539,11 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
 // flagged 0 WOULD hold zeros, a plane flagged 1 the constant 1; their memory is left as it was.
 int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                            const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
-                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream) {
+                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, unsigned char* null_mask,
+                           void* stream) {
   if (!live) return SLN_E_BADARG;
   return scene_forward_impl(faces, face_class, B, F, image_size, num_classes, class_channel, class_depth_channel, near_depth, near_rgb, far,
-                            tex_eps, workspace, final_out, live, stream);
+                            tex_eps, workspace, final_out, live, null_mask, stream);
 }
 
 // live[b][ch] of the last sln_scene_forward, two bits.  Bit 0: the plane can hold a non-zero value (clear: it is all zeros).

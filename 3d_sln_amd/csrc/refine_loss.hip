@@ -556,7 +556,7 @@ static const unsigned char* live_of(const SlnRefineLoss* L, const RefineDims& d)
 static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float* image, int null_fill, unsigned char* mask, float* pooled,
                         const unsigned char* live, hipStream_t st) {
   const long npix = (long)d.B * d.S * d.S;
-  if (null_fill) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask, live);
+  if (null_fill == 1) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask, live);      // 2: `mask` is given
   static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
   if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
     hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
@@ -590,7 +590,11 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, workspace, &pooled, &mask, &partial);
   const unsigned char* live = live_of(L, d);
-  launch_pool(L, d, image, 1, mask, pooled, live, st);
+  // the null mask as the producer of `image` computed it (SlnRefineLoss::null_mask: the scene pass's compose kernel sums the 29
+  // depth-hot values of a pixel in this kernel's order while it has them in registers): null_mask_kernel's launch is skipped
+  const bool ext_mask = live != nullptr && L->null_mask != nullptr;
+  if (ext_mask) mask = const_cast<unsigned char*>(L->null_mask);
+  launch_pool(L, d, image, ext_mask ? 2 : 1, mask, pooled, live, st);
   const long nl = (long)d.B * d.n_scales * d.P * d.P;
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
   hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial, live, L->pooled_ones);
@@ -610,6 +614,7 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
   float* pooled; unsigned char* mask; float2* partial;
   carve(L, const_cast<void*>(workspace), &pooled, &mask, &partial);
   const unsigned char* live = live_of(L, d);
+  if (live != nullptr && L->null_mask != nullptr) mask = const_cast<unsigned char*>(L->null_mask);
   static const int abl = std::getenv("SLN_RBWD_ABL") ? std::atoi(std::getenv("SLN_RBWD_ABL")) : 0;      // lab: 1 no stage-1 loads, 2 no stage-2 sums
   static const bool new_sep = std::getenv("SLN_RBWD_NEW") != nullptr;          // lab: the LDS-staged multi-strip kernel (slower so far, see LAB_NOTES)
   static const int rows8 = std::getenv("SLN_RBWD_ROWS") ? std::atoi(std::getenv("SLN_RBWD_ROWS")) : 16;

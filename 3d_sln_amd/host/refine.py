@@ -765,8 +765,12 @@ class RefineBatch:
         # the semantic planes of classes without a visible pixel are zeros, and the scene pass never reads their gradients nor
         # those of such classes' depth-hot planes: the loss skips them (SlnRefineLoss::live_planes, refreshed after every scene pass)
         self.live = torch.full((R, DR.N_SCENE_CHANNELS), 3, dtype=torch.uint8, device=dev)
+        self.null_mask = None
         if not os.environ.get("SLN_REFINE_ALL_PLANES"):
             self.loss.desc.live_planes = self.live.data_ptr()
+            if not os.environ.get("SLN_REFINE_NULL_MASK_APART"):       # (lab switch: the loss computes the null mask itself)
+                self.null_mask = torch.zeros(R, S, S, dtype=torch.uint8, device=dev)
+                self.loss.desc.null_mask = self.null_mask.data_ptr()
             if not os.environ.get("SLN_REFINE_POOL_ONES"):             # (lab switch: pool the constant planes per room)
                 self._pooled_ones = self.loss.pooled_ones()
                 self.loss.desc.pooled_ones = self._pooled_ones.data_ptr()
@@ -821,7 +825,7 @@ class RefineBatch:
         rl = self.loss
         if rl.desc.live_planes:
             _lib.check(L.sln_scene_forward_live(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0,
-                                                1e-3, P(self.scene_ws), P(self.image), P(self.live), st), "sln_scene_forward_live")
+                                                1e-3, P(self.scene_ws), P(self.image), P(self.live), P(self.null_mask), st), "sln_scene_forward_live")
         else:
             _lib.check(L.sln_scene_forward(P(self.faces), P(self.cls), R, self.F2, S, self.chan.numel(), P(self.chan), P(self.dch), 0.1, 0.001, 100.0,
                                            1e-3, P(self.scene_ws), P(self.image), st), "sln_scene_forward")

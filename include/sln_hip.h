@@ -345,7 +345,8 @@ int sln_scene_forward(const float* faces, const int32_t* face_class, int B, int 
  * flagged 1 the constant 1: their memory is left as it was). */
 int sln_scene_forward_live(const float* faces, const int32_t* face_class, int B, int F, int image_size, int num_classes,
                            const int32_t* class_channel, const int32_t* class_depth_channel, float near_depth, float near_rgb,
-                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live, void* stream);
+                           float far, float tex_eps, void* workspace, float* final_out, unsigned char* live,
+                           unsigned char* null_mask /* optional [B, S, S]: SlnRefineLoss::null_mask */, void* stream);
 /* live [B, 70] (bytes) of the last sln_scene_forward on `workspace`, two bits per channel: bit 0 clear = the plane is all zeros
  * (semantic channels of classes without a visible pixel in that image), bit 1 clear = sln_scene_backward never reads the
  * plane's gradient (those, and the depth-hot planes of such classes, which hold the constant 1).  The refinement loss skips
@@ -454,6 +455,9 @@ typedef struct {
                                                  * bit 0 clear - the plane is all zeros: forward writes its pooled plane as zeros
                                                  * without reading it; bit 1 clear - nobody reads the plane's gradient: backward
                                                  * leaves that plane of grad_image as it is.  NULL: every plane is processed. */
+  const unsigned char* null_mask;               /* optional [B, S, S] (device), with live_planes: 1 where the 29 depth-hot values of the pixel sum
+                                                 * to < 0.5 (test_render_refine.py:332), as sln_scene_forward_live writes it - the loss then
+                                                 * does not compute it */
   const float* pooled_ones;                     /* optional [n_scales, P, P] (device): sln_refine_pool of an all-ones plane.  With live_planes,
                                                  * the planes flagged "constant 1" are then not pooled per image: the loss reads this table */
 } SlnRefineLoss;

@@ -611,6 +611,7 @@ def test_sparse_scene_image_and_its_flags_describe_the_full_image():
                    "sln_scene_live_channels")
         torch.cuda.synchronize()
         live, img = rb.live.cpu().numpy(), rb.image.cpu().numpy()
+        null_mask = rb.null_mask.cpu().numpy()
         rb.close()
     full, flags = full.cpu().numpy(), flags.cpu().numpy()
     assert set(np.unique(flags).tolist()) <= {0, 1, 3}
@@ -623,6 +624,8 @@ def test_sparse_scene_image_and_its_flags_describe_the_full_image():
             elif flags[b, ch] == 1:
                 assert (full[b, ch] == 1.0).all(), (b, ch)
     assert (full != -7.0).all()
+    # the null mask the compose kernel hands to the loss (SlnRefineLoss::null_mask): where the depth-hot values of a pixel sum to < 0.5
+    assert np.array_equal(null_mask.astype(bool), full[:, 41:].astype(np.float64).sum(1) < 0.5)
     # the batch's own render of the same faces (rb.faces is rewritten by the next iteration's placement only)
     assert np.array_equal(live, flags)
     for b in range(live.shape[0]):
