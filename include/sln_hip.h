@@ -452,9 +452,12 @@ typedef struct {
   int per_room;                                 /* != 0: the B images are B independent rooms (one refinement loop each): loss_out is
                                                  * [B][3], every room's L1 mean runs over its own elements, inv_count is [B][n_scales] */
   const unsigned char* live_planes;             /* optional [B, channels] (device), as written by sln_scene_live_channels for `image`:
-                                                 * bit 0 clear - the plane is all zeros: forward writes its pooled plane as zeros
-                                                 * without reading it; bit 1 clear - nobody reads the plane's gradient: backward
-                                                 * leaves that plane of grad_image as it is.  NULL: every plane is processed. */
+                                                 * bit 0 clear - the plane is all zeros: forward does not read it (a semantic plane
+                                                 * enters the cross-entropy as zeros, unpooled; a depth-hot plane gets a zero pooled
+                                                 * plane); value 1 - the plane is the constant 1: pooled from 1.f without loads (or not at
+                                                 * all, see pooled_ones); bit 1 clear - nobody reads the plane's gradient: backward
+                                                 * leaves that plane of grad_image as it is.  NULL: every plane is processed.  Honoured
+                                                 * for the shapes of the refinement loop (P <= 96, 40 semantic channels), ignored else. */
   const unsigned char* null_mask;               /* optional [B, S, S] (device), with live_planes: 1 where the 29 depth-hot values of the pixel sum
                                                  * to < 0.5 (test_render_refine.py:332), as sln_scene_forward_live writes it - the loss then
                                                  * does not compute it */
