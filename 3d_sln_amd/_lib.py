@@ -211,6 +211,7 @@ SIGNATURES = {
     "sln_refine_sgd_rooms": (C.c_int, [c_f32p, c_f32p, C.c_int, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int, C.c_float, c_f32p, c_f32p,
                                        C.c_int64, C.c_float, C.c_void_p]),
     "sln_refine_loss_workspace_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "sln_refine_loss_live_ok": (C.c_int, [C.POINTER(SlnRefineLoss)]),
     "sln_refine_loss_init": (C.c_int, [C.POINTER(SlnRefineLoss), C.c_void_p, C.c_void_p]),
     "sln_refine_pool": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, C.c_int, C.c_void_p, c_f32p, C.c_void_p]),
     "sln_refine_loss_forward": (C.c_int, [C.POINTER(SlnRefineLoss), c_f32p, c_f32p, C.c_void_p, c_f32p, C.c_void_p, c_f32p, C.c_void_p]),

@@ -580,6 +580,17 @@ int sln_refine_pool(const SlnRefineLoss* L, const float* image, int null_fill, v
   return 0;
 }
 
+// 1 when live_planes (and with it null_mask / pooled_ones) of this descriptor would be honoured - the shapes the LDS pooling kernel
+// and the separable backward kernel take; 0 when every plane is processed regardless.  A producer that leaves dead planes of the
+// image unwritten (sln_scene_forward_live) must not be paired with a loss that reads them: ask first.
+int sln_refine_loss_live_ok(const SlnRefineLoss* L) {
+  if (check(L)) return 0;
+  SlnRefineLoss probe = *L;
+  static const unsigned char one = 1;
+  probe.live_planes = &one;                       // (only compared against NULL)
+  return live_of(&probe, dims_of(&probe)) != nullptr ? 1 : 0;
+}
+
 int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const float* target_depth_pooled, const int32_t* labels,
                             const float* inv_count, void* workspace, float* loss_out, void* stream) {
   int r = check(L);

@@ -766,7 +766,9 @@ class RefineBatch:
         # those of such classes' depth-hot planes: the loss skips them (SlnRefineLoss::live_planes, refreshed after every scene pass)
         self.live = torch.full((R, DR.N_SCENE_CHANNELS), 3, dtype=torch.uint8, device=dev)
         self.null_mask = None
-        if not os.environ.get("SLN_REFINE_ALL_PLANES"):
+        # (only when the loss takes the flags for this geometry - image sizes below the pooled size do not: it would read planes
+        #  the sparse scene pass leaves unwritten)
+        if not os.environ.get("SLN_REFINE_ALL_PLANES") and L.sln_refine_loss_live_ok(C.byref(self.loss.desc)):
             self.loss.desc.live_planes = self.live.data_ptr()
             if not os.environ.get("SLN_REFINE_NULL_MASK_APART"):       # (lab switch: the loss computes the null mask itself)
                 self.null_mask = torch.zeros(R, S, S, dtype=torch.uint8, device=dev)

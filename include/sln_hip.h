@@ -465,6 +465,10 @@ typedef struct {
                                                  * the planes flagged "constant 1" are then not pooled per image: the loss reads this table */
 } SlnRefineLoss;
 int64_t sln_refine_loss_workspace_bytes(int B, int image_size, int pooled_size, int n_scales, int n_sem, int n_dep);
+/* 1 when live_planes / null_mask / pooled_ones of L would be honoured (the refinement loop's shapes), 0 when every plane is processed
+ * whatever they say: a producer that leaves dead planes unwritten (sln_scene_forward_live) must only be paired with a loss that
+ * does not read them */
+int sln_refine_loss_live_ok(const SlnRefineLoss* L);
 int sln_refine_loss_init(const SlnRefineLoss* L /* host struct */, void* workspace, void* stream);   /* validates L; once per workspace */
 /* The resampling alone: pooled_out [B][n_scales][n_sem + n_dep][P][P] of `image` (null_fill != 0: with the null-fill of the
  * last depth channel).  The caller derives the target's pooled depth and labels from it, so that regions where the iterate

@@ -698,3 +698,34 @@ def test_the_side_stream_of_a_caller_stream_overlaps_with_it():
     assert all(0 <= i < 4 for i, _ in seen), seen
     assert all(o == 1 for _, o in seen), "a side stream that does not overlap with its caller stream: %s" % (seen,)
     del junk
+
+
+def test_rooms_in_flight_at_an_image_size_the_sparse_loss_path_does_not_take():
+    """64 x 64 renders are UP-sampled to the 96 x 96 pooled maps: an image pixel feeds more pooled pixels than the register-list
+    backward kernel holds, the loss ignores live_planes there (sln_refine_loss_live_ok = 0) - the batch must then render every
+    plane (not the sparse scene pass, whose dead planes the loss would read) and still equal the one-room loop."""
+    R = pkg("host.refine"); M = pkg("host.Sg2ScVAE_model")
+    import ctypes as C
+    _lib = pkg("_lib"); L = _lib.lib()
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, mlp_normalization="batch")
+    model, sd = _room_model(cfg)
+    rooms = _random_rooms(2, cfg, seed=31)
+    bank = R.MeshBank(FURN, "cuda", seed=3)
+    kw = dict(bank=bank, learning_rate=1e-3, image_size=64, iters=2)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        rb = R.RefineBatch(model, rooms, **kw)
+        took_flags = bool(rb.loss.desc.live_planes)
+        assert took_flags == bool(L.sln_refine_loss_live_ok(C.byref(rb.loss.desc)))
+        losses = rb.run().cpu().numpy().copy()
+        res = [(b.cpu().numpy().copy(), i.cpu().numpy().copy()) for b, i in rb.results()]
+        rb.close()
+        for r in range(2):
+            m1 = M.Sg2ScVAEModel(**cfg.model_kwargs()); m1.load_state_dict(sd); m1 = m1.cuda().eval()
+            rm = rooms[r]
+            l1, (b1, i1) = R.finetune_vae_fast(m1, rm["objs"], rm["triples"], rm["boxes"], rm["angles"], rm["attributes"], rm["class_names"], iters=2,
+                                               bank=bank, learning_rate=1e-3, image_size=64)
+            assert_close(losses[:, r], l1.cpu().numpy(), "losses of room %d vs finetune_vae_fast" % r, rtol=1e-5)
+            assert_close(res[r][0], b1.cpu().numpy(), "boxes of room %d" % r, rtol=1e-5, atol=1e-6)
+    torch.cuda.synchronize()
+    assert not took_flags, "expected the all-planes path at this size (if the kernels learnt to take it, this test needs another size)"
