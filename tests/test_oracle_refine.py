@@ -1,6 +1,6 @@
-"""Known-answer tests of oracle/refine_ref.py (CPU): the restated object loop of mesh_render_func and the refinement loss.
-The reference files cannot be imported here (neural_renderer / pymesh), so the restatement is held to cases whose answer
-follows from the cited statements by hand."""
+"""Known-answer tests of oracle/refine_ref.py (CPU): the restated object loop of mesh_render_func and the refinement loss on cases
+whose answer follows from the cited statements by hand.  (tests/test_oracle_refine_golden.py holds the same functions to fixtures made
+by executing the reference's own source.)"""
 import math
 
 import numpy as np
