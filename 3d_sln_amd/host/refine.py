@@ -67,23 +67,109 @@ class MeshBank:
                                      bbox_min=v.min(0).values, bbox_max=v.max(0).values)
 
 
+    vocab = None        # class list of the scene tensor's planes (object_idx_to_name[1:], diff_render.py:65); None: synthetic.FURNITURE
+    shell = None        # wall / floor / ceiling meshes + their table boxes (see from_arrays); None: quads built from the room box
+
     @classmethod
-    def from_arrays(cls, meshes, device):
+    def from_arrays(cls, meshes, device, vocab=None, shell=None):
         """Caller-supplied meshes - the seam of models/diff_render.py:62,131, where the reference hands the retrieved SUNCG model's
-        vertices / faces to the placement: ``meshes`` = {class name: (V [n,3] float, F [m,3] int)} (one model per class, any
-        topology; faces index V).  The bounding box the placement scales by is the vertices' own (models/misc.py:88-94 reads it from
-        the model table)."""
+        vertices / faces to the placement: ``meshes`` = {class name: (V [n,3] float, F [m,3] int)} or (V, F, bbox_min, bbox_max)
+        (one model per class, any topology; faces index V).  The bounding box the placement scales by is the model table's
+        (diff_render.py:106-115 read ``bbox_min`` / ``bbox_max`` of suncg_data) - the vertices' own when none is given.
+        ``vocab``: the class list that lays out the 70 planes (``object_idx_to_name[1:]``, diff_render.py:65-69,372-379).
+        ``shell``: the room's retrieved wall / floor / ceiling (diff_render.py:166-342) as arrays - dict(wall_v [n,3], wall_f = list of
+        [m,3] sub-meshes over wall_v (models/misc.py:84-104), wall_bbox [2,3], floor_v, floor_f, floor_bbox [2,3], ceil_v, ceil_f);
+        without it the shell is five quads on the room box."""
         bank = cls.__new__(cls)
         bank.models = {}
-        for name, (V, F) in meshes.items():
+        for name, mesh in meshes.items():
+            V, F = mesh[0], mesh[1]
             v = torch.as_tensor(np.asarray(V, dtype=np.float32)).reshape(-1, 3).to(device)
             f = torch.as_tensor(np.asarray(F).astype(np.int32)).reshape(-1, 3).to(device)
             if v.shape[0] == 0 or f.shape[0] == 0:
                 raise ValueError("mesh of class %r is empty" % (name,))
             if int(f.min()) < 0 or int(f.max()) >= v.shape[0]:
                 raise IndexError("faces of class %r index vertices outside [0, %d)" % (name, v.shape[0]))
-            bank.models[name] = dict(v=v.contiguous(), f=f.contiguous(), bbox_min=v.min(0).values, bbox_max=v.max(0).values)
+            lo = torch.as_tensor(np.asarray(mesh[2], dtype=np.float32)).to(device) if len(mesh) > 2 else v.min(0).values
+            hi = torch.as_tensor(np.asarray(mesh[3], dtype=np.float32)).to(device) if len(mesh) > 3 else v.max(0).values
+            bank.models[name] = dict(v=v.contiguous(), f=f.contiguous(), bbox_min=lo, bbox_max=hi)
+        bank.vocab = list(vocab) if vocab is not None else None
+        if shell is not None:
+            sh = {k: (np.asarray(shell[k], dtype=np.float32) if not k.endswith("_f") else None) for k in shell}
+            sh["wall_f"] = [np.asarray(f).astype(np.int64).reshape(-1, 3) for f in shell["wall_f"]]
+            sh["floor_f"], sh["ceil_f"] = (np.asarray(shell[k]).astype(np.int64).reshape(-1, 3) for k in ("floor_f", "ceil_f"))
+            for f, nv, what in [(f, sh["wall_v"].shape[0], "wall") for f in sh["wall_f"]] + [(sh["floor_f"], sh["floor_v"].shape[0], "floor"),
+                                                                                                (sh["ceil_f"], sh["ceil_v"].shape[0], "ceiling")]:
+                if f.size and (int(f.min()) < 0 or int(f.max()) >= nv):
+                    raise IndexError("faces of the %s index vertices outside [0, %d)" % (what, nv))
+            bank.shell = sh
         return bank
+
+
+def _classes_of(bank):
+    return list(bank.vocab) if getattr(bank, "vocab", None) is not None else list(synthetic.FURNITURE)
+
+
+_PROCEDURAL_SHELL = ("floor", "ceiling", "wall", "wall", "wall")
+_SHELL_DIV = 6
+
+
+def shell_topology(bank):
+    """[(class, vertex count, faces [m,3] int64 numpy)] of the room shell in buffer order - does not depend on the room."""
+    sh = getattr(bank, "shell", None)
+    if sh is None:
+        unit = np.zeros(3), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+        v, f = synthetic._grid_quad(unit[0], unit[1], unit[2], _SHELL_DIV)
+        return [(nm, v.shape[0], f.astype(np.int64)) for nm in _PROCEDURAL_SHELL]
+    # reference order (diff_render.py:166-342): every wall sub-mesh with its own copy of the wall's vertices, the floor, the ceiling
+    return ([("wall", sh["wall_v"].shape[0], f) for f in sh["wall_f"]] +
+            [("floor", sh["floor_v"].shape[0], sh["floor_f"]), ("ceiling", sh["ceil_v"].shape[0], sh["ceil_f"])])
+
+
+def _scaled_into_room(v, scale, model_center, center):
+    """diff_render.py:188-200: [I | center - scale * model_center] x diag(scale) as two 4x4 matrices applied to the homogeneous
+    vertices - in fp32 on the host with the reference's operation order, so that the shell's vertices are the reference's bit for bit"""
+    move, grow = torch.eye(4), torch.eye(4)
+    move[:3, 3] = center - scale * model_center
+    grow[:3, :3] = grow[:3, :3] * scale
+    hom = torch.cat((v.t(), torch.ones(1, v.shape[0])), 0)
+    return torch.matmul(torch.matmul(move, grow)[:3], hom).t().contiguous()
+
+
+def place_shell(bank, room_ext):
+    """Vertices of the room shell in room coordinates, [sum of shell_topology's vertex counts, 3] fp32 on the host.
+    Procedural bank: floor, ceiling, back / left / right wall on the room box.  Bank with shell tables: diff_render.py:166-342 - the
+    walls are scaled isotropically by the LARGEST ratio of room extent to the table's wall box and centred in the room, a wall
+    sub-mesh that comes closer to the camera than 0.9 of the depth while its mean x lies in the middle 80 % of the width is dropped
+    (:203-213; here: its vertices collapse to one point, so that the face list keeps its shape and order); floor: x / z ratios, y = 0;
+    ceiling: x / z ratios of its own bounding box, resting on the room's height.  One-off per room: the room row is frozen (:55-60)."""
+    sh = getattr(bank, "shell", None)
+    room = [float(x) for x in room_ext]
+    if sh is None:
+        quads = [((0, 0, 0), (0, 0, room[2]), (room[0], 0, 0)), ((0, room[1], 0), (room[0], 0, 0), (0, 0, room[2])),
+                 ((0, 0, 0), (room[0], 0, 0), (0, room[1], 0)), ((0, 0, 0), (0, room[1], 0), (0, 0, room[2])),
+                 ((room[0], 0, 0), (0, 0, room[2]), (0, room[1], 0))]               # floor, ceiling, three walls (the order of shell_topology)
+        sv = [synthetic._grid_quad(np.array(p0, np.float64), np.array(du, np.float64), np.array(dv, np.float64), _SHELL_DIV)[0] for p0, du, dv in quads]
+        return torch.from_numpy(np.concatenate(sv).astype(np.float32))
+    ext = torch.tensor(room, dtype=torch.float32)
+    T = torch.from_numpy
+    lo, hi = T(sh["wall_bbox"][0]), T(sh["wall_bbox"][1])
+    wall = _scaled_into_room(T(sh["wall_v"]), torch.max(ext / (hi - lo)), (lo + hi) / 2.0, ext / 2.0)
+    parts = []
+    for f in sh["wall_f"]:
+        fz, fx = wall[:, 2][T(f)], wall[:, 0][T(f)]
+        drop = f.shape[0] > 0 and bool(fz.max() > 0.9 * ext[2]) and bool(fx.mean() > 0.1 * ext[0]) and bool(fx.mean() < 0.9 * ext[0])
+        parts.append(torch.zeros_like(wall) if drop else wall)
+    lo, hi = T(sh["floor_bbox"][0]), T(sh["floor_bbox"][1])
+    span = hi - lo
+    parts.append(_scaled_into_room(T(sh["floor_v"]), torch.max(ext[0] / span[0], ext[2] / span[2]), (lo + hi) / 2.0,
+                                   torch.stack((ext[0] / 2.0, ext.new_zeros(()), ext[2] / 2.0))))
+    cv = T(sh["ceil_v"])
+    hi, lo = cv.max(0).values, cv.min(0).values
+    span = hi - lo
+    scale = torch.max(ext[0] / span[0], ext[2] / span[2])
+    parts.append(_scaled_into_room(cv, scale, (lo + hi) / 2.0, torch.stack((ext[0] / 2.0, 0.5 * (scale * span)[1] + ext[1], ext[2] / 2.0))))
+    return torch.cat(parts).contiguous()
 
 
 def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=None):
@@ -91,7 +177,7 @@ def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=N
     face_buf [1,F,3] int32, class_ranges, obj sizes, size_loss.  ``boxes`` [n,6] in room-normalised units with the
     room row last, ``angles`` [n] in bins, ``room_box`` the frozen room row (6,)."""
     dev = boxes.device
-    ranges = {c: [] for c in synthetic.FURNITURE}
+    ranges = {c: [] for c in _classes_of(bank)}
     ranges.update(wall=[], floor=[], ceiling=[])
     verts, faces, sizes, voff, foff = [], [], [], 0, 0
     size_loss = boxes.new_zeros(())
@@ -115,18 +201,15 @@ def assemble_scene(boxes, angles, class_names, bank, room_box, obj_size_target=N
         trans = center - scale * torch.matmul(rot, mcenter)
         v = torch.matmul(m["v"], (rot * scale).t()) + trans
         verts.append(v); faces.append(m["f"] + voff)
-        ranges[name].append([foff, foff + m["f"].shape[0]])
+        ranges.setdefault(name, []).append([foff, foff + m["f"].shape[0]])
         voff += v.shape[0]; foff += m["f"].shape[0]
-    # room shell from the frozen room box (the reference retrieves wall/floor/ceiling meshes and scales them to it)
-    room = [float(x) for x in room_box[3:]]
-    shell = [("floor", (0, 0, 0), (0, 0, room[2]), (room[0], 0, 0)), ("ceiling", (0, room[1], 0), (room[0], 0, 0), (0, 0, room[2])),
-             ("wall", (0, 0, 0), (room[0], 0, 0), (0, room[1], 0)), ("wall", (0, 0, 0), (0, room[1], 0), (0, 0, room[2])),
-             ("wall", (room[0], 0, 0), (0, 0, room[2]), (0, room[1], 0))]
-    for nm, p0, du, dv in shell:
-        v, f = synthetic._grid_quad(np.array(p0, np.float64), np.array(du, np.float64), np.array(dv, np.float64), 6)
-        verts.append(torch.from_numpy(v.astype(np.float32)).to(dev)); faces.append(torch.from_numpy(f.astype(np.int32)).to(dev) + voff)
+    # room shell for the frozen room box (diff_render.py:166-342; see place_shell)
+    shell_v = place_shell(bank, room_box[3:].detach().cpu().tolist()).to(dev)
+    at = 0
+    for nm, nv, f in shell_topology(bank):
+        verts.append(shell_v[at:at + nv]); faces.append(torch.from_numpy(f.astype(np.int32)).to(dev) + voff)
         ranges[nm].append([foff, foff + f.shape[0]])
-        voff += v.shape[0]; foff += f.shape[0]
+        voff += nv; foff += f.shape[0]; at += nv
     return torch.cat(verts)[None], torch.cat(faces)[None], ranges, sizes, size_loss
 
 
@@ -423,11 +506,7 @@ class RefineScene:
         Vm = self._Vm
         room_host = [float(x) for x in room_box.detach().cpu().tolist()]           # one device -> host copy per scene
         room = room_host[3:]
-        shell = [((0, 0, 0), (0, 0, room[2]), (room[0], 0, 0)), ((0, room[1], 0), (room[0], 0, 0), (0, 0, room[2])),
-                 ((0, 0, 0), (room[0], 0, 0), (0, room[1], 0)), ((0, 0, 0), (0, room[1], 0), (0, 0, room[2])),
-                 ((room[0], 0, 0), (0, 0, room[2]), (0, room[1], 0))]               # floor, ceiling, three walls (the order of _static_part)
-        sv = [synthetic._grid_quad(np.array(p0, np.float64), np.array(du, np.float64), np.array(dv, np.float64), 6)[0] for p0, du, dv in shell]
-        self.shell_v = torch.from_numpy(np.concatenate(sv).astype(np.float32)).to(dev)
+        self.shell_v = place_shell(bank, room).to(dev)                             # (the order of shell_topology / _static_part)
         Kc, Rc, tc = DR.get_cam_mat([room_host], "cpu")
         self.K, self.R, self.t = Kc.to(dev), Rc.to(dev), tc.to(dev)
         # descriptor of the fused placement kernels (csrc/placement.hip)
@@ -452,18 +531,16 @@ class RefineScene:
             mv[k, :m["v"].shape[0]] = m["v"]
         msize = torch.stack([m["bbox_max"] - m["bbox_min"] for m in models]) if models else torch.ones(1, 3, device=dev)
         mcenter = torch.stack([(m["bbox_min"] + m["bbox_max"]) / 2.0 for m in models]) if models else torch.zeros(1, 3, device=dev)
-        ranges = {c: [] for c in synthetic.FURNITURE}
+        ranges = {c: [] for c in _classes_of(bank)}
         ranges.update(wall=[], floor=[], ceiling=[])
         faces, foff = [], 0
         for k, (i, m) in enumerate(zip(vis, models)):
             faces.append(m["f"].long() + k * Vm)
             ranges.setdefault(class_names[i], []).append([foff, foff + m["f"].shape[0]]); foff += m["f"].shape[0]
         voff = n_vis * Vm
-        unit = np.zeros(3), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])            # the quads' topology does not depend on their corners
-        for nm in ("floor", "ceiling", "wall", "wall", "wall"):
-            v, f = synthetic._grid_quad(unit[0], unit[1], unit[2], 6)
+        for nm, nv, f in shell_topology(bank):                                 # topology only: the corners are the room's (place_shell)
             faces.append(torch.from_numpy(f.astype(np.int64)).to(dev) + voff)
-            ranges[nm].append([foff, foff + f.shape[0]]); voff += v.shape[0]; foff += f.shape[0]
+            ranges[nm].append([foff, foff + f.shape[0]]); voff += nv; foff += f.shape[0]
         faces = torch.cat(faces)                                             # [F,3] into the flattened vertex list
         faces32 = faces.to(torch.int32)[None].contiguous()
         classes, chan, dch = DR.class_tables(ranges.keys())
@@ -539,7 +616,7 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
         target, _, sizes = scene.render(boxes_gt, angles_gt.float())
     labels = target_labels(target)
     fused = RefineLoss(target) if fused_loss else None             # the PSP / L1 / cross-entropy block as two C calls
-    size_target = sizes.detach().clone()
+    size_target = sizes.detach().clone()                           # (a buffer: filled with the FIRST iterate's sizes below)
     n = boxes_gt.shape[0]
     noise = torch.zeros(n, device=dev)
     # the soft-argmax noise of every iteration, drawn in the reference's order (one randn(n) per iteration) but uploaded once:
@@ -553,6 +630,16 @@ def finetune_vae_fast(model, objs, triples, boxes_gt, angles_gt, attributes, cla
     angle_last = angles_gt[-1:].detach().float().contiguous()
     if fused_head:
         flat_grad.zero_()                                  # from here on the update kernel leaves the gradient buffer zeroed
+    if iters > 0 and scene.n_vis:
+        # the size penalty holds the objects to the sizes of the FIRST iterate (test_render_refine.py:319-327: size_infos is what the
+        # first mesh_render_func call on boxes_pred returns; the target render's sizes are discarded): one decoder + placement pass
+        # with iteration 0's z, parameters and noise row.  Iteration 0 then measures its own sizes against themselves - a size loss
+        # of exactly 0 with zero gradient, which is the reference's ``size_loss = 0.0`` of the first call.
+        with torch.no_grad():
+            bp0, ap0 = model.decoder(z, objs, triples, attributes)
+            b0 = torch.cat([bp0[:-1], boxes_gt[-1:]], 0)
+            i0 = torch.cat([(softargmax(ap0, sum_dim=1) + noise_all[0] / 10.0)[:-1], angles_gt[-1:].float()], 0)
+            size_target.copy_(_PlaceFn.apply(b0, i0, scene, None)[2])
 
     def iteration():
         boxes_pred, angles_pred = model.decoder(z, objs, triples, attributes)
@@ -808,6 +895,26 @@ class RefineBatch:
         self._graph = None
         self.k = 0
         tick("tables, buffers")
+        if self.iters > 0:
+            self._first_iterate_sizes()
+            tick("first iterate's sizes")
+
+    def _first_iterate_sizes(self):
+        """The size penalty holds every object to the size of the FIRST iterate (testing/test_render_refine.py:319-327: ``size_infos`` is
+        what the first ``mesh_render_func`` call on ``boxes_pred`` returns; the sizes of the target render are ``unused_sizes``): one
+        decoder + head + placement forward of all rooms with iteration 0's z, parameters and noise row, whose ``sizes`` become the
+        rooms' targets.  Iteration 0 then measures its own sizes against themselves: a size loss of exactly 0 with zero gradient - the
+        reference's ``size_loss = 0.0`` of a first call."""
+        L, st, P = _lib.lib(), _lib.current_stream_ptr(), _lib.ptr
+        _lib.check(L.sln_vae_group_decoder(self._group, st), "sln_vae_group_decoder")
+        if not self._fused_head:
+            _lib.check(L.sln_refine_head_forward_rooms(self.N, self.model.Nangle, P(self.room_of_row), P(self.last_row), P(self.boxes_pred),
+                                                       P(self.angles_pred), P(self.noise_all[0]), P(self.box_last), P(self.angle_last), 2.0,
+                                                       P(self.boxes), P(self.idx), st), "sln_refine_head_forward_rooms")
+        _lib.check(L.sln_place_forward_rooms(P(self._place_tab), self.R, self.F2 // 2, st), "sln_place_forward_rooms")
+        for r, sc in enumerate(self.scenes):
+            if sc.n_vis:
+                self._size_targets[r].copy_(self.sizes[r, :sc.n_vis])
 
     def launches(self):
         f, b, s1 = C.c_int(0), C.c_int(0), C.c_int(0)
@@ -975,7 +1082,8 @@ def finetune_vae(model, objs, triples, boxes_gt, angles_gt, attributes, class_na
     with torch.no_grad():
         target = render_fn(v, f, ranges, room_box, image_size=image_size)
     labels = target_labels(target)
-    size_target = [s.clone() for s in sizes]
+    size_target = None                   # the sizes of the FIRST iterate, not the target's (test_render_refine.py:319-327: the target render's
+    #                                      sizes are "unused_sizes"; size_infos is what the first render of boxes_pred returns)
     losses = []
     for k in range(iters):
         opt = torch.optim.SGD([{'params': [z]}, {'params': list(model.parameters()), 'lr': learning_rate / 10.0}], lr=2e-4,
@@ -986,7 +1094,9 @@ def finetune_vae(model, objs, triples, boxes_gt, angles_gt, attributes, class_na
         idx = softargmax(angles_pred, sum_dim=1) + torch.randn(angles_pred.shape[0], generator=gen).to(dev) / 10.0
         idx.register_hook(quad_grad)
         idx = torch.cat([idx[:-1], angles_gt[-1:].float()], 0)
-        v, f, ranges, _, size_loss = assemble_scene(boxes_pred, idx, class_names, bank, room_box, size_target)
+        v, f, ranges, sizes_k, size_loss = assemble_scene(boxes_pred, idx, class_names, bank, room_box, size_target)
+        if size_target is None:
+            size_target = [s.clone() for s in sizes_k]
         image = render_fn(v, f, ranges, room_box, image_size=image_size)
         loss, dl, sl = refinement_loss(image, target, labels, size_loss)
         opt.zero_grad()

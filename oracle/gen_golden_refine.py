@@ -240,7 +240,7 @@ def gen_scene():
     tables = synth_tables()
     out = _tables_to_arrays(tables)
     for tag, S, seed, n_obj in (("s64", 64, 3, 5), ("s256", 256, 4, 8)):
-        ns, _ = reference_namespaces(tables, S)
+        ns, ns2 = reference_namespaces(tables, S)
         objs, boxes, angles = synth_room(seed, n_obj)
         B = [torch.from_numpy(b.copy()) for b in boxes]
         A = [torch.tensor(float(a)) for a in angles]
@@ -266,6 +266,15 @@ def gen_scene():
                     p + "grad_boxes_size": b2.grad.numpy(), p + "grad_angles_size": (a2.grad if a2.grad is not None else torch.zeros_like(a2)).numpy(),
                     p + "target_summary": _image_summary(tgt), p + "image_summary": _image_summary(img)})
         assert ids2 == {} and sizes2 == []
+        # the loss statements of the loop (:328-350) on (iterate, target), and the gradient they send back into the image
+        lv, ld, ls, gimg = reference_loss(ns2, img.detach(), tgt.detach())
+        out.update({p + "loss": np.float64(lv), p + "loss_depth": np.float64(ld), p + "loss_sem": np.float64(ls)})
+        gd = gimg.double()[0]
+        out[p + "grad_image_summary"] = torch.stack([gd.sum((1, 2)), gd.abs().sum((1, 2)), (gd * gd).sum((1, 2))], 1).numpy()
+        if S <= 64:
+            out[p + "grad_image"] = gimg.numpy()
+        else:
+            out[p + "grad_image_sub"] = gimg.numpy()[:, :, 1::4, 2::4]
         if S <= 64:
             out[p + "target"], out[p + "image"] = tgt.detach().numpy(), img.detach().numpy()
         else:                                      # 256^2: every 4th row / column of every plane + the summaries above
@@ -294,6 +303,33 @@ def _k_loop(finetune_node):
                 break
     assert done == 1
     return ast.fix_missing_locations(loop)
+
+
+def _loss_block(finetune_node):
+    """the statements of the loop body from the null fill (:329) to ``loss_val = depth_loss*100 + semantic_loss*100`` (:350), as a module"""
+    loop = _k_loop(finetune_node)
+    for parent in ast.walk(loop):
+        body = getattr(parent, "body", None)
+        if not isinstance(body, list):
+            continue
+        src = [ast.unparse(st) for st in body]
+        a = [i for i, t in enumerate(src) if t.startswith("iter_image[:, -1][")]
+        b = [i for i, t in enumerate(src) if t.startswith("loss_val = depth_loss * 100")]
+        if a and b:
+            return ast.fix_missing_locations(ast.Module(body=body[a[0]:b[0] + 1], type_ignores=[]))
+    raise SystemExit("loss block not found")
+
+
+def reference_loss(ns2, image, target):
+    """runs the reference's loss statements on (iterate, target) -> (loss_val, depth_loss, semantic_loss, d loss_val / d image)"""
+    leaf = image.clone().requires_grad_(True)
+    env = dict(ns2)
+    node = env.pop("_finetune_node")
+    env.update(iter_image=leaf * 1.0, target=target, target_mesh=None, long_dtype=torch.LongTensor, orig_scaler=0.5)
+    import copy
+    exec(compile(_loss_block(copy.deepcopy(node)), "testing/test_render_refine.py", "exec"), env)
+    env["loss_val"].backward()
+    return float(env["loss_val"].detach()), float(env["depth_loss"].detach()), float(env["semantic_loss"].detach()), leaf.grad
 
 
 LOOP_CFG = dict(embedding_dim=32, gconv_num_layers=2, num_objs=len(VOCAB) + 1)

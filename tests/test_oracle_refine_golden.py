@@ -125,3 +125,15 @@ def test_refine_loop_matches_the_reference_loop(r):
         name = key[len(p) + 6:]
         p0 = g["state:" + name]
         _close(sd[name].detach().numpy() - p0, g[key][-1] - p0, 1e-3, "four steps of " + name)
+
+
+def test_refinement_loss_matches_the_reference_statements():
+    """the loop's loss statements (:328-350) run by the generator on (iterate, target) of the 64^2 scene: value, parts, d / d image"""
+    g = _load("refine_scene.npz")
+    img = torch.from_numpy(g["s64:image"]).requires_grad_(True)
+    tgt = torch.from_numpy(g["s64:target"])
+    loss, depth, sem = rf.refinement_loss(img * 1.0, tgt, rf.target_labels(tgt), torch.zeros(()))
+    loss.backward()
+    _close(float(loss.detach()), float(g["s64:loss"]), 1e-6, "loss"); _close(float(depth.detach()), float(g["s64:loss_depth"]), 1e-6, "depth")
+    _close(float(sem.detach()), float(g["s64:loss_sem"]), 1e-6, "sem")
+    _close(img.grad, g["s64:grad_image"], 1e-5, "d loss / d image")
