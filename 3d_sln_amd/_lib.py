@@ -126,9 +126,12 @@ SIGNATURES = {
     "sln_vae_group_decoder": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_group_decoder_backward": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sln_vae_group_launches": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sln_vae_group_transposes": (C.c_int64, [C.c_void_p]),
     "sln_vae_group_fused_params": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int]),
     "sln_vae_group_destroy": (None, [C.c_void_p]),
     "sln_debug_side_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "sln_side_stream_prepare": (C.c_int, [C.c_void_p]),
+    "sln_side_stream_forget": (C.c_int, [C.c_void_p]),
     "sln_prof_enable": (C.c_int, [C.c_int]),
     "sln_set_deterministic": (C.c_int, [C.c_int]),
     "sln_get_deterministic": (C.c_int, []),
@@ -169,6 +172,7 @@ SIGNATURES = {
     "sln_scene_forward_live": (C.c_int, [c_f32p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, c_f32p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sln_spade_prepare": (C.c_int, [C.c_void_p]),
+    "sln_spade_release": (C.c_int, [C.c_void_p, C.c_int]),
     "sln_spade_conv": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, C.c_int, C.c_int,
                                  C.c_float, c_f32p, C.c_void_p]),
     "sln_spade_modulate": (C.c_int, [c_f32p, C.c_int, C.c_int, C.c_int, C.c_int, c_f32p, c_f32p, C.c_int, C.c_int, c_f32p, c_f32p,

@@ -104,7 +104,11 @@ struct ZState { float z; int idx; float w0, w1, w2; };
 // default near=0.1 while its class passes use the constructor's near, SURVEY.md 2.1 "known asymmetry").
 // (statistics of the fused scene pass: defined here because the tile kernel's TEX form takes them along)
 constexpr int DET_BANDS = 16;        // row bands of the deterministic masked sums (scene_bwd_masked_sums_det_kernel)
-struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int det_ticket; int pad_; float det_part[DET_BANDS][64]; };
+// vis[c]: some pixel of the class pass belongs to a face of class c - the predicate under which scene_compose writes the class's
+// semantic plane and scene_bwd_maps reads its gradient; cnt[c] counts the pixels that also pass the 0.1 mask of diff_render.py:403
+// (the same set while the class textures are all ones: the sample is 1).  The live flags of the semantic planes follow vis, those of
+// the depth-hot planes cnt (an empty mask makes the plane the constant mean / wall_max without a gradient, :412-421).
+struct SceneStats { double sum[64]; double cnt[64]; double gsum[64]; int wall_key; int wall_any; int det_ticket; int pad_; float det_part[DET_BANDS][64]; int vis[64]; };
 
 // order-preserving float <-> int key (atomicMax on the key == float max, negatives included)
 __device__ __forceinline__ int fkey(float v) { const int b = __float_as_int(v); return b >= 0 ? b : b ^ 0x7fffffff; }
@@ -230,14 +234,15 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
     // ... and scene_stats_kernel's (per-class depth sums in exact fixed point, visible-face marks, the wall's maximum depth): the
     // tile's sums in LDS, one set of device atomics per tile.  Exact integer / power-of-two arithmetic: the statistics are the
     // same bits as the separate pass gave, whatever the order of the tiles.
-    __shared__ unsigned long long ssum[64]; __shared__ int scnt[64];
+    __shared__ unsigned long long ssum[64]; __shared__ int scnt[64]; __shared__ int svis[64];
     __shared__ int s_wkey, s_wany;
-    if (tid < 64) { ssum[tid] = 0ull; scnt[tid] = 0; }
+    if (tid < 64) { ssum[tid] = 0ull; scnt[tid] = 0; svis[tid] = 0; }
     if (tid == 0) { s_wkey = (int)0x80000000; s_wany = 0; }
     __syncthreads();
     if (inimg && Bz.idx >= 0) {
       const_cast<FaceRec*>(rb)[Bz.idx].pad_[1] = 1;
       const int c = st_cls[(long)b * F + Bz.idx];
+      if (c >= 0 && c < st_nc) svis[c] = 1;
       if (c >= 0 && c < st_nc && class_image_value(tpx[0]) > 0.1f) {
         const float dd = depth_value(A.idx >= 0 ? A.z : far);
         atomicAdd(&ssum[c], (unsigned long long)(long long)rint((double)dd * 4294967296.0)); atomicAdd(&scnt[c], 1);
@@ -249,6 +254,7 @@ __global__ __launch_bounds__(256) void raster_tile_kernel(const FaceRec* __restr
       atomicAdd(&st_out[b].sum[tid], (double)(long long)ssum[tid] * (1.0 / 4294967296.0));
       atomicAdd(&st_out[b].cnt[tid], (double)scnt[tid]);
     }
+    if (tid < st_nc && svis[tid]) st_out[b].vis[tid] = 1;
     if (tid == 0 && s_wany) {
       atomicMax(&st_out[b].wall_any, 1);
       atomicMax(&st_out[b].wall_key, s_wkey);
@@ -1114,10 +1120,10 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
   // integer sum is exact and does not depend on the order the lanes arrive in (the LDS float atomics of rounds 1-2 did, at ulp level,
   // and carried the rounding of a 65 536-term fp32 sum); as a double it is a multiple of 2^-32 below 2^21: the cross-block fp64
   // atomics are exact too.  The statistics of the forward pass are order-independent in every mode.
-  __shared__ unsigned long long ssum[64]; __shared__ int scnt[64];
+  __shared__ unsigned long long ssum[64]; __shared__ int scnt[64]; __shared__ int svis[64];
   __shared__ int s_wkey, s_wany;        // the block's wall maximum: ONE pair of device atomics per block (every wall pixel - a third
                                         // of a room image - used to issue its own pair on the same two words)
-  if (threadIdx.x < 64) { ssum[threadIdx.x] = 0ull; scnt[threadIdx.x] = 0; }
+  if (threadIdx.x < 64) { ssum[threadIdx.x] = 0ull; scnt[threadIdx.x] = 0; svis[threadIdx.x] = 0; }
   if (threadIdx.x == 0) { s_wkey = (int)0x80000000; s_wany = 0; }
   __syncthreads();
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < plane; p += (long)gridDim.x * blockDim.x) {
@@ -1129,6 +1135,7 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
     rec[(long)b * F + f].pad_[1] = 1;       // the face owns a pixel of the class pass (raster_prep_kernel cleared the flag): see pixel_map_backward_kernel
     const int c = cls[(long)b * F + f];
     if (c < 0 || c >= NC) continue;
+    svis[c] = 1;
     if (!(class_image_value(v) > 0.1f)) continue;
     const float dd = depth_value(d);
     atomicAdd(&ssum[c], (unsigned long long)(long long)rint((double)dd * 4294967296.0)); atomicAdd(&scnt[c], 1);
@@ -1142,6 +1149,7 @@ __global__ void scene_stats_kernel(const int32_t* __restrict__ fi_b, const float
     atomicAdd(&st[b].sum[threadIdx.x], (double)(long long)ssum[threadIdx.x] * (1.0 / 4294967296.0));
     atomicAdd(&st[b].cnt[threadIdx.x], (double)scnt[threadIdx.x]);
   }
+  if (threadIdx.x < NC && svis[threadIdx.x]) st[b].vis[threadIdx.x] = 1;
   if (threadIdx.x == 0 && s_wany) {
     atomicMax(&st[b].wall_any, 1);
     atomicMax(&st[b].wall_key, s_wkey);
@@ -1154,7 +1162,7 @@ __device__ __forceinline__ unsigned char scene_live_flag(const SceneStats& sb, c
   unsigned char v = (ch == 0 || ch == nch - 1) ? 3 : 0;
   if (!v) {
     if (ch < 41) {
-      for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && sb.cnt[c] > 0.0) v = 3;
+      for (int c = 0; c < NC; ++c) if (chan[c] + 1 == ch && sb.vis[c] != 0) v = 3;
     } else {
       for (int c = 0; c < NC; ++c) if (dch[c] + 41 == ch) v |= sb.cnt[c] > 0.0 ? 3 : 1;
     }
@@ -1387,8 +1395,9 @@ __device__ __forceinline__ void scene_bwd_grad_planes_body(const int bc, float (
                                                            float* __restrict__ g, float* __restrict__ gT) {
   const int b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
   // a plane is only ever read for the class of a VISIBLE pixel (the reference pixel of a scan): classes without a single
-  // visible pixel in this image (typically half of the 32) are skipped
-  if (!(st[b].cnt[c] > 0.0)) return;
+  // visible pixel in this image (typically half of the 32) are skipped - `vis`, the predicate the scan's reference pixels and the
+  // live flags of the semantic planes use (not the 0.1 mask count)
+  if (st[b].vis[c] == 0) return;
   const long plane = (long)is * is;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const float* src = gout + ((long)b * nch + 1 + chan[c]) * plane;
@@ -1480,7 +1489,7 @@ __global__ void scene_prep_kernel(const float* __restrict__ faces, long n, int i
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (long)B * 64) {
     const int b = (int)(i / 64), k = (int)(i % 64);
-    st[b].sum[k] = 0.0; st[b].cnt[k] = 0.0; st[b].gsum[k] = 0.0;
+    st[b].sum[k] = 0.0; st[b].cnt[k] = 0.0; st[b].gsum[k] = 0.0; st[b].vis[k] = 0;
     if (k == 0) { st[b].wall_key = (int)0x80000000; st[b].wall_any = 0; }
   }
   if (i < n) {

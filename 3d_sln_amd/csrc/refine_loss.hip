@@ -524,6 +524,9 @@ static int check(const SlnRefineLoss* L) {
   if (L->n_sem != 40) return SLN_E_UNSUPPORTED;      // NYU-40 one-hot block of the scene tensor (models/diff_render.py:3)
   if (L->sem0 < 0 || L->dep0 != L->sem0 + L->n_sem || L->dep0 + L->n_dep > L->channels || L->n_dep <= 0) return SLN_E_BADARG;
   if (!L->s2_k0 || !L->s2_k1 || !L->s2_l1 || !L->s1_i0 || !L->s1_i1 || !L->s1_l1 || !L->col_ptr || !L->col_out || !L->col_w) return SLN_E_BADARG;
+  // per_room: a 128-row block of loss_kernel must not cover two rooms (checked here - init and every entry point - so that an
+  // unsupported geometry fails before anything is launched or overwritten)
+  if (L->per_room && ((long)L->n_scales * L->pooled_size * L->pooled_size) % 128 != 0) return SLN_E_UNSUPPORTED;
   return 0;
 }
 
@@ -610,7 +613,6 @@ int sln_refine_loss_forward(const SlnRefineLoss* L, const float* image, const fl
   const dim3 lg((unsigned)((nl + 127) / 128), 1 + sln_cdiv(d.n_dep, DCH));
   hipLaunchKernelGGL((loss_kernel<40>), lg, dim3(128), 0, st, pooled, d, target_depth_pooled, labels, inv_count, partial, live, L->pooled_ones);
   const long per_room_rows = (long)d.n_scales * d.P * d.P;
-  if (d.per_room && per_room_rows % 128 != 0) return SLN_E_UNSUPPORTED;       // a block of loss_kernel would cover two rooms
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(d.per_room ? d.B : 1), dim3(256), 0, st, partial, (int)(lg.x * lg.y), d, loss_out, (int)lg.x,
                      (int)(per_room_rows / 128));
   SLN_CHECK_LAUNCH();

@@ -584,29 +584,59 @@ static int launch_conv_split_finish(const ConvArgs& a, const float* part, int S,
   return 0;
 }
 
-// scratch of the input-channel split: ONE allocation of 128 MB on first use (never during a capture of the caller's stream), never
-// grown or freed - a launch whose partial sums would not fit splits fewer ways
-// One scratch per (device, stream), under a mutex (round 5; it was one process-wide buffer: two calls on two streams - the plane
-// memo of the host mirror is keyed per stream for exactly that use - interleaved their partial sums, and a second GPU of the
-// process dereferenced device 0's memory).  Launches of one stream are ordered, so a stream's buffer needs no further guard.
-// A stream first seen while the caller captures it gets none (an allocation would be recorded): such a launch takes the unsplit
-// path, which rounds differently - run one eager call on the stream (or sln_spade_prepare) before capturing.
-constexpr size_t CONV_PART_BYTES = (size_t)128 << 20;
-struct ConvPartSlot { int dev; hipStream_t st; float* p; };
+// Scratch of the input-channel split.  A split launch has < 192 workgroups of 8 x 16 pixels x <= 128 rows and at most ~(512 + 192)
+// partial workgroups in all: its partial sums are <= 704 x 128 x 128 floats = 46 MB whatever the layer - one slot of 48 MB serves every
+// split launch of a stream (round 5 pinned 128 MB per stream, for ever).
+// One slot per (device, stream), under a mutex: launches of one stream are ordered, so a stream's slot needs no further guard; two
+// streams never share one (their partial sums would interleave).  At most 16 slots (768 MB): the least recently used one is freed
+// for a new stream (hipFree waits for the device, so no launch still reads it); sln_spade_release frees a stream's slot (or all).
+// A slot cannot be allocated while the caller captures the stream: such a launch FAILS with SLN_E_STATE (it used to fall back to
+// the unsplit kernel silently, whose sums round differently - results depended on the process's history): call sln_spade_prepare on
+// the stream (or run one eager forward) before capturing.
+constexpr size_t CONV_PART_BYTES = (size_t)48 << 20;
+constexpr size_t CONV_PART_SLOTS = 16;
+struct ConvPartSlot { int dev; hipStream_t st; float* p; uint64_t used; };
 static std::mutex g_conv_part_mu;
 static std::vector<ConvPartSlot> g_conv_parts;
-static float* conv_part_scratch(hipStream_t st) {
+static uint64_t g_conv_part_clock = 0;
+static int conv_part_scratch(hipStream_t st, float** out) {
+  *out = nullptr;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return SLN_E_STATE;
   std::lock_guard<std::mutex> lk(g_conv_part_mu);
-  for (const ConvPartSlot& e : g_conv_parts) if (e.dev == dev && e.st == st) return e.p;
-  if (g_conv_parts.size() >= 32) return nullptr;                 // 4 GB of scratch: stop growing, later streams run unsplit
+  for (ConvPartSlot& e : g_conv_parts) if (e.dev == dev && e.st == st) { e.used = ++g_conv_part_clock; *out = e.p; return 0; }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return SLN_E_STATE;
+  if (g_conv_parts.size() >= CONV_PART_SLOTS) {
+    size_t lru = 0;
+    for (size_t i = 1; i < g_conv_parts.size(); ++i) if (g_conv_parts[i].used < g_conv_parts[lru].used) lru = i;
+    int cur = dev;
+    if (g_conv_parts[lru].dev != cur) (void)hipSetDevice(g_conv_parts[lru].dev);
+    (void)hipFree(g_conv_parts[lru].p);
+    if (g_conv_parts[lru].dev != cur) (void)hipSetDevice(cur);
+    g_conv_parts.erase(g_conv_parts.begin() + (long)lru);
+  }
   float* p = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&p), CONV_PART_BYTES) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-  g_conv_parts.push_back(ConvPartSlot{dev, st, p});
-  return p;
+  if (hipMalloc(reinterpret_cast<void**>(&p), CONV_PART_BYTES) != hipSuccess) { (void)hipGetLastError(); return SLN_E_NOMEM; }
+  g_conv_parts.push_back(ConvPartSlot{dev, st, p, ++g_conv_part_clock});
+  *out = p;
+  return 0;
+}
+static int conv_part_release(hipStream_t st, bool all) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return SLN_E_STATE;
+  std::lock_guard<std::mutex> lk(g_conv_part_mu);
+  int n = 0;
+  for (size_t i = 0; i < g_conv_parts.size();) {
+    ConvPartSlot& e = g_conv_parts[i];
+    if (all || (e.dev == dev && e.st == st)) {
+      if (e.dev != dev) (void)hipSetDevice(e.dev);
+      (void)hipFree(e.p);
+      if (e.dev != dev) (void)hipSetDevice(dev);
+      g_conv_parts.erase(g_conv_parts.begin() + (long)i); ++n;
+    } else ++i;
+  }
+  return n;
 }
 
 // Batch-1 calls (test_SPADE_shade.py:77-79: one call per z).  The 1 024 / 512-channel layers at 8 x 8 .. 64 x 64 pixels are 8 .. 64
@@ -628,10 +658,10 @@ int launch_conv_split(const ConvArgs& a, hipStream_t st, bool* done) {
   int S = (int)std::min<long>(std::min(split_max, nch / 8), (target + blocks - 1) / blocks);
   S = (int)std::min<size_t>((size_t)S, CONV_PART_BYTES / (one * sizeof(float)));
   if (S <= 1) return 0;
-  float* part = conv_part_scratch(st);
-  if (part == nullptr) return 0;
+  float* part = nullptr;
+  *done = true;                                            // from here on the launch is the split one - or an error, never another kernel
+  { const int r = conv_part_scratch(st, &part); if (r) return r; }
   ConvArgs p = a; p.part = part; p.part_stride = (long)one;
-  *done = true;
   const int r = launch_conv_dma<BMC, KS, CEPI_BIAS_ACT, TH, 4, BLK>(p, st, S);
   return r ? r : launch_conv_split_finish(a, part, S, (long)one, st);
 }
@@ -1295,7 +1325,11 @@ int sln_spade_conv_sums(const float* x, int B, int Cin, int H, int W, const floa
   return big ? launch_conv<128, 1, CEPI_BIAS_ACT>(a, st) : launch_conv<64, 1, CEPI_BIAS_ACT>(a, st);
 }
 int sln_spade_prepare(void* stream) {
-  return conv_part_scratch((hipStream_t)stream) != nullptr ? 0 : SLN_E_NOMEM;
+  float* p = nullptr;
+  return conv_part_scratch((hipStream_t)stream, &p);
+}
+int sln_spade_release(void* stream, int all) {
+  return conv_part_release((hipStream_t)stream, all != 0);
 }
 
 int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,

@@ -1672,6 +1672,25 @@ struct SlnVaeGroup {
   hipStream_t side = nullptr;                      // a pooled stream that overlaps with the caller's (sln_overlapping_stream), per run()
   hipEvent_t ev_fork = nullptr, ev_tr = nullptr, ev_join = nullptr;
   bool tr_pending = false, use_side = true;
+  // W^T of the decoder's weights is built by the forward pass (side stream) and consumed by the backward pass's dgrads.  wt_valid says
+  // that the copy in the engines' workspaces matches the parameters: set by a forward's transposition, cleared when a backward has
+  // run (its fused wgrads - or the caller's optimizer right behind it - step W).  A backward that finds it clear (no forward in
+  // front of it, or a second backward after one forward) transposes first.
+  bool wt_valid = false;
+  int64_t n_transposes = 0;        // W^T builds so far (diagnostics: sln_vae_group_transposes)
+  // what create() redirected in every engine (outputs / gradient inputs of its decoder): put back by fail() and the destructor, so
+  // that an engine used on its own afterwards does not write into the group's freed arrays
+  struct EngineIO { float *boxes_pred, *logits, *angles_pred, *dbp, *dlogits, *dz; };
+  std::vector<EngineIO> saved_io;
+  void restore_engines() {
+    for (size_t r = 0; r < saved_io.size() && r < eng.size(); ++r) {
+      SlnVae* h = eng[r]; const EngineIO& s = saved_io[r];
+      h->boxes_pred = s.boxes_pred; h->logits = s.logits; h->angles_pred = s.angles_pred; h->dbp = s.dbp; h->dlogits = s.dlogits; h->dz = s.dz;
+      h->rec = nullptr;
+      h->drop_graphs();
+    }
+    saved_io.clear();
+  }
   std::vector<std::pair<const float*, int64_t>> fused;      // room 0's parameter tensors stepped by the wgrad launches (io.sgd_step)
   std::vector<RecStep> singles;          // steps without a multi form: replayed through the single-room launchers
   std::vector<int> single_room;
@@ -1904,8 +1923,10 @@ struct SlnVaeGroup {
         case SK_DEC_ASSEMBLE_BWD: r = sln_launch_dec_assemble_bwd_multi(l.tab, l.count, l.variant, l.gx, l.smem_floats, st); break;
         case L_ZERO: r = sln_launch_zero_multi(static_cast<const MZero*>(l.tab), l.count, l.max_n16, st); break;
         case L_TRANSPOSE:
+          if (l.variant == 1 && wt_valid) break;          // backward's own transposition: only when no forward left a valid W^T
           r = sln_launch_transpose_table(static_cast<const TransposeEntry*>(l.tab), l.count, l.gx, st);
           if (!r && l.on_side && use_side) { r = (int)hipEventRecord(ev_tr, side); tr_pending = true; }
+          if (!r) { wt_valid = true; ++n_transposes; }
           break;
         case L_BN_GRADS: r = sln_launch_bn_param_grads(static_cast<const BnTableEntry*>(l.tab), l.count, l.gx, eng[0]->cfg.recurrent ? 0 : 1, st); break;
         case L_LOG_SOFTMAX: r = sln_launch_log_softmax(logits, io.angles_pred, rows_total, n_angle, st); break;
@@ -1914,6 +1935,7 @@ struct SlnVaeGroup {
       }
       if (r) return r;
     }
+    if (&prog == &bwd) wt_valid = false;             // the parameters move behind a backward pass (fused wgrads, or the caller's step)
     return 0;
   }
   // a recorded step through the single-room launcher (a room whose block has no multi form)
@@ -1956,7 +1978,7 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
   g->R = R; g->io = *io; g->io.row0_host = nullptr; g->rows_total = io->rows_total; g->n_angle = engines[0]->cfg.n_angle;
   g->eng.assign(engines, engines + R);
   int rc = sln_gemm_init();
-  auto fail = [&](int code) { for (SlnVae* h : g->eng) h->rec = nullptr; delete g; return code; };
+  auto fail = [&](int code) { for (SlnVae* h : g->eng) h->rec = nullptr; g->restore_engines(); delete g; return code; };
   if (rc) return fail(rc);
   {
     void* p = nullptr;
@@ -1972,6 +1994,7 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
     const size_t row0 = (size_t)io->row0_host[r];
     const int E = h->E, na = h->cfg.n_angle;
     // the engine's outputs / gradient inputs of the decoder become slices of the group's row-concatenated arrays
+    g->saved_io.push_back(SlnVaeGroup::EngineIO{h->boxes_pred, h->logits, h->angles_pred, h->dbp, h->dlogits, h->dz});
     h->boxes_pred = io->boxes_pred + row0 * h->cfg.box_dim; h->logits = g->logits + row0 * na; h->angles_pred = io->angles_pred + row0 * na;
     if (h->dbp_ld != 8 && h->dbp_ld != h->cfg.box_dim) return fail(SLN_E_UNSUPPORTED);
     h->dbp = io->d_boxes_pred + row0 * h->dbp_ld; h->dlogits = g->dlogits + row0 * na; h->dz = io->dz + row0 * E;
@@ -2040,14 +2063,13 @@ int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io,
     g->bwd.push_back(l);
   }
   {
-    // W^T: built by the forward call's side-stream launch (join); a backward without a forward in front of it (or with the side
-    // stream switched off) builds it here
+    // W^T: built by the forward call's launch (side stream: join).  A backward that does not find a valid one - no forward in
+    // front of it, or a second backward after one forward, whose first has stepped W - builds it here (variant 1: skipped when
+    // SlnVaeGroup::wt_valid)
     SlnVaeGroup::Launch j; j.kind = SlnVaeGroup::L_JOIN_TR; g->bwd.push_back(j);
-    if (!g->use_side) {
-      SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles;
-      l.tab = g->fwd[1].tab;
-      g->bwd.push_back(l);
-    }
+    SlnVaeGroup::Launch l; l.kind = SlnVaeGroup::L_TRANSPOSE; l.count = (int)trs.size(); l.gx = tr_tiles; l.variant = 1;
+    l.tab = g->fwd[1].tab;
+    g->bwd.push_back(l);
   }
   {
     std::vector<SlnVaeGroup::Launch> rest;
@@ -2087,6 +2109,8 @@ int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single
   return 0;
 }
 
+int64_t sln_vae_group_transposes(const SlnVaeGroup* g) { return g ? g->n_transposes : -1; }
+
 int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64_t* numel, int max) {
   if (!g || max < 0 || (max > 0 && (!params || !numel))) return SLN_E_BADARG;
   const int n = (int)g->fused.size();
@@ -2094,7 +2118,11 @@ int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64
   return n;
 }
 
-void sln_vae_group_destroy(SlnVaeGroup* g) { delete g; }
+void sln_vae_group_destroy(SlnVaeGroup* g) {
+  if (!g) return;
+  g->restore_engines();          // (the engines must still be alive: destroy a group before its engines)
+  delete g;
+}
 
 int64_t sln_vae_tap(SlnVae* h, int layer, int what, float* dst, void* stream) {
   if (!h || layer < 0 || layer >= (int)h->layers.size() || !dst) return SLN_E_BADARG;

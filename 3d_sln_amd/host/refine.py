@@ -894,6 +894,10 @@ class RefineBatch:
         self.noise = torch.zeros(N, **f32)
         self._graph = None
         self.k = 0
+        # the side stream of the wgrads / the scene backward's depth chain is PROBED for real overlap with the caller's stream, which
+        # synchronises that stream: here, at set-up, not inside the first iteration's asynchronous calls (csrc/streams.hip)
+        if not torch.cuda.is_current_stream_capturing():
+            L.sln_side_stream_prepare(st)
         tick("tables, buffers")
         if self.iters > 0:
             self._first_iterate_sizes()
@@ -1000,57 +1004,6 @@ class RefineBatch:
             self.close()
         except Exception:
             pass
-
-
-class RefineBatches:
-    """``RefineBatch`` over ``groups`` sub-batches of the rooms, each on its own stream, their iterations issued alternately.  A
-    refinement iteration is two kinds of work: ~90 dependent decoder launches of a few microseconds (the chip idles between them)
-    and a handful of throughput-bound render / loss kernels.  With two sub-batches in flight the decoder chain of one runs under
-    the render / loss kernels of the other.  Rooms are independent and a room's numbers do not depend on its batch, so the
-    grouping changes nothing but the clock.  Same results interface as ``RefineBatch`` (``losses`` [iters, R], ``results()``)."""
-
-    def __init__(self, model, rooms, groups=2, **kw):
-        R = len(rooms)
-        groups = max(1, min(int(groups), R))
-        cuts = [round(i * R / groups) for i in range(groups + 1)]
-        self.spans = [(cuts[i], cuts[i + 1]) for i in range(groups) if cuts[i + 1] > cuts[i]]
-        dev = model.flat_params.device
-        self.streams = [torch.cuda.Stream(device=dev) for _ in self.spans]
-        cur = torch.cuda.current_stream(dev)
-        self.batches = []
-        for (a, b), st in zip(self.spans, self.streams):
-            self.batches.append(RefineBatch(model, rooms[a:b], **kw))      # (built on the caller's stream: the encoder runs on `model`'s one engine)
-        self.iters, self.R = self.batches[0].iters, R
-        for st in self.streams:
-            st.wait_stream(cur)
-
-    def run(self, iters=None, capture=False):
-        n = (self.iters - self.batches[0].k) if iters is None else int(iters)
-        cur = torch.cuda.current_stream()
-        for st in self.streams:
-            st.wait_stream(cur)
-        for _ in range(n):
-            for b, st in zip(self.batches, self.streams):
-                with torch.cuda.stream(st):
-                    b.run(1, capture=capture)
-        for st in self.streams:
-            cur.wait_stream(st)
-        return self.losses
-
-    @property
-    def losses(self):
-        k = self.batches[0].k
-        return torch.cat([b.losses[:k] for b in self.batches], 1)
-
-    def results(self):
-        return [r for b in self.batches for r in b.results()]
-
-    def launches(self):
-        return self.batches[0].launches()
-
-    def close(self):
-        for b in self.batches:
-            b.close()
 
 
 def finetune_vae_fast_batch(model, rooms, iters=60, bank=None, learning_rate=1e-4, noise_seed=13, image_size=256, capture=False):

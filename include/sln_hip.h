@@ -214,7 +214,12 @@ typedef struct SlnVaeGroupIO {
                                    * gradient buffers (sln_vae_group_fused_params lists the tensors; the caller's optimizer
                                    * steps the others: sln_refine_sgd_rooms over the remaining ranges)                     */
 } SlnVaeGroupIO;
+/* While a group exists its engines' decoder outputs / gradient inputs are slices of the group's arrays; a failed create and
+ * sln_vae_group_destroy put the engines' own buffers back (destroy a group BEFORE its engines). */
 int sln_vae_group_create(SlnVae* const* engines, int R, const SlnVaeGroupIO* io, SlnVaeGroup** out);
+/* forward also rebuilds W^T of the decoder's weights for the following backward; a backward that is not preceded by a forward of
+ * the same group since the last backward (the parameters have been stepped in between) rebuilds it itself.  Parameters changed by
+ * the caller BETWEEN a forward and its backward are not noticed. */
 int sln_vae_group_decoder(SlnVaeGroup* g, void* stream);
 /* parameter gradients are accumulated (+=) into every room's gradient buffer (but see SlnVaeGroupIO::sgd_step), dz is written */
 int sln_vae_group_decoder_backward(SlnVaeGroup* g, void* stream);
@@ -223,6 +228,8 @@ int sln_vae_group_decoder_backward(SlnVaeGroup* g, void* stream);
 int sln_vae_group_fused_params(const SlnVaeGroup* g, const float** params, int64_t* numel, int max);
 /* launches per forward / backward pass and how many of them are single-room fallbacks (diagnostics) */
 int sln_vae_group_launches(const SlnVaeGroup* g, int* fwd, int* bwd, int* single_room_fallbacks);
+/* how many times the group has built W^T of the decoder's weights so far (one per forward, plus one per backward that found none valid) */
+int64_t sln_vae_group_transposes(const SlnVaeGroup* g);
 void sln_vae_group_destroy(SlnVaeGroup* g);
 
 /* Diagnostics: the pooled side stream the library runs next to `stream` (wgrads of a room group, the depth chain of the scene
@@ -230,6 +237,14 @@ void sln_vae_group_destroy(SlnVaeGroup* g);
  * queue do not - the runtime deals streams to a few queues round-robin - so the library probes once per caller stream and keeps a
  * pooled stream that does (csrc/streams.hip). */
 int sln_debug_side_stream(void* stream, int* index, int* overlapped);
+/* The probe is a HOST SYNCHRONISATION of `stream` (hipStreamSynchronize + a ~150 us spin kernel per candidate).  Without a prepare call
+ * it happens inside the first sln_scene_backward / sln_vae_group_decoder[_backward] on a stream (never inside a capture: a stream first
+ * met while captured gets the pool's first stream unprobed).  sln_side_stream_prepare probes now: 1 = a pooled stream overlaps with
+ * `stream`, 0 = none (side work runs on `stream`), < 0 error (SLN_E_STATE inside a capture).  A pick is probed again after 4 096
+ * look-ups; sln_side_stream_forget drops it (call it before destroying the stream: the next stream with the same handle may sit on
+ * another hardware queue); returns the number of entries dropped. */
+int sln_side_stream_prepare(void* stream);
+int sln_side_stream_forget(void* stream);
 
 /* Per-kernel-family timing with HIP events on the launch stream (bench.py roofline figures).
  * Families: 0 gemm_nt (forward/dgrad), 1 gemm_tn (wgrad), 2 edge scatter/gather, 3 other.
@@ -489,10 +504,17 @@ int sln_refine_loss_backward(const SlnRefineLoss* L, const void* workspace, cons
  *   (W = W_orig / (u . (W_mat v))); for the modulation conv the rows of gamma and beta are interleaved in
  *   groups of 32: rows [64 g, 64 g + 32) = gamma of channels [32 g, 32 g + 32), the next 32 rows their beta.
  * ============================================================================================= */
-/* Allocates the per-(device, stream) scratch of the small-launch input-channel split (128 MB) for `stream` now.  Optional: the first
- * eager convolution on a stream does the same; a stream that is first seen while it is being captured gets no scratch and runs
- * those launches unsplit (other rounding, ~1e-6) - call this (or run one eager forward) on the stream before capturing it. */
+/* Small convolution launches (< 192 workgroups: the batch-1 calls of testing/test_SPADE_shade.py:77-79) split their input channels
+ * over several workgroups and add the partial sums in a fixed order; the partial sums live in a 48 MB scratch slot per (device,
+ * stream) - at most 16 slots, the least recently used one is freed for a new stream.
+ * sln_spade_prepare allocates `stream`'s slot now (optional: the first eager split launch on a stream does the same).  A slot cannot
+ * be allocated while the stream is being captured: a split launch on a stream first seen during its capture fails with SLN_E_STATE
+ * (-3) - call sln_spade_prepare (or run one eager forward) on the stream before capturing it.  An allocation failure is SLN_E_NOMEM.
+ * sln_spade_release frees the slot of `stream` on the current device (all != 0: every slot of the process); it waits for the device.
+ * Returns the number of slots freed.  Call it before destroying a stream that ran SPADE launches (a recycled handle would otherwise
+ * inherit the slot, which is harmless, or keep 48 MB alive). */
 int sln_spade_prepare(void* stream);
+int sln_spade_release(void* stream, int all);
 /* y = act(conv_ks(x) + bias): ks = 3 (ReflectionPad2d(1)) or 1; act 0 none, 1 ReLU, 2 LeakyReLU(slope) */
 int sln_spade_conv(const float* x, int B, int Cin, int H, int W, const float* wp, const float* bias, int rows, int rows_pad,
                    int ksize, int act, float slope, float* y, void* stream);

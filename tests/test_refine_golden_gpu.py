@@ -119,9 +119,9 @@ def test_scene_matches_the_reference_mesh_render_func(tag, S):
 
     def same_image(got, full_key, sub_key, sum_key, flips):
         if full_key in g.files:
-            bad = int((np.abs(got.cpu().numpy() - g[full_key]) > 1e-4).any(1).sum())
+            bad = int((np.abs(got.detach().cpu().numpy() - g[full_key]) > 1e-4).any(1).sum())
         else:
-            bad = int((np.abs(got.cpu().numpy()[:, :, ::4, ::4] - g[sub_key]) > 1e-4).any(1).sum())
+            bad = int((np.abs(got.detach().cpu().numpy()[:, :, ::4, ::4] - g[sub_key]) > 1e-4).any(1).sum())
         assert bad <= flips, "%d pixels differ from the reference's image" % bad
         s = summary(got)
         assert np.abs(s[:, 2] - g[sum_key][:, 2]).max() <= flips, "covered pixels per plane"

@@ -44,7 +44,7 @@ def main():
                 for n_it in (iters, 2 * iters, iters, 2 * iters, iters, 2 * iters):
                     torch.cuda.synchronize(); t0 = time.perf_counter()
                     G = int(os.environ.get("GROUPS", "1"))
-                    rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it) if G <= 1 else R.RefineBatches(model, rooms, groups=G, bank=bank, iters=n_it)
+                    rb = R.RefineBatch(model, rooms, bank=bank, iters=n_it)
                     torch.cuda.synchronize(); t1 = time.perf_counter()
                     rb.run(capture=capture)
                     t_enq = time.perf_counter() - t1                  # host time to enqueue everything (the GPU may still be running)
