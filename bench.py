@@ -30,6 +30,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The CPU-oracle legs (parity checks, cpu_baseline) run OpenMP teams; with the default ACTIVE wait policy their threads keep spinning
+# for a while after a parallel region and starve the thread that issues the next leg's GPU launches (round 5: the render leg's
+# wall-clock mean was 1.9x its median behind the parity check).  Set before torch / libgomp load: idle teams sleep at once.
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 VALU_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak (2 flop x 64 lanes x 4 SIMD x 256 CU x 2.4 GHz)
@@ -143,6 +148,21 @@ def profile_rows(prefixes, leg):
     return (round(tot_b / n_b) if n_b else None), (round(tot_us / n_us, 2) if n_us else None)
 
 
+def profile_step_traffic(leg, per_step_kernel="adam_kernel"):
+    """Counter HBM bytes of ONE step of `leg`'s profiled command: sum over every kernel row of bytes per launch x launches, divided by
+    the number of steps the trace saw (= the calls of a kernel that runs once per step).  -> (bytes per step, steps) or (None, None)"""
+    import csv
+    try:
+        rows = list(csv.DictReader(open(profile_csv(leg))))
+    except OSError:
+        return None, None
+    steps = sum(int(r["calls"]) for r in rows if r["kernel"].startswith(per_step_kernel))
+    have = [r for r in rows if r.get("hbm_MB_per_launch_corrected")]
+    if not steps or not have:
+        return None, None
+    return sum(float(r["hbm_MB_per_launch_corrected"]) * 1e6 * int(r["calls"]) for r in have) / steps, steps
+
+
 def traffic_source(leg, traffic):
     return (os.path.relpath(profile_csv(leg), ROOT) + " (bytes per launch)") if traffic else PROFILE_STATUS.get(leg, "missing: not looked up")
 
@@ -211,10 +231,20 @@ def check_vae(lib, torch, M, model, batch):
         lg = model.loss(kl_weight=0.1).cpu().numpy()
         rmu, rlv, rbp, rap = vae_ref.forward({k: t.clone() for k, t in sdb.items()}, cfgb, *cb, epsb, True)
         rt, _ = vae_ref.losses(cfgb, cb[2], rbp, cb[3], rap, rmu, rlv, 0.1)
+        # ... and in fp64: north_star's 1e-4 is held against this one; the fp32 oracle's own distance from it is printed beside it
+        sd64 = {k: (t.double() if t.is_floating_point() else t.clone()) for k, t in sdb.items()}
+        cb64 = [cb[0], cb[1], cb[2].double(), cb[3], cb[4]]
+        dmu, dlv, dbp, dap = vae_ref.forward(sd64, cfgb, *cb64, epsb.double(), True)
+        dt_, _ = vae_ref.losses(cfgb, cb64[2], dbp, cb64[3], dap, dmu, dlv, 0.1)
     model.load_state_dict(sdb)                       # the forward above moved the BatchNorm running statistics: restore
     e_full = rel_err(lg[3], float(rt))
-    require(e_full <= 1e-3, "VAE bench batch: total loss %.6f vs oracle %.6f" % (lg[3], float(rt)))
-    return {"small_step_loss_rel_err": e_loss, "small_step_grad_rel_err": e_grad, "bench_batch_loss_rel_err": e_full}
+    e_64 = rel_err(lg[3], float(dt_))
+    e_ref = rel_err(float(rt), float(dt_))
+    e_bp = rel_err(bp.cpu().numpy(), dbp.numpy())
+    require(e_64 <= 1e-4 and e_bp <= 1e-4 + 4 * rel_err(rbp.numpy(), dbp.numpy()),
+            "VAE bench batch: total loss %.6f vs fp64 oracle %.6f (%.2e), boxes_pred %.2e" % (lg[3], float(dt_), e_64, e_bp))
+    return {"small_step_loss_rel_err": e_loss, "small_step_grad_rel_err": e_grad, "bench_batch_loss_rel_err": e_full,
+            "bench_batch_loss_rel_err_vs_fp64_oracle": e_64, "fp32_oracle_vs_fp64_oracle": e_ref, "bench_batch_boxes_pred_rel_err_vs_fp64": e_bp}
 
 
 def check_render(torch, pk, rooms_idx):
@@ -245,6 +275,52 @@ def check_spade(torch, S):
     e = rel_err(out, ref)
     require(e <= 1e-4, "SPADE small generator: image rel err %.2e" % e)
     return {"small_generator_image_rel_err": e}
+
+
+def check_refine(torch):
+    """The device refinement loop (RefineBatch: 2 rooms in flight, every kernel of the loop, 4 iterations at 96 x 96) against the
+    REFERENCE'S OWN k loop of finetune_VAE, executed from its source text by oracle/gen_golden_refine.py (tests/golden/refine_loop.npz;
+    the rasterizer under it is the restated one): per iteration the loss, the boxes, the soft-argmax angles and z at 1e-4."""
+    import numpy as np
+    from oracle import refine_ref, vae_ref
+    R = importlib.import_module("3d_sln_amd.host.refine")
+    M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "refine_loop.npz"))
+    t = refine_ref.load_tables(g)
+    bank = R.MeshBank.from_arrays({k: (m["v"], m["f"], m["bbox_min"], m["bbox_max"]) for k, m in t["models"].items()}, "cuda",
+                                  vocab=t["vocab"], shell=t["shell"])
+    cfg = vae_ref.VaeConfig(embedding_dim=32, gconv_num_layers=2, num_objs=len(t["vocab"]) + 1)
+    model = M.Sg2ScVAEModel(**cfg.model_kwargs())
+    model.load_state_dict({k[6:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("state:")})
+    model = model.cuda().eval()
+    names = ["__room__"] + t["vocab"]
+    rooms = [dict(objs=torch.from_numpy(g["room%d:objs" % r]).cuda(), triples=torch.from_numpy(g["room%d:triples" % r]).cuda(),
+                  boxes=torch.from_numpy(g["room%d:in_boxes" % r]).cuda(), angles=torch.from_numpy(g["room%d:in_angles" % r]).cuda(),
+                  attributes=torch.from_numpy(g["room%d:attributes" % r]).cuda(), class_names=[names[int(o)] for o in g["room%d:objs" % r]])
+             for r in (0, 1)]
+    it = int(g["room0:noise"].shape[0])
+    rb = R.RefineBatch(model, rooms, bank=bank, image_size=96, iters=it)
+    errs = {"loss": 0.0, "boxes": 0.0, "angle_idx": 0.0, "z": 0.0, "z0_from_encoder": 0.0}
+    try:
+        for i in (0, 1):
+            a, n = rb.row0[i], rb.rows[i]
+            errs["z0_from_encoder"] = max(errs["z0_from_encoder"], rel_err(rb.z[a:a + n].cpu().numpy(), g["room%d:z0" % i]))
+            rb.z[a:a + n] = torch.from_numpy(g["room%d:z0" % i]).cuda()
+        for k in range(it):
+            rb.run(1)
+            for i in (0, 1):
+                a, n = rb.row0[i], rb.rows[i]
+                p = "room%d:" % i
+                errs["loss"] = max(errs["loss"], rel_err(float(rb.losses[k, i]), g[p + "loss"][k]))
+                errs["boxes"] = max(errs["boxes"], rel_err(rb.boxes[a:a + n].cpu().numpy(), g[p + "boxes"][k]))
+                errs["angle_idx"] = max(errs["angle_idx"], rel_err(rb.idx[a:a + n].cpu().numpy(), g[p + "idx"][k]))
+                errs["z"] = max(errs["z"], rel_err(rb.z[a:a + n].cpu().numpy(), g[p + "z"][k]))
+    finally:
+        rb.close()
+    require(max(errs["loss"], errs["boxes"], errs["angle_idx"], errs["z"]) <= 1e-4 and errs["z0_from_encoder"] <= 1e-4,
+            "refinement loop vs the reference's loop: " + ", ".join("%s %.2e" % kv for kv in errs.items()))
+    errs["against"] = "the reference's own finetune_VAE k loop run from its source (tests/golden/refine_loop.npz), 2 rooms x %d iterations, 96 x 96" % it
+    return errs
 
 
 def vae_dropin_leg(args, torch, M, syn, fused_ms):
@@ -510,14 +586,16 @@ def render_leg(args, lib, torch, rank):
     torch.cuda.synchronize()
     fam = prof_read(lib)
     lib.check(lib.lib().sln_prof_enable(0), "prof")
-    # the median batch (HIP events around every iteration): in the default run (parity checks in front: the oracle's OpenMP threads
-    # are still spinning) the first few of the 100 iterations are host-starved and the wall-clock mean is ~2x the median; with
-    # --no-check the two agree.  The mean is printed too
+    # renders_per_s = rooms / WALL-CLOCK MEAN batch time of the timed loop (as rounds 1-4 reported it; round 5 printed the median
+    # because the mean was 1.9x the median behind the parity check - the oracle's OpenMP threads were still spinning; they sleep now,
+    # see OMP_WAIT_POLICY at the top).  The median (HIP events around every iteration) is printed next to it with their ratio.
     p50_ms = per[int(0.5 * (len(per) - 1))]
-    per_render = p50_ms * 1e-3 / args.rooms
+    mean_ms = dt / args.render_iters * 1e3
+    per_render = mean_ms * 1e-3 / args.rooms
     tris = tri_count / args.rooms
-    res.update({"renders_per_s": round(1.0 / per_render, 1), "renders_per_s_note": "rooms / median batch time (events); wall-clock mean below",
-                "wall_mean_ms_per_batch": round(dt / args.render_iters * 1e3, 4), "ms_per_room_fwd_bwd": round(per_render * 1e3, 4),
+    res.update({"renders_per_s": round(1.0 / per_render, 1), "renders_per_s_note": "rooms / wall-clock mean batch time of the timed loop",
+                "renders_per_s_median": round(args.rooms / (p50_ms * 1e-3), 1), "mean_over_median": round(mean_ms / p50_ms, 3),
+                "wall_mean_ms_per_batch": round(mean_ms, 4), "ms_per_room_fwd_bwd": round(per_render * 1e3, 4),
                 "ms_per_batch_p10_p50_p90": [round(per[int(q * (len(per) - 1))], 4) for q in (0.1, 0.5, 0.9)],
                 "warmup": args.render_warmup, "iters": args.render_iters,
                 "nmr_equivalent_raster_passes_per_s": round(33.0 / per_render, 1),
@@ -536,7 +614,7 @@ def render_leg(args, lib, torch, rank):
     # (ii) the kernels that actually carry the time, named as in profiles/: the forward tile kernel is bound by per-pixel edge
     # tests on the vector ALUs (3 edge functions x 2 fma + sign tests per (pixel, face) pair: counted from the brute-force
     # 256^2 x 2F tests the package performs = the work replaced, and priced at the fp32 vector peak).
-    whole_ms = p50_ms
+    whole_ms = mean_ms
     res["roofline"] = {"kernel": "scene_forward + scene_backward (all launches of one batch)", "bound": "hbm",
                        "achieved": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -686,6 +764,9 @@ def refine_leg(args, lib, torch):
     R = importlib.import_module("3d_sln_amd.host.refine")
     M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
     syn = importlib.import_module("3d_sln_amd.host.synthetic")
+    parity = None
+    if not args.no_check:
+        parity = check_refine(torch)
     names = ["bed", "chair", "table", "sofa", "desk", "cabinet", "lamp", "television", "bookshelf", "dresser", "night_stand", "shelves",
              "__room__"]
     n = len(names)
@@ -847,7 +928,7 @@ def refine_leg(args, lib, torch):
                     "sample": "%d iteration(s) of the same 12-object room through oracle/vae_ref.py + refine_ref.py + raster_ref.py (33 brute-force raster "
                               "passes per render), %.2f s per iteration" % (n_cpu, t_cpu / n_cpu)}
     one_room_bytes = 4 * 70 * 256.0 * 256.0 * 4.0 + 4 * (4 * 69 * 96 * 96 * 4.0) + 9 * 4.0 * sum(ln for _, ln in model.decoder_param_ranges())
-    return {"rooms_%d" % nr: batch, "rooms_%d" % args.refine_rooms_large: larger, "cpu_baseline": cpu_base,
+    return {"parity": parity, "rooms_%d" % nr: batch, "rooms_%d" % args.refine_rooms_large: larger, "cpu_baseline": cpu_base,
             "model": "VAE over-fitted to the legs' rooms (%d fused Adam steps; last losses [bbox, angle, KL, total] = %s): its decoder places "
                      "the furniture in view, as a trained checkpoint does" % (args.refine_fit_steps, fit),
             "roofline": {"kernel": "one refinement iteration of ONE room (all launches; latency-bound: ~110 dependent launches)", "bound": "hbm", "unit": "GB/s",
@@ -1361,6 +1442,11 @@ def main():
         if "gemm_nt" in per_family:
             per_family["gemm_nt"]["traffic_nt_and_dual_rows"] = tr_ntd
         traffic, prof_us = per_family[dom]["traffic"], per_family[dom]["rocprof_avg_launch_us"]
+        if dom == "gemm_nt":
+            # `traffic`, `algorithmic_bytes_per_launch` and their quotient over ONE launch set: the forward Linears + dgrads, i.e. the
+            # gemm_nt rows and the twin-head gemm_group rows of the profile together (round 5 printed the gemm_nt rows' traffic next
+            # to the NT + head launches' algorithmic bytes)
+            traffic = tr_ntd
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
                            "flop_per_launch": round(fam[dom]["work"] / fam[dom]["launches"], 1),
@@ -1369,6 +1455,8 @@ def main():
                            "frac_note": "frac = frac_event (HIP events around the eager launches of this run, gaps included); frac_rocprof "
                                         "divides the same flops by the kernel durations of profiles/%s_vae_kernel_stats.csv" % PROFILE_TAG,
                            "traffic_source": traffic_source("vae", traffic),
+                           "traffic_launch_set": ("%d launches per step: gemm_nt + gemm_group rows (forward Linears, dgrads, twin heads)" % nt_launches)
+                                                 if dom == "gemm_nt" else "the %s rows" % dom,
                            "algorithmic_bytes_per_launch": per_family[dom if dom in ("gemm_nt", "gemm_tn") else "gemm_nt"]["algorithmic_bytes_per_launch"],
                            "traffic_over_algorithmic": per_family[dom if dom in ("gemm_nt", "gemm_tn") else "gemm_nt"]["traffic_over_algorithmic"],
                            "algorithmic_bytes_note": "launch-weighted mean over the step: fp32 operand rows (x2 for the two-source BatchNorm-"
@@ -1379,6 +1467,14 @@ def main():
                                 "achieved": round(gemm_flop / (ms_per_step * 1e-3) / 1e12, 2),
                                 "frac": round(gemm_flop / (ms_per_step * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                                 "gemm_flop_per_step": round(gemm_flop, 1)}
+        step_bytes, step_n = profile_step_traffic("vae")
+        survey_bytes = 19.0e6 * args.graphs                      # 1.2 GB per 64-graph step (BatchNorm-materialised model), 19 MB per graph
+        out["roofline_step"].update({"traffic": round(step_bytes) if step_bytes else None,
+                                     "traffic_source": ("%s: sum over all kernels of bytes per launch x launches, / %d traced steps"
+                                                        % (os.path.relpath(profile_csv("vae"), ROOT), step_n)) if step_bytes else PROFILE_STATUS.get("vae", "missing"),
+                                     "survey_bytes_per_step": int(survey_bytes),
+                                     "traffic_over_survey_bytes": round(step_bytes / survey_bytes, 3) if step_bytes else None,
+                                     "hbm_gbs_at_this_step_time": round(step_bytes / (ms_per_step * 1e-3) / 1e9, 1) if step_bytes else None})
         if "edge" in fam:
             e = fam["edge"]
             gbs = e["work"] / (e["ms"] * 1e-3) / 1e9
@@ -1438,6 +1534,30 @@ def main():
             log('sampling leg'); out["sampling"] = sampling_leg(args, lib, torch)
         log('done')
     if rank == 0:
+        # LAST key of the line: every config of the metric in one compact object (a log tail then carries both halves of
+        # "VAE steps/sec + 256^2 diff-render fps", each leg's roofline fraction and its in-run parity figure)
+        def dig(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or d.get(k) is None:
+                    return None
+                d = d[k]
+            return d
+        sg = lambda x: None if x is None else float("%.3g" % x)
+        lb = out.get("vae_large_batch") or {}
+        big = max(lb, key=lambda k: int(k)) if lb else None
+        out["summary"] = {
+            "c2_graphs_per_s": out["value"], "c2_ms_step": round(ms_per_step, 4), "c2_frac_mfma_step": dig(out, "roofline_step", "frac"),
+            "c2_frac_mfma_gemm_nt": dig(out, "roofline", "frac"), "c2_err": sg(dig(out, "parity", "bench_batch_loss_rel_err_vs_fp64_oracle")),
+            "c3_renders_per_s": dig(out, "render", "renders_per_s"), "c3_renders_per_s_median": dig(out, "render", "renders_per_s_median"),
+            "c3_frac_hbm": dig(out, "render", "roofline", "frac"), "c3_px_diff": dig(out, "render", "parity", "face_index_pixels_differing"),
+            "c4_images_per_s": dig(out, "spade", "images_per_s"), "c4_frac_mfma": dig(out, "spade", "frac_mfma_end_to_end"),
+            "c4_err": sg(dig(out, "spade", "parity", "full_size_image_rel_err_vs_reference_fixture")),
+            "refine%d_ms" % args.refine_rooms: dig(out, "refine", "rooms_%d" % args.refine_rooms, "ms_per_iteration"),
+            "refine%d_ms" % args.refine_rooms_large: dig(out, "refine", "rooms_%d" % args.refine_rooms_large, "ms_per_iteration"),
+            "refine_err": sg(max([dig(out, "refine", "parity", k) or 0.0 for k in ("loss", "boxes", "angle_idx", "z")]) if dig(out, "refine", "parity") else None),
+            "sampling_layouts_per_s": dig(out, "sampling", "layouts_per_s"),
+            "large_batch_frac_mfma": dig(lb, big, "frac_mfma_whole_step") if big else None,
+            "cpu_graphs_per_s": dig(out, "cpu_baseline", "value"), "n_gpus": world}
         print(json.dumps(out))
     if dp:
         dist.barrier()
