@@ -45,11 +45,15 @@ def test_scene_assembly_and_refinement_loss_match_cpu_restatement():
         loss.backward()
         res[dev] = (loss.item(), dl.item(), sl.item(), b2.grad.cpu().numpy(), a2.grad.cpu().numpy(), target.cpu().numpy())
     c, g = res["cpu"], res["cuda"]
-    assert (np.abs(c[5] - g[5]) > 1e-4).mean() < 1e-3            # a few silhouette pixels may flip (CPU vs GPU projection rounding)
-    assert abs(c[0] - g[0]) <= 2e-3 * abs(c[0]), (c[0], g[0])
-    assert abs(c[1] - g[1]) <= 2e-3 * abs(c[1]) and abs(c[2] - g[2]) <= 2e-3 * abs(c[2])
-    assert_close(g[3], c[3], "d loss / d boxes", rtol=2e-2, atol=2e-2 * np.abs(c[3]).max())
-    assert_close(g[4], c[4], "d loss / d angles", rtol=2e-2, atol=2e-2 * np.abs(c[4]).max())
+    # a few silhouette pixels may land on the other side (torch's CPU and GPU matmuls round the projection differently): counted.
+    # Bounds as the reference-executed fixtures justify them (tests/test_refine_golden_gpu.py: loss / boxes / angles 1e-4 over four
+    # iterations of the whole loop; gradients THROUGH silhouettes 5e-3 of their largest entry)
+    flipped = int((np.abs(c[5] - g[5]) > 1e-4).any(1).sum())
+    assert flipped <= 8, "%d of %d pixels differ" % (flipped, c[5].shape[-1] ** 2)
+    assert abs(c[0] - g[0]) <= 2e-4 * abs(c[0]), (c[0], g[0])
+    assert abs(c[1] - g[1]) <= 5e-4 * abs(c[1]) and abs(c[2] - g[2]) <= 1e-4 * abs(c[2]), (c[1], g[1], c[2], g[2])
+    assert_close(g[3], c[3], "d loss / d boxes", rtol=5e-3, atol=0)
+    assert_close(g[4], c[4], "d loss / d angles", rtol=5e-3, atol=0)
     assert np.abs(c[3]).max() > 0 and np.abs(c[4]).max() > 0
 
 

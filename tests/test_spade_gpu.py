@@ -398,7 +398,7 @@ def test_full_size_generator_at_the_bench_weights_within_1e4_of_the_fp64_oracle(
     assert float(g["out_abs_mean"][0]) < 0.5
     e_crop = float(np.abs(out0[:, :, 100:132, 60:92].numpy() - g["out_crop"]).max()) / scale
     e_rows = float(np.abs(out0[:, :, ::37, :].numpy() - g["out_rows"]).max()) / scale
-    assert max(e_crop, e_rows) <= 2e-4, ("HIP vs the reference's own fp32 output", e_crop, e_rows)
+    assert max(e_crop, e_rows) <= 1e-4, ("HIP vs the reference's own fp32 output (north_star: 1e-4; measured 7.7e-6)", e_crop, e_rows)
     for n, t in taps.items():
         assert_close(_checks(t)[1:], g["check:" + n][1:], "spade_bench:" + n, rtol=1e-4)
     cfg = spade_ref.SpadeConfig()
@@ -413,9 +413,8 @@ def test_full_size_generator_at_the_bench_weights_within_1e4_of_the_fp64_oracle(
         e_hip = float((out[b].double() - r64[b]).abs().max()) / scale
         e_cpu = float((r32[b].double() - r64[b]).abs().max()) / scale
         e_hc = float((out[b].double() - r32[b].double()).abs().max()) / scale
-        assert e_hip <= 1e-4 + e_cpu, (b, e_hip, e_cpu)
-        assert e_hip <= 1.5e-4, (b, e_hip)
-        assert e_hc <= 2e-4, (b, e_hc)
+        assert e_hip <= 1e-4, (b, e_hip, "north_star's 1e-4 against the fp64 oracle (measured 3.5e-6; the fp32 oracle itself: %.1e)" % e_cpu)
+        assert e_hc <= 1e-4, (b, e_hc)
 
 
 @pytest.mark.parametrize("Cin,Cout,H,B", [(512, 128, 16, 2), (1024, 256, 8, 1), (520, 64, 32, 2), (512, 128, 64, 16)])
