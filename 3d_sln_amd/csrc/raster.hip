@@ -471,6 +471,8 @@ struct PixDenseView {
     return r;
   }
   __device__ __forceinline__ float eval(const Loaded& L, const Ref&, int& fq) const { fq = L.fq; return L.diff > 0.f ? L.diff : 0.f; }
+  __device__ __forceinline__ Loaded issue(int p, const Ref& ref) const { return load(p, ref); }
+  static __device__ __forceinline__ void pin(Loaded&) {}
 };
 struct PixDense {            // C-channel image: one positive-part test over the channel sum (package's rgb mode, C=3)
   const int32_t* fi; const float* rgb; const float* grad; int C, is;
@@ -520,6 +522,8 @@ struct PixMultiView {
     return r;
   }
   __device__ __forceinline__ float eval(const Loaded& L, const Ref&, int& fq) const { fq = L.fq; return L.tot; }
+  __device__ __forceinline__ Loaded issue(int p, const Ref& ref) const { return load(p, ref); }
+  static __device__ __forceinline__ void pin(Loaded&) {}
 };
 struct PixMulti {
   const int32_t* fi; const float* const* rgb; const float* const* grad; const unsigned long long* mask; int is, shift;
@@ -577,6 +581,14 @@ struct PixClassView {
     asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w), "+v"(r.g_cr));
     return r;
   }
+  // the two loads without the pin, and the pin on its own: several windows' loads go out before the first pin waits (phase 2a)
+  __device__ __forceinline__ Loaded issue(int p, const Ref& ref) const {
+    Loaded r;
+    r.iq = *reinterpret_cast<const int4*>(rec + (unsigned)p * 16u);
+    r.g_cr = *reinterpret_cast<const float*>(g + ((unsigned)max(ref.cp, 0) * plane4 + (unsigned)p * 4u));
+    return r;
+  }
+  static __device__ __forceinline__ void pin(Loaded& r) { asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w), "+v"(r.g_cr)); }
   __device__ __forceinline__ float eval(const Loaded& L, const Ref& ref, int& fq) const {
     const int cr = ref.cp;
     const int4 iq = L.iq;
@@ -618,6 +630,12 @@ __device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2)
 // small faces had finished - the kernel ran as long as its largest face.  Units outside the edge's d0 range exit at
 // once; each unit adds its two partial sums to the face gradient with two atomics.
 constexpr int PMB_DC = 64;
+#ifndef PMB_ILP
+#define PMB_ILP 4            // windows of a row in flight per pass of phase 2a
+#endif
+#ifndef PMB_LONG
+#define PMB_LONG 32          // rows of at least this many pixels are scanned row by row (phase 2a); 0: every row flattened
+#endif
 // diff / dist of a contributing scan pixel: v_rcp_f32 (1 ulp) and a multiplication instead of the ~12-instruction IEEE division
 // sequence, twice per contributing pixel in a kernel bound by instruction issue (0.774 -> 0.750 ms per 16 rooms forward + backward).
 // The face gradient is a sum of thousands of such terms whose order already differs from the restatement's (lane partial sums,
@@ -717,6 +735,8 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   PmbStep sp; sp.lo = 0; sp.ofrom = 0; sp.ifrom = 0; sp.cross = 0.f;
   int li = 0;
   float r0 = 0.f, r1 = 0.f;
+  typename View::Ref rin_keep, rout_keep;        // the step's two reference records (phase 2a reads them with v_readlane)
+  { int4 z4 = make_int4(0, 0, 0, 0); rin_keep = *reinterpret_cast<typename View::Ref*>(&z4); rout_keep = rin_keep; }
   if (d0 <= c_to) {
     const float d1_cross = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]) * (d0 - p[0][0]) + p[0][1];
     sp.cross = d1_cross;
@@ -729,6 +749,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       typename View::Ref rin, rout;
       V.ref_pair(V.idx(d0, d1_in), V.idx(d0, d1_out), rin, rout);
       s_ref[lane][0] = rin; s_ref[lane][1] = rout;
+      rin_keep = rin; rout_keep = rout;
       if (rin.fi == fn) {                                              // outward scan to the image border
         const int lim = dir > 0 ? is - 1 : 0;
         const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
@@ -742,6 +763,12 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       sp.ifrom = from; li = max(to - from + 1, 0);
     }
   }
+  // Rows of at least PMB_LONG pixels (94 % of the scan pixels of a furnished room: outward scans run to the image border) are
+  // scanned by the whole wavefront, one row at a time (phase 2a); only the shorter rows enter the flattened space of phase 2b.
+  const int lo_all = sp.lo, li_all = li;
+  const bool long_o = PMB_LONG > 0 && lo_all >= PMB_LONG, long_i = PMB_LONG > 0 && li_all >= PMB_LONG;
+  if (long_o) sp.lo = 0;
+  if (long_i) li = 0;
   int incl = sp.lo + li;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
@@ -752,7 +779,68 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   __syncthreads();
   const int W = s_pre[64];
 
-  // ---- phase 2: the scan pixels of all steps, flattened ----
+  // ---- phase 2a: one row per pass of the wavefront (round 6) ----
+  // Everything that describes the row - its step's crossing, ratios, reference record, first pixel, length - is wavefront-uniform
+  // (v_readlane of the owning lane's phase-1 registers): a lane adds its offset to a scalar base, loads and evaluates; no walk along
+  // the prefix, no per-lane LDS reads, PMB_ILP windows' loads in flight at once.  Measured on the 16-room batch: 293 -> 272 us.
+  // The launch is bound by the instructions it ISSUES, vector and scalar together (one of each per cycle and CU): halving the vector
+  // instructions of a window (they became scalar ones), four windows' loads in flight instead of one, and every load redirected to one
+  // cache-resident 64 KB window each moved the kernel by less than 5 % (LAB_NOTES, round 6).
+  if (PMB_LONG > 0) {
+    const int gz = wstep >> 6, zme = wfirst >> 6;                  // long walks of few images are split over gridDim.z workgroups
+    int widx = 0;
+#pragma unroll
+    for (int scan = 0; scan < 2; ++scan) {
+      unsigned long long m = __ballot(scan == 0 ? long_o : long_i);
+      const int4 myref = scan == 0 ? *reinterpret_cast<const int4*>(&rin_keep) : *reinterpret_cast<const int4*>(&rout_keep);
+      while (m != 0ull) {
+        const int l = (int)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const int len = __builtin_amdgcn_readlane(scan == 0 ? lo_all : li_all, l);
+        const int from = __builtin_amdgcn_readlane(scan == 0 ? sp.ofrom : sp.ifrom, l);
+        const float crs = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sp.cross), l));
+        const float q0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r0), l));
+        const float q1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(r1), l));
+        int4 ru;
+        ru.x = __builtin_amdgcn_readlane(myref.x, l); ru.y = __builtin_amdgcn_readlane(myref.y, l);
+        ru.z = __builtin_amdgcn_readlane(myref.z, l); ru.w = __builtin_amdgcn_readlane(myref.w, l);
+        const typename View::Ref ref = *reinterpret_cast<const typename View::Ref*>(&ru);
+        const int d0r = c_from + l;
+        for (int k = 0; k < len; k += 64 * PMB_ILP, ++widx) {
+          if (gz > 1 && widx % gz != zme) continue;
+          typename View::Loaded ld[PMB_ILP];
+#pragma unroll
+          for (int u = 0; u < PMB_ILP; ++u) {
+            const int t = min(k + 64 * u + lane, len - 1);            // (clamped: the load is unconditional, the result masked below)
+            ld[u] = V.issue(V.idx(d0r, from + t), ref);
+          }
+#pragma unroll
+          for (int u = 0; u < PMB_ILP; ++u) View::pin(ld[u]);
+#pragma unroll
+          for (int u = 0; u < PMB_ILP; ++u) {
+            const int t = k + 64 * u + lane;
+            int fq;
+            const float diff = V.eval(ld[u], ref, fq);
+            if (t < len && (scan == 0 || fq == fn) && diff > 0.f) {       // inward: this face's pixels only
+              const float dc = (from + t) - crs;
+              if (q0 != 0.f) {
+                float dist = pix_scale(q0 * dc, is, pow2, s2);
+                dist = 0 < dist ? dist + eps : dist - eps;
+                acc0 -= PMB_DIV(diff, dist);
+              }
+              if (q1 != 0.f) {
+                float dist = pix_scale(q1 * dc, is, pow2, s2);
+                dist = 0 < dist ? dist + eps : dist - eps;
+                acc1 -= PMB_DIV(diff, dist);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  // ---- phase 2b: the scan pixels of the remaining (short) rows of all steps, flattened ----
   // Few images (gridDim.z > 1, pixel_map_scan_split): the launch lasts as long as the longest walk - a wall edge is 64 steps
   // x up to 256 scan pixels per chunk = 256 windows of two dependent loads each, 150 us - so gridDim.z workgroups repeat
   // phase 1 (one memory round trip) and deal the windows among themselves.

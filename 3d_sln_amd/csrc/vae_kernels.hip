@@ -1032,6 +1032,9 @@ int sln_launch_bn_relu_apply(const float* x, int ld, int col0, int cols, int row
 int sln_launch_scatter_avg_fwd(const float* A2, int ld, int H, int D, BnView bn2, GraphCsr g, int O, float* pooled,
                                hipStream_t st) {
   if (O <= 0) return 0;
+  // lab (SLN_EDGE_ABL: bit 0 this launcher skipped - outputs are then garbage): bounds what folding the edge launches into their
+  // neighbours could return at most (round 6, LAB_NOTES)
+  { static const int a = std::getenv("SLN_EDGE_ABL") ? std::atoi(std::getenv("SLN_EDGE_ABL")) : 0; if (a & 1) return 0; }
   // algorithmic bytes: both halves of A2 once, pooled once, the entry list
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * H + 4.0 * O * H + 16.0 * g.T, st);
   if (H % 4 == 0 && D % 4 == 0 && ld % 4 == 0 && al16(A2) && al16(pooled)) {
@@ -1047,6 +1050,7 @@ int sln_launch_scatter_avg_bwd(const float* dM, const float* dP, int lddp, int d
                                int D, BnView bn2, GraphCsr g, int T, float* g2, double* gsums, int cstride,
                                hipStream_t st) {
   if (T <= 0) return 0;
+  { static const int a = std::getenv("SLN_EDGE_ABL") ? std::atoi(std::getenv("SLN_EDGE_ABL")) : 0; if (a & 2) return 0; }      // lab, see sln_launch_scatter_avg_fwd
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * T * (2 * H) + (dP ? 4.0 * T * D : 0.0) + 2.0 * 4.0 * T * (2 * H + D) + 8.0 * T, st);
   if (H % 4 == 0 && D % 4 == 0 && ld % 4 == 0 && (!dP || (lddp % 4 == 0 && dpcol0 % 4 == 0 && al16(dP))) && al16(dM) && al16(A2) && al16(g2)) {
     constexpr int RPT = 4;
@@ -1070,6 +1074,7 @@ int sln_launch_gather_bwd(const float* dG, int ldg, int D, GraphCsr g, int O, co
                           const float* xprev, int ldx, BnView bn, int masked, float* out, int ldo, double* gsums,
                           int cstride, hipStream_t st) {
   if (O <= 0) return 0;
+  { static const int a = std::getenv("SLN_EDGE_ABL") ? std::atoi(std::getenv("SLN_EDGE_ABL")) : 0; if (a & 4) return 0; }      // lab, see sln_launch_scatter_avg_fwd
   SlnProfScope prof(SLN_FAM_EDGE, 4.0 * g.T * 2 * D + (masked ? 2.0 : 1.0) * 4.0 * O * D + 16.0 * g.T, st);
   if (D % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && (!add1 || (ldadd1 % 4 == 0 && al16(add1))) && (!masked || (ldx % 4 == 0 && al16(xprev))) &&
       al16(dG) && al16(out)) {
