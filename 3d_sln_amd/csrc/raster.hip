@@ -1694,7 +1694,12 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // value then receives two adds from the scans (one per incident edge: a + b is b + a) onto the zero fill and one more from the
   // depth walk, in stream order; the gradient sums take their fixed-order forms (one workgroup per plane / per image).
   const bool det = g_sln_deterministic != 0;
-  SceneSide* sd = (!det && n >= 16384) ? scene_side() : nullptr;
+  // Not inside a stream capture (round 6): a captured fork becomes a forked hipGraph, and this runtime replays forked graphs node
+  // by node from the host (0.31-0.40 ms of enqueue per replayed refinement iteration against 0.09 ms for a linear graph) without
+  // running the branches side by side - 16 rooms: 1.69-1.72 ms per replayed iteration with the forks, 1.66 ms without, 1.56-1.59 ms
+  // eager with them (profiles/r06_refine_batch_by_rooms.txt).  SLN_CAPTURE_SIDE=1 keeps the forks in captures (lab).
+  static const bool capture_side = std::getenv("SLN_CAPTURE_SIDE") != nullptr;
+  SceneSide* sd = (!det && n >= 16384 && (capture_side || !sln_capturing(st))) ? scene_side() : nullptr;
   // One stream and three events per device serve every caller: two host threads (or a capturing and an eager caller) enqueuing
   // their fork / mid / join records at the same time would cross their dependencies, so the fork..join section is exclusive
   // (host-side enqueue only: microseconds).  The guard below also JOINS on every way out: an error return between fork and join

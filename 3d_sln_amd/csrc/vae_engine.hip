@@ -1892,7 +1892,10 @@ struct SlnVaeGroup {
 
   int run(const std::vector<Launch>& prog, hipStream_t st) {
     const bool want_side = use_side;
-    side = want_side ? sln_overlapping_stream(st) : nullptr;
+    // (no side stream inside a capture: this runtime replays a forked hipGraph node by node from the host and does not overlap its
+    //  branches - see sln_scene_backward; SLN_CAPTURE_SIDE=1 keeps the forks, lab)
+    static const bool capture_side = std::getenv("SLN_CAPTURE_SIDE") != nullptr;
+    side = (want_side && (capture_side || !sln_capturing(st))) ? sln_overlapping_stream(st) : nullptr;
     struct Restore { bool& flag; bool v; ~Restore() { flag = v; } } restore{use_side, want_side};
     if (side == nullptr) use_side = false;          // none to be had (first use inside a capture): this pass on the caller's stream
     for (const Launch& l : prog) {

@@ -957,7 +957,11 @@ class RefineBatch:
                                           (self.lr / 10.0) * 1.1, P(self.z), P(self.dz), self.z.numel(), 2e-4 * 1.1, st), "sln_refine_sgd_rooms")
 
     def run(self, iters=None, capture=False):
-        """``iters`` more iterations (default: all that remain).  ``capture``: one iteration recorded into a hipGraph and replayed."""
+        """``iters`` more iterations (default: all that remain).  ``capture``: one iteration recorded into a hipGraph and replayed -
+        a LINEAR graph: inside a capture the library keeps its side work (wgrads, the depth chain of the scene backward) on the
+        captured stream, because this runtime replays forked graphs node by node from the host without overlapping the branches.
+        What a replay buys is the host (0.09 ms of enqueue per iteration instead of 0.3-0.4 ms); the GPU time is that of the one-stream
+        order, ~5 % above the eager loop with its side streams (16 rooms: 1.66 against 1.56-1.59 ms) - eager is the default."""
         n = (self.iters - self.k) if iters is None else int(iters)
         if self.k + n > self.iters:
             raise ValueError("RefineBatch was built for %d iterations (the noise of every iteration is drawn at construction)" % self.iters)

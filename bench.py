@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FAMILIES = ["gemm_nt", "gemm_tn", "edge", "other", "raster_fwd", "raster_bwd", "conv", "gemm_dual"]
 # rocprofv3 summaries, ONE PER LEG (tools/profile_round.sh r03): kernel-trace statistics of a run that executes that leg's
 # workload only, joined with the HBM traffic of two PMC passes of the same command (profiles/README.md)
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 
 
 def profile_csv(leg):
@@ -83,6 +83,9 @@ def parse():
                     help="Adam steps that over-fit the VAE to the refinement legs' rooms first (0: refine from the random decoder, the empty room)")
     ap.add_argument("--refine-rooms-large", type=int, default=64, help="a second, larger batch of rooms in flight (0 = skip)")
     ap.add_argument("--no-sampling", action="store_true")
+    ap.add_argument("--legs-only", action="store_true",
+                    help="run ONLY the side legs that are not switched off (no VAE loop at all) and print their objects: the command of "
+                         "tools/profile_round.sh's per-leg traces, whose kernel tables must not contain another leg's launches")
     ap.add_argument("--sampling-draws", type=int, default=20000, help="posterior draws of the heat-map leg (testing/test_heatmap.py:39: num_iter)")
     ap.add_argument("--large-batches", type=str, default="128,256,512,1024,4096", help="extra VAE points (graphs per step; 128 = options/options.py:34, 512 = configs[4]'s global batch on one GPU), '' = none")
     ap.add_argument("--no-colorize", action="store_true", help="skip the one-map / 50-z SPADE leg (per-leg profiles: batch-32 launches only)")
@@ -1199,6 +1202,23 @@ def main():
     lib.check(lib.lib().sln_device_ok(), "sln_device_ok")
     M = importlib.import_module("3d_sln_amd.host.Sg2ScVAE_model")
     syn = importlib.import_module("3d_sln_amd.host.synthetic")
+
+    if args.legs_only:
+        if world != 1:
+            raise SystemExit("bench.py: --legs-only is a single-GPU mode")
+        out = {"metric": "scene-graph VAE steps/sec + 256² diff-render fps, 1/2/4/8 MI355X", "value": None, "legs_only": True, "n_gpus": 1}
+        if not args.no_render:
+            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
+        if not args.no_spade:
+            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
+        if not args.no_graph_build:
+            log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
+        if not args.no_refine:
+            log('refine leg'); out["refine"] = refine_leg(args, lib, torch)
+        if not args.no_sampling:
+            log('sampling leg'); out["sampling"] = sampling_leg(args, lib, torch)
+        print(json.dumps(out))
+        return
 
     torch.manual_seed(42)
     kwargs = dict(vocab=syn.default_vocab(), batch_size=args.graphs, train_3d=True, decoder_cat=True, embedding_dim=64,

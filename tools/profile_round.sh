@@ -11,7 +11,7 @@
 # and the kernel trace of the DEFAULT bench command (all legs)            -> <tag>_rocprofv3_kernel_stats_raw.csv
 # tools/summarize_profile.py / summarize_sq.py condense them into profiles/.
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp && export TMPDIR=/tmp; cd "$ROOT"
 P=/tmp/prof_$TAG          # raw rocprofv3 output stays on the box (tens of MB); only the summaries travel back
@@ -20,12 +20,14 @@ FAILED=""
 COMMON="--no-cpu --no-check --no-dropin --large-batches= --no-graph-build --no-refine --no-sampling"
 declare -A FLAGS
 FLAGS[vae]="$COMMON --no-render --no-spade --steps 100 --warmup 10"
-FLAGS[render]="$COMMON --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 40 --render-warmup 5"
-FLAGS[spade]="$COMMON --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 6 --spade-warmup 2"
+# (render / spade: --legs-only - no VAE step runs in those traces; rounds 3-5 ran 125 of them in front of the leg, and the `pct` column of
+#  the leg's table was a share of the wrong total)
+FLAGS[render]="$COMMON --legs-only --no-spade --prof-steps 0 --render-iters 40 --render-warmup 5"
+FLAGS[spade]="$COMMON --legs-only --no-render --no-colorize --prof-steps 0 --spade-iters 6 --spade-warmup 2"
 declare -A SHORT
 SHORT[vae]="$COMMON --no-graph --no-render --no-spade --steps 12 --warmup 3 --prof-steps 0"
-SHORT[render]="$COMMON --no-graph --no-spade --steps 3 --warmup 2 --prof-steps 0 --render-iters 4 --render-warmup 2"
-SHORT[spade]="$COMMON --no-graph --no-render --no-colorize --steps 3 --warmup 2 --prof-steps 0 --spade-iters 1 --spade-warmup 1"
+SHORT[render]="$COMMON --legs-only --no-spade --prof-steps 0 --render-iters 4 --render-warmup 2"
+SHORT[spade]="$COMMON --legs-only --no-render --no-colorize --prof-steps 0 --spade-iters 1 --spade-warmup 1"
 flatten() { for g in $(find "$1" -name '*.csv'); do mv "$g" "$1/" 2>/dev/null; done; }
 for leg in ${LEGS:-vae render spade}; do
   D="$P/$leg"; mkdir -p "$D"
