@@ -30,11 +30,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# The CPU-oracle legs (parity checks, cpu_baseline) run OpenMP teams; with the default ACTIVE wait policy their threads keep spinning
-# for a while after a parallel region and starve the thread that issues the next leg's GPU launches (round 5: the render leg's
-# wall-clock mean was 1.9x its median behind the parity check).  Set before torch / libgomp load: idle teams sleep at once.
-os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
-os.environ.setdefault("GOMP_SPINCOUNT", "0")
+# The CPU-oracle legs (parity checks, cpu_baseline) run OpenMP teams whose idle threads spin between parallel regions; unbounded, they
+# starve the thread that issues the next leg's GPU launches (round 5: the render leg's wall-clock mean was 1.9x its median behind the
+# parity check).  A bounded spin (set before torch / libgomp load) keeps both: the render mean equals its median, and the CPU baselines
+# stay at their round-5 level - OMP_WAIT_POLICY=PASSIVE (sleep at once) cost the oracle 20 % (299 vs 375 graphs/s, tools/lab/omp_ab.sh).
+os.environ.setdefault("GOMP_SPINCOUNT", "30000")
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 VALU_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector peak (2 flop x 64 lanes x 4 SIMD x 256 CU x 2.4 GHz)
