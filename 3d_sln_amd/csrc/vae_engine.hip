@@ -164,7 +164,8 @@ struct SlnVae {
     GemmTNArgs probs[SLN_TN_MULTI_MAX]; TnMultiMeta meta; int n = 0, blocks = 0; bool x2 = false, xg = false; double flops = 0.0;
     bool dirty = true; GemmTNArgs* dev_probs = nullptr; TnMultiMeta* dev_meta = nullptr;
   };
-  // table slots of the per-pass wgrad launches: [0, tn_slots / 2) decoder pass, the rest encoder pass.  Sized from the layer count
+  // table slots of the per-pass wgrad launches: three regions of tn_slots / 3 - decoder pass, encoder pass, and (round 6) the ONE flush of
+  // a full iteration, whose tables must not share slots with the two-half graphs of the same engine.  Sized from the layer count
   // at creation (per-layer flushing - SLN_TN_PER_LAYER, deterministic mode with shared 'recurrent' weights - takes up to two per
   // layer; a launch that finds none runs its problems one by one)
   int tn_slots = 32;
@@ -173,7 +174,7 @@ struct SlnVae {
   int det_seen = 0;                              // g_sln_deterministic the captured iterations were recorded with
   bool tn_per_layer = false;                     // flush after every GraphTripleConv instead of once per pass
   bool tn_side = false, tn_side_busy = false;    // run the wgrad launches on the side stream, next to the dgrad chain
-  int tn_slot_next[2] = {0, 0};
+  int tn_slot_next[3] = {0, 0, 0};
   std::vector<GemmTNArgs> deferred;
   TnGroup* tn_groups_store = nullptr;            // [2 sets][TN_SLOTS][2], heap (a TnGroup is 50 KB)
   TnGroup& tn_group(int set, int slot, int k) { return tn_groups_store[((size_t)set * tn_slots + slot) * 2 + k]; }
@@ -288,7 +289,7 @@ struct SlnVae {
           tiles += tl; ++want;
         }
         int r = -1;
-        const bool have_slot = tn_slot_next[which] < tn_slots / 2;
+        const bool have_slot = tn_slot_next[which] < tn_slots / 3;
         for (; have_slot && want >= 1; want /= 2) {
           tmp.n = want;
           for (int i = 0; i < want; ++i) tmp.probs[i] = kind[next + i];
@@ -303,7 +304,7 @@ struct SlnVae {
           continue;
         }
         next += (size_t)tmp.n;
-        const int slot = which * (tn_slots / 2) + tn_slot_next[which]++;
+        const int slot = which * (tn_slots / 3) + tn_slot_next[which]++;
         TnGroup& g = tn_group(set, slot, k);
         if (g.n != tmp.n || std::memcmp(g.probs, tmp.probs, sizeof(GemmTNArgs) * (size_t)tmp.n) != 0 ||
             std::memcmp(&g.meta, &tmp.meta, sizeof(TnMultiMeta)) != 0) {
@@ -351,6 +352,7 @@ struct SlnVae {
   bool it_zero_in_prologue = false;   // ... and that launch also clears the iteration's accumulators
   bool it_prologue = false;       // enc_assemble + both predicate gathers (+ the N(0,1) draw) already issued as ONE launch
   bool it_fused_loss = false;     // log_softmax is taken inside the loss kernel
+  bool it_one_flush = false;      // full iterations: the decoder pass's wgrads ride with the encoder pass's launches (SLN_TN_ONE_FLUSH=0: off)
   bool it_merge_bn = false;       // ONE running-statistics launch per iteration (after the decoder) and ONE parameter-gradient launch
   bool no_merge = false;          // SLN_NO_MERGE=1 at creation: none of the three
   bool gconv_only = false;        // a bare GraphTripleConvNet (sln_gconv_net_*): units = the modules' four Linears, one net, no heads
@@ -905,7 +907,11 @@ int SlnVae::decoder_backward(hipStream_t st) {
     for (int i = n_bn_enc; i < (int)bns.size(); ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev + n_bn_enc, nb, maxc, cfg.recurrent ? 0 : 1, st));
   }
-  RET_IF(flush_deferred(0, st));       // every decoder-side wgrad: after this launch the upper half of the flat gradient is final
+  // (round 6, full iterations only: the decoder pass's wgrads wait and share the encoder pass's launches - two multi-problem launches
+  //  per step instead of four, 1.871 -> 1.845 ms per 64-graph step; their operands are per-layer buffers that nothing overwrites
+  //  before the end of the iteration.  SLN_TN_ONE_FLUSH=0 restores the flush per pass; the two-half data-parallel form always
+  //  flushes here: the decoder's half of the gradient must be final for its all-reduce)
+  if (!it_one_flush) RET_IF(flush_deferred(0, st));       // every decoder-side wgrad: after this launch the upper half of the flat gradient is final
   return 0;
 }
 
@@ -913,7 +919,7 @@ int SlnVae::decoder_backward(hipStream_t st) {
 int SlnVae::encoder_backward(hipStream_t st) {
   const bool tr = enc_training;
   if (ev_next > 4096) ev_next = 0;
-  tn_slot_next[1] = 0;
+  tn_slot_next[1] = tn_slot_next[2] = 0;
   if (enc_stats_doubles && !bulk_zeroed) RET_IF(sln_zero_async(gstats_base, enc_stats_doubles * sizeof(double), st));
   RET_IF(refresh_transposes(st));
   const int last = L - 1, W = 2 * E;
@@ -995,7 +1001,7 @@ int SlnVae::encoder_backward(hipStream_t st) {
     for (int i = 0; i < n_bn_enc; ++i) maxc = bns[i].C > maxc ? bns[i].C : maxc;
     RET_IF(sln_launch_bn_param_grads(bn_table_dev, n_bn_enc, maxc, cfg.recurrent ? 0 : 1, st));
   }
-  RET_IF(flush_deferred(1, st));
+  RET_IF(flush_deferred(it_one_flush ? 2 : 1, st));        // (region 2: the whole iteration's wgrads in one flush, see decoder_backward)
   return 0;
 }
 
@@ -1014,6 +1020,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     if (!it_zero_in_prologue) HIP_RET(hipMemsetAsync(zero_begin, 0, zero_bytes, st));
     bulk_zeroed = true;
     it_merge_bn = !no_merge && (mode == TRAIN_BACKWARD || mode == TRAIN_FULL);    // the two-half form hands the decoder's gradients out early
+    { static const bool one = !(std::getenv("SLN_TN_ONE_FLUSH") && std::getenv("SLN_TN_ONE_FLUSH")[0] == '0'); it_one_flush = one && defer && !tn_per_layer && (mode == TRAIN_BACKWARD || mode == TRAIN_FULL); }
     if (!it_prologue && draw_eps) r = sln_launch_randn(eps_buf, (long)O * E, scalars, st);       // Sg2ScVAE_model.py:182
     if (!r) r = encoder_forward(step_training, st);
     if (!r) r = decoder_forward(nullptr, eps, step_training, st);
@@ -1030,7 +1037,7 @@ int SlnVae::train_iteration(const float* eps, int mode, hipStream_t st) {
     if (!r) r = encoder_backward(st);
   }
   bulk_zeroed = false;
-  it_prologue = it_fused_loss = it_merge_bn = it_zero_in_prologue = false;
+  it_prologue = it_fused_loss = it_merge_bn = it_zero_in_prologue = it_one_flush = false;
   RET_IF(r);
   RET_IF(join_tn_side(st));            // the parameter gradients are complete behind this point (all-reduce, optimizer)
   if (mode == TRAIN_FULL) {
@@ -1124,7 +1131,7 @@ int sln_vae_create(const SlnVaeConfig* c, SlnVae** out) {
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
     { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
-    h->tn_slots = 2 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
+    h->tn_slots = 3 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
     h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * (size_t)h->tn_slots * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
@@ -1531,7 +1538,7 @@ int sln_gconv_net_create(int D, int H, int Dout, int num_layers, int recurrent, 
     const char* nf = std::getenv("SLN_NO_DEFER");
     h->defer = !(nf && nf[0] == '1');
     { const char* v = std::getenv("SLN_NO_MERGE"); h->no_merge = v && v[0] == '1'; }
-    h->tn_slots = 2 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
+    h->tn_slots = 3 * (2 * h->L + 8 > 16 ? 2 * h->L + 8 : 16);
     h->tn_groups_store = new (std::nothrow) SlnVae::TnGroup[2 * (size_t)h->tn_slots * 2];
     if (!h->tn_groups_store) { delete h; return SLN_E_BADARG; }
     { const char* v = std::getenv("SLN_TN_PER_LAYER"); h->tn_per_layer = v && v[0] == '1'; }
@@ -1599,7 +1606,7 @@ int sln_gconv_net_backward(SlnVae* h, const float* d_new_obj, const float* d_new
   const int D = h->Dec, L = h->L;
   const bool tr = h->enc_training;
   h->ev_next = 0;
-  h->tn_slot_next[0] = h->tn_slot_next[1] = 0;
+  h->tn_slot_next[0] = h->tn_slot_next[1] = h->tn_slot_next[2] = 0;
   if (h->stats_doubles) RET_IF(sln_zero_async(h->gstats_base, h->stats_doubles * sizeof(double), st));
   h->wt_fresh = false;                      // the caller's optimizer owns the parameters: rebuild W^T every backward
   RET_IF(h->refresh_transposes(st));

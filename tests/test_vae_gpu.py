@@ -397,7 +397,7 @@ def test_replicated_batch_gives_the_same_losses_and_gradients():
     if os.environ.get("SLN_TEST_SPREAD_REPORT"):
         print("2048 vs 256 graphs: worst", errs[:6], "rel L2", rel_l2(g32, g4), "| 256 vs 64 graphs: rel L2", rel_l2(g4, g1))
     assert worst[1] < 2e-5, "gradient of %s differs by %.2e of its scale between 4 and 32 copies of the batch" % worst
-    assert rel_l2(g32, g4) < 2e-6
+    assert rel_l2(g32, g4) < 4e-6      # (2.3e-6 since round 6: both passes' wgrads share two launches, whose row chunks are planned over more problems)
     assert rel_l2(g4, g1) < 2e-2       # other kernel bodies at 64 graphs, see above
     # the BatchNorm running statistics (momentum update of the same batch statistics; the unbiased variance's n / (n - 1) differs
     # by 1 / rows between the two sizes).  Not the updated parameters: the first Adam step moves an entry by lr * g / |g|, so the
