@@ -1444,7 +1444,7 @@ def main():
             per_family[k]["frac_rocprof"] = round(fam[k]["work"] / fam[k]["launches"] / (us_k * 1e-6) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4) if us_k else None
         per_family["gemm_nt"]["what"] = "forward Linears and dgrads, one launch each (64x64 tiles of 32x32x2 MFMAs, 64x96 / 64x160 tiles of 16x16x4 MFMAs for N = 384 / 640, 32x32 split-K tiles for the object side)"
         if "gemm_tn" in per_family:
-            per_family["gemm_tn"]["what"] = "every wgrad of a backward pass in one multi-problem launch (two per pass: gathered / plain rows)"
+            per_family["gemm_tn"]["what"] = "every wgrad of the iteration in two multi-problem launches (gathered / plain rows; the decoder pass's problems ride with the encoder pass's since round 6)"
             per_family["gemm_tn"]["algorithmic_bytes_per_launch"] = int(shp["tn_bytes_step"] / max(per_family["gemm_tn"]["launches_per_step"], 1))
         if "gemm_dual" in per_family:
             per_family["gemm_dual"]["what"] = "the twin head branches (box / angle), two Linears per launch"
