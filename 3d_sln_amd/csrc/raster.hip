@@ -600,12 +600,14 @@ struct PixClassView {
     if (cq >= 0) {
       const float g3 = __int_as_float(iq.w);
       const float dv = vq - (cr == cq ? vr : 0.f);
-      float diff = 0.f; diff += dv * g3; diff += dv * g3; diff += dv * g3;
+      // the package sums the three (identical) colour channels: ((0 + x) + x) + x.  x + x is exact and 2x + x rounds once, to the
+      // nearest float of 3x - the same value as the single multiplication below (two instructions less per term)
+      const float diff = 3.0f * (dv * g3);
       if (diff > 0.f) tot += diff;
     }
     if (cr >= 0 && cr != cq) {
       const float dv = 0.f - vr;
-      float diff = 0.f; diff += dv * g_cr; diff += dv * g_cr; diff += dv * g_cr;
+      const float diff = 3.0f * (dv * g_cr);
       if (diff > 0.f) tot += diff;
     }
     return tot;
@@ -631,10 +633,10 @@ __device__ __forceinline__ float pix_scale(float x, int is, bool pow2, float s2)
 // once; each unit adds its two partial sums to the face gradient with two atomics.
 constexpr int PMB_DC = 64;
 #ifndef PMB_ILP
-#define PMB_ILP 4            // windows of a row in flight per pass of phase 2a
+#define PMB_ILP 2            // windows of a row in flight per pass of phase 2a (same-box A/B of 1 / 2 / 3 / 4 / 8: 0.590 / 0.549 / 0.556 / 0.571 / 0.688 ms per 16-room batch)
 #endif
 #ifndef PMB_LONG
-#define PMB_LONG 32          // rows of at least this many pixels are scanned row by row (phase 2a); 0: every row flattened
+#define PMB_LONG 64          // rows of at least this many pixels are scanned row by row (phase 2a); 0: every row flattened (16 / 32 / 48 / 64: 0.586 / 0.571 / 0.548 / 0.546 ms with two windows per pass)
 #endif
 // diff / dist of a contributing scan pixel: v_rcp_f32 (1 ulp) and a multiplication instead of the ~12-instruction IEEE division
 // sequence, twice per contributing pixel in a kernel bound by instruction issue (0.774 -> 0.750 ms per 16 rooms forward + backward).
@@ -782,7 +784,8 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // ---- phase 2a: one row per pass of the wavefront (round 6) ----
   // Everything that describes the row - its step's crossing, ratios, reference record, first pixel, length - is wavefront-uniform
   // (v_readlane of the owning lane's phase-1 registers): a lane adds its offset to a scalar base, loads and evaluates; no walk along
-  // the prefix, no per-lane LDS reads, PMB_ILP windows' loads in flight at once.  Measured on the 16-room batch: 293 -> 272 us.
+  // the prefix, no per-lane LDS reads, PMB_ILP windows' loads in flight at once.  Measured on the 16-room batch: 293 -> 272 us
+  // (four windows per pass, rows >= 32), -> ~255 us with two windows per pass and rows >= 64 (the mean row is 112 pixels: a pass of 128).
   // The launch is bound by the instructions it ISSUES, vector and scalar together (one of each per cycle and CU): halving the vector
   // instructions of a window (they became scalar ones), four windows' loads in flight instead of one, and every load redirected to one
   // cache-resident 64 KB window each moved the kernel by less than 5 % (LAB_NOTES, round 6).
