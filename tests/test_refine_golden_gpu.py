@@ -185,12 +185,13 @@ def _check_loop(g, r, losses, z_hist, boxes_hist, idx_hist, params_after, model_
         assert_close(idx_hist[k], g[p + "idx"][k], "angle idx[%d]" % k, rtol=1e-4, atol=0)
         assert_close(z_hist[k], g[p + "z"][k], "z[%d]" % k, rtol=1e-5, atol=0)
         z_prev = g[p + "z"][k - 1] if k else g[p + "z0"]
-        # the step of z IS the gradient through the render (x 2.2e-4): pixel-map gradients with a handful of flipped silhouette pixels
-        assert_close(z_hist[k] - z_prev, g[p + "z"][k] - z_prev, "step of z[%d]" % k, rtol=2e-2, atol=0)
+        # the step of z IS the gradient through the render (x 2.2e-4).  Measured (tools/lab/refine_loop_errs.py): z equals the
+        # reference's bit for bit in room 0 and to one ulp of z (3e-7 absolute, 1.4e-2 of a step of 7e-6) in room 1
+        assert_close(z_hist[k] - z_prev, g[p + "z"][k] - z_prev, "step of z[%d]" % k, rtol=1e-3, atol=4e-7)
     for name, got in params_after.items():
         p0 = g["state:" + name]
         want = g[p + "param:" + name][it - 1]
-        assert_close(got - p0, want - p0, "%d steps of %s" % (it, name), rtol=2e-2, atol=1e-9)
+        assert_close(got - p0, want - p0, "%d steps of %s" % (it, name), rtol=6e-3, atol=1e-9)        # measured <= 2.1e-3 of the four steps' size
 
 
 @pytest.mark.parametrize("rooms", [[0, 1], [1]])
@@ -246,4 +247,4 @@ def test_one_room_loops_match_the_reference_loop():
     assert_close(idx.cpu(), g["room0:idx"][it - 1], "angle idx of the last iteration", rtol=1e-4, atol=0)
     for name in [k[len("room0:param:"):] for k in g.files if k.startswith("room0:param:")]:
         got = dict(model.named_parameters())[name].detach().cpu().numpy()
-        assert_close(got - p0[name], g["room0:param:" + name][it - 1] - g["state:" + name], "%d steps of %s" % (it, name), rtol=2e-2, atol=1e-9)
+        assert_close(got - p0[name], g["room0:param:" + name][it - 1] - g["state:" + name], "%d steps of %s" % (it, name), rtol=1e-2, atol=1e-9)
