@@ -1,7 +1,7 @@
 #!/bin/bash
 # The two small text files of profiles/<tag>_*: cost of SLN_DETERMINISTIC=1 and the data-parallel code path on one GPU.
 #   tools/round_extras.sh r03        (GPU box, repository root)
-TAG=${1:-r05}
+TAG=${1:-r06}
 V="--no-render --no-spade --no-graph-build --no-refine --no-sampling --no-cpu --no-dropin --large-batches= --steps 200 --warmup 20"
 R="--no-spade --no-graph-build --no-refine --no-sampling --no-cpu --no-check --no-dropin --large-batches= --steps 3 --warmup 2 --prof-steps 0"
 pick_vae='import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d["kernels"]; print("%-18s %.4f  %s   gemm_tn %.3f ms per step (%d launches)" % (sys.argv[1], d["ms_per_step"], d["ms_per_step_p10_p50_p90"], k["gemm_tn"]["ms_per_step"], k["gemm_tn"]["launches_per_step"]))'
