@@ -57,6 +57,29 @@ def test_recorded_bench_line_carries_the_contract_keys():
         assert d["render"]["roofline_kernels"][k]["bound"] == "hbm" and d["render"]["roofline_kernels"][k]["frac"] <= 1.0
 
 
+def test_round6_bench_line_ends_with_the_summary_of_every_config():
+    """profiles/r06_bench.json: the LAST key of the line is `summary` (what the tail of a log shows): both halves of the metric - c2
+    graphs/s and c3 renders/s, mean and median -, the other legs, every roofline fraction and every in-run parity figure; the render
+    figure is the wall-clock mean and agrees with the median; roofline traffic and algorithmic bytes come from one launch set; the
+    refinement leg carries its parity against the reference-executed loop."""
+    import json
+    line = open(os.path.join(ROOT, "profiles", "r06_bench.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    assert list(d.keys())[-1] == "summary" and len(json.dumps(d["summary"])) <= 700
+    s = d["summary"]
+    for k in ("c2_graphs_per_s", "c2_frac_mfma_step", "c3_renders_per_s", "c3_renders_per_s_median", "c3_frac_hbm", "c4_images_per_s",
+              "c4_frac_mfma", "refine16_ms", "refine64_ms", "sampling_layouts_per_s", "c2_err", "c3_px_diff", "c4_err", "refine_err"):
+        assert s.get(k) is not None, k
+    assert s["c2_graphs_per_s"] == d["value"] and s["c3_renders_per_s"] == d["render"]["renders_per_s"]
+    assert d["render"]["mean_over_median"] <= 1.05
+    assert max(s["c2_err"], s["c4_err"], s["refine_err"]) <= 1e-4 and s["c3_px_diff"] == 0
+    r = d["roofline"]
+    assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3, "one launch set for numerator and denominator"
+    rs = d["roofline_step"]
+    assert rs["traffic"] > 0 and abs(rs["traffic_over_survey_bytes"] - rs["traffic"] / rs["survey_bytes_per_step"]) < 2e-3
+    assert d["refine"]["parity"]["loss"] <= 1e-4 and "finetune_VAE" in d["refine"]["parity"]["against"]
+
+
 import pytest       # noqa: E402
 
 
