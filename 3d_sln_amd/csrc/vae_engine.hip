@@ -232,10 +232,11 @@ struct SlnVae {
   }
   // the wgrad launches may run on the side stream: fork behind the producer of their operands, join before anything reads the
   // parameter gradients (end of an iteration / of an eager backward call)
+  hipStream_t tn_side_stream = nullptr;          // the stream the current iteration's wgrad launches went to (join_tn_side)
   int join_tn_side(hipStream_t st) {
     if (!tn_side_busy) return 0;
     hipEvent_t e = next_event();
-    hipError_t r = hipEventRecord(e, side);
+    hipError_t r = hipEventRecord(e, tn_side_stream ? tn_side_stream : side);
     if (r == hipSuccess) r = hipStreamWaitEvent(st, e, 0);
     tn_side_busy = false;
     return (int)r;
@@ -260,11 +261,15 @@ struct SlnVae {
     }
     hipStream_t lst = st;
     if (tn_side && side) {
+      // (lab, SLN_TN_SIDE=1) eager launches: a pooled stream that is PROBED to overlap with the caller's (csrc/streams.hip: the engine's
+      // own side stream may share the caller's hardware queue); captures keep the engine's stream
+      hipStream_t sd = sln_capturing(st) ? side : sln_overlapping_stream(st);
+      if (sd == nullptr) sd = side;
       hipEvent_t e = next_event();
       hipError_t r = hipEventRecord(e, st);
-      if (r == hipSuccess) r = hipStreamWaitEvent(side, e, 0);
+      if (r == hipSuccess) r = hipStreamWaitEvent(sd, e, 0);
       if (r != hipSuccess) { deferred.clear(); return (int)r; }
-      lst = side; tn_side_busy = true;
+      lst = sd; tn_side_stream = sd; tn_side_busy = true;
     }
     static thread_local TnGroup tmp;
     // two kinds of problems (X rows gathered: every net1.0; plain rows: the rest).  A launch group is closed by problem count
@@ -320,6 +325,7 @@ struct SlnVae {
           } else {                    // wgrads on the side stream (SLN_TN_SIDE=1): blocking, as before
             hipError_t e = hipStreamSynchronize(st);          // an earlier launch may still read the old table
             if (e == hipSuccess && side) e = hipStreamSynchronize(side);
+            if (e == hipSuccess && lst != side) e = hipStreamSynchronize(lst);
             if (e != hipSuccess) { deferred.clear(); return (int)e; }
             r = upload_group(g);
             if (r) { deferred.clear(); return r; }
