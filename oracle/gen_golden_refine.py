@@ -24,7 +24,7 @@ What is injected (and therefore NOT pinned by these fixtures):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/gen_golden_refine.py [helpers|scene|loop|all]
 
-Writes tests/golden/refine_helpers.npz, refine_scene.npz, refine_loop.npz (numeric arrays only).
+Writes tests/golden/refine_helpers.npz, refine_scene.npz, refine_loop.npz, refine_loop_recurrent.npz (numeric arrays only).
 """
 from __future__ import annotations
 
@@ -336,6 +336,12 @@ LOOP_CFG = dict(embedding_dim=32, gconv_num_layers=2, num_objs=len(VOCAB) + 1)
 LOOP_ITERS = 4
 LOOP_ROOMS = ((21, 5), (22, 7))           # (seed, objects): R = 2 rooms
 LOOP_IMAGE = 96
+# second fixture: a 'recurrent' decoder (models/graph.py:129-143: ONE GraphTripleConv applied gconv_num_layers times - every wgrad of the
+# refinement step adds into the same weights), one room, three iterations
+LOOP_CASES = {
+    "refine_loop": (LOOP_CFG, LOOP_ROOMS, LOOP_ITERS),
+    "refine_loop_recurrent": (dict(embedding_dim=32, gconv_num_layers=3, gconv_mode="recurrent", num_objs=len(VOCAB) + 1), ((23, 6),), 3),
+}
 
 
 def _room_graph(cfg, seed, n_obj):
@@ -349,7 +355,7 @@ def _room_graph(cfg, seed, n_obj):
     return objs_np, tri, boxes_np, angles_np, attrs_np
 
 
-def loop_state(cfg, ref_vae, ref_utils, steps=400, settle=80):
+def loop_state(cfg, ref_vae, ref_utils, rooms=LOOP_ROOMS, steps=400, settle=80):
     """A 'checkpoint' for the loop: the reference model over-fitted to the fixture's rooms with the reference's own loss (a randomly
     initialised decoder predicts degenerate boxes, the render is an empty room and nothing reaches z).  ``settle`` steps at lr 0 let the
     BatchNorm running statistics - what model.eval() reads - catch up with the final weights.  How the state was made is immaterial to
@@ -359,7 +365,7 @@ def loop_state(cfg, ref_vae, ref_utils, steps=400, settle=80):
     model = ref_vae.Sg2ScVAEModel(**cfg.model_kwargs())
     model.load_state_dict({k_: v_.clone() for k_, v_ in sd.items()})
     parts, off = [], 0
-    for seed, n_obj in LOOP_ROOMS:
+    for seed, n_obj in rooms:
         ob, tr, bx, an, at = _room_graph(cfg, seed, n_obj)
         tr = tr.copy(); tr[:, 0] += off; tr[:, 2] += off
         parts.append((ob, tr, bx, an, at)); off += n_obj + 1
@@ -379,13 +385,19 @@ def loop_state(cfg, ref_vae, ref_utils, steps=400, settle=80):
     return {k_: v_.detach().clone() for k_, v_ in model.state_dict().items()}
 
 
-def gen_loop():
+def gen_loop(only=None):
+    for name, (cfg_kw, rooms, iters) in LOOP_CASES.items():
+        if only is None or name in only:
+            _gen_loop_case(name, cfg_kw, rooms, iters)
+
+
+def _gen_loop_case(case, cfg_kw, LOOP_ROOMS, LOOP_ITERS):
     from oracle import gen_golden, vae_ref
     tables = synth_tables()
     out = _tables_to_arrays(tables)
     ref_graph, ref_vae, ref_utils = gen_golden._import_reference()
-    cfg = vae_ref.VaeConfig(**LOOP_CFG)
-    sd0 = loop_state(cfg, ref_vae, ref_utils)
+    cfg = vae_ref.VaeConfig(**cfg_kw)
+    sd0 = loop_state(cfg, ref_vae, ref_utils, LOOP_ROOMS)
     for k_, v_ in sd0.items():
         out["state:" + k_] = v_.numpy()
     for r, (seed, n_obj) in enumerate(LOOP_ROOMS):
@@ -416,7 +428,8 @@ def gen_loop():
                             z=e["z"].detach().clone().numpy(), boxes=e["boxes_pred"].detach().clone().numpy(),
                             idx=e["angles_pred_idx2"].detach().clone().numpy(), image=_image_summary(e["iter_image"]),
                             dz=e["z"].grad.detach().clone().numpy(),
-                            params={k_: p.detach().clone().numpy() for k_, p in e["model"].named_parameters() if k_.startswith(("box_net", "angle_net.0", "gconv_net_dc.gconvs.1.net2.0"))}))
+                            params={k_: p.detach().clone().numpy() for k_, p in e["model"].named_parameters()
+                                    if k_.startswith(("box_net", "angle_net.0", "gconv_net_dc.gconvs.1.net2.0", "gconv_net_dc.gconvs.0.net1.0"))}))
         env.update(model=model, z=None, z_np=z_np.copy(), save_name=tmp,        # (a copy: on the CPU .type(FloatTensor) aliases z_np, which SGD then steps)
                    float_dtype=torch.FloatTensor, long_dtype=torch.LongTensor,
                    args=types.SimpleNamespace(learning_rate=1e-4), objs=objs, triples=triples, attributes=attributes, obj_to_img=obj_to_img,
@@ -438,8 +451,8 @@ def gen_loop():
             out[p + "param:" + name] = np.stack([x["params"][name] for x in rec])
         print("loop room %d (%d objects): losses %s" % (r, n_obj, " ".join("%.5f" % x["loss"] for x in rec)))
         print("    depth %s  sem %s  size %s" % (["%.5f" % x["depth"] for x in rec], ["%.5f" % x["sem"] for x in rec], ["%.2e" % x["size"] for x in rec]))
-    np.savez_compressed(os.path.join(GOLD, "refine_loop.npz"), **out)
-    print("wrote refine_loop.npz: %d arrays" % len(out))
+    np.savez_compressed(os.path.join(GOLD, case + ".npz"), **out)
+    print("wrote %s.npz: %d arrays" % (case, len(out)))
 
 
 if __name__ == "__main__":

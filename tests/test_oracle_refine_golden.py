@@ -90,12 +90,12 @@ def test_render_room_matches_the_reference_mesh_render_func(tag, S):
     _close(b2.grad, g[p + "grad_boxes_size"], 1e-5, "d size loss / d boxes")
 
 
-@pytest.mark.parametrize("r", [0, 1])
-def test_refine_loop_matches_the_reference_loop(r):
-    g = _load("refine_loop.npz")
+@pytest.mark.parametrize("case,r", [("refine_loop", 0), ("refine_loop", 1), ("refine_loop_recurrent", 0)])
+def test_refine_loop_matches_the_reference_loop(case, r):
+    g = _load(case + ".npz")
     tables = rf.load_tables(g)
-    from oracle.gen_golden_refine import LOOP_CFG, LOOP_IMAGE
-    cfg = vae_ref.VaeConfig(**LOOP_CFG)
+    from oracle.gen_golden_refine import LOOP_CASES, LOOP_IMAGE
+    cfg = vae_ref.VaeConfig(**LOOP_CASES[case][0])
     sd = {k[6:]: torch.from_numpy(g[k]).clone() for k in g.files if k.startswith("state:")}
     train = [k for k in vae_ref.trainable_keys(cfg)]
     for k in train:
