@@ -1,39 +1,35 @@
-"""Host-side tensor helpers of host/sampling.py that need no GPU: the heat-map accumulation against a numpy
-restatement of the reference's loop (testing/test_heatmap.py:80-99)."""
+"""Host-side tensor helpers of host/sampling.py that need no GPU, against fixtures made by executing the reference's own source
+(oracle/gen_golden_sampling.py): the heat-map accumulation (testing/test_heatmap.py:74-99) and get_sg_from_words."""
 import numpy as np
 import torch
 
-from conftest import pkg
+from conftest import load_golden, pkg
 
 
-def _reference_loop(boxes, size, clip):
-    n, O, _ = boxes.shape
-    out = np.zeros((O - 1, size, size))
-    for obj in range(O - 1):
-        for trial in range(n):
-            bb, nz = boxes[trial][obj], boxes[trial][-1]
-            bb = np.array(bb) * np.concatenate([nz[3:] - nz[:3], nz[3:] - nz[:3]])
-            ct = (bb[:3] + bb[3:]) * 0.5
-            if clip:
-                ct = np.clip(ct, 0.0, 1.0)
-            elif not (np.all(ct > 0.0) and np.all(ct < 1.0)):
-                continue
-            rd = np.floor(ct * (size - 1)).astype("int")
-            out[obj, rd[2], rd[0]] += 1.0
-        out[obj] = out[obj] / max(np.sum(out[obj]), 1.0)
-    return out
-
-
-def test_layout_heatmap_equals_reference_loop():
+def test_layout_heatmap_equals_the_reference_loop():
+    """host/sampling.py::layout_heatmap against the maps the reference's own accumulation loop produced (testing/test_heatmap.py:74-99,
+    executed from its source by oracle/gen_golden_sampling.py with matplotlib replaced by a recorder): clipped and rejecting variants,
+    room rows that are not the unit box."""
     S = pkg("host.sampling")
-    rng = np.random.default_rng(0)
-    boxes = rng.uniform(-0.2, 1.2, size=(300, 5, 6)).astype(np.float32)
-    boxes[:, -1] = [0, 0, 0, 1, 1, 1]
-    for clip in (True, False):
-        got = S.layout_heatmap(torch.from_numpy(boxes), 50, clip).numpy()
-        want = _reference_loop(boxes, 50, clip)
-        assert np.allclose(got, want, atol=1e-7), clip
+    g = load_golden("sampling_helpers")
+    for tag, clip in (("clip", True), ("reject", False)):
+        boxes, want, size = g["heat_%s:boxes" % tag], g["heat_%s:maps" % tag], int(g["heat_%s:size" % tag])
+        got = S.layout_heatmap(torch.from_numpy(boxes), size, clip).numpy()
+        assert got.shape == want.shape
+        assert np.allclose(got, want, atol=1e-7), tag
         assert np.allclose(got.sum((1, 2))[want.sum((1, 2)) > 0], 1.0)
+
+
+def test_scene_graph_from_words_equals_the_reference_function():
+    """... and scene_graph_from_words against get_sg_from_words (testing/test_utils.py:43-90, executed from its source)"""
+    S = pkg("host.sampling")
+    from oracle.gen_golden_sampling import SCENES
+    g = load_golden("sampling_helpers")
+    for i, (objs, rels) in enumerate(SCENES):
+        o, t, a = S.scene_graph_from_words(objs, rels)
+        assert np.array_equal(o.numpy(), g["sg%d:objs" % i]) and np.array_equal(t.numpy(), g["sg%d:triples" % i])
+        assert np.array_equal(a.numpy(), g["sg%d:attributes" % i])
+        assert o.dtype == torch.int64 and t.dtype == torch.int64 and a.dtype == torch.int64
 
 
 def test_scene_graph_from_words_layout():
