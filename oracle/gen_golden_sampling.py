@@ -62,5 +62,45 @@ def main():
     print("wrote sampling_helpers.npz: %d arrays" % len(out))
 
 
+def gen_spade_input():
+    """`colorize_with_spade` (testing/test_SPADE_shade.py:30-79) and `save_color` (:16-27) executed from their source: imageio serves the
+    procedural scene of oracle/spade_input_ref.py::synth_scene at the 1 024^2 the function hard-codes, the generator is a recorder (it
+    receives `total`, the [1,41,256,256] tensor under test), skimage's resize - not installed here, PARITY UNPINNED - is the scipy
+    restatement of oracle/spade_input_ref.py."""
+    import tempfile
+    from oracle import spade_input_ref as sir
+    from oracle.gen_golden_refine import _neutralise
+    _neutralise()
+    th = os.path.join(REF, "testing", "test_SPADE_shade.py")
+    depth, masks = sir.synth_scene(1024, seed=2)
+    d = tempfile.mkdtemp(prefix="sln_spade_input_")
+    files = {"room_0000_depth.exr": np.stack([depth] * 3, -1)}
+    for name, m in masks.items():
+        files["room_0000_mask_%s.png" % name] = np.stack([m] * 3, -1)
+    for f in files:
+        open(os.path.join(d, f), "w").close()
+    seen, written = [], []
+
+    class Writer:
+        def append_data(self, a): written.append(np.array(a))
+        def close(self): pass
+    fake = torch.from_numpy(np.random.default_rng(9).uniform(-1, 1, size=(1, 3, 16, 16)).astype(np.float32))
+    ns = dict(np=np, torch=torch, os=os, print=_quiet, resize=lambda a, shape, **k: sir.resize_skimage(a, shape),
+              imageio=types.SimpleNamespace(imread=lambda p: files[os.path.basename(p)], get_writer=lambda *a, **k: Writer()),
+              colorization_model=lambda total, z: (seen.append(total.clone()), fake)[1])
+    _run(_top_level(th, ["save_color", "colorize_with_spade"]).values(), ns, th)
+    torch.manual_seed(0)
+    ns["colorize_with_spade"](2, d, tempfile.mkdtemp(prefix="sln_spade_out_"))
+    assert len(seen) == 2 and torch.equal(seen[0], seen[1]) and seen[0].shape == (1, 41, 256, 256) and len(written) == 2
+    total = seen[0][0].numpy()
+    live = np.nonzero(np.abs(total).reshape(41, -1).max(1) > 1e-6)[0]          # (the spline prefilter along the channel axis leaves ~1e-17 in empty channels)
+    out = {"total_channels": live.astype(np.int64), "total_half": total[live][:, ::2, ::2].astype(np.float32),
+           "total_sums": total.astype(np.float64).reshape(41, -1).sum(1), "total_abs_sums": np.abs(total.astype(np.float64)).reshape(41, -1).sum(1),
+           "save_color_in": fake.numpy(), "save_color_out": written[0]}
+    np.savez_compressed(os.path.join(GOLD, "spade_input.npz"), **out)
+    print("wrote spade_input.npz: live channels", live.tolist())
+
+
 if __name__ == "__main__":
     main()
+    gen_spade_input()

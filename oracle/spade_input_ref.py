@@ -4,7 +4,9 @@ TEST INFRASTRUCTURE ONLY.  numpy / scipy restatement of the array work in ``colo
 (/root/reference/testing/test_SPADE_shade.py:50-76): depth normalisation, class-mask thresholding, channel stacking and
 ``skimage.transform.resize(total, [256, 256], preserve_range=True, order=3, anti_aliasing=True)``.
 
-Parity status: the numpy steps are the reference's own lines; the resize is PARITY UNPINNED - scikit-image is not installed
+Parity status: the numpy steps are PINNED (round 6): oracle/gen_golden_sampling.py::gen_spade_input executes the reference's
+``colorize_with_spade`` and ``save_color`` from their source text (imageio replaced by arrays, the generator by a recorder) and
+tests/test_spade_input.py holds ``build_input`` / ``save_color_array`` to what they produced; the resize is PARITY UNPINNED - scikit-image is not installed
 in this image (and the reference pins no version), so its documented algorithm (scikit-image >= 0.19, transform/_warps.py
 ``resize``: ``ndi.gaussian_filter(image, sigma=(factor-1)/2 per resized axis, mode='mirror')`` followed by
 ``ndi.zoom(..., order=3, mode='mirror', grid_mode=True)``; ``mode='reflect'`` of skimage maps to scipy's 'mirror') is
@@ -58,3 +60,22 @@ def save_color_array(img):
     """save_color (test_SPADE_shade.py:16-27): [-1,1] CHW -> uint8 HWC"""
     a = (np.asarray(img, dtype=np.float32) + 1.0) / 2.0
     return (a.transpose((1, 2, 0)) * 255.0).astype(np.uint8)
+
+
+def synth_scene(n=256, seed=0):
+    """a procedural (depth [n,n] float32, {class: mask [n,n] 0..255}) pair: a tilted floor with background hits (the .exr's 65504), four
+    class masks with anti-aliasing greys below the threshold and one row exactly AT it - shared by tests/test_spade_input.py and
+    oracle/gen_golden_sampling.py::gen_spade_input"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:n, 0:n] / n
+    depth = (2.0 + 3.0 * yy + np.sin(6 * xx) + 0.05 * rng.standard_normal((n, n))).astype(np.float32)
+    depth[:8 * n // 256, :8 * n // 256] = 65504.0                       # background hits: the reference clips at max(d[d < 20])
+    masks = {}
+    for name, (y0, x0, h, w) in {"bed": (40, 30, 90, 120), "night_stand": (150, 170, 40, 50), "wall": (0, 0, 256, 40),
+                                 "floor_mat": (200, 60, 30, 100)}.items():
+        m = np.zeros((n, n), np.float32)
+        m[y0 * n // 256:(y0 + h) * n // 256, x0 * n // 256:(x0 + w) * n // 256] = 255
+        m[(y0 + 3) * n // 256, x0 * n // 256:(x0 + w) * n // 256] = 120      # exactly 120 stays 120 (neither < nor > 120)
+        m += rng.integers(0, 100, size=(n, n)) * (m == 0)                     # anti-aliasing greys below the threshold
+        masks[name] = m
+    return depth, masks

@@ -1,26 +1,15 @@
 """SPADE input builder (host/spade_input.py) against the scipy.ndimage restatement of the reference's preprocessing
-(oracle/spade_input_ref.py; skimage itself is not in this image - parity unpinned for the resize, see the oracle header)."""
+(oracle/spade_input_ref.py; skimage itself is not in this image - parity unpinned for the resize, see the oracle header) and,
+for everything but the resize, against what the reference's own `colorize_with_spade` / `save_color` produced when executed from
+their source (oracle/gen_golden_sampling.py::gen_spade_input -> tests/golden/spade_input.npz)."""
 import numpy as np
 import torch
 
-from conftest import pkg
+from conftest import load_golden, pkg
 from oracle import spade_input_ref as R
 
 
-def _scene(n=256, seed=0):
-    rng = np.random.default_rng(seed)
-    yy, xx = np.mgrid[0:n, 0:n] / n
-    depth = (2.0 + 3.0 * yy + np.sin(6 * xx) + 0.05 * rng.standard_normal((n, n))).astype(np.float32)
-    depth[:8, :8] = 65504.0                                              # background hits in the .exr: the reference clips at max(d[d<20])
-    masks = {}
-    for name, (y0, x0, h, w) in {"bed": (40, 30, 90, 120), "night_stand": (150, 170, 40, 50), "wall": (0, 0, 256, 40),
-                                 "floor_mat": (200, 60, 30, 100)}.items():
-        m = np.zeros((n, n), np.float32)
-        m[y0 * n // 256:(y0 + h) * n // 256, x0 * n // 256:(x0 + w) * n // 256] = 255
-        m[(y0 + 3) * n // 256, x0 * n // 256:(x0 + w) * n // 256] = 120      # exactly 120 stays 120 (neither < nor > 120)
-        m += rng.integers(0, 100, size=(n, n)) * (m == 0)                     # anti-aliasing greys below the threshold
-        masks[name] = m
-    return depth, masks
+_scene = R.synth_scene
 
 
 def test_file_name_rule_and_class_order():
@@ -58,3 +47,22 @@ def test_to_uint8_is_save_color():
     got = S.to_uint8(img).numpy()
     for i in range(2):
         assert np.array_equal(got[i], R.save_color_array(img[i].numpy()))
+
+
+def test_oracle_and_product_reproduce_the_reference_function():
+    """`colorize_with_spade` (testing/test_SPADE_shade.py:30-79) executed from its source on the 1 024^2 scene: the [1,41,256,256] tensor
+    it hands the generator (every second pixel of the live channels + per-channel sums) and `save_color`'s uint8 image.  The oracle
+    must reproduce it exactly (same numpy lines, same scipy resize); the product's matrix form of the resize to 2e-6."""
+    S = pkg("host.spade_input")
+    g = load_golden("spade_input")
+    depth, masks = R.synth_scene(1024, seed=2)
+    want_half, chans = g["total_half"], g["total_channels"]
+    ora = R.build_input(depth, masks, size=256)[0]
+    assert np.array_equal(ora[chans][:, ::2, ::2], want_half)
+    assert np.allclose(ora.astype(np.float64).reshape(41, -1).sum(1), g["total_sums"], rtol=0, atol=1e-9)
+    got = S.build_input(torch.from_numpy(depth), {k: torch.from_numpy(v) for k, v in masks.items()}, size=256)[0].numpy()
+    assert np.abs(got[chans][:, ::2, ::2] - want_half).max() <= 2e-6
+    assert np.abs(got.astype(np.float64).reshape(41, -1).sum(1) - g["total_sums"]).max() <= 2e-6 * 256 * 256
+    assert sorted(chans.tolist()) == sorted([0] + [1 + R.NYU40.index(k) for k in masks])
+    img = torch.from_numpy(g["save_color_in"])
+    assert np.array_equal(S.to_uint8(img).numpy()[0], g["save_color_out"]) and np.array_equal(R.save_color_array(img[0].numpy()), g["save_color_out"])
