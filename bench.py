@@ -22,6 +22,7 @@ before anything is printed.  The oracle is only ever the checker and the timed C
 """
 import argparse
 import ctypes as C
+import gc
 import importlib
 import json
 import os
@@ -203,6 +204,14 @@ def log(msg):
 
 
 # ------------------------------------------------------------------------------------------------------------- checks
+def leg(name):
+    """A leg starts with the cyclic collector run by hand: main() switches the automatic one off, because a generation-2 pass over the
+    objects the CPU oracles leave behind takes ~50 ms on the host, and when it lands inside a 20-step timed loop the GPU idles for that
+    long behind it (round 6: `--steps 20` showed the render leg's mean at 2x its median - one 53 ms iteration out of 100)."""
+    log(name + " leg")
+    gc.collect()
+
+
 def check_vae(lib, torch, M, model, batch):
     """Smoke-style check of the fused step on a small configuration (1e-4 on the loss and on a gradient tensor) and a gross-error
     guard on the bench's own model and batch (forward + loss of the 64-graph batch against the oracle)."""
@@ -580,9 +589,15 @@ def render_leg(args, lib, torch, rank):
     for k in range(args.render_iters):
         it()
         marks[k + 1].record()
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    per = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.render_iters))
+    per_raw = [marks[k].elapsed_time(marks[k + 1]) for k in range(args.render_iters)]
+    per = sorted(per_raw)
+    if os.environ.get("SLN_BENCH_DEBUG"):
+        worst = sorted(range(len(per_raw)), key=lambda k: -per_raw[k])[:6]
+        log("render debug: slowest iterations (index, ms): %s; host enqueue of the loop %.1f ms for %.1f ms of GPU time" %
+            ([(k, round(per_raw[k], 3)) for k in worst], t_enq * 1e3, sum(per_raw)))
     lib.check(lib.lib().sln_prof_enable(1), "prof")
     for _ in range(5):
         it()
@@ -1163,6 +1178,7 @@ def vae_gemm_shapes(O, T, E=64, L=5, box_dim=6, n_angle=24):
 
 def main():
     args = parse()
+    gc.disable()                                 # collected by hand at the leg boundaries instead, see leg()
     import torch
     import torch.distributed as dist
 
@@ -1208,15 +1224,15 @@ def main():
             raise SystemExit("bench.py: --legs-only is a single-GPU mode")
         out = {"metric": "scene-graph VAE steps/sec + 256² diff-render fps, 1/2/4/8 MI355X", "value": None, "legs_only": True, "n_gpus": 1}
         if not args.no_render:
-            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
+            leg('render'); out["render"] = render_leg(args, lib, torch, rank)
         if not args.no_spade:
-            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
+            leg('spade'); out["spade"] = spade_leg(args, lib, torch)
         if not args.no_graph_build:
-            log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
+            leg('graph-build'); out["graph_build"] = graph_build_leg(args, lib, torch)
         if not args.no_refine:
-            log('refine leg'); out["refine"] = refine_leg(args, lib, torch)
+            leg('refine'); out["refine"] = refine_leg(args, lib, torch)
         if not args.no_sampling:
-            log('sampling leg'); out["sampling"] = sampling_leg(args, lib, torch)
+            leg('sampling'); out["sampling"] = sampling_leg(args, lib, torch)
         print(json.dumps(out))
         return
 
@@ -1268,6 +1284,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    gc.collect()
     with torch.cuda.stream(stream):
         for _ in range(args.warmup):
             losses = step()
@@ -1536,22 +1553,22 @@ def main():
         # the BASELINE configs first (render, SPADE), on a memory pool that has only seen the headline loop: behind the
         # large-batch points (11 GB workspaces allocated and released) the scene backward measured 0.55 instead of 0.43 ms
         if not args.no_render:
-            log('render leg'); out["render"] = render_leg(args, lib, torch, rank)
+            leg('render'); out["render"] = render_leg(args, lib, torch, rank)
         if not args.no_spade:
-            log('spade leg'); out["spade"] = spade_leg(args, lib, torch)
+            leg('spade'); out["spade"] = spade_leg(args, lib, torch)
         if not args.no_cpu:
-            log('c1 leg'); out["c1"] = c1_leg(args, torch, M)
+            leg('c1'); out["c1"] = c1_leg(args, torch, M)
         if not args.no_dropin:
-            log('drop-in VAE leg'); out["vae_dropin"] = vae_dropin_leg(args, torch, M, syn, ms_per_step)
+            leg('drop-in VAE'); out["vae_dropin"] = vae_dropin_leg(args, torch, M, syn, ms_per_step)
         sizes = [int(x) for x in args.large_batches.split(",") if x.strip()]
         if sizes:
-            log('large-batch leg'); out["vae_large_batch"] = large_batch_leg(args, torch, M, syn, sizes)
+            leg('large-batch'); out["vae_large_batch"] = large_batch_leg(args, torch, M, syn, sizes)
         if not args.no_graph_build:
-            log('graph-build leg'); out["graph_build"] = graph_build_leg(args, lib, torch)
+            leg('graph-build'); out["graph_build"] = graph_build_leg(args, lib, torch)
         if not args.no_refine:
-            log('refine leg'); out["refine"] = refine_leg(args, lib, torch)
+            leg('refine'); out["refine"] = refine_leg(args, lib, torch)
         if not args.no_sampling:
-            log('sampling leg'); out["sampling"] = sampling_leg(args, lib, torch)
+            leg('sampling'); out["sampling"] = sampling_leg(args, lib, torch)
         log('done')
     if rank == 0:
         # LAST key of the line: every config of the metric in one compact object (a log tail then carries both halves of
