@@ -663,6 +663,13 @@ constexpr int PMB_DC = 64;
 // (one ds_read_b128 instead of four ds_read_b32), the 16-byte reference records (one read, selected by address), the ratios of
 // a step read only by contributing pixels, and image-local 32-bit pixel offsets.
 struct __align__(16) PmbStep { int lo, ofrom, ifrom; float cross; };
+#ifdef PMB_STAMP
+// lab build only: per-workgroup clock sums (prologue, phase 1, phase 2a load waits / evaluation / passes / rows, phase 2b), one slot per
+// workgroup, read back by sln_lab_pmb_stamps
+constexpr int PMB_STAMP_SLOTS = 1 << 19;
+__device__ unsigned long long g_pmb_stamp[PMB_STAMP_SLOTS][8];
+#define PMB_T() ((unsigned long long)clock64())
+#endif
 template <typename PIX>
 __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int B, int F, int is,
                                                                 float eps, float* __restrict__ gfaces, const FaceRec* __restrict__ vis) {
@@ -680,6 +687,10 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // (32-bit arithmetic: the first version did this mapping with 64-bit integers - four software divisions, ~600 scalar
   // instructions in front of every one of the 370 k workgroups of a 16-room batch, as many as all their scan windows issue)
   const int lane = threadIdx.x;
+#ifdef PMB_STAMP
+  const unsigned long long T_start = PMB_T();
+  unsigned long long T_p1 = 0, T_wait = 0, T_eval = 0, T_2b = 0, N_pass = 0, N_rows = 0, T_pro = 0;
+#endif
   unsigned bu, fnu; int ea;
   if (B >= 8) {
     const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;       // < 6 * 8 * ceil(B / 8) * F: the launcher refuses grids beyond 2^32
@@ -728,9 +739,15 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   const int wfirst = 64 * (int)blockIdx.z, wstep = 64 * (int)gridDim.z;
   // an edge longer than PMB_DC steps takes several rounds (chunks) in the same wavefront: one workgroup per chunk filled the
   // grid with empty workgroups (three out of four), whose dispatch alone cost ~0.25 ms per batch of 16 rooms
+#ifdef PMB_STAMP
+  T_pro = PMB_T() - T_start;
+#endif
   for (int c_from = d0_from; c_from <= d0_to; c_from += PMB_DC) {
   const int c_to = min(d0_to, c_from + PMB_DC - 1);
   __syncthreads();                              // the LDS tables of the previous round are no longer read
+#ifdef PMB_STAMP
+  const unsigned long long T_c0 = PMB_T();
+#endif
 
   // ---- phase 1: one edge step per lane ----
   const int d0 = c_from + lane;
@@ -780,6 +797,9 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   s_ratio[lane] = make_float2(r0, r1);
   __syncthreads();
   const int W = s_pre[64];
+#ifdef PMB_STAMP
+  T_p1 += PMB_T() - T_c0;
+#endif
 
   // ---- phase 2a: one row per pass of the wavefront (round 6) ----
   // Everything that describes the row - its step's crossing, ratios, reference record, first pixel, length - is wavefront-uniform
@@ -809,8 +829,14 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
         ru.z = __builtin_amdgcn_readlane(myref.z, l); ru.w = __builtin_amdgcn_readlane(myref.w, l);
         const typename View::Ref ref = *reinterpret_cast<const typename View::Ref*>(&ru);
         const int d0r = c_from + l;
+#ifdef PMB_STAMP
+        ++N_rows;
+#endif
         for (int k = 0; k < len; k += 64 * PMB_ILP, ++widx) {
           if (gz > 1 && widx % gz != zme) continue;
+#ifdef PMB_STAMP
+          const unsigned long long T_a = PMB_T();
+#endif
           typename View::Loaded ld[PMB_ILP];
 #pragma unroll
           for (int u = 0; u < PMB_ILP; ++u) {
@@ -819,6 +845,10 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
           }
 #pragma unroll
           for (int u = 0; u < PMB_ILP; ++u) View::pin(ld[u]);
+#ifdef PMB_STAMP
+          const unsigned long long T_b = PMB_T();
+          T_wait += T_b - T_a; ++N_pass;
+#endif
 #pragma unroll
           for (int u = 0; u < PMB_ILP; ++u) {
             const int t = k + 64 * u + lane;
@@ -838,10 +868,17 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
               }
             }
           }
+#ifdef PMB_STAMP
+          asm volatile("" : "+v"(acc0), "+v"(acc1));
+          T_eval += PMB_T() - T_b;
+#endif
         }
       }
     }
   }
+#ifdef PMB_STAMP
+  const unsigned long long T_2b0 = PMB_T();
+#endif
 
   // ---- phase 2b: the scan pixels of the remaining (short) rows of all steps, flattened ----
   // Few images (gridDim.z > 1, pixel_map_scan_split): the launch lasts as long as the longest walk - a wall edge is 64 steps
@@ -879,12 +916,20 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
       }
     }
   }
+#ifdef PMB_STAMP
+  asm volatile("" : "+v"(acc0), "+v"(acc1));
+  T_2b += PMB_T() - T_2b0;
+#endif
   }   // rounds
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { acc0 += __shfl_xor(acc0, off, 64); acc1 += __shfl_xor(acc1, off, 64); }
   if (lane == 0) {
     if (acc0 != 0.f) atomicAdd(gfaces + 9 * i + pi[0] * 3 + (1 - axis), acc0);
     if (acc1 != 0.f) atomicAdd(gfaces + 9 * i + pi[1] * 3 + (1 - axis), acc1);
+#ifdef PMB_STAMP
+    unsigned long long* o = g_pmb_stamp[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (PMB_STAMP_SLOTS - 1)];
+    o[0] = PMB_T() - T_start; o[1] = T_pro; o[2] = T_p1; o[3] = T_wait; o[4] = T_eval; o[5] = N_pass; o[6] = T_2b; o[7] = N_rows;
+#endif
   }
 }
 
@@ -1008,6 +1053,12 @@ __global__ __launch_bounds__(64) void project_faces_bwd_det_kernel(const float* 
 }
 
 }  // namespace
+#ifdef PMB_STAMP
+extern "C" int sln_lab_pmb_stamps(unsigned long long* host, int clear) {
+  if (clear) { void* p = nullptr; if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_pmb_stamp)) != hipSuccess) return -1; return (int)hipMemset(p, 0, sizeof(g_pmb_stamp)); }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_pmb_stamp), sizeof(g_pmb_stamp));
+}
+#endif
 
 // ====================================================================================================
 // C ABI
@@ -1711,7 +1762,10 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   std::unique_lock<std::mutex> side_lock(side_mu, std::defer_lock);
   // (round 5) what BOTH chains wait for runs first, on the caller's stream: the zero-fill of the face gradient and the one launch
   // that builds the scan kernel's tables (records + gradient planes); the fork comes behind it, and the scan kernel - the longest
-  // launch of the pass - starts as soon as its tables exist instead of a fork and an event later (see scene_bwd_tables_kernel)
+  // launch of the pass - starts as soon as its tables exist instead of a fork and an event later (see scene_bwd_tables_kernel).
+  // (round 6: forking in FRONT of the tables launch puts the depth chain next to it 60 us earlier - and changes nothing: the tables
+  // launch takes 78 us instead of 52 and the scans 281 instead of 262 when the per-face depth walk runs beside their start; the
+  // batch is the sum of its kernels' work whichever way they are laid side by side, 0.540 vs 0.538 ms same-box)
   const int t32 = sln_cdiv(is, 32);
   {
     const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
