@@ -360,9 +360,16 @@ __global__ void texture_sample_chw_kernel(const float* __restrict__ faces, const
 __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __restrict__ faces, const int32_t* __restrict__ fi,
                                                                  const float* __restrict__ w, const float* __restrict__ depth,
                                                                  const float* __restrict__ gd, int F, int is,
-                                                                 float* __restrict__ gfaces) {
-  const size_t i = blockIdx.x;
-  const int b = (int)(blockIdx.x / (unsigned)F), fn = (int)(blockIdx.x - (unsigned)b * (unsigned)F), lane = threadIdx.x;      // 32-bit division
+                                                                 float* __restrict__ gfaces, int image_minor) {
+  // Block order (round 6): image-minor when the image count is a multiple of 8 - consecutive workgroups go to consecutive XCDs, so
+  // image b is walked by XCD b mod 8 alone (its maps stay in one L2), and every image's large faces are dispatched at the same
+  // point of the launch instead of the last image's starting when the others are done.  SLN_DEPTH_BWD_ORDER=0 (lab): image-major.
+  const unsigned nimg = gridDim.x / (unsigned)F;
+  const int lane = threadIdx.x;
+  int b, fn;
+  if (image_minor) { fn = (int)(blockIdx.x / nimg); b = (int)(blockIdx.x - (unsigned)fn * nimg); }
+  else { b = (int)(blockIdx.x / (unsigned)F); fn = (int)(blockIdx.x - (unsigned)b * (unsigned)F); }                            // 32-bit divisions
+  const size_t i = (size_t)b * F + fn;
 
   float fl[9];
 #pragma unroll
@@ -421,6 +428,10 @@ __global__ __launch_bounds__(64) void depth_backward_face_kernel(const float* __
   }
 }
 
+inline int depth_bwd_image_minor(int B) {
+  static const bool off = [] { const char* e = std::getenv("SLN_DEPTH_BWD_ORDER"); return e != nullptr && e[0] == '0'; }();
+  return !off && B >= 8 && B % 8 == 0 ? 1 : 0;
+}
 // Few (image, face) pairs leave the chip idle while the largest faces are walked: split their walks (see the two kernels).
 inline int small_batch_split(long units, int max_split, long budget = 32768) {
   int s = 1;
@@ -437,7 +448,7 @@ inline int depth_bwd_split(long units, int F) {
   static const int few = std::getenv("SLN_DEPTH_SPLIT_FACES") ? std::atoi(std::getenv("SLN_DEPTH_SPLIT_FACES")) : 2048;
   return F <= few ? small_batch_split(units, 8, 1L << 20) : small_batch_split(units, 8);
 }
-inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F); }
+inline unsigned pixel_map_grid_x(int B, int F);
 inline bool pixel_map_grid_ok(int B, int F) { return (long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F * 6 < (1L << 31); }   // 32-bit workgroup ids in the kernel
 inline int pixel_map_scan_split(long faces_total, int B) {
   if (B >= 8) return 1;                          // the image -> XCD affinity mapping of the kernel uses a 2-D grid
@@ -590,27 +601,21 @@ struct PixClassView {
   }
   static __device__ __forceinline__ void pin(Loaded& r) { asm volatile("" : "+v"(r.iq.x), "+v"(r.iq.y), "+v"(r.iq.z), "+v"(r.iq.w), "+v"(r.g_cr)); }
   __device__ __forceinline__ float eval(const Loaded& L, const Ref& ref, int& fq) const {
-    const int cr = ref.cp;
-    const int4 iq = L.iq;
-    const float g_cr = L.g_cr;
-    fq = iq.x;
-    const int cq = iq.y;
-    const float vq = cq >= 0 ? __int_as_float(iq.z) : 0.f, vr = cr >= 0 ? ref.v : 0.f;
-    float tot = 0.f;
-    if (cq >= 0) {
-      const float g3 = __int_as_float(iq.w);
-      const float dv = vq - (cr == cq ? vr : 0.f);
-      // the package sums the three (identical) colour channels: ((0 + x) + x) + x.  x + x is exact and 2x + x rounds once, to the
-      // nearest float of 3x - the same value as the single multiplication below (two instructions less per term)
-      const float diff = 3.0f * (dv * g3);
-      if (diff > 0.f) tot += diff;
-    }
-    if (cr >= 0 && cr != cq) {
-      const float dv = 0.f - vr;
-      const float diff = 3.0f * (dv * g_cr);
-      if (diff > 0.f) tot += diff;
-    }
-    return tot;
+    // the package's per-pixel term, two additions onto zero, each only when positive:
+    //   own class   (cq >= 0):             3 * ((vq - [cr == cq] * vr) * g[cq][q])
+    //   ref's class (cr >= 0, cr != cq):   3 * ((0 - vr) * g[cr][q])
+    // (3 * x for the package's ((0 + x) + x) + x over the three identical colour channels: x + x is exact, 2x + x rounds once, to the
+    // nearest float of 3x).  Round 6, fewer vector instructions for the same bits - the launch is bound by the vector instructions it
+    // issues (LAB_NOTES 9a-2): a record without a class holds v = 0 and g = 0 (scene_bwd_maps_body), so its own-class term is 3 * (0 * 0)
+    // and needs no class test; "add when positive" onto zero is max(x, 0) (NaN gives 0 either way), and 0 + a, a + 0 are exact.
+    const int cr = ref.cp, cq = L.iq.y;
+    fq = L.iq.x;
+    const float vr = ref.v;
+    const bool same = cr == cq;
+    const float da = fmaxf(3.0f * ((__int_as_float(L.iq.z) - (same ? vr : 0.f)) * __int_as_float(L.iq.w)), 0.f);
+    float db = 0.f;
+    if (cr >= 0) db = same ? 0.f : fmaxf(3.0f * ((0.f - vr) * L.g_cr), 0.f);
+    return da + db;
   }
 };
 struct PixClass {
@@ -663,16 +668,25 @@ constexpr int PMB_DC = 64;
 // (one ds_read_b128 instead of four ds_read_b32), the 16-byte reference records (one read, selected by address), the ratios of
 // a step read only by contributing pixels, and image-local 32-bit pixel offsets.
 struct __align__(16) PmbStep { int lo, ofrom, ifrom; float cross; };
+// orders a wavefront's own LDS writes before its own later reads: the workgroup is ONE wavefront and LDS executes a wavefront's
+// instructions in order, so this is a compiler fence, not an s_barrier
+#define PMB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+// grid of the launch: (images, padded to a multiple of 8 for the image -> XCD mapping of the kernel when there are at least 8) x F x 6
+// workgroups in one dimension, y = 1, z = scan split (few images)
+inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F * 6); }
+inline unsigned pixel_map_grid_y(int) { return 1u; }
 #ifdef PMB_STAMP
 // lab build only: per-workgroup clock sums (prologue, phase 1, phase 2a load waits / evaluation / passes / rows, phase 2b), one slot per
 // workgroup, read back by sln_lab_pmb_stamps
 constexpr int PMB_STAMP_SLOTS = 1 << 19;
-__device__ unsigned long long g_pmb_stamp[PMB_STAMP_SLOTS][8];
+__device__ unsigned long long g_pmb_stamp[PMB_STAMP_SLOTS][10];      // [8], [9]: wall clock (100 MHz) at the start and the end
 #define PMB_T() ((unsigned long long)clock64())
 #endif
-template <typename PIX>
-__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, PIX pix, int B, int F, int is,
-                                                                float eps, float* __restrict__ gfaces, const FaceRec* __restrict__ vis) {
+template <typename PIX, bool POW2>
+__global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __restrict__ faces, const FaceRec* __restrict__ vis,
+                                                                float* __restrict__ gfaces, int B, int F, int is, float eps, PIX pix) {
+  // (argument order, round 6: the pointers and scalars in front arrive in SGPRs with the wavefront - kernarg preload stops at the first
+  // by-value struct; with `pix` second it took five serialised scalar loads to reach the owner test below)
   typedef decltype(pix.view(0, 0)) View;
   __shared__ int s_pre[PMB_DC + 1];          // exclusive prefix of the scan lengths
   __shared__ PmbStep s_step[PMB_DC];
@@ -688,49 +702,74 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   // instructions in front of every one of the 370 k workgroups of a 16-room batch, as many as all their scan windows issue)
   const int lane = threadIdx.x;
 #ifdef PMB_STAMP
-  const unsigned long long T_start = PMB_T();
+  const unsigned long long T_start = PMB_T(), W_start = (unsigned long long)wall_clock64();
   unsigned long long T_p1 = 0, T_wait = 0, T_eval = 0, T_2b = 0, N_pass = 0, N_rows = 0, T_pro = 0;
 #endif
   unsigned bu, fnu; int ea;
   if (B >= 8) {
-    const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;       // < 6 * 8 * ceil(B / 8) * F: the launcher refuses grids beyond 2^32
+    // Order inside an XCD's share (round 6): its images one after the other, FACE-MAJOR - the six (edge, axis) units of a face side by
+    // side, faces in list order.  Workgroups are dispatched in block order, a unit of an owner lasts 10 us in the median and up to 90
+    // (a wall edge), an ownerless one ~3 us, so the order decides how full the chip is.  With all faces per (edge, axis), the order
+    // until round 5, owners and ownerless faces alternate in every sixth of an image and the long wall edges of the LAST image's fifth
+    // and sixth start at 75-80 % of the launch: 15 % of it ran below a fifth of the occupancy.  Face-major keeps an image's owners
+    // densely in flight and lets the ownerless run of its second half (the mirrored faces of fill_back) drain at the dispatch rate:
+    // 246 -> 222 us for the 16-room batch.  Measured and NOT kept (LAB_NOTES 9a-3): images in alternating pairs with the two halves of
+    // the face list interleaved (238 us: ~3 us ownerless workgroups in every slot again), 2 / 3 / 6 units per workgroup (224 / 231 /
+    // 314 us: the chip retires 4-wavefront workgroups as fast as 1-wavefront ones, but a workgroup keeps its LDS until its longest
+    // unit is done), 2 / 4 / 8 faces per workgroup walked one after the other (226 / 232 / 240 us).
+    const unsigned lin = blockIdx.x;                                // < 6 * 8 * ceil(B / 8) * F: the launcher refuses grids beyond 2^31
     const unsigned xcd = lin & 7u, j = lin >> 3;
     const unsigned per_img = (unsigned)F * 6u;
-    const unsigned img_local = j / per_img, rem = j - img_local * per_img;
+    const unsigned img_local = j / per_img, r = j - img_local * per_img;
+    fnu = r / 6u;
     bu = xcd + 8u * img_local;
     if (bu >= (unsigned)B) return;
-    const unsigned q = rem / (unsigned)F;
-    ea = (int)q;
-    fnu = rem - q * (unsigned)F;
-  } else {
-    bu = blockIdx.x / (unsigned)F; fnu = blockIdx.x - bu * (unsigned)F; ea = blockIdx.y;
+    ea = (int)(r - fnu * 6u);
+  } else {                                                          // fewer images than XCDs: the same order without the affinity
+    const unsigned per_img = (unsigned)F * 6u;
+    bu = blockIdx.x / per_img;
+    const unsigned r = blockIdx.x - bu * per_img;
+    fnu = r / 6u;
+    ea = (int)(r - fnu * 6u);
   }
   const int b = (int)bu, fn = (int)fnu;
   const size_t i = (size_t)bu * F + fnu;
   // A face that owns no pixel of the map contributes nothing: outward scans start from a pixel of the face under the edge, inward
   // scans count the face's own pixels only.  The fused scene pass marks the owners in its forward (FaceRec::pad_[1]); their
-  // complement - every back-facing face, and the front-facing ones that are hidden or fall between pixel centres - leaves here on
-  // one scalar load instead of loading the face, walking its edge and scanning its interior for nothing.
-  if (vis != nullptr && vis[i].pad_[1] == 0) return;
+  // complement - every back-facing face, and the front-facing ones that are hidden or fall between pixel centres - leaves here
+  // instead of walking its edge and scanning its interior for nothing.
+  // The owner flag, the face and the edge's vertices (rotated by e, scan axis first; read at computed offsets: picking six of the nine
+  // words of a face held in scalar registers by the run-time (e, axis) was a chain of ~90 scalar selects) are ALL requested before the
+  // first of them is tested: one scalar-memory round trip in front of phase 1 instead of three.
   const int e = ea >> 1, axis = ea & 1;
-  float face[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) face[k] = faces[9 * i + k];
-  if (backfacing(face)) return;
-  const bool pow2 = (is & (is - 1)) == 0;
-  const float s2 = 2.0f / (float)is;
-  // the edge's vertices (rotated by e) with the scan axis first: read straight from memory at computed offsets (the face sits
-  // in scalar registers, and picking six of its nine words by the run-time (e, axis) was a chain of ~90 scalar selects per workgroup)
   int pi[3];
 #pragma unroll
   for (int n = 0; n < 3; ++n) pi[n] = e + n >= 3 ? e + n - 3 : e + n;
-  const View V = pix.view(axis, b);
   const float* fp = faces + 9 * i;
+  int own = 1;
+  if (vis != nullptr) own = vis[i].pad_[1];
+  float face[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) face[k] = fp[k];
+  float praw[3][2];
+#pragma unroll
+  for (int n = 0; n < 3; ++n)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) praw[n][d] = fp[3 * pi[n] + ((d + axis) & 1)];
+  asm volatile("" : "+s"(own), "+s"(face[0]), "+s"(face[1]), "+s"(face[3]), "+s"(face[4]), "+s"(face[6]), "+s"(face[7]),
+               "+s"(praw[0][0]), "+s"(praw[0][1]), "+s"(praw[1][0]), "+s"(praw[1][1]), "+s"(praw[2][0]), "+s"(praw[2][1]));
+  if (own == 0) return;
+  if (backfacing(face)) return;
+  // (round 6) a template parameter: as a run-time flag the power-of-two test was two scalar branches per distance term - four per
+  // window - around an IEEE division that the 256 x 256 images never execute
+  constexpr bool pow2 = POW2;
+  const float s2 = 2.0f / (float)is;
+  const View V = pix.view(axis, b);
   float p[3][2];
 #pragma unroll
   for (int n = 0; n < 3; ++n)
 #pragma unroll
-    for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (fp[3 * pi[n] + ((d + axis) & 1)] * is + is - 1);
+    for (int d = 0; d < 2; ++d) p[n][d] = 0.5f * (praw[n][d] * is + is - 1);
   const int dir = (axis == 0) ? (p[0][0] < p[1][0] ? -1 : 1) : (p[0][0] < p[1][0] ? 1 : -1);
   const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.f);
   const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)(is - 1));
@@ -744,7 +783,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 #endif
   for (int c_from = d0_from; c_from <= d0_to; c_from += PMB_DC) {
   const int c_to = min(d0_to, c_from + PMB_DC - 1);
-  __syncthreads();                              // the LDS tables of the previous round are no longer read
+  PMB_SYNC();                                   // the LDS tables of the previous round are no longer read
 #ifdef PMB_STAMP
   const unsigned long long T_c0 = PMB_T();
 #endif
@@ -795,7 +834,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   if (lane == 0) s_pre[0] = 0;
   s_step[lane] = sp;
   s_ratio[lane] = make_float2(r0, r1);
-  __syncthreads();
+  PMB_SYNC();
   const int W = s_pre[64];
 #ifdef PMB_STAMP
   T_p1 += PMB_T() - T_c0;
@@ -812,6 +851,12 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
   if (PMB_LONG > 0) {
     const int gz = wstep >> 6, zme = wfirst >> 6;                  // long walks of few images are split over gridDim.z workgroups
     int widx = 0;
+    unsigned long long m_fast = 0ull, m_pos0 = 0ull, m_pos1 = 0ull;
+    if (pow2) {
+      const float a0 = fabsf(r0), a1 = fabsf(r1);
+      m_fast = __ballot((r0 == 0.f || (a0 > 1e-18f && a0 < 1e18f)) && (r1 == 0.f || (a1 > 1e-18f && a1 < 1e18f)));
+      m_pos0 = __ballot(r0 > 0.f); m_pos1 = __ballot(r1 > 0.f);
+    }
 #pragma unroll
     for (int scan = 0; scan < 2; ++scan) {
       unsigned long long m = __ballot(scan == 0 ? long_o : long_i);
@@ -829,6 +874,12 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
         ru.z = __builtin_amdgcn_readlane(myref.z, l); ru.w = __builtin_amdgcn_readlane(myref.w, l);
         const typename View::Ref ref = *reinterpret_cast<const typename View::Ref*>(&ru);
         const int d0r = c_from + l;
+        // the fast form of the distance term (below): the row's flag and the signs of its two ratios are bits of three ballots taken once
+        // per round, picked and turned into +-eps by the scalar unit
+        const bool fast = ((m_fast >> l) & 1ull) != 0ull;
+        const float e0 = (((m_pos0 >> l) & 1ull) != 0ull) == (dir > 0) ? eps : -eps;
+        const float e1 = (((m_pos1 >> l) & 1ull) != 0ull) == (dir > 0) ? eps : -eps;
+        const float qs0 = q0 * s2, qs1 = q1 * s2;
 #ifdef PMB_STAMP
         ++N_rows;
 #endif
@@ -856,6 +907,14 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
             const float diff = V.eval(ld[u], ref, fq);
             if (t < len && (scan == 0 || fq == fn) && diff > 0.f) {       // inward: this face's pixels only
               const float dc = (from + t) - crs;
+              if (pow2 && scan == 0 && fast) {
+                // outward row, power-of-two image: every pixel lies beyond the crossing in direction dir (dc != 0, sign(dc) = dir), so
+                // the sign of dist - hence the sign of its eps - is the row's, and (q * dc) * s2 == (q * s2) * dc bit for bit (s2 is a
+                // power of two, |q| within 1e-18 .. 1e18: no under- or overflow): multiply, add, reciprocal, multiply, subtract per term
+                // instead of two multiplications, compare, select, add, reciprocal, multiply, subtract
+                if (q0 != 0.f) acc0 -= PMB_DIV(diff, qs0 * dc + e0);
+                if (q1 != 0.f) acc1 -= PMB_DIV(diff, qs1 * dc + e1);
+              } else {
               if (q0 != 0.f) {
                 float dist = pix_scale(q0 * dc, is, pow2, s2);
                 dist = 0 < dist ? dist + eps : dist - eps;
@@ -865,6 +924,7 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
                 float dist = pix_scale(q1 * dc, is, pow2, s2);
                 dist = 0 < dist ? dist + eps : dist - eps;
                 acc1 -= PMB_DIV(diff, dist);
+              }
               }
             }
           }
@@ -929,9 +989,12 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
 #ifdef PMB_STAMP
     unsigned long long* o = g_pmb_stamp[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & (PMB_STAMP_SLOTS - 1)];
     o[0] = PMB_T() - T_start; o[1] = T_pro; o[2] = T_p1; o[3] = T_wait; o[4] = T_eval; o[5] = N_pass; o[6] = T_2b; o[7] = N_rows;
+    o[8] = W_start; o[9] = (unsigned long long)wall_clock64();
 #endif
   }
 }
+
+#define PMB_KERNEL(PIX, is) ((((is) & ((is) - 1)) == 0) ? pixel_map_backward_kernel<PIX, true> : pixel_map_backward_kernel<PIX, false>)
 
 // ----------------------------------------------------------------------------------------------------
 // projection + vertex->face gather (neural_renderer.projection with the reference README's patch - no distortion - followed by
@@ -1156,7 +1219,7 @@ int sln_raster_backward_depth(const float* faces, const int32_t* face_index, con
   if ((long)B * F > 0)
     // (deterministic mode: one wavefront per face - a single add per value onto the caller's zeros)
     hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)((long)B * F), g_sln_deterministic ? 1 : depth_bwd_split((long)B * F, F)), dim3(64), 0, st, faces,
-                       face_index, weight, depth, grad_depth, F, image_size, grad_faces);
+                       face_index, weight, depth, grad_depth, F, image_size, grad_faces, depth_bwd_image_minor(B));
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1173,8 +1236,8 @@ int sln_raster_backward_rgb(const float* faces, const int32_t* face_index, const
   PixDense pix{face_index, rgb, grad_rgb, channels, image_size};
   // (deterministic mode: no scan split - every gradient value then receives exactly two adds, one per incident edge, and a + b
   // is b + a)
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixDense>), dim3(pixel_map_grid_x(B, F), 6, g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, image_size, eps,
-                     grad_faces, (const FaceRec*)nullptr);
+  hipLaunchKernelGGL(PMB_KERNEL(PixDense, image_size), dim3(pixel_map_grid_x(B, F), pixel_map_grid_y(B), g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, (const FaceRec*)nullptr,
+                     grad_faces, B, F, image_size, eps, pix);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1212,8 +1275,8 @@ int sln_raster_backward_rgb_multi(const float* faces, const int32_t* face_index,
   int shift = -1;
   if ((image_size & (image_size - 1)) == 0) { shift = 0; while ((1 << shift) < image_size) ++shift; }
   PixMulti pix{face_index, rgb_chw, grad_chw, mask, image_size, shift};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixMulti>), dim3(pixel_map_grid_x(B, F), 6, g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)),
-                     dim3(64), 0, st, faces, pix, B, F, image_size, eps, grad_faces, (const FaceRec*)nullptr);
+  hipLaunchKernelGGL(PMB_KERNEL(PixMulti, image_size), dim3(pixel_map_grid_x(B, F), pixel_map_grid_y(B), g_sln_deterministic ? 1 : pixel_map_scan_split(n, B)),
+                     dim3(64), 0, st, faces, (const FaceRec*)nullptr, grad_faces, B, F, image_size, eps, pix);
   SLN_CHECK_LAUNCH();
   return 0;
 }
@@ -1760,18 +1823,22 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   // used to leave the side stream un-joined - work on grad_faces still in flight, and an active stream capture invalidated.
   static std::mutex side_mu;
   std::unique_lock<std::mutex> side_lock(side_mu, std::defer_lock);
-  // (round 5) what BOTH chains wait for runs first, on the caller's stream: the zero-fill of the face gradient and the one launch
-  // that builds the scan kernel's tables (records + gradient planes); the fork comes behind it, and the scan kernel - the longest
-  // launch of the pass - starts as soon as its tables exist instead of a fork and an event later (see scene_bwd_tables_kernel).
-  // (round 6: forking in FRONT of the tables launch puts the depth chain next to it 60 us earlier - and changes nothing: the tables
-  // launch takes 78 us instead of 52 and the scans 281 instead of 262 when the per-face depth walk runs beside their start; the
-  // batch is the sum of its kernels' work whichever way they are laid side by side, 0.540 vs 0.538 ms same-box)
+  // What BOTH chains wait for runs first, on the caller's stream: the zero-fill of the face gradient.  The fork follows at once and the
+  // launch that builds the scan kernel's tables (records + gradient planes) comes behind it on the caller's stream, so the depth chain's
+  // four small kernels run NEXT TO the tables launch and its per-face walk next to the start of the scans.  (Round 5 forked behind the
+  // tables launch.  With the scan kernel in its round-5 dispatch order that was equal - 0.540 vs 0.538 ms per 16-room batch: the scans
+  // ended in a 40 us tail of low occupancy that absorbed the depth chain wherever it started.  With the face-major order the tail is
+  // gone and the late fork costs: 0.549 vs 0.520 ms, same box.  SLN_SCENE_FORK_LATE=1 restores it.)
   const int t32 = sln_cdiv(is, 32);
+  static const bool fork_late = std::getenv("SLN_SCENE_FORK_LATE") != nullptr;      // lab
+  auto tables = [&]() {
+    hipLaunchKernelGGL(scene_bwd_tables_kernel, dim3(t32, t32, B + B * num_classes), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel,
+                       grad_final, B, F, is, num_classes, 70, w.st, w.prec, w.precT, w.g, w.gT);
+  };
   {
     const int e = sln_zero_async(grad_faces, sizeof(float) * 9 * (size_t)n, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(scene_bwd_tables_kernel, dim3(t32, t32, B + B * num_classes), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel,
-                       grad_final, B, F, is, num_classes, 70, w.st, w.prec, w.precT, w.g, w.gT);
+    if (fork_late) tables();
   }
   hipStream_t sd_st = st;
   if (sd != nullptr) {
@@ -1780,6 +1847,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
     if (sd->stream != nullptr && hipEventRecord(sd->fork, st) == hipSuccess && hipStreamWaitEvent(sd->stream, sd->fork, 0) == hipSuccess) sd_st = sd->stream;
     else { sd = nullptr; side_lock.unlock(); }
   }
+  if (!fork_late) tables();
   struct Join {
     SceneSide* sd; hipStream_t st; hipError_t err;
     void run() {
@@ -1803,12 +1871,12 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
                      face_class, class_depth_channel, F, is, num_classes, 70, grad_final, w.st, w.gd);
   if (!det)
     hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, depth_bwd_split(n, F)), dim3(64), 0, sd_st, faces, w.fiA, w.wA, w.dA, w.gd, F, is,
-                       grad_faces);
+                       grad_faces, depth_bwd_image_minor(B));
   PixClass pix{w.prec, w.precT, w.g, w.gT, is, num_classes};
-  hipLaunchKernelGGL((pixel_map_backward_kernel<PixClass>), dim3(pixel_map_grid_x(B, F), 6, det ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, pix, B, F, is, pix_eps,
-                     grad_faces, (const FaceRec*)w.rec);
+  hipLaunchKernelGGL(PMB_KERNEL(PixClass, is), dim3(pixel_map_grid_x(B, F), pixel_map_grid_y(B), det ? 1 : pixel_map_scan_split(n, B)), dim3(64), 0, st, faces, (const FaceRec*)w.rec,
+                     grad_faces, B, F, is, pix_eps, pix);
   if (det)
-    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, 1), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces);
+    hipLaunchKernelGGL(depth_backward_face_kernel, dim3((unsigned)n, 1), dim3(64), 0, st, faces, w.fiA, w.wA, w.dA, w.gd, F, is, grad_faces, depth_bwd_image_minor(B));
   join.run();                     // whatever follows on `st` sees both chains
   if (join.err != hipSuccess) return (int)join.err;
   SLN_CHECK_LAUNCH();
