@@ -696,10 +696,10 @@ struct __align__(16) PmbStep { int lo, ofrom, ifrom; float cross; };
 // orders a wavefront's own LDS writes before its own later reads: the workgroup is ONE wavefront and LDS executes a wavefront's
 // instructions in order, so this is a compiler fence, not an s_barrier
 #define PMB_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
-// grid of the launch: (images, padded to a multiple of 8 for the image -> XCD mapping of the kernel when there are at least 8) x F x 6
-// workgroups in one dimension, y = 1, z = scan split (few images)
-inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 : B) * F * 6); }
-inline unsigned pixel_map_grid_y(int) { return 1u; }
+// grid of the launch: B >= 8 (image -> XCD mapping in the kernel): one dimension, 8 * ceil(B / 8) * F * 6 workgroups; fewer images:
+// (B * F, 6, scan split)
+inline unsigned pixel_map_grid_x(int B, int F) { return (unsigned)((long)(B >= 8 ? (B + 7) / 8 * 8 * 6 : B) * F); }
+inline unsigned pixel_map_grid_y(int B) { return B >= 8 ? 1u : 6u; }
 #ifdef PMB_STAMP
 // lab build only: per-workgroup clock sums (prologue, phase 1, phase 2a load waits / evaluation / passes / rows, phase 2b), one slot per
 // workgroup, read back by sln_lab_pmb_stamps
@@ -750,12 +750,11 @@ __global__ __launch_bounds__(64) void pixel_map_backward_kernel(const float* __r
     bu = xcd + 8u * img_local;
     if (bu >= (unsigned)B) return;
     ea = (int)(r - fnu * 6u);
-  } else {                                                          // fewer images than XCDs: the same order without the affinity
-    const unsigned per_img = (unsigned)F * 6u;
-    bu = blockIdx.x / per_img;
-    const unsigned r = blockIdx.x - bu * per_img;
-    fnu = r / 6u;
-    ea = (int)(r - fnu * 6u);
+  } else {
+    // fewer images than XCDs: grid (B * F, 6, scan split), all faces per (edge, axis).  Face-major was measured here too (round 6) and
+    // is WORSE for a single image without owner flags (the drop-in Renderer's rgb backward: 113 -> 165 us per pass): the launch lasts
+    // as long as its longest walks, and in this order they start in every sixth of the launch instead of in one burst.
+    bu = blockIdx.x / (unsigned)F; fnu = blockIdx.x - bu * (unsigned)F; ea = (int)blockIdx.y;
   }
   const int b = (int)bu, fn = (int)fnu;
   const size_t i = (size_t)bu * F + fnu;
