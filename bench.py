@@ -637,6 +637,11 @@ def render_leg(args, lib, torch, rank):
                        "achieved": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": round(bytes_per_render * args.rooms / (whole_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                        "traffic": None, "algorithmic_bytes_per_launch": int(bytes_per_render * args.rooms)}
+    # counter bytes of one batch (every kernel of the leg-isolated profile, per batch = per call of the scan kernel)
+    tr_b, tr_n = profile_step_traffic("render", "pixel_map_backward_kernel")
+    if tr_b:
+        res["roofline"].update(traffic=int(tr_b), traffic_over_algorithmic=round(tr_b / (bytes_per_render * args.rooms), 3),
+                               traffic_source=os.path.relpath(profile_csv("render"), ROOT) + " (all kernels of one 16-room batch, %d batches traced)" % tr_n)
     tr_pm, us_pm = profile_rows(["pixel_map_backward", "class_scan_backward"], "render")
     tr_rt, us_rt = profile_rows(["raster_tile_kernel"], "render")
     brute_tests = 256.0 * 256.0 * 2.0 * tris * args.rooms          # (pixel, face) pairs of ONE brute-force pass over the batch
