@@ -108,12 +108,13 @@ __global__ __launch_bounds__(256) void pool_lds_kernel(const float* __restrict__
                                                        RefineDims d,
                                                        const int* __restrict__ s2_k0, const int* __restrict__ s2_k1, const float* __restrict__ s2_l1,
                                                        const int* __restrict__ s1_i0, const int* __restrict__ s1_i1, const float* __restrict__ s1_l1,
-                                                       float* __restrict__ pooled, const unsigned char* __restrict__ live, const int skip_ones) {
+                                                       float* __restrict__ pooled, const unsigned char* __restrict__ live, const int skip_ones,
+                                                       const int scale_rev) {
   __shared__ float inter[POOL_LDS_MAX * POOL_LDS_MAX];
   const int nc = d.n_sem + d.n_dep;
   // (planes x scales grid.  Round 5 tried the four scale-workgroups of a plane on one XCD, adjacent in launch order, so that the
   //  plane is read from HBM once: 280 us against 223 - the scales differ 9x in work and interleaving them unbalances the XCDs)
-  const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = blockIdx.y;
+  const int cc = blockIdx.x % nc, b = blockIdx.x / nc, s = scale_rev ? d.n_scales - 1 - (int)blockIdx.y : (int)blockIdx.y;
   const int c = d.sem0 + cc;
   const int lv = live != nullptr ? live[b * d.C + c] : 3;
   if (!(lv & 1)) {                                                // an all-zero plane: its pooled plane is zero (what the taps would give)
@@ -561,9 +562,12 @@ static void launch_pool(const SlnRefineLoss* L, const RefineDims& d, const float
   const long npix = (long)d.B * d.S * d.S;
   if (null_fill == 1) hipLaunchKernelGGL(null_mask_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, image, d, mask, live);      // 2: `mask` is given
   static const bool no_lds = std::getenv("SLN_POOL_NO_LDS") != nullptr;      // lab: the per-pixel kernel
+  // the scales' workgroups differ 9x in work (intermediate images of 32^2 .. 96^2 pixels) and workgroups are dispatched in block order:
+  // the largest scale first (round 6: 76 -> 62 us with 16 rooms in flight; SLN_POOL_SCALE_ORDER=0 restores the ascending order)
+  static const int scale_rev = [] { const char* e = std::getenv("SLN_POOL_SCALE_ORDER"); return e != nullptr && e[0] == '0' ? 0 : 1; }();
   if (!no_lds && d.pmax <= POOL_LDS_MAX && d.P <= POOL_LDS_MAX) {
     hipLaunchKernelGGL(pool_lds_kernel, dim3(d.B * (d.n_sem + d.n_dep), d.n_scales), dim3(256), 0, st, image, mask, null_fill, d, L->s2_k0, L->s2_k1,
-                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled, live, (live != nullptr && L->pooled_ones != nullptr) ? 1 : 0);
+                       L->s2_l1, L->s1_i0, L->s1_i1, L->s1_l1, pooled, live, (live != nullptr && L->pooled_ones != nullptr) ? 1 : 0, scale_rev);
     return;
   }
   const long np = (long)d.B * d.n_scales * sln_cdiv(d.n_sem + d.n_dep, CG) * d.P * d.P;
