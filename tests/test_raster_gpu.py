@@ -308,14 +308,15 @@ def test_fused_scene_matches_33_pass_restatement(image_size, target):
         assert_close(v3.grad.cpu().numpy(), v1.grad.numpy(), "dV passes", rtol=1e-4, atol=2e-4 * v1.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("n_rooms", [3, 9])
+@pytest.mark.parametrize("n_rooms", [3, 8, 9, 17])
 def test_batched_rooms_with_padding_equal_single_room_renders(n_rooms):
     """Ragged rooms (different V / F) are batched by padding with degenerate faces of class -1: the padded batch must
-    reproduce each room's own render and vertex gradients.  9 rooms: the image -> XCD mapping of the pixel-map backward
-    (batches of 8 and more, here with a remainder) against the single-room launches, which use the small-batch split."""
+    reproduce each room's own render and vertex gradients.  8 rooms and more: the image -> XCD block mappings of the tile kernel,
+    the depth walk and the pixel-map backward (one-dimensional grids padded to a multiple of 8 images: exactly 8, a remainder of 1
+    on one and on two rounds of images) against the single-room launches, which use the plain grids and the small-batch split."""
     DR = pkg("host.diff_render")
     spec = ((11, 4, 300), (12, 7, 600), (13, 3, 200), (14, 5, 450), (15, 6, 500), (16, 2, 150), (17, 8, 700), (18, 4, 350), (19, 5, 250))
-    rooms = [rr.synth_room(s, n_objects=n, target_faces=t) for s, n, t in spec[:n_rooms]]
+    rooms = [rr.synth_room(spec[i % 9][0] + 100 * (i // 9), n_objects=spec[i % 9][1], target_faces=spec[i % 9][2]) for i in range(n_rooms)]
     IS = 96
     singles, grads = [], []
     go = torch.randn(n_rooms, 70, IS, IS, generator=torch.Generator().manual_seed(2)).cuda()
