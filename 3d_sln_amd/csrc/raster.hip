@@ -1589,11 +1589,11 @@ __global__ __launch_bounds__(256) void scene_bwd_masked_sums_kernel(const int32_
 }
 
 // per-pixel class / value maps of the class pass and their transposes (32x32 LDS tiles)
-__device__ __forceinline__ void scene_bwd_maps_body(const int b, PixRec (*tile)[33], const int32_t* __restrict__ fi_b, const float* __restrict__ val,
+__device__ __forceinline__ void scene_bwd_maps_body(const int b, const int tile_x, PixRec (*tile)[33], const int32_t* __restrict__ fi_b, const float* __restrict__ val,
                                                     const int32_t* __restrict__ cls, const int32_t* __restrict__ chan,
                                                     const float* __restrict__ gout, int F, int is, int NC, int nch,
                                                     PixRec* __restrict__ rec, PixRec* __restrict__ recT) {
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int x0 = tile_x * 32, y0 = blockIdx.y * 32;
   const long plane = (long)is * is;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int r = ty; r < 32; r += 8) {
@@ -1619,10 +1619,10 @@ __device__ __forceinline__ void scene_bwd_maps_body(const int b, PixRec (*tile)[
 }
 
 // g[b,c,y,x] = d final[b, 1+chan[c], flip(y), x] / 3  and its transpose
-__device__ __forceinline__ void scene_bwd_grad_planes_body(const int bc, float (*t)[33], const float* __restrict__ gout, const int32_t* __restrict__ chan,
+__device__ __forceinline__ void scene_bwd_grad_planes_body(const int bc, const int tile_x, float (*t)[33], const float* __restrict__ gout, const int32_t* __restrict__ chan,
                                                            int is, int NC, int nch, const SceneStats* __restrict__ st,
                                                            float* __restrict__ g, float* __restrict__ gT) {
-  const int b = bc / NC, c = bc % NC, x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int b = bc / NC, c = bc % NC, x0 = tile_x * 32, y0 = blockIdx.y * 32;
   // a plane is only ever read for the class of a VISIBLE pixel (the reference pixel of a scan): classes without a single
   // visible pixel in this image (typically half of the 32) are skipped - `vis`, the predicate the scan's reference pixels and the
   // live flags of the semantic planes use (not the 0.1 mask count)
@@ -1642,6 +1642,9 @@ __device__ __forceinline__ void scene_bwd_grad_planes_body(const int bc, float (
     if (x < is && y < is) gT[(long)bc * plane + (long)x * is + y] = t[tx][r];
   }
 }
+#ifndef TABLES_TPB
+#define TABLES_TPB 2         // 32 x 32 tiles per workgroup of scene_bwd_tables_kernel (same-box, 16-room batch, 1 / 2 / 4 / 8: 0.4925 / 0.4855 / 0.4859 / 0.4949 ms)
+#endif
 // Both tables the edge scans read - the per-pixel records and the class-gradient planes, each with its transpose - in ONE launch
 // (blockIdx.z < B: records of image z; above: plane (b, c) = z - B).  Round 5: they were two launches on two streams with an event
 // between them and the scan kernel; the scan kernel (the longest of the pass, on the critical path) started ~40 us after the
@@ -1652,8 +1655,16 @@ __global__ __launch_bounds__(256) void scene_bwd_tables_kernel(const int32_t* __
                                                                const SceneStats* __restrict__ st, PixRec* __restrict__ rec,
                                                                PixRec* __restrict__ recT, float* __restrict__ g, float* __restrict__ gT) {
   __shared__ PixRec tile[32][33];
-  if ((int)blockIdx.z < B) scene_bwd_maps_body(blockIdx.z, tile, fi_b, val, cls, chan, gout, F, is, NC, nch, rec, recT);
-  else scene_bwd_grad_planes_body(blockIdx.z - B, reinterpret_cast<float (*)[33]>(&tile[0][0]), gout, chan, is, NC, nch, st, g, gT);
+  // TABLES_TPB tiles of a row of tiles per workgroup (round 6): half as many workgroups next to the depth chain's small kernels (the
+  // launch alone is unchanged, 52 us; beside them 78 -> 72 us)
+  const int t32 = (is + 31) / 32;
+  for (int k = 0; k < TABLES_TPB; ++k) {
+    const int tile_x = blockIdx.x * TABLES_TPB + k;
+    if (tile_x >= t32) break;
+    if (k > 0) __syncthreads();                  // the previous tile's transposed reads are done
+    if ((int)blockIdx.z < B) scene_bwd_maps_body(blockIdx.z, tile_x, tile, fi_b, val, cls, chan, gout, F, is, NC, nch, rec, recT);
+    else scene_bwd_grad_planes_body(blockIdx.z - B, tile_x, reinterpret_cast<float (*)[33]>(&tile[0][0]), gout, chan, is, NC, nch, st, g, gT);
+  }
 }
 
 // d(loss)/d(raw depth map of the depth pass), unflipped [B,is,is]
@@ -1856,7 +1867,7 @@ int sln_scene_backward(const float* faces, const int32_t* face_class, int B, int
   const int t32 = sln_cdiv(is, 32);
   static const bool fork_late = std::getenv("SLN_SCENE_FORK_LATE") != nullptr;      // lab
   auto tables = [&]() {
-    hipLaunchKernelGGL(scene_bwd_tables_kernel, dim3(t32, t32, B + B * num_classes), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel,
+    hipLaunchKernelGGL(scene_bwd_tables_kernel, dim3(sln_cdiv(t32, TABLES_TPB), t32, B + B * num_classes), dim3(256), 0, st, w.fiB, w.val, face_class, class_channel,
                        grad_final, B, F, is, num_classes, 70, w.st, w.prec, w.precT, w.g, w.gT);
   };
   {
